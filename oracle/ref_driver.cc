@@ -1,0 +1,53 @@
+// ref_driver.cc -- host driver around the REFERENCE's own kernel bodies.
+//
+// TEST INFRASTRUCTURE ONLY; built only in the container that has
+// /root/reference (oracle/Makefile target `ref`).  The two __global__ kernel
+// bodies of caffe2/modules/detectron/sigmoid_adaptive_distillation_loss_op.cu
+// (lines 28-105) are extracted at build time into a temporary file that is
+// passed as -DREF_KERNELS_INC=... and deleted afterwards; no reference text
+// is stored in this repository.  The only definitions supplied here are the
+// three CUDA spellings the bodies use (`__global__`, the grid-stride loop
+// macro, and the mixed-type `max` overloads CUDA's math headers provide);
+// the arithmetic that runs is the reference's, compiled by g++ for the host.
+//
+// What this is NOT: a build of the reference operator.  RunOnDevice's
+// epilogue (math::Sum, math::Scale; .cu:135-138,167-168) needs the Caffe2
+// core + CUDA and is restated in oracle/ssad_oracle.c instead.
+#include <cfloat>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+
+#define __global__
+#define CUDA_1D_KERNEL_LOOP(i, n) for (size_t i = 0; i < (size_t)(n); ++i)
+
+static inline float max(float a, float b) { return a > b ? a : b; }
+static inline double max(float a, double b) { return (double)a > b ? (double)a : b; }
+static inline double max(double a, double b) { return a > b ? a : b; }
+
+namespace ref_kernels {
+#include REF_KERNELS_INC
+}  // namespace ref_kernels
+
+extern "C" {
+
+__attribute__((visibility("default"))) void ref_distill_loss_kernel(
+    int N, int D, int H, int W, int ignored_label, const float* logits,
+    const float* targets, const int* gt, const float* weight_pos, float gamma,
+    float alpha, float beta, int num_classes, float* losses) {
+  ref_kernels::SigmoidAdaptiveDistillLossKernel(
+      N, D, H, W, ignored_label, logits, targets, gt, weight_pos, gamma, alpha,
+      beta, num_classes, losses);
+}
+
+__attribute__((visibility("default"))) void ref_distill_grad_kernel(
+    int N, int D, int H, int W, int ignored_label, const float* logits,
+    const float* targets, const int* gt, float* dX, const float* weight_pos,
+    float gamma, float alpha, float beta, int num_classes,
+    const float* avg_loss) {
+  ref_kernels::SigmoidAdaptiveDistillLossGradientKernel(
+      N, D, H, W, ignored_label, logits, targets, gt, dX, weight_pos, gamma,
+      alpha, beta, num_classes, avg_loss);
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures in tests/golden/.
+
+Runs ONLY in the build container (needs /root/reference to build
+oracle/_ref/libref_kernels.so = the reference's own kernel bodies compiled
+for the host; see oracle/ref_driver.cc).  The fixtures hold inputs (or the
+seed that regenerates them) and the outputs of the reference kernels; no
+reference source text is stored.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Fixtures:
+  distill_small.npz   N=1,A=2,C=3,H=4,W=5; beta in {0, 0.3}; every label kind;
+                      per-element loss, dX, scalar (reference kernels)
+  distill_cfg1.npz    BASELINE config 1 (N=2,A=9,C=80,H=W=64, seed 0): scalar
+                      loss (128-lane order and float64), sum|dX|, 4096 sampled
+                      (index, loss_i, dX_i) triples (reference kernels)
+  distill_edges.npz   x in {-100,-30,-5,0,5,30,100} x q in {0,1e-30,1e-6,.5,
+                      1-1e-6,1} x beta in {0,1}, incl. NaN positions
+  powsum.npz          5 random tensors, power 1.8: float64 numpy answer
+  conv_small.npz      3x3 convs fwd/bwd, float64 torch (independent impl.)
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import oracle  # noqa: E402
+import ssad_amd  # noqa: E402
+from ssad_amd import synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def ref_fwd_bwd(x, q, lab, wp, gamma, alpha, beta, C, ign, dloss=1.0):
+    le = oracle.ref_distill_loss_elems(x, q, lab, wp, gamma=gamma, alpha=alpha,
+                                       beta=beta, num_classes=C, ignored_label=ign)
+    dx = oracle.ref_distill_grad_elems(x, q, lab, wp, dloss, gamma=gamma,
+                                       alpha=alpha, beta=beta, num_classes=C,
+                                       ignored_label=ign)
+    return le, dx
+
+
+def make_small():
+    rng = np.random.default_rng(7)
+    N, A, C, H, W = 1, 2, 3, 4, 5
+    x, q, lab = synth.distill_inputs(rng, N, A, C, H, W)
+    lab = rng.integers(-1, C + 1, size=lab.shape).astype(np.int32)  # -1,0,1,2,3
+    out = dict(logits=x, teacher=q, labels=lab)
+    for beta in (0.0, 0.3):
+        for wp in (0.5, 123.4):
+            for gamma, alpha in ((2.0, 0.5), (1.0, 0.25), (1.5, 0.75)):
+                le, dx = ref_fwd_bwd(x, q, lab, wp, gamma, alpha, beta, C, -1, dloss=0.7)
+                key = "b%g_n%g_g%g_a%g" % (beta, wp, gamma, alpha)
+                out["loss_" + key] = le
+                out["dx_" + key] = dx
+                out["sum128_" + key] = np.float32(oracle.sum128(le))
+    # a different ignored_label value
+    le, dx = ref_fwd_bwd(x, q, lab, 3.0, 2.0, 0.5, 0.0, C, 2)
+    out["loss_ign2"] = le
+    out["dx_ign2"] = dx
+    np.savez_compressed(os.path.join(OUT, "distill_small.npz"), **out)
+
+
+def make_cfg1():
+    rng = np.random.default_rng(0)
+    N, A, C, H, W = 2, 9, 80, 64, 64
+    x, q, lab = synth.distill_inputs(rng, N, A, C, H, W)
+    pw32, pw64 = oracle.pow_sum([q], 1.8)
+    out = dict(seed=0, shape=np.array([N, A, C, H, W]), normalizer_powsum=np.float32(pw32),
+               normalizer_powsum_f64=pw64)
+    idx = np.random.default_rng(1).choice(x.size, 4096, replace=False).astype(np.int64)
+    out["sample_idx"] = idx
+    for beta in (0.0, 0.3):
+        for wp_name, wp in (("ps", float(pw32)), ("fix", 123.4)):
+            le, dx = ref_fwd_bwd(x, q, lab, wp, 2.0, 0.5, beta, C, -1)
+            key = "b%g_%s" % (beta, wp_name)
+            out["sum128_" + key] = np.float32(oracle.sum128(le))
+            out["sum64_" + key] = np.sum(le.astype(np.float64))
+            out["sumabs_dx_" + key] = np.sum(np.abs(dx.astype(np.float64)))
+            out["loss_s_" + key] = le.ravel()[idx]
+            out["dx_s_" + key] = dx.ravel()[idx]
+    np.savez_compressed(os.path.join(OUT, "distill_cfg1.npz"), **out)
+
+
+def make_edges():
+    xs = np.array([-100, -30, -5, 0, 5, 30, 100], np.float32)
+    qs = np.array([0, 1e-30, 1e-6, .5, 1 - 1e-6, 1], np.float32)
+    X, Q = np.meshgrid(xs, qs, indexing="ij")
+    # shape N=1, D=A*C with A=1, C=len(xs)*len(qs)... keep it 4-D: 1 x 1 x 7 x 6
+    x = X.reshape(1, 1, 7, 6).astype(np.float32)
+    q = Q.reshape(1, 1, 7, 6).astype(np.float32)
+    lab = np.zeros((1, 1, 7, 6), np.int32)
+    lab[0, 0, :, 3] = -1  # an ignored column: NaN must still propagate (0*NaN)
+    out = dict(logits=x, teacher=q, labels=lab)
+    for beta in (0.0, 1.0):
+        le, dx = ref_fwd_bwd(x, q, lab, 10.0, 2.0, 0.5, beta, 1, -1)
+        out["loss_b%g" % beta] = le
+        out["dx_b%g" % beta] = dx
+    np.savez_compressed(os.path.join(OUT, "distill_edges.npz"), **out)
+
+
+def make_powsum():
+    rng = np.random.default_rng(11)
+    shapes = [(2, 18, 8, 12), (2, 18, 4, 6), (2, 18, 2, 3), (1, 5), (7,)]
+    arrs = [np.clip(synth.sigmoid(rng.standard_normal(s) * 2 - 1), 1e-6, 1).astype(np.float32)
+            for s in shapes]
+    out = {"in%d" % i: a for i, a in enumerate(arrs)}
+    for power in (1.8, 1.0, 2.0, 0.5):
+        out["sum_p%g" % power] = sum(
+            np.sum(np.power(a.astype(np.float64), power)) for a in arrs)
+    np.savez_compressed(os.path.join(OUT, "powsum.npz"), **out)
+
+
+def conv_case_inputs(seed, N, Cin, M, H, W):
+    """Seeded conv inputs shared by the fixture generator and the tests."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, 3, 3)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    dY = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    return X, Wt, b, dY
+
+
+CONV_CASES = [("c8m8", 2, 8, 8, 7, 9), ("c8m36", 2, 8, 36, 7, 9),
+              ("c12m20", 3, 12, 20, 5, 7), ("c64m48", 1, 64, 48, 10, 14),
+              ("c256m256", 1, 256, 256, 10, 14), ("c256m720", 2, 256, 720, 5, 7)]
+
+
+def make_conv():
+    """float64 torch conv2d + autograd = independent implementation.  Inputs
+    are regenerated from the seed; outputs are stored as 2048 samples each."""
+    import torch
+    import torch.nn.functional as F
+    out = {}
+    for ci, (name, N, Cin, M, H, W) in enumerate(CONV_CASES):
+        X, Wt, b, dY = conv_case_inputs(100 + ci, N, Cin, M, H, W)
+        tx = torch.tensor(X, dtype=torch.float64, requires_grad=True)
+        tw = torch.tensor(Wt, dtype=torch.float64, requires_grad=True)
+        tb = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(tx, tw, tb, stride=1, padding=1)
+        y.backward(torch.tensor(dY, dtype=torch.float64))
+        srng = np.random.default_rng(1000 + ci)
+        for key, arr in (("Y", y.detach().numpy()), ("dW", tw.grad.numpy()),
+                         ("dX", tx.grad.numpy())):
+            k = min(2048, arr.size)
+            idx = srng.choice(arr.size, k, replace=False).astype(np.int64)
+            out["%s_%s_idx" % (name, key)] = idx
+            out["%s_%s" % (name, key)] = arr.ravel()[idx]
+        out[name + "_db"] = tb.grad.numpy()
+        out[name + "_dims"] = np.array([100 + ci, N, Cin, M, H, W])
+    np.savez_compressed(os.path.join(OUT, "conv_small.npz"), **out)
+
+
+if __name__ == "__main__":
+    oracle.build(ref=True)
+    assert oracle.load_ref() is not None
+    make_small()
+    make_cfg1()
+    make_edges()
+    make_powsum()
+    make_conv()
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
