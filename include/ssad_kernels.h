@@ -1,0 +1,178 @@
+/*
+ * ssad_kernels.h -- raw C-ABI launchers for the gfx950 hot-path kernels.
+ *
+ * This is layer (3) of the drop-in boundary: plain pointers,
+ * sizes and a stream handle, no C++ / torch / Caffe2 types.  The operator
+ * classes in csrc/ops/ (registered for HIPContext, see c2hip_capi.h) call
+ * exactly these entry points from RunOnDevice(); a foreign host (the torch
+ * bridge, a cgo/ctypes stub, the reference's own Operator<HIPContext> build)
+ * can call them directly.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - every launcher is asynchronous on `stream` and returns 0 on success or
+ *     the hipError_t of the failed call / a negative SSAD_E_* code;
+ *   - tensors are dense NCHW fp32, labels int32, as the reference's
+ *     operators require.
+ *
+ * Reference citations are relative to /root/reference/caffe2/.
+ */
+#ifndef SSAD_KERNELS_H_
+#define SSAD_KERNELS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSAD_API __attribute__((visibility("default")))
+
+#define SSAD_E_BADARG (-1)       /* inconsistent dims / unsupported geometry */
+#define SSAD_E_WORKSPACE (-2)    /* workspace too small */
+#define SSAD_MAX_LEVELS 8        /* FPN levels fused into one launch */
+#define SSAD_MAX_POWSUM_INPUTS 8 /* inputs per PowSum launch (chunked above) */
+
+typedef void* ssad_stream_t;
+
+/* ---------------------------------------------------------------------- */
+/* SigmoidAdaptiveDistillLoss                                              */
+/* replaces modules/detectron/sigmoid_adaptive_distillation_loss_op.cu:    */
+/*   28-67 + 108-141 (kernel, math::Sum, math::Scale) in ONE streaming     */
+/*   pass + a fixed-order partial reduce (no full-size losses_ temp).      */
+/* ---------------------------------------------------------------------- */
+
+typedef struct {
+  float gamma;         /* arg "gamma", default 1.0  (.h:33)  */
+  float alpha;         /* arg "alpha", default 0.25 (.h:34)  */
+  float beta;          /* arg "beta",  default 0    (.h:35)  */
+  int num_classes;     /* arg "num_classes", default 80      */
+  int ignored_label;   /* arg "ignored_label", default -1    */
+  float scale;         /* arg "scale", default 1.0, >= 0     */
+} ssad_distill_params;
+
+/* One FPN level of logits N x D x H x W (D = A*num_classes), teacher probs
+ * of the same shape, labels N x A x H x W. */
+typedef struct {
+  const float* logits;
+  const float* teacher_prob;
+  const int32_t* labels;
+  float* out;          /* fwd: scalar loss;  bwd: dX (N x D x H x W) */
+  int N, D, H, W;
+} ssad_distill_level;
+
+/* bytes of scratch the forward needs for `n_levels` levels */
+SSAD_API size_t ssad_distill_loss_workspace_bytes(int n_levels);
+
+/* loss[l] = scale * sum_i loss_i over level l, for all levels in one launch
+ * (+ one tiny fixed-order finalize launch).  normalizer: device scalar
+ * (input 3 of the op). */
+SSAD_API int ssad_distill_loss_forward(
+    const ssad_distill_level* levels_host, int n_levels,
+    const float* normalizer, const ssad_distill_params* params_host,
+    void* workspace, size_t workspace_bytes, ssad_stream_t stream);
+
+/* dX = d(scale*loss)/d(logits) * dloss, /Np and *scale folded into the one
+ * pass (.cu:69-105 + 161-168).  dloss[l]: device scalars, one per level
+ * (dloss_stride = 0 to share one). */
+SSAD_API int ssad_distill_loss_backward(
+    const ssad_distill_level* levels_host, int n_levels,
+    const float* normalizer, const float* dloss, int dloss_stride,
+    const ssad_distill_params* params_host, ssad_stream_t stream);
+
+/* ---------------------------------------------------------------------- */
+/* PowSum  (modules/detectron/pow_sum_op.cu:26-43)                         */
+/* ---------------------------------------------------------------------- */
+
+SSAD_API size_t ssad_pow_sum_workspace_bytes(int n_inputs);
+
+/* out[0] = sum_j sum_i powf(inputs[j][i], power); all inputs in one launch. */
+SSAD_API int ssad_pow_sum(
+    const float* const* inputs_host, const int64_t* sizes_host, int n_inputs,
+    float power, float* out, void* workspace, size_t workspace_bytes,
+    ssad_stream_t stream);
+
+/* ---------------------------------------------------------------------- */
+/* Elementwise ops on the path                                             */
+/* ---------------------------------------------------------------------- */
+
+/* Relu, in place allowed (caffe2/operators/relu_op.cu:22-27) */
+SSAD_API int ssad_relu(const float* x, float* y, int64_t n, ssad_stream_t stream);
+/* ReluGradient: dx = y > 0 ? dy : 0 (relu_op.cu:29-36), in place allowed */
+SSAD_API int ssad_relu_grad(const float* y, const float* dy, float* dx,
+                            int64_t n, ssad_stream_t stream);
+/* Sigmoid (caffe2/operators/sigmoid_op.cu:25-29) */
+SSAD_API int ssad_sigmoid(const float* x, float* y, int64_t n, ssad_stream_t stream);
+/* out = sum_k in[k]  (the autograd Sum of shared-weight gradients,
+ * caffe2/python/core.py:706-741); out may alias in[0] */
+SSAD_API int ssad_sum_n(const float* const* inputs_host, int n_inputs,
+                        float* out, int64_t n, ssad_stream_t stream);
+/* y = alpha * x (math::Scale), in place allowed */
+SSAD_API int ssad_scale(const float* x, float* y, float alpha, int64_t n,
+                        ssad_stream_t stream);
+/* Fused parameter update (detectron/lib/modeling/optimizer.py:115-130 +
+ * caffe2/sgd/momentum_sgd_op_gpu.cu:22-38): g' = is_bias ? 2g : g + wd*w;
+ * m = lr*g' + mu*m; g = m; w -= m.  lr: device scalar. */
+SSAD_API int ssad_momentum_sgd_update(
+    float* w, float* g, float* m, const float* lr, float momentum,
+    float weight_decay, int is_bias, int64_t n, ssad_stream_t stream);
+
+/* ---------------------------------------------------------------------- */
+/* Conv 3x3 / stride 1 / pad 1, NCHW fp32, exact-fp32 MFMA                 */
+/* replaces caffe2/operators/conv_op_cudnn.cc:567-617 (fwd) and            */
+/* 1011-1058 (bwd bias / filter / data)                                    */
+/* ---------------------------------------------------------------------- */
+
+/* One FPN level sharing the same filter: X is N x Cin x H x W,
+ * Y is N x Cout x H x W. */
+typedef struct {
+  const float* x;      /* fwd: input;   dgrad: dY;        wgrad: X        */
+  float* y;            /* fwd: output;  dgrad: dX;        wgrad: unused   */
+  const float* aux;    /* dgrad: forward output to mask by (ReluGradient
+                          fused) or NULL;  wgrad: dY                       */
+  int N, H, W;
+} ssad_conv_level;
+
+/* floats in a packed filter for (M outputs, K input channels) */
+SSAD_API size_t ssad_conv_packed_filter_floats(int M, int K);
+
+/* Repack W[Cout][Cin][3][3] into the MFMA A-operand stream used by the
+ * forward kernel (packed_fwd, Cout x Cin) and/or by the data-gradient kernel
+ * (packed_dgrad: flipped + transposed, Cin x Cout).  Either may be NULL. */
+SSAD_API int ssad_conv_pack_filter(
+    const float* w, int Cout, int Cin, float* packed_fwd, float* packed_dgrad,
+    ssad_stream_t stream);
+
+#define SSAD_CONV_RELU 1      /* y = max(y, 0) in the epilogue            */
+#define SSAD_CONV_MASK_AUX 2  /* y = aux > 0 ? y : 0 (fused ReluGradient) */
+
+/* y = conv3x3(x, packed) (+ bias) for every level in one launch.
+ * Used for the forward (packed_fwd, Cout outputs, Cin inputs) and for the
+ * data gradient (packed_dgrad, outputs = Cin, inputs = Cout, bias NULL). */
+SSAD_API int ssad_conv3x3_forward(
+    const ssad_conv_level* levels_host, int n_levels, const float* packed,
+    const float* bias, int Cout, int Cin, int flags, ssad_stream_t stream);
+
+SSAD_API size_t ssad_conv3x3_wgrad_workspace_bytes(
+    const ssad_conv_level* levels_host, int n_levels, int Cout, int Cin);
+
+/* dW[Cout][Cin][3][3] = sum over levels, images, pixels (overwrites, beta=0
+ * like conv_op_cudnn.cc:1037; accumulate != 0 adds to dW instead) and
+ * db[Cout] = sum dY (db may be NULL).  Deterministic split-K reduction. */
+SSAD_API int ssad_conv3x3_wgrad(
+    const ssad_conv_level* levels_host, int n_levels, float* dW, float* db,
+    int Cout, int Cin, int accumulate, void* workspace, size_t workspace_bytes,
+    ssad_stream_t stream);
+
+/* ---------------------------------------------------------------------- */
+/* Introspection                                                           */
+/* ---------------------------------------------------------------------- */
+SSAD_API const char* ssad_kernels_arch(void);   /* "gfx950" */
+SSAD_API int ssad_kernels_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSAD_KERNELS_H_ */

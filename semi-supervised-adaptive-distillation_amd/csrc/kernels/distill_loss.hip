@@ -1,0 +1,525 @@
+// distill_loss.hip -- SigmoidAdaptiveDistillLoss (+Gradient) and PowSum for
+// gfx950 (MI355X).
+//
+// What the reference does (caffe2/modules/detectron/
+// sigmoid_adaptive_distillation_loss_op.cu:108-141): an elementwise kernel
+// writes a full-size `losses_` temp, a single 128-thread block sums it
+// (caffe2/utils/math_gpu.cu:1023-1058) and a third launch scales one float.
+// The gradient op (.cu:144-171) writes dX and then re-reads/re-writes all of
+// it to multiply by `scale`.  PowSum (pow_sum_op.cu:26-43) repeats the
+// temp + one-block-sum pattern once per FPN level.
+//
+// What this file does instead: every FPN level of a step is handled by ONE
+// streaming launch.  HBM traffic is the algorithmic minimum -- logits +
+// teacher probabilities read once with 16-byte loads, labels read once per
+// (image, anchor, position) and reused across the 80 classes from cache,
+// dX written once with /Np and *scale folded in.  The sum is a wavefront
+// (64-lane) shuffle reduction in double, one partial per workgroup, followed
+// by a fixed-order finalize launch: results are deterministic and closer to
+// the exact sum than the reference's 128-lane fp32 order.
+//
+// Work decomposition: logits are N x (A*C) x H x W.  For a fixed (image n,
+// anchor a) the C*H*W floats are contiguous ("slab") and share one H*W
+// label plane, so a work item is (slab, chunk-of-slab) and the label of flat
+// position i inside the slab is labels[slab*HW + i % HW].
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ssad_kernels.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 8192;   // partial slots in the workspace
+constexpr int kVecPerItem = 8;     // float4 per thread per work item
+
+struct LevelArgs {
+  const float* x;
+  const float* q;
+  const int32_t* g;
+  float* out;
+  int hw;            // H*W
+  int slab;          // C*H*W floats per (n, a)
+  int n_slabs;       // N*A
+  int chunks;        // work items per slab
+  int items;         // n_slabs * chunks
+  int block_start;   // first blockIdx.x of this level
+  int blocks;        // blocks assigned to this level
+  int vec4;          // 1: HW % 4 == 0 and 16-byte aligned pointers
+};
+
+struct LaunchArgs {
+  LevelArgs lv[SSAD_MAX_LEVELS];
+  int n_levels;
+  float gamma, alpha, beta, scale;
+  int ignored;
+};
+
+// ---- math helpers ---------------------------------------------------------
+
+template <bool FAST> __device__ __forceinline__ float exp_f(float v) {
+  if constexpr (FAST) return __expf(v); else return expf(v);
+}
+template <bool FAST> __device__ __forceinline__ float log_f(float v) {
+  if constexpr (FAST) return __logf(v); else return logf(v);
+}
+
+// AT^gamma and AT^(gamma-1); gamma == 2 and gamma == 1 are multiplies.
+template <int GAMMA_MODE>
+__device__ __forceinline__ void pow_pair(float at, float gamma, float& pg, float& pgm1) {
+  if constexpr (GAMMA_MODE == 2) { pg = at * at; pgm1 = at; }
+  else if constexpr (GAMMA_MODE == 1) { pg = at; pgm1 = 1.0f; }
+  else { pg = powf(at, gamma); pgm1 = powf(at, gamma - 1.0f); }
+}
+
+constexpr float kLogFltMin = -87.33654475f;  // logf(FLT_MIN)
+
+// Shared front end of the forward and gradient formulas
+// (.cu:56-61 and .cu:88-95).  Returns the pieces both need.
+struct Pieces {
+  float p;        // student probability sigma(x)
+  float logp;     // log(max(FLT_MIN, p))
+  float log1mp;   // -max(x,0) - log(1 + e^-|x|)
+  float at;       // adaptive target 1 - exp(-DL)
+  float edl;      // exp(-DL)
+};
+
+template <bool FAST, bool NEED_P>
+__device__ __forceinline__ Pieces front(float x, float q, float beta) {
+  Pieces r;
+  const float ax = fabsf(x);
+  const float e = exp_f<FAST>(-ax);            // e^-|x|  in (0, 1]
+  const float onepe = 1.0f + e;
+  const float sp = log_f<FAST>(onepe);         // softplus(-|x|)
+  const float xpos = fmaxf(x, 0.0f);
+  // binary entropy of the teacher: NaN outside (0,1), incl. 0*log(0), and it
+  // propagates even when beta == 0 (.cu:58-59).
+  float ent;
+  if (beta != 0.0f) {
+    ent = beta * (q * log_f<false>(q) + (1.0f - q) * log_f<false>(1.0f - q));
+  } else {
+    ent = (q > 0.0f && q < 1.0f) ? 0.0f : __builtin_nanf("");
+  }
+  // DL = -x*(q - [x>=0]) + softplus(-|x|) + ent
+  const float dl = (xpos - x * q) + sp + ent;
+  r.edl = exp_f<FAST>(-dl);
+  r.at = 1.0f - r.edl;
+  r.log1mp = -xpos - sp;
+  // log p = min(x,0) - softplus(-|x|), clamped where p underflows FLT_MIN
+  r.logp = fmaxf(fminf(x, 0.0f) - sp, kLogFltMin);
+  if constexpr (NEED_P) {
+    const float inv = __frcp_rn(onepe);
+    r.p = (x >= 0.0f) ? inv : e * inv;
+  } else {
+    r.p = 0.0f;
+  }
+  return r;
+}
+
+template <bool FAST, int GAMMA_MODE>
+__device__ __forceinline__ float loss_elem(
+    float x, float q, bool keep, float gamma, float beta, float w_pos, float w_neg) {
+  const Pieces f = front<FAST, false>(x, q, beta);
+  float pg, pgm1;
+  pow_pair<GAMMA_MODE>(f.at, gamma, pg, pgm1);
+  const float ce = q * f.logp * w_pos + (1.0f - q) * f.log1mp * w_neg;
+  const float v = -pg * ce;
+  return v * (keep ? 1.0f : 0.0f);   // multiply: NaN survives an ignored label
+}
+
+template <bool FAST, int GAMMA_MODE>
+__device__ __forceinline__ float grad_elem(
+    float x, float q, bool keep, float gamma, float alpha, float beta, float mult) {
+  const Pieces f = front<FAST, true>(x, q, beta);
+  float pg, pgm1;
+  pow_pair<GAMMA_MODE>(f.at, gamma, pg, pgm1);
+  const float S = alpha * q * f.logp + (1.0f - alpha) * (1.0f - q) * f.log1mp;
+  const float diff = q - f.p;
+  const float t1 = -diff * gamma * pgm1 * f.edl * S;
+  const float t2 = pg * (alpha * diff - (1.0f - 2.0f * alpha) * (1.0f - q) * f.p);
+  const float g = -(t1 + t2) * mult;   // mult = dloss * scale / Np
+  return g * (keep ? 1.0f : 0.0f);
+}
+
+// ---- reductions -----------------------------------------------------------
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Sum over the 256-thread workgroup; result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v) {
+  __shared__ double wsum[kThreads / 64];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) wsum[wid] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < kThreads / 64; ++i) t += wsum[i];
+  }
+  return t;
+}
+
+__device__ __forceinline__ int find_level(const LaunchArgs& a, int bid) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < SSAD_MAX_LEVELS; ++i)
+    if (i < a.n_levels && bid >= a.lv[i].block_start) l = i;
+  return l;
+}
+
+// ---- forward ---------------------------------------------------------------
+
+template <bool FAST, int GAMMA_MODE>
+__global__ __launch_bounds__(kThreads) void distill_fwd_kernel(
+    const LaunchArgs args, const float* __restrict__ normalizer,
+    double* __restrict__ partials) {
+  const LevelArgs& L = args.lv[find_level(args, blockIdx.x)];
+  const int lb = blockIdx.x - L.block_start;
+  const float np = fmaxf(normalizer[0], 1.0f);
+  const float w_pos = args.alpha / np;
+  const float w_neg = (1.0f - args.alpha) / np;
+  const float gamma = args.gamma, beta = args.beta;
+  const int ignored = args.ignored;
+  float acc = 0.0f;
+
+  for (int item = lb; item < L.items; item += L.blocks) {
+    const int slab = item / L.chunks;
+    const int chunk = item - slab * L.chunks;
+    const float* xs = L.x + (size_t)slab * L.slab;
+    const float* qs = L.q + (size_t)slab * L.slab;
+    const int32_t* gs = L.g + (size_t)slab * L.hw;
+    if (L.vec4) {
+      const int n4 = L.slab >> 2;
+      const int base = chunk * (kThreads * kVecPerItem) + threadIdx.x;
+#pragma unroll 4
+      for (int u = 0; u < kVecPerItem; ++u) {
+        const int i4 = base + u * kThreads;
+        if (i4 < n4) {
+          const float4 xv = reinterpret_cast<const float4*>(xs)[i4];
+          const float4 qv = reinterpret_cast<const float4*>(qs)[i4];
+          const int pos = (i4 * 4) % L.hw;
+          const int4 gv = *reinterpret_cast<const int4*>(gs + pos);
+          acc += loss_elem<FAST, GAMMA_MODE>(xv.x, qv.x, gv.x != ignored, gamma, beta, w_pos, w_neg);
+          acc += loss_elem<FAST, GAMMA_MODE>(xv.y, qv.y, gv.y != ignored, gamma, beta, w_pos, w_neg);
+          acc += loss_elem<FAST, GAMMA_MODE>(xv.z, qv.z, gv.z != ignored, gamma, beta, w_pos, w_neg);
+          acc += loss_elem<FAST, GAMMA_MODE>(xv.w, qv.w, gv.w != ignored, gamma, beta, w_pos, w_neg);
+        }
+      }
+    } else {
+      const int base = chunk * (kThreads * kVecPerItem * 4) + threadIdx.x;
+      for (int u = 0; u < kVecPerItem * 4; ++u) {
+        const int i = base + u * kThreads;
+        if (i < L.slab) {
+          const int pos = i % L.hw;
+          acc += loss_elem<FAST, GAMMA_MODE>(xs[i], qs[i], gs[pos] != ignored, gamma, beta, w_pos, w_neg);
+        }
+      }
+    }
+  }
+  const double t = block_sum((double)acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// One workgroup per level: fixed-order sum of that level's partials, then
+// the float multiply by scale (math::Scale on one element, .cu:137-138).
+__global__ __launch_bounds__(kThreads) void distill_finalize_kernel(
+    const LaunchArgs args, const double* __restrict__ partials) {
+  const LevelArgs& L = args.lv[blockIdx.x];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < L.blocks; i += kThreads) v += partials[L.block_start + i];
+  const double t = block_sum(v);
+  if (threadIdx.x == 0) L.out[0] = (float)t * args.scale;
+}
+
+// ---- backward --------------------------------------------------------------
+
+template <bool FAST, int GAMMA_MODE>
+__global__ __launch_bounds__(kThreads) void distill_bwd_kernel(
+    const LaunchArgs args, const float* __restrict__ normalizer,
+    const float* __restrict__ dloss, int dloss_stride) {
+  const int level = find_level(args, blockIdx.x);
+  const LevelArgs& L = args.lv[level];
+  const int lb = blockIdx.x - L.block_start;
+  const float np = fmaxf(normalizer[0], 1.0f);
+  const float mult = dloss[(size_t)level * dloss_stride] * args.scale / np;
+  const float gamma = args.gamma, alpha = args.alpha, beta = args.beta;
+  const int ignored = args.ignored;
+
+  for (int item = lb; item < L.items; item += L.blocks) {
+    const int slab = item / L.chunks;
+    const int chunk = item - slab * L.chunks;
+    const float* xs = L.x + (size_t)slab * L.slab;
+    const float* qs = L.q + (size_t)slab * L.slab;
+    float* ds = L.out + (size_t)slab * L.slab;
+    const int32_t* gs = L.g + (size_t)slab * L.hw;
+    if (L.vec4) {
+      const int n4 = L.slab >> 2;
+      const int base = chunk * (kThreads * kVecPerItem) + threadIdx.x;
+#pragma unroll 4
+      for (int u = 0; u < kVecPerItem; ++u) {
+        const int i4 = base + u * kThreads;
+        if (i4 < n4) {
+          const float4 xv = reinterpret_cast<const float4*>(xs)[i4];
+          const float4 qv = reinterpret_cast<const float4*>(qs)[i4];
+          const int pos = (i4 * 4) % L.hw;
+          const int4 gv = *reinterpret_cast<const int4*>(gs + pos);
+          float4 o;
+          o.x = grad_elem<FAST, GAMMA_MODE>(xv.x, qv.x, gv.x != ignored, gamma, alpha, beta, mult);
+          o.y = grad_elem<FAST, GAMMA_MODE>(xv.y, qv.y, gv.y != ignored, gamma, alpha, beta, mult);
+          o.z = grad_elem<FAST, GAMMA_MODE>(xv.z, qv.z, gv.z != ignored, gamma, alpha, beta, mult);
+          o.w = grad_elem<FAST, GAMMA_MODE>(xv.w, qv.w, gv.w != ignored, gamma, alpha, beta, mult);
+          reinterpret_cast<float4*>(ds)[i4] = o;
+        }
+      }
+    } else {
+      const int base = chunk * (kThreads * kVecPerItem * 4) + threadIdx.x;
+      for (int u = 0; u < kVecPerItem * 4; ++u) {
+        const int i = base + u * kThreads;
+        if (i < L.slab) {
+          const int pos = i % L.hw;
+          ds[i] = grad_elem<FAST, GAMMA_MODE>(xs[i], qs[i], gs[pos] != ignored, gamma, alpha, beta, mult);
+        }
+      }
+    }
+  }
+}
+
+// ---- PowSum ----------------------------------------------------------------
+
+struct PowArgs {
+  const float* ptr[SSAD_MAX_POWSUM_INPUTS];
+  long long n[SSAD_MAX_POWSUM_INPUTS];
+  int block_start[SSAD_MAX_POWSUM_INPUTS];
+  int blocks[SSAD_MAX_POWSUM_INPUTS];
+  int n_inputs;
+  float power;
+};
+
+// x^p.  Positive normal x (teacher probabilities) take the exp2/log2 path;
+// everything else goes through powf for the exact special-case behaviour.
+template <bool FAST>
+__device__ __forceinline__ float pow_elem(float x, float p) {
+  if constexpr (FAST) {
+    if (x >= FLT_MIN && x < 3.0e38f) return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x));
+  }
+  return powf(x, p);
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(kThreads) void pow_sum_kernel(
+    const PowArgs args, double* __restrict__ partials) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < SSAD_MAX_POWSUM_INPUTS; ++i)
+    if (i < args.n_inputs && (int)blockIdx.x >= args.block_start[i]) j = i;
+  const float* x = args.ptr[j];
+  const long long n = args.n[j];
+  const int lb = blockIdx.x - args.block_start[j];
+  const int nb = args.blocks[j];
+  const float p = args.power;
+  float acc = 0.0f;
+  double dacc = 0.0;
+  const bool aligned = ((uintptr_t)x & 15) == 0;
+  const long long n4 = aligned ? (n >> 2) : 0;
+  int folds = 0;
+  for (long long i4 = (long long)lb * kThreads + threadIdx.x; i4 < n4; i4 += (long long)nb * kThreads) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i4];
+    acc += pow_elem<FAST>(v.x, p) + pow_elem<FAST>(v.y, p) + pow_elem<FAST>(v.z, p) + pow_elem<FAST>(v.w, p);
+    if (++folds == 64) { dacc += (double)acc; acc = 0.0f; folds = 0; }
+  }
+  for (long long i = n4 * 4 + (long long)lb * kThreads + threadIdx.x; i < n; i += (long long)nb * kThreads)
+    acc += pow_elem<FAST>(x[i], p);
+  dacc += (double)acc;
+  const double t = block_sum(dacc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(kThreads) void pow_sum_finalize_kernel(
+    const double* __restrict__ partials, int n, float* __restrict__ out, int accumulate) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += kThreads) v += partials[i];
+  const double t = block_sum(v);
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0f) + (float)t;
+}
+
+// ---- host side ---------------------------------------------------------------
+
+int gamma_mode(float g) { return g == 2.0f ? 2 : (g == 1.0f ? 1 : 0); }
+
+bool accurate_math() {
+  static const bool v = [] {
+    const char* e = getenv("SSAD_ACCURATE_MATH");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+
+int build_args(const ssad_distill_level* lv, int n_levels,
+               const ssad_distill_params* P, LaunchArgs* out, int* total_blocks) {
+  if (n_levels < 1 || n_levels > SSAD_MAX_LEVELS || !P) return SSAD_E_BADARG;
+  if (P->num_classes <= 0 || !(P->scale >= 0.0f)) return SSAD_E_BADARG;
+  LaunchArgs& a = *out;
+  a.n_levels = n_levels;
+  a.gamma = P->gamma; a.alpha = P->alpha; a.beta = P->beta; a.scale = P->scale;
+  a.ignored = P->ignored_label;
+  long long total_items = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const ssad_distill_level& s = lv[l];
+    if (s.N < 0 || s.D < 0 || s.H < 0 || s.W < 0) return SSAD_E_BADARG;
+    if (s.D % P->num_classes != 0) return SSAD_E_BADARG;
+    const long long hw = (long long)s.H * s.W;
+    const long long slab = hw * P->num_classes;
+    const long long n_slabs = (long long)s.N * (s.D / P->num_classes);
+    if (slab >= (1LL << 31) || n_slabs >= (1LL << 31) || hw * 4 >= (1LL << 31)) return SSAD_E_BADARG;
+    LevelArgs& L = a.lv[l];
+    L.x = s.logits; L.q = s.teacher_prob; L.g = s.labels; L.out = s.out;
+    L.hw = (int)hw; L.slab = (int)slab; L.n_slabs = (int)n_slabs;
+    const long long per_item = (long long)kThreads * kVecPerItem * 4;
+    const long long chunks = slab > 0 ? (slab + per_item - 1) / per_item : 0;
+    const long long items = chunks * n_slabs;
+    if (items >= (1LL << 31)) return SSAD_E_BADARG;
+    L.chunks = (int)(chunks > 0 ? chunks : 1);
+    L.items = (int)items;
+    const uintptr_t al = (uintptr_t)s.logits | (uintptr_t)s.teacher_prob |
+                         (uintptr_t)s.labels | (uintptr_t)s.out;
+    L.vec4 = (hw % 4 == 0) && ((al & 15) == 0);
+    total_items += items;
+  }
+  // distribute at most kMaxBlocks blocks proportionally to the work
+  int start = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    LevelArgs& L = a.lv[l];
+    long long b = L.items;
+    if (total_items > kMaxBlocks - n_levels) {
+      b = (long long)L.items * (kMaxBlocks - n_levels) / total_items;
+    }
+    if (b < 1) b = 1;   // every level owns >= 1 block so its output is written
+    if (b > L.items && L.items > 0) b = L.items;
+    L.block_start = start;
+    L.blocks = (int)b;
+    start += (int)b;
+  }
+  *total_blocks = start;
+  return 0;
+}
+
+#define LAUNCH_BY_MODE(KERNEL, fast, gm, ...)                                   \
+  do {                                                                          \
+    if (fast) {                                                                 \
+      if (gm == 2) hipLaunchKernelGGL((KERNEL<true, 2>), __VA_ARGS__);          \
+      else if (gm == 1) hipLaunchKernelGGL((KERNEL<true, 1>), __VA_ARGS__);     \
+      else hipLaunchKernelGGL((KERNEL<true, 0>), __VA_ARGS__);                  \
+    } else {                                                                    \
+      if (gm == 2) hipLaunchKernelGGL((KERNEL<false, 2>), __VA_ARGS__);         \
+      else if (gm == 1) hipLaunchKernelGGL((KERNEL<false, 1>), __VA_ARGS__);    \
+      else hipLaunchKernelGGL((KERNEL<false, 0>), __VA_ARGS__);                 \
+    }                                                                           \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+size_t ssad_distill_loss_workspace_bytes(int n_levels) {
+  (void)n_levels;
+  return sizeof(double) * kMaxBlocks;
+}
+
+int ssad_distill_loss_forward(
+    const ssad_distill_level* levels_host, int n_levels, const float* normalizer,
+    const ssad_distill_params* params_host, void* workspace,
+    size_t workspace_bytes, ssad_stream_t stream) {
+  LaunchArgs a;
+  int blocks = 0;
+  const int rc = build_args(levels_host, n_levels, params_host, &a, &blocks);
+  if (rc) return rc;
+  if (!workspace || workspace_bytes < sizeof(double) * (size_t)blocks) return SSAD_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  double* partials = (double*)workspace;
+  const bool fast = !accurate_math();
+  const int gm = gamma_mode(a.gamma);
+  LAUNCH_BY_MODE(distill_fwd_kernel, fast, gm, dim3(blocks), dim3(kThreads), 0, s,
+                 a, normalizer, partials);
+  hipLaunchKernelGGL(distill_finalize_kernel, dim3(n_levels), dim3(kThreads), 0, s,
+                     a, (const double*)partials);
+  return (int)hipGetLastError();
+}
+
+int ssad_distill_loss_backward(
+    const ssad_distill_level* levels_host, int n_levels, const float* normalizer,
+    const float* dloss, int dloss_stride, const ssad_distill_params* params_host,
+    ssad_stream_t stream) {
+  LaunchArgs a;
+  int blocks = 0;
+  const int rc = build_args(levels_host, n_levels, params_host, &a, &blocks);
+  if (rc) return rc;
+  long long total = 0;
+  for (int l = 0; l < n_levels; ++l) total += a.lv[l].items;
+  if (total == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const bool fast = !accurate_math();
+  const int gm = gamma_mode(a.gamma);
+  LAUNCH_BY_MODE(distill_bwd_kernel, fast, gm, dim3(blocks), dim3(kThreads), 0, s,
+                 a, normalizer, dloss, dloss_stride);
+  return (int)hipGetLastError();
+}
+
+size_t ssad_pow_sum_workspace_bytes(int n_inputs) {
+  (void)n_inputs;
+  return sizeof(double) * kMaxBlocks;
+}
+
+int ssad_pow_sum(
+    const float* const* inputs_host, const int64_t* sizes_host, int n_inputs,
+    float power, float* out, void* workspace, size_t workspace_bytes,
+    ssad_stream_t stream) {
+  if (n_inputs < 1 || !out) return SSAD_E_BADARG;
+  if (!workspace || workspace_bytes < sizeof(double) * kMaxBlocks) return SSAD_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  double* partials = (double*)workspace;
+  const bool fast = !accurate_math();
+  // groups of SSAD_MAX_POWSUM_INPUTS inputs per launch; later groups add on
+  for (int g0 = 0; g0 < n_inputs; g0 += SSAD_MAX_POWSUM_INPUTS) {
+    PowArgs a;
+    const int cnt = (n_inputs - g0 < SSAD_MAX_POWSUM_INPUTS) ? n_inputs - g0 : SSAD_MAX_POWSUM_INPUTS;
+    a.n_inputs = cnt;
+    a.power = power;
+    long long total = 0;
+    for (int j = 0; j < cnt; ++j) {
+      if (sizes_host[g0 + j] < 0) return SSAD_E_BADARG;
+      total += sizes_host[g0 + j];
+    }
+    int start = 0;
+    const int budget = 2048;  // 8 workgroups per CU
+    for (int j = 0; j < cnt; ++j) {
+      const long long n = sizes_host[g0 + j];
+      a.ptr[j] = inputs_host[g0 + j];
+      a.n[j] = n;
+      long long want = (n + (long long)kThreads * 16 - 1) / ((long long)kThreads * 16);
+      long long share = total > 0 ? (n * budget + total - 1) / total : 1;
+      long long b = want < share ? want : share;
+      if (b < 1) b = 1;
+      a.block_start[j] = start;
+      a.blocks[j] = (int)b;
+      start += (int)b;
+    }
+    for (int j = cnt; j < SSAD_MAX_POWSUM_INPUTS; ++j) {
+      a.ptr[j] = nullptr; a.n[j] = 0; a.block_start[j] = start; a.blocks[j] = 0;
+    }
+    if (fast) hipLaunchKernelGGL(pow_sum_kernel<true>, dim3(start), dim3(kThreads), 0, s, a, partials);
+    else hipLaunchKernelGGL(pow_sum_kernel<false>, dim3(start), dim3(kThreads), 0, s, a, partials);
+    hipLaunchKernelGGL(pow_sum_finalize_kernel, dim3(1), dim3(kThreads), 0, s,
+                       (const double*)partials, start, out, g0 > 0 ? 1 : 0);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

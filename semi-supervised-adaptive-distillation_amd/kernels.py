@@ -1,0 +1,296 @@
+"""ctypes binding of the raw kernel launchers (include/ssad_kernels.h).
+
+torch is used here only as plumbing: device memory (torch tensors) and the
+current HIP stream.  Every function launches hand-written gfx950 kernels from
+libcaffe2_detectron_ops_hip.so; there is NO fallback -- if the library is
+missing or a launch fails this raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libcaffe2_detectron_ops_hip.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+MAX_LEVELS = 8
+CONV_RELU = 1
+CONV_MASK_AUX = 2
+
+
+class KernelError(RuntimeError):
+    pass
+
+
+class DistillParams(C.Structure):
+    _fields_ = [("gamma", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
+                ("num_classes", C.c_int), ("ignored_label", C.c_int),
+                ("scale", C.c_float)]
+
+
+class DistillLevel(C.Structure):
+    _fields_ = [("logits", C.c_void_p), ("teacher_prob", C.c_void_p),
+                ("labels", C.c_void_p), ("out", C.c_void_p),
+                ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int)]
+
+
+class ConvLevel(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("aux", C.c_void_p),
+                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """The HIP extension; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KernelError(
+            "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i32, i64, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.c_float
+    L.ssad_distill_loss_workspace_bytes.restype = sz
+    L.ssad_distill_loss_workspace_bytes.argtypes = [i32]
+    L.ssad_distill_loss_forward.argtypes = [
+        C.POINTER(DistillLevel), i32, vp, C.POINTER(DistillParams), vp, sz, vp]
+    L.ssad_distill_loss_backward.argtypes = [
+        C.POINTER(DistillLevel), i32, vp, vp, i32, C.POINTER(DistillParams), vp]
+    L.ssad_pow_sum_workspace_bytes.restype = sz
+    L.ssad_pow_sum_workspace_bytes.argtypes = [i32]
+    L.ssad_pow_sum.argtypes = [C.POINTER(vp), C.POINTER(i64), i32, f32, vp, vp, sz, vp]
+    L.ssad_relu.argtypes = [vp, vp, i64, vp]
+    L.ssad_relu_grad.argtypes = [vp, vp, vp, i64, vp]
+    L.ssad_sigmoid.argtypes = [vp, vp, i64, vp]
+    L.ssad_sum_n.argtypes = [C.POINTER(vp), i32, vp, i64, vp]
+    L.ssad_scale.argtypes = [vp, vp, f32, i64, vp]
+    L.ssad_momentum_sgd_update.argtypes = [vp, vp, vp, vp, f32, f32, i32, i64, vp]
+    L.ssad_conv_packed_filter_floats.restype = sz
+    L.ssad_conv_packed_filter_floats.argtypes = [i32, i32]
+    L.ssad_conv_pack_filter.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.ssad_conv3x3_forward.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp]
+    L.ssad_conv3x3_wgrad_workspace_bytes.restype = sz
+    L.ssad_conv3x3_wgrad_workspace_bytes.argtypes = [C.POINTER(ConvLevel), i32, i32, i32]
+    L.ssad_conv3x3_wgrad.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp, sz, vp]
+    L.ssad_kernels_arch.restype = C.c_char_p
+    L.ssad_kernels_abi_version.restype = i32
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise KernelError("%s failed with code %d" % (what, rc))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+        raise KernelError("%s must be a contiguous float32 device tensor" % name)
+    return t
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, tag):
+    dev = torch.cuda.current_device()
+    key = (dev, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device="cuda")
+        _ws_cache[key] = buf
+    return buf
+
+
+# ---------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------
+
+def _distill_levels(levels, outs):
+    arr = (DistillLevel * len(levels))()
+    for i, ((x, q, g), o) in enumerate(zip(levels, outs)):
+        _f32c(x, "logits"); _f32c(q, "teacher_prob")
+        if g.dtype != torch.int32 or not g.is_contiguous():
+            raise KernelError("labels must be contiguous int32")
+        if x.dim() != 4 or q.shape != x.shape:
+            raise KernelError("logits/teacher must be 4-D and equal-shaped")
+        N, D, H, W = x.shape
+        arr[i] = DistillLevel(x.data_ptr(), q.data_ptr(), g.data_ptr(), o.data_ptr(),
+                              N, D, H, W)
+    return arr
+
+
+def distill_loss_forward(levels, normalizer, *, gamma=1.0, alpha=0.25, beta=0.0,
+                         num_classes=80, ignored_label=-1, scale=1.0):
+    """levels: list of (logits NxDxHxW, teacher_prob, labels NxAxHxW int32).
+    Returns a float32 tensor [n_levels] of scalar losses."""
+    L = lib()
+    n = len(levels)
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    outs = [out[i:i + 1] for i in range(n)]
+    arr = _distill_levels(levels, outs)
+    P = DistillParams(gamma, alpha, beta, num_classes, ignored_label, scale)
+    nb = L.ssad_distill_loss_workspace_bytes(n)
+    ws = _workspace(nb, "distill")
+    _check(L.ssad_distill_loss_forward(arr, n, _ptr(normalizer), C.byref(P),
+                                       _ptr(ws), nb, _stream()), "distill_loss_forward")
+    return out
+
+
+def distill_loss_backward(levels, normalizer, dloss, *, gamma=1.0, alpha=0.25,
+                          beta=0.0, num_classes=80, ignored_label=-1, scale=1.0,
+                          out=None):
+    """dloss: float32 device tensor with one value per level (or one shared).
+    Returns the list of dX tensors."""
+    L = lib()
+    n = len(levels)
+    outs = out if out is not None else [torch.empty_like(x) for (x, _, _) in levels]
+    arr = _distill_levels(levels, outs)
+    P = DistillParams(gamma, alpha, beta, num_classes, ignored_label, scale)
+    stride = 1 if dloss.numel() >= n and n > 1 else 0
+    _check(L.ssad_distill_loss_backward(arr, n, _ptr(normalizer), _ptr(dloss), stride,
+                                        C.byref(P), _stream()), "distill_loss_backward")
+    return outs
+
+
+def pow_sum(inputs, power=1.0):
+    L = lib()
+    n = len(inputs)
+    for t in inputs:
+        _f32c(t, "PowSum input")
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in inputs])
+    sizes = (C.c_int64 * n)(*[t.numel() for t in inputs])
+    out = torch.empty((), dtype=torch.float32, device="cuda")
+    nb = L.ssad_pow_sum_workspace_bytes(n)
+    ws = _workspace(nb, "powsum")
+    _check(L.ssad_pow_sum(ptrs, sizes, n, power, _ptr(out), _ptr(ws), nb, _stream()),
+           "pow_sum")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# elementwise
+# ---------------------------------------------------------------------------
+
+def relu_(x):
+    _check(lib().ssad_relu(_ptr(x), _ptr(x), x.numel(), _stream()), "relu")
+    return x
+
+
+def relu(x):
+    y = torch.empty_like(x)
+    _check(lib().ssad_relu(_ptr(_f32c(x, "x")), _ptr(y), x.numel(), _stream()), "relu")
+    return y
+
+
+def relu_grad(y, dy, out=None):
+    dx = out if out is not None else torch.empty_like(dy)
+    _check(lib().ssad_relu_grad(_ptr(_f32c(y, "y")), _ptr(_f32c(dy, "dy")), _ptr(dx),
+                                y.numel(), _stream()), "relu_grad")
+    return dx
+
+
+def sigmoid(x, out=None):
+    y = out if out is not None else torch.empty_like(x)
+    _check(lib().ssad_sigmoid(_ptr(_f32c(x, "x")), _ptr(y), x.numel(), _stream()), "sigmoid")
+    return y
+
+
+def sum_n(inputs, out=None):
+    n = len(inputs)
+    o = out if out is not None else torch.empty_like(inputs[0])
+    ptrs = (C.c_void_p * n)(*[_f32c(t, "sum input").data_ptr() for t in inputs])
+    _check(lib().ssad_sum_n(ptrs, n, _ptr(o), o.numel(), _stream()), "sum_n")
+    return o
+
+
+def scale_(x, alpha):
+    _check(lib().ssad_scale(_ptr(x), _ptr(x), alpha, x.numel(), _stream()), "scale")
+    return x
+
+
+def momentum_sgd_update_(w, g, m, lr, momentum=0.9, weight_decay=1e-4, is_bias=False):
+    """In place on w, g, m; lr is a float32 device scalar tensor."""
+    _check(lib().ssad_momentum_sgd_update(
+        _ptr(_f32c(w, "w")), _ptr(_f32c(g, "g")), _ptr(_f32c(m, "m")), _ptr(lr),
+        momentum, weight_decay, int(is_bias), w.numel(), _stream()), "momentum_sgd")
+
+
+# ---------------------------------------------------------------------------
+# conv 3x3
+# ---------------------------------------------------------------------------
+
+def conv_pack_filter(w, want_fwd=True, want_dgrad=True):
+    """w: Cout x Cin x 3 x 3.  Returns (packed_fwd, packed_dgrad)."""
+    L = lib()
+    _f32c(w, "filter")
+    Cout, Cin, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise KernelError("only 3x3 filters")
+    pf = torch.empty(L.ssad_conv_packed_filter_floats(Cout, Cin), dtype=torch.float32,
+                     device="cuda") if want_fwd else None
+    pd = torch.empty(L.ssad_conv_packed_filter_floats(Cin, Cout), dtype=torch.float32,
+                     device="cuda") if want_dgrad else None
+    _check(L.ssad_conv_pack_filter(_ptr(w), Cout, Cin, _ptr(pf), _ptr(pd), _stream()),
+           "conv_pack_filter")
+    return pf, pd
+
+
+def _conv_levels(xs, ys, auxs):
+    n = len(xs)
+    arr = (ConvLevel * n)()
+    for i in range(n):
+        N, _, H, W = xs[i].shape
+        arr[i] = ConvLevel(xs[i].data_ptr(),
+                           ys[i].data_ptr() if ys is not None and ys[i] is not None else 0,
+                           auxs[i].data_ptr() if auxs is not None and auxs[i] is not None else 0,
+                           N, H, W)
+    return arr
+
+
+def conv3x3_forward(xs, packed, bias, Cout, *, relu=False, mask_by=None, out=None):
+    """xs: list of N x Cin x H x W tensors (FPN levels sharing the filter).
+    Returns the list of N x Cout x H x W outputs (one launch for all levels)."""
+    L = lib()
+    for x in xs:
+        _f32c(x, "conv input")
+    Cin = xs[0].shape[1]
+    ys = out if out is not None else [
+        torch.empty((x.shape[0], Cout, x.shape[2], x.shape[3]), dtype=torch.float32,
+                    device="cuda") for x in xs]
+    flags = (CONV_RELU if relu else 0) | (CONV_MASK_AUX if mask_by is not None else 0)
+    arr = _conv_levels(xs, ys, mask_by)
+    _check(L.ssad_conv3x3_forward(arr, len(xs), _ptr(packed), _ptr(bias), Cout, Cin, flags,
+                                  _stream()), "conv3x3_forward")
+    return ys
+
+
+def conv3x3_wgrad(xs, dys, Cout, *, want_db=True, accumulate=False, dW=None, db=None):
+    """dW[Cout,Cin,3,3] and db[Cout] summed over all levels and images."""
+    L = lib()
+    Cin = xs[0].shape[1]
+    for x, d in zip(xs, dys):
+        _f32c(x, "x"); _f32c(d, "dy")
+    arr = _conv_levels(xs, None, dys)
+    nb = L.ssad_conv3x3_wgrad_workspace_bytes(arr, len(xs), Cout, Cin)
+    ws = _workspace(nb, "wgrad")
+    if dW is None:
+        dW = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device="cuda")
+    if db is None and want_db:
+        db = torch.empty(Cout, dtype=torch.float32, device="cuda")
+    _check(L.ssad_conv3x3_wgrad(arr, len(xs), _ptr(dW), _ptr(db) if want_db else None, Cout,
+                                Cin, int(accumulate), _ptr(ws), nb, _stream()),
+           "conv3x3_wgrad")
+    return dW, db

@@ -1,0 +1,370 @@
+"""GPU parity: the hand-written gfx950 kernels, called through the raw C-ABI
+(include/ssad_kernels.h), against the CPU oracle and the golden fixtures.
+
+Tolerances (BASELINE.json: loss/grad within 1e-4 rel, fp32):
+  loss scalars            |a-b| <= 1e-4 |b|
+  per-element dX          |a-b| <= 1e-4 |b| + 1e-6 max|b|   (the abs floor covers
+                          elements where 1-exp(-DL) cancels in fp32 in BOTH the
+                          reference and here)
+  conv outputs / grads    |a-b| <= 1e-4 |b| + 1e-5 max|b|   (K = 2304..6480 fp32
+                          accumulations)
+NaN positions must coincide exactly.
+"""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle  # noqa: E402
+from ssad_amd import synth  # noqa: E402
+import make_golden as mg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from ssad_amd import kernels
+    kernels.lib()  # raises if the HIP extension is missing: no fallback
+    return kernels
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(got, ref, rtol, afloor, what=""):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    ng, nr = np.isnan(got), np.isnan(ref)
+    assert np.array_equal(ng, nr), "%s: NaN positions differ (%d vs %d)" % (what, ng.sum(), nr.sum())
+    ok = ~nr
+    if not ok.any():
+        return
+    scale = float(np.max(np.abs(ref[ok]))) if ok.any() else 0.0
+    err = np.abs(got[ok] - ref[ok])
+    lim = rtol * np.abs(ref[ok]) + afloor * scale
+    bad = err > lim
+    assert not bad.any(), "%s: %d/%d outside tol, worst err %.3e (ref %.3e, scale %.3e)" % (
+        what, int(bad.sum()), bad.size, float(err[bad].max()),
+        float(np.abs(ref[ok])[bad][np.argmax(err[bad])]), scale)
+
+
+LOSS_RTOL, DX_RTOL, DX_FLOOR = 1e-4, 1e-4, 1e-6
+CONV_RTOL, CONV_FLOOR = 1e-4, 1e-5
+
+
+# ---------------------------------------------------------------------------
+# SigmoidAdaptiveDistillLoss
+# ---------------------------------------------------------------------------
+
+def run_distill(K, levels_np, wp, dloss, **kw):
+    levels = [(dev(x), dev(q), dev(g)) for (x, q, g) in levels_np]
+    norm = dev(np.array([wp], np.float32))
+    loss = K.distill_loss_forward(levels, norm, **kw).cpu().numpy()
+    dl = dev(np.full(len(levels), dloss, np.float32))
+    dxs = [d.cpu().numpy() for d in K.distill_loss_backward(levels, norm, dl, **kw)]
+    return loss, dxs
+
+
+def test_distill_small_golden(K, golden_dir):
+    g = np.load(os.path.join(golden_dir, "distill_small.npz"))
+    x, q, lab = g["logits"], g["teacher"], g["labels"]
+    for beta in (0.0, 0.3):
+        for wp in (0.5, 123.4):
+            for gamma, alpha in ((2.0, 0.5), (1.0, 0.25), (1.5, 0.75)):
+                key = "b%g_n%g_g%g_a%g" % (beta, wp, gamma, alpha)
+                kw = dict(gamma=gamma, alpha=alpha, beta=beta, num_classes=3,
+                          ignored_label=-1, scale=1.0)
+                loss, dxs = run_distill(K, [(x, q, lab)], wp, 0.7, **kw)
+                ref_sum = np.sum(g["loss_" + key].astype(np.float64))
+                close(loss[0], ref_sum, LOSS_RTOL, 0, "loss " + key)
+                close(dxs[0], g["dx_" + key], DX_RTOL, DX_FLOOR, "dx " + key)
+                ign = np.repeat(lab == -1, 3, axis=1)
+                assert np.all(dxs[0][ign] == 0)
+    kw = dict(gamma=2.0, alpha=0.5, beta=0.0, num_classes=3, ignored_label=2, scale=1.0)
+    loss, dxs = run_distill(K, [(x, q, lab)], 3.0, 1.0, **kw)
+    close(loss[0], np.sum(g["loss_ign2"].astype(np.float64)), LOSS_RTOL, 0, "ign2")
+    close(dxs[0], g["dx_ign2"], DX_RTOL, DX_FLOOR, "dx ign2")
+
+
+def test_distill_edges_nan_parity(K, golden_dir):
+    """teacher prob 0 / 1 -> NaN (even ignored, even beta=0); p underflow clamp."""
+    g = np.load(os.path.join(golden_dir, "distill_edges.npz"))
+    x, q, lab = g["logits"], g["teacher"], g["labels"]
+    for beta in (0.0, 1.0):
+        kw = dict(gamma=2.0, alpha=0.5, beta=beta, num_classes=1, ignored_label=-1, scale=1.0)
+        # per-element check through the gradient; the forward sum is NaN
+        loss, dxs = run_distill(K, [(x, q, lab)], 10.0, 1.0, **kw)
+        assert np.isnan(loss[0])
+        close(dxs[0], g["dx_b%g" % beta], DX_RTOL, DX_FLOOR, "edge dx")
+        # forward per element: one element per launch would be slow; instead
+        # check the non-NaN columns as their own tensors
+        cols = [1, 2, 3, 4]
+        xs, qs, ls = x[..., cols], q[..., cols], lab[..., cols]
+        loss2, _ = run_distill(K, [(np.ascontiguousarray(xs), np.ascontiguousarray(qs),
+                                    np.ascontiguousarray(ls))], 10.0, 1.0, **kw)
+        ref = np.sum(g["loss_b%g" % beta][..., cols].astype(np.float64))
+        close(loss2[0], ref, LOSS_RTOL, 0, "edge loss")
+
+
+def test_distill_cfg1_golden_and_oracle(K, golden_dir):
+    """BASELINE config 1: H=W=64, A=9, C=80, N=2."""
+    g = np.load(os.path.join(golden_dir, "distill_cfg1.npz"))
+    N, A, C, H, W = [int(v) for v in g["shape"]]
+    x, q, lab = synth.distill_inputs(np.random.default_rng(int(g["seed"])), N, A, C, H, W)
+    idx = g["sample_idx"]
+    ps = K.pow_sum([dev(q)], 1.8).cpu().numpy()
+    close(ps, g["normalizer_powsum_f64"], 1e-5, 0, "powsum normalizer")
+    for beta in (0.0, 0.3):
+        for wp_name, wp in (("ps", float(g["normalizer_powsum"])), ("fix", 123.4)):
+            key = "b%g_%s" % (beta, wp_name)
+            for scale in (1.0, 0.125):
+                kw = dict(gamma=2.0, alpha=0.5, beta=beta, num_classes=C,
+                          ignored_label=-1, scale=scale)
+                loss, dxs = run_distill(K, [(x, q, lab)], wp, 1.0, **kw)
+                close(loss[0], g["sum64_" + key] * scale, LOSS_RTOL, 0, "loss " + key)
+                close(dxs[0].ravel()[idx], g["dx_s_" + key] * np.float32(scale),
+                      DX_RTOL, DX_FLOOR, "dx samples " + key)
+                close(np.sum(np.abs(dxs[0].astype(np.float64))),
+                      g["sumabs_dx_" + key] * scale, 1e-5, 0, "sum|dx| " + key)
+            # full tensor against the oracle
+            ref = oracle.distill_loss_backward(x, q, lab, wp, gamma=2.0, alpha=0.5, beta=beta,
+                                               num_classes=C, ignored_label=-1, scale=0.125)
+            close(dxs[0], ref, DX_RTOL, DX_FLOOR, "dx full " + key)
+
+
+def test_distill_multilevel_one_launch(K):
+    """All five FPN levels (incl. the odd 5x7 map -> scalar path) in one launch."""
+    rng = np.random.default_rng(42)
+    N, A, C = 2, 9, 80
+    shapes = [(20, 28), (10, 14), (5, 7), (3, 5), (1, 1)]
+    levels = [synth.distill_inputs(rng, N, A, C, h, w) for (h, w) in shapes]
+    kw = dict(gamma=2.0, alpha=0.5, beta=0.0, num_classes=C, ignored_label=-1, scale=0.5)
+    loss, dxs = run_distill(K, levels, 77.0, 1.0, **kw)
+    for i, (x, q, g) in enumerate(levels):
+        _, s64, _ = oracle.distill_loss_forward(x, q, g, 77.0, **kw)
+        close(loss[i], s64, LOSS_RTOL, 0, "level %d" % i)
+        close(dxs[i], oracle.distill_loss_backward(x, q, g, 77.0, **kw), DX_RTOL, DX_FLOOR,
+              "dx level %d" % i)
+
+
+def test_distill_general_gamma_and_empty(K):
+    rng = np.random.default_rng(1)
+    x, q, g = synth.distill_inputs(rng, 1, 2, 5, 6, 8)
+    kw = dict(gamma=1.7, alpha=0.3, beta=0.2, num_classes=5, ignored_label=-1, scale=2.0)
+    loss, dxs = run_distill(K, [(x, q, g)], 0.1, 0.3, **kw)   # normalizer < 1 -> clamped to 1
+    _, s64, _ = oracle.distill_loss_forward(x, q, g, 0.1, **kw)
+    close(loss[0], s64, LOSS_RTOL, 0, "gamma 1.7")
+    close(dxs[0], oracle.distill_loss_backward(x, q, g, 0.1, 0.3, **kw), DX_RTOL, DX_FLOOR, "dx")
+    e = (np.zeros((0, 10, 4, 4), np.float32), np.zeros((0, 10, 4, 4), np.float32),
+         np.zeros((0, 2, 4, 4), np.int32))
+    loss, _ = run_distill(K, [e], 5.0, 1.0, **kw)
+    assert loss[0] == 0.0
+
+
+def test_distill_full_size_properties(K):
+    """BASELINE size (bs=16, P3 80x112): size-independent properties --
+    scale linearity, ignored labels give exact zeros, determinism, and a
+    checksum against a chunked oracle on a slice."""
+    N, A, C, H, W = 16, 9, 80, 80, 112
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((N, A * C, H, W), device="cuda", generator=gen) * 2 - 4
+    q = torch.sigmoid(torch.randn((N, A * C, H, W), device="cuda", generator=gen) * 2 - 4)
+    q = q.clamp_(1e-6, 1 - 1e-6)
+    u = torch.rand((N, A, H, W), device="cuda", generator=gen)
+    lab = torch.where(u < 0.05, -1, 0).to(torch.int32)
+    norm = K.pow_sum([q], 1.8).reshape(1)
+    kw = dict(gamma=2.0, alpha=0.5, beta=0.0, num_classes=C, ignored_label=-1)
+    l1 = K.distill_loss_forward([(x, q, lab)], norm, scale=1.0, **kw)
+    l2 = K.distill_loss_forward([(x, q, lab)], norm, scale=0.125, **kw)
+    l3 = K.distill_loss_forward([(x, q, lab)], norm, scale=1.0, **kw)
+    assert float(l1[0]) == float(l3[0]), "not deterministic"
+    assert abs(float(l2[0]) - 0.125 * float(l1[0])) <= 1e-6 * abs(float(l1[0]))
+    one = torch.ones(1, device="cuda")
+    dx = K.distill_loss_backward([(x, q, lab)], norm, one, scale=1.0, **kw)[0]
+    ign = (lab == -1).repeat_interleave(C, dim=1)
+    assert bool((dx[ign] == 0).all())
+    assert bool(torch.isfinite(dx).all())
+    # slice check against the oracle: image 3 only (same normalizer)
+    xs, qs, ls = x[3:4].cpu().numpy(), q[3:4].cpu().numpy(), lab[3:4].cpu().numpy()
+    ref = oracle.distill_loss_backward(xs, qs, ls, float(norm[0]), scale=1.0, **kw)
+    close(dx[3:4].cpu().numpy(), ref, DX_RTOL, DX_FLOOR, "full-size slice")
+    # sum over images of per-image losses == whole loss (checksum of checksums)
+    parts = [float(K.distill_loss_forward([(x[i:i + 1], q[i:i + 1], lab[i:i + 1])], norm,
+                                          scale=1.0, **kw)[0]) for i in range(N)]
+    assert abs(sum(parts) - float(l1[0])) <= 1e-5 * abs(float(l1[0]))
+
+
+# ---------------------------------------------------------------------------
+# PowSum
+# ---------------------------------------------------------------------------
+
+def test_powsum_golden(K, golden_dir):
+    g = np.load(os.path.join(golden_dir, "powsum.npz"))
+    arrs = [dev(g["in%d" % i].ravel()) for i in range(5)]
+    for power in (1.8, 1.0, 2.0, 0.5):
+        got = K.pow_sum(arrs, power).cpu().numpy()
+        close(got, g["sum_p%g" % power], 1e-5, 0, "powsum %g" % power)
+
+
+def test_powsum_many_inputs_and_specials(K):
+    rng = np.random.default_rng(2)
+    arrs = [rng.random(n).astype(np.float32) for n in (1, 7, 64, 1000, 5, 3, 129, 4097, 33, 2, 11)]
+    got = K.pow_sum([dev(a) for a in arrs], 1.8).cpu().numpy()
+    close(got, sum(np.sum(a.astype(np.float64) ** 1.8) for a in arrs), 1e-5, 0, "11 inputs")
+    # zeros, negatives (NaN for non-integer power), unaligned views
+    z = np.array([0.0, 0.5, 0.0, 2.0], np.float32)
+    close(K.pow_sum([dev(z)], 1.8).cpu().numpy(), 0.5 ** 1.8 + 2.0 ** 1.8, 1e-6, 0, "zeros")
+    neg = np.array([0.5, -0.5], np.float32)
+    assert np.isnan(K.pow_sum([dev(neg)], 1.8).cpu().numpy())
+    base = dev(rng.random(1001).astype(np.float32))
+    view = base[1:]   # 4-byte aligned only
+    close(K.pow_sum([view], 2.0).cpu().numpy(), float((view.double() ** 2).sum()), 1e-6, 0,
+          "unaligned")
+    assert float(K.pow_sum([dev(np.zeros(0, np.float32))], 1.8)) == 0.0
+
+
+# ---------------------------------------------------------------------------
+# elementwise
+# ---------------------------------------------------------------------------
+
+def test_elementwise(K):
+    rng = np.random.default_rng(3)
+    for n in (1, 5, 1023, 4096, 100003):
+        x = rng.standard_normal(n).astype(np.float32)
+        dy = rng.standard_normal(n).astype(np.float32)
+        y = K.relu(dev(x)).cpu().numpy()
+        assert np.array_equal(y, oracle.relu(x))
+        assert np.array_equal(K.relu_grad(dev(y), dev(dy)).cpu().numpy(), oracle.relu_grad(y, dy))
+        close(K.sigmoid(dev(x)).cpu().numpy(), oracle.sigmoid(x), 1e-6, 0, "sigmoid")
+        xs = [rng.standard_normal(n).astype(np.float32) for _ in range(5)]
+        ref = xs[0].copy()
+        for a in xs[1:]:
+            ref = ref + a
+        assert np.array_equal(K.sum_n([dev(a) for a in xs]).cpu().numpy(), ref)
+        for is_bias in (False, True):
+            w, gr, m = (rng.standard_normal(n).astype(np.float32) for _ in range(3))
+            tw, tg, tm = dev(w), dev(gr), dev(m)
+            K.momentum_sgd_update_(tw, tg, tm, dev(np.array([0.01], np.float32)), 0.9, 1e-4, is_bias)
+            rw, rg, rm = oracle.sgd_update(w, gr, m, 0.01, 0.9, 1e-4, is_bias)
+            close(tw.cpu().numpy(), rw, 1e-6, 1e-7, "sgd w")
+            close(tm.cpu().numpy(), rm, 1e-6, 1e-7, "sgd m")
+            close(tg.cpu().numpy(), rg, 1e-6, 1e-7, "sgd g")
+
+
+# ---------------------------------------------------------------------------
+# conv3x3
+# ---------------------------------------------------------------------------
+
+def conv_all(K, Xs, Wt, b, dYs, relu=False):
+    """forward, dgrad, wgrad through the raw launchers for a list of levels."""
+    tX = [dev(X) for X in Xs]
+    tW, tb = dev(Wt), dev(b) if b is not None else None
+    M = Wt.shape[0]
+    pf, pd = K.conv_pack_filter(tW)
+    Y = K.conv3x3_forward(tX, pf, tb, M, relu=relu)
+    tdY = [dev(d) for d in dYs]
+    dX = K.conv3x3_forward(tdY, pd, None, Wt.shape[1])
+    dW, db = K.conv3x3_wgrad(tX, tdY, M)
+    return ([y.cpu().numpy() for y in Y], [d.cpu().numpy() for d in dX],
+            dW.cpu().numpy(), db.cpu().numpy())
+
+
+@pytest.mark.parametrize("case", mg.CONV_CASES, ids=[c[0] for c in mg.CONV_CASES])
+def test_conv_golden_float64(K, golden_dir, case):
+    g = np.load(os.path.join(golden_dir, "conv_small.npz"))
+    name = case[0]
+    seed, N, Cin, M, H, W = [int(v) for v in g[name + "_dims"]]
+    X, Wt, b, dY = mg.conv_case_inputs(seed, N, Cin, M, H, W)
+    Y, dX, dW, db = conv_all(K, [X], Wt, b, [dY])
+    for key, arr in (("Y", Y[0]), ("dW", dW), ("dX", dX[0])):
+        ref = g["%s_%s" % (name, key)]
+        got = arr.ravel()[g["%s_%s_idx" % (name, key)]]
+        close(got, ref, CONV_RTOL, CONV_FLOOR, name + " " + key)
+    close(db, g[name + "_db"], CONV_RTOL, CONV_FLOOR, name + " db")
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 8, 32, 1, 1), (2, 5, 7, 3, 4), (1, 16, 40, 9, 17), (2, 36, 256, 5, 7),
+    (1, 256, 36, 10, 14), (1, 24, 64, 17, 33), (3, 8, 65, 2, 31), (1, 720, 256, 5, 7)],
+    ids=lambda s: "N%d_C%d_M%d_%dx%d" % s)
+def test_conv_vs_oracle_ragged(K, shape):
+    N, Cin, M, H, W = shape
+    rng = np.random.default_rng(sum(shape))
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, 3, 3)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    dY = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    Y, dX, dW, db = conv_all(K, [X], Wt, b, [dY])
+    rY = oracle.conv_forward(X, Wt, b)
+    rdW, rdb, rdX = oracle.conv_backward(X, Wt, dY)
+    close(Y[0], rY, CONV_RTOL, CONV_FLOOR, "Y")
+    close(dX[0], rdX, CONV_RTOL, CONV_FLOOR, "dX")
+    close(dW, rdW, CONV_RTOL, CONV_FLOOR, "dW")
+    close(db, rdb, CONV_RTOL, CONV_FLOOR, "db")
+
+
+def test_conv_multilevel_shared_filter(K):
+    """Five pyramid levels through one launch; dW/db are the sum over levels
+    (the autograd Sum of caffe2/python/core.py:706-741)."""
+    rng = np.random.default_rng(8)
+    N, Cin, M = 2, 32, 48
+    shapes = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
+    Xs = [rng.standard_normal((N, Cin, h, w)).astype(np.float32) for h, w in shapes]
+    dYs = [rng.standard_normal((N, M, h, w)).astype(np.float32) for h, w in shapes]
+    Wt = (rng.standard_normal((M, Cin, 3, 3)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    Y, dX, dW, db = conv_all(K, Xs, Wt, b, dYs, relu=True)
+    rdW = np.zeros_like(Wt)
+    rdb = np.zeros_like(b)
+    for i in range(len(shapes)):
+        close(Y[i], oracle.relu(oracle.conv_forward(Xs[i], Wt, b)), CONV_RTOL, CONV_FLOOR, "Y%d" % i)
+        w_, b_, x_ = oracle.conv_backward(Xs[i], Wt, dYs[i])
+        close(dX[i], x_, CONV_RTOL, CONV_FLOOR, "dX%d" % i)
+        rdW += w_
+        rdb += b_
+    close(dW, rdW, CONV_RTOL, CONV_FLOOR, "dW sum")
+    close(db, rdb, CONV_RTOL, CONV_FLOOR, "db sum")
+
+
+def test_conv_fused_relu_grad_mask(K):
+    rng = np.random.default_rng(12)
+    N, Cin, M, H, W = 2, 16, 24, 9, 11
+    Yprev = rng.standard_normal((N, Cin, H, W)).astype(np.float32)   # forward output (post-relu source)
+    Yprev = np.maximum(Yprev, 0)
+    dY = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, 3, 3)) * 0.05).astype(np.float32)
+    _, pd = K.conv_pack_filter(dev(Wt))
+    got = K.conv3x3_forward([dev(dY)], pd, None, Cin, mask_by=[dev(Yprev)])[0].cpu().numpy()
+    _, _, rdX = oracle.conv_backward(Yprev, Wt, dY)
+    close(got, oracle.relu_grad(Yprev, rdX), CONV_RTOL, CONV_FLOOR, "masked dX")
+
+
+def test_conv_full_size_adjoint_identities(K):
+    """BASELINE size (bs=16, 256->256 at P3+P4): <conv(X,W),dY> = <X,dgrad(dY)>
+    = <W,wgrad(X,dY)> -- size-independent properties of the three kernels --
+    plus a slice against the oracle."""
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    N, C, M = 16, 256, 256
+    shapes = [(80, 112), (40, 56)]
+    Xs = [torch.randn((N, C, h, w), device="cuda", generator=gen) for h, w in shapes]
+    dYs = [torch.randn((N, M, h, w), device="cuda", generator=gen) for h, w in shapes]
+    Wt = torch.randn((M, C, 3, 3), device="cuda", generator=gen) * 0.02
+    pf, pd = K.conv_pack_filter(Wt)
+    Ys = K.conv3x3_forward(Xs, pf, None, M)
+    dXs = K.conv3x3_forward(dYs, pd, None, C)
+    dW, _ = K.conv3x3_wgrad(Xs, dYs, M, want_db=False)
+    a = sum(float((y.double() * d.double()).sum()) for y, d in zip(Ys, dYs))
+    b = sum(float((x.double() * d.double()).sum()) for x, d in zip(Xs, dXs))
+    c = float((Wt.double() * dW.double()).sum())
+    scale = sum(float((y.double().abs() * d.double().abs()).sum()) for y, d in zip(Ys, dYs))
+    assert abs(a - b) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, b, c, scale)
+    # slice: one image of the P4 level against the oracle
+    x1 = Xs[1][5:6].cpu().numpy()
+    ref = oracle.conv_forward(x1, Wt.cpu().numpy(), None)
+    close(Ys[1][5:6].cpu().numpy(), ref, CONV_RTOL, CONV_FLOOR, "full-size slice")
