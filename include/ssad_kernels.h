@@ -112,6 +112,12 @@ SSAD_API int ssad_sum_n(const float* const* inputs_host, int n_inputs,
 /* y = alpha * x (math::Scale), in place allowed */
 SSAD_API int ssad_scale(const float* x, float* y, float alpha, int64_t n,
                         ssad_stream_t stream);
+/* out = sum_k w_k[0] * x_k (caffe2 WeightedSum; each w_k is a one-element
+ * device blob); out may alias x_0; n_pairs <= 8 */
+SSAD_API int ssad_weighted_sum(const float* const* xs_host, const float* const* ws_host,
+                               int n_pairs, float* out, int64_t n, ssad_stream_t stream);
+/* y[i] = value (ConstantFill) */
+SSAD_API int ssad_fill(float* y, float value, int64_t n, ssad_stream_t stream);
 /* Fused parameter update (detectron/lib/modeling/optimizer.py:115-130 +
  * caffe2/sgd/momentum_sgd_op_gpu.cu:22-38): g' = is_bias ? 2g : g + wd*w;
  * m = lr*g' + mu*m; g = m; w -= m.  lr: device scalar. */

@@ -1,0 +1,250 @@
+#include "c2hip_capi.h"
+
+#include <cstring>
+
+#include "c2/operator.h"
+
+using namespace caffe2;
+
+struct c2hip_workspace { Workspace ws; };
+struct c2hip_operator { std::unique_ptr<OperatorBase> op; };
+
+namespace {
+
+thread_local std::string g_last_error;
+
+template <class F>
+int guarded(F&& f) {
+  try {
+    f();
+    g_last_error.clear();
+    return 0;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+  } catch (...) {
+    g_last_error = "unknown C++ exception";
+  }
+  return 1;
+}
+
+size_t join_to(const vector<string>& items, char* buf, size_t buflen) {
+  string s;
+  for (size_t i = 0; i < items.size(); ++i) {
+    if (i) s += '\n';
+    s += items[i];
+  }
+  if (buf && buflen > 0) {
+    const size_t n = s.size() < buflen - 1 ? s.size() : buflen - 1;
+    memcpy(buf, s.data(), n);
+    buf[n] = 0;
+  }
+  return s.size() + 1;
+}
+
+vector<string> split_lines(const char* s) {
+  vector<string> out;
+  if (!s) return out;
+  string cur;
+  for (const char* p = s;; ++p) {
+    if (*p == '\n' || *p == 0) {
+      out.push_back(cur);
+      cur.clear();
+      if (*p == 0) break;
+    } else {
+      cur.push_back(*p);
+    }
+  }
+  return out;
+}
+
+OperatorDef parse_def(const void* bytes, size_t n) {
+  OperatorDef def;
+  CAFFE_ENFORCE(ParseOperatorDef(bytes, n, &def), "Cannot parse the serialized OperatorDef");
+  return def;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* c2hip_last_error(void) { return g_last_error.c_str(); }
+
+c2hip_workspace* c2hip_workspace_create(void) { return new c2hip_workspace(); }
+void c2hip_workspace_destroy(c2hip_workspace* ws) { delete ws; }
+int c2hip_has_blob(c2hip_workspace* ws, const char* name) { return ws->ws.HasBlob(name) ? 1 : 0; }
+int c2hip_remove_blob(c2hip_workspace* ws, const char* name) { return ws->ws.RemoveBlob(name) ? 0 : 1; }
+size_t c2hip_blobs(c2hip_workspace* ws, char* buf, size_t buflen) {
+  return join_to(ws->ws.Blobs(), buf, buflen);
+}
+
+int c2hip_feed_blob(c2hip_workspace* ws, const char* name, const void* host_data,
+                    const int64_t* dims, int ndim, int dtype, int device_type, int device_id) {
+  return guarded([&] {
+    CAFFE_ENFORCE(ndim >= 0 && ndim <= C2HIP_MAX_DIMS);
+    const TypeMeta meta = TypeMeta::FromId(dtype);
+    const vector<TIndex> d(dims, dims + ndim);
+    Blob* blob = ws->ws.CreateBlob(name);
+    if (device_type == C2HIP_CPU) {
+      TensorCPU* t = blob->GetMutable<TensorCPU>();
+      t->Resize(d);
+      void* dst = t->raw_mutable_data(meta);
+      if (t->nbytes()) memcpy(dst, host_data, t->nbytes());
+    } else {
+      CAFFE_ENFORCE(IsGPUDeviceType(device_type), "unknown device type ", device_type);
+      HIPContext ctx(device_id);
+      ctx.SwitchToDevice(0);
+      TensorHIP* t = blob->GetMutable<TensorHIP>();
+      t->Resize(d);
+      void* dst = t->raw_mutable_data(meta);
+      if (t->nbytes()) {
+        HIP_ENFORCE(hipMemcpyAsync(dst, host_data, t->nbytes(), hipMemcpyHostToDevice,
+                                   ctx.hip_stream()));
+        ctx.FinishDeviceComputation();
+      }
+    }
+  });
+}
+
+int c2hip_blob_info(c2hip_workspace* ws, const char* name, int* dtype, int* device_type,
+                    int* ndim, int64_t* dims) {
+  return guarded([&] {
+    const Blob* b = ws->ws.GetBlob(name);
+    CAFFE_ENFORCE(b != nullptr, "Can't find blob: ", name);
+    auto fill = [&](const auto& t, int dev) {
+      *dtype = (int)t.meta().id;
+      *device_type = dev;
+      *ndim = t.ndim();
+      CAFFE_ENFORCE_LE(t.ndim(), C2HIP_MAX_DIMS);
+      for (int i = 0; i < t.ndim(); ++i) dims[i] = t.dim(i);
+    };
+    if (b->IsType<TensorCPU>()) fill(b->Get<TensorCPU>(), C2HIP_CPU);
+    else if (b->IsType<TensorHIP>()) fill(b->Get<TensorHIP>(), C2HIP_HIP);
+    else CAFFE_THROW("blob ", name, " does not hold a tensor");
+  });
+}
+
+int c2hip_fetch_blob(c2hip_workspace* ws, const char* name, void* host_out, size_t nbytes) {
+  return guarded([&] {
+    const Blob* b = ws->ws.GetBlob(name);
+    CAFFE_ENFORCE(b != nullptr, "Can't find blob: ", name);
+    if (b->IsType<TensorCPU>()) {
+      const TensorCPU& t = b->Get<TensorCPU>();
+      CAFFE_ENFORCE_EQ(t.nbytes(), nbytes);
+      if (nbytes) memcpy(host_out, t.raw_data(), nbytes);
+    } else if (b->IsType<TensorHIP>()) {
+      const TensorHIP& t = b->Get<TensorHIP>();
+      CAFFE_ENFORCE_EQ(t.nbytes(), nbytes);
+      // all pool / external streams of the device may hold pending writers
+      HIP_ENFORCE(hipDeviceSynchronize());
+      if (nbytes) HIP_ENFORCE(hipMemcpy(host_out, t.raw_data(), nbytes, hipMemcpyDeviceToHost));
+    } else {
+      CAFFE_THROW("blob ", name, " does not hold a tensor");
+    }
+  });
+}
+
+void* c2hip_blob_data_ptr(c2hip_workspace* ws, const char* name) {
+  void* p = nullptr;
+  guarded([&] {
+    const Blob* b = ws->ws.GetBlob(name);
+    CAFFE_ENFORCE(b != nullptr, "Can't find blob: ", name);
+    CAFFE_ENFORCE(b->IsType<TensorHIP>(), "blob ", name, " is not a HIP tensor");
+    p = const_cast<void*>(b->Get<TensorHIP>().raw_data());
+  });
+  return p;
+}
+
+int c2hip_share_external(c2hip_workspace* ws, const char* name, void* device_ptr,
+                         const int64_t* dims, int ndim, int dtype, int device_id) {
+  (void)device_id;
+  return guarded([&] {
+    CAFFE_ENFORCE(ndim >= 0 && ndim <= C2HIP_MAX_DIMS);
+    Blob* blob = ws->ws.CreateBlob(name);
+    blob->Reset();
+    TensorHIP* t = blob->GetMutable<TensorHIP>();
+    t->Resize(vector<TIndex>(dims, dims + ndim));
+    t->ShareExternalPointer(device_ptr, TypeMeta::FromId(dtype));
+  });
+}
+
+int c2hip_run_operator_once(c2hip_workspace* ws, const void* def_bytes, size_t n) {
+  return guarded([&] {
+    const OperatorDef def = parse_def(def_bytes, n);
+    auto op = CreateOperator(def, &ws->ws);
+    CAFFE_ENFORCE(op->Run(), "Error when running operator ", def.type);
+  });
+}
+
+c2hip_operator* c2hip_create_operator(c2hip_workspace* ws, const void* def_bytes, size_t n) {
+  c2hip_operator* h = nullptr;
+  guarded([&] {
+    const OperatorDef def = parse_def(def_bytes, n);
+    auto op = CreateOperator(def, &ws->ws);
+    h = new c2hip_operator{std::move(op)};
+  });
+  return h;
+}
+
+int c2hip_run_operator(c2hip_operator* op, int sync) {
+  return guarded([&] {
+    const bool ok = sync ? op->op->Run() : op->op->RunAsync();
+    CAFFE_ENFORCE(ok, "Error when running operator ", op->op->def().type);
+  });
+}
+
+void c2hip_destroy_operator(c2hip_operator* op) { delete op; }
+
+size_t c2hip_registered_operators(int device_type, char* buf, size_t buflen) {
+  size_t need = 0;
+  guarded([&] { need = join_to(RegistryForDevice(device_type)->Keys(), buf, buflen); });
+  return need;
+}
+
+int c2hip_has_schema(const char* op_type, int* min_in, int* max_in, int* min_out, int* max_out) {
+  const OpSchema* s = OpSchemaRegistry::Schema(op_type);
+  if (!s) return 0;
+  if (min_in) *min_in = s->min_input();
+  if (max_in) *max_in = s->max_input();
+  if (min_out) *min_out = s->min_output();
+  if (max_out) *max_out = s->max_output();
+  return 1;
+}
+
+int c2hip_get_gradient_defs(const void* def_bytes, size_t n, const char* g_output_names,
+                            void* out_defs, size_t out_defs_cap, size_t* out_defs_len,
+                            int* n_defs, char* out_g_inputs, size_t out_g_inputs_cap) {
+  return guarded([&] {
+    const OperatorDef def = parse_def(def_bytes, n);
+    vector<GradientWrapper> g_out(def.output.size());
+    const vector<string> names = split_lines(g_output_names);
+    for (size_t i = 0; i < g_out.size() && i < names.size(); ++i) g_out[i].dense_ = names[i];
+    const GradientOpsMeta meta = GetGradientForOp(def, g_out);
+    string packed;
+    for (const OperatorDef& g : meta.ops_) {
+      const string s = SerializeOperatorDef(g);
+      const uint32_t len = (uint32_t)s.size();
+      packed.append((const char*)&len, 4);
+      packed += s;
+    }
+    CAFFE_ENFORCE_LE(packed.size(), out_defs_cap, "gradient def buffer too small");
+    if (!packed.empty()) memcpy(out_defs, packed.data(), packed.size());
+    *out_defs_len = packed.size();
+    *n_defs = (int)meta.ops_.size();
+    vector<string> gi;
+    for (const GradientWrapper& w : meta.g_input_) gi.push_back(w.dense_);
+    CAFFE_ENFORCE_LE(join_to(gi, out_g_inputs, out_g_inputs_cap), out_g_inputs_cap);
+  });
+}
+
+int c2hip_set_stream(int device_id, void* hip_stream, int enabled) {
+  return guarded([&] { HIPContext::SetExternalStream(device_id, (hipStream_t)hip_stream, enabled != 0); });
+}
+
+int c2hip_device_synchronize(int device_id) {
+  return guarded([&] {
+    HIP_ENFORCE(hipSetDevice(device_id));
+    HIP_ENFORCE(hipDeviceSynchronize());
+  });
+}
+
+}  // extern "C"

@@ -92,6 +92,29 @@ __global__ __launch_bounds__(kThreads) void sum_n_kernel(
   }
 }
 
+struct WSumArgs { const float* x[kMaxSum]; const float* w[kMaxSum]; int n_in; };
+
+// out = sum_k w_k[0] * x_k  (WeightedSum, weights are one-element device blobs)
+__global__ __launch_bounds__(kThreads) void weighted_sum_kernel(
+    const WSumArgs args, float* __restrict__ out, long long n) {
+  float wk[kMaxSum];
+#pragma unroll
+  for (int k = 0; k < kMaxSum; ++k) wk[k] = k < args.n_in ? args.w[k][0] : 0.0f;
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kMaxSum; ++k)
+      if (k < args.n_in) s += wk[k] * args.x[k][i];
+    out[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void fill_kernel(float* __restrict__ y, float v, long long n) {
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) y[i] = v;
+}
+
 __global__ __launch_bounds__(kThreads) void sgd_kernel(
     float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
     const float* __restrict__ lr_p, float mu, float wd, int is_bias, long long n) {
@@ -162,6 +185,29 @@ int ssad_momentum_sgd_update(float* w, float* g, float* m, const float* lr, floa
   if (n == 0) return 0;
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream,
                      w, g, m, lr, momentum, weight_decay, is_bias, (long long)n);
+  return (int)hipGetLastError();
+}
+
+int ssad_weighted_sum(const float* const* xs_host, const float* const* ws_host, int n_pairs,
+                      float* out, int64_t n, ssad_stream_t stream) {
+  if (n_pairs < 1 || n_pairs > kMaxSum || n < 0) return SSAD_E_BADARG;
+  if (n == 0) return 0;
+  WSumArgs a;
+  a.n_in = n_pairs;
+  for (int k = 0; k < kMaxSum; ++k) {
+    a.x[k] = k < n_pairs ? xs_host[k] : nullptr;
+    a.w[k] = k < n_pairs ? ws_host[k] : nullptr;
+  }
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(grid_for(n)), dim3(kThreads), 0,
+                     (hipStream_t)stream, a, out, (long long)n);
+  return (int)hipGetLastError();
+}
+
+int ssad_fill(float* y, float value, int64_t n, ssad_stream_t stream) {
+  if (n < 0) return SSAD_E_BADARG;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream,
+                     y, value, (long long)n);
   return (int)hipGetLastError();
 }
 

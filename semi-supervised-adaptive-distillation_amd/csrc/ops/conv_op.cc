@@ -1,0 +1,182 @@
+#include "ops/conv_op.h"
+
+#include "ssad_kernels.h"
+
+namespace caffe2 {
+
+// caffe2/operators/conv_pool_op_base.h:45-194, restated.
+ConvGeometry ParseConvGeometry(const OperatorBase& op) {
+  ConvGeometry g;
+  g.kernel = op.GetRepeatedArgument<int>("kernels");
+  g.stride = op.GetRepeatedArgument<int>("strides");
+  g.pads = op.GetRepeatedArgument<int>("pads");
+  g.dilation = op.GetRepeatedArgument<int>("dilations");
+  g.group = op.GetSingleArgument<int>("group", 1);
+  g.order = op.GetSingleArgument<string>("order", "NCHW");
+  const int legacy_pad = op.GetSingleArgument<int>("legacy_pad", 0);   // NOTSET
+  CAFFE_ENFORCE(legacy_pad == 0 || legacy_pad == 3,
+                "legacy padding VALID/SAME is not supported by the HIP conv operators");
+
+  auto pair_arg = [&](const char* single, const char* h, const char* w, vector<int>* out) {
+    if (op.HasArgument(single)) {
+      out->assign(2, op.GetSingleArgument<int>(single, 0));
+    } else if (op.HasArgument(h) && op.HasArgument(w)) {
+      out->push_back(op.GetSingleArgument<int>(h, 0));
+      out->push_back(op.GetSingleArgument<int>(w, 0));
+    }
+  };
+  pair_arg("kernel", "kernel_h", "kernel_w", &g.kernel);
+  pair_arg("stride", "stride_h", "stride_w", &g.stride);
+  pair_arg("dilation", "dilation_h", "dilation_w", &g.dilation);
+  if (op.HasArgument("pad")) {
+    g.pads.assign(4, op.GetSingleArgument<int>("pad", 0));
+  } else if (op.HasArgument("pad_t") && op.HasArgument("pad_l") && op.HasArgument("pad_b") &&
+             op.HasArgument("pad_r")) {
+    g.pads = {op.GetSingleArgument<int>("pad_t", 0), op.GetSingleArgument<int>("pad_l", 0),
+              op.GetSingleArgument<int>("pad_b", 0), op.GetSingleArgument<int>("pad_r", 0)};
+  }
+  if (g.kernel.empty()) g.kernel.assign(2, 0);
+  if (g.stride.empty()) g.stride.assign(g.kernel.size(), 1);
+  if (g.pads.empty()) g.pads.assign(g.kernel.size() * 2, 0);
+  if (g.dilation.empty()) g.dilation.assign(g.kernel.size(), 1);
+  CAFFE_ENFORCE_EQ(g.stride.size(), g.kernel.size());
+  CAFFE_ENFORCE_EQ(g.dilation.size(), g.kernel.size());
+  CAFFE_ENFORCE_EQ(g.pads.size(), 2 * g.kernel.size());
+  for (size_t d = 0; d < g.kernel.size(); ++d) {
+    CAFFE_ENFORCE_GE(g.pads[d], 0);
+    CAFFE_ENFORCE_GE(g.pads[g.kernel.size() + d], 0);
+    CAFFE_ENFORCE(g.kernel[d],
+                  "If you are doing convolution or pooling, you will need to set explicitly "
+                  "the kernel size.");
+    CAFFE_ENFORCE_GE(g.dilation[d], 0);
+    CAFFE_ENFORCE_GE(g.stride[d], 0);
+  }
+  CAFFE_ENFORCE(g.order == "NCHW" || g.order == "NHWC", "Unknown storage order: ", g.order);
+  return g;
+}
+
+bool IsSubnetGeometry(const ConvGeometry& g) {
+  return g.order == "NCHW" && g.group == 1 && g.kernel == vector<int>{3, 3} &&
+         g.stride == vector<int>{1, 1} && g.dilation == vector<int>{1, 1} &&
+         g.pads == vector<int>{1, 1, 1, 1};
+}
+
+namespace {
+enum { INPUT = 0, FILTER = 1, BIAS = 2, OUTPUT_GRAD = 2 };
+enum { FILTER_GRAD = 0, BIAS_OR_INPUT_GRAD = 1, INPUT_GRAD = 2 };
+}  // namespace
+
+template <>
+bool ConvOp<float, HIPContext>::RunOnDevice() {
+  auto& X = Input(INPUT);
+  auto& filter = Input(FILTER);
+  auto* Y = Output(0);
+  CAFFE_ENFORCE_EQ(X.ndim(), 4);
+  CAFFE_ENFORCE_EQ(X.ndim(), filter.ndim());
+  const int N = X.dim32(0), C = X.dim32(1), H = X.dim32(2), W = X.dim32(3);
+  const int M = filter.dim32(0);
+  CAFFE_ENFORCE(C == filter.dim32(1) * geom_.group,
+                "Convolution op: input channels does not match: # of input channels ", C,
+                " is not equal to kernel channels * group:", filter.dim32(1), "*", geom_.group);
+  CAFFE_ENFORCE(filter.dim32(2) == geom_.kernel[0] && filter.dim32(3) == geom_.kernel[1]);
+  const float* bias = nullptr;
+  if (InputSize() == 3) {
+    auto& b = Input(BIAS);
+    CAFFE_ENFORCE(b.ndim() == 1);
+    CAFFE_ENFORCE(b.dim32(0) == M);
+    bias = b.data<float>();
+  }
+  Y->Resize(N, M, H, W);   // 3x3 / s1 / p1 keeps the spatial size
+
+  hipStream_t s = context_.hip_stream();
+  packed_filter_.Resize((TIndex)ssad_conv_packed_filter_floats(M, C));
+  float* packed = packed_filter_.mutable_data<float>();
+  CAFFE_ENFORCE_EQ(ssad_conv_pack_filter(filter.data<float>(), M, C, packed, nullptr, s), 0);
+  ssad_conv_level lv{X.data<float>(), Y->mutable_data<float>(), nullptr, N, H, W};
+  const int rc = ssad_conv3x3_forward(&lv, 1, packed, bias, M, C,
+                                      fuse_relu_ ? SSAD_CONV_RELU : 0, s);
+  CAFFE_ENFORCE_EQ(rc, 0, "Conv launch failed");
+  return true;
+}
+
+template <>
+bool ConvGradientOp<float, HIPContext>::RunOnDevice() {
+  auto& X = Input(INPUT);
+  auto& filter = Input(FILTER);
+  auto& dY = Input(OUTPUT_GRAD);
+  auto* dfilter = Output(FILTER_GRAD);
+  CAFFE_ENFORCE_EQ(X.ndim(), 4);
+  CAFFE_ENFORCE_EQ(X.ndim(), filter.ndim());
+  const int N = X.dim32(0), C = X.dim32(1), H = X.dim32(2), W = X.dim32(3);
+  const int M = filter.dim32(0);
+  CAFFE_ENFORCE(filter.dim32(1) * geom_.group == C);
+  CAFFE_ENFORCE(filter.dim32(2) == geom_.kernel[0] && filter.dim32(3) == geom_.kernel[1]);
+  CAFFE_ENFORCE_EQ(dY.ndim(), 4);
+  CAFFE_ENFORCE(dY.dim32(0) == N && dY.dim32(1) == M && dY.dim32(2) == H && dY.dim32(3) == W,
+                "output gradient shape does not match the convolution output");
+  dfilter->ResizeLike(filter);
+  float* db = nullptr;
+  if (!no_bias_) {
+    auto* dbias = Output(BIAS_OR_INPUT_GRAD);
+    dbias->Resize(M);
+    db = dbias->mutable_data<float>();
+  }
+  hipStream_t s = context_.hip_stream();
+
+  // filter (+ bias) gradient: overwrite, beta = 0 (conv_op_cudnn.cc:1037)
+  ssad_conv_level wl{X.data<float>(), nullptr, dY.data<float>(), N, H, W};
+  const size_t wsb = ssad_conv3x3_wgrad_workspace_bytes(&wl, 1, M, C);
+  workspace_.Resize((TIndex)wsb);
+  int rc = ssad_conv3x3_wgrad(&wl, 1, dfilter->mutable_data<float>(), db, M, C, 0,
+                              workspace_.mutable_data<uint8_t>(), wsb, s);
+  CAFFE_ENFORCE_EQ(rc, 0, "ConvGradient (filter) launch failed");
+
+  if (OutputSize() == 3 || (no_bias_ && OutputSize() == 2)) {
+    auto* dX = Output(no_bias_ ? BIAS_OR_INPUT_GRAD : INPUT_GRAD);
+    dX->ResizeLike(X);
+    packed_filter_.Resize((TIndex)ssad_conv_packed_filter_floats(C, M));
+    float* packed = packed_filter_.mutable_data<float>();
+    CAFFE_ENFORCE_EQ(ssad_conv_pack_filter(filter.data<float>(), M, C, nullptr, packed, s), 0);
+    ssad_conv_level dl{dY.data<float>(), dX->mutable_data<float>(),
+                       relu_grad_on_input_ ? X.data<float>() : nullptr, N, H, W};
+    rc = ssad_conv3x3_forward(&dl, 1, packed, nullptr, C, M,
+                              relu_grad_on_input_ ? SSAD_CONV_MASK_AUX : 0, s);
+    CAFFE_ENFORCE_EQ(rc, 0, "ConvGradient (data) launch failed");
+  }
+  return true;
+}
+
+REGISTER_HIP_OPERATOR(Conv, ConvOp<float, HIPContext>);
+REGISTER_HIP_OPERATOR(ConvGradient, ConvGradientOp<float, HIPContext>);
+
+OPERATOR_SCHEMA(Conv)
+    .NumInputs(2, 3)
+    .NumOutputs(1)
+    .SetDoc("2-D convolution (cross-correlation) Y = W * X + b.")
+    .Input(0, "X", "Input data blob, NCHW.")
+    .Input(1, "filter", "The filter blob, M x C x kH x kW.")
+    .Input(2, "bias", "The 1D bias blob of length M.")
+    .Output(0, "Y", "Output data blob.");
+OPERATOR_SCHEMA(ConvGradient).NumInputs(2, 3).NumOutputs(1, 3);
+
+// caffe2/operators/conv_gradient_op.cc:35-77
+class GetConvGradient : public GradientMakerBase {
+  using GradientMakerBase::GradientMakerBase;
+  vector<OperatorDef> GetGradientDefs() override {
+    CAFFE_ENFORCE(def_.input.size() == 3 || def_.input.size() == 2);
+    vector<Argument> args = def_.arg;
+    // the fusion extension of the forward op does not transfer to the gradient
+    for (auto it = args.begin(); it != args.end();)
+      it = (it->name == "fuse_relu") ? args.erase(it) : it + 1;
+    if (def_.input.size() == 3) {
+      return SingleGradientDef("ConvGradient", "", vector<string>{I(0), I(1), GO(0)},
+                               vector<string>{GI(1), GI(2), GI(0)}, args);
+    }
+    args.push_back(MakeArgument("no_bias", 1));
+    return SingleGradientDef("ConvGradient", "", vector<string>{I(0), I(1), GO(0)},
+                             vector<string>{GI(1), GI(0)}, args);
+  }
+};
+REGISTER_GRADIENT(Conv, GetConvGradient);
+
+}  // namespace caffe2

@@ -1,0 +1,198 @@
+// The small stock operators the hot path runs through, for HIPContext:
+//   Relu / ReluGradient        caffe2/operators/relu_op.cu:38-66
+//   Sigmoid                    caffe2/operators/sigmoid_op.cu:25-29
+//   Sum                        caffe2/operators/utility_ops.h (SumOp), used by
+//                              the autograd accumulation core.py:706-741
+//   Scale                      caffe2/operators/scale_op.h
+//   WeightedSum                caffe2/operators/utility_ops.h (WeightedSumOp)
+//   ConstantFill (float)       caffe2/operators/filler_op.h
+//   MomentumSGDUpdate          caffe2/sgd/momentum_sgd_op.h:97-131
+#include "c2/operator.h"
+#include "ssad_kernels.h"
+
+namespace caffe2 {
+
+#define LAUNCH_OK(call, what) CAFFE_ENFORCE_EQ((call), 0, what, " launch failed")
+
+class ReluHIPOp final : public Operator<HIPContext> {
+ public:
+  using Operator<HIPContext>::Operator;
+  bool RunOnDevice() override {
+    auto& X = Input(0);
+    auto* Y = Output(0);
+    CAFFE_ENFORCE_GT(X.size(), 0);
+    Y->ResizeLike(X);
+    LAUNCH_OK(ssad_relu(X.data<float>(), Y->mutable_data<float>(), X.size(),
+                        context_.hip_stream()), "Relu");
+    return true;
+  }
+};
+
+class ReluGradientHIPOp final : public Operator<HIPContext> {
+ public:
+  using Operator<HIPContext>::Operator;
+  bool RunOnDevice() override {
+    auto& Y = Input(0);
+    auto& dY = Input(1);
+    auto* dX = Output(0);
+    CAFFE_ENFORCE_GT(Y.size(), 0);
+    CAFFE_ENFORCE_EQ(dY.size(), Y.size());
+    dX->ResizeLike(Y);
+    LAUNCH_OK(ssad_relu_grad(Y.data<float>(), dY.data<float>(), dX->mutable_data<float>(),
+                             Y.size(), context_.hip_stream()), "ReluGradient");
+    return true;
+  }
+};
+
+class SigmoidHIPOp final : public Operator<HIPContext> {
+ public:
+  using Operator<HIPContext>::Operator;
+  bool RunOnDevice() override {
+    auto& X = Input(0);
+    auto* Y = Output(0);
+    Y->ResizeLike(X);
+    LAUNCH_OK(ssad_sigmoid(X.data<float>(), Y->mutable_data<float>(), X.size(),
+                           context_.hip_stream()), "Sigmoid");
+    return true;
+  }
+};
+
+class SumHIPOp final : public Operator<HIPContext> {
+ public:
+  using Operator<HIPContext>::Operator;
+  bool RunOnDevice() override {
+    auto& X0 = Input(0);
+    auto* Y = Output(0);
+    vector<const float*> ptrs(InputSize());
+    for (int i = 0; i < InputSize(); ++i) {
+      CAFFE_ENFORCE(Input(i).dims() == X0.dims(), "Sum: input ", i, " has a different shape");
+      ptrs[i] = Input(i).data<float>();
+    }
+    Y->ResizeLike(X0);
+    LAUNCH_OK(ssad_sum_n(ptrs.data(), InputSize(), Y->mutable_data<float>(), X0.size(),
+                         context_.hip_stream()), "Sum");
+    return true;
+  }
+};
+
+class ScaleHIPOp final : public Operator<HIPContext> {
+ public:
+  ScaleHIPOp(const OperatorDef& d, Workspace* ws)
+      : Operator<HIPContext>(d, ws), scale_(GetSingleArgument<float>("scale", 1.0f)) {}
+  bool RunOnDevice() override {
+    auto& X = Input(0);
+    auto* Y = Output(0);
+    Y->ResizeLike(X);
+    LAUNCH_OK(ssad_scale(X.data<float>(), Y->mutable_data<float>(), scale_, X.size(),
+                         context_.hip_stream()), "Scale");
+    return true;
+  }
+ private:
+  float scale_;
+};
+
+// inputs X0, w0, X1, w1, ... ; output may alias X0
+class WeightedSumHIPOp final : public Operator<HIPContext> {
+ public:
+  using Operator<HIPContext>::Operator;
+  bool RunOnDevice() override {
+    CAFFE_ENFORCE_EQ(InputSize() % 2, 0);
+    const int pairs = InputSize() / 2;
+    auto& X0 = Input(0);
+    vector<const float*> xs(pairs), ws(pairs);
+    for (int k = 0; k < pairs; ++k) {
+      CAFFE_ENFORCE_EQ(Input(2 * k).size(), X0.size());
+      CAFFE_ENFORCE_EQ(Input(2 * k + 1).size(), 1);
+      xs[k] = Input(2 * k).data<float>();
+      ws[k] = Input(2 * k + 1).data<float>();
+    }
+    auto* Y = Output(0);
+    Y->ResizeLike(X0);
+    LAUNCH_OK(ssad_weighted_sum(xs.data(), ws.data(), pairs, Y->mutable_data<float>(), X0.size(),
+                                context_.hip_stream()), "WeightedSum");
+    return true;
+  }
+};
+
+// float only; shape from arg `shape` or from input 0 (as filler_op.h)
+class ConstantFillHIPOp final : public Operator<HIPContext> {
+ public:
+  ConstantFillHIPOp(const OperatorDef& d, Workspace* ws)
+      : Operator<HIPContext>(d, ws),
+        value_(GetSingleArgument<float>("value", 0.0f)),
+        shape_(GetRepeatedArgument<int64_t>("shape")) {}
+  bool RunOnDevice() override {
+    auto* Y = Output(0);
+    if (InputSize() > 0) Y->ResizeLike(Input(0)); else Y->Resize(shape_);
+    LAUNCH_OK(ssad_fill(Y->mutable_data<float>(), value_, Y->size(), context_.hip_stream()),
+              "ConstantFill");
+    return true;
+  }
+ private:
+  float value_;
+  vector<int64_t> shape_;
+};
+
+// inputs [grad, momentum, lr, param] -> outputs [grad, momentum, param] in place
+class MomentumSGDUpdateHIPOp final : public Operator<HIPContext> {
+ public:
+  MomentumSGDUpdateHIPOp(const OperatorDef& d, Workspace* ws)
+      : Operator<HIPContext>(d, ws),
+        momentum_(GetSingleArgument<float>("momentum", 0.0f)),
+        nesterov_(GetSingleArgument<int>("nesterov", 0)) {
+    CAFFE_ENFORCE(!nesterov_, "nesterov momentum is not on the path and not implemented");
+  }
+  bool RunOnDevice() override {
+    auto& g = Input(0);
+    auto& m = Input(1);
+    CAFFE_ENFORCE_EQ(Input(2).size(), 1);
+    CAFFE_ENFORCE_EQ(g.size(), m.size());
+    CAFFE_ENFORCE_EQ(Input(3).size(), g.size());
+    Output(0)->ResizeLike(g);
+    Output(1)->ResizeLike(m);
+    Output(2)->ResizeLike(Input(3));
+    float* gp = Output(0)->mutable_data<float>();
+    float* mp = Output(1)->mutable_data<float>();
+    float* wp = Output(2)->mutable_data<float>();
+    CAFFE_ENFORCE(gp == g.data<float>() && mp == m.data<float>() && wp == Input(3).data<float>(),
+                  "MomentumSGDUpdate runs in place: outputs must alias grad, momentum, param");
+    LAUNCH_OK(ssad_momentum_sgd_update(wp, gp, mp, Input(2).data<float>(), momentum_, 0.0f, 0,
+                                       g.size(), context_.hip_stream()), "MomentumSGDUpdate");
+    return true;
+  }
+ private:
+  float momentum_;
+  int nesterov_;
+};
+
+REGISTER_HIP_OPERATOR(Relu, ReluHIPOp);
+REGISTER_HIP_OPERATOR(ReluGradient, ReluGradientHIPOp);
+REGISTER_HIP_OPERATOR(Sigmoid, SigmoidHIPOp);
+REGISTER_HIP_OPERATOR(Sum, SumHIPOp);
+REGISTER_HIP_OPERATOR(Scale, ScaleHIPOp);
+REGISTER_HIP_OPERATOR(WeightedSum, WeightedSumHIPOp);
+REGISTER_HIP_OPERATOR(ConstantFill, ConstantFillHIPOp);
+REGISTER_HIP_OPERATOR(MomentumSGDUpdate, MomentumSGDUpdateHIPOp);
+
+OPERATOR_SCHEMA(Relu).NumInputs(1).NumOutputs(1).AllowInplace({{0, 0}});
+OPERATOR_SCHEMA(ReluGradient).NumInputs(2).NumOutputs(1).AllowInplace({{1, 0}});
+OPERATOR_SCHEMA(Sigmoid).NumInputs(1).NumOutputs(1).AllowInplace({{0, 0}});
+OPERATOR_SCHEMA(Sum).NumInputs(1, INT_MAX).NumOutputs(1).AllowInplace({{0, 0}});
+OPERATOR_SCHEMA(Scale).NumInputs(1).NumOutputs(1).AllowInplace({{0, 0}});
+OPERATOR_SCHEMA(WeightedSum).NumInputs(2, INT_MAX).NumOutputs(1).AllowInplace({{0, 0}});
+OPERATOR_SCHEMA(ConstantFill).NumInputs(0, 1).NumOutputs(1).AllowInplace({{0, 0}});
+OPERATOR_SCHEMA(MomentumSGDUpdate).NumInputs(4).NumOutputs(3).AllowInplace({{0, 0}, {1, 1}, {3, 2}});
+
+// Relu's gradient is taken w.r.t. its OUTPUT (relu_op.cc GetReluGradient)
+class GetReluGradient : public GradientMakerBase {
+  using GradientMakerBase::GradientMakerBase;
+  vector<OperatorDef> GetGradientDefs() override {
+    return SingleGradientDef("ReluGradient", "", vector<string>{O(0), GO(0)},
+                             vector<string>{GI(0)}, vector<Argument>());
+  }
+};
+REGISTER_GRADIENT(Relu, GetReluGradient);
+NO_GRADIENT(PowSum);
+NO_GRADIENT(ConstantFill);
+
+}  // namespace caffe2
