@@ -153,6 +153,8 @@ SSAD_API int ssad_conv_pack_filter(
 
 #define SSAD_CONV_RELU 1      /* y = max(y, 0) in the epilogue            */
 #define SSAD_CONV_MASK_AUX 2  /* y = aux > 0 ? y : 0 (fused ReluGradient) */
+#define SSAD_CONV_SIGMOID 4   /* y = 1/(1+exp(-y)) (teacher cls_pred -> prob,
+                                 caffe2/operators/sigmoid_op.cu:25-29 fused) */
 
 /* y = conv3x3(x, packed) (+ bias) for every level in one launch.
  * Used for the forward (packed_fwd, Cout outputs, Cin inputs) and for the

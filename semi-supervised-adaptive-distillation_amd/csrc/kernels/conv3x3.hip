@@ -272,6 +272,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_kernel(const FwdArgs args) 
         float v = acc[t][r];
         if (args.bias) v += args.bias[m];
         if (flags & SSAD_CONV_RELU) v = v > 0.0f ? v : 0.0f;
+        if (flags & SSAD_CONV_SIGMOID) v = 1.0f / (1.0f + expf(-v));
         const int o = m * HW + py * W + px;
         if (aux) v = aux[o] > 0.0f ? v : 0.0f;
         yout[o] = v;

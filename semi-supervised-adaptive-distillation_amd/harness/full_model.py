@@ -1,0 +1,144 @@
+"""ResNet-FPN backbones (torch, MIOpen convs) + the HIP subnet pipeline.
+
+Structure follows detectron/lib/modeling/ResNet.py:85-130 (bottleneck stages
+3-4-{6,23}-3, stride on the first 1x1 as with the MSRA weights, frozen BN as a
+per-channel affine = AffineChannel) and FPN.py:116-250 for RetinaNet
+(laterals on res3..res5, 3x3 output convs, P6 = conv3x3/2 on res5, P7 =
+conv3x3/2 on relu(P6); levels P3..P7 at 256 channels).  Random weights.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Affine(nn.Module):
+    """AffineChannel (frozen BN): y = x * s + b, s and b not trained."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.register_buffer("s", torch.ones(1, c, 1, 1))
+        self.register_buffer("b", torch.zeros(1, c, 1, 1))
+
+    def forward(self, x):
+        return x * self.s + self.b
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, cin, cmid, cout, stride):
+        super().__init__()
+        self.c1 = nn.Conv2d(cin, cmid, 1, stride=stride, bias=False)
+        self.a1 = Affine(cmid)
+        self.c2 = nn.Conv2d(cmid, cmid, 3, padding=1, bias=False)
+        self.a2 = Affine(cmid)
+        self.c3 = nn.Conv2d(cmid, cout, 1, bias=False)
+        self.a3 = Affine(cout)
+        self.proj = None
+        if cin != cout or stride != 1:
+            self.proj = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False),
+                                      Affine(cout))
+
+    def forward(self, x):
+        sc = x if self.proj is None else self.proj(x)
+        y = F.relu(self.a1(self.c1(x)))
+        y = F.relu(self.a2(self.c2(y)))
+        y = self.a3(self.c3(y))
+        return F.relu(y + sc)
+
+
+class ResNetFPN(nn.Module):
+    def __init__(self, depth=50, fpn_dim=256):
+        super().__init__()
+        blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[depth]
+        self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False),
+                                  Affine(64), nn.ReLU(inplace=True),
+                                  nn.MaxPool2d(3, stride=2, padding=1))
+        stages, cin = [], 64
+        for i, n in enumerate(blocks):
+            cmid, cout = 64 * 2 ** i, 256 * 2 ** i
+            layers = []
+            for j in range(n):
+                layers.append(Bottleneck(cin, cmid, cout, 2 if (j == 0 and i > 0) else 1))
+                cin = cout
+            stages.append(nn.Sequential(*layers))
+        self.res2, self.res3, self.res4, self.res5 = stages
+        self.lat = nn.ModuleList([nn.Conv2d(c, fpn_dim, 1) for c in (2048, 1024, 512)])
+        self.out = nn.ModuleList([nn.Conv2d(fpn_dim, fpn_dim, 3, padding=1) for _ in range(3)])
+        self.p6 = nn.Conv2d(2048, fpn_dim, 3, stride=2, padding=1)
+        self.p7 = nn.Conv2d(fpn_dim, fpn_dim, 3, stride=2, padding=1)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+        # the stem and res2 are frozen in Detectron (TRAIN.FREEZE_CONV_BODY / FREEZE_AT = 2)
+        for p in list(self.stem.parameters()) + list(self.res2.parameters()):
+            p.requires_grad_(False)
+
+    def forward(self, x):
+        c2 = self.res2(self.stem(x))
+        c3 = self.res3(c2)
+        c4 = self.res4(c3)
+        c5 = self.res5(c4)
+        t5 = self.lat[0](c5)
+        t4 = self.lat[1](c4) + F.interpolate(t5, scale_factor=2, mode="nearest")
+        t3 = self.lat[2](c3) + F.interpolate(t4, scale_factor=2, mode="nearest")
+        p5, p4, p3 = self.out[0](t5), self.out[1](t4), self.out[2](t3)
+        p6 = self.p6(c5)
+        p7 = self.p7(F.relu(p6))
+        return [p3, p4, p5, p6, p7]      # finest first, matching synth.LEVEL_SHAPES_600
+
+
+class FullDistillModel(object):
+    """One distillation iteration of the whole detector on one GPU."""
+
+    def __init__(self, heads, student_depth=50, teacher_depth=101, device="cuda",
+                 process_group=None, world_size=1, lr=0.01, momentum=0.9, weight_decay=1e-4):
+        self.heads = heads
+        self.pg, self.world = process_group, world_size
+        g = torch.Generator().manual_seed(7)
+        with torch.random.fork_rng():
+            torch.manual_seed(7)
+            self.student = ResNetFPN(student_depth).to(device)
+            self.teacher = ResNetFPN(teacher_depth).to(device).eval()
+        del g
+        for p in self.teacher.parameters():
+            p.requires_grad_(False)
+        self.trainable = [p for p in self.student.parameters() if p.requires_grad]
+        self.opt = torch.optim.SGD(self.trainable, lr=lr, momentum=momentum,
+                                   weight_decay=weight_decay)
+        if self.pg is not None and world_size > 1:
+            import torch.distributed as dist
+            for p in self.student.parameters():
+                dist.broadcast(p.data, src=0, group=self.pg)
+            # one flat gradient bucket for the backbone: few, large all-reduces
+            n = sum(p.numel() for p in self.trainable)
+            self.flat_grad = torch.zeros(n, device=device)
+            off = 0
+            for p in self.trainable:
+                p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+                off += p.numel()
+
+    def step(self, images, labels, d_bbox_pred):
+        h = self.heads
+        h.pack_student()
+        with torch.no_grad():
+            t_fpn = [t.contiguous() for t in self.teacher(images)]
+            h.teacher_forward(t_fpn)
+        s_fpn = self.student(images)
+        s_in = [t.detach().contiguous() for t in s_fpn]
+        h.student_forward(s_in)
+        h.distill_loss(labels)
+        d_fpn = h.backward(d_bbox_pred)
+        # gradient w.r.t. each FPN level = cls-subnet part + bbox-subnet part
+        grads = [a + b for a, b in zip(d_fpn["cls"], d_fpn["bbox"])]
+        if self.pg is not None and self.world > 1:
+            self.flat_grad.zero_()
+        else:
+            self.opt.zero_grad(set_to_none=True)
+        torch.autograd.backward(s_fpn, grads)
+        if self.pg is not None and self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+        h.sgd_step()
+        self.opt.step()
+        return h.losses

@@ -1,0 +1,240 @@
+"""Fused execution of the hot path: teacher heads forward, student heads
+forward, PowSum + SigmoidAdaptiveDistillLoss, student heads backward, gradient
+all-reduce and SGD -- the per-GPU work of one training iteration of
+`build_generic_retinanet_model_dissstillation`
+(detectron/lib/modeling/model_builder.py:373-411) restricted to the subnets.
+
+Same arithmetic as running the operator graph of modeling/retinanet_heads.py
+through the workspace (tests check that), but scheduled MI355X-first:
+
+  * the five FPN levels that share a filter run as ONE launch per layer
+    (the reference runs 5 cuDNN calls; its DAG executor overlaps them at best);
+  * Relu / ReluGradient / Sigmoid live in conv epilogues, the 5-way gradient
+    Sum over levels (caffe2/python/core.py:706-741) in the wgrad reduction;
+  * filters are repacked once per step, not once per level;
+  * all activations, gradients, parameters, parameter gradients and momenta
+    are pre-allocated once (HBM is 288 GB; nothing is allocated in the step);
+    parameter gradients live in two flat buckets (cls subnet, bbox subnet) so
+    the data-parallel exchange is two large RCCL all-reduces that overlap the
+    remaining backward instead of ~20 per-tensor ones
+    (detectron/lib/modeling/optimizer.py:72-92).
+
+torch provides device memory, streams and torch.distributed only.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import synth
+from .data_parallel import BucketedAllReduce
+from .modeling.retinanet_heads import HeadConfig
+
+
+def head_param_specs(cfg):
+    """(name, shape, is_bias) in bucket order: cls subnet then bbox subnet."""
+    A, C, D = cfg.num_anchors, cfg.num_classes - 1, cfg.fpn_dim
+    specs = []
+    for tower, pred_dim in (("cls", A * C), ("bbox", 4 * A)):
+        for i in range(cfg.num_convs):
+            stem = "retnet_%s_conv_n%d_fpn%d" % (tower, i, cfg.k_min)
+            specs.append((stem + "_w", (D, D, 3, 3), False, tower))
+            specs.append((stem + "_b", (D,), True, tower))
+        stem = "retnet_%s_pred_fpn%d" % (tower, cfg.k_min)
+        specs.append((stem + "_w", (pred_dim, D, 3, 3), False, tower))
+        specs.append((stem + "_b", (pred_dim,), True, tower))
+    return specs
+
+
+class FlatParams(object):
+    """Parameters (or gradients / momenta) of both subnets in one flat
+    buffer; `bucket[tower]` is the contiguous slice of one subnet."""
+
+    def __init__(self, cfg, device, init=None):
+        self.specs = head_param_specs(cfg)
+        total = sum(int(np.prod(s)) for _, s, _, _ in self.specs)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        self.views = OrderedDict()
+        self.bucket = {}
+        off = 0
+        starts = {}
+        for name, shape, _, tower in self.specs:
+            n = int(np.prod(shape))
+            starts.setdefault(tower, off)
+            self.views[name] = self.flat[off:off + n].view(shape)
+            off += n
+            self.bucket[tower] = self.flat[starts[tower]:off]
+        if init is not None:
+            for name, arr in init.items():
+                self.views[name].copy_(torch.as_tensor(arr))
+
+    def __getitem__(self, name):
+        return self.views[name]
+
+
+class DistillHeads(object):
+    def __init__(self, cfg=None, N=2, shapes=synth.LEVEL_SHAPES_600, device="cuda",
+                 student_init=None, teacher_init=None, teacher_bbox_tower=True,
+                 lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, world_size=1):
+        self.cfg = cfg or HeadConfig()
+        self.N, self.shapes, self.device = N, list(shapes), device
+        self.teacher_bbox_tower = teacher_bbox_tower
+        self.momentum, self.weight_decay = momentum, weight_decay
+        self.pg, self.world_size = process_group, world_size
+        self.dp = BucketedAllReduce(process_group, world_size)
+        cfg = self.cfg
+        self.A, self.C, self.D = cfg.num_anchors, cfg.num_classes - 1, cfg.fpn_dim
+        self.params = FlatParams(cfg, device, student_init)
+        self.teacher = FlatParams(cfg, device, teacher_init)
+        self.grads = FlatParams(cfg, device)
+        self.moms = FlatParams(cfg, device)
+        self.lr = torch.full((1,), lr, dtype=torch.float32, device=device)
+        self.one = torch.ones(len(self.shapes), dtype=torch.float32, device=device)
+
+        def lv(ch):
+            return [torch.empty((N, ch, h, w), dtype=torch.float32, device=device)
+                    for (h, w) in self.shapes]
+        D = self.D
+        # student activations (kept for backward) and their gradients
+        self.act = {t: [lv(D) for _ in range(cfg.num_convs)] for t in ("cls", "bbox")}
+        self.cls_logits, self.bbox_pred = lv(self.A * self.C), lv(4 * self.A)
+        self.d_cls_logits = lv(self.A * self.C)
+        self.dbuf = [lv(D), lv(D)]            # ping-pong for tower gradients
+        self.d_fpn = {t: lv(D) for t in ("cls", "bbox")}
+        # teacher scratch: two ping-pong feature sets + probabilities
+        self.t_buf = [lv(D), lv(D)]
+        self.t_prob = lv(self.A * self.C)
+        self.t_bbox = lv(4 * self.A) if teacher_bbox_tower else None
+        # packed filters (rebuilt every step from the current weights)
+        self.packed = {}
+        self.t_packed = None
+        self.losses = None
+        self.normalizer = None
+
+    # -- parameters -----------------------------------------------------------
+    def _layers(self, tower):
+        cfg = self.cfg
+        names = ["retnet_%s_conv_n%d_fpn%d" % (tower, i, cfg.k_min) for i in range(cfg.num_convs)]
+        names.append("retnet_%s_pred_fpn%d" % (tower, cfg.k_min))
+        return names
+
+    def pack_student(self, want_dgrad=True):
+        for tower in ("cls", "bbox"):
+            for name in self._layers(tower):
+                self.packed[name] = K.conv_pack_filter(self.params[name + "_w"], True, want_dgrad)
+
+    def pack_teacher(self):
+        """The teacher is frozen: pack once."""
+        self.t_packed = {}
+        for tower in ("cls", "bbox"):
+            for name in self._layers(tower):
+                self.t_packed[name] = K.conv_pack_filter(self.teacher[name + "_w"], True, False)[0]
+
+    # -- forward ----------------------------------------------------------------
+    def _tower_forward(self, params, packed_of, tower, feats, out_of, pred_out, sigmoid=False):
+        layers = self._layers(tower)
+        x = feats
+        for i, name in enumerate(layers[:-1]):
+            x = K.conv3x3_forward(x, packed_of(name), params[name + "_b"], self.D, relu=True,
+                                  out=out_of(i))
+        name = layers[-1]
+        Cout = params[name + "_b"].numel()
+        return K.conv3x3_forward(x, packed_of(name), params[name + "_b"], Cout, sigmoid=sigmoid,
+                                 out=pred_out)
+
+    def teacher_forward(self, fpn_feats):
+        """Teacher subnets in test mode: cls tower -> Sigmoid probabilities
+        (retinanet_heads.py:153-163); its bbox tower runs too, as in the
+        reference's graph, unless teacher_bbox_tower=False."""
+        if self.t_packed is None:
+            self.pack_teacher()
+        pk = lambda n: self.t_packed[n]
+        pingpong = lambda i: self.t_buf[i & 1]
+        self._tower_forward(self.teacher, pk, "cls", fpn_feats, pingpong, self.t_prob,
+                            sigmoid=True)
+        if self.teacher_bbox_tower:
+            self._tower_forward(self.teacher, pk, "bbox", fpn_feats, pingpong, self.t_bbox)
+        return self.t_prob
+
+    def student_forward(self, fpn_feats):
+        self.fpn_in = fpn_feats
+        pk = lambda n: self.packed[n][0]
+        self._tower_forward(self.params, pk, "cls", fpn_feats, lambda i: self.act["cls"][i],
+                            self.cls_logits)
+        self._tower_forward(self.params, pk, "bbox", fpn_feats, lambda i: self.act["bbox"][i],
+                            self.bbox_pred)
+        return self.cls_logits, self.bbox_pred
+
+    # -- losses -------------------------------------------------------------------
+    def distill_loss(self, labels):
+        """PowSum normaliser + the five SigmoidAdaptiveDistillLoss, forward and
+        gradient w.r.t. the student logits (loss gradient = 1.0,
+        utils/blob.py:166-172)."""
+        cfg = self.cfg
+        kw = dict(gamma=cfg.distill_gamma, alpha=cfg.distill_alpha, beta=cfg.distill_beta,
+                  num_classes=self.C, ignored_label=cfg.ignored_label,
+                  scale=cfg.loss_scale * cfg.temperature * cfg.temperature)
+        self.normalizer = K.pow_sum(self.t_prob, cfg.logits_power).reshape(1)
+        levels = list(zip(self.cls_logits, self.t_prob, labels))
+        self.losses = K.distill_loss_forward(levels, self.normalizer, **kw)
+        K.distill_loss_backward(levels, self.normalizer, self.one, out=self.d_cls_logits, **kw)
+        return self.losses
+
+    # -- backward -------------------------------------------------------------------
+    def _tower_backward(self, tower, d_pred):
+        """d_pred: gradient w.r.t. the prediction conv output, per level."""
+        layers = self._layers(tower)
+        acts = self.act[tower]
+        dy = d_pred
+        for li in range(len(layers) - 1, -1, -1):
+            name = layers[li]
+            x_in = acts[li - 1] if li > 0 else self.fpn_in
+            Cout = self.params[name + "_b"].numel()
+            K.conv3x3_wgrad(x_in, dy, Cout, dW=self.grads[name + "_w"], db=self.grads[name + "_b"])
+            # data gradient; for li > 0 the input is a ReLU output, so the
+            # ReluGradient mask (Y > 0) is the conv input itself
+            out = self.dbuf[li & 1] if li > 0 else self.d_fpn[tower]
+            dy = K.conv3x3_forward(dy, self.packed[name][1], None, self.D,
+                                   mask_by=x_in if li > 0 else None, out=out)
+        return dy
+
+    def backward(self, d_bbox_pred):
+        """Backward of both subnets.  The cls subnet goes first; its bucket's
+        all-reduce then overlaps the bbox subnet's backward."""
+        self._tower_backward("cls", self.d_cls_logits)
+        self._allreduce_async("cls")
+        self._tower_backward("bbox", d_bbox_pred)
+        self._allreduce_async("bbox")
+        return self.d_fpn
+
+    # -- data parallel ------------------------------------------------------------------
+    def _allreduce_async(self, tower):
+        self.dp.issue(self.grads.bucket[tower])
+
+    def wait_gradients(self):
+        self.dp.wait()
+
+    def broadcast_params(self, src=0):
+        """Initial parameter sync (detectron/lib/utils/net.py:185-208)."""
+        self.dp.broadcast([self.params.flat, self.moms.flat], src=src)
+
+    # -- update -------------------------------------------------------------------------
+    def sgd_step(self):
+        self.wait_gradients()
+        for name, _, is_bias, _ in self.params.specs:
+            K.momentum_sgd_update_(self.params[name], self.grads[name], self.moms[name], self.lr,
+                                   self.momentum, self.weight_decay, is_bias)
+
+    # -- one iteration --------------------------------------------------------------------
+    def step(self, student_fpn, teacher_fpn, labels, d_bbox_pred, update=True):
+        self.pack_student()
+        self.teacher_forward(teacher_fpn)
+        self.student_forward(student_fpn)
+        self.distill_loss(labels)
+        self.backward(d_bbox_pred)
+        if update:
+            self.sgd_step()
+        else:
+            self.wait_gradients()
+        return self.losses

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 MAX_LEVELS = 8
 CONV_RELU = 1
 CONV_MASK_AUX = 2
+CONV_SIGMOID = 4
 
 
 class KernelError(RuntimeError):
@@ -260,7 +261,8 @@ def _conv_levels(xs, ys, auxs):
     return arr
 
 
-def conv3x3_forward(xs, packed, bias, Cout, *, relu=False, mask_by=None, out=None):
+def conv3x3_forward(xs, packed, bias, Cout, *, relu=False, sigmoid=False, mask_by=None,
+                    out=None):
     """xs: list of N x Cin x H x W tensors (FPN levels sharing the filter).
     Returns the list of N x Cout x H x W outputs (one launch for all levels)."""
     L = lib()
@@ -270,7 +272,8 @@ def conv3x3_forward(xs, packed, bias, Cout, *, relu=False, mask_by=None, out=Non
     ys = out if out is not None else [
         torch.empty((x.shape[0], Cout, x.shape[2], x.shape[3]), dtype=torch.float32,
                     device="cuda") for x in xs]
-    flags = (CONV_RELU if relu else 0) | (CONV_MASK_AUX if mask_by is not None else 0)
+    flags = ((CONV_RELU if relu else 0) | (CONV_MASK_AUX if mask_by is not None else 0)
+             | (CONV_SIGMOID if sigmoid else 0))
     arr = _conv_levels(xs, ys, mask_by)
     _check(L.ssad_conv3x3_forward(arr, len(xs), _ptr(packed), _ptr(bias), Cout, Cin, flags,
                                   _stream()), "conv3x3_forward")

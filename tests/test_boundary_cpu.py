@@ -1,0 +1,220 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports
+every symbol include/*.h declares, the protobuf wire codec round-trips
+between Python and C++, registry / schema / gradient makers behave like the
+reference's, and the graph builder reproduces the op list captured from the
+reference's retinanet_heads.py."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ssad_amd  # noqa: F401
+from ssad_amd.caffe2_hip import _capi, caffe2_pb2, core, dyndep, workspace
+from ssad_amd.modeling import retinanet_heads as rh
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    dyndep.InitOpsLibrary()
+    return _capi.load()
+
+
+def declared_symbols():
+    names = []
+    for h in ("ssad_kernels.h", "c2hip_capi.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"#define[^\n]*", "", text)
+        names += re.findall(r"(?:SSAD_API|C2HIP_CAPI)\s+[^;(]*?\b(\w+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = declared_symbols()
+    assert len(names) >= 40, names
+    raw = ctypes.CDLL(_capi.LIB_PATH)
+    missing = [n for n in names if not hasattr(raw, n)]
+    assert not missing, "declared in include/ but not exported: %s" % missing
+    assert raw.ssad_kernels_abi_version() == 1
+    raw.ssad_kernels_arch.restype = ctypes.c_char_p
+    assert raw.ssad_kernels_arch() == b"gfx950"
+
+
+def test_registered_operators(lib):
+    for op in ("SigmoidAdaptiveDistillLoss", "SigmoidAdaptiveDistillLossGradient", "PowSum",
+               "Conv", "ConvGradient", "Relu", "ReluGradient", "Sigmoid", "Sum", "Scale",
+               "WeightedSum", "ConstantFill", "MomentumSGDUpdate"):
+        assert core.IsOperator(op), op
+    assert not core.IsOperator("NoSuchOp")
+    mi, ma, mo, mx = (ctypes.c_int() for _ in range(4))
+    assert lib.c2hip_has_schema(b"SigmoidAdaptiveDistillLoss", mi, ma, mo, mx)
+    assert (mi.value, ma.value, mo.value, mx.value) == (4, 4, 1, 1)
+    assert lib.c2hip_has_schema(b"SigmoidAdaptiveDistillLossGradient", mi, ma, mo, mx)
+    assert (mi.value, ma.value) == (5, 5)
+    assert lib.c2hip_has_schema(b"PowSum", mi, ma, mo, mx)
+    assert mi.value == 1 and ma.value >= 1000 and mo.value == 1
+
+
+def test_proto_wire_roundtrip_python_and_cpp(lib):
+    op = core.CreateOperator(
+        "SigmoidAdaptiveDistillLoss", ["x", "t", "g", "n"], ["loss"], gamma=2.0, alpha=0.5,
+        scale=0.125, beta=0.0, num_classes=80, ignored_label=-1,
+        device_option=core.DeviceOption(caffe2_pb2.CUDA, 3), engine="CUDNN")
+    back = caffe2_pb2.OperatorDef().ParseFromString(op.SerializeToString())
+    assert back.to_jsonable() == op.to_jsonable()
+    assert back.device_option == op.device_option
+    # C++ parses the bytes, builds the gradient def, serializes it back
+    gops, gin = core.GradientRegistry.GetGradientForOp(op, ["loss_grad"])
+    assert len(gops) == 1 and gin == ["x_grad", None, None, None]   # logits only (.cc:99-112)
+    g = gops[0]
+    assert g.type == "SigmoidAdaptiveDistillLossGradient" and g.is_gradient_op
+    assert g.input == ["x", "t", "g", "n", "loss_grad"] and g.output == ["x_grad"]
+    args = {a.name: a for a in g.arg}
+    assert args["ignored_label"].i == -1 and args["num_classes"].i == 80
+    assert abs(args["scale"].f - 0.125) < 1e-9 and abs(args["gamma"].f - 2.0) < 1e-9
+    assert g.device_option == op.device_option
+
+
+def test_conv_and_relu_gradient_makers(lib):
+    c = core.CreateOperator("Conv", ["X", "w", "b"], ["Y"], kernel=3, pad=1, stride=1,
+                            order="NCHW", engine="CUDNN", exhaustive_search=False)
+    gops, gin = core.GradientRegistry.GetGradientForOp(c, ["Y_grad"])
+    assert gops[0].type == "ConvGradient" and gops[0].input == ["X", "w", "Y_grad"]
+    assert gops[0].output == ["w_grad", "b_grad", "X_grad"] and gin == ["X_grad", "w_grad", "b_grad"]
+    c2 = core.CreateOperator("Conv", ["X", "w"], ["Y"], kernel=3, pad=1, stride=1)
+    gops, gin = core.GradientRegistry.GetGradientForOp(c2, ["Y_grad"])
+    assert gops[0].output == ["w_grad", "X_grad"]
+    assert any(a.name == "no_bias" and a.i == 1 for a in gops[0].arg)
+    r = core.CreateOperator("Relu", ["Y"], ["Y"])
+    gops, gin = core.GradientRegistry.GetGradientForOp(r, ["Y_grad"])
+    assert gops[0].type == "ReluGradient" and gops[0].input == ["Y", "Y_grad"]
+    with pytest.raises(_capi.C2Error):
+        core.GradientRegistry.GetGradientForOp(core.CreateOperator("Sigmoid", ["a"], ["b"]), ["g"])
+
+
+def test_errors_match_reference_behaviour(lib):
+    workspace.ResetWorkspace()
+    x = np.zeros((1, 6, 2, 2), np.float32)
+    for n in ("x", "t"):
+        workspace.FeedBlob(n, x)
+    workspace.FeedBlob("g", np.zeros((1, 2, 2, 2), np.int32))
+    workspace.FeedBlob("n", np.ones((), np.float32))
+    # no CPU implementation, exactly like the reference (.h:42-45)
+    op = core.CreateOperator("SigmoidAdaptiveDistillLoss", ["x", "t", "g", "n"], ["l"], num_classes=3)
+    with pytest.raises(_capi.C2Error, match="Not Implemented"):
+        workspace.RunOperatorOnce(op)
+    with pytest.raises(_capi.C2Error, match="Not Implemented"):
+        workspace.RunOperatorOnce(core.CreateOperator("PowSum", ["x"], ["s"], power=1.8))
+    # scale < 0 is rejected in the constructor (.h:39)
+    with pytest.raises(_capi.C2Error, match="scale_ >= 0"):
+        workspace.RunOperatorOnce(core.CreateOperator(
+            "SigmoidAdaptiveDistillLoss", ["x", "t", "g", "n"], ["l"], scale=-1.0))
+    # schema: wrong input count
+    with pytest.raises(_capi.C2Error, match="Input size"):
+        workspace.RunOperatorOnce(core.CreateOperator("SigmoidAdaptiveDistillLoss", ["x", "t"], ["l"]))
+    # missing input blob
+    with pytest.raises(_capi.C2Error, match="non-existing input blob"):
+        workspace.RunOperatorOnce(core.CreateOperator("PowSum", ["nope"], ["s"]))
+    # unknown operator / no implementation for the device
+    with pytest.raises(_capi.C2Error, match="Cannot create operator"):
+        workspace.RunOperatorOnce(core.CreateOperator("Conv", ["x", "t"], ["y"], kernel=3))
+    assert workspace.HasBlob("x") and "x" in workspace.Blobs()
+    assert np.array_equal(workspace.FetchBlob("g"), np.zeros((1, 2, 2, 2), np.int32))
+    workspace.ResetWorkspace()
+    assert not workspace.HasBlob("x")
+
+
+def golden_graph():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "head_graph_r50_distill.json")))
+
+
+def op_signature(op):
+    ja = op.to_jsonable()
+    args = {a["name"]: a.get("f", a.get("i", a.get("s"))) for a in ja["arg"]}
+    if op.engine:
+        args["engine"] = op.engine
+    return ja["type"], ja["input"], ja["output"], args
+
+
+def same_args(mine, ref):
+    if set(mine) != set(ref):
+        return False
+    for k, v in ref.items():
+        if isinstance(v, str):
+            if mine[k] != v:
+                return False
+        elif abs(float(mine[k]) - float(v)) > 1e-6 * max(1.0, abs(float(v))):
+            return False
+    return True
+
+
+def build_student(train=True, prefix="", fuse=False):
+    core._REGISTERED_OPERATORS.update(["SelectSmoothL1Loss", "SigmoidFocalLoss"])  # graph-only
+    m = rh.HeadModel(rh.HeadConfig(fuse_relu=fuse), train=train)
+    blobs = [prefix + "fpn_%d" % l for l in range(7, 2, -1)]
+    rh.add_fpn_retinanet_outputs(m, blobs, 256, prefix)
+    return m
+
+
+def test_head_graph_matches_reference_builder(lib):
+    """same ops, blob names, args as the list captured
+    from the reference's retinanet_heads.py (tests/golden/make_head_graph.py)."""
+    g = golden_graph()
+    m = build_student()
+    lg = {}
+    lg.update(rh.add_fpn_retinanet_losses(m))
+    lg.update(rh.add_distill_loss(m))
+    ops = m.net.Proto().op
+    assert len(ops) == len(g["student_ops"]) == 121
+    for mine, ref in zip(ops, g["student_ops"]):
+        t, i, o, a = op_signature(mine)
+        assert (t, i, o) == (ref["type"], ref["input"], ref["output"])
+        assert same_args(a, ref["args"]), (t, a, ref["args"])
+    assert lg == g["loss_gradients"]
+    assert m.losses == g["student_losses"] and m.metrics == g["student_metrics"]
+    ref_params = {p["name"]: p for p in g["student_params"]}
+    assert [p[0] for p in m.params] == [p["name"] for p in g["student_params"]]
+    for name, shape, (filler, kw) in m.params:
+        assert shape == ref_params[name]["shape"] and filler == ref_params[name]["init"][0]
+        for k, v in ref_params[name]["init"][1].items():
+            assert abs(kw[k] - v) < 1e-6
+    # teacher (test mode): + Sigmoid per level under the teacher/ prefix
+    t = build_student(train=False, prefix="teacher/")
+    tops = t.net.Proto().op
+    assert len(tops) == len(g["teacher_ops"])
+    for mine, ref in zip(tops, g["teacher_ops"]):
+        ty, i, o, a = op_signature(mine)
+        assert (ty, i, o) == (ref["type"], ref["input"], ref["output"]) and same_args(a, ref["args"])
+
+
+def test_backward_graph_shared_weight_accumulation(lib):
+    """Gradient generation: 50 ConvGradient + 40 ReluGradient + 5 distill
+    gradients; every shared head parameter gets five `_grad_autosplit_k`
+    pieces summed by one Sum op (caffe2/python/core.py:706-741)."""
+    m = build_student()
+    loss_grads = rh.add_distill_loss(m)
+    n_fwd = len(m.net.Proto().op)
+    grad_map = m.net.AddGradientOperators(loss_grads)
+    bwd = m.net.Proto().op[n_fwd:]
+    hist = {}
+    for op in bwd:
+        hist[op.type] = hist.get(op.type, 0) + 1
+    # only the cls subnet receives a gradient from the distillation loss
+    assert hist["SigmoidAdaptiveDistillLossGradient"] == 5
+    assert hist["ConvGradient"] == 25 and hist["ReluGradient"] == 20
+    sums = [op for op in bwd if op.type == "Sum"]
+    w = "retnet_cls_conv_n0_fpn3_w"
+    s = [op for op in sums if op.output == [w + "_grad"]]
+    assert len(s) == 1 and s[0].input == ["%s_grad_autosplit_%d" % (w, k) for k in range(5)]
+    assert grad_map[w] == w + "_grad" and grad_map["retnet_cls_pred_fpn3_b"] == "retnet_cls_pred_fpn3_b_grad"
+    assert len(sums) == 10   # 5 weights + 5 biases of the cls subnet
+    # every autosplit piece is written by exactly one ConvGradient
+    written = [o for op in bwd if op.type == "ConvGradient" for o in op.output]
+    for k in range(5):
+        assert written.count("%s_grad_autosplit_%d" % (w, k)) == 1
+    assert grad_map["fpn_3"] == "fpn_3_grad"

@@ -1,0 +1,229 @@
+"""GPU parity through the operator boundary: OperatorDefs (protobuf bytes)
+-> C-ABI -> Operator<HIPContext>::RunOnDevice -> HIP kernels, driven exactly
+as the reference's Python layer drives Caffe2 (FeedBlob / RunOperatorOnce /
+CreateNet / RunNet), checked against the CPU oracle; then the fused pipeline
+(head_pipeline.DistillHeads) against the operator graph and the oracle."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+import ssad_amd  # noqa: E402,F401
+from oracle import head_step, oracle  # noqa: E402
+from ssad_amd import synth  # noqa: E402
+from ssad_amd.caffe2_hip import caffe2_pb2, core, dyndep, workspace  # noqa: E402
+from ssad_amd.modeling import retinanet_heads as rh  # noqa: E402
+from test_gpu_kernels import (CONV_FLOOR, CONV_RTOL, DX_FLOOR, DX_RTOL, LOSS_RTOL,  # noqa: E402
+                              close)
+
+pytestmark = pytest.mark.gpu
+
+# the reference graph says CUDA; the HIP registry serves it
+GPU = core.DeviceOption(caffe2_pb2.CUDA, 0)
+
+
+@pytest.fixture(autouse=True)
+def fresh_workspace():
+    assert torch.cuda.is_available()
+    dyndep.InitOpsLibrary()
+    workspace.ResetWorkspace()
+    yield
+    workspace.ResetWorkspace()
+
+
+def feed(name, arr):
+    workspace.FeedBlob(name, arr, device_option=GPU)
+
+
+def test_distill_loss_operator_and_gradient():
+    rng = np.random.default_rng(21)
+    N, A, C, H, W = 2, 3, 7, 6, 8
+    x, q, g = synth.distill_inputs(rng, N, A, C, H, W)
+    feed("logits", x); feed("prob", q); feed("labels", g)
+    feed("norm", np.array(55.5, np.float32))
+    feed("dloss", np.array(1.0, np.float32))
+    kw = dict(gamma=2.0, alpha=0.5, beta=0.0, num_classes=C, ignored_label=-1, scale=0.125)
+    with core.DeviceScope(GPU):
+        op = core.CreateOperator("SigmoidAdaptiveDistillLoss",
+                                 ["logits", "prob", "labels", "norm"], ["loss"], **kw)
+    workspace.RunOperatorOnce(op)
+    loss = workspace.FetchBlob("loss")
+    assert loss.shape == ()                       # Resize(vector<TIndex>()) -> 0-dim
+    _, s64, _ = oracle.distill_loss_forward(x, q, g, 55.5, **kw)
+    close(loss, s64, LOSS_RTOL, 0, "op loss")
+    gops, gin = core.GradientRegistry.GetGradientForOp(op, ["dloss"])
+    workspace.RunOperatorsOnce(gops)
+    dx = workspace.FetchBlob(gin[0])
+    assert dx.shape == x.shape
+    close(dx, oracle.distill_loss_backward(x, q, g, 55.5, 1.0, **kw), DX_RTOL, DX_FLOOR, "op dX")
+    # bad shapes raise EnforceNotMet instead of reading out of bounds
+    feed("badlabels", np.zeros((N, A, H, W - 1), np.int32))
+    with core.DeviceScope(GPU):
+        bad = core.CreateOperator("SigmoidAdaptiveDistillLoss",
+                                  ["logits", "prob", "badlabels", "norm"], ["l2"], **kw)
+    with pytest.raises(Exception, match="labels must be"):
+        workspace.RunOperatorOnce(bad)
+
+
+def test_powsum_operator():
+    rng = np.random.default_rng(22)
+    arrs = [rng.random(s).astype(np.float32) for s in ((2, 9, 4, 5), (2, 9, 2, 3), (7,))]
+    for i, a in enumerate(arrs):
+        feed("p%d" % i, a)
+    with core.DeviceScope(GPU):
+        op = core.CreateOperator("PowSum", ["p0", "p1", "p2"], ["distill_normalizer"], power=1.8)
+    workspace.RunOperatorOnce(op)
+    got = workspace.FetchBlob("distill_normalizer")
+    assert got.shape == ()
+    close(got, oracle.pow_sum(arrs, 1.8)[1], 1e-5, 0, "PowSum op")
+
+
+def test_conv_relu_operators_and_gradients():
+    rng = np.random.default_rng(23)
+    N, Cin, M, H, W = 2, 16, 24, 9, 13
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, 3, 3)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    dY = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    feed("X", X); feed("w", Wt); feed("b", b); feed("Y_grad_in", dY)
+    with core.DeviceScope(GPU):
+        conv = core.CreateOperator("Conv", ["X", "w", "b"], ["Y"], kernel=3, pad=1, stride=1,
+                                   order="NCHW", engine="CUDNN", exhaustive_search=False)
+        relu = core.CreateOperator("Relu", ["Y"], ["Y"])
+    workspace.RunOperatorOnce(conv)
+    rY = oracle.conv_forward(X, Wt, b)
+    close(workspace.FetchBlob("Y"), rY, CONV_RTOL, CONV_FLOOR, "Conv op")
+    workspace.RunOperatorOnce(relu)
+    Yr = workspace.FetchBlob("Y")
+    close(Yr, oracle.relu(rY), CONV_RTOL, CONV_FLOOR, "Relu in place")
+    g_relu, gi = core.GradientRegistry.GetGradientForOp(relu, ["Y_grad_in"])
+    workspace.RunOperatorsOnce(g_relu)
+    dpre = workspace.FetchBlob(gi[0])
+    assert np.array_equal(dpre, oracle.relu_grad(Yr, dY))
+    g_conv, gi = core.GradientRegistry.GetGradientForOp(conv, [gi[0]])
+    workspace.RunOperatorsOnce(g_conv)
+    rdW, rdb, rdX = oracle.conv_backward(X, Wt, dpre)
+    close(workspace.FetchBlob("w_grad"), rdW, CONV_RTOL, CONV_FLOOR, "dW")
+    close(workspace.FetchBlob("b_grad"), rdb, CONV_RTOL, CONV_FLOOR, "db")
+    close(workspace.FetchBlob("X_grad"), rdX, CONV_RTOL, CONV_FLOOR, "dX")
+    # a geometry outside the engine's scope is refused at construction
+    with core.DeviceScope(GPU):
+        c5 = core.CreateOperator("Conv", ["X", "w", "b"], ["Y5"], kernel=5, pad=2, stride=1)
+    with pytest.raises(Exception, match="Cannot create operator|HIP Conv engine"):
+        workspace.RunOperatorOnce(c5)
+
+
+def test_sgd_update_ops_follow_optimizer_py():
+    """Scale(2x) for biases / WeightedSum(g + wd*w) for weights, then
+    MomentumSGDUpdate (detectron/lib/modeling/optimizer.py:115-130)."""
+    rng = np.random.default_rng(24)
+    w, g, m = (rng.standard_normal(1000).astype(np.float32) for _ in range(3))
+    feed("lr", np.array([0.02], np.float32)); feed("one", np.array([1.0], np.float32))
+    feed("wd", np.array([1e-4], np.float32))
+    for is_bias in (False, True):
+        feed("p", w); feed("p_grad", g); feed("p_momentum", m)
+        with core.DeviceScope(GPU):
+            ops = [core.CreateOperator("Scale", ["p_grad"], ["p_grad"], scale=2.0) if is_bias else
+                   core.CreateOperator("WeightedSum", ["p_grad", "one", "p", "wd"], ["p_grad"]),
+                   core.CreateOperator("MomentumSGDUpdate", ["p_grad", "p_momentum", "lr", "p"],
+                                       ["p_grad", "p_momentum", "p"], momentum=0.9)]
+        workspace.RunOperatorsOnce(ops)
+        rw, rg, rm = oracle.sgd_update(w, g, m, 0.02, 0.9, 1e-4, is_bias)
+        close(workspace.FetchBlob("p"), rw, 1e-6, 1e-7, "w")
+        close(workspace.FetchBlob("p_momentum"), rm, 1e-6, 1e-7, "m")
+        close(workspace.FetchBlob("p_grad"), rg, 1e-6, 1e-7, "g")
+
+
+SHAPES = [(10, 14), (5, 7), (3, 4), (2, 2), (1, 1)]     # P3..P7 of a tiny image
+
+
+def small_problem(seed=31, N=2):
+    rng = np.random.default_rng(seed)
+    cfg = rh.HeadConfig(num_gpus=1)
+    S, T = synth.head_params(rng), synth.head_params(rng)
+    # larger weights than the N(0, 0.01) init so that gradients are well above fp32 noise
+    for P in (S, T):
+        for k in P:
+            if k.endswith("_w"):
+                P[k] = (P[k] * 3).astype(np.float32)
+    fs = synth.fpn_features(rng, N, SHAPES)
+    ft = synth.fpn_features(rng, N, SHAPES)
+    labs = [synth.distill_inputs(rng, N, 9, 80, h, w)[2] for h, w in SHAPES]
+    db = [(rng.standard_normal((N, 36, h, w)) * 1e-3).astype(np.float32) for h, w in SHAPES]
+    return cfg, S, T, fs, ft, labs, db
+
+
+def test_head_graph_through_workspace_vs_oracle_and_fused():
+    """The whole hot path as the reference runs it: teacher graph (test mode),
+    student graph, PowSum + SigmoidAdaptiveDistillLoss, autograd backward with
+    the shared-weight Sum, all through CreateNet / RunNet -- against the
+    oracle's composition and against the fused DistillHeads pipeline."""
+    cfg, S, T, fs, ft, labs, db = small_problem()
+    levels = list(cfg.levels())
+    with core.DeviceScope(GPU):
+        teacher = rh.HeadModel(cfg, train=False, name="teacher")
+        rh.add_fpn_retinanet_outputs(teacher, ["teacher/fpn_%d" % l for l in reversed(levels)],
+                                     256, "teacher/")
+        student = rh.HeadModel(cfg, train=True, name="student")
+        rh.add_fpn_retinanet_outputs(student, ["fpn_%d" % l for l in reversed(levels)], 256)
+        loss_grads = rh.add_distill_loss(student)
+        for l in levels:   # stand-in for the SelectSmoothL1Loss gradient
+            loss_grads["retnet_bbox_pred_fpn%d" % l] = "retnet_bbox_pred_fpn%d_grad" % l
+        grad_map = student.net.AddGradientOperators(loss_grads)
+    for k, v in S.items():
+        feed(k, v)
+    for k, v in T.items():
+        feed("teacher/" + k, v)
+    for i, l in enumerate(levels):
+        feed("fpn_%d" % l, fs[i]); feed("teacher/fpn_%d" % l, ft[i])
+        feed("retnet_cls_labels_fpn%d" % l, labs[i])
+        feed("retnet_bbox_pred_fpn%d_grad" % l, db[i])
+    workspace.CreateNet(teacher.net)
+    workspace.CreateNet(student.net)
+    workspace.RunNet(teacher.net)
+    workspace.RunNet(student.net, sync_every_op=True)    # reference semantics
+    ref = head_step.head_step(S, T, fs, ft, labs, db, scale=cfg.loss_scale)
+
+    close(workspace.FetchBlob("distill_normalizer"), ref["normalizer"], 1e-5, 0, "normalizer")
+    for i, l in enumerate(levels):
+        close(workspace.FetchBlob("teacher/retnet_cls_prob_fpn%d" % l), ref["t_prob"][i],
+              CONV_RTOL, CONV_FLOOR, "teacher prob")
+        close(workspace.FetchBlob("retnet_cls_pred_fpn%d" % l), ref["cls_logits"][i],
+              CONV_RTOL, CONV_FLOOR, "cls logits")
+        close(workspace.FetchBlob("fl_distill_fpn%d" % l), ref["losses"][i], 2e-4, 0, "loss")
+    for name, g in ref["grads"].items():
+        close(workspace.FetchBlob(grad_map[name]), g, 2e-4, 2e-5, "graph grad " + name)
+    for i, l in enumerate(levels):
+        want = ref["d_fpn"]["cls"][i] + ref["d_fpn"]["bbox"][i]
+        close(workspace.FetchBlob(grad_map["fpn_%d" % l]), want, 2e-4, 2e-5, "d fpn")
+
+    # fused pipeline: same numbers
+    from ssad_amd.head_pipeline import DistillHeads
+    dev = torch.device("cuda", 0)
+    heads = DistillHeads(cfg, N=fs[0].shape[0], shapes=SHAPES, device=dev, student_init=S,
+                         teacher_init=T)
+    t = lambda arrs: [torch.from_numpy(a).to(dev) for a in arrs]
+    losses = heads.step(t(fs), t(ft), t(labs), t(db), update=False)
+    close(losses.cpu().numpy(), ref["losses"], 2e-4, 0, "fused losses")
+    for name, g in ref["grads"].items():
+        close(heads.grads[name].cpu().numpy(), g, 2e-4, 2e-5, "fused grad " + name)
+        close(heads.grads[name].cpu().numpy(), workspace.FetchBlob(grad_map[name]), 2e-4, 2e-5,
+              "fused vs graph " + name)
+    for tower in ("cls", "bbox"):
+        for i in range(len(SHAPES)):
+            close(heads.d_fpn[tower][i].cpu().numpy(), ref["d_fpn"][tower][i], 2e-4, 2e-5, "d_fpn")
+
+
+def test_fused_sgd_step_matches_oracle():
+    cfg, S, T, fs, ft, labs, db = small_problem(seed=33, N=1)
+    from ssad_amd.head_pipeline import DistillHeads
+    dev = torch.device("cuda", 0)
+    heads = DistillHeads(cfg, N=1, shapes=SHAPES, device=dev, student_init=S, teacher_init=T,
+                         lr=0.01)
+    t = lambda arrs: [torch.from_numpy(a).to(dev) for a in arrs]
+    heads.step(t(fs), t(ft), t(labs), t(db), update=True)
+    ref = head_step.head_step(S, T, fs, ft, labs, db, scale=cfg.loss_scale)
+    for name, _, is_bias, _ in heads.params.specs:
+        w, _, m = oracle.sgd_update(S[name], ref["grads"][name], np.zeros_like(S[name]), 0.01, 0.9,
+                                    1e-4, is_bias)
+        close(heads.params[name].cpu().numpy(), w, 1e-5, 1e-6, "updated " + name)
