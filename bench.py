@@ -90,7 +90,7 @@ def cpu_baseline(args, cfg):
     timed on the host cores of this box, on a bounded sample: ONE image."""
     from oracle import oracle, head_step
     from ssad_amd import synth
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)   # beyond ~64 threads the 256-row GEMMs stop scaling
     oracle.set_num_threads(cores)
     shapes = synth.LEVEL_SHAPES_600 if (args.cpu_sample == "all" or
                                         (args.cpu_sample == "auto" and cores >= 16)) \
@@ -171,7 +171,7 @@ def main():
         from ssad_amd.harness.full_model import FullDistillModel
         model = FullDistillModel(heads, student_depth=50, teacher_depth=101, device=dev,
                                  process_group=pg, world_size=world)
-        images = torch.randn((N, 3, 640, 896), device=dev, generator=gen) * 50.0
+        images = torch.randn((N, 3, 640, 896), device=dev, generator=gen)
 
         def step():
             model.step(images, labels, d_bbox)

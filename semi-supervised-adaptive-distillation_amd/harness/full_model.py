@@ -67,9 +67,16 @@ class ResNetFPN(nn.Module):
         self.p7 = nn.Conv2d(fpn_dim, fpn_dim, 3, stride=2, padding=1)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
-                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                nn.init.kaiming_normal_(m.weight, mode="fan_in", nonlinearity="relu")
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
+            if isinstance(m, Bottleneck):
+                # frozen-BN affines carry no statistics with random weights:
+                # damp the residual branch so activations stay O(1) through
+                # 16 / 33 blocks (a trained model's BN does this job)
+                m.a3.s.fill_(0.25)
+        for m in list(self.lat) + list(self.out) + [self.p6, self.p7]:
+            nn.init.xavier_uniform_(m.weight)
         # the stem and res2 are frozen in Detectron (TRAIN.FREEZE_CONV_BODY / FREEZE_AT = 2)
         for p in list(self.stem.parameters()) + list(self.res2.parameters()):
             p.requires_grad_(False)
@@ -92,7 +99,7 @@ class FullDistillModel(object):
     """One distillation iteration of the whole detector on one GPU."""
 
     def __init__(self, heads, student_depth=50, teacher_depth=101, device="cuda",
-                 process_group=None, world_size=1, lr=0.01, momentum=0.9, weight_decay=1e-4):
+                 process_group=None, world_size=1, lr=1e-3, momentum=0.9, weight_decay=1e-4):
         self.heads = heads
         self.pg, self.world = process_group, world_size
         g = torch.Generator().manual_seed(7)
