@@ -41,6 +41,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ssad_kernels.h"
 
@@ -54,6 +55,18 @@ constexpr int PITCH = 48;    // LDS floats per patch row (18 used)
 constexpr int kBlock = 512;  // 8 waves
 
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Buffer descriptor from values the compiler must treat as wave-uniform:
+// every input goes through readfirstlane, otherwise hipcc wraps each buffer
+// load in a waterfall loop that serialises the loads.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, int bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const int n = __builtin_amdgcn_readfirstlane(bytes);
+  void* q = (void*)(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, n, 0x00020000);
+}
 
 // ---------------------------------------------------------------------------
 // Filter packing
@@ -128,7 +141,7 @@ struct FwdArgs {
 };
 
 // WM x WP waves; each wave: 32 output channels x PT pixel tiles (2 rows x 16).
-template <int WM, int WP, int PT>
+template <int WM, int WP, int PT, bool TAP_FENCE>
 __global__ __launch_bounds__(kBlock, 2) void conv3x3_kernel(const FwdArgs args) {
   static_assert(WM * WP * 64 == kBlock, "8 waves");
   constexpr int PR = 2 * PT * WP;            // patch rows
@@ -165,9 +178,14 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_kernel(const FwdArgs args) 
   const bool active = mtile < mtiles;         // wave-uniform
 
   // ---- staging map (fixed per thread) -------------------------------------
-  // element e -> (channel c, patch row r, patch col q); LDS and global offsets
-  int s_lds[SITER], s_goff[SITER], s_ch[SITER];
-  bool s_ok[SITER];
+  // element e -> (channel c, patch row r, patch col q).  The global side is a
+  // raw buffer load: descriptor = this image's K x H x W block (channels past
+  // K read as 0), per-lane byte offset pushed out of range outside the image,
+  // chunk step through the scalar offset.
+  constexpr unsigned kOOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t xrsrc = uniform_rsrc(xin, K * HW * 4);
+  int s_lds[SITER];
+  unsigned s_voff[SITER];
 #pragma unroll
   for (int it = 0; it < SITER; ++it) {
     const int e = tid + it * kBlock;
@@ -176,11 +194,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_kernel(const FwdArgs args) 
     const int r = rem / (TW + 2);
     const int q = rem - r * (TW + 2);
     const int gy = y0 - 1 + r, gx = x0 - 1 + q;
-    s_ok[it] = (e < STAGE) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const bool ok = (e < STAGE) && gy >= 0 && gy < H && gx >= 0 && gx < W;
     s_lds[it] = (e < STAGE) ? c * CS + r * PITCH + q : -1;
-    s_goff[it] = c * HW + gy * W + gx;
-    s_ch[it] = c;
+    s_voff[it] = ok ? (unsigned)((c * HW + gy * W + gx) * 4) : kOOB;
   }
+  const int chunk_bytes = KC * HW * 4;
 
   // ---- operand addressing ---------------------------------------------------
   const int kk = lane >> 5;                  // which channel of the k-pair
@@ -197,41 +215,38 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_kernel(const FwdArgs args) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-  // ---- prologue: stage chunk 0 ----------------------------------------------
   float sreg[SITER];
+  auto stage_load = [&](int ch) {
+    const int soff = __builtin_amdgcn_readfirstlane(ch * chunk_bytes);
 #pragma unroll
-  for (int it = 0; it < SITER; ++it) {
-    const bool ok = s_ok[it] && (s_ch[it] < K);
-    const float v = xin[ok ? s_goff[it] : 0];   // unconditional load, clamped address
-    sreg[it] = ok ? v : 0.0f;
-  }
+    for (int it = 0; it < SITER; ++it)
+      sreg[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+          xrsrc, s_voff[it], soff, 0));
+  };
+  auto stage_store = [&](float* buf) {
 #pragma unroll
-  for (int it = 0; it < SITER; ++it)
-    if (s_lds[it] >= 0) lds[s_lds[it]] = sreg[it];
-  float4 a0 = astream[0];
-  float4 a1 = astream[64];
+    for (int it = 0; it < SITER; ++it)
+      if (s_lds[it] >= 0) buf[s_lds[it]] = sreg[it];
+  };
+
+  // ---- prologue: stage chunk 0 ----------------------------------------------
+  stage_load(0);
+  stage_store(lds);
   __syncthreads();
 
   const int chunks = args.chunks;
-  for (int ch = 0; ch < chunks; ++ch) {
-    const float* buf = bbase + (ch & 1) * BUF;
-    // global loads for the next chunk's patch (land while we compute)
-    const bool more = ch + 1 < chunks;
-    if (more) {
-      const int coff = (ch + 1) * KC * HW;
+  if (active) {
+    float4 a0 = astream[0];
+    float4 a1 = astream[64];
+    for (int ch = 0; ch < chunks; ++ch) {
+      const float* buf = bbase + (ch & 1) * BUF;
+      const bool more = ch + 1 < chunks;
+      if (more) stage_load(ch + 1);          // lands while we compute
 #pragma unroll
-      for (int it = 0; it < SITER; ++it) {
-        const bool ok = s_ok[it] && ((ch + 1) * KC + s_ch[it] < K);
-        const float v = xin[ok ? coff + s_goff[it] : 0];
-        sreg[it] = ok ? v : 0.0f;
-      }
-    }
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      // prefetch the A operands two taps ahead (linear stream)
-      const float4 a2 = astream[(long long)(ch * 9 + tap + 2) * 64];
-      const int r = tap / 3, s = tap % 3;
-      if (active) {
+      for (int tap = 0; tap < 9; ++tap) {
+        // prefetch the A operands two taps ahead (linear stream)
+        const float4 a2 = astream[(long long)(ch * 9 + tap + 2) * 64];
+        const int r = tap / 3, s = tap % 3;
         const float av[4] = {a0.x, a0.y, a0.z, a0.w};
 #pragma unroll
         for (int cp = 0; cp < 4; ++cp) {
@@ -241,21 +256,28 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_kernel(const FwdArgs args) 
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cp], b, acc[t], 0, 0, 0);
           }
         }
+        a0 = a1;
+        a1 = a2;
+        // keep each tap's {A wait, 16 LDS reads, 4*PT MFMAs} together
+        if constexpr (TAP_FENCE) __builtin_amdgcn_sched_barrier(0);
       }
-      a0 = a1;
-      a1 = a2;
+      if (more) stage_store(lds + ((ch + 1) & 1) * BUF);
+      __syncthreads();
     }
-    if (more) {
-      float* nb = lds + ((ch + 1) & 1) * BUF;
-#pragma unroll
-      for (int it = 0; it < SITER; ++it)
-        if (s_lds[it] >= 0) nb[s_lds[it]] = sreg[it];
+  } else {
+    // a wave past the last output-channel tile only helps staging
+    for (int ch = 0; ch < chunks; ++ch) {
+      const bool more = ch + 1 < chunks;
+      if (more) {
+        stage_load(ch + 1);
+        stage_store(lds + ((ch + 1) & 1) * BUF);
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    return;
   }
 
   // ---- epilogue ----------------------------------------------------------------
-  if (!active) return;
   const int flags = args.flags;
   float* yout = L.y + (long long)n * M * HW;
   const float* aux = (flags & SSAD_CONV_MASK_AUX) ? L.aux + (long long)n * M * HW : nullptr;
@@ -353,10 +375,16 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_wgrad_kernel(const WgArgs a
   const int x_r = x_pos / (TW + 2), x_q = x_pos - x_r * (TW + 2);
   const bool x_used = x_pos < X_POS;
 
-  // Patch coordinates of the patch being prefetched (wave-uniform).
-  int q_y0 = 0, q_x0 = 0, q_H = 0, q_W = 0;
-  const float* q_dy = nullptr;
-  const float* q_x = nullptr;
+  // Patch being prefetched.  Staging loads are raw buffer loads: the
+  // descriptor (wave-uniform, SGPRs) bounds the channel range, the per-lane
+  // byte offset is ONE VGPR that is pushed out of range for pixels outside the
+  // image, and the per-iteration channel step goes through the scalar offset.
+  // Out-of-range reads return 0, so there is no select after the load and all
+  // 16 loads of a half-patch are in flight together.
+  constexpr unsigned kOOB = 0x80000000u;
+  __amdgpu_buffer_rsrc_t q_dy_rsrc, q_x_rsrc;
+  unsigned q_dy_voff = kOOB, q_x_voff = kOOB;
+  int q_HW4 = 0;
   auto locate = [&](int p) {
     int l = 0;
 #pragma unroll
@@ -368,36 +396,38 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_wgrad_kernel(const WgArgs a
     const int n = q / per_img;
     q -= n * per_img;
     const int ty = q / L.tiles_x, tx = q - ty * L.tiles_x;
-    q_y0 = ty * WG_PR; q_x0 = tx * TW; q_H = L.H; q_W = L.W;
-    const long long HW = (long long)L.H * L.W;
-    q_dy = L.dy + ((long long)n * M + m_base) * HW;
-    q_x = L.x + ((long long)n * K + c_base) * HW;
+    const int y0 = ty * WG_PR, x0 = tx * TW;
+    const int H = L.H, W = L.W;
+    const int HW = H * W;
+    q_HW4 = HW * 4;
+    const int m_left = M - m_base < WG_MT * 32 ? M - m_base : WG_MT * 32;
+    const int c_left = K - c_base < WG_CT * 32 ? K - c_base : WG_CT * 32;
+    float* dyp = const_cast<float*>(L.dy) + ((long long)n * M + m_base) * HW;
+    float* xp = const_cast<float*>(L.x) + ((long long)n * K + c_base) * HW;
+    q_dy_rsrc = uniform_rsrc(dyp, (m_left > 0 ? m_left : 0) * q_HW4);
+    q_x_rsrc = uniform_rsrc(xp, (c_left > 0 ? c_left : 0) * q_HW4);
+    {
+      const int gy = y0 + d_r, gx = x0 + d_c;
+      const bool pin = gy < H && gx < W;
+      q_dy_voff = pin ? (unsigned)((d_m0 * HW + gy * W + gx) * 4) : kOOB;
+    }
+    {
+      const int gy = y0 - 1 + x_r, gx = x0 - 1 + x_q;
+      const bool pin = x_used && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      q_x_voff = pin ? (unsigned)((x_c0 * HW + gy * W + gx) * 4) : kOOB;
+    }
   };
   auto load_dy = [&]() {
-    const int HW = q_H * q_W;
-    const int gy = q_y0 + d_r, gx = q_x0 + d_c;
-    const bool pin = gy < q_H && gx < q_W;
-    const int poff = gy * q_W + gx;
 #pragma unroll
-    for (int it = 0; it < DY_IT; ++it) {
-      const int m = d_m0 + it * 8;
-      const bool ok = pin && (m_base + m < M);
-      const float v = q_dy[ok ? m * HW + poff : 0];
-      dreg[it] = ok ? v : 0.0f;
-    }
+    for (int it = 0; it < DY_IT; ++it)
+      dreg[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+          q_dy_rsrc, q_dy_voff, __builtin_amdgcn_readfirstlane(it * 8 * q_HW4), 0));
   };
   auto load_x = [&]() {
-    const int HW = q_H * q_W;
-    const int gy = q_y0 - 1 + x_r, gx = q_x0 - 1 + x_q;
-    const bool pin = x_used && gy >= 0 && gy < q_H && gx >= 0 && gx < q_W;
-    const int poff = gy * q_W + gx;
 #pragma unroll
-    for (int it = 0; it < X_IT; ++it) {
-      const int c = x_c0 + it * 4;
-      const bool ok = pin && (c_base + c < K);
-      const float v = q_x[ok ? c * HW + poff : 0];
-      xreg[it] = ok ? v : 0.0f;
-    }
+    for (int it = 0; it < X_IT; ++it)
+      xreg[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+          q_x_rsrc, q_x_voff, __builtin_amdgcn_readfirstlane(it * 4 * q_HW4), 0));
   };
   auto store_dy = [&](float* buf) {
 #pragma unroll
@@ -481,7 +511,10 @@ __global__ void wgrad_reduce_kernel(
   *o = accumulate ? *o + s : s;
 }
 
-// db[m] (+)= sum over levels, images, pixels of dY.  One workgroup per m.
+// db[m] (+)= sum over levels, images, pixels of dY.  HBM-streaming: workgroup
+// (m, part) sums the (level, image) rows r with r % kBiasParts == part using
+// 16-byte loads; partials are combined in a fixed order (deterministic).
+constexpr int kBiasParts = 8;
 struct BiasArgs {
   const float* dy[SSAD_MAX_LEVELS];
   int N[SSAD_MAX_LEVELS];
@@ -491,15 +524,30 @@ struct BiasArgs {
 };
 
 __global__ __launch_bounds__(256) void bias_grad_kernel(
-    const BiasArgs args, float* __restrict__ db, int accumulate) {
-  const int m = blockIdx.x;
+    const BiasArgs args, double* __restrict__ partials) {
+  const int m = blockIdx.x, part = blockIdx.y;
   double acc = 0.0;
+  int row = 0;
   for (int l = 0; l < args.n_levels; ++l) {
     const int HW = args.HW[l];
-    for (int n = 0; n < args.N[l]; ++n) {
+    for (int n = 0; n < args.N[l]; ++n, ++row) {
+      if (row % kBiasParts != part) continue;
       const float* p = args.dy[l] + ((long long)n * args.M + m) * HW;
       float a = 0.0f;
-      for (int i = threadIdx.x; i < HW; i += 256) a += p[i];
+      if ((((uintptr_t)p) & 15) == 0) {
+        const int n4 = HW >> 2;
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        int i = threadIdx.x;
+        for (; i + 768 < n4; i += 1024) {
+          const float4 v0 = p4[i], v1 = p4[i + 256], v2 = p4[i + 512], v3 = p4[i + 768];
+          a += (v0.x + v0.y + v0.z + v0.w) + (v1.x + v1.y + v1.z + v1.w) +
+               (v2.x + v2.y + v2.z + v2.w) + (v3.x + v3.y + v3.z + v3.w);
+        }
+        for (; i < n4; i += 256) { const float4 v = p4[i]; a += v.x + v.y + v.z + v.w; }
+        for (int j = n4 * 4 + threadIdx.x; j < HW; j += 256) a += p[j];
+      } else {
+        for (int i = threadIdx.x; i < HW; i += 256) a += p[i];
+      }
       acc += (double)a;
     }
   }
@@ -508,17 +556,24 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float t = (float)(ws[0] + ws[1] + ws[2] + ws[3]);
-    db[m] = accumulate ? db[m] + t : t;
-  }
+  if (threadIdx.x == 0) partials[m * kBiasParts + part] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ void bias_grad_finalize_kernel(const double* __restrict__ partials, int M,
+                                          float* __restrict__ db, int accumulate) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double t = 0.0;
+#pragma unroll
+  for (int k = 0; k < kBiasParts; ++k) t += partials[m * kBiasParts + k];
+  db[m] = accumulate ? db[m] + (float)t : (float)t;
 }
 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 
-template <int WM, int WP, int PT>
+template <int WM, int WP, int PT, bool TAP_FENCE>
 int launch_fwd(const ssad_conv_level* lv, int n_levels, const float* packed,
                const float* bias, int M, int K, int flags, hipStream_t s) {
   constexpr int PR = 2 * PT * WP;
@@ -532,7 +587,7 @@ int launch_fwd(const ssad_conv_level* lv, int n_levels, const float* packed,
     L.x = lv[l].x; L.y = lv[l].y; L.aux = lv[l].aux;
     L.N = lv[l].N; L.H = lv[l].H; L.W = lv[l].W;
     if (L.N < 0 || L.H < 0 || L.W < 0) return SSAD_E_BADARG;
-    if ((long long)L.H * L.W * (K > M ? K : M) >= (1LL << 31)) return SSAD_E_BADARG;
+    if ((long long)L.H * L.W * (K > M ? K : M) >= (1LL << 29)) return SSAD_E_BADARG;
     if ((flags & SSAD_CONV_MASK_AUX) && !L.aux) return SSAD_E_BADARG;
     L.tiles_x = cdiv(L.W, TW); L.tiles_y = cdiv(L.H, PR);
     L.block_start = (int)blocks;
@@ -542,8 +597,8 @@ int launch_fwd(const ssad_conv_level* lv, int n_levels, const float* packed,
   for (int l = n_levels; l < SSAD_MAX_LEVELS; ++l) a.lv[l] = FwdLevel{};
   if (blocks == 0) return 0;
   const int gy = cdiv(cdiv(M, 32), WM);
-  hipLaunchKernelGGL((conv3x3_kernel<WM, WP, PT>), dim3((unsigned)blocks, gy), dim3(kBlock),
-                     0, s, a);
+  hipLaunchKernelGGL((conv3x3_kernel<WM, WP, PT, TAP_FENCE>), dim3((unsigned)blocks, gy),
+                     dim3(kBlock), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -572,9 +627,37 @@ int ssad_conv3x3_forward(const ssad_conv_level* levels_host, int n_levels,
   if (n_levels < 1 || n_levels > SSAD_MAX_LEVELS || Cout <= 0 || Cin <= 0 || !packed)
     return SSAD_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
+  static const int variant = [] {
+    const char* e = getenv("SSAD_CONV_VARIANT");
+    return e ? atoi(e) : -1;
+  }();
   if (Cout <= 64)
-    return launch_fwd<2, 4, 2>(levels_host, n_levels, packed, bias, Cout, Cin, flags, s);
-  return launch_fwd<8, 1, 4>(levels_host, n_levels, packed, bias, Cout, Cin, flags, s);
+    return launch_fwd<2, 4, 2, true>(levels_host, n_levels, packed, bias, Cout, Cin, flags, s);
+  // patch = 8 rows (PT = 4) or 4 rows (PT = 2): pick the one whose workgroup
+  // count quantises better onto the 256 CUs (all workgroups cost the same).
+  int use_pt2 = 0;
+  {
+    long long t4 = 0, t2 = 0;
+    for (int l = 0; l < n_levels; ++l) {
+      const long long tx = cdiv(levels_host[l].W, TW);
+      t4 += (long long)levels_host[l].N * tx * cdiv(levels_host[l].H, 8);
+      t2 += (long long)levels_host[l].N * tx * cdiv(levels_host[l].H, 4);
+    }
+    const int gy = cdiv(cdiv(Cout, 32), 8);
+    auto makespan = [&](long long tiles, double unit) {
+      const long long blocks = tiles * gy;
+      return (double)((blocks + 255) / 256) * unit;
+    };
+    use_pt2 = makespan(t2, 0.51) < makespan(t4, 1.0);
+  }
+  if (variant >= 0) use_pt2 = variant & 1;
+  const bool fence = variant >= 0 ? ((variant >> 1) & 1) : true;
+  if (use_pt2) {
+    if (fence) return launch_fwd<8, 1, 2, true>(levels_host, n_levels, packed, bias, Cout, Cin, flags, s);
+    return launch_fwd<8, 1, 2, false>(levels_host, n_levels, packed, bias, Cout, Cin, flags, s);
+  }
+  if (fence) return launch_fwd<8, 1, 4, true>(levels_host, n_levels, packed, bias, Cout, Cin, flags, s);
+  return launch_fwd<8, 1, 4, false>(levels_host, n_levels, packed, bias, Cout, Cin, flags, s);
 }
 
 static int wgrad_plan(const ssad_conv_level* lv, int n_levels, int Cout, int Cin, WgArgs* a) {
@@ -589,6 +672,7 @@ static int wgrad_plan(const ssad_conv_level* lv, int n_levels, int Cout, int Cin
     L.x = lv[l].x; L.dy = lv[l].aux;
     L.N = lv[l].N; L.H = lv[l].H; L.W = lv[l].W;
     if (L.N < 0 || L.H < 0 || L.W < 0) return SSAD_E_BADARG;
+    if ((long long)L.H * L.W * (Cin > Cout ? Cin : Cout) >= (1LL << 29)) return SSAD_E_BADARG;
     L.tiles_x = cdiv(L.W, TW); L.tiles_y = cdiv(L.H, WG_PR);
     L.patch_start = (int)patches;
     patches += (long long)L.N * L.tiles_x * L.tiles_y;
@@ -608,7 +692,8 @@ size_t ssad_conv3x3_wgrad_workspace_bytes(const ssad_conv_level* levels_host, in
                                           int Cout, int Cin) {
   WgArgs a;
   if (wgrad_plan(levels_host, n_levels, Cout, Cin, &a)) return 0;
-  return sizeof(float) * (size_t)a.splits * a.mblocks * WG_MT * a.cblocks * WG_CT * 9 * 1024;
+  return sizeof(float) * (size_t)a.splits * a.mblocks * WG_MT * a.cblocks * WG_CT * 9 * 1024 +
+         sizeof(double) * (size_t)Cout * kBiasParts;
 }
 
 int ssad_conv3x3_wgrad(const ssad_conv_level* levels_host, int n_levels, float* dW, float* db,
@@ -621,7 +706,8 @@ int ssad_conv3x3_wgrad(const ssad_conv_level* levels_host, int n_levels, float* 
     if (!levels_host[l].aux && levels_host[l].N * levels_host[l].H * levels_host[l].W > 0)
       return SSAD_E_BADARG;
   const int mtp = a.mblocks * WG_MT, ctp = a.cblocks * WG_CT;
-  const size_t need = sizeof(float) * (size_t)a.splits * mtp * ctp * 9 * 1024;
+  const size_t slab_bytes = sizeof(float) * (size_t)a.splits * mtp * ctp * 9 * 1024;
+  const size_t need = slab_bytes + sizeof(double) * (size_t)Cout * kBiasParts;
   if (!workspace || workspace_bytes < need) return SSAD_E_WORKSPACE;
   a.slabs = (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
@@ -645,7 +731,10 @@ int ssad_conv3x3_wgrad(const ssad_conv_level* levels_host, int n_levels, float* 
       b.N[l] = l < n_levels ? levels_host[l].N : 0;
       b.HW[l] = l < n_levels ? levels_host[l].H * levels_host[l].W : 0;
     }
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, b, db, accumulate);
+    double* bp = (double*)((char*)workspace + slab_bytes);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout, kBiasParts), dim3(256), 0, s, b, bp);
+    hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s,
+                       (const double*)bp, Cout, db, accumulate);
   }
   return (int)hipGetLastError();
 }
