@@ -139,7 +139,7 @@ def main():
     heads = DistillHeads(cfg, N=N, shapes=shapes, device=dev,
                          student_init=synth.head_params(np.random.default_rng(1)),
                          teacher_init=synth.head_params(np.random.default_rng(2)),
-                         process_group=pg, world_size=world)
+                         process_group=pg, world_size=world, lr=1e-4)
     heads.broadcast_params()
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     labels = [torch.from_numpy(synth.distill_inputs(rng, N, 9, 80, h, w)[2]).to(dev)

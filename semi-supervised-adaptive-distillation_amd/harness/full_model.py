@@ -99,7 +99,7 @@ class FullDistillModel(object):
     """One distillation iteration of the whole detector on one GPU."""
 
     def __init__(self, heads, student_depth=50, teacher_depth=101, device="cuda",
-                 process_group=None, world_size=1, lr=1e-3, momentum=0.9, weight_decay=1e-4):
+                 process_group=None, world_size=1, lr=1e-5, momentum=0.9, weight_decay=1e-4):
         self.heads = heads
         self.pg, self.world = process_group, world_size
         g = torch.Generator().manual_seed(7)
