@@ -19,9 +19,13 @@
 // the exact sum than the reference's 128-lane fp32 order.
 //
 // Work decomposition: logits are N x (A*C) x H x W.  For a fixed (image n,
-// anchor a) the C*H*W floats are contiguous ("slab") and share one H*W
-// label plane, so a work item is (slab, chunk-of-slab) and the label of flat
-// position i inside the slab is labels[slab*HW + i % HW].
+// anchor a) the C class planes of H*W floats are contiguous ("slab") and share
+// ONE H*W label plane.  A work item is (slab, block of positions): each thread
+// owns 4 consecutive positions (one 16-byte load per plane), reads their labels
+// once into registers and walks the C class planes, so label bytes leave HBM
+// once per (image, anchor, position) -- the algorithmic minimum -- and no
+// per-element index arithmetic remains in the loop.  For small maps the 256
+// threads split into position lanes x class lanes.
 
 #include <hip/hip_runtime.h>
 #include <float.h>
@@ -34,7 +38,6 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxBlocks = 8192;   // partial slots in the workspace
-constexpr int kVecPerItem = 8;     // float4 per thread per work item
 
 struct LevelArgs {
   const float* x;
@@ -44,11 +47,15 @@ struct LevelArgs {
   int hw;            // H*W
   int slab;          // C*H*W floats per (n, a)
   int n_slabs;       // N*A
-  int chunks;        // work items per slab
+  int chunks;        // position blocks per slab
   int items;         // n_slabs * chunks
   int block_start;   // first blockIdx.x of this level
   int blocks;        // blocks assigned to this level
   int vec4;          // 1: HW % 4 == 0 and 16-byte aligned pointers
+  int pl_shift;      // log2(position lanes); class lanes = 256 >> pl_shift
+  int classes;       // C
+  int cgroups;       // class groups per position block (work-item granularity)
+  int cper;          // classes per group
 };
 
 struct LaunchArgs {
@@ -177,6 +184,61 @@ __device__ __forceinline__ int find_level(const LaunchArgs& a, int bid) {
 
 // ---- forward ---------------------------------------------------------------
 
+// Shared traversal: calls f(x, q, keep) for every element of the work items
+// of this workgroup; BWD stores f's result to L.out, otherwise sums it.
+template <bool BWD, class F>
+__device__ __forceinline__ float traverse(const LevelArgs& L, int lb, int ignored, F f) {
+  float acc = 0.0f;
+  const int pl = 1 << L.pl_shift;
+  const int cl = kThreads >> L.pl_shift;
+  const int pi = threadIdx.x & (pl - 1);
+  const int ci = threadIdx.x >> L.pl_shift;
+  const int hw = L.hw;
+  for (int item = lb; item < L.items; item += L.blocks) {
+    const int sc = item / L.cgroups;
+    const int cg = item - sc * L.cgroups;
+    const int slab = sc / L.chunks;
+    const int chunk = sc - slab * L.chunks;
+    const int c_begin = cg * L.cper + ci;
+    const int c_end = (cg + 1) * L.cper < L.classes ? (cg + 1) * L.cper : L.classes;
+    const float* xs = L.x + (size_t)slab * L.slab;
+    const float* qs = L.q + (size_t)slab * L.slab;
+    float* ds = BWD ? L.out + (size_t)slab * L.slab : nullptr;
+    const int32_t* gs = L.g + (size_t)slab * hw;
+    if (L.vec4) {
+      const int pos = (chunk * pl + pi) * 4;
+      if (pos < hw) {
+        const int4 gv = *reinterpret_cast<const int4*>(gs + pos);
+        const bool k0 = gv.x != ignored, k1 = gv.y != ignored, k2 = gv.z != ignored,
+                   k3 = gv.w != ignored;
+#pragma unroll 4
+        for (int c = c_begin; c < c_end; c += cl) {
+          const int o = c * hw + pos;
+          const float4 xv = *reinterpret_cast<const float4*>(xs + o);
+          const float4 qv = *reinterpret_cast<const float4*>(qs + o);
+          float4 r;
+          r.x = f(xv.x, qv.x, k0); r.y = f(xv.y, qv.y, k1);
+          r.z = f(xv.z, qv.z, k2); r.w = f(xv.w, qv.w, k3);
+          if constexpr (BWD) *reinterpret_cast<float4*>(ds + o) = r;
+          else acc += (r.x + r.y) + (r.z + r.w);
+        }
+      }
+    } else {
+      const int pos = chunk * pl + pi;
+      if (pos < hw) {
+        const bool k0 = gs[pos] != ignored;
+#pragma unroll 4
+        for (int c = c_begin; c < c_end; c += cl) {
+          const int o = c * hw + pos;
+          const float r = f(xs[o], qs[o], k0);
+          if constexpr (BWD) ds[o] = r; else acc += r;
+        }
+      }
+    }
+  }
+  return acc;
+}
+
 template <bool FAST, int GAMMA_MODE>
 __global__ __launch_bounds__(kThreads) void distill_fwd_kernel(
     const LaunchArgs args, const float* __restrict__ normalizer,
@@ -187,43 +249,9 @@ __global__ __launch_bounds__(kThreads) void distill_fwd_kernel(
   const float w_pos = args.alpha / np;
   const float w_neg = (1.0f - args.alpha) / np;
   const float gamma = args.gamma, beta = args.beta;
-  const int ignored = args.ignored;
-  float acc = 0.0f;
-
-  for (int item = lb; item < L.items; item += L.blocks) {
-    const int slab = item / L.chunks;
-    const int chunk = item - slab * L.chunks;
-    const float* xs = L.x + (size_t)slab * L.slab;
-    const float* qs = L.q + (size_t)slab * L.slab;
-    const int32_t* gs = L.g + (size_t)slab * L.hw;
-    if (L.vec4) {
-      const int n4 = L.slab >> 2;
-      const int base = chunk * (kThreads * kVecPerItem) + threadIdx.x;
-#pragma unroll 4
-      for (int u = 0; u < kVecPerItem; ++u) {
-        const int i4 = base + u * kThreads;
-        if (i4 < n4) {
-          const float4 xv = reinterpret_cast<const float4*>(xs)[i4];
-          const float4 qv = reinterpret_cast<const float4*>(qs)[i4];
-          const int pos = (i4 * 4) % L.hw;
-          const int4 gv = *reinterpret_cast<const int4*>(gs + pos);
-          acc += loss_elem<FAST, GAMMA_MODE>(xv.x, qv.x, gv.x != ignored, gamma, beta, w_pos, w_neg);
-          acc += loss_elem<FAST, GAMMA_MODE>(xv.y, qv.y, gv.y != ignored, gamma, beta, w_pos, w_neg);
-          acc += loss_elem<FAST, GAMMA_MODE>(xv.z, qv.z, gv.z != ignored, gamma, beta, w_pos, w_neg);
-          acc += loss_elem<FAST, GAMMA_MODE>(xv.w, qv.w, gv.w != ignored, gamma, beta, w_pos, w_neg);
-        }
-      }
-    } else {
-      const int base = chunk * (kThreads * kVecPerItem * 4) + threadIdx.x;
-      for (int u = 0; u < kVecPerItem * 4; ++u) {
-        const int i = base + u * kThreads;
-        if (i < L.slab) {
-          const int pos = i % L.hw;
-          acc += loss_elem<FAST, GAMMA_MODE>(xs[i], qs[i], gs[pos] != ignored, gamma, beta, w_pos, w_neg);
-        }
-      }
-    }
-  }
+  const float acc = traverse<false>(L, lb, args.ignored, [&](float x, float q, bool keep) {
+    return loss_elem<FAST, GAMMA_MODE>(x, q, keep, gamma, beta, w_pos, w_neg);
+  });
   const double t = block_sum((double)acc);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
@@ -251,45 +279,9 @@ __global__ __launch_bounds__(kThreads) void distill_bwd_kernel(
   const float np = fmaxf(normalizer[0], 1.0f);
   const float mult = dloss[(size_t)level * dloss_stride] * args.scale / np;
   const float gamma = args.gamma, alpha = args.alpha, beta = args.beta;
-  const int ignored = args.ignored;
-
-  for (int item = lb; item < L.items; item += L.blocks) {
-    const int slab = item / L.chunks;
-    const int chunk = item - slab * L.chunks;
-    const float* xs = L.x + (size_t)slab * L.slab;
-    const float* qs = L.q + (size_t)slab * L.slab;
-    float* ds = L.out + (size_t)slab * L.slab;
-    const int32_t* gs = L.g + (size_t)slab * L.hw;
-    if (L.vec4) {
-      const int n4 = L.slab >> 2;
-      const int base = chunk * (kThreads * kVecPerItem) + threadIdx.x;
-#pragma unroll 4
-      for (int u = 0; u < kVecPerItem; ++u) {
-        const int i4 = base + u * kThreads;
-        if (i4 < n4) {
-          const float4 xv = reinterpret_cast<const float4*>(xs)[i4];
-          const float4 qv = reinterpret_cast<const float4*>(qs)[i4];
-          const int pos = (i4 * 4) % L.hw;
-          const int4 gv = *reinterpret_cast<const int4*>(gs + pos);
-          float4 o;
-          o.x = grad_elem<FAST, GAMMA_MODE>(xv.x, qv.x, gv.x != ignored, gamma, alpha, beta, mult);
-          o.y = grad_elem<FAST, GAMMA_MODE>(xv.y, qv.y, gv.y != ignored, gamma, alpha, beta, mult);
-          o.z = grad_elem<FAST, GAMMA_MODE>(xv.z, qv.z, gv.z != ignored, gamma, alpha, beta, mult);
-          o.w = grad_elem<FAST, GAMMA_MODE>(xv.w, qv.w, gv.w != ignored, gamma, alpha, beta, mult);
-          reinterpret_cast<float4*>(ds)[i4] = o;
-        }
-      }
-    } else {
-      const int base = chunk * (kThreads * kVecPerItem * 4) + threadIdx.x;
-      for (int u = 0; u < kVecPerItem * 4; ++u) {
-        const int i = base + u * kThreads;
-        if (i < L.slab) {
-          const int pos = i % L.hw;
-          ds[i] = grad_elem<FAST, GAMMA_MODE>(xs[i], qs[i], gs[pos] != ignored, gamma, alpha, beta, mult);
-        }
-      }
-    }
-  }
+  traverse<true>(L, lb, args.ignored, [&](float x, float q, bool keep) {
+    return grad_elem<FAST, GAMMA_MODE>(x, q, keep, gamma, alpha, beta, mult);
+  });
 }
 
 // ---- PowSum ----------------------------------------------------------------
@@ -382,15 +374,27 @@ int build_args(const ssad_distill_level* lv, int n_levels,
     LevelArgs& L = a.lv[l];
     L.x = s.logits; L.q = s.teacher_prob; L.g = s.labels; L.out = s.out;
     L.hw = (int)hw; L.slab = (int)slab; L.n_slabs = (int)n_slabs;
-    const long long per_item = (long long)kThreads * kVecPerItem * 4;
-    const long long chunks = slab > 0 ? (slab + per_item - 1) / per_item : 0;
-    const long long items = chunks * n_slabs;
-    if (items >= (1LL << 31)) return SSAD_E_BADARG;
-    L.chunks = (int)(chunks > 0 ? chunks : 1);
-    L.items = (int)items;
     const uintptr_t al = (uintptr_t)s.logits | (uintptr_t)s.teacher_prob |
                          (uintptr_t)s.labels | (uintptr_t)s.out;
     L.vec4 = (hw % 4 == 0) && ((al & 15) == 0);
+    L.classes = P->num_classes;
+    // position lanes: smallest power of two covering the plane, at most 256
+    const long long units = L.vec4 ? hw / 4 : hw;      // 16-byte (or scalar) columns
+    int shift = 0;
+    while ((1LL << shift) < units && shift < 8) ++shift;
+    L.pl_shift = shift;
+    const long long chunks = units > 0 ? (units + (1LL << shift) - 1) >> shift : 0;
+    // class groups: >= 4 iterations per thread, about C/4 classes per item
+    const int cl = kThreads >> shift;
+    int cper = (P->num_classes + 3) / 4;
+    if (cper < 4 * cl) cper = 4 * cl;
+    cper = (cper + cl - 1) / cl * cl;
+    L.cper = cper;
+    L.cgroups = (P->num_classes + cper - 1) / cper;
+    const long long items = chunks * n_slabs * L.cgroups;
+    if (items >= (1LL << 31)) return SSAD_E_BADARG;
+    L.chunks = (int)(chunks > 0 ? chunks : 1);
+    L.items = (int)items;
     total_items += items;
   }
   // distribute at most kMaxBlocks blocks proportionally to the work
