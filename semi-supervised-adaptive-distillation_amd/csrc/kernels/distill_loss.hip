@@ -94,7 +94,7 @@ struct Pieces {
   float edl;      // exp(-DL)
 };
 
-template <bool FAST, bool NEED_P>
+template <bool FAST, bool NEED_P, bool BETA0>
 __device__ __forceinline__ Pieces front(float x, float q, float beta) {
   Pieces r;
   const float ax = fabsf(x);
@@ -105,10 +105,10 @@ __device__ __forceinline__ Pieces front(float x, float q, float beta) {
   // binary entropy of the teacher: NaN outside (0,1), incl. 0*log(0), and it
   // propagates even when beta == 0 (.cu:58-59).
   float ent;
-  if (beta != 0.0f) {
+  if constexpr (!BETA0) {
     ent = beta * (q * log_f<false>(q) + (1.0f - q) * log_f<false>(1.0f - q));
   } else {
-    ent = (q > 0.0f && q < 1.0f) ? 0.0f : __builtin_nanf("");
+    ent = (q > 0.0f && q < 1.0f) ? 0.0f : __builtin_nanf("");   // a select, no branch
   }
   // DL = -x*(q - [x>=0]) + softplus(-|x|) + ent
   const float dl = (xpos - x * q) + sp + ent;
@@ -126,10 +126,10 @@ __device__ __forceinline__ Pieces front(float x, float q, float beta) {
   return r;
 }
 
-template <bool FAST, int GAMMA_MODE>
+template <bool FAST, int GAMMA_MODE, bool BETA0>
 __device__ __forceinline__ float loss_elem(
     float x, float q, bool keep, float gamma, float beta, float w_pos, float w_neg) {
-  const Pieces f = front<FAST, false>(x, q, beta);
+  const Pieces f = front<FAST, false, BETA0>(x, q, beta);
   float pg, pgm1;
   pow_pair<GAMMA_MODE>(f.at, gamma, pg, pgm1);
   const float ce = q * f.logp * w_pos + (1.0f - q) * f.log1mp * w_neg;
@@ -137,10 +137,10 @@ __device__ __forceinline__ float loss_elem(
   return v * (keep ? 1.0f : 0.0f);   // multiply: NaN survives an ignored label
 }
 
-template <bool FAST, int GAMMA_MODE>
+template <bool FAST, int GAMMA_MODE, bool BETA0>
 __device__ __forceinline__ float grad_elem(
     float x, float q, bool keep, float gamma, float alpha, float beta, float mult) {
-  const Pieces f = front<FAST, true>(x, q, beta);
+  const Pieces f = front<FAST, true, BETA0>(x, q, beta);
   float pg, pgm1;
   pow_pair<GAMMA_MODE>(f.at, gamma, pg, pgm1);
   const float S = alpha * q * f.logp + (1.0f - alpha) * (1.0f - q) * f.log1mp;
@@ -201,26 +201,40 @@ __device__ __forceinline__ float traverse(const LevelArgs& L, int lb, int ignore
     const int chunk = sc - slab * L.chunks;
     const int c_begin = cg * L.cper + ci;
     const int c_end = (cg + 1) * L.cper < L.classes ? (cg + 1) * L.cper : L.classes;
-    const float* xs = L.x + (size_t)slab * L.slab;
-    const float* qs = L.q + (size_t)slab * L.slab;
-    float* ds = BWD ? L.out + (size_t)slab * L.slab : nullptr;
-    const int32_t* gs = L.g + (size_t)slab * hw;
+    const float* __restrict__ xs = L.x + (size_t)slab * L.slab;
+    const float* __restrict__ qs = L.q + (size_t)slab * L.slab;
+    float* __restrict__ ds = BWD ? L.out + (size_t)slab * L.slab : nullptr;
+    const int32_t* __restrict__ gs = L.g + (size_t)slab * hw;
     if (L.vec4) {
       const int pos = (chunk * pl + pi) * 4;
       if (pos < hw) {
         const int4 gv = *reinterpret_cast<const int4*>(gs + pos);
         const bool k0 = gv.x != ignored, k1 = gv.y != ignored, k2 = gv.z != ignored,
                    k3 = gv.w != ignored;
-#pragma unroll 4
-        for (int c = c_begin; c < c_end; c += cl) {
-          const int o = c * hw + pos;
-          const float4 xv = *reinterpret_cast<const float4*>(xs + o);
-          const float4 qv = *reinterpret_cast<const float4*>(qs + o);
+        auto one = [&](int o, const float4& xv, const float4& qv) {
           float4 r;
           r.x = f(xv.x, qv.x, k0); r.y = f(xv.y, qv.y, k1);
           r.z = f(xv.z, qv.z, k2); r.w = f(xv.w, qv.w, k3);
           if constexpr (BWD) *reinterpret_cast<float4*>(ds + o) = r;
           else acc += (r.x + r.y) + (r.z + r.w);
+        };
+        int c = c_begin;
+        // four class planes per step: all eight 16-byte loads are issued
+        // before the first use, so each wave keeps 8 KiB in flight
+        for (; c + 3 * cl < c_end; c += 4 * cl) {
+          float4 xv[4], qv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int o = (c + u * cl) * hw + pos;
+            xv[u] = *reinterpret_cast<const float4*>(xs + o);
+            qv[u] = *reinterpret_cast<const float4*>(qs + o);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) one((c + u * cl) * hw + pos, xv[u], qv[u]);
+        }
+        for (; c < c_end; c += cl) {
+          const int o = c * hw + pos;
+          one(o, *reinterpret_cast<const float4*>(xs + o), *reinterpret_cast<const float4*>(qs + o));
         }
       }
     } else {
@@ -239,7 +253,7 @@ __device__ __forceinline__ float traverse(const LevelArgs& L, int lb, int ignore
   return acc;
 }
 
-template <bool FAST, int GAMMA_MODE>
+template <bool FAST, int GAMMA_MODE, bool BETA0>
 __global__ __launch_bounds__(kThreads) void distill_fwd_kernel(
     const LaunchArgs args, const float* __restrict__ normalizer,
     double* __restrict__ partials) {
@@ -250,7 +264,7 @@ __global__ __launch_bounds__(kThreads) void distill_fwd_kernel(
   const float w_neg = (1.0f - args.alpha) / np;
   const float gamma = args.gamma, beta = args.beta;
   const float acc = traverse<false>(L, lb, args.ignored, [&](float x, float q, bool keep) {
-    return loss_elem<FAST, GAMMA_MODE>(x, q, keep, gamma, beta, w_pos, w_neg);
+    return loss_elem<FAST, GAMMA_MODE, BETA0>(x, q, keep, gamma, beta, w_pos, w_neg);
   });
   const double t = block_sum((double)acc);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void distill_finalize_kernel(
 
 // ---- backward --------------------------------------------------------------
 
-template <bool FAST, int GAMMA_MODE>
+template <bool FAST, int GAMMA_MODE, bool BETA0>
 __global__ __launch_bounds__(kThreads) void distill_bwd_kernel(
     const LaunchArgs args, const float* __restrict__ normalizer,
     const float* __restrict__ dloss, int dloss_stride) {
@@ -280,7 +294,7 @@ __global__ __launch_bounds__(kThreads) void distill_bwd_kernel(
   const float mult = dloss[(size_t)level * dloss_stride] * args.scale / np;
   const float gamma = args.gamma, alpha = args.alpha, beta = args.beta;
   traverse<true>(L, lb, args.ignored, [&](float x, float q, bool keep) {
-    return grad_elem<FAST, GAMMA_MODE>(x, q, keep, gamma, alpha, beta, mult);
+    return grad_elem<FAST, GAMMA_MODE, BETA0>(x, q, keep, gamma, alpha, beta, mult);
   });
 }
 
@@ -322,11 +336,19 @@ __global__ __launch_bounds__(kThreads) void pow_sum_kernel(
   const bool aligned = ((uintptr_t)x & 15) == 0;
   const long long n4 = aligned ? (n >> 2) : 0;
   int folds = 0;
-  for (long long i4 = (long long)lb * kThreads + threadIdx.x; i4 < n4; i4 += (long long)nb * kThreads) {
-    const float4 v = reinterpret_cast<const float4*>(x)[i4];
-    acc += pow_elem<FAST>(v.x, p) + pow_elem<FAST>(v.y, p) + pow_elem<FAST>(v.z, p) + pow_elem<FAST>(v.w, p);
-    if (++folds == 64) { dacc += (double)acc; acc = 0.0f; folds = 0; }
+  const long long step = (long long)nb * kThreads;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  long long i4 = (long long)lb * kThreads + threadIdx.x;
+  auto add4 = [&](const float4& v) {
+    acc += (pow_elem<FAST>(v.x, p) + pow_elem<FAST>(v.y, p)) +
+           (pow_elem<FAST>(v.z, p) + pow_elem<FAST>(v.w, p));
+  };
+  for (; i4 + 3 * step < n4; i4 += 4 * step) {      // four 16-byte loads in flight
+    const float4 v0 = x4[i4], v1 = x4[i4 + step], v2 = x4[i4 + 2 * step], v3 = x4[i4 + 3 * step];
+    add4(v0); add4(v1); add4(v2); add4(v3);
+    if (++folds == 16) { dacc += (double)acc; acc = 0.0f; folds = 0; }
   }
+  for (; i4 < n4; i4 += step) add4(x4[i4]);
   for (long long i = n4 * 4 + (long long)lb * kThreads + threadIdx.x; i < n; i += (long long)nb * kThreads)
     acc += pow_elem<FAST>(x[i], p);
   dacc += (double)acc;
@@ -386,7 +408,8 @@ int build_args(const ssad_distill_level* lv, int n_levels,
     const long long chunks = units > 0 ? (units + (1LL << shift) - 1) >> shift : 0;
     // class groups: >= 4 iterations per thread, about C/4 classes per item
     const int cl = kThreads >> shift;
-    int cper = (P->num_classes + 3) / 4;
+    static const int cg_want = [] { const char* e = getenv("SSAD_LOSS_CGROUPS"); return e ? atoi(e) : 4; }();
+    int cper = (P->num_classes + cg_want - 1) / cg_want;
     if (cper < 4 * cl) cper = 4 * cl;
     cper = (cper + cl - 1) / cl * cl;
     L.cper = cper;
@@ -398,12 +421,13 @@ int build_args(const ssad_distill_level* lv, int n_levels,
     total_items += items;
   }
   // distribute at most kMaxBlocks blocks proportionally to the work
+  static const int max_blocks = [] { const char* e = getenv("SSAD_LOSS_MAXBLOCKS"); return e ? atoi(e) : kMaxBlocks; }();
   int start = 0;
   for (int l = 0; l < n_levels; ++l) {
     LevelArgs& L = a.lv[l];
     long long b = L.items;
-    if (total_items > kMaxBlocks - n_levels) {
-      b = (long long)L.items * (kMaxBlocks - n_levels) / total_items;
+    if (total_items > max_blocks - n_levels) {
+      b = (long long)L.items * (max_blocks - n_levels) / total_items;
     }
     if (b < 1) b = 1;   // every level owns >= 1 block so its output is written
     if (b > L.items && L.items > 0) b = L.items;
@@ -415,17 +439,23 @@ int build_args(const ssad_distill_level* lv, int n_levels,
   return 0;
 }
 
-#define LAUNCH_BY_MODE(KERNEL, fast, gm, ...)                                   \
-  do {                                                                          \
-    if (fast) {                                                                 \
-      if (gm == 2) hipLaunchKernelGGL((KERNEL<true, 2>), __VA_ARGS__);          \
-      else if (gm == 1) hipLaunchKernelGGL((KERNEL<true, 1>), __VA_ARGS__);     \
-      else hipLaunchKernelGGL((KERNEL<true, 0>), __VA_ARGS__);                  \
-    } else {                                                                    \
-      if (gm == 2) hipLaunchKernelGGL((KERNEL<false, 2>), __VA_ARGS__);         \
-      else if (gm == 1) hipLaunchKernelGGL((KERNEL<false, 1>), __VA_ARGS__);    \
-      else hipLaunchKernelGGL((KERNEL<false, 0>), __VA_ARGS__);                 \
-    }                                                                           \
+#define LAUNCH_BY_MODE3(KERNEL, FAST_, b0, gm, ...)                                   \
+  do {                                                                                \
+    if (b0) {                                                                         \
+      if (gm == 2) hipLaunchKernelGGL((KERNEL<FAST_, 2, true>), __VA_ARGS__);         \
+      else if (gm == 1) hipLaunchKernelGGL((KERNEL<FAST_, 1, true>), __VA_ARGS__);    \
+      else hipLaunchKernelGGL((KERNEL<FAST_, 0, true>), __VA_ARGS__);                 \
+    } else {                                                                          \
+      if (gm == 2) hipLaunchKernelGGL((KERNEL<FAST_, 2, false>), __VA_ARGS__);        \
+      else if (gm == 1) hipLaunchKernelGGL((KERNEL<FAST_, 1, false>), __VA_ARGS__);   \
+      else hipLaunchKernelGGL((KERNEL<FAST_, 0, false>), __VA_ARGS__);                \
+    }                                                                                 \
+  } while (0)
+
+#define LAUNCH_BY_MODE(KERNEL, fast, b0, gm, ...)                                     \
+  do {                                                                                \
+    if (fast) LAUNCH_BY_MODE3(KERNEL, true, b0, gm, __VA_ARGS__);                     \
+    else LAUNCH_BY_MODE3(KERNEL, false, b0, gm, __VA_ARGS__);                         \
   } while (0)
 
 }  // namespace
@@ -450,7 +480,7 @@ int ssad_distill_loss_forward(
   double* partials = (double*)workspace;
   const bool fast = !accurate_math();
   const int gm = gamma_mode(a.gamma);
-  LAUNCH_BY_MODE(distill_fwd_kernel, fast, gm, dim3(blocks), dim3(kThreads), 0, s,
+  LAUNCH_BY_MODE(distill_fwd_kernel, fast, a.beta == 0.0f, gm, dim3(blocks), dim3(kThreads), 0, s,
                  a, normalizer, partials);
   hipLaunchKernelGGL(distill_finalize_kernel, dim3(n_levels), dim3(kThreads), 0, s,
                      a, (const double*)partials);
@@ -471,7 +501,7 @@ int ssad_distill_loss_backward(
   hipStream_t s = (hipStream_t)stream;
   const bool fast = !accurate_math();
   const int gm = gamma_mode(a.gamma);
-  LAUNCH_BY_MODE(distill_bwd_kernel, fast, gm, dim3(blocks), dim3(kThreads), 0, s,
+  LAUNCH_BY_MODE(distill_bwd_kernel, fast, a.beta == 0.0f, gm, dim3(blocks), dim3(kThreads), 0, s,
                  a, normalizer, dloss, dloss_stride);
   return (int)hipGetLastError();
 }
