@@ -184,6 +184,29 @@ __device__ __forceinline__ int find_level(const LaunchArgs& a, int bid) {
 
 // ---- forward ---------------------------------------------------------------
 
+// Streamed-once data: non-temporal 16-byte accesses (env SSAD_LOSS_NT=0 turns
+// them into plain accesses for A/B runs).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef SSAD_LOSS_NT
+#define SSAD_LOSS_NT 1
+#endif
+__device__ __forceinline__ float4 ld4(const float* p) {
+#if SSAD_LOSS_NT
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void st4(float* p, const float4& r) {
+#if SSAD_LOSS_NT
+  f32x4 v; v.x = r.x; v.y = r.y; v.z = r.z; v.w = r.w;
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = r;
+#endif
+}
+
 // Shared traversal: calls f(x, q, keep) for every element of the work items
 // of this workgroup; BWD stores f's result to L.out, otherwise sums it.
 template <bool BWD, class F>
@@ -215,7 +238,7 @@ __device__ __forceinline__ float traverse(const LevelArgs& L, int lb, int ignore
           float4 r;
           r.x = f(xv.x, qv.x, k0); r.y = f(xv.y, qv.y, k1);
           r.z = f(xv.z, qv.z, k2); r.w = f(xv.w, qv.w, k3);
-          if constexpr (BWD) *reinterpret_cast<float4*>(ds + o) = r;
+          if constexpr (BWD) st4(ds + o, r);
           else acc += (r.x + r.y) + (r.z + r.w);
         };
         int c = c_begin;
@@ -226,15 +249,15 @@ __device__ __forceinline__ float traverse(const LevelArgs& L, int lb, int ignore
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int o = (c + u * cl) * hw + pos;
-            xv[u] = *reinterpret_cast<const float4*>(xs + o);
-            qv[u] = *reinterpret_cast<const float4*>(qs + o);
+            xv[u] = ld4(xs + o);
+            qv[u] = ld4(qs + o);
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) one((c + u * cl) * hw + pos, xv[u], qv[u]);
         }
         for (; c < c_end; c += cl) {
           const int o = c * hw + pos;
-          one(o, *reinterpret_cast<const float4*>(xs + o), *reinterpret_cast<const float4*>(qs + o));
+          one(o, ld4(xs + o), ld4(qs + o));
         }
       }
     } else {
@@ -337,18 +360,18 @@ __global__ __launch_bounds__(kThreads) void pow_sum_kernel(
   const long long n4 = aligned ? (n >> 2) : 0;
   int folds = 0;
   const long long step = (long long)nb * kThreads;
-  const float4* x4 = reinterpret_cast<const float4*>(x);
   long long i4 = (long long)lb * kThreads + threadIdx.x;
   auto add4 = [&](const float4& v) {
     acc += (pow_elem<FAST>(v.x, p) + pow_elem<FAST>(v.y, p)) +
            (pow_elem<FAST>(v.z, p) + pow_elem<FAST>(v.w, p));
   };
   for (; i4 + 3 * step < n4; i4 += 4 * step) {      // four 16-byte loads in flight
-    const float4 v0 = x4[i4], v1 = x4[i4 + step], v2 = x4[i4 + 2 * step], v3 = x4[i4 + 3 * step];
+    const float4 v0 = ld4(x + 4 * i4), v1 = ld4(x + 4 * (i4 + step)),
+                 v2 = ld4(x + 4 * (i4 + 2 * step)), v3 = ld4(x + 4 * (i4 + 3 * step));
     add4(v0); add4(v1); add4(v2); add4(v3);
     if (++folds == 16) { dacc += (double)acc; acc = 0.0f; folds = 0; }
   }
-  for (; i4 < n4; i4 += step) add4(x4[i4]);
+  for (; i4 < n4; i4 += step) add4(ld4(x + 4 * i4));
   for (long long i = n4 * 4 + (long long)lb * kThreads + threadIdx.x; i < n; i += (long long)nb * kThreads)
     acc += pow_elem<FAST>(x[i], p);
   dacc += (double)acc;
