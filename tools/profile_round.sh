@@ -1,0 +1,34 @@
+#!/bin/bash
+# Collect the round's rocprofv3 evidence on the GPU box; only small summaries
+# land in gpurun_out/ (the .db captures stay in /tmp).
+#   tools/profile_round.sh r01
+set -u
+TAG=${1:-rXX}
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/profiles_$TAG
+mkdir -p $O
+cd $R
+run() { # name, title, rocprof args..., -- cmd
+  local name=$1; shift; local title=$1; shift
+  rm -rf /tmp/prof_$name
+  rocprofv3 "$@" > $O/$name.log 2>&1
+  local db=$(ls /tmp/prof_$name/*.db 2>/dev/null | head -1)
+  if [ -n "$db" ]; then
+    python tools/rocpd_summary.py $db $O/$name.md --json $O/$name.json --title "$title" > /dev/null
+  else
+    echo "no db for $name" >> $O/$name.log
+  fi
+  tail -2 $O/$name.log | cut -c1-300 > $O/$name.tail; rm -f $O/$name.log
+}
+run bench_full_trace "rocprofv3 --kernel-trace --stats: python bench.py --steps 5 --warmup 2 (default = full workload)" \
+    --kernel-trace --stats -d /tmp/prof_bench_full_trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline
+run bench_heads_trace "rocprofv3 --kernel-trace --stats: python bench.py --workload heads --steps 5 --warmup 2" \
+    --kernel-trace --stats -d /tmp/prof_bench_heads_trace -o t -- python bench.py --workload heads --steps 5 --warmup 2 --no-cpu-baseline
+run pmc_fetch "PMC pass 1 (FETCH_SIZE, KB): python tools/kbench.py" \
+    --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_pmc_fetch -o t -- python tools/kbench.py
+run pmc_write "PMC pass 2 (WRITE_SIZE, KB): python tools/kbench.py" \
+    --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_pmc_write -o t -- python tools/kbench.py
+run pmc_mfma "PMC pass 3 (MFMA / LDS): python tools/kbench.py --what conv" \
+    --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES -d /tmp/prof_pmc_mfma -o t -- python tools/kbench.py --what conv
+ls -la $O
