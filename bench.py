@@ -204,6 +204,19 @@ def main():
 
     if rank == 0:
         ks = timer.summary()
+        traffic, traffic_note = None, None
+        try:   # HBM bytes per launch from the committed PMC passes (profiles/README.md)
+            import glob
+            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]))
+            ks_ = [v for k, v in pm["kernels"].items() if k.startswith("conv3x3_kernel<8, 1")]
+            if ks_:
+                traffic = int(sum((v.get("FETCH_SIZE_KB_raw", 0) + v.get("WRITE_SIZE_KB", 0)) * 1024
+                                  for v in ks_) / len(ks_))
+                traffic_note = ("FETCH_SIZE+WRITE_SIZE per dispatch from separate rocprofv3 --pmc "
+                                "passes (profiles/); FETCH uncalibrated for this kernel's mixed "
+                                "4-B/16-B loads (true value between 1x and 2x)")
+        except Exception:
+            pass
         out = {
             "metric": METRIC, "value": round(world * N * args.steps / dt, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -218,7 +231,7 @@ def main():
                 "bound": "mfma", "achieved": round(ks["tflops"], 2) if ks else None,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ks["tflops"] / PEAK_F32_MFMA_TFLOPS, 4) if ks else None,
-                "traffic": None,
+                "traffic": traffic, "traffic_note": traffic_note,
                 "launches_timed": ks["launches"] if ks else 0,
                 "avg_launch_ms": round(ks["avg_ms"], 4) if ks else None,
                 "flops_per_launch": ks["flops_per_launch"] if ks else None},
