@@ -121,7 +121,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("SSAD_DP_FORCE") == "1":
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
@@ -239,7 +239,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(out))
-    if world > 1:
+    if pg is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -27,20 +27,22 @@ class BucketedAllReduce(object):
 
     @property
     def active(self):
-        return self.pg is not None and self.world_size > 1
+        # SSAD_DP_FORCE=1 runs the collectives even on a 1-rank group (used to
+        # exercise the RCCL path on a single-GPU box)
+        import os
+        return self.pg is not None and (self.world_size > 1 or os.environ.get("SSAD_DP_FORCE") == "1")
 
     def issue(self, bucket):
         """Start the sum all-reduce of one flat gradient bucket (in place)."""
         if not self.active:
             return
         import torch.distributed as dist
-        if bucket.is_cuda:
-            # the collective runs on RCCL's stream; order it after the kernels
-            # that produced the bucket on the current stream
-            work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        else:
-            work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self._pending.append(work)
+        # On GPU the collective runs on RCCL's own stream; torch orders it after
+        # the kernels already enqueued on the current stream (the HIP kernels
+        # of this package launch on torch's current stream) and work.wait()
+        # orders later kernels after it.
+        self._pending.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg,
+                                             async_op=True))
 
     def wait(self):
         for w in self._pending:

@@ -6,6 +6,8 @@ per-channel affine = AffineChannel) and FPN.py:116-250 for RetinaNet
 (laterals on res3..res5, 3x3 output convs, P6 = conv3x3/2 on res5, P7 =
 conv3x3/2 on relu(P6); levels P3..P7 at 256 channels).  Random weights.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -113,7 +115,8 @@ class FullDistillModel(object):
         self.trainable = [p for p in self.student.parameters() if p.requires_grad]
         self.opt = torch.optim.SGD(self.trainable, lr=lr, momentum=momentum,
                                    weight_decay=weight_decay)
-        if self.pg is not None and world_size > 1:
+        self.dist_on = self.pg is not None and (world_size > 1 or os.environ.get("SSAD_DP_FORCE") == "1")
+        if self.dist_on:
             import torch.distributed as dist
             for p in self.student.parameters():
                 dist.broadcast(p.data, src=0, group=self.pg)
@@ -138,12 +141,12 @@ class FullDistillModel(object):
         d_fpn = h.backward(d_bbox_pred)
         # gradient w.r.t. each FPN level = cls-subnet part + bbox-subnet part
         grads = [a + b for a, b in zip(d_fpn["cls"], d_fpn["bbox"])]
-        if self.pg is not None and self.world > 1:
+        if self.dist_on:
             self.flat_grad.zero_()
         else:
             self.opt.zero_grad(set_to_none=True)
         torch.autograd.backward(s_fpn, grads)
-        if self.pg is not None and self.world > 1:
+        if self.dist_on:
             import torch.distributed as dist
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
         h.sgd_step()
