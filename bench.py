@@ -99,9 +99,10 @@ def cpu_baseline(args, cfg):
     S, T = synth.head_params(rng), synth.head_params(rng)
     f = synth.fpn_features(rng, 1, shapes)
     labs = [synth.distill_inputs(rng, 1, 9, 80, h, w)[2] for h, w in shapes]
-    db = [(rng.standard_normal((1, 36, h, w)) * 1e-3).astype(np.float32) for h, w in shapes]
+    tg = [synth.bbox_targets(rng, l) for l in labs]
+    fg = np.array([max(1, sum(t[0].shape[0] for t in tg))], np.float32)
     t0 = time.time()
-    head_step.head_step(S, T, f, f, labs, db, scale=1.0)
+    head_step.head_step(S, T, f, f, labs, scale=1.0, bbox_targets=tg, fg_num=fg)
     dt = time.time() - t0
     frac = sum(h * w for h, w in shapes) / float(sum(h * w for h, w in synth.LEVEL_SHAPES_600))
     return {
@@ -154,7 +155,15 @@ def main():
             lab[fg] = torch.randint(1, 81, (int(fg.sum()),), device=dev, generator=gen,
                                     dtype=torch.int32)
             labels.append(lab)
-    d_bbox = [torch.randn((N, 36, h, w), device=dev, generator=gen) * 1e-4 for h, w in shapes]
+    # box-regression targets for every foreground anchor (SelectSmoothL1Loss inputs)
+    bbox_targets, n_fg = [], 0
+    for lab in labels:
+        idx = torch.nonzero(lab > 0)
+        Lc = torch.stack([idx[:, 0], 4 * idx[:, 1], idx[:, 2], idx[:, 3]], dim=1).float().contiguous()
+        Y = (torch.randn((Lc.shape[0], 4), device=dev, generator=gen) * 0.5).contiguous()
+        bbox_targets.append((Y, Lc))
+        n_fg += Lc.shape[0]
+    fg_num = torch.tensor([float(max(n_fg, 1))], device=dev)
 
     timer = KernelTimer()
     timer.wrap(K)
@@ -164,9 +173,10 @@ def main():
         t_fpn = [torch.randn((N, 256, h, w), device=dev, generator=gen) for h, w in shapes]
 
         def step():
-            heads.step(s_fpn, t_fpn, labels, d_bbox)
+            heads.step(s_fpn, t_fpn, labels, bbox_targets=bbox_targets, fg_num=fg_num)
         wl = ("heads-only: RetinaNet cls+bbox subnets (teacher fwd, student fwd+bwd) + PowSum + "
-              "SigmoidAdaptiveDistillLoss fwd/bwd + SGD on synthetic FPN features")
+              "SigmoidAdaptiveDistillLoss + SigmoidFocalLoss + SelectSmoothL1Loss fwd/bwd + SGD "
+              "on synthetic FPN features")
     else:
         from ssad_amd.harness.full_model import FullDistillModel
         model = FullDistillModel(heads, student_depth=50, teacher_depth=101, device=dev,
@@ -174,10 +184,10 @@ def main():
         images = torch.randn((N, 3, 640, 896), device=dev, generator=gen)
 
         def step():
-            model.step(images, labels, d_bbox)
+            model.step(images, labels, bbox_targets, fg_num)
         wl = ("R-50-FPN student + R-101-FPN teacher adaptive distillation, 600 px (3x640x896): "
-              "backbones = PyTorch/MIOpen harness, subnets + distillation losses + subnet SGD = "
-              "this repo's HIP kernels")
+              "backbones = PyTorch/MIOpen harness; subnets, distillation + focal + smooth-L1 "
+              "losses and subnet SGD = this repo's HIP kernels")
 
     for _ in range(args.warmup):
         step()
@@ -225,7 +235,9 @@ def main():
             "config": {"workload": wl, "batch_per_gpu": N, "image": "3x640x896",
                        "fpn_levels": [list(s) for s in shapes], "anchors": 9, "classes": 80,
                        "parallelism": "dp%d" % world,
-                       "distill_loss": loss_val},
+                       "distill_loss": loss_val,
+                       "focal_loss": [float(v) for v in heads.focal_losses.cpu()],
+                       "bbox_loss": [float(v) for v in heads.bbox_losses.cpu()]},
             "roofline": {
                 "kernel": "conv3x3_kernel<8,1,4> (subnet conv3x3 fwd / data-grad, fp32 MFMA)",
                 "bound": "mfma", "achieved": round(ks["tflops"], 2) if ks else None,

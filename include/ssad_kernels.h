@@ -83,6 +83,56 @@ SSAD_API int ssad_distill_loss_backward(
     const ssad_distill_params* params_host, ssad_stream_t stream);
 
 /* ---------------------------------------------------------------------- */
+/* The student's supervised losses                   */
+/* SigmoidFocalLoss    modules/detectron/sigmoid_focal_loss_op.cu:26-172   */
+/* SelectSmoothL1Loss  modules/detectron/select_smooth_l1_loss_op.cu:23-176*/
+/* ---------------------------------------------------------------------- */
+
+typedef struct {
+  float gamma;        /* arg "gamma", default 1.0  */
+  float alpha;        /* arg "alpha", default 0.25 */
+  int num_classes;    /* arg "num_classes", default 80 */
+  float scale;        /* arg "scale", default 1.0, >= 0 */
+} ssad_focal_params;
+
+/* Same level struct as the distillation loss; teacher_prob is unused (may be
+ * NULL).  Labels: -1 ignore, 0 background, 1..num_classes foreground class.
+ * fg_num: device scalar (input 2 of the op).  Workspace as
+ * ssad_distill_loss_workspace_bytes. */
+SSAD_API int ssad_focal_loss_forward(
+    const ssad_distill_level* levels_host, int n_levels, const float* fg_num,
+    const ssad_focal_params* params_host, void* workspace, size_t workspace_bytes,
+    ssad_stream_t stream);
+SSAD_API int ssad_focal_loss_backward(
+    const ssad_distill_level* levels_host, int n_levels, const float* fg_num,
+    const float* dloss, int dloss_stride, const ssad_focal_params* params_host,
+    ssad_stream_t stream);
+
+/* Fused classification losses for the training step: ONE pass over the
+ * logits yields distill_losses[l], focal_losses[l] and levels[l].out = dX =
+ * d(distill)/dx + d(focal)/dx with both loss gradients = 1.0 (what the
+ * reference obtains from 2 forward ops, 2 gradient ops and an autograd Sum).
+ * Requires focal gamma == 2 (RetinaNet). */
+SSAD_API size_t ssad_cls_losses_fused_workspace_bytes(int n_levels);
+SSAD_API int ssad_cls_losses_fused(
+    const ssad_distill_level* levels_host, int n_levels, const float* normalizer,
+    const float* fg_num, const ssad_distill_params* distill_host,
+    const ssad_focal_params* focal_host, float* distill_losses, float* focal_losses,
+    void* workspace, size_t workspace_bytes, ssad_stream_t stream);
+
+/* Y_hat N x D x H x W box predictions; Y M x 4 targets; L M x 4 float rows
+ * (n, c, y, x) locating each foreground box; S device scalar (#fg). */
+SSAD_API int ssad_select_smooth_l1_forward(
+    const float* Y_hat, const float* Y, const float* L, const float* S, int N, int D, int H,
+    int W, int M, float beta, float scale, float* loss, ssad_stream_t stream);
+/* dY_hat must be zero-filled by the caller (the operator does it, as the
+ * reference's math::Set); writes the M*4 non-zero entries. */
+SSAD_API int ssad_select_smooth_l1_backward(
+    const float* Y_hat, const float* Y, const float* L, const float* S, const float* dloss,
+    int N, int D, int H, int W, int M, float beta, float scale, float* dY_hat,
+    ssad_stream_t stream);
+
+/* ---------------------------------------------------------------------- */
 /* PowSum  (modules/detectron/pow_sum_op.cu:26-43)                         */
 /* ---------------------------------------------------------------------- */
 

@@ -48,9 +48,14 @@ def tower_backward(params, tower, feats, acts, d_pred):
     return grads, dy
 
 
-def head_step(student, teacher, fpn_student, fpn_teacher, labels, d_bbox_pred, *,
+def head_step(student, teacher, fpn_student, fpn_teacher, labels, d_bbox_pred=None, *,
               num_classes=80, gamma=2.0, alpha=0.5, beta=0.0, ignored_label=-1, scale=1.0,
-              power=1.8, teacher_bbox_tower=True):
+              power=1.8, teacher_bbox_tower=True, bbox_targets=None, fg_num=None,
+              focal_gamma=2.0, focal_alpha=0.25, bbox_beta=0.11, loss_scale=None):
+    """With bbox_targets / fg_num the student's supervised losses
+    (SigmoidFocalLoss + SelectSmoothL1Loss, retinanet_heads.py:259-307) join
+    the distillation loss, as in the reference graph."""
+    loss_scale = scale if loss_scale is None else loss_scale
     t_logits = tower_forward(teacher, "cls", fpn_teacher)
     t_prob = [oracle.sigmoid(x) for x in t_logits]
     if teacher_bbox_tower:
@@ -66,10 +71,23 @@ def head_step(student, teacher, fpn_student, fpn_teacher, labels, d_bbox_pred, *
         _, l64, _ = oracle.distill_loss_forward(x, q, g, norm32, **kw)
         losses.append(l64)
         d_logits.append(oracle.distill_loss_backward(x, q, g, norm32, 1.0, **kw))
+    focal_losses, bbox_losses = [], []
+    if bbox_targets is not None:
+        fkw = dict(gamma=focal_gamma, alpha=focal_alpha, num_classes=num_classes, scale=loss_scale)
+        d_bbox_pred = []
+        for i, (x, g) in enumerate(zip(cls_logits, labels)):
+            focal_losses.append(oracle.focal_loss_forward(x, g, fg_num, **fkw)[1])
+            d_logits[i] = d_logits[i] + oracle.focal_loss_backward(x, g, fg_num, 1.0, **fkw)
+        for pred, (Y, Lc) in zip(bbox_pred, bbox_targets):
+            bbox_losses.append(oracle.select_smooth_l1_forward(pred, Y, Lc, fg_num, beta=bbox_beta,
+                                                               scale=loss_scale)[1])
+            d_bbox_pred.append(oracle.select_smooth_l1_backward(pred, Y, Lc, fg_num, 1.0,
+                                                                beta=bbox_beta, scale=loss_scale))
     grads, d_fpn = {}, {}
     g, d_fpn["cls"] = tower_backward(student, "cls", fpn_student, acts["cls"], d_logits)
     grads.update(g)
     g, d_fpn["bbox"] = tower_backward(student, "bbox", fpn_student, acts["bbox"], d_bbox_pred)
     grads.update(g)
-    return dict(losses=np.array(losses), normalizer=norm64, grads=grads, d_fpn=d_fpn,
+    return dict(losses=np.array(losses), focal_losses=np.array(focal_losses),
+                bbox_losses=np.array(bbox_losses), normalizer=norm64, grads=grads, d_fpn=d_fpn,
                 cls_logits=cls_logits, bbox_pred=bbox_pred, t_prob=t_prob, d_logits=d_logits)

@@ -33,6 +33,11 @@ class DistillParams(C.Structure):
     ]
 
 
+class FocalParams(C.Structure):
+    _fields_ = [("gamma", C.c_float), ("alpha", C.c_float), ("num_classes", C.c_int),
+                ("scale", C.c_float)]
+
+
 class ConvGeom(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "kernel_h", "kernel_w", "stride_h", "stride_w",
@@ -65,6 +70,21 @@ def load():
     lib.oracle_distill_loss_backward.argtypes = [
         f32p, f32p, i32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int,
         C.POINTER(DistillParams), f32p]
+    lib.oracle_focal_loss_forward.restype = None
+    lib.oracle_focal_loss_forward.argtypes = [
+        f32p, i32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(FocalParams),
+        C.c_void_p, f64p]
+    lib.oracle_focal_loss_backward.restype = None
+    lib.oracle_focal_loss_backward.argtypes = [
+        f32p, i32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(FocalParams), f32p]
+    lib.oracle_select_smooth_l1_forward.restype = None
+    lib.oracle_select_smooth_l1_forward.argtypes = [
+        f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+        C.c_float, f64p]
+    lib.oracle_select_smooth_l1_backward.restype = None
+    lib.oracle_select_smooth_l1_backward.argtypes = [
+        f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+        C.c_float, f32p]
     lib.oracle_pow_sum.restype = None
     lib.oracle_pow_sum.argtypes = [
         C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_float, f64p]
@@ -106,6 +126,20 @@ def load_ref():
     lib.ref_distill_loss_kernel.argtypes = [
         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, i32p, f32p,
         C.c_float, C.c_float, C.c_float, C.c_int, f32p]
+    lib.ref_focal_loss_kernel.restype = None
+    lib.ref_focal_loss_kernel.argtypes = [
+        C.c_int, C.c_int, C.c_int, C.c_int, f32p, i32p, f32p, C.c_float, C.c_float, C.c_int, f32p]
+    lib.ref_focal_grad_kernel.restype = None
+    lib.ref_focal_grad_kernel.argtypes = [
+        C.c_int, C.c_int, C.c_int, C.c_int, f32p, i32p, f32p, f32p, C.c_float, C.c_float,
+        C.c_int, f32p]
+    lib.ref_smoothl1_kernel.restype = None
+    lib.ref_smoothl1_kernel.argtypes = [
+        C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, C.c_float]
+    lib.ref_smoothl1_grad_kernel.restype = None
+    lib.ref_smoothl1_grad_kernel.argtypes = [
+        C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, C.c_float, f32p,
+        C.c_float]
     lib.ref_distill_grad_kernel.restype = None
     lib.ref_distill_grad_kernel.argtypes = [
         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, i32p, f32p,
@@ -167,6 +201,60 @@ def distill_loss_backward(logits, teacher, labels, normalizer, dloss=1.0, *,
     load().oracle_distill_loss_backward(
         logits, teacher, labels, wp, go, N, D, H, W, C.byref(P), dX)
     return dX
+
+
+def focal_loss_forward(logits, labels, normalizer, *, gamma=1.0, alpha=0.25, num_classes=80,
+                       scale=1.0, want_elems=False):
+    """SigmoidFocalLoss: returns (loss_ref_order, loss_f64, per_element_or_None)."""
+    logits = _c(logits, np.float32)
+    labels = _c(labels, np.int32)
+    wp = _c(np.asarray(normalizer).reshape(-1)[:1], np.float32)
+    N, D, H, W = logits.shape
+    P = FocalParams(gamma, alpha, num_classes, scale)
+    out = np.zeros(2, np.float64)
+    elems = np.empty(logits.shape, np.float32) if want_elems else None
+    load().oracle_focal_loss_forward(logits, labels, wp, N, D, H, W, C.byref(P),
+                                     elems.ctypes.data if want_elems else None, out)
+    return np.float32(out[0]), float(out[1]), elems
+
+
+def focal_loss_backward(logits, labels, normalizer, dloss=1.0, *, gamma=1.0, alpha=0.25,
+                        num_classes=80, scale=1.0):
+    logits = _c(logits, np.float32)
+    labels = _c(labels, np.int32)
+    wp = _c(np.asarray(normalizer).reshape(-1)[:1], np.float32)
+    go = _c(np.asarray(dloss).reshape(-1)[:1], np.float32)
+    N, D, H, W = logits.shape
+    P = FocalParams(gamma, alpha, num_classes, scale)
+    dX = np.empty(logits.shape, np.float32)
+    load().oracle_focal_loss_backward(logits, labels, wp, go, N, D, H, W, C.byref(P), dX)
+    return dX
+
+
+def select_smooth_l1_forward(Y_hat, Y, L, S, *, beta=1.0, scale=1.0):
+    """SelectSmoothL1Loss: returns (loss_ref_order, loss_f64)."""
+    Y_hat = _c(Y_hat, np.float32)
+    Y = _c(Y, np.float32).reshape(-1, 4)
+    L = _c(L, np.float32).reshape(-1, 4)
+    S = _c(np.asarray(S).reshape(-1)[:1], np.float32)
+    N, D, H, W = Y_hat.shape
+    out = np.zeros(2, np.float64)
+    load().oracle_select_smooth_l1_forward(Y_hat, Y.ravel(), L.ravel(), S, N, D, H, W, Y.shape[0],
+                                           beta, scale, out)
+    return np.float32(out[0]), float(out[1])
+
+
+def select_smooth_l1_backward(Y_hat, Y, L, S, dloss=1.0, *, beta=1.0, scale=1.0):
+    Y_hat = _c(Y_hat, np.float32)
+    Y = _c(Y, np.float32).reshape(-1, 4)
+    L = _c(L, np.float32).reshape(-1, 4)
+    S = _c(np.asarray(S).reshape(-1)[:1], np.float32)
+    go = _c(np.asarray(dloss).reshape(-1)[:1], np.float32)
+    N, D, H, W = Y_hat.shape
+    out = np.empty(Y_hat.shape, np.float32)
+    load().oracle_select_smooth_l1_backward(Y_hat, Y.ravel(), L.ravel(), S, go, N, D, H, W,
+                                            Y.shape[0], beta, scale, out)
+    return out
 
 
 def pow_sum(inputs, power=1.0):
@@ -284,3 +372,35 @@ def ref_distill_grad_elems(logits, teacher, labels, normalizer, dloss, *,
                                 labels, out, wp, gamma, alpha, beta,
                                 num_classes, go)
     return out
+
+
+def ref_focal_elems(logits, labels, normalizer, dloss, *, gamma, alpha, num_classes):
+    """(per-element loss, dX before the *scale pass) from the reference kernels."""
+    lib = load_ref()
+    assert lib is not None, "oracle/_ref not built (needs /root/reference)"
+    logits = _c(logits, np.float32)
+    labels = _c(labels, np.int32)
+    wp = _c(np.asarray(normalizer).reshape(-1)[:1], np.float32)
+    go = _c(np.asarray(dloss).reshape(-1)[:1], np.float32)
+    N, D, H, W = logits.shape
+    le, dx = np.empty(logits.shape, np.float32), np.empty(logits.shape, np.float32)
+    lib.ref_focal_loss_kernel(N, D, H, W, logits, labels, wp, gamma, alpha, num_classes, le)
+    lib.ref_focal_grad_kernel(N, D, H, W, logits, labels, dx, wp, gamma, alpha, num_classes, go)
+    return le, dx
+
+
+def ref_smoothl1_elems(Y_hat, Y, L, S, dloss, *, beta, norm):
+    """(zero-initialised loss buffer, d_Y_hat) from the reference kernels."""
+    lib = load_ref()
+    assert lib is not None, "oracle/_ref not built (needs /root/reference)"
+    Y_hat = _c(Y_hat, np.float32)
+    Y = _c(Y, np.float32).reshape(-1, 4)
+    L = _c(L, np.float32).reshape(-1, 4)
+    S = _c(np.asarray(S).reshape(-1)[:1], np.float32)
+    go = _c(np.asarray(dloss).reshape(-1)[:1], np.float32)
+    N, D, H, W = Y_hat.shape
+    buf, dy = np.zeros(Y_hat.shape, np.float32), np.zeros(Y_hat.shape, np.float32)
+    lib.ref_smoothl1_kernel(D, H, W, Y.shape[0], Y_hat, Y.ravel(), L.ravel(), buf, S, beta)
+    lib.ref_smoothl1_grad_kernel(D, H, W, Y.shape[0], Y_hat, Y.ravel(), L.ravel(), dy, go, norm,
+                                 S, beta)
+    return buf, dy

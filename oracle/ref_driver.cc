@@ -24,10 +24,19 @@
 static inline float max(float a, float b) { return a > b ? a : b; }
 static inline double max(float a, double b) { return (double)a > b ? (double)a : b; }
 static inline double max(double a, double b) { return a > b ? a : b; }
+static inline float abs(float a) { return a < 0 ? -a : a; }   // CUDA's float overload
 
 namespace ref_kernels {
 #include REF_KERNELS_INC
 }  // namespace ref_kernels
+// caffe2/modules/detectron/sigmoid_focal_loss_op.cu:26-109 and
+// select_smooth_l1_loss_op.cu:23-86 (row f2 of SURVEY.md 8f), same treatment
+namespace ref_focal {
+#include REF_FOCAL_INC
+}
+namespace ref_smoothl1 {
+#include REF_SMOOTHL1_INC
+}
 
 extern "C" {
 
@@ -48,6 +57,32 @@ __attribute__((visibility("default"))) void ref_distill_grad_kernel(
   ref_kernels::SigmoidAdaptiveDistillLossGradientKernel(
       N, D, H, W, ignored_label, logits, targets, gt, dX, weight_pos, gamma,
       alpha, beta, num_classes, avg_loss);
+}
+
+__attribute__((visibility("default"))) void ref_focal_loss_kernel(
+    int N, int D, int H, int W, const float* logits, const int* targets, const float* weight_pos,
+    float gamma, float alpha, int num_classes, float* losses) {
+  ref_focal::SigmoidFocalLossKernel(N, D, H, W, logits, targets, weight_pos, gamma, alpha,
+                                    num_classes, losses);
+}
+
+__attribute__((visibility("default"))) void ref_focal_grad_kernel(
+    int N, int D, int H, int W, const float* logits, const int* targets, float* dX,
+    const float* weight_pos, float gamma, float alpha, int num_classes, const float* avg_loss) {
+  ref_focal::SigmoidFocalLossGradientKernel(N, D, H, W, logits, targets, dX, weight_pos, gamma,
+                                            alpha, num_classes, avg_loss);
+}
+
+__attribute__((visibility("default"))) void ref_smoothl1_kernel(
+    int D, int H, int W, int M, const float* Y_hat, const float* Y, const float* L, float* out,
+    const float* S, float beta) {
+  ref_smoothl1::SelectSmoothL1Kernel(D, H, W, M, Y_hat, Y, L, out, S, beta);
+}
+
+__attribute__((visibility("default"))) void ref_smoothl1_grad_kernel(
+    int D, int H, int W, int M, const float* Y_hat, const float* Y, const float* L, float* out,
+    const float* d_loss, float norm, const float* S, float beta) {
+  ref_smoothl1::SelectSmoothL1GradientKernel(D, H, W, M, Y_hat, Y, L, out, d_loss, norm, S, beta);
 }
 
 }  // extern "C"

@@ -207,16 +207,31 @@ __device__ __forceinline__ void st4(float* p, const float4& r) {
 #endif
 }
 
-// Shared traversal: calls f(x, q, keep) for every element of the work items
-// of this workgroup; BWD stores f's result to L.out, otherwise sums it.
-template <bool BWD, class F>
-__device__ __forceinline__ float traverse(const LevelArgs& L, int lb, int ignored, F f) {
-  float acc = 0.0f;
+// Shared traversal: calls f(x, q, t, d) for every element of the work items of
+// this workgroup (x logit, q teacher probability or 0 when !HAS_Q, t label of
+// the element's (image, anchor, position), d class index).  MODE 0: sum f's
+// result; MODE 1: store it to L.out; MODE 2: f returns {value to store, two
+// values to sum} (fused losses + gradient).
+struct Acc2 { float a, b; };
+struct Fused { float store, a, b; };
+
+template <int MODE, bool HAS_Q, class F>
+__device__ __forceinline__ Acc2 traverse(const LevelArgs& L, int lb, F f) {
+  Acc2 acc{0.0f, 0.0f};
   const int pl = 1 << L.pl_shift;
   const int cl = kThreads >> L.pl_shift;
   const int pi = threadIdx.x & (pl - 1);
   const int ci = threadIdx.x >> L.pl_shift;
   const int hw = L.hw;
+  auto fold = [&](float& dst, float x, float q, int t, int d) {
+    if constexpr (MODE == 2) {
+      const Fused r = f(x, q, t, d);
+      dst = r.store; acc.a += r.a; acc.b += r.b;
+    } else {
+      const float r = f(x, q, t, d);
+      if constexpr (MODE == 1) dst = r; else acc.a += r;
+    }
+  };
   for (int item = lb; item < L.items; item += L.blocks) {
     const int sc = item / L.cgroups;
     const int cg = item - sc * L.cgroups;
@@ -225,55 +240,96 @@ __device__ __forceinline__ float traverse(const LevelArgs& L, int lb, int ignore
     const int c_begin = cg * L.cper + ci;
     const int c_end = (cg + 1) * L.cper < L.classes ? (cg + 1) * L.cper : L.classes;
     const float* __restrict__ xs = L.x + (size_t)slab * L.slab;
-    const float* __restrict__ qs = L.q + (size_t)slab * L.slab;
-    float* __restrict__ ds = BWD ? L.out + (size_t)slab * L.slab : nullptr;
+    const float* __restrict__ qs = HAS_Q ? L.q + (size_t)slab * L.slab : nullptr;
+    float* __restrict__ ds = MODE != 0 ? L.out + (size_t)slab * L.slab : nullptr;
     const int32_t* __restrict__ gs = L.g + (size_t)slab * hw;
     if (L.vec4) {
       const int pos = (chunk * pl + pi) * 4;
       if (pos < hw) {
         const int4 gv = *reinterpret_cast<const int4*>(gs + pos);
-        const bool k0 = gv.x != ignored, k1 = gv.y != ignored, k2 = gv.z != ignored,
-                   k3 = gv.w != ignored;
-        auto one = [&](int o, const float4& xv, const float4& qv) {
-          float4 r;
-          r.x = f(xv.x, qv.x, k0); r.y = f(xv.y, qv.y, k1);
-          r.z = f(xv.z, qv.z, k2); r.w = f(xv.w, qv.w, k3);
-          if constexpr (BWD) st4(ds + o, r);
-          else acc += (r.x + r.y) + (r.z + r.w);
+        auto one = [&](int c, const float4& xv, const float4& qv) {
+          float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+          fold(r.x, xv.x, qv.x, gv.x, c); fold(r.y, xv.y, qv.y, gv.y, c);
+          fold(r.z, xv.z, qv.z, gv.z, c); fold(r.w, xv.w, qv.w, gv.w, c);
+          if constexpr (MODE != 0) st4(ds + c * hw + pos, r);
         };
         int c = c_begin;
-        // four class planes per step: all eight 16-byte loads are issued
-        // before the first use, so each wave keeps 8 KiB in flight
+        // four class planes per step: all 16-byte loads are issued before the
+        // first use, so each wave keeps 8 KiB in flight
         for (; c + 3 * cl < c_end; c += 4 * cl) {
           float4 xv[4], qv[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int o = (c + u * cl) * hw + pos;
             xv[u] = ld4(xs + o);
-            qv[u] = ld4(qs + o);
+            qv[u] = HAS_Q ? ld4(qs + o) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) one((c + u * cl) * hw + pos, xv[u], qv[u]);
+          for (int u = 0; u < 4; ++u) one(c + u * cl, xv[u], qv[u]);
         }
         for (; c < c_end; c += cl) {
           const int o = c * hw + pos;
-          one(o, ld4(xs + o), ld4(qs + o));
+          one(c, ld4(xs + o), HAS_Q ? ld4(qs + o) : make_float4(0.f, 0.f, 0.f, 0.f));
         }
       }
     } else {
       const int pos = chunk * pl + pi;
       if (pos < hw) {
-        const bool k0 = gs[pos] != ignored;
+        const int t = gs[pos];
 #pragma unroll 4
         for (int c = c_begin; c < c_end; c += cl) {
           const int o = c * hw + pos;
-          const float r = f(xs[o], qs[o], k0);
-          if constexpr (BWD) ds[o] = r; else acc += r;
+          float r = 0.0f;
+          fold(r, xs[o], HAS_Q ? qs[o] : 0.0f, t, c);
+          if constexpr (MODE != 0) ds[o] = r;
         }
       }
     }
   }
   return acc;
+}
+
+// ---- SigmoidFocalLoss element formulas (sigmoid_focal_loss_op.cu:33-66, 74-105)
+
+struct FocalPieces { float p, omp, logp, log1mp; };
+
+template <bool FAST>
+__device__ __forceinline__ FocalPieces focal_front(float x) {
+  FocalPieces r;
+  const float e = exp_f<FAST>(-fabsf(x));
+  const float onepe = 1.0f + e;
+  const float sp = log_f<FAST>(onepe);
+  const float inv = __frcp_rn(onepe);
+  r.p = (x >= 0.0f) ? inv : e * inv;
+  r.omp = 1.0f - r.p;                      // as the reference: 1 - (rounded p)
+  r.logp = fmaxf(fminf(x, 0.0f) - sp, kLogFltMin);
+  r.log1mp = -fmaxf(x, 0.0f) - sp;
+  return r;
+}
+
+template <bool FAST, int GAMMA_MODE>
+__device__ __forceinline__ float focal_loss_elem(float x, int t, int d, float gamma, float zp, float zn) {
+  const FocalPieces f = focal_front<FAST>(x);
+  float a, b, unused;
+  pow_pair<GAMMA_MODE>(f.omp, gamma, a, unused);
+  pow_pair<GAMMA_MODE>(f.p, gamma, b, unused);
+  const float c1 = (t == d + 1) ? 1.0f : 0.0f;
+  const float c2 = (t != -1 && t != d + 1) ? 1.0f : 0.0f;
+  return -c1 * (a * f.logp) * zp - c2 * (b * f.log1mp) * zn;
+}
+
+template <bool FAST, int GAMMA_MODE>
+__device__ __forceinline__ float focal_grad_elem(float x, int t, int d, float gamma, float zp,
+                                                 float zn, float mult) {
+  const FocalPieces f = focal_front<FAST>(x);
+  float a, b, unused;
+  pow_pair<GAMMA_MODE>(f.omp, gamma, a, unused);
+  pow_pair<GAMMA_MODE>(f.p, gamma, b, unused);
+  const float term1 = a * (f.omp - f.p * gamma * f.logp);
+  const float term2 = b * (f.log1mp * f.omp * gamma - f.p);
+  const float c1 = (t == d + 1) ? 1.0f : 0.0f;
+  const float c2 = (t != -1 && t != d + 1) ? 1.0f : 0.0f;
+  return (-c1 * zp * term1 - c2 * zn * term2) * mult;      // mult = dloss * scale
 }
 
 template <bool FAST, int GAMMA_MODE, bool BETA0>
@@ -286,10 +342,11 @@ __global__ __launch_bounds__(kThreads) void distill_fwd_kernel(
   const float w_pos = args.alpha / np;
   const float w_neg = (1.0f - args.alpha) / np;
   const float gamma = args.gamma, beta = args.beta;
-  const float acc = traverse<false>(L, lb, args.ignored, [&](float x, float q, bool keep) {
-    return loss_elem<FAST, GAMMA_MODE, BETA0>(x, q, keep, gamma, beta, w_pos, w_neg);
+  const int ignored = args.ignored;
+  const Acc2 acc = traverse<0, true>(L, lb, [&](float x, float q, int t, int) {
+    return loss_elem<FAST, GAMMA_MODE, BETA0>(x, q, t != ignored, gamma, beta, w_pos, w_neg);
   });
-  const double t = block_sum((double)acc);
+  const double t = block_sum((double)acc.a);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
@@ -316,9 +373,141 @@ __global__ __launch_bounds__(kThreads) void distill_bwd_kernel(
   const float np = fmaxf(normalizer[0], 1.0f);
   const float mult = dloss[(size_t)level * dloss_stride] * args.scale / np;
   const float gamma = args.gamma, alpha = args.alpha, beta = args.beta;
-  traverse<true>(L, lb, args.ignored, [&](float x, float q, bool keep) {
-    return grad_elem<FAST, GAMMA_MODE, BETA0>(x, q, keep, gamma, alpha, beta, mult);
+  const int ignored = args.ignored;
+  traverse<1, true>(L, lb, [&](float x, float q, int t, int) {
+    return grad_elem<FAST, GAMMA_MODE, BETA0>(x, q, t != ignored, gamma, alpha, beta, mult);
   });
+}
+
+// ---- SigmoidFocalLoss kernels --------------------------------------------------
+
+struct FocalScalars { float gamma, alpha, scale; };
+
+template <bool FAST, int GAMMA_MODE>
+__global__ __launch_bounds__(kThreads) void focal_fwd_kernel(
+    const LaunchArgs args, const FocalScalars fs, const float* __restrict__ fg_num,
+    double* __restrict__ partials) {
+  const LevelArgs& L = args.lv[find_level(args, blockIdx.x)];
+  const int lb = blockIdx.x - L.block_start;
+  const float np = fmaxf(fg_num[0], 1.0f);
+  const float zp = fs.alpha / np, zn = (1.0f - fs.alpha) / np, gamma = fs.gamma;
+  const Acc2 acc = traverse<0, false>(L, lb, [&](float x, float, int t, int d) {
+    return focal_loss_elem<FAST, GAMMA_MODE>(x, t, d, gamma, zp, zn);
+  });
+  const double t = block_sum((double)acc.a);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+template <bool FAST, int GAMMA_MODE>
+__global__ __launch_bounds__(kThreads) void focal_bwd_kernel(
+    const LaunchArgs args, const FocalScalars fs, const float* __restrict__ fg_num,
+    const float* __restrict__ dloss, int dloss_stride) {
+  const int level = find_level(args, blockIdx.x);
+  const LevelArgs& L = args.lv[level];
+  const int lb = blockIdx.x - L.block_start;
+  const float np = fmaxf(fg_num[0], 1.0f);
+  const float zp = fs.alpha / np, zn = (1.0f - fs.alpha) / np, gamma = fs.gamma;
+  const float mult = dloss[(size_t)level * dloss_stride] * fs.scale;
+  traverse<1, false>(L, lb, [&](float x, float, int t, int d) {
+    return focal_grad_elem<FAST, GAMMA_MODE>(x, t, d, gamma, zp, zn, mult);
+  });
+}
+
+// Both classification losses of the student in ONE pass over the logits:
+// distillation loss sum, focal loss sum and dX = d(distill)/dx + d(focal)/dx
+// (the reference runs two forward kernels, two gradient kernels, two Scale
+// passes and an autograd Sum over the same N x 720 x H x W tensor).
+template <bool FAST, int GAMMA_MODE, bool BETA0>
+__global__ __launch_bounds__(kThreads) void cls_losses_fused_kernel(
+    const LaunchArgs args, const FocalScalars fs, const float* __restrict__ normalizer,
+    const float* __restrict__ fg_num, double* __restrict__ partials, int focal_offset) {
+  const LevelArgs& L = args.lv[find_level(args, blockIdx.x)];
+  const int lb = blockIdx.x - L.block_start;
+  const float np = fmaxf(normalizer[0], 1.0f);
+  const float w_pos = args.alpha / np, w_neg = (1.0f - args.alpha) / np;
+  const float d_mult = args.scale / np;                  // dloss = 1 (utils/blob.py:166-172)
+  const float nf = fmaxf(fg_num[0], 1.0f);
+  const float zp = fs.alpha / nf, zn = (1.0f - fs.alpha) / nf;
+  const float gamma = args.gamma, alpha = args.alpha, beta = args.beta, fgamma = fs.gamma;
+  const float f_mult = fs.scale;
+  const int ignored = args.ignored;
+  const Acc2 acc = traverse<2, true>(L, lb, [&](float x, float q, int t, int d) {
+    const bool keep = t != ignored;
+    Fused r;
+    r.a = loss_elem<FAST, GAMMA_MODE, BETA0>(x, q, keep, gamma, beta, w_pos, w_neg);
+    r.b = focal_loss_elem<FAST, 2>(x, t, d, fgamma, zp, zn);
+    r.store = grad_elem<FAST, GAMMA_MODE, BETA0>(x, q, keep, gamma, alpha, beta, d_mult) +
+              focal_grad_elem<FAST, 2>(x, t, d, fgamma, zp, zn, f_mult);
+    return r;
+  });
+  const double ta = block_sum((double)acc.a);
+  __syncthreads();
+  const double tb = block_sum((double)acc.b);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = ta;
+    partials[focal_offset + blockIdx.x] = tb;
+  }
+}
+
+// finalize for the fused kernel: level l -> out_a[l], out_b[l]
+__global__ __launch_bounds__(kThreads) void fused_finalize_kernel(
+    const LaunchArgs args, const double* __restrict__ partials, int focal_offset,
+    float* __restrict__ out_a, float* __restrict__ out_b, float scale_a, float scale_b) {
+  const LevelArgs& L = args.lv[blockIdx.x];
+  double va = 0.0, vb = 0.0;
+  for (int i = threadIdx.x; i < L.blocks; i += kThreads) {
+    va += partials[L.block_start + i];
+    vb += partials[focal_offset + L.block_start + i];
+  }
+  const double ta = block_sum(va);
+  __syncthreads();
+  const double tb = block_sum(vb);
+  if (threadIdx.x == 0) {
+    out_a[blockIdx.x] = (float)ta * scale_a;
+    out_b[blockIdx.x] = (float)tb * scale_b;
+  }
+}
+
+// ---- SelectSmoothL1Loss (select_smooth_l1_loss_op.cu:23-86) ---------------------
+// M foreground boxes x 4 coordinates; tiny.  One workgroup.
+
+__global__ __launch_bounds__(kThreads) void smooth_l1_fwd_kernel(
+    const float* __restrict__ Y_hat, const float* __restrict__ Y, const float* __restrict__ Lc,
+    const float* __restrict__ S, int D, int H, int W, int M, float beta, float scale,
+    float* __restrict__ out) {
+  const double s = (double)fmaxf(S[0], 1.0f);
+  double acc = 0.0;
+  for (int e = threadIdx.x; e < M * 4; e += kThreads) {
+    const int i = e >> 2, j = e & 3;
+    const int n = (int)Lc[i * 4], c = (int)Lc[i * 4 + 1], y = (int)Lc[i * 4 + 2], x = (int)Lc[i * 4 + 3];
+    const size_t ind = ((size_t)n * D + c + j) * H * W + (size_t)y * W + x;
+    const float val = Y_hat[ind] - Y[e];
+    const float a = fabsf(val);
+    const float l = a < beta ? (float)((0.5 * (double)val * (double)val / (double)beta) / s)
+                             : (float)(((double)a - 0.5 * (double)beta) / s);
+    acc += (double)l;
+  }
+  const double t = block_sum(acc);
+  if (threadIdx.x == 0) out[0] = (float)t * scale;
+}
+
+// dY_hat must be zero-filled first (the op does that, as the reference's
+// math::Set, .cu:143-145); this scatters the M*4 non-zero entries.
+__global__ __launch_bounds__(kThreads) void smooth_l1_bwd_kernel(
+    const float* __restrict__ Y_hat, const float* __restrict__ Y, const float* __restrict__ Lc,
+    const float* __restrict__ S, const float* __restrict__ dloss, int D, int H, int W, int M,
+    float beta, float scale, float* __restrict__ dY_hat) {
+  const float s = fmaxf(S[0], 1.0f);
+  const float nd = scale * dloss[0];
+  for (int e = blockIdx.x * kThreads + threadIdx.x; e < M * 4; e += gridDim.x * kThreads) {
+    const int i = e >> 2, j = e & 3;
+    const int n = (int)Lc[i * 4], c = (int)Lc[i * 4 + 1], y = (int)Lc[i * 4 + 2], x = (int)Lc[i * 4 + 3];
+    const size_t ind = ((size_t)n * D + c + j) * H * W + (size_t)y * W + x;
+    const float val = Y_hat[ind] - Y[e];
+    const float a = fabsf(val);
+    const float sign = (float)((0.0f < val) - (val < 0.0f));
+    dY_hat[ind] = a < beta ? nd * val / beta / s : nd * sign / s;
+  }
 }
 
 // ---- PowSum ----------------------------------------------------------------
@@ -400,7 +589,8 @@ bool accurate_math() {
 }
 
 int build_args(const ssad_distill_level* lv, int n_levels,
-               const ssad_distill_params* P, LaunchArgs* out, int* total_blocks) {
+               const ssad_distill_params* P, LaunchArgs* out, int* total_blocks,
+               bool out_is_tensor = false) {
   if (n_levels < 1 || n_levels > SSAD_MAX_LEVELS || !P) return SSAD_E_BADARG;
   if (P->num_classes <= 0 || !(P->scale >= 0.0f)) return SSAD_E_BADARG;
   LaunchArgs& a = *out;
@@ -419,8 +609,9 @@ int build_args(const ssad_distill_level* lv, int n_levels,
     LevelArgs& L = a.lv[l];
     L.x = s.logits; L.q = s.teacher_prob; L.g = s.labels; L.out = s.out;
     L.hw = (int)hw; L.slab = (int)slab; L.n_slabs = (int)n_slabs;
+    // `out` is a full-size tensor (16-byte stores) only for the gradient
     const uintptr_t al = (uintptr_t)s.logits | (uintptr_t)s.teacher_prob |
-                         (uintptr_t)s.labels | (uintptr_t)s.out;
+                         (uintptr_t)s.labels | (out_is_tensor ? (uintptr_t)s.out : 0);
     L.vec4 = (hw % 4 == 0) && ((al & 15) == 0);
     L.classes = P->num_classes;
     // position lanes: smallest power of two covering the plane, at most 256
@@ -516,7 +707,7 @@ int ssad_distill_loss_backward(
     ssad_stream_t stream) {
   LaunchArgs a;
   int blocks = 0;
-  const int rc = build_args(levels_host, n_levels, params_host, &a, &blocks);
+  const int rc = build_args(levels_host, n_levels, params_host, &a, &blocks, true);
   if (rc) return rc;
   long long total = 0;
   for (int l = 0; l < n_levels; ++l) total += a.lv[l].items;
@@ -526,6 +717,116 @@ int ssad_distill_loss_backward(
   const int gm = gamma_mode(a.gamma);
   LAUNCH_BY_MODE(distill_bwd_kernel, fast, a.beta == 0.0f, gm, dim3(blocks), dim3(kThreads), 0, s,
                  a, normalizer, dloss, dloss_stride);
+  return (int)hipGetLastError();
+}
+
+static int focal_levels(const ssad_distill_level* lv, int n_levels, const ssad_focal_params* F,
+                        LaunchArgs* a, int* blocks, bool out_is_tensor) {
+  if (!F) return SSAD_E_BADARG;
+  ssad_distill_params P{F->gamma, F->alpha, 0.0f, F->num_classes, -1, F->scale};
+  return build_args(lv, n_levels, &P, a, blocks, out_is_tensor);
+}
+
+int ssad_focal_loss_forward(const ssad_distill_level* levels_host, int n_levels,
+                            const float* fg_num, const ssad_focal_params* params_host,
+                            void* workspace, size_t workspace_bytes, ssad_stream_t stream) {
+  LaunchArgs a;
+  int blocks = 0;
+  const int rc = focal_levels(levels_host, n_levels, params_host, &a, &blocks, false);
+  if (rc) return rc;
+  if (!workspace || workspace_bytes < sizeof(double) * (size_t)blocks) return SSAD_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const FocalScalars fs{params_host->gamma, params_host->alpha, params_host->scale};
+  const int gm = gamma_mode(fs.gamma);
+  double* partials = (double*)workspace;
+#define FOCAL_LAUNCH(K, ...)                                                              \
+  do {                                                                                    \
+    if (!accurate_math()) {                                                               \
+      if (gm == 2) hipLaunchKernelGGL((K<true, 2>), __VA_ARGS__);                         \
+      else if (gm == 1) hipLaunchKernelGGL((K<true, 1>), __VA_ARGS__);                    \
+      else hipLaunchKernelGGL((K<true, 0>), __VA_ARGS__);                                 \
+    } else {                                                                              \
+      if (gm == 2) hipLaunchKernelGGL((K<false, 2>), __VA_ARGS__);                        \
+      else if (gm == 1) hipLaunchKernelGGL((K<false, 1>), __VA_ARGS__);                   \
+      else hipLaunchKernelGGL((K<false, 0>), __VA_ARGS__);                                \
+    }                                                                                     \
+  } while (0)
+  FOCAL_LAUNCH(focal_fwd_kernel, dim3(blocks), dim3(kThreads), 0, s, a, fs, fg_num, partials);
+  hipLaunchKernelGGL(distill_finalize_kernel, dim3(n_levels), dim3(kThreads), 0, s, a,
+                     (const double*)partials);
+  return (int)hipGetLastError();
+}
+
+int ssad_focal_loss_backward(const ssad_distill_level* levels_host, int n_levels,
+                             const float* fg_num, const float* dloss, int dloss_stride,
+                             const ssad_focal_params* params_host, ssad_stream_t stream) {
+  LaunchArgs a;
+  int blocks = 0;
+  const int rc = focal_levels(levels_host, n_levels, params_host, &a, &blocks, true);
+  if (rc) return rc;
+  long long total = 0;
+  for (int l = 0; l < n_levels; ++l) total += a.lv[l].items;
+  if (total == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const FocalScalars fs{params_host->gamma, params_host->alpha, params_host->scale};
+  const int gm = gamma_mode(fs.gamma);
+  FOCAL_LAUNCH(focal_bwd_kernel, dim3(blocks), dim3(kThreads), 0, s, a, fs, fg_num, dloss,
+               dloss_stride);
+  return (int)hipGetLastError();
+}
+
+size_t ssad_cls_losses_fused_workspace_bytes(int n_levels) {
+  (void)n_levels;
+  return 2 * sizeof(double) * kMaxBlocks;
+}
+
+int ssad_cls_losses_fused(const ssad_distill_level* levels_host, int n_levels,
+                          const float* normalizer, const float* fg_num,
+                          const ssad_distill_params* distill_host,
+                          const ssad_focal_params* focal_host, float* distill_losses,
+                          float* focal_losses, void* workspace, size_t workspace_bytes,
+                          ssad_stream_t stream) {
+  if (!focal_host || !distill_host || focal_host->gamma != 2.0f ||
+      focal_host->num_classes != distill_host->num_classes)
+    return SSAD_E_BADARG;     // the fused kernel specialises the focal gamma = 2 of RetinaNet
+  LaunchArgs a;
+  int blocks = 0;
+  const int rc = build_args(levels_host, n_levels, distill_host, &a, &blocks, true);
+  if (rc) return rc;
+  if (!workspace || workspace_bytes < 2 * sizeof(double) * kMaxBlocks) return SSAD_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  double* partials = (double*)workspace;
+  const FocalScalars fs{focal_host->gamma, focal_host->alpha, focal_host->scale};
+  const bool fast = !accurate_math();
+  const int gm = gamma_mode(a.gamma);
+  LAUNCH_BY_MODE(cls_losses_fused_kernel, fast, a.beta == 0.0f, gm, dim3(blocks), dim3(kThreads),
+                 0, s, a, fs, normalizer, fg_num, partials, kMaxBlocks);
+  hipLaunchKernelGGL(fused_finalize_kernel, dim3(n_levels), dim3(kThreads), 0, s, a,
+                     (const double*)partials, kMaxBlocks, distill_losses, focal_losses, a.scale,
+                     fs.scale);
+  return (int)hipGetLastError();
+}
+
+int ssad_select_smooth_l1_forward(const float* Y_hat, const float* Y, const float* L,
+                                  const float* S, int N, int D, int H, int W, int M, float beta,
+                                  float scale, float* loss, ssad_stream_t stream) {
+  if (N < 0 || D < 0 || H < 0 || W < 0 || M < 0 || !(beta > 0.0f) || !(scale >= 0.0f))
+    return SSAD_E_BADARG;
+  hipLaunchKernelGGL(smooth_l1_fwd_kernel, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, Y_hat,
+                     Y, L, S, D, H, W, M, beta, scale, loss);
+  return (int)hipGetLastError();
+}
+
+int ssad_select_smooth_l1_backward(const float* Y_hat, const float* Y, const float* L,
+                                   const float* S, const float* dloss, int N, int D, int H, int W,
+                                   int M, float beta, float scale, float* dY_hat,
+                                   ssad_stream_t stream) {
+  if (N < 0 || D < 0 || H < 0 || W < 0 || M < 0 || !(beta > 0.0f) || !(scale >= 0.0f))
+    return SSAD_E_BADARG;
+  if (M == 0) return 0;
+  const int grid = (M * 4 + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(smooth_l1_bwd_kernel, dim3(grid > 256 ? 256 : grid), dim3(kThreads), 0,
+                     (hipStream_t)stream, Y_hat, Y, L, S, dloss, D, H, W, M, beta, scale, dY_hat);
   return (int)hipGetLastError();
 }
 

@@ -128,7 +128,7 @@ class FullDistillModel(object):
                 p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
                 off += p.numel()
 
-    def step(self, images, labels, d_bbox_pred):
+    def step(self, images, labels, bbox_targets, fg_num):
         h = self.heads
         h.pack_student()
         with torch.no_grad():
@@ -137,8 +137,8 @@ class FullDistillModel(object):
         s_fpn = self.student(images)
         s_in = [t.detach().contiguous() for t in s_fpn]
         h.student_forward(s_in)
-        h.distill_loss(labels)
-        d_fpn = h.backward(d_bbox_pred)
+        h.cls_losses(labels, fg_num)
+        d_fpn = h.backward(h.bbox_losses_fwd_bwd(bbox_targets, fg_num))
         # gradient w.r.t. each FPN level = cls-subnet part + bbox-subnet part
         grads = [a + b for a, b in zip(d_fpn["cls"], d_fpn["bbox"])]
         if self.dist_on:

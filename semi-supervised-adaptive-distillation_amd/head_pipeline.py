@@ -91,6 +91,8 @@ class DistillHeads(object):
         self.moms = FlatParams(cfg, device)
         self.lr = torch.full((1,), lr, dtype=torch.float32, device=device)
         self.one = torch.ones(len(self.shapes), dtype=torch.float32, device=device)
+        self.focal_losses = None
+        self.bbox_losses = None
 
         def lv(ch):
             return [torch.empty((N, ch, h, w), dtype=torch.float32, device=device)
@@ -100,6 +102,7 @@ class DistillHeads(object):
         self.act = {t: [lv(D) for _ in range(cfg.num_convs)] for t in ("cls", "bbox")}
         self.cls_logits, self.bbox_pred = lv(self.A * self.C), lv(4 * self.A)
         self.d_cls_logits = lv(self.A * self.C)
+        self.d_bbox_pred = lv(4 * self.A)
         self.dbuf = [lv(D), lv(D)]            # ping-pong for tower gradients
         self.d_fpn = {t: lv(D) for t in ("cls", "bbox")}
         # teacher scratch: two ping-pong feature sets + probabilities
@@ -181,6 +184,38 @@ class DistillHeads(object):
         K.distill_loss_backward(levels, self.normalizer, self.one, out=self.d_cls_logits, **kw)
         return self.losses
 
+    def _distill_kw(self):
+        cfg = self.cfg
+        return dict(gamma=cfg.distill_gamma, alpha=cfg.distill_alpha, beta=cfg.distill_beta,
+                    num_classes=self.C, ignored_label=cfg.ignored_label,
+                    scale=cfg.loss_scale * cfg.temperature * cfg.temperature)
+
+    def cls_losses(self, labels, fg_num):
+        """Both classification losses of the student (SigmoidFocalLoss,
+        retinanet_heads.py:282-297, and SigmoidAdaptiveDistillLoss, :331-348) and
+        their summed gradient w.r.t. the logits in ONE pass (the reference:
+        2 forward ops + 2 gradient ops + an autograd Sum per level)."""
+        cfg = self.cfg
+        self.normalizer = K.pow_sum(self.t_prob, cfg.logits_power).reshape(1)
+        levels = list(zip(self.cls_logits, self.t_prob, labels))
+        focal_kw = dict(gamma=cfg.focal_gamma, alpha=cfg.focal_alpha, num_classes=self.C,
+                        scale=cfg.loss_scale)
+        self.losses, self.focal_losses, _ = K.cls_losses_fused(
+            levels, self.normalizer, fg_num, self._distill_kw(), focal_kw, out=self.d_cls_logits)
+        return self.losses, self.focal_losses
+
+    def bbox_losses_fwd_bwd(self, bbox_targets, fg_num):
+        """SelectSmoothL1Loss per level (retinanet_heads.py:268-280) and its
+        gradient w.r.t. the box predictions.  bbox_targets: [(Y [M,4], L [M,4])]."""
+        cfg = self.cfg
+        kw = dict(beta=cfg.bbox_reg_beta, scale=cfg.loss_scale * cfg.bbox_reg_weight)
+        losses = []
+        for pred, (Y, Lc), dst in zip(self.bbox_pred, bbox_targets, self.d_bbox_pred):
+            losses.append(K.select_smooth_l1_forward(pred, Y, Lc, fg_num, **kw))
+            K.select_smooth_l1_backward(pred, Y, Lc, fg_num, self.one[:1], out=dst, **kw)
+        self.bbox_losses = torch.stack(losses)
+        return self.d_bbox_pred
+
     # -- backward -------------------------------------------------------------------
     def _tower_backward(self, tower, d_pred):
         """d_pred: gradient w.r.t. the prediction conv output, per level."""
@@ -227,11 +262,20 @@ class DistillHeads(object):
                                    self.momentum, self.weight_decay, is_bias)
 
     # -- one iteration --------------------------------------------------------------------
-    def step(self, student_fpn, teacher_fpn, labels, d_bbox_pred, update=True):
+    def step(self, student_fpn, teacher_fpn, labels, d_bbox_pred=None, update=True,
+             bbox_targets=None, fg_num=None):
+        """One iteration.  With `bbox_targets` and `fg_num` the student's
+        supervised losses are part of the step (the full reference graph);
+        without them only the distillation loss drives the cls subnet and
+        `d_bbox_pred` must supply the box-subnet gradient."""
         self.pack_student()
         self.teacher_forward(teacher_fpn)
         self.student_forward(student_fpn)
-        self.distill_loss(labels)
+        if bbox_targets is not None:
+            self.cls_losses(labels, fg_num)
+            d_bbox_pred = self.bbox_losses_fwd_bwd(bbox_targets, fg_num)
+        else:
+            self.distill_loss(labels)
         self.backward(d_bbox_pred)
         if update:
             self.sgd_step()

@@ -30,6 +30,11 @@ class DistillParams(C.Structure):
                 ("scale", C.c_float)]
 
 
+class FocalParams(C.Structure):
+    _fields_ = [("gamma", C.c_float), ("alpha", C.c_float), ("num_classes", C.c_int),
+                ("scale", C.c_float)]
+
+
 class DistillLevel(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("teacher_prob", C.c_void_p),
                 ("labels", C.c_void_p), ("out", C.c_void_p),
@@ -61,6 +66,20 @@ def lib():
         C.POINTER(DistillLevel), i32, vp, C.POINTER(DistillParams), vp, sz, vp]
     L.ssad_distill_loss_backward.argtypes = [
         C.POINTER(DistillLevel), i32, vp, vp, i32, C.POINTER(DistillParams), vp]
+    L.ssad_focal_loss_forward.argtypes = [
+        C.POINTER(DistillLevel), i32, vp, C.POINTER(FocalParams), vp, sz, vp]
+    L.ssad_focal_loss_backward.argtypes = [
+        C.POINTER(DistillLevel), i32, vp, vp, i32, C.POINTER(FocalParams), vp]
+    L.ssad_cls_losses_fused_workspace_bytes.restype = sz
+    L.ssad_cls_losses_fused_workspace_bytes.argtypes = [i32]
+    L.ssad_cls_losses_fused.argtypes = [
+        C.POINTER(DistillLevel), i32, vp, vp, C.POINTER(DistillParams), C.POINTER(FocalParams),
+        vp, vp, vp, sz, vp]
+    L.ssad_select_smooth_l1_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32,
+                                                vp, vp]
+    L.ssad_select_smooth_l1_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32,
+                                                 f32, vp, vp]
+    L.ssad_fill.argtypes = [vp, f32, i64, vp]
     L.ssad_pow_sum_workspace_bytes.restype = sz
     L.ssad_pow_sum_workspace_bytes.argtypes = [i32]
     L.ssad_pow_sum.argtypes = [C.POINTER(vp), C.POINTER(i64), i32, f32, vp, vp, sz, vp]
@@ -122,14 +141,16 @@ def _workspace(nbytes, tag):
 def _distill_levels(levels, outs):
     arr = (DistillLevel * len(levels))()
     for i, ((x, q, g), o) in enumerate(zip(levels, outs)):
-        _f32c(x, "logits"); _f32c(q, "teacher_prob")
+        _f32c(x, "logits")
+        if q is not None:
+            _f32c(q, "teacher_prob")
         if g.dtype != torch.int32 or not g.is_contiguous():
             raise KernelError("labels must be contiguous int32")
-        if x.dim() != 4 or q.shape != x.shape:
+        if x.dim() != 4 or (q is not None and q.shape != x.shape):
             raise KernelError("logits/teacher must be 4-D and equal-shaped")
         N, D, H, W = x.shape
-        arr[i] = DistillLevel(x.data_ptr(), q.data_ptr(), g.data_ptr(), o.data_ptr(),
-                              N, D, H, W)
+        arr[i] = DistillLevel(x.data_ptr(), q.data_ptr() if q is not None else 0, g.data_ptr(),
+                              o.data_ptr(), N, D, H, W)
     return arr
 
 
@@ -164,6 +185,81 @@ def distill_loss_backward(levels, normalizer, dloss, *, gamma=1.0, alpha=0.25,
     _check(L.ssad_distill_loss_backward(arr, n, _ptr(normalizer), _ptr(dloss), stride,
                                         C.byref(P), _stream()), "distill_loss_backward")
     return outs
+
+
+def focal_loss_forward(levels, fg_num, *, gamma=1.0, alpha=0.25, num_classes=80, scale=1.0):
+    """SigmoidFocalLoss; levels: list of (logits, labels).  Returns [n_levels] losses."""
+    L = lib()
+    n = len(levels)
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    arr = _distill_levels([(x, None, g) for x, g in levels], [out[i:i + 1] for i in range(n)])
+    P = FocalParams(gamma, alpha, num_classes, scale)
+    nb = L.ssad_distill_loss_workspace_bytes(n)
+    ws = _workspace(nb, "distill")
+    _check(L.ssad_focal_loss_forward(arr, n, _ptr(fg_num), C.byref(P), _ptr(ws), nb, _stream()),
+           "focal_loss_forward")
+    return out
+
+
+def focal_loss_backward(levels, fg_num, dloss, *, gamma=1.0, alpha=0.25, num_classes=80,
+                        scale=1.0, out=None):
+    L = lib()
+    n = len(levels)
+    outs = out if out is not None else [torch.empty_like(x) for x, _ in levels]
+    arr = _distill_levels([(x, None, g) for x, g in levels], outs)
+    P = FocalParams(gamma, alpha, num_classes, scale)
+    stride = 1 if dloss.numel() >= n and n > 1 else 0
+    _check(L.ssad_focal_loss_backward(arr, n, _ptr(fg_num), _ptr(dloss), stride, C.byref(P),
+                                      _stream()), "focal_loss_backward")
+    return outs
+
+
+def cls_losses_fused(levels, normalizer, fg_num, distill_kw, focal_kw, out=None):
+    """One pass over the logits: returns (distill_losses, focal_losses, dX list) where
+    dX = d(distill)/dx + d(focal)/dx for loss gradients of 1.0."""
+    L = lib()
+    n = len(levels)
+    dl = torch.empty(n, dtype=torch.float32, device="cuda")
+    fl = torch.empty(n, dtype=torch.float32, device="cuda")
+    outs = out if out is not None else [torch.empty_like(x) for x, _, _ in levels]
+    arr = _distill_levels(levels, outs)
+    DP = DistillParams(distill_kw["gamma"], distill_kw["alpha"], distill_kw.get("beta", 0.0),
+                       distill_kw["num_classes"], distill_kw.get("ignored_label", -1),
+                       distill_kw.get("scale", 1.0))
+    FP = FocalParams(focal_kw["gamma"], focal_kw["alpha"], focal_kw["num_classes"],
+                     focal_kw.get("scale", 1.0))
+    nb = L.ssad_cls_losses_fused_workspace_bytes(n)
+    ws = _workspace(nb, "clsfused")
+    _check(L.ssad_cls_losses_fused(arr, n, _ptr(normalizer), _ptr(fg_num), C.byref(DP),
+                                   C.byref(FP), _ptr(dl), _ptr(fl), _ptr(ws), nb, _stream()),
+           "cls_losses_fused")
+    return dl, fl, outs
+
+
+def select_smooth_l1_forward(Y_hat, Y, Lc, S, *, beta=1.0, scale=1.0):
+    """Y [M,4], Lc [M,4] float rows (n, c, y, x), S device scalar.  Returns a scalar tensor."""
+    out = torch.zeros((), dtype=torch.float32, device="cuda")
+    M = Y.shape[0] if Y.numel() else 0
+    if M == 0:
+        return out
+    N, D, H, W = Y_hat.shape
+    _check(lib().ssad_select_smooth_l1_forward(
+        _ptr(_f32c(Y_hat, "Y_hat")), _ptr(_f32c(Y, "Y")), _ptr(_f32c(Lc, "L")), _ptr(S), N, D, H,
+        W, M, beta, scale, _ptr(out), _stream()), "select_smooth_l1_forward")
+    return out
+
+
+def select_smooth_l1_backward(Y_hat, Y, Lc, S, dloss, *, beta=1.0, scale=1.0, out=None):
+    dy = out if out is not None else torch.empty_like(Y_hat)
+    _check(lib().ssad_fill(_ptr(dy), 0.0, dy.numel(), _stream()), "fill")
+    M = Y.shape[0] if Y.numel() else 0
+    if M:
+        N, D, H, W = Y_hat.shape
+        _check(lib().ssad_select_smooth_l1_backward(
+            _ptr(_f32c(Y_hat, "Y_hat")), _ptr(_f32c(Y, "Y")), _ptr(_f32c(Lc, "L")), _ptr(S),
+            _ptr(dloss), N, D, H, W, M, beta, scale, _ptr(dy), _stream()),
+            "select_smooth_l1_backward")
+    return dy
 
 
 def pow_sum(inputs, power=1.0):

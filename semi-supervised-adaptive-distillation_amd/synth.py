@@ -54,3 +54,14 @@ def head_params(rng, dim=FPN_DIM, A=NUM_ANCHORS, C=NUM_CLASSES, num_convs=4,
         rng.standard_normal((4 * A, dim, 3, 3)) * 0.01).astype(np.float32)
     p["retnet_bbox_pred_fpn3_b"] = np.zeros(4 * A, np.float32)
     return p
+
+
+def bbox_targets(rng, labels, bbox_dim=36):
+    """Foreground box-regression inputs of SelectSmoothL1Loss for one level:
+    for every foreground anchor (label > 0) a row (n, 4*a, y, x) in L and a
+    4-vector target in Y (detectron/lib/roi_data/retinanet.py:262-306 builds
+    them the same way).  Returns (Y [M,4] f32, L [M,4] f32)."""
+    n, a, y, x = np.nonzero(labels > 0)
+    L = np.stack([n, 4 * a, y, x], axis=1).astype(np.float32)
+    Y = (rng.standard_normal((L.shape[0], 4)) * 0.5).astype(np.float32)
+    return Y, L

@@ -17,6 +17,8 @@ Fixtures:
                       (index, loss_i, dX_i) triples (reference kernels)
   distill_edges.npz   x in {-100,-30,-5,0,5,30,100} x q in {0,1e-30,1e-6,.5,
                       1-1e-6,1} x beta in {0,1}, incl. NaN positions
+  focal_smoothl1.npz  SigmoidFocalLoss / SelectSmoothL1Loss per-element outputs of the
+                      reference kernels (row f2)
   powsum.npz          5 random tensors, power 1.8: float64 numpy answer
   conv_small.npz      3x3 convs fwd/bwd, float64 torch (independent impl.)
 """
@@ -116,6 +118,37 @@ def make_powsum():
     np.savez_compressed(os.path.join(OUT, "powsum.npz"), **out)
 
 
+def make_focal_smoothl1():
+    """Row f2: SigmoidFocalLoss and SelectSmoothL1Loss from the reference kernels."""
+    rng = np.random.default_rng(17)
+    N, A, C, H, W = 2, 3, 5, 6, 7
+    x, _, _ = synth.distill_inputs(rng, N, A, C, H, W)
+    x = (x + 3.0).astype(np.float32)                 # both signs
+    lab = rng.integers(-1, C + 1, size=(N, A, H, W)).astype(np.int32)
+    out = dict(logits=x, labels=lab)
+    for wp in (0.5, 37.0):
+        for gamma, alpha in ((2.0, 0.25), (1.0, 0.5), (1.5, 0.75)):
+            le, dx = oracle.ref_focal_elems(x, lab, wp, 0.7, gamma=gamma, alpha=alpha, num_classes=C)
+            key = "n%g_g%g_a%g" % (wp, gamma, alpha)
+            out["fl_" + key], out["fdx_" + key] = le, dx
+    # extreme logits: log(max(p, FLT_MIN)) clamp and 1-p cancellation
+    xe = np.array([-100, -30, -5, 0, 5, 30, 100], np.float32).reshape(1, 1, 1, 7)
+    xe = np.repeat(xe, 3, axis=1)                    # A=1, C=3
+    labe = np.array([[[[1, 2, 3, 0, -1, 1, 2]]]], np.int32)
+    le, dx = oracle.ref_focal_elems(xe, labe, 4.0, 1.0, gamma=2.0, alpha=0.25, num_classes=3)
+    out.update(e_logits=xe, e_labels=labe, e_fl=le, e_fdx=dx)
+    # SelectSmoothL1Loss
+    Yh = rng.standard_normal((N, 4 * A, H, W)).astype(np.float32)
+    Y, L = synth.bbox_targets(rng, lab, 4 * A)
+    out.update(Y_hat=Yh, Y=Y, L=L)
+    for S in (0.5, float(L.shape[0])):
+        for beta in (0.11, 1.0):
+            buf, dy = oracle.ref_smoothl1_elems(Yh, Y, L, S, 0.7, beta=beta, norm=0.125)
+            key = "s%g_b%g" % (S, beta)
+            out["sl_" + key], out["sdy_" + key] = buf, dy
+    np.savez_compressed(os.path.join(OUT, "focal_smoothl1.npz"), **out)
+
+
 def conv_case_inputs(seed, N, Cin, M, H, W):
     """Seeded conv inputs shared by the fixture generator and the tests."""
     rng = np.random.default_rng(seed)
@@ -163,6 +196,7 @@ if __name__ == "__main__":
     make_cfg1()
     make_edges()
     make_powsum()
+    make_focal_smoothl1()
     make_conv()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -368,3 +368,78 @@ def test_conv_full_size_adjoint_identities(K):
     x1 = Xs[1][5:6].cpu().numpy()
     ref = oracle.conv_forward(x1, Wt.cpu().numpy(), None)
     close(Ys[1][5:6].cpu().numpy(), ref, CONV_RTOL, CONV_FLOOR, "full-size slice")
+
+
+# ---------------------------------------------------------------------------
+# Row f2: SigmoidFocalLoss, SelectSmoothL1Loss, fused classification losses
+# ---------------------------------------------------------------------------
+
+def test_focal_loss_golden_and_oracle(K, golden_dir):
+    g = np.load(os.path.join(golden_dir, "focal_smoothl1.npz"))
+    x, lab = g["logits"], g["labels"]
+    C = 5
+    for wp in (0.5, 37.0):
+        for gamma, alpha in ((2.0, 0.25), (1.0, 0.5), (1.5, 0.75)):
+            key = "n%g_g%g_a%g" % (wp, gamma, alpha)
+            kw = dict(gamma=gamma, alpha=alpha, num_classes=C, scale=0.5)
+            fg = dev(np.array([wp], np.float32))
+            loss = K.focal_loss_forward([(dev(x), dev(lab))], fg, **kw).cpu().numpy()
+            close(loss[0], 0.5 * np.sum(g["fl_" + key].astype(np.float64)), LOSS_RTOL, 0, "focal " + key)
+            dx = K.focal_loss_backward([(dev(x), dev(lab))], fg, dev(np.array([0.7], np.float32)),
+                                       **kw)[0].cpu().numpy()
+            close(dx, g["fdx_" + key] * np.float32(0.5), DX_RTOL, DX_FLOOR, "focal dx " + key)
+    fg = dev(np.array([4.0], np.float32))
+    kw = dict(gamma=2.0, alpha=0.25, num_classes=3, scale=1.0)
+    xe, le = g["e_logits"], g["e_labels"]
+    loss = K.focal_loss_forward([(dev(xe), dev(le))], fg, **kw).cpu().numpy()
+    close(loss[0], np.sum(g["e_fl"].astype(np.float64)), LOSS_RTOL, 0, "focal extremes")
+    dx = K.focal_loss_backward([(dev(xe), dev(le))], fg, dev(np.ones(1, np.float32)), **kw)[0]
+    close(dx.cpu().numpy(), g["e_fdx"], DX_RTOL, DX_FLOOR, "focal dx extremes")
+
+
+def test_select_smooth_l1_golden(K, golden_dir):
+    g = np.load(os.path.join(golden_dir, "focal_smoothl1.npz"))
+    Yh, Y, L = g["Y_hat"], g["Y"], g["L"]
+    for S in (0.5, float(L.shape[0])):
+        for beta in (0.11, 1.0):
+            key = "s%g_b%g" % (S, beta)
+            tS = dev(np.array([S], np.float32))
+            loss = K.select_smooth_l1_forward(dev(Yh), dev(Y), dev(L), tS, beta=beta, scale=2.0)
+            close(loss.cpu().numpy(), 2.0 * np.sum(g["sl_" + key].astype(np.float64)), 1e-5, 0, key)
+            dy = K.select_smooth_l1_backward(dev(Yh), dev(Y), dev(L), tS,
+                                             dev(np.array([0.7], np.float32)), beta=beta, scale=0.125)
+            close(dy.cpu().numpy(), g["sdy_" + key], 1e-5, 1e-7, "dy " + key)
+    e = dev(np.zeros((0, 4), np.float32))
+    assert float(K.select_smooth_l1_forward(dev(Yh), e, e, dev(np.ones(1, np.float32)))) == 0.0
+    assert not bool(K.select_smooth_l1_backward(dev(Yh), e, e, dev(np.ones(1, np.float32)),
+                                                dev(np.ones(1, np.float32))).any())
+
+
+def test_fused_cls_losses_equal_separate_ops(K):
+    """distill + focal in one pass == the two operators + the autograd Sum."""
+    rng = np.random.default_rng(77)
+    N, A, C = 2, 9, 80
+    shapes = [(10, 14), (5, 7), (3, 4)]
+    levels_np = []
+    for h, w in shapes:
+        x, q, _ = synth.distill_inputs(rng, N, A, C, h, w)
+        lab = np.zeros((N, A, h, w), np.int32)
+        u = rng.random(lab.shape)
+        lab[u < 0.05] = -1
+        fgm = (u >= 0.05) & (u < 0.12)
+        lab[fgm] = rng.integers(1, C + 1, size=int(fgm.sum()))
+        levels_np.append((x, q, lab))
+    dkw = dict(gamma=2.0, alpha=0.5, beta=0.0, num_classes=C, ignored_label=-1, scale=0.125)
+    fkw = dict(gamma=2.0, alpha=0.25, num_classes=C, scale=0.125)
+    norm, fgn = 41.5, 17.0
+    levels = [(dev(x), dev(q), dev(g)) for x, q, g in levels_np]
+    dl, fl, dxs = K.cls_losses_fused(levels, dev(np.array([norm], np.float32)),
+                                     dev(np.array([fgn], np.float32)), dkw, fkw)
+    for i, (x, q, g) in enumerate(levels_np):
+        _, d64, _ = oracle.distill_loss_forward(x, q, g, norm, **dkw)
+        _, f64, _ = oracle.focal_loss_forward(x, g, fgn, **fkw)
+        close(dl[i].cpu().numpy(), d64, LOSS_RTOL, 0, "fused distill loss")
+        close(fl[i].cpu().numpy(), f64, LOSS_RTOL, 0, "fused focal loss")
+        ref = oracle.distill_loss_backward(x, q, g, norm, 1.0, **dkw) + \
+            oracle.focal_loss_backward(x, g, fgn, 1.0, **fkw)
+        close(dxs[i].cpu().numpy(), ref, DX_RTOL, 2 * DX_FLOOR, "fused dX")

@@ -159,3 +159,45 @@ def test_relu_sigmoid_sgd():
     rel_close(w2, w - mm, 1e-6, 1e-8)
     w3, g3, m3 = oracle.sgd_update(w, gr, m, 0.01, 0.9, 1e-4, is_bias=True)
     rel_close(m3, np.float32(0.01) * (2 * gr) + np.float32(0.9) * m, 1e-6, 1e-8)
+
+
+def test_focal_loss_oracle_vs_reference_kernels(golden_dir):
+    """Row f2: SigmoidFocalLoss (sigmoid_focal_loss_op.cu:26-109)."""
+    g = np.load(os.path.join(golden_dir, "focal_smoothl1.npz"))
+    x, lab = g["logits"], g["labels"]
+    C = 5
+    for wp in (0.5, 37.0):
+        for gamma, alpha in ((2.0, 0.25), (1.0, 0.5), (1.5, 0.75)):
+            key = "n%g_g%g_a%g" % (wp, gamma, alpha)
+            s128, s64, elems = oracle.focal_loss_forward(x, lab, wp, gamma=gamma, alpha=alpha,
+                                                         num_classes=C, want_elems=True)
+            rel_close(elems, g["fl_" + key], 2e-5, 1e-9)
+            rel_close(s128, np.float32(oracle.sum128(g["fl_" + key])), 2e-5, 1e-9)
+            dx = oracle.focal_loss_backward(x, lab, wp, 0.7, gamma=gamma, alpha=alpha, num_classes=C)
+            rel_close(dx, g["fdx_" + key], 5e-5, 1e-9)
+            ign = np.repeat(lab == -1, C, axis=1)
+            assert np.all(elems[ign] == 0) and np.all(dx[ign] == 0)
+    _, _, e = oracle.focal_loss_forward(g["e_logits"], g["e_labels"], 4.0, gamma=2.0, alpha=0.25,
+                                        num_classes=3, want_elems=True)
+    rel_close(e, g["e_fl"], 2e-5, 1e-12)
+    rel_close(oracle.focal_loss_backward(g["e_logits"], g["e_labels"], 4.0, gamma=2.0, alpha=0.25,
+                                         num_classes=3), g["e_fdx"], 5e-5, 1e-12)
+
+
+def test_select_smooth_l1_oracle_vs_reference_kernels(golden_dir):
+    """Row f2: SelectSmoothL1Loss (select_smooth_l1_loss_op.cu:23-86)."""
+    g = np.load(os.path.join(golden_dir, "focal_smoothl1.npz"))
+    Yh, Y, L = g["Y_hat"], g["Y"], g["L"]
+    assert Y.shape[0] > 10
+    for S in (0.5, float(L.shape[0])):
+        for beta in (0.11, 1.0):
+            key = "s%g_b%g" % (S, beta)
+            s128, s64 = oracle.select_smooth_l1_forward(Yh, Y, L, S, beta=beta, scale=1.0)
+            rel_close(s64, np.sum(g["sl_" + key].astype(np.float64)), 1e-6, 0)
+            rel_close(s128, np.float32(oracle.sum128(g["sl_" + key])), 1e-5, 0)
+            dy = oracle.select_smooth_l1_backward(Yh, Y, L, S, 0.7, beta=beta, scale=0.125)
+            rel_close(dy, g["sdy_" + key], 1e-6, 0)
+    # no foreground boxes: zero loss, zero gradient (.cu:101-105,146-149)
+    e = np.zeros((0, 4), np.float32)
+    assert oracle.select_smooth_l1_forward(Yh, e, e, 3.0)[1] == 0.0
+    assert not oracle.select_smooth_l1_backward(Yh, e, e, 3.0).any()
