@@ -48,7 +48,8 @@ def test_library_exports_every_declared_symbol(lib):
 def test_registered_operators(lib):
     for op in ("SigmoidAdaptiveDistillLoss", "SigmoidAdaptiveDistillLossGradient", "PowSum",
                "Conv", "ConvGradient", "Relu", "ReluGradient", "Sigmoid", "Sum", "Scale",
-               "WeightedSum", "ConstantFill", "MomentumSGDUpdate"):
+               "WeightedSum", "ConstantFill", "MomentumSGDUpdate", "SigmoidFocalLoss",
+               "SigmoidFocalLossGradient", "SelectSmoothL1Loss", "SelectSmoothL1LossGradient"):
         assert core.IsOperator(op), op
     assert not core.IsOperator("NoSuchOp")
     mi, ma, mo, mx = (ctypes.c_int() for _ in range(4))
@@ -154,7 +155,6 @@ def same_args(mine, ref):
 
 
 def build_student(train=True, prefix="", fuse=False):
-    core._REGISTERED_OPERATORS.update(["SelectSmoothL1Loss", "SigmoidFocalLoss"])  # graph-only
     m = rh.HeadModel(rh.HeadConfig(fuse_relu=fuse), train=train)
     blobs = [prefix + "fpn_%d" % l for l in range(7, 2, -1)]
     rh.add_fpn_retinanet_outputs(m, blobs, 256, prefix)
@@ -218,3 +218,25 @@ def test_backward_graph_shared_weight_accumulation(lib):
     for k in range(5):
         assert written.count("%s_grad_autosplit_%d" % (w, k)) == 1
     assert grad_map["fpn_3"] == "fpn_3_grad"
+
+
+def test_full_backward_graph_with_supervised_losses(lib):
+    """All three loss families: 50 ConvGradient, 40 ReluGradient, the two
+    gradients of every cls logit blob (focal + distill) summed by autograd."""
+    m = build_student()
+    lg = rh.add_fpn_retinanet_losses(m)
+    lg.update(rh.add_distill_loss(m))
+    n_fwd = len(m.net.Proto().op)
+    grad_map = m.net.AddGradientOperators(lg)
+    bwd = m.net.Proto().op[n_fwd:]
+    hist = {}
+    for op in bwd:
+        hist[op.type] = hist.get(op.type, 0) + 1
+    assert hist["ConvGradient"] == 50 and hist["ReluGradient"] == 40
+    assert hist["SigmoidFocalLossGradient"] == 5 and hist["SelectSmoothL1LossGradient"] == 5
+    assert hist["SigmoidAdaptiveDistillLossGradient"] == 5
+    s = [op for op in bwd if op.type == "Sum" and op.output == ["retnet_cls_pred_fpn3_grad"]]
+    assert len(s) == 1 and len(s[0].input) == 2
+    # 20 shared parameters + 5 logits blobs + 5 fpn blobs (cls + bbox towers)
+    assert hist["Sum"] == 30
+    assert grad_map["fpn_7"] == "fpn_7_grad"

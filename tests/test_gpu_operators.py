@@ -148,17 +148,25 @@ def small_problem(seed=31, N=2):
                 P[k] = (P[k] * 3).astype(np.float32)
     fs = synth.fpn_features(rng, N, SHAPES)
     ft = synth.fpn_features(rng, N, SHAPES)
-    labs = [synth.distill_inputs(rng, N, 9, 80, h, w)[2] for h, w in SHAPES]
-    db = [(rng.standard_normal((N, 36, h, w)) * 1e-3).astype(np.float32) for h, w in SHAPES]
-    return cfg, S, T, fs, ft, labs, db
+    labs = []
+    for h, w in SHAPES:
+        lab = synth.distill_inputs(rng, N, 9, 80, h, w)[2]
+        u = rng.random(lab.shape)
+        lab[u < 0.1] = rng.integers(1, 81, size=int((u < 0.1).sum()))   # enough foreground
+        labs.append(lab)
+    tg = [synth.bbox_targets(rng, l) for l in labs]
+    fg = np.array([float(sum(t[0].shape[0] for t in tg))], np.float32)
+    return cfg, S, T, fs, ft, labs, tg, fg
 
 
 def test_head_graph_through_workspace_vs_oracle_and_fused():
     """The whole hot path as the reference runs it: teacher graph (test mode),
-    student graph, PowSum + SigmoidAdaptiveDistillLoss, autograd backward with
-    the shared-weight Sum, all through CreateNet / RunNet -- against the
-    oracle's composition and against the fused DistillHeads pipeline."""
-    cfg, S, T, fs, ft, labs, db = small_problem()
+    student graph, SelectSmoothL1Loss + SigmoidFocalLoss + PowSum +
+    SigmoidAdaptiveDistillLoss (all 121 forward ops of the reference builder),
+    autograd backward with the shared-weight Sum and the focal + distill
+    gradient Sum, all through CreateNet / RunNet -- against the oracle's
+    composition and against the fused DistillHeads pipeline."""
+    cfg, S, T, fs, ft, labs, tg, fg = small_problem()
     levels = list(cfg.levels())
     with core.DeviceScope(GPU):
         teacher = rh.HeadModel(cfg, train=False, name="teacher")
@@ -166,23 +174,27 @@ def test_head_graph_through_workspace_vs_oracle_and_fused():
                                      256, "teacher/")
         student = rh.HeadModel(cfg, train=True, name="student")
         rh.add_fpn_retinanet_outputs(student, ["fpn_%d" % l for l in reversed(levels)], 256)
-        loss_grads = rh.add_distill_loss(student)
-        for l in levels:   # stand-in for the SelectSmoothL1Loss gradient
-            loss_grads["retnet_bbox_pred_fpn%d" % l] = "retnet_bbox_pred_fpn%d_grad" % l
+        loss_grads = rh.add_fpn_retinanet_losses(student)
+        loss_grads.update(rh.add_distill_loss(student))
+        assert len(student.net.Proto().op) == 121
         grad_map = student.net.AddGradientOperators(loss_grads)
     for k, v in S.items():
         feed(k, v)
     for k, v in T.items():
         feed("teacher/" + k, v)
+    feed("retnet_fg_num", fg.reshape(()))
     for i, l in enumerate(levels):
         feed("fpn_%d" % l, fs[i]); feed("teacher/fpn_%d" % l, ft[i])
         feed("retnet_cls_labels_fpn%d" % l, labs[i])
-        feed("retnet_bbox_pred_fpn%d_grad" % l, db[i])
+        feed("retnet_roi_bbox_targets_fpn%d" % l, tg[i][0])
+        feed("retnet_roi_fg_bbox_locs_fpn%d" % l, tg[i][1])
     workspace.CreateNet(teacher.net)
     workspace.CreateNet(student.net)
     workspace.RunNet(teacher.net)
     workspace.RunNet(student.net, sync_every_op=True)    # reference semantics
-    ref = head_step.head_step(S, T, fs, ft, labs, db, scale=cfg.loss_scale)
+    ref = head_step.head_step(S, T, fs, ft, labs, scale=cfg.loss_scale, bbox_targets=tg, fg_num=fg,
+                              focal_gamma=cfg.focal_gamma, focal_alpha=cfg.focal_alpha,
+                              bbox_beta=cfg.bbox_reg_beta)
 
     close(workspace.FetchBlob("distill_normalizer"), ref["normalizer"], 1e-5, 0, "normalizer")
     for i, l in enumerate(levels):
@@ -190,7 +202,10 @@ def test_head_graph_through_workspace_vs_oracle_and_fused():
               CONV_RTOL, CONV_FLOOR, "teacher prob")
         close(workspace.FetchBlob("retnet_cls_pred_fpn%d" % l), ref["cls_logits"][i],
               CONV_RTOL, CONV_FLOOR, "cls logits")
-        close(workspace.FetchBlob("fl_distill_fpn%d" % l), ref["losses"][i], 2e-4, 0, "loss")
+        close(workspace.FetchBlob("fl_distill_fpn%d" % l), ref["losses"][i], 2e-4, 0, "distill loss")
+        close(workspace.FetchBlob("fl_fpn%d" % l), ref["focal_losses"][i], 2e-4, 0, "focal loss")
+        close(workspace.FetchBlob("retnet_loss_bbox_fpn%d" % l), ref["bbox_losses"][i], 2e-4, 1e-9,
+              "bbox loss")
     for name, g in ref["grads"].items():
         close(workspace.FetchBlob(grad_map[name]), g, 2e-4, 2e-5, "graph grad " + name)
     for i, l in enumerate(levels):
@@ -203,8 +218,11 @@ def test_head_graph_through_workspace_vs_oracle_and_fused():
     heads = DistillHeads(cfg, N=fs[0].shape[0], shapes=SHAPES, device=dev, student_init=S,
                          teacher_init=T)
     t = lambda arrs: [torch.from_numpy(a).to(dev) for a in arrs]
-    losses = heads.step(t(fs), t(ft), t(labs), t(db), update=False)
-    close(losses.cpu().numpy(), ref["losses"], 2e-4, 0, "fused losses")
+    losses = heads.step(t(fs), t(ft), t(labs), update=False,
+                        bbox_targets=[tuple(t(p)) for p in tg], fg_num=torch.from_numpy(fg).to(dev))
+    close(losses.cpu().numpy(), ref["losses"], 2e-4, 0, "fused distill losses")
+    close(heads.focal_losses.cpu().numpy(), ref["focal_losses"], 2e-4, 0, "fused focal losses")
+    close(heads.bbox_losses.cpu().numpy(), ref["bbox_losses"], 2e-4, 1e-9, "fused bbox losses")
     for name, g in ref["grads"].items():
         close(heads.grads[name].cpu().numpy(), g, 2e-4, 2e-5, "fused grad " + name)
         close(heads.grads[name].cpu().numpy(), workspace.FetchBlob(grad_map[name]), 2e-4, 2e-5,
@@ -215,14 +233,17 @@ def test_head_graph_through_workspace_vs_oracle_and_fused():
 
 
 def test_fused_sgd_step_matches_oracle():
-    cfg, S, T, fs, ft, labs, db = small_problem(seed=33, N=1)
+    cfg, S, T, fs, ft, labs, tg, fg = small_problem(seed=33, N=1)
     from ssad_amd.head_pipeline import DistillHeads
     dev = torch.device("cuda", 0)
     heads = DistillHeads(cfg, N=1, shapes=SHAPES, device=dev, student_init=S, teacher_init=T,
                          lr=0.01)
     t = lambda arrs: [torch.from_numpy(a).to(dev) for a in arrs]
-    heads.step(t(fs), t(ft), t(labs), t(db), update=True)
-    ref = head_step.head_step(S, T, fs, ft, labs, db, scale=cfg.loss_scale)
+    heads.step(t(fs), t(ft), t(labs), update=True, bbox_targets=[tuple(t(p)) for p in tg],
+               fg_num=torch.from_numpy(fg).to(dev))
+    ref = head_step.head_step(S, T, fs, ft, labs, scale=cfg.loss_scale, bbox_targets=tg, fg_num=fg,
+                              focal_gamma=cfg.focal_gamma, focal_alpha=cfg.focal_alpha,
+                              bbox_beta=cfg.bbox_reg_beta)
     for name, _, is_bias, _ in heads.params.specs:
         w, _, m = oracle.sgd_update(S[name], ref["grads"][name], np.zeros_like(S[name]), 0.01, 0.9,
                                     1e-4, is_bias)
