@@ -248,7 +248,7 @@ def main():
                 "avg_launch_ms": round(ks["avg_ms"], 4) if ks else None,
                 "flops_per_launch": ks["flops_per_launch"] if ks else None},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(out))
     if pg is not None:

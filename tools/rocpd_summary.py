@@ -26,9 +26,16 @@ def main():
         i = args.index("--json"); js = args[i + 1]; del args[i:i + 2]
     if "--title" in args:
         i = args.index("--title"); title = args[i + 1]; del args[i:i + 2]
+    tail = None
+    if "--tail-fraction" in args:   # only kernels in the last fraction of the timeline
+        i = args.index("--tail-fraction"); tail = float(args[i + 1]); del args[i:i + 2]
     db = sqlite3.connect(args[0])
     cur = db.cursor()
     rows = cur.execute("select name, start, end from kernels").fetchall()
+    if tail and rows:
+        t0, t1 = min(r[1] for r in rows), max(r[2] for r in rows)
+        cut = t1 - (t1 - t0) * tail
+        rows = [r for r in rows if r[1] >= cut]
     agg = {}
     for n, s, e in rows:
         a = agg.setdefault(short(n), [0, 0, 1 << 62, 0])
