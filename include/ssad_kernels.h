@@ -33,6 +33,7 @@ extern "C" {
 #define SSAD_E_BADARG (-1)       /* inconsistent dims / unsupported geometry */
 #define SSAD_E_WORKSPACE (-2)    /* workspace too small */
 #define SSAD_MAX_LEVELS 8        /* FPN levels fused into one launch */
+#define SSAD_MAX_CONV_PROBLEMS 24 /* (level, filter) problems per conv launch */
 #define SSAD_MAX_POWSUM_INPUTS 8 /* inputs per PowSum launch (chunked above) */
 
 typedef void* ssad_stream_t;
@@ -189,6 +190,12 @@ typedef struct {
   const float* aux;    /* dgrad: forward output to mask by (ReluGradient
                           fused) or NULL;  wgrad: dY                       */
   int N, H, W;
+  /* forward / dgrad only: this problem's own packed filter and bias, or NULL
+   * to use the launch-wide ones.  Lets independent convolutions of equal
+   * (Cout, Cin) -- the cls and bbox tower layer of the same depth, teacher and
+   * student -- share ONE launch, which fills the last wave of workgroups. */
+  const float* packed;
+  const float* bias;
 } ssad_conv_level;
 
 /* floats in a packed filter for (M outputs, K input channels) */
@@ -206,7 +213,8 @@ SSAD_API int ssad_conv_pack_filter(
 #define SSAD_CONV_SIGMOID 4   /* y = 1/(1+exp(-y)) (teacher cls_pred -> prob,
                                  caffe2/operators/sigmoid_op.cu:25-29 fused) */
 
-/* y = conv3x3(x, packed) (+ bias) for every level in one launch.
+/* y = conv3x3(x, packed) (+ bias) for every level in one launch
+ * (n_levels <= SSAD_MAX_CONV_PROBLEMS).
  * Used for the forward (packed_fwd, Cout outputs, Cin inputs) and for the
  * data gradient (packed_dgrad, outputs = Cin, inputs = Cout, bias NULL). */
 SSAD_API int ssad_conv3x3_forward(

@@ -125,13 +125,15 @@ struct FwdLevel {
   const float* x;
   float* y;
   const float* aux;
+  const float* packed;
+  const float* bias;
   int N, H, W;
   int tiles_x, tiles_y;   // patches per image
   int block_start;        // first blockIdx.x of this level
 };
 
 struct FwdArgs {
-  FwdLevel lv[SSAD_MAX_LEVELS];
+  FwdLevel lv[SSAD_MAX_CONV_PROBLEMS];
   int n_levels;
   const float* packed;
   const float* bias;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_kernel(const FwdArgs args) 
   // ---- which patch -------------------------------------------------------
   int l = 0;
 #pragma unroll
-  for (int i = 1; i < SSAD_MAX_LEVELS; ++i)
+  for (int i = 1; i < SSAD_MAX_CONV_PROBLEMS; ++i)
     if (i < args.n_levels && (int)blockIdx.x >= args.lv[i].block_start) l = i;
   const FwdLevel& L = args.lv[l];
   const int H = L.H, W = L.W;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_kernel(const FwdArgs args) 
   const int pcol = lane & 15;
   // B base: channel kk, row (wp*PT*2 + prow), col pcol   (+ tap/ch/tile imms)
   const float* bbase = lds + kk * CS + (wp * PT * 2 + prow) * PITCH + pcol;
-  const float4* astream = reinterpret_cast<const float4*>(args.packed) +
+  const float4* astream = reinterpret_cast<const float4*>(L.packed) +
                           ((long long)(active ? mtile : 0) * args.chunks) * 9 * 64 + lane;
 
   f32x16 acc[PT];
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_kernel(const FwdArgs args) 
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = mbase + (r & 3) + 8 * (r >> 2);
-    bv[r] = (args.bias && m < M) ? args.bias[m] : 0.0f;
+    bv[r] = (L.bias && m < M) ? L.bias[m] : 0.0f;
   }
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
@@ -591,6 +593,9 @@ int launch_fwd(const ssad_conv_level* lv, int n_levels, const float* packed,
   for (int l = 0; l < n_levels; ++l) {
     FwdLevel& L = a.lv[l];
     L.x = lv[l].x; L.y = lv[l].y; L.aux = lv[l].aux;
+    L.packed = lv[l].packed ? lv[l].packed : packed;
+    L.bias = lv[l].packed ? lv[l].bias : bias;
+    if (!L.packed) return SSAD_E_BADARG;
     L.N = lv[l].N; L.H = lv[l].H; L.W = lv[l].W;
     if (L.N < 0 || L.H < 0 || L.W < 0) return SSAD_E_BADARG;
     if ((long long)L.H * L.W * (K > M ? K : M) >= (1LL << 29)) return SSAD_E_BADARG;
@@ -600,7 +605,7 @@ int launch_fwd(const ssad_conv_level* lv, int n_levels, const float* packed,
     blocks += (long long)L.N * L.tiles_x * L.tiles_y;
     if (blocks >= (1LL << 31)) return SSAD_E_BADARG;
   }
-  for (int l = n_levels; l < SSAD_MAX_LEVELS; ++l) a.lv[l] = FwdLevel{};
+  for (int l = n_levels; l < SSAD_MAX_CONV_PROBLEMS; ++l) a.lv[l] = FwdLevel{};
   if (blocks == 0) return 0;
   const int gy = cdiv(cdiv(M, 32), WM);
   hipLaunchKernelGGL((conv3x3_kernel<WM, WP, PT, TAP_FENCE>), dim3((unsigned)blocks, gy),
@@ -630,7 +635,7 @@ int ssad_conv_pack_filter(const float* w, int Cout, int Cin, float* packed_fwd,
 int ssad_conv3x3_forward(const ssad_conv_level* levels_host, int n_levels,
                          const float* packed, const float* bias, int Cout, int Cin,
                          int flags, ssad_stream_t stream) {
-  if (n_levels < 1 || n_levels > SSAD_MAX_LEVELS || Cout <= 0 || Cin <= 0 || !packed)
+  if (n_levels < 1 || n_levels > SSAD_MAX_CONV_PROBLEMS || Cout <= 0 || Cin <= 0)
     return SSAD_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   static const int variant = [] {

@@ -92,7 +92,7 @@ bool ConvOp<float, HIPContext>::RunOnDevice() {
   packed_filter_.Resize((TIndex)ssad_conv_packed_filter_floats(M, C));
   float* packed = packed_filter_.mutable_data<float>();
   CAFFE_ENFORCE_EQ(ssad_conv_pack_filter(filter.data<float>(), M, C, packed, nullptr, s), 0);
-  ssad_conv_level lv{X.data<float>(), Y->mutable_data<float>(), nullptr, N, H, W};
+  ssad_conv_level lv{X.data<float>(), Y->mutable_data<float>(), nullptr, N, H, W, nullptr, nullptr};
   const int rc = ssad_conv3x3_forward(&lv, 1, packed, bias, M, C,
                                       fuse_relu_ ? SSAD_CONV_RELU : 0, s);
   CAFFE_ENFORCE_EQ(rc, 0, "Conv launch failed");
@@ -124,7 +124,7 @@ bool ConvGradientOp<float, HIPContext>::RunOnDevice() {
   hipStream_t s = context_.hip_stream();
 
   // filter (+ bias) gradient: overwrite, beta = 0 (conv_op_cudnn.cc:1037)
-  ssad_conv_level wl{X.data<float>(), nullptr, dY.data<float>(), N, H, W};
+  ssad_conv_level wl{X.data<float>(), nullptr, dY.data<float>(), N, H, W, nullptr, nullptr};
   const size_t wsb = ssad_conv3x3_wgrad_workspace_bytes(&wl, 1, M, C);
   workspace_.Resize((TIndex)wsb);
   int rc = ssad_conv3x3_wgrad(&wl, 1, dfilter->mutable_data<float>(), db, M, C, 0,
@@ -138,7 +138,7 @@ bool ConvGradientOp<float, HIPContext>::RunOnDevice() {
     float* packed = packed_filter_.mutable_data<float>();
     CAFFE_ENFORCE_EQ(ssad_conv_pack_filter(filter.data<float>(), M, C, nullptr, packed, s), 0);
     ssad_conv_level dl{dY.data<float>(), dX->mutable_data<float>(),
-                       relu_grad_on_input_ ? X.data<float>() : nullptr, N, H, W};
+                       relu_grad_on_input_ ? X.data<float>() : nullptr, N, H, W, nullptr, nullptr};
     rc = ssad_conv3x3_forward(&dl, 1, packed, nullptr, C, M,
                               relu_grad_on_input_ ? SSAD_CONV_MASK_AUX : 0, s);
     CAFFE_ENFORCE_EQ(rc, 0, "ConvGradient (data) launch failed");

@@ -133,10 +133,9 @@ class FullDistillModel(object):
         h.pack_student()
         with torch.no_grad():
             t_fpn = [t.contiguous() for t in self.teacher(images)]
-            h.teacher_forward(t_fpn)
         s_fpn = self.student(images)
         s_in = [t.detach().contiguous() for t in s_fpn]
-        h.student_forward(s_in)
+        h.forward_all(t_fpn, s_in)
         h.cls_losses(labels, fg_num)
         d_fpn = h.backward(h.bbox_losses_fwd_bwd(bbox_targets, fg_num))
         # gradient w.r.t. each FPN level = cls-subnet part + bbox-subnet part

@@ -33,23 +33,29 @@ from .modeling.retinanet_heads import HeadConfig
 
 
 def head_param_specs(cfg):
-    """(name, shape, is_bias) in bucket order: cls subnet then bbox subnet."""
+    """(name, shape, is_bias, bucket) in the order the backward pass finishes
+    them: prediction layers, then tower layers from the deepest to the first,
+    cls and bbox subnet interleaved (their layers of equal depth run in the
+    same launches).  Bucket "late" (ready first) = predictions + upper half of
+    the towers, bucket "early" = lower half."""
     A, C, D = cfg.num_anchors, cfg.num_classes - 1, cfg.fpn_dim
     specs = []
-    for tower, pred_dim in (("cls", A * C), ("bbox", 4 * A)):
-        for i in range(cfg.num_convs):
-            stem = "retnet_%s_conv_n%d_fpn%d" % (tower, i, cfg.k_min)
-            specs.append((stem + "_w", (D, D, 3, 3), False, tower))
-            specs.append((stem + "_b", (D,), True, tower))
-        stem = "retnet_%s_pred_fpn%d" % (tower, cfg.k_min)
-        specs.append((stem + "_w", (pred_dim, D, 3, 3), False, tower))
-        specs.append((stem + "_b", (pred_dim,), True, tower))
+
+    def add(stem, cout, bucket):
+        specs.append((stem + "_w", (cout, D, 3, 3), False, bucket))
+        specs.append((stem + "_b", (cout,), True, bucket))
+    add("retnet_cls_pred_fpn%d" % cfg.k_min, A * C, "late")
+    add("retnet_bbox_pred_fpn%d" % cfg.k_min, 4 * A, "late")
+    for i in range(cfg.num_convs - 1, -1, -1):
+        bucket = "late" if i >= cfg.num_convs // 2 else "early"
+        for tower in ("cls", "bbox"):
+            add("retnet_%s_conv_n%d_fpn%d" % (tower, i, cfg.k_min), D, bucket)
     return specs
 
 
 class FlatParams(object):
     """Parameters (or gradients / momenta) of both subnets in one flat
-    buffer; `bucket[tower]` is the contiguous slice of one subnet."""
+    buffer; `bucket[name]` is the contiguous slice of one all-reduce bucket."""
 
     def __init__(self, cfg, device, init=None):
         self.specs = head_param_specs(cfg)
@@ -103,10 +109,10 @@ class DistillHeads(object):
         self.cls_logits, self.bbox_pred = lv(self.A * self.C), lv(4 * self.A)
         self.d_cls_logits = lv(self.A * self.C)
         self.d_bbox_pred = lv(4 * self.A)
-        self.dbuf = [lv(D), lv(D)]            # ping-pong for tower gradients
+        self.dbuf = {"cls": [lv(D), lv(D)], "bbox": [lv(D), lv(D)]}   # ping-pong tower gradients
         self.d_fpn = {t: lv(D) for t in ("cls", "bbox")}
-        # teacher scratch: two ping-pong feature sets + probabilities
-        self.t_buf = [lv(D), lv(D)]
+        # teacher scratch: two ping-pong feature sets per tower + probabilities
+        self.t_buf = {"cls": [lv(D), lv(D)], "bbox": [lv(D), lv(D)]}
         self.t_prob = lv(self.A * self.C)
         self.t_bbox = lv(4 * self.A) if teacher_bbox_tower else None
         # packed filters (rebuilt every step from the current weights)
@@ -135,38 +141,45 @@ class DistillHeads(object):
                 self.t_packed[name] = K.conv_pack_filter(self.teacher[name + "_w"], True, False)[0]
 
     # -- forward ----------------------------------------------------------------
-    def _tower_forward(self, params, packed_of, tower, feats, out_of, pred_out, sigmoid=False):
-        layers = self._layers(tower)
-        x = feats
-        for i, name in enumerate(layers[:-1]):
-            x = K.conv3x3_forward(x, packed_of(name), params[name + "_b"], self.D, relu=True,
-                                  out=out_of(i))
-        name = layers[-1]
-        Cout = params[name + "_b"].numel()
-        return K.conv3x3_forward(x, packed_of(name), params[name + "_b"], Cout, sigmoid=sigmoid,
-                                 out=pred_out)
-
-    def teacher_forward(self, fpn_feats):
-        """Teacher subnets in test mode: cls tower -> Sigmoid probabilities
-        (retinanet_heads.py:153-163); its bbox tower runs too, as in the
-        reference's graph, unless teacher_bbox_tower=False."""
+    def forward_all(self, teacher_fpn, student_fpn):
+        """Teacher (test mode) and student subnets.  The four tower layers of
+        equal depth (teacher/student x cls/bbox) are independent convolutions
+        of the same shape, so each depth is ONE launch of 20 (level, filter)
+        problems: 12 480 equal workgroups fill the 256 CUs to 99 % where five
+        separate launches would each leave a partial last wave.  Teacher
+        cls_pred carries the Sigmoid epilogue (retinanet_heads.py:153-163)."""
         if self.t_packed is None:
             self.pack_teacher()
-        pk = lambda n: self.t_packed[n]
-        pingpong = lambda i: self.t_buf[i & 1]
-        self._tower_forward(self.teacher, pk, "cls", fpn_feats, pingpong, self.t_prob,
-                            sigmoid=True)
+        self.fpn_in = student_fpn
+        cfg = self.cfg
+        tx = {"cls": teacher_fpn, "bbox": teacher_fpn}
+        sx = {"cls": student_fpn, "bbox": student_fpn}
+        for i in range(cfg.num_convs):
+            probs = []
+            for t in ("cls", "bbox"):
+                name = self._layers(t)[i]
+                if t == "cls" or self.teacher_bbox_tower:
+                    out = self.t_buf[t][i & 1]
+                    probs.append(dict(xs=tx[t], packed=self.t_packed[name],
+                                      bias=self.teacher[name + "_b"], out=out))
+                    tx[t] = out
+                out = self.act[t][i]
+                probs.append(dict(xs=sx[t], packed=self.packed[name][0],
+                                  bias=self.params[name + "_b"], out=out))
+                sx[t] = out
+            K.conv3x3_forward_multi(probs, self.D, relu=True)
+        cp = self._layers("cls")[-1]
+        K.conv3x3_forward(tx["cls"], self.t_packed[cp], self.teacher[cp + "_b"], self.A * self.C,
+                          sigmoid=True, out=self.t_prob)
+        K.conv3x3_forward(sx["cls"], self.packed[cp][0], self.params[cp + "_b"], self.A * self.C,
+                          out=self.cls_logits)
+        bp = self._layers("bbox")[-1]
+        probs = [dict(xs=sx["bbox"], packed=self.packed[bp][0], bias=self.params[bp + "_b"],
+                      out=self.bbox_pred)]
         if self.teacher_bbox_tower:
-            self._tower_forward(self.teacher, pk, "bbox", fpn_feats, pingpong, self.t_bbox)
-        return self.t_prob
-
-    def student_forward(self, fpn_feats):
-        self.fpn_in = fpn_feats
-        pk = lambda n: self.packed[n][0]
-        self._tower_forward(self.params, pk, "cls", fpn_feats, lambda i: self.act["cls"][i],
-                            self.cls_logits)
-        self._tower_forward(self.params, pk, "bbox", fpn_feats, lambda i: self.act["bbox"][i],
-                            self.bbox_pred)
+            probs.append(dict(xs=tx["bbox"], packed=self.t_packed[bp],
+                              bias=self.teacher[bp + "_b"], out=self.t_bbox))
+        K.conv3x3_forward_multi(probs, 4 * self.A)
         return self.cls_logits, self.bbox_pred
 
     # -- losses -------------------------------------------------------------------
@@ -217,35 +230,45 @@ class DistillHeads(object):
         return self.d_bbox_pred
 
     # -- backward -------------------------------------------------------------------
-    def _tower_backward(self, tower, d_pred):
-        """d_pred: gradient w.r.t. the prediction conv output, per level."""
-        layers = self._layers(tower)
-        acts = self.act[tower]
-        dy = d_pred
-        for li in range(len(layers) - 1, -1, -1):
-            name = layers[li]
-            x_in = acts[li - 1] if li > 0 else self.fpn_in
-            Cout = self.params[name + "_b"].numel()
-            K.conv3x3_wgrad(x_in, dy, Cout, dW=self.grads[name + "_w"], db=self.grads[name + "_b"])
-            # data gradient; for li > 0 the input is a ReLU output, so the
-            # ReluGradient mask (Y > 0) is the conv input itself
-            out = self.dbuf[li & 1] if li > 0 else self.d_fpn[tower]
-            dy = K.conv3x3_forward(dy, self.packed[name][1], None, self.D,
-                                   mask_by=x_in if li > 0 else None, out=out)
-        return dy
-
     def backward(self, d_bbox_pred):
-        """Backward of both subnets.  The cls subnet goes first; its bucket's
-        all-reduce then overlaps the bbox subnet's backward."""
-        self._tower_backward("cls", self.d_cls_logits)
-        self._allreduce_async("cls")
-        self._tower_backward("bbox", d_bbox_pred)
-        self._allreduce_async("bbox")
+        """Backward of both subnets, depth by depth from the prediction layers
+        down.  Per depth: the two weight gradients (each already one workgroup
+        per CU) and ONE data-gradient launch for both towers.  For tower
+        layers the data gradient carries the ReluGradient mask, which is the
+        layer's own post-ReLU input.  Each gradient bucket is all-reduced as
+        soon as its last weight gradient is enqueued."""
+        cfg = self.cfg
+        nl = cfg.num_convs
+        dy = {"cls": self.d_cls_logits, "bbox": d_bbox_pred}
+        # prediction layers (different widths: separate launches)
+        for t in ("cls", "bbox"):
+            name = self._layers(t)[-1]
+            x_in = self.act[t][nl - 1]
+            Cout = self.params[name + "_b"].numel()
+            K.conv3x3_wgrad(x_in, dy[t], Cout, dW=self.grads[name + "_w"], db=self.grads[name + "_b"])
+            dy[t] = K.conv3x3_forward(dy[t], self.packed[name][1], None, self.D, mask_by=x_in,
+                                      out=self.dbuf[t][nl & 1])
+        for li in range(nl - 1, -1, -1):
+            probs = []
+            for t in ("cls", "bbox"):
+                name = self._layers(t)[li]
+                x_in = self.act[t][li - 1] if li > 0 else self.fpn_in
+                K.conv3x3_wgrad(x_in, dy[t], self.D, dW=self.grads[name + "_w"],
+                                db=self.grads[name + "_b"])
+                out = self.dbuf[t][li & 1] if li > 0 else self.d_fpn[t]
+                probs.append(dict(xs=dy[t], packed=self.packed[name][1], bias=None, out=out,
+                                  mask_by=x_in if li > 0 else None))
+                dy[t] = out
+            K.conv3x3_forward_multi(probs, self.D)
+            if li == nl // 2:
+                self._allreduce_async("late")
+        self._allreduce_async("early")
         return self.d_fpn
 
     # -- data parallel ------------------------------------------------------------------
     def _allreduce_async(self, tower):
-        self.dp.issue(self.grads.bucket[tower])
+        if tower in self.grads.bucket:
+            self.dp.issue(self.grads.bucket[tower])
 
     def wait_gradients(self):
         self.dp.wait()
@@ -269,8 +292,7 @@ class DistillHeads(object):
         without them only the distillation loss drives the cls subnet and
         `d_bbox_pred` must supply the box-subnet gradient."""
         self.pack_student()
-        self.teacher_forward(teacher_fpn)
-        self.student_forward(student_fpn)
+        self.forward_all(teacher_fpn, student_fpn)
         if bbox_targets is not None:
             self.cls_losses(labels, fg_num)
             d_bbox_pred = self.bbox_losses_fwd_bwd(bbox_targets, fg_num)

@@ -43,7 +43,8 @@ class DistillLevel(C.Structure):
 
 class ConvLevel(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("aux", C.c_void_p),
-                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int)]
+                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("packed", C.c_void_p), ("bias", C.c_void_p)]
 
 
 _lib = None
@@ -345,7 +346,7 @@ def conv_pack_filter(w, want_fwd=True, want_dgrad=True):
     return pf, pd
 
 
-def _conv_levels(xs, ys, auxs):
+def _conv_levels(xs, ys, auxs, packs=None, biases=None):
     n = len(xs)
     arr = (ConvLevel * n)()
     for i in range(n):
@@ -353,7 +354,9 @@ def _conv_levels(xs, ys, auxs):
         arr[i] = ConvLevel(xs[i].data_ptr(),
                            ys[i].data_ptr() if ys is not None and ys[i] is not None else 0,
                            auxs[i].data_ptr() if auxs is not None and auxs[i] is not None else 0,
-                           N, H, W)
+                           N, H, W,
+                           packs[i].data_ptr() if packs is not None else 0,
+                           biases[i].data_ptr() if biases is not None and biases[i] is not None else 0)
     return arr
 
 
@@ -373,6 +376,30 @@ def conv3x3_forward(xs, packed, bias, Cout, *, relu=False, sigmoid=False, mask_b
     arr = _conv_levels(xs, ys, mask_by)
     _check(L.ssad_conv3x3_forward(arr, len(xs), _ptr(packed), _ptr(bias), Cout, Cin, flags,
                                   _stream()), "conv3x3_forward")
+    return ys
+
+
+def conv3x3_forward_multi(problems, Cout, *, relu=False, sigmoid=False):
+    """Independent convolutions of equal (Cout, Cin) in ONE launch.
+    problems: list of dicts {xs, packed, bias, out, mask_by(optional)} -- e.g. the
+    cls-tower and bbox-tower layer of the same depth, for teacher and student."""
+    L = lib()
+    xs, ys, auxs, packs, biases = [], [], [], [], []
+    for p in problems:
+        n = len(p["xs"])
+        xs += list(p["xs"]); ys += list(p["out"])
+        auxs += list(p["mask_by"]) if p.get("mask_by") is not None else [None] * n
+        packs += [p["packed"]] * n
+        biases += [p.get("bias")] * n
+    masked = [a is not None for a in auxs]
+    if any(masked) and not all(masked):
+        raise KernelError("either every problem of a launch is masked or none")
+    Cin = xs[0].shape[1]
+    flags = ((CONV_RELU if relu else 0) | (CONV_MASK_AUX if all(masked) and masked else 0)
+             | (CONV_SIGMOID if sigmoid else 0))
+    arr = _conv_levels(xs, ys, auxs, packs, biases)
+    _check(L.ssad_conv3x3_forward(arr, len(xs), None, None, Cout, Cin, flags, _stream()),
+           "conv3x3_forward_multi")
     return ys
 
 

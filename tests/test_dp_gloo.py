@@ -32,7 +32,7 @@ def _worker(rank, world, port, outdir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ssad_amd.head_pipeline import FlatParams
-    cfg = HeadConfig(num_convs=1, fpn_dim=8, aspect_ratios=(1.0,), scales_per_octave=1,
+    cfg = HeadConfig(num_convs=2, fpn_dim=8, aspect_ratios=(1.0,), scales_per_octave=1,
                      num_classes=4, num_gpus=world)
     params, grads, moms = (FlatParams(cfg, "cpu") for _ in range(3))
     g0 = torch.Generator().manual_seed(100)            # same initial params on rank 0 only
@@ -43,8 +43,9 @@ def _worker(rank, world, port, outdir):
     gr = torch.Generator().manual_seed(7 + rank)       # rank-local gradients
     grads.flat.copy_(torch.randn(grads.flat.shape, generator=gr))
     local = grads.flat.clone()
-    for tower in ("cls", "bbox"):                      # one all-reduce per bucket
-        dp.issue(grads.bucket[tower])
+    assert set(grads.bucket) <= {"late", "early"} and grads.bucket
+    for name in grads.bucket:                          # one all-reduce per bucket
+        dp.issue(grads.bucket[name])
     dp.wait()
     # identical SGD on every rank (optimizer.py:95-130)
     for name, _, is_bias, _ in params.specs:
