@@ -112,6 +112,13 @@ class FullDistillModel(object):
         del g
         for p in self.teacher.parameters():
             p.requires_grad_(False)
+        # harness tuning knobs (A/B via env): MIOpen solver search and NHWC layout
+        if os.environ.get("SSAD_HARNESS_BENCHMARK", "0") == "1":
+            torch.backends.cudnn.benchmark = True
+        self.channels_last = os.environ.get("SSAD_HARNESS_NHWC", "0") == "1"
+        if self.channels_last:
+            self.student = self.student.to(memory_format=torch.channels_last)
+            self.teacher = self.teacher.to(memory_format=torch.channels_last)
         self.trainable = [p for p in self.student.parameters() if p.requires_grad]
         self.opt = torch.optim.SGD(self.trainable, lr=lr, momentum=momentum,
                                    weight_decay=weight_decay)
@@ -130,6 +137,8 @@ class FullDistillModel(object):
 
     def step(self, images, labels, bbox_targets, fg_num):
         h = self.heads
+        if self.channels_last:
+            images = images.contiguous(memory_format=torch.channels_last)
         h.pack_student()
         with torch.no_grad():
             t_fpn = [t.contiguous() for t in self.teacher(images)]
