@@ -115,7 +115,7 @@ class FullDistillModel(object):
         # harness tuning knobs (A/B via env): MIOpen solver search and NHWC layout
         if os.environ.get("SSAD_HARNESS_BENCHMARK", "0") == "1":
             torch.backends.cudnn.benchmark = True
-        self.channels_last = os.environ.get("SSAD_HARNESS_NHWC", "0") == "1"
+        self.channels_last = os.environ.get("SSAD_HARNESS_NHWC", "1") == "1"   # +4.5 % step time
         if self.channels_last:
             self.student = self.student.to(memory_format=torch.channels_last)
             self.teacher = self.teacher.to(memory_format=torch.channels_last)
