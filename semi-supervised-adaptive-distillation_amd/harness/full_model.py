@@ -7,6 +7,7 @@ per-channel affine = AffineChannel) and FPN.py:116-250 for RetinaNet
 conv3x3/2 on relu(P6); levels P3..P7 at 256 channels).  Random weights.
 """
 import os
+import sys
 
 import torch
 import torch.nn as nn
@@ -135,28 +136,56 @@ class FullDistillModel(object):
                 p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
                 off += p.numel()
 
+    def _mark(self, name):
+        if self._timing is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._timing.append((name, e))
+
     def step(self, images, labels, bbox_targets, fg_num):
         h = self.heads
+        self._timing = [] if os.environ.get("SSAD_HARNESS_TIMING") == "1" else None
+        self._mark("start")
         if self.channels_last:
             images = images.contiguous(memory_format=torch.channels_last)
         h.pack_student()
         with torch.no_grad():
             t_fpn = [t.contiguous() for t in self.teacher(images)]
+        self._mark("teacher backbone fwd")
         s_fpn = self.student(images)
         s_in = [t.detach().contiguous() for t in s_fpn]
+        self._mark("student backbone fwd")
         h.forward_all(t_fpn, s_in)
+        self._mark("subnets fwd (teacher+student)")
         h.cls_losses(labels, fg_num)
-        d_fpn = h.backward(h.bbox_losses_fwd_bwd(bbox_targets, fg_num))
-        # gradient w.r.t. each FPN level = cls-subnet part + bbox-subnet part
-        grads = [a + b for a, b in zip(d_fpn["cls"], d_fpn["bbox"])]
+        d_bbox = h.bbox_losses_fwd_bwd(bbox_targets, fg_num)
+        self._mark("losses")
+        d_fpn = h.backward(d_bbox)
+        self._mark("subnets bwd")
+        # gradient w.r.t. each FPN level = cls-subnet part + bbox-subnet part,
+        # in the memory format of the forward output (a mismatched format sends
+        # MIOpen's backward to its slow non-packed fallback kernels)
+        grads = []
+        for a, b, f in zip(d_fpn["cls"], d_fpn["bbox"], s_fpn):
+            g = a + b
+            if self.channels_last:
+                g = g.contiguous(memory_format=torch.channels_last)
+            grads.append(g)
         if self.dist_on:
             self.flat_grad.zero_()
         else:
             self.opt.zero_grad(set_to_none=True)
         torch.autograd.backward(s_fpn, grads)
+        self._mark("student backbone bwd")
         if self.dist_on:
             import torch.distributed as dist
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
         h.sgd_step()
         self.opt.step()
+        self._mark("all-reduce + SGD")
+        if self._timing is not None:
+            torch.cuda.synchronize()
+            print("harness timing: " + ", ".join(
+                "%s %.1f ms" % (self._timing[i][0], self._timing[i - 1][1].elapsed_time(self._timing[i][1]))
+                for i in range(1, len(self._timing))), file=sys.stderr)
         return h.losses
