@@ -14,47 +14,36 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-class Affine(nn.Module):
-    """AffineChannel (frozen BN): y = x * s + b, s and b not trained."""
-
-    def __init__(self, c):
-        super().__init__()
-        self.register_buffer("s", torch.ones(1, c, 1, 1))
-        self.register_buffer("b", torch.zeros(1, c, 1, 1))
-
-    def forward(self, x):
-        return x * self.s + self.b
+def conv_frozen_bn(cin, cout, k, stride=1, padding=0):
+    """Conv followed by a frozen-BN AffineChannel (y = x*s + b with constant s, b;
+    detectron/lib/modeling/ResNet.py uses AffineChannel after every conv).  With
+    s and b constant the affine folds exactly into the conv: W' = s*W, bias = b,
+    so the harness runs one conv-with-bias instead of conv + two elementwise ops."""
+    return nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=True)
 
 
 class Bottleneck(nn.Module):
     def __init__(self, cin, cmid, cout, stride):
         super().__init__()
-        self.c1 = nn.Conv2d(cin, cmid, 1, stride=stride, bias=False)
-        self.a1 = Affine(cmid)
-        self.c2 = nn.Conv2d(cmid, cmid, 3, padding=1, bias=False)
-        self.a2 = Affine(cmid)
-        self.c3 = nn.Conv2d(cmid, cout, 1, bias=False)
-        self.a3 = Affine(cout)
-        self.proj = None
-        if cin != cout or stride != 1:
-            self.proj = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False),
-                                      Affine(cout))
+        self.c1 = conv_frozen_bn(cin, cmid, 1, stride=stride)
+        self.c2 = conv_frozen_bn(cmid, cmid, 3, padding=1)
+        self.c3 = conv_frozen_bn(cmid, cout, 1)
+        self.proj = conv_frozen_bn(cin, cout, 1, stride=stride) if (cin != cout or stride != 1) else None
 
     def forward(self, x):
         sc = x if self.proj is None else self.proj(x)
-        y = F.relu(self.a1(self.c1(x)))
-        y = F.relu(self.a2(self.c2(y)))
-        y = self.a3(self.c3(y))
-        return F.relu(y + sc)
+        y = F.relu(self.c1(x), inplace=True)
+        y = F.relu(self.c2(y), inplace=True)
+        y = self.c3(y)
+        return F.relu(y.add_(sc), inplace=True)
 
 
 class ResNetFPN(nn.Module):
     def __init__(self, depth=50, fpn_dim=256):
         super().__init__()
         blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[depth]
-        self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False),
-                                  Affine(64), nn.ReLU(inplace=True),
-                                  nn.MaxPool2d(3, stride=2, padding=1))
+        self.stem = nn.Sequential(conv_frozen_bn(3, 64, 7, stride=2, padding=3),
+                                  nn.ReLU(inplace=True), nn.MaxPool2d(3, stride=2, padding=1))
         stages, cin = [], 64
         for i, n in enumerate(blocks):
             cmid, cout = 64 * 2 ** i, 256 * 2 ** i
@@ -73,11 +62,13 @@ class ResNetFPN(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_in", nonlinearity="relu")
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
+        for m in self.modules():
             if isinstance(m, Bottleneck):
-                # frozen-BN affines carry no statistics with random weights:
-                # damp the residual branch so activations stay O(1) through
-                # 16 / 33 blocks (a trained model's BN does this job)
-                m.a3.s.fill_(0.25)
+                # frozen-BN scales carry no statistics with random weights: damp
+                # the residual branch (folded scale 0.25) so activations stay
+                # O(1) through 16 / 33 blocks (a trained model's BN does this job)
+                with torch.no_grad():
+                    m.c3.weight.mul_(0.25)
         for m in list(self.lat) + list(self.out) + [self.p6, self.p7]:
             nn.init.xavier_uniform_(m.weight)
         # the stem and res2 are frozen in Detectron (TRAIN.FREEZE_CONV_BODY / FREEZE_AT = 2)
