@@ -43,6 +43,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "ssad_kernels.h"
 
 namespace {
@@ -722,13 +724,12 @@ int ssad_conv3x3_wgrad(const ssad_conv_level* levels_host, int n_levels, float* 
   if (!workspace || workspace_bytes < need) return SSAD_E_WORKSPACE;
   a.slabs = (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
   const size_t lds_bytes = sizeof(float) * 2 * WG_BUF;
-  if (!attr_set) {
+  static std::once_flag lds_once;    // > 64 KiB of dynamic LDS needs the opt-in, once per process
+  std::call_once(lds_once, [&] {
     (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(a.splits, a.mblocks, a.cblocks), dim3(kBlock),
                      lds_bytes, s, a);
   const long long per_split = (long long)mtp * ctp * 9 * 1024;
