@@ -94,6 +94,10 @@ def lib():
     L.ssad_conv_packed_filter_floats.argtypes = [i32, i32]
     L.ssad_conv_pack_filter.argtypes = [vp, i32, i32, vp, vp, vp]
     L.ssad_conv3x3_forward.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp]
+    L.ssad_conv_wino_filter_floats.restype = sz
+    L.ssad_conv_wino_filter_floats.argtypes = [i32, i32]
+    L.ssad_conv_wino_pack_filter.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.ssad_conv3x3_forward_wino.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp]
     L.ssad_conv3x3_wgrad_workspace_bytes.restype = sz
     L.ssad_conv3x3_wgrad_workspace_bytes.argtypes = [C.POINTER(ConvLevel), i32, i32, i32]
     L.ssad_conv3x3_wgrad.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp, sz, vp]
@@ -346,6 +350,22 @@ def conv_pack_filter(w, want_fwd=True, want_dgrad=True):
     return pf, pd
 
 
+def conv_wino_pack_filter(w, want_fwd=True, want_dgrad=True):
+    """Winograd-domain filters U = G g G^T in MFMA operand order: (fwd, dgrad)."""
+    L = lib()
+    _f32c(w, "filter")
+    Cout, Cin, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise KernelError("only 3x3 filters")
+    pf = torch.empty(L.ssad_conv_wino_filter_floats(Cout, Cin), dtype=torch.float32,
+                     device="cuda") if want_fwd else None
+    pd = torch.empty(L.ssad_conv_wino_filter_floats(Cin, Cout), dtype=torch.float32,
+                     device="cuda") if want_dgrad else None
+    _check(L.ssad_conv_wino_pack_filter(_ptr(w), Cout, Cin, _ptr(pf), _ptr(pd), _stream()),
+           "conv_wino_pack_filter")
+    return pf, pd
+
+
 def _conv_levels(xs, ys, auxs, packs=None, biases=None):
     n = len(xs)
     arr = (ConvLevel * n)()
@@ -361,7 +381,7 @@ def _conv_levels(xs, ys, auxs, packs=None, biases=None):
 
 
 def conv3x3_forward(xs, packed, bias, Cout, *, relu=False, sigmoid=False, mask_by=None,
-                    out=None):
+                    out=None, wino=False):
     """xs: list of N x Cin x H x W tensors (FPN levels sharing the filter).
     Returns the list of N x Cout x H x W outputs (one launch for all levels)."""
     L = lib()
@@ -374,12 +394,13 @@ def conv3x3_forward(xs, packed, bias, Cout, *, relu=False, sigmoid=False, mask_b
     flags = ((CONV_RELU if relu else 0) | (CONV_MASK_AUX if mask_by is not None else 0)
              | (CONV_SIGMOID if sigmoid else 0))
     arr = _conv_levels(xs, ys, mask_by)
-    _check(L.ssad_conv3x3_forward(arr, len(xs), _ptr(packed), _ptr(bias), Cout, Cin, flags,
-                                  _stream()), "conv3x3_forward")
+    fn = L.ssad_conv3x3_forward_wino if wino else L.ssad_conv3x3_forward
+    _check(fn(arr, len(xs), _ptr(packed), _ptr(bias), Cout, Cin, flags, _stream()),
+           "conv3x3_forward")
     return ys
 
 
-def conv3x3_forward_multi(problems, Cout, *, relu=False, sigmoid=False):
+def conv3x3_forward_multi(problems, Cout, *, relu=False, sigmoid=False, wino=False):
     """Independent convolutions of equal (Cout, Cin) in ONE launch.
     problems: list of dicts {xs, packed, bias, out, mask_by(optional)} -- e.g. the
     cls-tower and bbox-tower layer of the same depth, for teacher and student."""
@@ -398,8 +419,8 @@ def conv3x3_forward_multi(problems, Cout, *, relu=False, sigmoid=False):
     flags = ((CONV_RELU if relu else 0) | (CONV_MASK_AUX if all(masked) and masked else 0)
              | (CONV_SIGMOID if sigmoid else 0))
     arr = _conv_levels(xs, ys, auxs, packs, biases)
-    _check(L.ssad_conv3x3_forward(arr, len(xs), None, None, Cout, Cin, flags, _stream()),
-           "conv3x3_forward_multi")
+    fn = L.ssad_conv3x3_forward_wino if wino else L.ssad_conv3x3_forward
+    _check(fn(arr, len(xs), None, None, Cout, Cin, flags, _stream()), "conv3x3_forward_multi")
     return ys
 
 

@@ -443,3 +443,47 @@ def test_fused_cls_losses_equal_separate_ops(K):
         ref = oracle.distill_loss_backward(x, q, g, norm, 1.0, **dkw) + \
             oracle.focal_loss_backward(x, g, fgn, 1.0, **fkw)
         close(dxs[i].cpu().numpy(), ref, DX_RTOL, 2 * DX_FLOOR, "fused dX")
+
+
+# ---------------------------------------------------------------------------
+# Winograd F(2x2,3x3) engine: same contract, same tolerance as the direct kernel
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [
+    (1, 8, 128, 8, 16), (2, 16, 40, 9, 17), (2, 36, 256, 5, 7), (1, 256, 256, 10, 14),
+    (1, 24, 130, 17, 33), (3, 8, 65, 2, 31), (1, 720, 256, 5, 7), (2, 256, 720, 3, 4)],
+    ids=lambda s: "N%d_C%d_M%d_%dx%d" % s)
+def test_winograd_vs_oracle(K, shape):
+    N, Cin, M, H, W = shape
+    rng = np.random.default_rng(1000 + sum(shape))
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, 3, 3)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    dY = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    pf, pd = K.conv_wino_pack_filter(dev(Wt))
+    Y = K.conv3x3_forward([dev(X)], pf, dev(b), M, wino=True)[0].cpu().numpy()
+    close(Y, oracle.conv_forward(X, Wt, b), CONV_RTOL, CONV_FLOOR, "wino Y")
+    dX = K.conv3x3_forward([dev(dY)], pd, None, Cin, wino=True)[0].cpu().numpy()
+    close(dX, oracle.conv_backward(X, Wt, dY, want_db=False)[2], CONV_RTOL, CONV_FLOOR, "wino dX")
+    # epilogues
+    Yr = K.conv3x3_forward([dev(X)], pf, dev(b), M, relu=True, wino=True)[0].cpu().numpy()
+    close(Yr, oracle.relu(oracle.conv_forward(X, Wt, b)), CONV_RTOL, CONV_FLOOR, "wino relu")
+    Xp = np.maximum(X, 0)
+    dXm = K.conv3x3_forward([dev(dY)], pd, None, Cin, mask_by=[dev(Xp)], wino=True)[0].cpu().numpy()
+    close(dXm, oracle.relu_grad(Xp, oracle.conv_backward(Xp, Wt, dY, want_db=False)[2]),
+          CONV_RTOL, CONV_FLOOR, "wino masked dX")
+
+
+def test_winograd_multilevel_matches_direct_full_size(K):
+    gen = torch.Generator(device="cuda").manual_seed(19)
+    N, C, M = 4, 256, 256
+    shapes = [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)]
+    Xs = [torch.randn((N, C, h, w), device="cuda", generator=gen) for h, w in shapes]
+    Wt = torch.randn((M, C, 3, 3), device="cuda", generator=gen) * 0.02
+    b = torch.randn(M, device="cuda", generator=gen)
+    pf, _ = K.conv_pack_filter(Wt, True, False)
+    wf, _ = K.conv_wino_pack_filter(Wt, True, False)
+    Yd = K.conv3x3_forward(Xs, pf, b, M, relu=True)
+    Yw = K.conv3x3_forward(Xs, wf, b, M, relu=True, wino=True)
+    for a, c in zip(Yd, Yw):
+        close(c.cpu().numpy(), a.cpu().numpy(), CONV_RTOL, CONV_FLOOR, "wino vs direct")
