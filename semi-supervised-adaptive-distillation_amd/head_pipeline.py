@@ -86,6 +86,8 @@ class DistillHeads(object):
         self.cfg = cfg or HeadConfig()
         self.N, self.shapes, self.device = N, list(shapes), device
         self.teacher_bbox_tower = teacher_bbox_tower
+        import os
+        self.wino = os.environ.get("SSAD_CONV_ENGINE", "winograd").lower() != "direct"
         self.momentum, self.weight_decay = momentum, weight_decay
         self.pg, self.world_size = process_group, world_size
         self.dp = BucketedAllReduce(process_group, world_size)
@@ -128,17 +130,37 @@ class DistillHeads(object):
         names.append("retnet_%s_pred_fpn%d" % (tower, cfg.k_min))
         return names
 
+    # Engine choice per convolution: the Winograd F(2x2,3x3) kernel wherever the
+    # output is >= 128 channels wide (all tower layers, cls_pred, every data
+    # gradient), the direct kernel for the 36-channel bbox_pred forward.
+    # SSAD_CONV_ENGINE=direct forces the direct kernel everywhere.
+    def _use_wino(self, cout):
+        return self.wino and cout >= 128
+
+    def _pack(self, w, want_fwd, want_dgrad):
+        """-> (fwd_packed, dgrad_packed) in the layout of the engine that will
+        consume each (forward: Cout outputs; data gradient: Cin outputs)."""
+        cout, cin = w.shape[0], w.shape[1]
+        pf = pd = None
+        if want_fwd:
+            pf = (K.conv_wino_pack_filter(w, True, False)[0] if self._use_wino(cout)
+                  else K.conv_pack_filter(w, True, False)[0])
+        if want_dgrad:
+            pd = (K.conv_wino_pack_filter(w, False, True)[1] if self._use_wino(cin)
+                  else K.conv_pack_filter(w, False, True)[1])
+        return pf, pd
+
     def pack_student(self, want_dgrad=True):
         for tower in ("cls", "bbox"):
             for name in self._layers(tower):
-                self.packed[name] = K.conv_pack_filter(self.params[name + "_w"], True, want_dgrad)
+                self.packed[name] = self._pack(self.params[name + "_w"], True, want_dgrad)
 
     def pack_teacher(self):
         """The teacher is frozen: pack once."""
         self.t_packed = {}
         for tower in ("cls", "bbox"):
             for name in self._layers(tower):
-                self.t_packed[name] = K.conv_pack_filter(self.teacher[name + "_w"], True, False)[0]
+                self.t_packed[name] = self._pack(self.teacher[name + "_w"], True, False)[0]
 
     # -- forward ----------------------------------------------------------------
     def forward_all(self, teacher_fpn, student_fpn):
@@ -167,19 +189,20 @@ class DistillHeads(object):
                 probs.append(dict(xs=sx[t], packed=self.packed[name][0],
                                   bias=self.params[name + "_b"], out=out))
                 sx[t] = out
-            K.conv3x3_forward_multi(probs, self.D, relu=True)
+            K.conv3x3_forward_multi(probs, self.D, relu=True, wino=self._use_wino(self.D))
         cp = self._layers("cls")[-1]
+        wn = self._use_wino(self.A * self.C)
         K.conv3x3_forward(tx["cls"], self.t_packed[cp], self.teacher[cp + "_b"], self.A * self.C,
-                          sigmoid=True, out=self.t_prob)
+                          sigmoid=True, out=self.t_prob, wino=wn)
         K.conv3x3_forward(sx["cls"], self.packed[cp][0], self.params[cp + "_b"], self.A * self.C,
-                          out=self.cls_logits)
+                          out=self.cls_logits, wino=wn)
         bp = self._layers("bbox")[-1]
         probs = [dict(xs=sx["bbox"], packed=self.packed[bp][0], bias=self.params[bp + "_b"],
                       out=self.bbox_pred)]
         if self.teacher_bbox_tower:
             probs.append(dict(xs=tx["bbox"], packed=self.t_packed[bp],
                               bias=self.teacher[bp + "_b"], out=self.t_bbox))
-        K.conv3x3_forward_multi(probs, 4 * self.A)
+        K.conv3x3_forward_multi(probs, 4 * self.A, wino=self._use_wino(4 * self.A))
         return self.cls_logits, self.bbox_pred
 
     # -- losses -------------------------------------------------------------------
@@ -247,7 +270,7 @@ class DistillHeads(object):
             Cout = self.params[name + "_b"].numel()
             K.conv3x3_wgrad(x_in, dy[t], Cout, dW=self.grads[name + "_w"], db=self.grads[name + "_b"])
             dy[t] = K.conv3x3_forward(dy[t], self.packed[name][1], None, self.D, mask_by=x_in,
-                                      out=self.dbuf[t][nl & 1])
+                                      out=self.dbuf[t][nl & 1], wino=self._use_wino(self.D))
         for li in range(nl - 1, -1, -1):
             probs = []
             for t in ("cls", "bbox"):
@@ -259,7 +282,7 @@ class DistillHeads(object):
                 probs.append(dict(xs=dy[t], packed=self.packed[name][1], bias=None, out=out,
                                   mask_by=x_in if li > 0 else None))
                 dy[t] = out
-            K.conv3x3_forward_multi(probs, self.D)
+            K.conv3x3_forward_multi(probs, self.D, wino=self._use_wino(self.D))
             if li == nl // 2:
                 self._allreduce_async("late")
         self._allreduce_async("early")
