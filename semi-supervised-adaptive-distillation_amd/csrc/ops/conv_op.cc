@@ -61,6 +61,15 @@ bool IsSubnetGeometry(const ConvGeometry& g) {
          g.pads == vector<int>{1, 1, 1, 1};
 }
 
+// Algorithm choice, like cuDNN's internal one (conv_op_cudnn.cc:541-558):
+// Winograd F(2x2,3x3) for outputs >= 128 channels wide, the direct kernel
+// otherwise; arg hip_algo = "direct" | "winograd" overrides.
+bool UseWinograd(const string& algo, int out_channels) {
+  if (algo == "direct") return false;
+  if (algo == "winograd") return true;
+  return out_channels >= 128;
+}
+
 namespace {
 enum { INPUT = 0, FILTER = 1, BIAS = 2, OUTPUT_GRAD = 2 };
 enum { FILTER_GRAD = 0, BIAS_OR_INPUT_GRAD = 1, INPUT_GRAD = 2 };
@@ -89,12 +98,20 @@ bool ConvOp<float, HIPContext>::RunOnDevice() {
   Y->Resize(N, M, H, W);   // 3x3 / s1 / p1 keeps the spatial size
 
   hipStream_t s = context_.hip_stream();
-  packed_filter_.Resize((TIndex)ssad_conv_packed_filter_floats(M, C));
-  float* packed = packed_filter_.mutable_data<float>();
-  CAFFE_ENFORCE_EQ(ssad_conv_pack_filter(filter.data<float>(), M, C, packed, nullptr, s), 0);
   ssad_conv_level lv{X.data<float>(), Y->mutable_data<float>(), nullptr, N, H, W, nullptr, nullptr};
-  const int rc = ssad_conv3x3_forward(&lv, 1, packed, bias, M, C,
-                                      fuse_relu_ ? SSAD_CONV_RELU : 0, s);
+  const int flags = fuse_relu_ ? SSAD_CONV_RELU : 0;
+  int rc;
+  if (UseWinograd(algo_, M)) {
+    packed_filter_.Resize((TIndex)ssad_conv_wino_filter_floats(M, C));
+    float* packed = packed_filter_.mutable_data<float>();
+    CAFFE_ENFORCE_EQ(ssad_conv_wino_pack_filter(filter.data<float>(), M, C, packed, nullptr, s), 0);
+    rc = ssad_conv3x3_forward_wino(&lv, 1, packed, bias, M, C, flags, s);
+  } else {
+    packed_filter_.Resize((TIndex)ssad_conv_packed_filter_floats(M, C));
+    float* packed = packed_filter_.mutable_data<float>();
+    CAFFE_ENFORCE_EQ(ssad_conv_pack_filter(filter.data<float>(), M, C, packed, nullptr, s), 0);
+    rc = ssad_conv3x3_forward(&lv, 1, packed, bias, M, C, flags, s);
+  }
   CAFFE_ENFORCE_EQ(rc, 0, "Conv launch failed");
   return true;
 }
@@ -134,13 +151,20 @@ bool ConvGradientOp<float, HIPContext>::RunOnDevice() {
   if (OutputSize() == 3 || (no_bias_ && OutputSize() == 2)) {
     auto* dX = Output(no_bias_ ? BIAS_OR_INPUT_GRAD : INPUT_GRAD);
     dX->ResizeLike(X);
-    packed_filter_.Resize((TIndex)ssad_conv_packed_filter_floats(C, M));
-    float* packed = packed_filter_.mutable_data<float>();
-    CAFFE_ENFORCE_EQ(ssad_conv_pack_filter(filter.data<float>(), M, C, nullptr, packed, s), 0);
     ssad_conv_level dl{dY.data<float>(), dX->mutable_data<float>(),
                        relu_grad_on_input_ ? X.data<float>() : nullptr, N, H, W, nullptr, nullptr};
-    rc = ssad_conv3x3_forward(&dl, 1, packed, nullptr, C, M,
-                              relu_grad_on_input_ ? SSAD_CONV_MASK_AUX : 0, s);
+    const int flags = relu_grad_on_input_ ? SSAD_CONV_MASK_AUX : 0;
+    if (UseWinograd(algo_, C)) {      // the data gradient has C output channels
+      packed_filter_.Resize((TIndex)ssad_conv_wino_filter_floats(C, M));
+      float* packed = packed_filter_.mutable_data<float>();
+      CAFFE_ENFORCE_EQ(ssad_conv_wino_pack_filter(filter.data<float>(), M, C, nullptr, packed, s), 0);
+      rc = ssad_conv3x3_forward_wino(&dl, 1, packed, nullptr, C, M, flags, s);
+    } else {
+      packed_filter_.Resize((TIndex)ssad_conv_packed_filter_floats(C, M));
+      float* packed = packed_filter_.mutable_data<float>();
+      CAFFE_ENFORCE_EQ(ssad_conv_pack_filter(filter.data<float>(), M, C, nullptr, packed, s), 0);
+      rc = ssad_conv3x3_forward(&dl, 1, packed, nullptr, C, M, flags, s);
+    }
     CAFFE_ENFORCE_EQ(rc, 0, "ConvGradient (data) launch failed");
   }
   return true;

@@ -19,6 +19,7 @@
 //   Conv          fuse_relu=1             Y = max(conv, 0)  (Conv + in-place Relu)
 //   ConvGradient  relu_grad_on_input=1    dX masked by X > 0 (= ReluGradient of
 //                                         the in-place Relu that produced X)
+//   both          hip_algo="direct"|"winograd"   pin the algorithm (default: by width)
 #ifndef C2HIP_CONV_OP_H_
 #define C2HIP_CONV_OP_H_
 
@@ -36,6 +37,7 @@ struct ConvGeometry {
 // the reference does; shared by Conv and ConvGradient.
 ConvGeometry ParseConvGeometry(const OperatorBase& op);
 bool IsSubnetGeometry(const ConvGeometry& g);   // 3x3 / s1 / p1 / d1 / g1 / NCHW
+bool UseWinograd(const string& algo, int out_channels);
 
 template <typename T, class Context>
 class ConvOp final : public Operator<Context> {
@@ -44,7 +46,8 @@ class ConvOp final : public Operator<Context> {
   ConvOp(const OperatorDef& def, Workspace* ws)
       : Operator<Context>(def, ws),
         geom_(ParseConvGeometry(*this)),
-        fuse_relu_(OperatorBase::GetSingleArgument<int>("fuse_relu", 0)) {
+        fuse_relu_(OperatorBase::GetSingleArgument<int>("fuse_relu", 0)),
+        algo_(OperatorBase::GetSingleArgument<string>("hip_algo", "auto")) {
     if (!IsSubnetGeometry(geom_))
       throw UnsupportedOperatorFeature(
           "HIP Conv engine implements kernel=3 stride=1 pad=1 dilation=1 group=1 NCHW only");
@@ -54,6 +57,7 @@ class ConvOp final : public Operator<Context> {
  private:
   ConvGeometry geom_;
   int fuse_relu_;
+  string algo_;
   Tensor<Context> packed_filter_;
 };
 
@@ -65,7 +69,8 @@ class ConvGradientOp final : public Operator<Context> {
       : Operator<Context>(def, ws),
         geom_(ParseConvGeometry(*this)),
         no_bias_(OperatorBase::GetSingleArgument<int>("no_bias", 0)),
-        relu_grad_on_input_(OperatorBase::GetSingleArgument<int>("relu_grad_on_input", 0)) {
+        relu_grad_on_input_(OperatorBase::GetSingleArgument<int>("relu_grad_on_input", 0)),
+        algo_(OperatorBase::GetSingleArgument<string>("hip_algo", "auto")) {
     CAFFE_ENFORCE(!(no_bias_ && OutputSize() == 3),
                   "If bias is not present, you should not have 3 grad output.");
     if (!IsSubnetGeometry(geom_))
@@ -78,6 +83,7 @@ class ConvGradientOp final : public Operator<Context> {
   ConvGeometry geom_;
   bool no_bias_;
   int relu_grad_on_input_;
+  string algo_;
   Tensor<Context> packed_filter_;
   Tensor<Context> workspace_;
 };
