@@ -243,21 +243,42 @@ __global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) 
     if (ch + 1 < chunks) transform(raw + ((ch + 1) & 1) * RAW, vbuf + ((ch + 1) & 1) * VBUF);
     if (active) {
       const float* vb = bbase + (ch & 1) * VBUF;
+      // B operands are double-buffered in registers: the four LDS reads of
+      // step+1 are issued before the eight MFMAs of step, so a 32-cycle MFMA
+      // never waits on an LDS round trip.
+      float bc[4][2], bn[4][2];
+#pragma unroll
+      for (int xr = 0; xr < 4; ++xr)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) bc[xr][g] = vb[(xr * KC) * VP + g * 16];
 #pragma unroll
       for (int step = 0; step < 8; ++step) {           // step = ks*4 + xq
         const float4 a3 = astream[(long long)(ch * 8 + step + 3) * 64];
-        const int ks = step >> 2, xq = step & 3;
+        if (step < 7) {
+          const int ks = (step + 1) >> 2, xq = (step + 1) & 3;
+#pragma unroll
+          for (int xr = 0; xr < 4; ++xr)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+              bn[xr][g] = vb[((xq * 4 + xr) * KC + ks * 4) * VP + g * 16];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int xq = step & 3;
         const float av[4] = {a0.x, a0.y, a0.z, a0.w};
 #pragma unroll
         for (int xr = 0; xr < 4; ++xr) {
           const int xi = xq * 4 + xr;
 #pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            const float b = vb[(xi * KC + ks * 4) * VP + g * 16];
-            acc[xi][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[xr], b, acc[xi][g], 0, 0, 0);
-          }
+          for (int g = 0; g < 2; ++g)
+            acc[xi][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[xr], bc[xr][g], acc[xi][g], 0, 0, 0);
         }
         a0 = a1; a1 = a2; a2 = a3;
+        if (step < 7) {
+#pragma unroll
+          for (int xr = 0; xr < 4; ++xr)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) bc[xr][g] = bn[xr][g];
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
