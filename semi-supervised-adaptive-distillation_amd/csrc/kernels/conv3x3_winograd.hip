@@ -9,14 +9,14 @@
 // [Cout x Cin] x [Cin x tiles] GEMMs that run on v_mfma_f32_16x16x4_f32.
 //
 // Workgroup = 8 wavefronts = 128 output channels x one 8x16-pixel output
-// patch (4 x 8 tiles) of one image of one level.  Per 8-channel chunk:
+// patch (4 x 8 tiles) of one image of one level.  Per KC-channel chunk:
 //   1. the raw 10x18 input patch is staged into LDS by raw buffer loads
 //      (zero outside the image), two chunks ahead;
 //   2. all 512 threads apply B^T d B (thread = channel x tile x half, 12 LDS
 //      reads, 24 add/sub, 8 LDS writes) into the transformed-input buffer
 //      V[xi][channel][tile], one chunk ahead;
 //   3. each wave (16 output channels x 32 tiles x 16 xi = 128 accumulator
-//      VGPRs) issues 64 MFMAs: the A operand (transformed filter) is a linear
+//      VGPRs) issues 8*KC MFMAs: the A operand (transformed filter) is a linear
 //      16-byte-per-lane stream from the pre-packed filter, prefetched three
 //      steps ahead; the B operand is `ds_read_b32 base+imm` from V (channel
 //      pitch 48 floats keeps the k / k+1 rows of an MFMA on disjoint banks).
@@ -38,7 +38,12 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int KC = 8;            // input channels per chunk
+#ifndef WINO_KC
+#define WINO_KC 16
+#endif
+constexpr int KC = WINO_KC;      // input channels per chunk (multiple of 8)
+constexpr int KS = KC / 4;       // MFMA k-steps (4 channels each) per chunk
+constexpr int STEPS = KS * 4;    // A-stream float4 per lane per chunk
 constexpr int PR = 8, PC = 16;   // output patch rows / cols (4 x 8 tiles of 2x2)
 constexpr int RP = 20;           // raw LDS row pitch (18 used)
 constexpr int RS = (PR + 2) * RP;        // raw floats per channel
@@ -62,7 +67,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, in
 // ---------------------------------------------------------------------------
 // Filter transform + packing:  U = G g G^T, stored in MFMA A-operand order
 //   packed[mt][chunk][ks][xq][lane][xr],  lane = k*16 + i:
-//     U[xi = 4*xq + xr][out = mt*16 + i][in = chunk*8 + ks*4 + k]
+//     U[xi = 4*xq + xr][out = mt*16 + i][in = chunk*KC + ks*4 + k]
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float wino_u(const float* g, int xi) {
   // rows of G g: r0 = g0, r1 = (g0+g1+g2)/2, r2 = (g0-g1+g2)/2, r3 = g2
@@ -85,12 +90,13 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, int Cout, int Cin,
     if (!dst) continue;
     const int M = pass == 0 ? Cout : Cin, K = pass == 0 ? Cin : Cout;
     const int mtiles = cdiv(M, 16), chunks = cdiv(K, KC);
-    const long long total = (long long)mtiles * chunks * 2048;
+    const long long total = (long long)mtiles * chunks * STEPS * 256;
     if (tid >= total + 1024) continue;
     float v = 0.0f;
     if (tid < total) {
-      const int xr = tid & 3, lane = (tid >> 2) & 63, xq = (tid >> 8) & 3, ks = (tid >> 10) & 1;
-      const long long r = tid >> 11;
+      const int xr = tid & 3, lane = (tid >> 2) & 63, xq = (tid >> 8) & 3;
+      long long r = tid >> 10;
+      const int ks = (int)(r % KS); r /= KS;
       const int chunk = (int)(r % chunks), mt = (int)(r / chunks);
       const int out = mt * 16 + (lane & 15), in = chunk * KC + ks * 4 + (lane >> 4);
       if (out < M && in < K) {
@@ -184,12 +190,16 @@ __global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) 
       if (s_lds[it] >= 0) buf[s_lds[it]] = sreg[it];
   };
 
-  // ---- input transform map: thread = (half, channel, tile) --------------------
+  // ---- input transform map: thread = (half, channel mod 8, tile), KC/8 rounds ----
   const int t_tile = tid & 31, t_c = (tid >> 5) & 7, t_half = tid >> 8;
   const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
   const int t_src = t_c * RS + (2 * t_ty + t_half) * RP + 2 * t_tx;   // rows half..half+2
   const int t_dst = (t_half * 8 * KC + t_c) * VP + t_tile;            // xi = 8*half + ...
-  auto transform = [&](const float* rb, float* vb) {
+  auto transform = [&](const float* rb0, float* vb0) {
+#pragma unroll
+   for (int rnd = 0; rnd < KC / 8; ++rnd) {
+    const float* rb = rb0 + rnd * 8 * RS;
+    float* vb = vb0 + rnd * 8 * VP;
     float d[3][4];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -211,13 +221,14 @@ __global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) 
       o[2 * KC * VP] = t[a][2] - t[a][1];
       o[3 * KC * VP] = t[a][1] - t[a][3];
     }
+   }
   };
 
   // ---- MFMA operands -------------------------------------------------------------
   const int kq = lane >> 4, jn = lane & 15;
   const float* bbase = vbuf + kq * VP + jn;
   const float4* astream = reinterpret_cast<const float4*>(L.packed) +
-                          (long long)(active ? mt : 0) * args.chunks * 8 * 64 + lane;
+                          (long long)(active ? mt : 0) * args.chunks * STEPS * 64 + lane;
 
   f32x4 acc[16][2];
 #pragma unroll
@@ -252,9 +263,9 @@ __global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) 
 #pragma unroll
         for (int g = 0; g < 2; ++g) bc[xr][g] = vb[(xr * KC) * VP + g * 16];
 #pragma unroll
-      for (int step = 0; step < 8; ++step) {           // step = ks*4 + xq
-        const float4 a3 = astream[(long long)(ch * 8 + step + 3) * 64];
-        if (step < 7) {
+      for (int step = 0; step < STEPS; ++step) {       // step = ks*4 + xq
+        const float4 a3 = astream[(long long)(ch * STEPS + step + 3) * 64];
+        if (step < STEPS - 1) {
           const int ks = (step + 1) >> 2, xq = (step + 1) & 3;
 #pragma unroll
           for (int xr = 0; xr < 4; ++xr)
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) 
             acc[xi][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[xr], bc[xr][g], acc[xi][g], 0, 0, 0);
         }
         a0 = a1; a1 = a2; a2 = a3;
-        if (step < 7) {
+        if (step < STEPS - 1) {
 #pragma unroll
           for (int xr = 0; xr < 4; ++xr)
 #pragma unroll
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) 
 extern "C" {
 
 size_t ssad_conv_wino_filter_floats(int M, int K) {
-  return (size_t)cdiv(M, 16) * cdiv(K, KC) * 2048 + 1024;
+  return (size_t)cdiv(M, 16) * cdiv(K, KC) * STEPS * 256 + 1024;
 }
 
 int ssad_conv_wino_pack_filter(const float* w, int Cout, int Cin, float* packed_fwd,
