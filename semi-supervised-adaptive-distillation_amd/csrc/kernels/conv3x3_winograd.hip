@@ -18,8 +18,10 @@
 //   3. each wave (16 output channels x 32 tiles x 16 xi = 128 accumulator
 //      VGPRs) issues 8*KC MFMAs: the A operand (transformed filter) is a linear
 //      16-byte-per-lane stream from the pre-packed filter, prefetched three
-//      steps ahead; the B operand is `ds_read_b32 base+imm` from V (channel
-//      pitch 48 floats keeps the k / k+1 rows of an MFMA on disjoint banks).
+//      steps ahead; the B operands of both tile groups come from one
+//      `ds_read_b64 base+imm` of V (32-float channel rows: the k / k+1 rows of
+//      an MFMA fall on disjoint halves of the 64 banks), double-buffered in
+//      registers one step ahead.
 //   One barrier per chunk.  The epilogue applies A^T M A lane-locally (the 16
 //   xi accumulators of one (channel, tile) sit in the same lane/register
 //   slot), then bias / ReLU / Sigmoid / ReLU-gradient mask as the direct
@@ -48,7 +50,7 @@ constexpr int PR = 8, PC = 16;   // output patch rows / cols (4 x 8 tiles of 2x2
 constexpr int RP = 20;           // raw LDS row pitch (18 used)
 constexpr int RS = (PR + 2) * RP;        // raw floats per channel
 constexpr int RAW = KC * RS;             // raw floats per buffer
-constexpr int VP = 48;                   // V channel pitch (32 tiles used)
+constexpr int VP = 32;                   // V channel pitch: 32 tiles stored as [tile&15][tile>>4]
 constexpr int VBUF = 16 * KC * VP;       // transformed floats per buffer
 constexpr int kBlock = 512;
 constexpr int BM = 128;                  // output channels per workgroup
@@ -194,7 +196,9 @@ __global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) 
   const int t_tile = tid & 31, t_c = (tid >> 5) & 7, t_half = tid >> 8;
   const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
   const int t_src = t_c * RS + (2 * t_ty + t_half) * RP + 2 * t_tx;   // rows half..half+2
-  const int t_dst = (t_half * 8 * KC + t_c) * VP + t_tile;            // xi = 8*half + ...
+  // tile t is stored at (t & 15) * 2 + (t >> 4): the two tile groups a lane
+  // feeds to its MFMAs are adjacent, one ds_read_b64 fetches both
+  const int t_dst = (t_half * 8 * KC + t_c) * VP + (t_tile & 15) * 2 + (t_tile >> 4);   // xi = 8*half + ...
   auto transform = [&](const float* rb0, float* vb0) {
 #pragma unroll
    for (int rnd = 0; rnd < KC / 8; ++rnd) {
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) 
 
   // ---- MFMA operands -------------------------------------------------------------
   const int kq = lane >> 4, jn = lane & 15;
-  const float* bbase = vbuf + kq * VP + jn;
+  const float* bbase = vbuf + kq * VP + jn * 2;
   const float4* astream = reinterpret_cast<const float4*>(L.packed) +
                           (long long)(active ? mt : 0) * args.chunks * STEPS * 64 + lane;
 
@@ -259,19 +263,20 @@ __global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) 
       // never waits on an LDS round trip.
       float bc[4][2], bn[4][2];
 #pragma unroll
-      for (int xr = 0; xr < 4; ++xr)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) bc[xr][g] = vb[(xr * KC) * VP + g * 16];
+      for (int xr = 0; xr < 4; ++xr) {
+        const float2 b2 = *reinterpret_cast<const float2*>(vb + (xr * KC) * VP);
+        bc[xr][0] = b2.x; bc[xr][1] = b2.y;
+      }
 #pragma unroll
       for (int step = 0; step < STEPS; ++step) {       // step = ks*4 + xq
         const float4 a3 = astream[(long long)(ch * STEPS + step + 3) * 64];
         if (step < STEPS - 1) {
           const int ks = (step + 1) >> 2, xq = (step + 1) & 3;
 #pragma unroll
-          for (int xr = 0; xr < 4; ++xr)
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-              bn[xr][g] = vb[((xq * 4 + xr) * KC + ks * 4) * VP + g * 16];
+          for (int xr = 0; xr < 4; ++xr) {
+            const float2 b2 = *reinterpret_cast<const float2*>(vb + ((xq * 4 + xr) * KC + ks * 4) * VP);
+            bn[xr][0] = b2.x; bn[xr][1] = b2.y;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         const int xq = step & 3;
