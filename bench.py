@@ -231,7 +231,7 @@ def main():
         try:   # HBM bytes per launch from the committed PMC passes (profiles/README.md)
             import glob
             pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]))
-            want = "wino_conv_kernel" if ks and ks["wino"] else "conv3x3_kernel<8, 1"
+            want = "wino_conv_z_kernel" if ks and ks["wino"] else "conv3x3_kernel<8, 1"
             ks_ = [v for k, v in pm["kernels"].items() if k.startswith(want)]
             if ks_:
                 traffic = int(sum((v.get("FETCH_SIZE_KB_raw", 0) + v.get("WRITE_SIZE_KB", 0)) * 1024
@@ -253,7 +253,7 @@ def main():
                        "focal_loss": [float(v) for v in heads.focal_losses.cpu()],
                        "bbox_loss": [float(v) for v in heads.bbox_losses.cpu()]},
             "roofline": {
-                "kernel": ("wino_conv_kernel (subnet conv3x3 fwd / data-grad, Winograd F(2x2,3x3) on "
+                "kernel": ("wino_conv_z_kernel (subnet conv3x3 fwd / data-grad, Winograd F(2x2,3x3) on "
                            "fp32 MFMA)" if ks and ks["wino"] else
                            "conv3x3_kernel<8,1,*> (subnet conv3x3 fwd / data-grad, fp32 MFMA)"),
                 "bound": "mfma", "achieved": round(ks["tflops"], 2) if ks else None,

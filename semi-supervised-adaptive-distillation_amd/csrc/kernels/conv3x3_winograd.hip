@@ -8,24 +8,20 @@
 // 16 element-wise products summed over input channels, i.e. 16 independent
 // [Cout x Cin] x [Cin x tiles] GEMMs that run on v_mfma_f32_16x16x4_f32.
 //
-// Workgroup = 8 wavefronts = 128 output channels x one 8x16-pixel output
-// patch (4 x 8 tiles) of one image of one level.  Per KC-channel chunk:
-//   1. the raw 10x18 input patch is staged into LDS by raw buffer loads
-//      (zero outside the image), two chunks ahead;
-//   2. all 512 threads apply B^T d B (thread = channel x tile x half, 12 LDS
-//      reads, 24 add/sub, 8 LDS writes) into the transformed-input buffer
-//      V[xi][channel][tile], one chunk ahead;
-//   3. each wave (16 output channels x 32 tiles x 16 xi = 128 accumulator
-//      VGPRs) issues 8*KC MFMAs: the A operand (transformed filter) is a linear
-//      16-byte-per-lane stream from the pre-packed filter, prefetched three
-//      steps ahead; the B operands of both tile groups come from one
-//      `ds_read_b64 base+imm` of V (32-float channel rows: the k / k+1 rows of
-//      an MFMA fall on disjoint halves of the 64 banks), double-buffered in
-//      registers one step ahead.
-//   One barrier per chunk.  The epilogue applies A^T M A lane-locally (the 16
-//   xi accumulators of one (channel, tile) sit in the same lane/register
-//   slot), then bias / ReLU / Sigmoid / ReLU-gradient mask as the direct
-//   kernel.
+// Two kernels share the data layout (8 wavefronts = 128 output channels x one
+// 8x16-pixel output patch = 4 x 8 tiles; per KC-channel chunk the 10x18 raw
+// patch goes to LDS, B^T d B turns it into V[xi][channel][tile], and each wave
+// (16 output channels x 32 tiles x 16 xi = 128 accumulator VGPRs) issues 8*KC
+// MFMAs whose A operand is a linear 16-byte-per-lane stream from the
+// pre-packed filter and whose B operands are `ds_read_b64 base+imm` of V):
+//   wino_conv_kernel    one workgroup per tile, register-staged raw patch,
+//                       transform burst.  Any Cin.  (SSAD_WINO_VARIANT=0)
+//   wino_conv_z_kernel  the default for Cin % 16 == 0: persistent workgroups,
+//                       LDS-DMA staging, transform / staging / tile bookkeeping
+//                       threaded through the MFMA steps (see its header).
+// The epilogue applies A^T M A lane-locally (the 16 xi accumulators of one
+// (channel, tile) sit in the same lane/register slot), then bias / ReLU /
+// Sigmoid / ReLU-gradient mask as the direct kernel.
 //
 // fp32 Winograd F(2,3) keeps ~1e-6 relative accuracy (inputs are only added /
 // subtracted, filters scaled by 1/2, 1/4); parity tests bound it at the same
@@ -33,12 +29,16 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "ssad_kernels.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef WINO_KC
 #define WINO_KC 16
@@ -132,6 +132,7 @@ struct WArgs {
   WLevel lv[SSAD_MAX_CONV_PROBLEMS];
   int n_levels;
   int M, K, chunks, flags;
+  int patches, mblocks;   // persistent variant: tiles = patches x mblocks
 };
 
 __global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) {
@@ -346,6 +347,463 @@ __global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) 
   }
 }
 
+constexpr int NRAW = 3;
+constexpr unsigned kOOBOff = 0x80000000u;
+
+#ifdef WINO_TIMELINE
+__device__ unsigned long long g_dbg[2][64][8];
+#define DBG(role, it, k) \
+  if (dbg_on && (it) < 64) g_dbg[role][it][k] = __builtin_readcyclecounter()
+#else
+#define DBG(role, it, k)
+#endif
+
+struct WTile {
+  int l, n, y0, x0, mb;
+};
+
+// ---------------------------------------------------------------------------
+// Variant Z: persistent, 8 symmetric waves, LDS-DMA staging, everything
+// threaded through the MFMA steps.
+//
+// Lessons from the variants above (cycle stamps, tower layer, bs 16):
+//  * the B^T d B burst is LDS-throughput bound (~1700 of 10800 cycles per
+//    chunk) and helper waves cannot do it (no VALU issue next to MFMA waves);
+//  * a wave alone on a SIMD is latency-bound on the filter stream, so the
+//    two waves of a SIMD must both stay in their MFMA steps all the time;
+//  * vmcnt retires in order, so HBM staging loads stall a wave's next filter
+//    operand -- unless that operand was requested BEFORE the staging loads.
+// So: no helper waves, <= 256 VGPRs (2 waves/SIMD as before), and per chunk s
+//   step 0      : each wave issues its 7 `buffer_load_dword ... lds` of chunk
+//                 s+3 (no VGPR data, no ds_write); the filter operands of
+//                 steps 0-7 are already in flight / in registers (ring of 8
+//                 float4, refilled right after use, i.e. 8 steps ahead);
+//   steps 4r+1  : 4 ds_read_b64 of the raw patch of chunk s+1 (round r),
+//   steps 4r+3  : 8 VALU + 4 ds_write_b32 into V[s+1];
+//   every step  : 8 MFMAs, B operands single-buffered (ds_read_b64 reissued
+//                 into the registers an MFMA pair just consumed);
+//   one barrier.
+// The raw patch lives in LDS as channel pairs with row pitch 40
+// (addr = (c>>1)*400 + r*40 + (c&1)*20 + q): the transform's ds_read_b64 of a
+// half-wave (4 x 8 tiles of one channel) then covers all 64 banks once.
+// Tiles of a workgroup are decoded once, in parallel, into an LDS list.
+// ---------------------------------------------------------------------------
+constexpr int ZP = 40;                    // raw row pitch (two channels side by side)
+constexpr int ZCP = (PR + 2) * ZP;        // 400 floats per channel pair
+constexpr int ZRAW = (KC / 2) * ZCP;      // 3200 floats = 50 wave-loads
+constexpr int ZL = 7;                     // wave-loads per wave per chunk (8 x 7 = 56 >= 50)
+constexpr int ZRAWP = 8 * ZL * 64;        // padded raw buffer (dummy loads land in the pad)
+constexpr int ZNT = 256;                  // tiles per workgroup in the LDS list
+constexpr int AD = 8;                     // filter operand ring depth (steps)
+static_assert(ZRAW <= ZRAWP && STEPS == 16 && AD == 8, "variant Z is written for KC = 16");
+
+__global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args) {
+  __shared__ float raw[NRAW * ZRAWP];
+  __shared__ float vbuf[2 * VBUF];
+  __shared__ int lv_start[32], lv_tx[32], lv_per[32];
+  __shared__ int trec[ZNT * 5];
+  __shared__ unsigned zvoff[8 * ZL * 64];   // per wave, per wave-load, per lane
+
+  const int K = args.K, M = args.M;
+  const int chunks = args.chunks;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int total = args.patches * args.mblocks;
+  const int my_n = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int S = my_n * chunks;     // flattened (tile, chunk) sequence length
+
+  // ---- level tables and this workgroup's tile list ----
+  if (tid < 32) {
+    int v = 0x7fffffff, tx = 1, per = 1;
+#pragma unroll
+    for (int i = 0; i < SSAD_MAX_CONV_PROBLEMS; ++i)
+      if (tid == i && i < args.n_levels) {
+        v = args.lv[i].block_start;
+        tx = args.lv[i].tiles_x;
+        per = args.lv[i].tiles_x * args.lv[i].tiles_y;
+      }
+    lv_start[tid] = v; lv_tx[tid] = tx; lv_per[tid] = per;
+  }
+  __syncthreads();
+  for (int i = tid; i < my_n; i += kBlock) {
+    const int t = (int)blockIdx.x + i * (int)gridDim.x;
+    const int mb = t / args.patches;
+    int pid = t - mb * args.patches;
+    int l = -1;
+    for (int k = 0; k < args.n_levels; ++k) l += pid >= lv_start[k];
+    pid -= lv_start[l];
+    const int per = lv_per[l], tx = lv_tx[l];
+    const int n = pid / per;
+    pid -= n * per;
+    const int ty0 = pid / tx, tx0 = pid - ty0 * tx;
+    int* r = trec + i * 5;
+    r[0] = l; r[1] = n; r[2] = ty0 * PR; r[3] = tx0 * PC; r[4] = mb;
+  }
+  __syncthreads();
+  auto get_tile = [&](int i) {
+    const int* r = trec + i * 5;
+    WTile o;
+    o.l = __builtin_amdgcn_readfirstlane(r[0]);
+    o.n = __builtin_amdgcn_readfirstlane(r[1]);
+    o.y0 = __builtin_amdgcn_readfirstlane(r[2]);
+    o.x0 = __builtin_amdgcn_readfirstlane(r[3]);
+    o.mb = __builtin_amdgcn_readfirstlane(r[4]);
+    return o;
+  };
+
+  // ---- staging: wave-load k = wave + 8j covers raw slots e = 64k + lane ----
+  // The per-tile byte offsets live in LDS (zvoff), not in VGPRs: a spilled
+  // offset would be reloaded from scratch with a vmcnt(0) wait in the middle
+  // of the filter-operand ring.
+  __amdgpu_buffer_rsrc_t xrsrc;
+  int chunk_bytes = 0;
+  int ld_tile = 0, ld_ch = 0, ld_buf = 0;      // load cursor over (tile, chunk), its raw buffer
+  unsigned* myvoff = zvoff + wave * (ZL * 64) + lane;
+  auto dma_next = [&]() {
+    if (ld_ch == 0) {
+      const WTile Tt = get_tile(ld_tile);
+      const WLevel& L = args.lv[Tt.l];
+      const int H = L.H, W = L.W, HW = H * W;
+      xrsrc = uniform_rsrc(L.x + (long long)Tt.n * K * HW, K * HW * 4);
+      chunk_bytes = KC * HW * 4;
+#pragma unroll 1
+      for (int j = 0; j < ZL; ++j) {
+        const int e = (wave + 8 * j) * 64 + lane;
+        const int p = e / ZCP, rem = e - p * ZCP;
+        const int r = rem / ZP, cq = rem - r * ZP;
+        const int hi = cq >= ZP / 2 ? 1 : 0;
+        const int q = cq - hi * (ZP / 2);
+        const int gy = Tt.y0 - 1 + r, gx = Tt.x0 - 1 + q;
+        const bool ok = (e < ZRAW) & (q < PC + 2) & ((unsigned)gy < (unsigned)H) &
+                        ((unsigned)gx < (unsigned)W);
+        myvoff[j * 64] = ok ? (unsigned)(((2 * p + hi) * HW + gy * W + gx) * 4) : kOOBOff;
+      }
+    }
+    const int soff = ld_ch * chunk_bytes;
+    float* dst = raw + ld_buf * ZRAWP + wave * 64;
+    unsigned vo[ZL];
+#pragma unroll
+    for (int j = 0; j < ZL; ++j) vo[j] = myvoff[j * 64];
+#pragma unroll
+    for (int j = 0; j < ZL; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(dst + j * 512),
+                                               4, vo[j], soff, 0, 0);
+    if (++ld_ch == chunks) { ld_ch = 0; ++ld_tile; }
+    if (++ld_buf == NRAW) ld_buf = 0;
+  };
+
+  // ---- transform: work item = (tile, channel, row a); wave w owns row a = w & 3 for
+  //      channels rnd*4 + (w>>2)*2 + (lane>>5);  row a of B^T d is dA + sg * dB:
+  //      a=0: d0-d2   a=1: d1+d2   a=2: d2-d1   a=3: d1-d3
+  const int t_row = wave & 3;
+  const int t_ra = t_row == 0 ? 0 : t_row == 2 ? 2 : 1;
+  const int t_rb = t_row == 0 ? 2 : t_row == 1 ? 2 : t_row == 2 ? 1 : 3;
+  const float t_sg = t_row == 1 ? 1.0f : -1.0f;
+  const int t_tile = lane & 31, t_c = (wave >> 2) * 2 + (lane >> 5);   // channel within a round of 4
+  const int t_src = (t_c >> 1) * ZCP + (t_c & 1) * (ZP / 2) + (2 * (t_tile >> 3)) * ZP + 2 * (t_tile & 7);
+  const int t_dst = (t_row * 4 * KC + t_c) * VP + (t_tile & 15) * 2 + (t_tile >> 4);
+  const int t_oa = t_src + t_ra * ZP, t_ob = t_src + t_rb * ZP;
+  auto xf_load = [&](const float* rb0, int rnd, float2 (&d)[4]) {
+    d[0] = *reinterpret_cast<const float2*>(rb0 + t_oa + rnd * 2 * ZCP);
+    d[1] = *reinterpret_cast<const float2*>(rb0 + t_oa + rnd * 2 * ZCP + 2);
+    d[2] = *reinterpret_cast<const float2*>(rb0 + t_ob + rnd * 2 * ZCP);
+    d[3] = *reinterpret_cast<const float2*>(rb0 + t_ob + rnd * 2 * ZCP + 2);
+  };
+  auto xf_store = [&](float* vb0, int rnd, const float2 (&d)[4]) {
+    const float t0 = fmaf(t_sg, d[2].x, d[0].x), t1 = fmaf(t_sg, d[2].y, d[0].y);
+    const float t2 = fmaf(t_sg, d[3].x, d[1].x), t3 = fmaf(t_sg, d[3].y, d[1].y);
+    float* o = vb0 + t_dst + rnd * 4 * VP;
+    o[0 * KC * VP] = t0 - t2;
+    o[1 * KC * VP] = t1 + t2;
+    o[2 * KC * VP] = t2 - t1;
+    o[3 * KC * VP] = t1 - t3;
+  };
+  auto transform = [&](const float* rb0, float* vb0) {
+#pragma unroll
+    for (int rnd = 0; rnd < KC / 4; ++rnd) {
+      float2 d[4];
+      xf_load(rb0, rnd, d);
+      xf_store(vb0, rnd, d);
+    }
+  };
+
+  // ---- compute-side per-lane constants ----
+#ifdef WINO_TIMELINE
+  const bool dbg_on = blockIdx.x == 3 && tid == 0;
+#endif
+  const int kq = lane >> 4, jn = lane & 15;
+  const float* bbase = vbuf + kq * VP + jn * 2;
+  const int mtiles = cdiv(M, 16);
+  const int stream_bytes = (mtiles * chunks * STEPS * 256 + 1024) * 4;
+  const unsigned a_voff = lane * 16;
+  auto stream_off = [&](const WTile& Tt) {
+    int mt = Tt.mb * (BM / 16) + wave;
+    if (mt >= mtiles) mt = 0;
+    return __builtin_amdgcn_readfirstlane(mt * chunks * STEPS * 1024);
+  };
+  auto a_load = [&](__amdgpu_buffer_rsrc_t rs, int soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, a_voff, soff, 0));
+  };
+  auto load_bias = [&](const WTile& Tt) {
+    const WLevel& L = args.lv[Tt.l];
+    f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (L.bias) {
+      const __amdgpu_buffer_rsrc_t brsrc = uniform_rsrc(L.bias, M * 4);
+      b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          brsrc, (unsigned)(((Tt.mb * (BM / 16) + wave) * 16 + kq * 4) * 4), 0, 0));
+    }
+    return b;
+  };
+
+  // ---- prologue: chunks 0..2 by DMA, chunk 0 transformed, filter ring primed ----
+  WTile T = get_tile(0);
+  __amdgpu_buffer_rsrc_t arsrc = uniform_rsrc(args.lv[T.l].packed, stream_bytes);
+  int abase = stream_off(T);
+  float4 ar[AD];
+#pragma unroll
+  for (int k = 0; k < AD; ++k) ar[k] = a_load(arsrc, abase + k * 1024);
+  f32x4 bv = load_bias(T);
+  dma_next();
+  if (S > 1) dma_next();
+  if (S > 2) dma_next();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  transform(raw, vbuf);
+  __syncthreads();
+
+  int s = 0;
+  int rbuf = 1;                      // raw buffer holding chunk s+1
+  WTile Tn = T;
+  __amdgpu_buffer_rsrc_t nrsrc = arsrc;
+  int nbase = abase;
+  const int look = chunks > 1 ? 1 : 0;
+  for (int i = 0; i < my_n; ++i) {
+    const int mt = T.mb * (BM / 16) + wave;
+    const bool active = mt < mtiles;
+    f32x4 acc[16][2];
+    // bias folded into the accumulators: b * u u^T, u = (1,0,0,-1), A^T u = (1,1)
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        acc[x][g] = (x == 0 || x == 15) ? bv : (x == 3 || x == 12) ? -bv : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < chunks; ++ch, ++s) {
+      DBG(1, s, 0);
+      // Side jobs, issued from inside the MFMA steps (active waves) so that they
+      // run under MFMAs instead of in front of them:
+      //  * chunk s+3 by DMA into the buffer chunk s vacated.  The ring already
+      //    holds / has requested the filter operands of the next 8 steps, so
+      //    these HBM loads sit behind them in the in-order vmcnt queue;
+      //  * once per tile, the next tile's filter stream position.
+      auto side_dma = [&]() { if (s + 3 < S) dma_next(); };
+      auto side_look = [&]() {
+        if (ch == look && i + 1 < my_n) {
+          Tn = get_tile(i + 1);
+          nrsrc = uniform_rsrc(args.lv[Tn.l].packed, stream_bytes);
+          nbase = stream_off(Tn);
+        }
+      };
+      const bool xf = s + 1 < S;
+      const float* xsrc = raw + rbuf * ZRAWP;
+      float* xdst = vbuf + ((s + 1) & 1) * VBUF;
+      DBG(1, s, 1);
+      // operands 8 steps ahead: past the tile's last chunk they come from the
+      // next tile (nrsrc / nbase are set by side_look at step 6 of chunk `look`,
+      // before the first such load at step 8 even when look is the last chunk)
+      const bool last = ch == chunks - 1;
+      if (active) {
+        const float* vb = bbase + (s & 1) * VBUF;
+        // B operands are single-buffered: right after the two MFMAs of an xr
+        // pair issue, the same registers take the next step's pair (a 2-step
+        // ring was measured: no gain).
+        float bc[4][2];
+#pragma unroll
+        for (int xr = 0; xr < 4; ++xr) {
+          const float2 b2 = *reinterpret_cast<const float2*>(vb + (xr * KC) * VP);
+          bc[xr][0] = b2.x; bc[xr][1] = b2.y;
+        }
+        float2 xd[4];
+#pragma unroll
+        for (int step = 0; step < STEPS; ++step) {       // step = ks*4 + xq
+          const int xq = step & 3;
+          const int nks = (step + 1) >> 2, nxq = (step + 1) & 3;
+          const float4 a0 = ar[step & (AD - 1)];
+          const float av[4] = {a0.x, a0.y, a0.z, a0.w};
+#pragma unroll
+          for (int xr = 0; xr < 4; ++xr) {
+            const int xi = xq * 4 + xr;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+              acc[xi][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[xr], bc[xr][g], acc[xi][g], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step < STEPS - 1) {
+              const float2 b2 = *reinterpret_cast<const float2*>(vb + ((nxq * 4 + xr) * KC + nks * 4) * VP);
+              bc[xr][0] = b2.x; bc[xr][1] = b2.y;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // refill the ring slot just consumed with the operand of step + 8
+          {
+            const bool tl = last && step + AD >= STEPS;
+            ar[step & (AD - 1)] = a_load(tl ? nrsrc : arsrc,
+                                         (tl ? nbase - chunks * STEPS * 1024 : abase) +
+                                             (ch * STEPS + step + AD) * 1024);
+          }
+          if (xf && (step & 3) == 1) xf_load(xsrc, step >> 2, xd);
+          if (xf && (step & 3) == 3) xf_store(xdst, step >> 2, xd);
+          if (step == 0) side_dma();
+          if (step == 6) side_look();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        side_dma();
+        side_look();
+        if (xf) transform(xsrc, xdst);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      DBG(1, s, 2);
+      if (++rbuf == NRAW) rbuf = 0;
+      __syncthreads();
+      DBG(1, s, 3);
+    }
+    DBG(1, s - 1, 4);
+    // next tile's bias flies during the epilogue
+    if (i + 1 < my_n) bv = load_bias(Tn);
+    if (active) {
+      const WLevel& L = args.lv[T.l];
+      const int H = L.H, W = L.W, HW = H * W;
+      const int flags = args.flags;
+      const bool relu = flags & SSAD_CONV_RELU, sigm = flags & SSAD_CONV_SIGMOID;
+      const bool masked = flags & SSAD_CONV_MASK_AUX;
+      // even W: a 2-pixel store is wholly inside or wholly outside the image, so
+      // edge tiles take the same path with out-of-range lanes sent to an
+      // out-of-bounds buffer offset (dropped stores, zero loads)
+      const bool fast = !(W & 1) && mt * 16 + 16 <= M;
+      // A^T M A for output channel row r of tile group g: v[a][b]
+      auto out_tile = [&](int g, int r, float (&v)[2][2]) {
+        float t[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float m0 = acc[j][g][r], m1 = acc[4 + j][g][r], m2 = acc[8 + j][g][r],
+                      m3 = acc[12 + j][g][r];
+          t[0][j] = m0 + m1 + m2;
+          t[1][j] = m1 - m2 - m3;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          v[a][0] = t[a][0] + t[a][1] + t[a][2];
+          v[a][1] = t[a][1] - t[a][2] - t[a][3];
+        }
+      };
+      if (fast && !sigm) {
+        // straight-line path: buffer stores, per-lane offset per tile group,
+        // (row, channel) displacement in the scalar offset
+        const int img_bytes = M * HW * 4;
+        const __amdgpu_buffer_rsrc_t yrsrc = uniform_rsrc(L.y + (long long)T.n * M * HW, img_bytes);
+        const __amdgpu_buffer_rsrc_t krsrc =
+            uniform_rsrc(masked ? L.aux + (long long)T.n * M * HW : L.y, img_bytes);
+        const float lo = relu ? 0.0f : -__builtin_inff();
+        unsigned vo[2][2];             // [tile group][row a]
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int tile = g * 16 + jn;
+          const int py = T.y0 + 2 * (tile >> 3), px = T.x0 + 2 * (tile & 7);
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+            vo[g][a] = ((py + a < H) & (px < W))
+                ? (unsigned)(((mt * 16 + kq * 4) * HW + (py + a) * W + px) * 4) : kOOBOff;
+        }
+        // channels r, r+1 of an accumulator quad are adjacent registers: the
+        // whole A^T M A runs as v_pk_add_f32 on (r, r+1) pairs; the final max
+        // (ReLU clamp or -inf) doubles as the repack into (x, x+1) store pairs.
+        auto emit = [&](auto has_mask) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              f32x2 kk[2][2];
+              if (decltype(has_mask)::value) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                  for (int a = 0; a < 2; ++a)
+                    kk[rr][a] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                        krsrc, vo[g][a], (2 * h + rr) * HW * 4, 0));
+              }
+              f32x2 t[2][4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const f32x2 m0 = h ? acc[j][g].zw : acc[j][g].xy;
+                const f32x2 m1 = h ? acc[4 + j][g].zw : acc[4 + j][g].xy;
+                const f32x2 m2 = h ? acc[8 + j][g].zw : acc[8 + j][g].xy;
+                const f32x2 m3 = h ? acc[12 + j][g].zw : acc[12 + j][g].xy;
+                t[0][j] = m0 + m1 + m2;
+                t[1][j] = m1 - m2 - m3;
+              }
+#pragma unroll
+              for (int a = 0; a < 2; ++a) {
+                const f32x2 v0 = t[a][0] + t[a][1] + t[a][2];
+                const f32x2 v1 = t[a][1] - t[a][2] - t[a][3];
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                  float o0 = fmaxf(rr ? v0.y : v0.x, lo), o1 = fmaxf(rr ? v1.y : v1.x, lo);
+                  if (decltype(has_mask)::value) {
+                    o0 = kk[rr][a].x > 0.0f ? o0 : 0.0f;
+                    o1 = kk[rr][a].y > 0.0f ? o1 : 0.0f;
+                  }
+                  __builtin_amdgcn_raw_buffer_store_b64(
+                      __builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, make_float2(o0, o1)),
+                      yrsrc, vo[g][a], (2 * h + rr) * HW * 4, 0);
+                }
+              }
+            }
+        };
+        if (masked) emit(std::true_type{}); else emit(std::false_type{});
+      } else {
+        float* yout = L.y + (long long)T.n * M * HW;
+        const float* aux = masked ? L.aux + (long long)T.n * M * HW : nullptr;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int tile = g * 16 + jn;
+          const int py = T.y0 + 2 * (tile >> 3), px = T.x0 + 2 * (tile & 7);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mt * 16 + kq * 4 + r;
+            float v[2][2];
+            out_tile(g, r, v);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              const int yy = py + a;
+              if (m < M && yy < H) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                  if (px + b < W) {
+                    float o = v[a][b];
+                    if (relu) o = o > 0.0f ? o : 0.0f;
+                    if (sigm) o = 1.0f / (1.0f + expf(-o));
+                    const int off = m * HW + yy * W + px + b;
+                    if (aux) o = aux[off] > 0.0f ? o : 0.0f;
+                    yout[off] = o;
+                  }
+              }
+            }
+          }
+        }
+      }
+    }
+    DBG(1, s - 1, 5);
+    // a wave that sat out this tile's MFMAs re-primes its ring for the next tile
+    if (!active && i + 1 < my_n) {
+#pragma unroll
+      for (int k = 0; k < AD; ++k) ar[k] = a_load(nrsrc, nbase + k * 1024);
+    }
+    T = Tn;
+    arsrc = nrsrc;
+    abase = nbase;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -391,9 +849,33 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
   }
   for (int l = n_levels; l < SSAD_MAX_CONV_PROBLEMS; ++l) a.lv[l] = WLevel{};
   if (blocks == 0) return 0;
+  a.patches = (int)blocks; a.mblocks = cdiv(Cout, BM);
+  static const int variant = [] { const char* e = getenv("SSAD_WINO_VARIANT"); return e ? atoi(e) : 2; }();
+  if (variant == 2 && a.chunks * KC == Cin) {
+    static const int cus2 = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        n = 256;
+      return n;
+    }();
+    const long long total = blocks * a.mblocks;
+    if (total >= (1LL << 31)) return SSAD_E_BADARG;
+    long long grid = total < cus2 ? total : cus2;
+    if (grid * ZNT < total) grid = (total + ZNT - 1) / ZNT;
+    hipLaunchKernelGGL(wino_conv_z_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+  }
+  // Cin not a multiple of 16, or SSAD_WINO_VARIANT=0: the non-persistent kernel
   hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)blocks, cdiv(Cout, BM)), dim3(kBlock), 0,
                      (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
+
+#ifdef WINO_TIMELINE
+int ssad_dbg_read(void* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg), sizeof(g_dbg));
+}
+#endif
 
 }  // extern "C"

@@ -487,3 +487,43 @@ def test_winograd_multilevel_matches_direct_full_size(K):
     Yw = K.conv3x3_forward(Xs, wf, b, M, relu=True, wino=True)
     for a, c in zip(Yd, Yw):
         close(c.cpu().numpy(), a.cpu().numpy(), CONV_RTOL, CONV_FLOOR, "wino vs direct")
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 144), (48, 16)])
+def test_winograd_persistent_short_reductions(K, cin, cout):
+    """More tiles than CUs with 1-3 channel chunks per tile: the persistent
+    kernel's cross-tile staging / filter-ring hand-over on every chunk."""
+    gen = torch.Generator(device="cuda").manual_seed(23 + cin)
+    N, H, W = 16, 40, 56
+    X = torch.randn((N, cin, H, W), device="cuda", generator=gen)
+    Wt = torch.randn((cout, cin, 3, 3), device="cuda", generator=gen) * 0.05
+    b = torch.randn(cout, device="cuda", generator=gen)
+    pf, _ = K.conv_pack_filter(Wt, True, False)
+    wf, _ = K.conv_wino_pack_filter(Wt, True, False)
+    Yd = K.conv3x3_forward([X], pf, b, cout, relu=True)[0]
+    Yw = K.conv3x3_forward([X], wf, b, cout, relu=True, wino=True)[0]
+    close(Yw.cpu().numpy(), Yd.cpu().numpy(), CONV_RTOL, CONV_FLOOR, "wino persistent vs direct")
+
+
+def test_winograd_multiproblem_masked_dgrad_full_size(K):
+    """Four independent towers x five levels in one launch (the head pipeline's
+    dgrad shape): per-problem filters, ReLU-gradient mask, 45-chunk reduction."""
+    gen = torch.Generator(device="cuda").manual_seed(29)
+    N, Cin, M = 2, 256, 720
+    shapes = [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)]
+    probs_w, probs_d = [], []
+    for t in range(3):
+        dYs = [torch.randn((N, M, h, w), device="cuda", generator=gen) for h, w in shapes]
+        Xs = [torch.relu(torch.randn((N, Cin, h, w), device="cuda", generator=gen)) for h, w in shapes]
+        Wt = torch.randn((M, Cin, 3, 3), device="cuda", generator=gen) * 0.02
+        _, pd = K.conv_pack_filter(Wt, False, True)
+        _, wd = K.conv_wino_pack_filter(Wt, False, True)
+        o1 = [torch.empty_like(x) for x in Xs]
+        o2 = [torch.empty_like(x) for x in Xs]
+        probs_d.append(dict(xs=dYs, packed=pd, out=o1, mask_by=Xs))
+        probs_w.append(dict(xs=dYs, packed=wd, out=o2, mask_by=Xs))
+    K.conv3x3_forward_multi(probs_d, Cin)
+    K.conv3x3_forward_multi(probs_w, Cin, wino=True)
+    for pd_, pw_ in zip(probs_d, probs_w):
+        for a, c in zip(pd_["out"], pw_["out"]):
+            close(c.cpu().numpy(), a.cpu().numpy(), CONV_RTOL, CONV_FLOOR, "wino multi dgrad vs direct")

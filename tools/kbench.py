@@ -12,7 +12,7 @@ import ssad_amd  # noqa
 from ssad_amd import kernels as K, synth
 
 
-def timeit(fn, iters=5, warm=2):
+def timeit(fn, iters=20, warm=10):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -54,6 +54,20 @@ def main():
         t = timeit(lambda: K.sigmoid(lv[0][0], out=outs[0]))
         print("sigmoid P3   %8.3f ms  %7.1f GB/s" % (t, lv[0][0].numel() * 8 / t / 1e6))
         del lv, outs
+    if "wino" in a.what:
+        for (M, Cin, name) in ((256, 256, "tower 256->256"), (720, 256, "cls_pred 256->720")):
+            Xs = [torch.randn((N, Cin, h, w), device=dev) for h, w in shapes]
+            Wt = torch.randn((M, Cin, 3, 3), device=dev) * 0.01
+            b = torch.zeros(M, device=dev)
+            px = sum(N * h * w for h, w in shapes)
+            fl = 2.0 * 9 * M * Cin * px
+            Ys = [torch.empty((N, M, h, w), device=dev) for h, w in shapes]
+            wf, wd = K.conv_wino_pack_filter(Wt)
+            t = timeit(lambda: K.conv3x3_forward(Xs, wf, b, M, relu=True, out=Ys, wino=True))
+            print("%-18s WINO fwd all-lvl %8.3f ms  %6.1f TF/s (direct-equivalent)" % (name, t, fl / t / 1e9))
+            t = timeit(lambda: K.conv3x3_forward(Xs[:1], wf, b, M, relu=True, out=Ys[:1], wino=True))
+            print("%-18s WINO fwd P3 only %8.3f ms  %6.1f TF/s" % (name, t, 2.0 * 9 * M * Cin * N * 8960 / t / 1e9))
+            del Xs, Ys
     if "conv" in a.what:
         for (M, Cin, name) in ((256, 256, "tower 256->256"), (720, 256, "cls_pred 256->720"),
                                (36, 256, "bbox_pred 256->36")):
