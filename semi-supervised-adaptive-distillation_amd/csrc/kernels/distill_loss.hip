@@ -469,25 +469,42 @@ __global__ __launch_bounds__(kThreads) void fused_finalize_kernel(
 }
 
 // ---- SelectSmoothL1Loss (select_smooth_l1_loss_op.cu:23-86) ---------------------
-// M foreground boxes x 4 coordinates; tiny.  One workgroup.
+// M foreground boxes x 4 coordinates, gathered through the location list: two
+// dependent global round trips per element, so the pass is latency-bound and
+// wants many workgroups (64K boxes on the finest level of a 16-image batch took
+// 480 us in one workgroup).  Per-workgroup double partials go to a
+// stream-ordered scratch allocation and are summed in index order by one
+// workgroup, so the result does not depend on the launch geometry's timing.
+__device__ __forceinline__ float smooth_l1_term(const float* __restrict__ Y_hat,
+                                                const float* __restrict__ Y,
+                                                const float* __restrict__ Lc, int e, int D, int H,
+                                                int W, float beta, double s) {
+  const int i = e >> 2, j = e & 3;
+  const int n = (int)Lc[i * 4], c = (int)Lc[i * 4 + 1], y = (int)Lc[i * 4 + 2], x = (int)Lc[i * 4 + 3];
+  const size_t ind = ((size_t)n * D + c + j) * H * W + (size_t)y * W + x;
+  const float val = Y_hat[ind] - Y[e];
+  const float a = fabsf(val);
+  return a < beta ? (float)((0.5 * (double)val * (double)val / (double)beta) / s)
+                  : (float)(((double)a - 0.5 * (double)beta) / s);
+}
 
 __global__ __launch_bounds__(kThreads) void smooth_l1_fwd_kernel(
     const float* __restrict__ Y_hat, const float* __restrict__ Y, const float* __restrict__ Lc,
-    const float* __restrict__ S, int D, int H, int W, int M, float beta, float scale,
-    float* __restrict__ out) {
+    const float* __restrict__ S, int D, int H, int W, int M, float beta,
+    double* __restrict__ partials) {
   const double s = (double)fmaxf(S[0], 1.0f);
   double acc = 0.0;
-  for (int e = threadIdx.x; e < M * 4; e += kThreads) {
-    const int i = e >> 2, j = e & 3;
-    const int n = (int)Lc[i * 4], c = (int)Lc[i * 4 + 1], y = (int)Lc[i * 4 + 2], x = (int)Lc[i * 4 + 3];
-    const size_t ind = ((size_t)n * D + c + j) * H * W + (size_t)y * W + x;
-    const float val = Y_hat[ind] - Y[e];
-    const float a = fabsf(val);
-    const float l = a < beta ? (float)((0.5 * (double)val * (double)val / (double)beta) / s)
-                             : (float)(((double)a - 0.5 * (double)beta) / s);
-    acc += (double)l;
-  }
+  for (int e = blockIdx.x * kThreads + threadIdx.x; e < M * 4; e += gridDim.x * kThreads)
+    acc += (double)smooth_l1_term(Y_hat, Y, Lc, e, D, H, W, beta, s);
   const double t = block_sum(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(kThreads) void smooth_l1_finalize_kernel(
+    const double* __restrict__ partials, int n, float scale, float* __restrict__ out) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += kThreads) v += partials[i];
+  const double t = block_sum(v);
   if (threadIdx.x == 0) out[0] = (float)t * scale;
 }
 
@@ -812,8 +829,19 @@ int ssad_select_smooth_l1_forward(const float* Y_hat, const float* Y, const floa
                                   float scale, float* loss, ssad_stream_t stream) {
   if (N < 0 || D < 0 || H < 0 || W < 0 || M < 0 || !(beta > 0.0f) || !(scale >= 0.0f))
     return SSAD_E_BADARG;
-  hipLaunchKernelGGL(smooth_l1_fwd_kernel, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, Y_hat,
-                     Y, L, S, D, H, W, M, beta, scale, loss);
+  hipStream_t st = (hipStream_t)stream;
+  int grid = (M * 4 + kThreads - 1) / kThreads;
+  if (grid < 1) grid = 1;
+  if (grid > 512) grid = 512;
+  double* partials = nullptr;
+  hipError_t err = hipMallocAsync((void**)&partials, sizeof(double) * grid, st);
+  if (err != hipSuccess) return (int)err;
+  hipLaunchKernelGGL(smooth_l1_fwd_kernel, dim3(grid), dim3(kThreads), 0, st, Y_hat, Y, L, S, D, H,
+                     W, M, beta, partials);
+  hipLaunchKernelGGL(smooth_l1_finalize_kernel, dim3(1), dim3(kThreads), 0, st, partials, grid,
+                     scale, loss);
+  err = hipFreeAsync(partials, st);
+  if (err != hipSuccess) return (int)err;
   return (int)hipGetLastError();
 }
 

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Merge the three PMC pass summaries of tools/profile_round.sh into
+profiles/<tag>_pmc.json (what bench.py quotes as roofline.traffic) and copy the
+round's markdown summaries from gpurun_out/profiles_<tag>/ into profiles/.
+
+    python tools/make_pmc_json.py r01
+"""
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    out = {}
+    for name, rename in (("pmc_fetch", {"FETCH_SIZE": "FETCH_SIZE_KB_raw"}),
+                         ("pmc_write", {"WRITE_SIZE": "WRITE_SIZE_KB"}), ("pmc_mfma", {})):
+        d = json.load(open(os.path.join(src, name + ".json")))
+        for k, c in d["counters"].items():
+            e = out.setdefault(k, {})
+            for cn, v in c.items():
+                e[rename.get(cn, cn)] = v
+        if name == "pmc_mfma":
+            for k, t in d["kernels"].items():
+                if k in out:
+                    out[k]["avg_us_mfma_pass"] = t["avg_us"]
+    for k, e in out.items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("GRBM_GUI_ACTIVE"):
+            # GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs on the chip
+            e["MfmaUtil_pct"] = round(100.0 * e["SQ_VALU_MFMA_BUSY_CYCLES"] /
+                                      (e["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 2)
+            # one MOPS unit = 512 flops (MI355X_MICROARCH.md, rocprofv3 section)
+            e["mfma_flops_per_dispatch"] = e.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0
+    note = ("per-dispatch averages over python tools/kbench.py; FETCH_SIZE raw (gfx950 counts wide "
+            "16-B streaming reads at 1/2: double it for those), GRBM_GUI_ACTIVE is summed over "
+            "the 8 XCDs")
+    json.dump({"kernels": out, "note": note}, open(os.path.join(dst, tag + "_pmc.json"), "w"),
+              indent=1, sort_keys=True)
+    for f in sorted(os.listdir(src)):
+        if f.endswith(".md"):
+            shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s" % (tag, f)))
+    print("wrote", os.path.join(dst, tag + "_pmc.json"))
+
+
+if __name__ == "__main__":
+    main()

@@ -9,22 +9,27 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
 cd $R
+SUMMARY_ARGS=""
 run() { # name, title, rocprof args..., -- cmd
   local name=$1; shift; local title=$1; shift
   rm -rf /tmp/prof_$name
   rocprofv3 "$@" > $O/$name.log 2>&1
   local db=$(ls /tmp/prof_$name/*.db 2>/dev/null | head -1)
   if [ -n "$db" ]; then
-    python tools/rocpd_summary.py $db $O/$name.md --json $O/$name.json --title "$title" > /dev/null
+    python tools/rocpd_summary.py $db $O/$name.md --json $O/$name.json --title "$title" $SUMMARY_ARGS > /dev/null
   else
     echo "no db for $name" >> $O/$name.log
   fi
   tail -2 $O/$name.log | cut -c1-300 > $O/$name.tail; rm -f $O/$name.log
 }
-run bench_full_trace "rocprofv3 --kernel-trace --stats: python bench.py --steps 5 --warmup 2 (default = full workload)" \
+# bench traces: only the 5 timed step periods (the once-per-step fused loss kernel
+# is the period marker), so MIOpen's find-phase candidates of step 1 do not show
+SUMMARY_ARGS="--marker cls_losses_fused_kernel --last 5"
+run bench_full_trace "rocprofv3 --kernel-trace --stats: python bench.py --steps 5 --warmup 2 (default = full workload), the 5 timed steps" \
     --kernel-trace --stats -d /tmp/prof_bench_full_trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline
-run bench_heads_trace "rocprofv3 --kernel-trace --stats: python bench.py --workload heads --steps 5 --warmup 2" \
+run bench_heads_trace "rocprofv3 --kernel-trace --stats: python bench.py --workload heads --steps 5 --warmup 2, the 5 timed steps" \
     --kernel-trace --stats -d /tmp/prof_bench_heads_trace -o t -- python bench.py --workload heads --steps 5 --warmup 2 --no-cpu-baseline
+SUMMARY_ARGS=""
 run pmc_fetch "PMC pass 1 (FETCH_SIZE, KB): python tools/kbench.py" \
     --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_pmc_fetch -o t -- python tools/kbench.py
 run pmc_write "PMC pass 2 (WRITE_SIZE, KB): python tools/kbench.py" \

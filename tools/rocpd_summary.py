@@ -29,6 +29,10 @@ def main():
     tail = None
     if "--tail-fraction" in args:   # only kernels in the last fraction of the timeline
         i = args.index("--tail-fraction"); tail = float(args[i + 1]); del args[i:i + 2]
+    marker, last = None, 0
+    if "--marker" in args:          # keep only the last K periods of a once-per-step kernel
+        i = args.index("--marker"); marker = args[i + 1]; del args[i:i + 2]
+        i = args.index("--last"); last = int(args[i + 1]); del args[i:i + 2]
     db = sqlite3.connect(args[0])
     cur = db.cursor()
     rows = cur.execute("select name, start, end from kernels").fetchall()
@@ -36,6 +40,14 @@ def main():
         t0, t1 = min(r[1] for r in rows), max(r[2] for r in rows)
         cut = t1 - (t1 - t0) * tail
         rows = [r for r in rows if r[1] >= cut]
+    if marker and rows:
+        # steady state only: from the end of the (K+1)-th last marker dispatch to the
+        # end of the last one = exactly K step periods (library warm-up / MIOpen
+        # find-phase candidates of the first steps are excluded)
+        ends = sorted(r[2] for r in rows if marker in r[0])
+        if len(ends) > last:
+            lo, hi = ends[-last - 1], ends[-1]
+            rows = [r for r in rows if r[1] >= lo and r[2] <= hi]
     agg = {}
     for n, s, e in rows:
         a = agg.setdefault(short(n), [0, 0, 1 << 62, 0])
