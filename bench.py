@@ -13,9 +13,11 @@ Workloads
   heads  the RetinaNet subnets + distillation losses only (this repo's HIP
          kernels end to end), fed synthetic FPN features;
   full   BASELINE config "R-50 student + R-101 teacher, bs=16/GPU, 600 px":
-         ResNet-FPN backbones run as a PyTorch/MIOpen harness (SURVEY.md 2.3:
-         out of scope as hand kernels), subnets + losses through the HIP
-         kernels.  This is the configuration the metric is quoted on.
+         ResNet-FPN backbones run as a PyTorch harness (out of
+         scope as hand kernels) whose >=128-channel 3x3 convolutions call this
+         repo's Winograd / wgrad kernels (the rest is MIOpen / rocBLAS); subnets
+         + losses through the HIP kernels.  This is the configuration the
+         metric is quoted on.
 """
 import argparse
 import json
@@ -199,8 +201,9 @@ def main():
         def step():
             model.step(images, labels, bbox_targets, fg_num)
         wl = ("R-50-FPN student + R-101-FPN teacher adaptive distillation, 600 px (3x640x896): "
-              "backbones = PyTorch/MIOpen harness; subnets, distillation + focal + smooth-L1 "
-              "losses and subnet SGD = this repo's HIP kernels")
+              "backbones = PyTorch harness (MIOpen/rocBLAS 1x1, 7x7, strided and 64-channel "
+              "convs; its other 3x3 convs on this repo's kernels); subnets, distillation + "
+              "focal + smooth-L1 losses and subnet SGD = this repo's HIP kernels")
 
     for _ in range(args.warmup):
         step()
