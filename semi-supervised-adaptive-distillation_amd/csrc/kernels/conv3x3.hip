@@ -45,6 +45,7 @@
 
 #include <mutex>
 
+#include "conv_internal.h"
 #include "ssad_kernels.h"
 
 namespace {
@@ -705,8 +706,11 @@ size_t ssad_conv3x3_wgrad_workspace_bytes(const ssad_conv_level* levels_host, in
                                           int Cout, int Cin) {
   WgArgs a;
   if (wgrad_plan(levels_host, n_levels, Cout, Cin, &a)) return 0;
-  return sizeof(float) * (size_t)a.splits * a.mblocks * WG_MT * a.cblocks * WG_CT * 9 * 1024 +
-         sizeof(double) * (size_t)Cout * kBiasParts;
+  size_t slab = sizeof(float) * (size_t)a.splits * a.mblocks * WG_MT * a.cblocks * WG_CT * 9 * 1024;
+  // sized for either engine, so the choice can change between calls
+  const size_t wino = ssad_wino_wgrad_workspace_bytes(levels_host, n_levels, Cout, Cin);
+  if (wino > slab) slab = wino;
+  return slab + sizeof(double) * (size_t)Cout * kBiasParts;
 }
 
 int ssad_conv3x3_wgrad(const ssad_conv_level* levels_host, int n_levels, float* dW, float* db,
@@ -719,22 +723,30 @@ int ssad_conv3x3_wgrad(const ssad_conv_level* levels_host, int n_levels, float* 
     if (!levels_host[l].aux && levels_host[l].N * levels_host[l].H * levels_host[l].W > 0)
       return SSAD_E_BADARG;
   const int mtp = a.mblocks * WG_MT, ctp = a.cblocks * WG_CT;
-  const size_t slab_bytes = sizeof(float) * (size_t)a.splits * mtp * ctp * 9 * 1024;
+  size_t slab_bytes = sizeof(float) * (size_t)a.splits * mtp * ctp * 9 * 1024;
+  const size_t wino_bytes = ssad_wino_wgrad_workspace_bytes(levels_host, n_levels, Cout, Cin);
+  if (wino_bytes > slab_bytes) slab_bytes = wino_bytes;
   const size_t need = slab_bytes + sizeof(double) * (size_t)Cout * kBiasParts;
   if (!workspace || workspace_bytes < need) return SSAD_E_WORKSPACE;
   a.slabs = (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds_bytes = sizeof(float) * 2 * WG_BUF;
-  static std::once_flag lds_once;    // > 64 KiB of dynamic LDS needs the opt-in, once per process
-  std::call_once(lds_once, [&] {
-    (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  });
-  hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(a.splits, a.mblocks, a.cblocks), dim3(kBlock),
-                     lds_bytes, s, a);
-  const long long per_split = (long long)mtp * ctp * 9 * 1024;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per_split + 255) / 256)), dim3(256),
-                     0, s, (const float*)a.slabs, a.splits, mtp, ctp, Cout, Cin, dW, accumulate);
+  if (ssad_wino_wgrad_eligible(Cout, Cin)) {
+    const int wrc = ssad_wino_wgrad_launch(levels_host, n_levels, dW, Cout, Cin, accumulate,
+                                           workspace, slab_bytes, s);
+    if (wrc) return wrc;
+  } else {
+    const size_t lds_bytes = sizeof(float) * 2 * WG_BUF;
+    static std::once_flag lds_once;    // > 64 KiB of dynamic LDS needs the opt-in, once per process
+    std::call_once(lds_once, [&] {
+      (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    });
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(a.splits, a.mblocks, a.cblocks), dim3(kBlock),
+                       lds_bytes, s, a);
+    const long long per_split = (long long)mtp * ctp * 9 * 1024;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per_split + 255) / 256)), dim3(256),
+                       0, s, (const float*)a.slabs, a.splits, mtp, ctp, Cout, Cin, dW, accumulate);
+  }
   if (db) {
     BiasArgs b;
     b.n_levels = n_levels; b.M = Cout;

@@ -1,0 +1,452 @@
+// conv3x3_wgrad_winograd.hip -- Winograd F(3x3, 2x2) filter gradient of the 3x3
+// convolution, fp32 on the gfx950 matrix cores.
+//
+// Same contract as conv3x3_wgrad_kernel (caffe2/operators/conv_op_cudnn.cc:
+// 1018-1041, conv_op_impl.h:430-520: dW[m][c][ky][kx] = sum over images and
+// pixels of dY[m][y][x] * X[c][y+ky-1][x+kx-1]) with 2.25x fewer multiplies:
+// per 2x2 output tile
+//     dU += (A dY A^T) (.) (B^T X B)          (16 products instead of 36)
+//     dW  = G^T dU G                           (once, in the reduce kernel)
+// with the F(2x2,3x3) matrices A (4x2), B^T (4x4), G (4x3) transposed into
+// their filter-gradient roles.  The 16 products are 16 independent
+// [Cout x tiles] x [tiles x Cin] GEMMs with the TILES as reduction dimension,
+// on v_mfma_f32_16x16x4_f32 (k = 4 tiles per instruction).
+//
+// Workgroup = 8 waves = 64 output x 64 input channels x 16 products, and a
+// contiguous 1/S share of all (level, image, 4x16-pixel unit) units; wave
+// (wm, wc) owns 32 x 16 channels = 2 x 16 accumulator quads = 128 VGPRs.
+// Neither operand is ever materialised in transformed form: per k-step a
+// lane reads the RAW 2x2 dY patch of its (channel, tile) (2 ds_read_b64) and
+// the raw 4x4 X window (8 ds_read_b64) from LDS and applies A . A^T (12 VALU)
+// and B^T . B (32 VALU) in registers -- the 32 MFMAs of the step take 1024
+// pipe cycles, the VALU work 200, and the second wave of the SIMD covers it.
+// (The sign pattern of A's last row is dropped here and re-applied in the
+// reduce kernel: row/column 3 of dU are negated there.)
+// LDS holds two stages of raw units: dY [64][4x16 (+2)] and X [64][6x20 (+10)]
+// floats.  Channel strides 66 / 130 = 2 mod 32: hipcc pairs the operand reads
+// into ds_read2_b64, which is served in groups of 16 consecutive lanes on 32
+// banks -- the 16 channels of a group then cover all 32 banks once (strides of
+// 4 mod 64, right for single ds_read_b64, measured 46 % conflict cycles).
+// The next unit is loaded through registers in
+// three portions requested at k-steps 0-2 and written after k-step 3 (26 VGPRs).
+// Partial dU slabs [S][16][Mp][Cp] are combined, transformed by G and scattered
+// into dW[m][c][3][3] by wino_wgrad_reduce_kernel in a fixed order.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "conv_internal.h"
+#include "ssad_kernels.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBlock = 512;
+constexpr int GM = 64, GC = 64;          // output / input channels per workgroup
+constexpr int UR = 4, UC = 16;           // unit: 4 x 16 output pixels = 2 x 8 tiles
+constexpr int SY = 66;                   // dY LDS channel stride (64 + 2)
+constexpr int XP = 20;                   // X LDS row pitch (18 used)
+constexpr int SX = 130;                  // X LDS channel stride (6 * 20 + 10)
+constexpr int STAGE = GM * SY + GC * SX; // floats per stage
+constexpr unsigned kOOB = 0x80000000u;
+
+__host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const unsigned n = __builtin_amdgcn_readfirstlane(bytes);
+  void* q = (void*)(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, n, 0x00020000);
+}
+
+struct GLevel {
+  const float* x;
+  const float* dy;
+  int N, H, W;
+  int ux, uy;            // units per row / column of one image
+  int unit_start;
+};
+
+struct GArgs {
+  GLevel lv[SSAD_MAX_LEVELS];
+  int n_levels;
+  int M, C;              // Cout, Cin
+  int mblocks, cblocks;
+  int total_units, per_split, splits;
+  float* slabs;          // [splits][16][mblocks*GM][cblocks*GC]
+};
+
+__global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args) {
+  __shared__ float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mb = blockIdx.x / args.cblocks, cb = blockIdx.x - mb * args.cblocks;
+  const int sp = blockIdx.y;
+  const int M = args.M, C = args.C;
+  const int u_begin = sp * args.per_split;
+  int u_end = u_begin + args.per_split;
+  if (u_end > args.total_units) u_end = args.total_units;
+
+  // ---- unit cursor of the LOADER (one unit ahead of the compute) ----
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < SSAD_MAX_LEVELS; ++i)
+    if (i < args.n_levels && u_begin >= args.lv[i].unit_start) l = i;
+  int cn, cuy, cux;          // image, unit row, unit column within level l
+  {
+    const GLevel& L = args.lv[l];
+    int r = u_begin - L.unit_start;
+    const int per_img = L.ux * L.uy;
+    cn = r / per_img;
+    r -= cn * per_img;
+    cuy = r / L.ux;
+    cux = r - cuy * L.ux;
+  }
+  auto advance = [&]() {
+    if (++cux == args.lv[l].ux) {
+      cux = 0;
+      if (++cuy == args.lv[l].uy) {
+        cuy = 0;
+        if (++cn == args.lv[l].N) {
+          cn = 0;
+          ++l;
+          // skip empty levels
+          while (l < args.n_levels && args.lv[l].N * args.lv[l].ux * args.lv[l].uy == 0) ++l;
+        }
+      }
+    }
+  };
+
+  // ---- staging maps ----
+  // dY: 64 m x 4 rows x 16 px = 1024 float4; thread -> two of them (m, m+32)
+  const int d_m = tid >> 4, d_row = (tid >> 2) & 3, d_c4 = tid & 3;
+  const int d_lds = d_m * SY + d_row * UC + d_c4 * 4;
+  // X: thread -> channel tid>>3, columns (tid&7) + 8j (j<3, col<18), rows 0..5
+  const int x_c = tid >> 3, x_sub = tid & 7;
+  // LDS channel slot: bit pairs (0,1) <-> (2,3) of the channel swapped, so that the
+  // 4 channels x 8 columns of a store group land on 32 different banks (slot
+  // stride 4 -> 8 banks) while the 16 channels of an operand read stay distinct mod 16
+  const int x_lds = GM * SY + ((x_c & 0x30) | ((x_c & 3) << 2) | ((x_c >> 2) & 3)) * SX + x_sub;
+
+  float4 ry[2];
+  float rx[3][2][3];         // portion p: rows 2p, 2p+1; [row in pair][col iter]
+  __amdgpu_buffer_rsrc_t dyrs, xrs;
+  unsigned dy_off[2], x_off[3];
+  bool vec4 = true;
+  int cW = 0, cHW = 0;
+  bool have_next = false;
+
+  // describe the unit under the cursor (offsets relative to the image's channel block)
+  auto setup_unit = [&]() {
+    const GLevel& L = args.lv[l];
+    const int H = L.H, W = L.W, HW = H * W;
+    cW = W; cHW = HW;
+    vec4 = !(W & 3);
+    const int y0 = cuy * UR, x0 = cux * UC;
+    const int m_left = M - mb * GM, c_left = C - cb * GC;
+    dyrs = uniform_rsrc(L.dy + ((long long)cn * M + mb * GM) * HW,
+                        (unsigned)((m_left < GM ? m_left : GM) * HW * 4));
+    xrs = uniform_rsrc(L.x + ((long long)cn * C + cb * GC) * HW,
+                       (unsigned)((c_left < GC ? c_left : GC) * HW * 4));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int gy = y0 + d_row, gx = x0 + d_c4 * 4;
+      const bool ok = gy < H && gx < W;
+      dy_off[k] = ok ? (unsigned)(((d_m + 32 * k) * HW + gy * W + gx) * 4) : kOOB;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int col = x_sub + 8 * j;
+      const int gx = x0 - 1 + col;
+      const bool ok = col < UC + 2 && gx >= 0 && gx < W;
+      // row validity is added per row at load time
+      x_off[j] = ok ? (unsigned)((x_c * HW + (y0 - 1) * W + gx) * 4) : kOOB;
+    }
+  };
+  int ny0 = 0, nH = 0;
+  auto load_portion = [&](int p) {
+    if (!have_next) return;
+    if (p < 2) {
+      if (vec4) {
+        ry[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(dyrs, dy_off[p], 0, 0));
+      } else {
+        // W % 4 != 0: the four pixels straddle the row end individually
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = dy_off[p] != kOOB && (int)(cux * UC + d_c4 * 4 + e) < cW;
+          t[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+              dyrs, ok ? dy_off[p] + 4 * e : kOOB, 0, 0));
+        }
+        ry[p] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 2 * p + rr;
+      const int gy = ny0 - 1 + row;
+      const bool rok = gy >= 0 && gy < nH;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        rx[p][rr][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            xrs, (rok && x_off[j] != kOOB) ? x_off[j] + (unsigned)(row * cW * 4) : kOOB, 0, 0));
+    }
+  };
+  auto store_portion = [&](int p, float* st) {
+    if (!have_next) return;
+    if (p < 2) {   // channel stride 66 floats: 8-byte aligned only
+      float2* q = reinterpret_cast<float2*>(st + d_lds + p * 32 * SY);
+      q[0] = make_float2(ry[p].x, ry[p].y);
+      q[1] = make_float2(ry[p].z, ry[p].w);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (x_sub + 8 * j < UC + 2) st[x_lds + (2 * p + rr) * XP + 8 * j] = rx[p][rr][j];
+  };
+
+  // ---- compute-side constants ----
+  const int wm = wave & 1, wc = wave >> 1;
+  const int ln = lane & 15, kq = lane >> 4;
+  const int a_base = (wm * 32 + ln) * SY;                  // + mg*16*SY + row*UC + col
+  const int b_base = GM * SY + (wc * 16 + ((ln & 3) << 2) + (ln >> 2)) * SX;   // slot of channel wc*16+ln
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int x = 0; x < 16; ++x)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) acc[x][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: first unit straight into stage 0 ----
+  have_next = u_begin < u_end;
+  if (have_next) {
+    setup_unit();
+    ny0 = cuy * UR; nH = args.lv[l].H;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { load_portion(p); store_portion(p, lds); }
+    advance();
+  }
+  __syncthreads();
+
+  for (int u = u_begin; u < u_end; ++u) {
+    const float* st = lds + ((u - u_begin) & 1) * STAGE;
+    float* nst = lds + (((u - u_begin) & 1) ^ 1) * STAGE;
+    have_next = u + 1 < u_end;
+    if (have_next) { setup_unit(); ny0 = cuy * UR; nH = args.lv[l].H; }
+    // raw operands of one k-step: B window d[4][4] as 8 float2, A patches 2 x 2 float2;
+    // those of k-step ks+1 are requested before the MFMAs of k-step ks
+    float2 rb[2][8], ra[2][4];
+    auto read_raw = [&](int ks, float2 (&b8)[8], float2 (&a4)[4]) {
+      const int ty = ks >> 1, tx = (ks & 1) * 4 + kq;
+      const float* bp = st + b_base + (2 * ty) * XP + 2 * tx;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        b8[2 * r] = *reinterpret_cast<const float2*>(bp + r * XP);
+        b8[2 * r + 1] = *reinterpret_cast<const float2*>(bp + r * XP + 2);
+      }
+#pragma unroll
+      for (int mg = 0; mg < 2; ++mg) {
+        const float* ap = st + a_base + mg * 16 * SY + (2 * ty) * UC + 2 * tx;
+        a4[2 * mg] = *reinterpret_cast<const float2*>(ap);
+        a4[2 * mg + 1] = *reinterpret_cast<const float2*>(ap + UC);
+      }
+    };
+    read_raw(0, rb[0], ra[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      // next unit: portion ks is requested now; all three go to LDS after the last k-step
+      if (ks < 3) load_portion(ks);
+      if (ks < 3) read_raw(ks + 1, rb[(ks + 1) & 1], ra[(ks + 1) & 1]);
+      const float2 (&b8)[8] = rb[ks & 1];
+      const float2 (&a4)[4] = ra[ks & 1];
+      // ---- B operand: raw 4x4 window -> V = B^T d B (16 values) ----
+      float v[16];
+      {
+        float d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          d[r][0] = b8[2 * r].x; d[r][1] = b8[2 * r].y; d[r][2] = b8[2 * r + 1].x; d[r][3] = b8[2 * r + 1].y;
+        }
+        float t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          t[0][j] = d[0][j] - d[2][j];
+          t[1][j] = d[1][j] + d[2][j];
+          t[2][j] = d[2][j] - d[1][j];
+          t[3][j] = d[1][j] - d[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i * 4 + 0] = t[i][0] - t[i][2];
+          v[i * 4 + 1] = t[i][1] + t[i][2];
+          v[i * 4 + 2] = t[i][2] - t[i][1];
+          v[i * 4 + 3] = t[i][1] - t[i][3];
+        }
+      }
+      // ---- A operand per 16-channel group: raw 2x2 -> A d A^T without the signs of
+      //      A's last row (re-applied by the reduce kernel) ----
+#pragma unroll
+      for (int mg = 0; mg < 2; ++mg) {
+        const float2 r0 = a4[2 * mg], r1 = a4[2 * mg + 1];
+        const float p[4] = {r0.x, r0.x + r1.x, r0.x - r1.x, r1.x};
+        const float q[4] = {r0.y, r0.y + r1.y, r0.y - r1.y, r1.y};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float dm[4] = {p[i], p[i] + q[i], p[i] - q[i], q[i]};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i * 4 + j][mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(dm[j], v[i * 4 + j],
+                                                                      acc[i * 4 + j][mg], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) store_portion(p, nst);
+    if (have_next) advance();
+    __syncthreads();
+  }
+
+  // ---- partial dU slab: [sp][xi][Mp][Cp] ----
+  const int Mp = args.mblocks * GM, Cp = args.cblocks * GC;
+  float* slab = args.slabs + (long long)sp * 16 * Mp * Cp;
+#pragma unroll
+  for (int x = 0; x < 16; ++x)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mb * GM + wm * 32 + g * 16 + kq * 4 + r;
+        const int c = cb * GC + wc * 16 + ln;
+        slab[((long long)x * Mp + m) * Cp + c] = acc[x][g][r];
+      }
+}
+
+// dW[m][c][ky][kx] (+)= (G^T (s s^T (.) sum_sp dU) G)[ky][kx],  s = (1,1,1,-1),
+// G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
+// Workgroup = one output channel m x 64 input channels; thread (j, c) sums
+// column j of dU over the splits (fixed order), applies G^T down the column,
+// the row pass and the [c][9] -> linear store go through LDS.
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(
+    const float* __restrict__ slabs, int splits, int Mp, int Cp, int M, int C,
+    float* __restrict__ dW, int accumulate) {
+  __shared__ float t[3][4][64];
+  __shared__ float o[64 * 9];
+  const int cl = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 64, m = blockIdx.y;
+  const int c = c0 + cl;
+  float u[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < Cp) {
+    const float* p = slabs + ((long long)j * Mp + m) * Cp + c;
+    const long long xs = (long long)4 * Mp * Cp, ss = (long long)16 * Mp * Cp;
+#pragma unroll 4
+    for (int s = 0; s < splits; ++s) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) u[i] += p[s * ss + i * xs];
+    }
+  }
+  // signs dropped by the main kernel: row 3 and column 3 (not both)
+  if (j == 3) { u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; }
+  else u[3] = -u[3];
+  const float h = 0.5f * (u[1] + u[2]);
+  t[0][j][cl] = u[0] + h;
+  t[1][j][cl] = 0.5f * (u[1] - u[2]);
+  t[2][j][cl] = h + u[3];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 3; e += 256) {
+    const int cc = e & 63, k = e >> 6;
+    const float g = 0.5f * (t[k][1][cc] + t[k][2][cc]);
+    o[cc * 9 + k * 3 + 0] = t[k][0][cc] + g;
+    o[cc * 9 + k * 3 + 1] = 0.5f * (t[k][1][cc] - t[k][2][cc]);
+    o[cc * 9 + k * 3 + 2] = g + t[k][3][cc];
+  }
+  __syncthreads();
+  const int nvalid = (C - c0 < 64 ? C - c0 : 64) * 9;
+  float* dst = dW + ((long long)m * C + c0) * 9;
+  for (int e = threadIdx.x; e < nvalid; e += 256) {
+    if (accumulate) dst[e] += o[e]; else dst[e] = o[e];
+  }
+}
+
+int plan(const ssad_conv_level* lv, int n_levels, int Cout, int Cin, GArgs* a) {
+  if (n_levels < 1 || n_levels > SSAD_MAX_LEVELS || Cout <= 0 || Cin <= 0) return SSAD_E_BADARG;
+  a->n_levels = n_levels;
+  a->M = Cout; a->C = Cin;
+  a->mblocks = cdiv(Cout, GM); a->cblocks = cdiv(Cin, GC);
+  long long units = 0;
+  for (int l = 0; l < SSAD_MAX_LEVELS; ++l) {
+    GLevel& L = a->lv[l];
+    L = GLevel{};
+    if (l >= n_levels) continue;
+    L.x = lv[l].x; L.dy = lv[l].aux;
+    L.N = lv[l].N; L.H = lv[l].H; L.W = lv[l].W;
+    if (L.N < 0 || L.H < 0 || L.W < 0) return SSAD_E_BADARG;
+    if ((long long)L.H * L.W * 64 >= (1LL << 29)) return SSAD_E_BADARG;
+    L.ux = cdiv(L.W, UC); L.uy = cdiv(L.H, UR);
+    L.unit_start = (int)units;
+    units += (long long)L.N * L.ux * L.uy;
+    if (units >= (1LL << 30)) return SSAD_E_BADARG;
+  }
+  a->total_units = (int)units;
+  // splits: minimise rounds(S) x units-per-split(S) on the chip's CUs (all
+  // workgroups cost the same), at least 8 units per split, smallest S on ties
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  const int oblocks = a->mblocks * a->cblocks;
+  int s = 1;
+  long long best = -1;
+  for (int t = 1; t <= 32; ++t) {
+    if (t > 1 && units / t < 8) break;
+    const long long cost = (long long)cdiv(oblocks * t, cus) * cdiv((int)(units ? units : 1), t);
+    if (best < 0 || cost < best) { best = cost; s = t; }
+  }
+  a->per_split = units ? cdiv((int)units, s) : 0;
+  a->splits = units ? cdiv((int)units, a->per_split) : 1;
+  return 0;
+}
+
+}  // namespace
+
+bool ssad_wino_wgrad_eligible(int Cout, int Cin) {
+  const char* e = getenv("SSAD_WGRAD_ENGINE");
+  if (e && e[0] == 'd') return false;            // "direct"
+  if (e && e[0] == 'w') return true;             // "winograd"
+  return Cout >= 64 && Cin >= 64;
+}
+
+size_t ssad_wino_wgrad_workspace_bytes(const ssad_conv_level* lv, int n_levels, int Cout, int Cin) {
+  GArgs a;
+  if (plan(lv, n_levels, Cout, Cin, &a)) return 0;
+  return sizeof(float) * (size_t)a.splits * 16 * a.mblocks * GM * a.cblocks * GC;
+}
+
+int ssad_wino_wgrad_launch(const ssad_conv_level* lv, int n_levels, float* dW, int Cout, int Cin,
+                           int accumulate, void* workspace, size_t workspace_bytes,
+                           hipStream_t stream) {
+  GArgs a;
+  const int rc = plan(lv, n_levels, Cout, Cin, &a);
+  if (rc) return rc;
+  const size_t need = sizeof(float) * (size_t)a.splits * 16 * a.mblocks * GM * a.cblocks * GC;
+  if (!workspace || workspace_bytes < need) return SSAD_E_WORKSPACE;
+  a.slabs = (float*)workspace;
+  if (a.total_units == 0) {
+    if (!accumulate) (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)Cout * Cin * 9, stream);
+    return (int)hipGetLastError();
+  }
+  hipLaunchKernelGGL(wino_wgrad_kernel, dim3(a.mblocks * a.cblocks, a.splits), dim3(kBlock), 0,
+                     stream, a);
+  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(Cin, 64), Cout), dim3(256), 0,
+                     stream, (const float*)a.slabs, a.splits, a.mblocks * GM, a.cblocks * GC, Cout,
+                     Cin, dW, accumulate);
+  return (int)hipGetLastError();
+}

@@ -527,3 +527,52 @@ def test_winograd_multiproblem_masked_dgrad_full_size(K):
     for pd_, pw_ in zip(probs_d, probs_w):
         for a, c in zip(pd_["out"], pw_["out"]):
             close(c.cpu().numpy(), a.cpu().numpy(), CONV_RTOL, CONV_FLOOR, "wino multi dgrad vs direct")
+
+
+# ---------------------------------------------------------------------------
+# Winograd F(3x3,2x2) filter gradient: same contract / tolerance as the direct wgrad
+# ---------------------------------------------------------------------------
+
+@pytest.fixture
+def wgrad_engine(monkeypatch):
+    def choose(name):
+        monkeypatch.setenv("SSAD_WGRAD_ENGINE", name)
+    return choose
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 64, 64, 8, 16), (2, 16, 40, 9, 17), (2, 36, 256, 5, 7), (1, 256, 256, 10, 14),
+    (1, 24, 130, 17, 33), (3, 8, 65, 2, 31), (1, 720, 256, 5, 7), (2, 256, 36, 13, 20)],
+    ids=lambda s: "N%d_C%d_M%d_%dx%d" % s)
+def test_winograd_wgrad_vs_oracle(K, wgrad_engine, shape):
+    N, Cin, M, H, W = shape
+    rng = np.random.default_rng(2000 + sum(shape))
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, 3, 3)) * 0.05).astype(np.float32)
+    dY = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    ref_dW, ref_db, _ = oracle.conv_backward(X, Wt, dY, want_db=True)
+    wgrad_engine("winograd")
+    dW, db = K.conv3x3_wgrad([dev(X)], [dev(dY)], M)
+    close(dW.cpu().numpy(), ref_dW, CONV_RTOL, CONV_FLOOR, "wino dW")
+    close(db.cpu().numpy(), ref_db, CONV_RTOL, CONV_FLOOR, "db")
+    # accumulate: dW += on top of a known tensor
+    base = dev(np.full_like(ref_dW, 0.25))
+    K.conv3x3_wgrad([dev(X)], [dev(dY)], M, dW=base, want_db=False, accumulate=True)
+    close(base.cpu().numpy(), ref_dW + 0.25, CONV_RTOL, CONV_FLOOR, "wino dW accumulate")
+
+
+def test_winograd_wgrad_multilevel_matches_direct_full_size(K, wgrad_engine):
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    N, C, M = 4, 256, 256
+    shapes = [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)]
+    Xs = [torch.randn((N, C, h, w), device="cuda", generator=gen) for h, w in shapes]
+    dYs = [torch.randn((N, M, h, w), device="cuda", generator=gen) for h, w in shapes]
+    wgrad_engine("direct")
+    dWd, _ = K.conv3x3_wgrad(Xs, dYs, M, want_db=False)
+    dWd = dWd.clone()
+    wgrad_engine("winograd")
+    dWw, _ = K.conv3x3_wgrad(Xs, dYs, M, want_db=False)
+    close(dWw.cpu().numpy(), dWd.cpu().numpy(), CONV_RTOL, CONV_FLOOR, "wino wgrad vs direct")
+    # deterministic
+    dW2, _ = K.conv3x3_wgrad(Xs, dYs, M, want_db=False)
+    assert torch.equal(dW2, dWw)
