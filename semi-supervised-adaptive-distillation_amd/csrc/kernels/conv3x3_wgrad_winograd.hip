@@ -29,6 +29,10 @@
 // 4 mod 64, right for single ds_read_b64, measured 46 % conflict cycles).
 // The next unit is loaded through registers in
 // three portions requested at k-steps 0-2 and written after k-step 3 (26 VGPRs).
+// Measured (cycle stamps, tower layer): per unit 8.2 k MFMA cycles take 13 k;
+// removing the global staging loads alone brings it to 8.5 k (the loads, not the
+// LDS stores or the transforms, are what stalls the waves); fewer/wider loads
+// with the same number of cache lines touched did not help.
 // Partial dU slabs [S][16][Mp][Cp] are combined, transformed by G and scattered
 // into dW[m][c][3][3] by wino_wgrad_reduce_kernel in a fixed order.
 
@@ -51,6 +55,13 @@ constexpr int XP = 20;                   // X LDS row pitch (18 used)
 constexpr int SX = 130;                  // X LDS channel stride (6 * 20 + 10)
 constexpr int STAGE = GM * SY + GC * SX; // floats per stage
 constexpr unsigned kOOB = 0x80000000u;
+
+#ifdef WGRAD_TIMELINE   // tools/wgrad_timeline.py
+__device__ unsigned long long g_wdbg[64][8];
+#define WDBG(it, k) if (dbg_on && (it) < 64) g_wdbg[it][k] = __builtin_readcyclecounter()
+#else
+#define WDBG(it, k)
+#endif
 
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -234,7 +245,11 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
   }
   __syncthreads();
 
+#ifdef WGRAD_TIMELINE
+  const bool dbg_on = blockIdx.x == 3 && blockIdx.y == 2 && tid == 0;
+#endif
   for (int u = u_begin; u < u_end; ++u) {
+    WDBG(u - u_begin, 0);
     const float* st = lds + ((u - u_begin) & 1) * STAGE;
     float* nst = lds + (((u - u_begin) & 1) ^ 1) * STAGE;
     have_next = u + 1 < u_end;
@@ -257,6 +272,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
         a4[2 * mg + 1] = *reinterpret_cast<const float2*>(ap + UC);
       }
     };
+    WDBG(u - u_begin, 1);
     read_raw(0, rb[0], ra[0]);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -306,10 +322,13 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
         }
       }
     }
+    WDBG(u - u_begin, 2);
 #pragma unroll
     for (int p = 0; p < 3; ++p) store_portion(p, nst);
+    WDBG(u - u_begin, 3);
     if (have_next) advance();
     __syncthreads();
+    WDBG(u - u_begin, 4);
   }
 
   // ---- partial dU slab: [sp][xi][Mp][Cp] ----
@@ -417,11 +436,17 @@ int plan(const ssad_conv_level* lv, int n_levels, int Cout, int Cin, GArgs* a) {
 
 }  // namespace
 
+#ifdef WGRAD_TIMELINE
+extern "C" __attribute__((visibility("default"))) int ssad_wdbg_read(void* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wdbg), sizeof(g_wdbg));
+}
+#endif
+
 bool ssad_wino_wgrad_eligible(int Cout, int Cin) {
   const char* e = getenv("SSAD_WGRAD_ENGINE");
   if (e && e[0] == 'd') return false;            // "direct"
   if (e && e[0] == 'w') return true;             // "winograd"
-  return Cout >= 64 && Cin >= 64;
+  return Cout >= 32 && Cin >= 64;
 }
 
 size_t ssad_wino_wgrad_workspace_bytes(const ssad_conv_level* lv, int n_levels, int Cout, int Cin) {

@@ -8,7 +8,7 @@
 #include "ssad_kernels.h"
 
 // Winograd F(3x3,2x2) filter-gradient engine (conv3x3_wgrad_winograd.hip).
-// Used by ssad_conv3x3_wgrad for Cout, Cin >= 64; SSAD_WGRAD_ENGINE=direct /
+// Used by ssad_conv3x3_wgrad for Cout >= 32, Cin >= 64; SSAD_WGRAD_ENGINE=direct /
 // winograd overrides the choice.
 bool ssad_wino_wgrad_eligible(int Cout, int Cin);
 size_t ssad_wino_wgrad_workspace_bytes(const ssad_conv_level* lv, int n_levels, int Cout, int Cin);
