@@ -101,6 +101,7 @@ class DistillHeads(object):
         self.one = torch.ones(len(self.shapes), dtype=torch.float32, device=device)
         self.focal_losses = None
         self.bbox_losses = None
+        self.preserved = OrderedDict()     # blobs of a loaded weights file the subnets do not own
 
         def lv(ch):
             return [torch.empty((N, ch, h, w), dtype=torch.float32, device=device)
@@ -301,6 +302,26 @@ class DistillHeads(object):
         self.dp.broadcast([self.params.flat, self.moms.flat], src=src)
 
     # -- update -------------------------------------------------------------------------
+    # -- learning rate (detector.py:594-648) ------------------------------------------
+    SCALE_MOMENTUM = True             # cfg.SOLVER.SCALE_MOMENTUM (config.py:634)
+    SCALE_MOMENTUM_THRESHOLD = 1.1    # config.py:638
+
+    def update_lr(self, new_lr):
+        """UpdateWorkspaceLr: set the step's learning rate; when it changes by more
+        than the threshold the update history V (= mu*V + lr*grad, so it carries
+        the old lr) is rescaled by new/old in one pass over the flat momentum
+        buffer (_CorrectMomentum runs one Scale op per parameter)."""
+        cur_lr = float(self.lr.item())
+        new_lr = float(np.float32(new_lr))
+        if cur_lr == new_lr:
+            return new_lr
+        eps = 1e-10
+        ratio = max(new_lr / max(cur_lr, eps), cur_lr / max(new_lr, eps))
+        self.lr.fill_(new_lr)
+        if self.SCALE_MOMENTUM and cur_lr > 1e-7 and ratio > self.SCALE_MOMENTUM_THRESHOLD:
+            K.scale_(self.moms.flat, new_lr / cur_lr)
+        return new_lr
+
     def sgd_step(self):
         self.wait_gradients()
         for name, _, is_bias, _ in self.params.specs:
