@@ -167,6 +167,14 @@ SSAD_API int ssad_scale(const float* x, float* y, float alpha, int64_t n,
  * device blob); out may alias x_0; n_pairs <= 8 */
 SSAD_API int ssad_weighted_sum(const float* const* xs_host, const float* const* ws_host,
                                int n_pairs, float* out, int64_t n, ssad_stream_t stream);
+/* AffineChannel (caffe2/modules/detectron/affine_channel_op.cu:27-40) with the
+ * residual Sum and Relu of a ResNet bottleneck folded in:
+ * y[n][c][p] = act(x[n][c][p] * scale[c] + bias[c] + residual[n][c][p]);
+ * scale, bias, residual may be NULL (1, 0, 0); relu != 0 clamps at 0; y may
+ * alias x or residual.  NCHW with HW = H*W. */
+SSAD_API int ssad_affine_channel(const float* x, const float* scale, const float* bias,
+                                 const float* residual, float* y, int N, int C, int HW,
+                                 int relu, ssad_stream_t stream);
 /* y[i] = value (ConstantFill) */
 SSAD_API int ssad_fill(float* y, float value, int64_t n, ssad_stream_t stream);
 /* Fused parameter update (detectron/lib/modeling/optimizer.py:115-130 +

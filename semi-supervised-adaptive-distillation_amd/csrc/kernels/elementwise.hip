@@ -141,6 +141,40 @@ int launch_map(const float* a, const float* b, float* y, int64_t n, F f, ssad_st
   return (int)hipGetLastError();
 }
 
+// AffineChannel (caffe2/modules/detectron/affine_channel_op.cu:27-40:
+// y = x * scale[c] + bias[c]) with the residual Sum and the Relu that follow it in a
+// ResNet bottleneck (detectron/lib/modeling/ResNet.py:193-245) folded into the one pass:
+//   y[n][c][p] = act(x[n][c][p] * scale[c] + bias[c] + residual[n][c][p]).
+// One workgroup per (n, c) row slice; scale / residual optional; in place allowed.
+__global__ __launch_bounds__(kThreads) void affine_channel_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ bias,
+    const float* __restrict__ residual, float* __restrict__ y, long long rows, int C, int HW,
+    int vec, int relu, int rows_per_block) {
+  const long long row0 = (long long)blockIdx.x * rows_per_block;
+  for (int rr = 0; rr < rows_per_block; ++rr) {
+    const long long row = row0 + rr;
+    if (row >= rows) break;
+    const int c = (int)(row % C);
+    const float s = scale ? scale[c] : 1.0f, b = bias ? bias[c] : 0.0f;
+    const float lo = relu ? 0.0f : -__builtin_inff();
+    const float* xr = x + row * HW;
+    const float* rp = residual ? residual + row * HW : nullptr;
+    float* yr = y + row * HW;
+    const int n4 = vec ? (HW >> 2) : 0;
+    for (int i = threadIdx.x; i < n4; i += kThreads) {
+      const float4 v = reinterpret_cast<const float4*>(xr)[i];
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rp) r = reinterpret_cast<const float4*>(rp)[i];
+      float4 o;
+      o.x = fmaxf(fmaf(v.x, s, b) + r.x, lo); o.y = fmaxf(fmaf(v.y, s, b) + r.y, lo);
+      o.z = fmaxf(fmaf(v.z, s, b) + r.z, lo); o.w = fmaxf(fmaf(v.w, s, b) + r.w, lo);
+      reinterpret_cast<float4*>(yr)[i] = o;
+    }
+    for (int i = n4 * 4 + threadIdx.x; i < HW; i += kThreads)
+      yr[i] = fmaxf(fmaf(xr[i], s, b) + (rp ? rp[i] : 0.0f), lo);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -213,5 +247,21 @@ int ssad_fill(float* y, float value, int64_t n, ssad_stream_t stream) {
 
 const char* ssad_kernels_arch(void) { return "gfx950"; }
 int ssad_kernels_abi_version(void) { return 1; }
+
+int ssad_affine_channel(const float* x, const float* scale, const float* bias,
+                        const float* residual, float* y, int N, int C, int HW, int relu,
+                        ssad_stream_t stream) {
+  if (N < 0 || C <= 0 || HW < 0 || !x || !y) return SSAD_E_BADARG;
+  const long long rows = (long long)N * C;
+  if (rows == 0 || HW == 0) return 0;
+  if (rows >= (1LL << 31)) return SSAD_E_BADARG;
+  const int vec = !(HW & 3) && aligned16(x, y, residual);
+  // small rows: several per workgroup so a launch stays <= ~64 K workgroups
+  int rpb = 1;
+  while (rows / rpb > 65536) rpb *= 2;
+  hipLaunchKernelGGL(affine_channel_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, scale, bias, residual, y, rows, C, HW, vec, relu, rpb);
+  return (int)hipGetLastError();
+}
 
 }  // extern "C"

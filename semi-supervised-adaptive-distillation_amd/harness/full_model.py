@@ -53,6 +53,37 @@ class _HipConv3x3Fn(torch.autograd.Function):
         return dx, dW, db, None, None
 
 
+class _BiasActFn(torch.autograd.Function):
+    """y = act(z + bias[c] (+ residual)) in ONE in-place pass over the conv output z
+    (torch runs bias add, residual add and ReLU as three passes).  z must not be
+    needed by its producer's backward (a convolution needs only input and weight)."""
+
+    @staticmethod
+    def forward(ctx, z, bias, residual, relu):
+        K = _K()
+        y = K.affine_channel_(z, bias.detach().contiguous(), residual=residual, relu=relu)
+        ctx.mark_dirty(z)
+        ctx.relu, ctx.has_res = relu, residual is not None
+        ctx.save_for_backward(y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        K = _K()
+        (y,) = ctx.saved_tensors
+        dz = dy.contiguous()
+        if ctx.relu:
+            dz = K.relu_grad(y, dz)
+        db = dz.sum((0, 2, 3)) if ctx.needs_input_grad[1] else None
+        return dz, db, (dz if ctx.has_res else None), None
+
+
+def bias_act(z, bias, residual=None, relu=True):
+    if not (z.requires_grad or bias.requires_grad or (residual is not None and residual.requires_grad)):
+        return _K().affine_channel_(z, bias.detach().contiguous(), residual=residual, relu=relu)
+    return _BiasActFn.apply(z, bias, residual, relu)
+
+
 class HipConv3x3(nn.Module):
     def __init__(self, cin, cout, relu=False):
         super().__init__()
@@ -80,6 +111,9 @@ class HipConv3x3(nn.Module):
 # (SSAD_HARNESS_HIP3X3=0), 155.0 ms MIOpen-only NCHW, 149.3 ms HIP 3x3 inside a
 # channels-last harness (layout copies around every call).
 _HIP3X3 = os.environ.get("SSAD_HARNESS_HIP3X3", "1") == "1"
+# bias + residual + ReLU after the MIOpen / rocBLAS convolutions of a bottleneck as one
+# fused AffineChannel pass of this repo (NCHW only) instead of three torch passes
+_FUSE_TAIL = os.environ.get("SSAD_HARNESS_FUSE_TAIL", "1") == "1"
 
 
 def conv_frozen_bn(cin, cout, k, stride=1, padding=0):
@@ -101,6 +135,12 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         sc = x if self.proj is None else self.proj(x)
+        if _FUSE_TAIL and x.is_contiguous():
+            # convolution without bias, then bias (+ residual) + ReLU in one pass
+            y = bias_act(F.conv2d(x, self.c1.weight, None, self.c1.stride), self.c1.bias)
+            y = self.c2(y) if self.hip2 else bias_act(
+                F.conv2d(y, self.c2.weight, None, 1, 1), self.c2.bias)
+            return bias_act(F.conv2d(y, self.c3.weight, None), self.c3.bias, residual=sc)
         y = F.relu(self.c1(x), inplace=True)
         y = self.c2(y) if self.hip2 else F.relu(self.c2(y), inplace=True)
         y = self.c3(y)
@@ -181,6 +221,8 @@ class FullDistillModel(object):
         if self.channels_last:
             self.student = self.student.to(memory_format=torch.channels_last)
             self.teacher = self.teacher.to(memory_format=torch.channels_last)
+        self.two_streams = os.environ.get("SSAD_HARNESS_TWO_STREAMS", "1") == "1"
+        self.side = torch.cuda.Stream() if self.two_streams else None
         self.trainable = [p for p in self.student.parameters() if p.requires_grad]
         self.opt = torch.optim.SGD(self.trainable, lr=lr, momentum=momentum,
                                    weight_decay=weight_decay)
@@ -210,12 +252,29 @@ class FullDistillModel(object):
         if self.channels_last:
             images = images.contiguous(memory_format=torch.channels_last)
         h.pack_student()
-        with torch.no_grad():
-            t_fpn = [t.contiguous() for t in self.teacher(images)]
-        self._mark("teacher backbone fwd")
-        s_fpn = self.student(images)
-        s_in = [t.detach().contiguous() for t in s_fpn]
-        self._mark("student backbone fwd")
+        if self.two_streams:
+            # teacher and student backbones are independent: on two streams the
+            # last partial round of CUs of one network's kernel is filled by the
+            # other network's next kernel (persistent / few-round launches leave
+            # 5-20 % of a launch idle at these feature-map sizes)
+            cur = torch.cuda.current_stream()
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                with torch.no_grad():
+                    t_fpn = [t.contiguous() for t in self.teacher(images)]
+            s_fpn = self.student(images)
+            s_in = [t.detach().contiguous() for t in s_fpn]
+            cur.wait_stream(self.side)
+            for t in t_fpn:
+                t.record_stream(cur)
+            self._mark("teacher + student backbone fwd (two streams)")
+        else:
+            with torch.no_grad():
+                t_fpn = [t.contiguous() for t in self.teacher(images)]
+            self._mark("teacher backbone fwd")
+            s_fpn = self.student(images)
+            s_in = [t.detach().contiguous() for t in s_fpn]
+            self._mark("student backbone fwd")
         h.forward_all(t_fpn, s_in)
         self._mark("subnets fwd (teacher+student)")
         h.cls_losses(labels, fg_num)

@@ -89,6 +89,7 @@ def lib():
     L.ssad_sigmoid.argtypes = [vp, vp, i64, vp]
     L.ssad_sum_n.argtypes = [C.POINTER(vp), i32, vp, i64, vp]
     L.ssad_scale.argtypes = [vp, vp, f32, i64, vp]
+    L.ssad_affine_channel.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.ssad_momentum_sgd_update.argtypes = [vp, vp, vp, vp, f32, f32, i32, i64, vp]
     L.ssad_conv_packed_filter_floats.restype = sz
     L.ssad_conv_packed_filter_floats.argtypes = [i32, i32]
@@ -131,7 +132,8 @@ _ws_cache = {}
 
 def _workspace(nbytes, tag):
     dev = torch.cuda.current_device()
-    key = (dev, tag)
+    # one buffer per (device, stream, use): launches on different streams may overlap
+    key = (dev, torch.cuda.current_stream().cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device="cuda")
@@ -302,6 +304,19 @@ def relu_grad(y, dy, out=None):
     _check(lib().ssad_relu_grad(_ptr(_f32c(y, "y")), _ptr(_f32c(dy, "dy")), _ptr(dx),
                                 y.numel(), _stream()), "relu_grad")
     return dx
+
+
+def affine_channel_(x, bias, scale=None, residual=None, relu=False):
+    """In place: x[n,c,:,:] = act(x * scale[c] + bias[c] + residual) (AffineChannel
+    + the bottleneck's residual Sum + Relu in one pass over an NCHW tensor)."""
+    _f32c(x, "x")
+    N, Cc = x.shape[0], x.shape[1]
+    hw = x.numel() // max(N * Cc, 1)
+    if residual is not None:
+        _f32c(residual, "residual")
+    _check(lib().ssad_affine_channel(_ptr(x), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(x),
+                                     N, Cc, hw, int(relu), _stream()), "affine_channel")
+    return x
 
 
 def sigmoid(x, out=None):

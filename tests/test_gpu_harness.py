@@ -56,3 +56,38 @@ def test_hip_conv3x3_autograd_matches_torch(fm, relu, channels_last):
         yf = m(x)
     assert _rel(yf, yr) < 1e-4
     assert np.isfinite(float(yf.sum()))
+
+
+@pytest.mark.parametrize("relu,with_res", [(True, True), (True, False), (False, True)])
+def test_fused_bias_residual_relu_matches_torch(fm, relu, with_res):
+    torch.manual_seed(9)
+    N, C, H, W = 3, 70, 9, 13                      # HW = 117: scalar tail path
+    z = torch.randn(N, C, H, W, device="cuda")
+    b = torch.randn(C, device="cuda")
+    r = torch.randn(N, C, H, W, device="cuda") if with_res else None
+    dy = torch.randn(N, C, H, W, device="cuda")
+
+    zr, br = z.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if with_res else None
+    yr = zr + br.view(1, C, 1, 1)
+    if with_res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy)
+
+    zs = z.clone().requires_grad_(True)
+    bh = b.clone().requires_grad_(True)
+    rh = r.clone().requires_grad_(True) if with_res else None
+    yh = fm.bias_act(zs * 1.0, bh, residual=rh, relu=relu)     # zs*1.0: a non-leaf, like a conv output
+    yh.backward(dy)
+    assert torch.allclose(yh, yr, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(zs.grad, zr.grad, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(bh.grad, br.grad, rtol=1e-5, atol=1e-4)
+    if with_res:
+        assert torch.allclose(rh.grad, rr.grad, rtol=1e-6, atol=1e-6)
+    # vectorised path (HW % 4 == 0), no autograd
+    z4 = torch.randn(2, 8, 4, 8, device="cuda")
+    want = torch.relu(z4 + b[:8].view(1, 8, 1, 1))
+    got = fm.bias_act(z4.clone(), b[:8].clone(), relu=True)
+    assert torch.equal(got, want)
