@@ -253,6 +253,37 @@ SSAD_API int ssad_conv3x3_wgrad(
     ssad_stream_t stream);
 
 /* ---------------------------------------------------------------------- */
+/* RetinaNet anchor labelling on the device (row f4)                       */
+/* ---------------------------------------------------------------------- */
+
+/* Replaces the numpy labelling of detectron/lib/roi_data/retinanet.py:97-306
+ * (+ data_utils.py:52-103, utils/cython_bbox.pyx:31-74, utils/boxes.py:193-224).
+ *   cell_anchors     device double [levels][A][4]: the A anchors of one cell per level
+ *                    (modeling/generate_anchors.py), octave-major then aspect ratio
+ *   field_sizes_host anchors are laid on a field_size x field_size grid per level
+ *                    (data_utils.py:71-75); crop_h/w_host: int(blob size / stride)
+ *   gt_boxes         device float [N][Gmax][4] (scaled), gt_classes int [N][Gmax]
+ *                    (1..num_classes-1), gt_counts int [N] valid entries per image
+ * Outputs per level l (host arrays of device pointers):
+ *   labels_out[l]    int32 [N][A][crop_h][crop_w]       retnet_cls_labels_fpn
+ *   locs_out[l]      float [capacity][4] = image, 4*anchor, y, x   retnet_roi_fg_bbox_locs_fpn
+ *   targets_out[l]   float [capacity][4]                retnet_roi_bbox_targets_fpn
+ *   counts_out       device int [levels]: entries produced (M); entries beyond
+ *                    `capacity` are dropped -- compare on the host
+ *   fg_bg_out        device float [2] = retnet_fg_num, retnet_bg_num
+ * The list order (image, anchor, y, x) and every tie rule follow the reference. */
+SSAD_API size_t ssad_retinanet_anchor_labels_workspace_bytes(
+    int levels, int A, int k_min, const int* field_sizes_host, int N, int Gmax);
+SSAD_API int ssad_retinanet_anchor_labels(
+    const double* cell_anchors, int levels, int A, int k_min, const int* field_sizes_host,
+    const int* crop_h_host, const int* crop_w_host, const float* gt_boxes,
+    const int* gt_classes, const int* gt_counts, int N, int Gmax, int num_classes,
+    float positive_overlap, float negative_overlap, int* const* labels_out_host,
+    float* const* locs_out_host, float* const* targets_out_host, int capacity,
+    int* counts_out, float* fg_bg_out, void* workspace, size_t workspace_bytes,
+    ssad_stream_t stream);
+
+/* ---------------------------------------------------------------------- */
 /* Introspection                                                           */
 /* ---------------------------------------------------------------------- */
 SSAD_API const char* ssad_kernels_arch(void);   /* "gfx950" */

@@ -481,6 +481,10 @@ __device__ __forceinline__ float smooth_l1_term(const float* __restrict__ Y_hat,
                                                 int W, float beta, double s) {
   const int i = e >> 2, j = e & 3;
   const int n = (int)Lc[i * 4], c = (int)Lc[i * 4 + 1], y = (int)Lc[i * 4 + 2], x = (int)Lc[i * 4 + 3];
+  // the reference's labelling can list anchors of the full anchor field that lie outside
+  // the (cropped) prediction map (roi_data/retinanet.py:278-293); it would read out of
+  // bounds there -- such entries contribute nothing here
+  if (y >= H || x >= W || y < 0 || x < 0) return 0.0f;
   const size_t ind = ((size_t)n * D + c + j) * H * W + (size_t)y * W + x;
   const float val = Y_hat[ind] - Y[e];
   const float a = fabsf(val);
@@ -519,6 +523,7 @@ __global__ __launch_bounds__(kThreads) void smooth_l1_bwd_kernel(
   for (int e = blockIdx.x * kThreads + threadIdx.x; e < M * 4; e += gridDim.x * kThreads) {
     const int i = e >> 2, j = e & 3;
     const int n = (int)Lc[i * 4], c = (int)Lc[i * 4 + 1], y = (int)Lc[i * 4 + 2], x = (int)Lc[i * 4 + 3];
+    if (y >= H || x >= W || y < 0 || x < 0) continue;     // see smooth_l1_term
     const size_t ind = ((size_t)n * D + c + j) * H * W + (size_t)y * W + x;
     const float val = Y_hat[ind] - Y[e];
     const float a = fabsf(val);

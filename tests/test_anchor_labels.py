@@ -1,0 +1,135 @@
+"""RetinaNet anchor labelling (row f4): oracle pinning on the CPU, HIP parity on the GPU."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from oracle import anchors as OA
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SO = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "cython_bbox.so")
+
+
+def rand_gts(rng, n, H=640, W=896, integer=False):
+    x1 = rng.uniform(0, W - 40, n)
+    y1 = rng.uniform(0, H - 40, n)
+    w = rng.uniform(12, 400, n)
+    h = rng.uniform(12, 400, n)
+    b = np.stack([x1, y1, np.minimum(x1 + w, W - 1), np.minimum(y1 + h, H - 1)], 1)
+    if integer:
+        b = np.round(b)          # integer boxes produce exact IoU ties between anchors
+    return b.astype(np.float32), rng.integers(1, 81, n).astype(np.int32)
+
+
+def test_cell_anchors_known_answers_and_product_module():
+    import ssad_amd  # noqa: F401
+    from ssad_amd.modeling import generate_anchors as GA
+    # outputs of the reference's generate_anchors(16, (128, 256, 512), (0.5, 1, 2)) run in
+    # the build container (its docstring table, generate_anchors.py:28-50, is the 1-based
+    # MATLAB original; the code subtracts 1, :77)
+    want = {(128, 0.5): [-84, -40, 99, 55], (256, 0.5): [-176, -88, 191, 103],
+            (512, 0.5): [-360, -184, 375, 199], (128, 1): [-56, -56, 71, 71],
+            (512, 1): [-248, -248, 263, 263], (128, 2): [-36, -80, 51, 95],
+            (512, 2): [-168, -344, 183, 359]}
+    for (size, ar), box in want.items():
+        assert np.array_equal(GA.cell_anchor(16, size, ar), np.array(box, float))
+        assert np.array_equal(OA.generate_anchors(16, (size,), (ar,))[0], np.array(box, float))
+    assert np.array_equal(GA.cell_anchors().astype(np.float32), OA.cell_anchors())
+    assert GA.field_sizes() == [128, 64, 32, 16, 8]
+    anchors, meta = OA.all_anchors()
+    assert anchors.shape == (9 * (128 ** 2 + 64 ** 2 + 32 ** 2 + 16 ** 2 + 8 ** 2), 4)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/cython_bbox.so not built "
+                    "(make -C oracle ref, needs /root/reference)")
+def test_oracle_iou_bit_exact_vs_compiled_reference():
+    spec = importlib.util.spec_from_file_location("cython_bbox", REF_SO)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    anchors, _ = OA.all_anchors()
+    rng = np.random.default_rng(5)
+    for integer in (False, True):
+        g, _ = rand_gts(rng, 37, integer=integer)
+        assert np.array_equal(ref.bbox_overlaps(anchors, g), OA.bbox_overlaps(anchors, g))
+
+
+def test_oracle_labelling_invariants():
+    rng = np.random.default_rng(6)
+    g = [rand_gts(rng, 7, integer=True), rand_gts(rng, 3)]
+    out = OA.retinanet_blobs([x[0] for x in g], [x[1] for x in g], 640, 896)
+    for lvl, (h, w) in zip(range(3, 8), ((80, 112), (40, 56), (20, 28), (10, 14), (5, 7))):
+        lab = out["labels_fpn%d" % lvl]
+        assert lab.shape == (2, 9, h, w) and lab.dtype == np.int32
+        assert lab.min() >= -1 and lab.max() <= 80
+        locs, tg = out["locs_fpn%d" % lvl], out["targets_fpn%d" % lvl]
+        assert locs.shape == tg.shape and locs.shape[1] == 4
+        # list order: image, anchor, y, x
+        key = [tuple(r) for r in locs]
+        assert key == sorted(key)
+        inside = (locs[:, 2] < h) & (locs[:, 3] < w)
+        for r in locs[inside]:
+            assert lab[int(r[0]), int(r[1]) // 4, int(r[2]), int(r[3])] > 0
+    assert out["fg_num"] > 0 and out["bg_num"] > out["fg_num"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["random", "integer_ties", "single_gt_image"])
+def test_device_labelling_matches_oracle(case):
+    import torch
+    import ssad_amd  # noqa: F401
+    from ssad_amd.roi_data.retinanet import RetinanetLabeler
+    rng = np.random.default_rng({"random": 11, "integer_ties": 12, "single_gt_image": 13}[case])
+    N, Gmax, H, W = 3, 24, 640, 896
+    counts = [9, 24, 1]
+    gts = [rand_gts(rng, c, H, W, integer=(case == "integer_ties")) for c in counts]
+    boxes = np.zeros((N, Gmax, 4), np.float32)
+    classes = np.zeros((N, Gmax), np.int32)
+    for i, (b, c) in enumerate(gts):
+        boxes[i, :len(b)] = b
+        classes[i, :len(c)] = c
+    lab = RetinanetLabeler(N, Gmax, H, W)
+    blobs = lab(torch.as_tensor(boxes).cuda(), torch.as_tensor(classes).cuda(),
+                torch.as_tensor(np.array(counts, np.int32)).cuda())
+    ref = OA.retinanet_blobs([g[0] for g in gts], [g[1] for g in gts], H, W)
+    assert float(blobs["retnet_fg_num"]) == float(ref["fg_num"])
+    assert float(blobs["retnet_bg_num"]) == float(ref["bg_num"])
+    for lvl in range(3, 8):
+        got = blobs["retnet_cls_labels_fpn%d" % lvl].cpu().numpy()
+        assert np.array_equal(got, ref["labels_fpn%d" % lvl]), "labels level %d" % lvl
+        locs = blobs["retnet_roi_fg_bbox_locs_fpn%d" % lvl].cpu().numpy()
+        assert np.array_equal(locs, ref["locs_fpn%d" % lvl]), "fg list level %d" % lvl
+        tg = blobs["retnet_roi_bbox_targets_fpn%d" % lvl].cpu().numpy()
+        np.testing.assert_allclose(tg, ref["targets_fpn%d" % lvl], rtol=2e-6, atol=2e-7)
+
+
+@pytest.mark.gpu
+def test_device_labelling_image_without_ground_truth():
+    """Documented deviation: the reference asserts; here such an image is all background."""
+    import torch
+    import ssad_amd  # noqa: F401
+    from ssad_amd.roi_data.retinanet import RetinanetLabeler
+    rng = np.random.default_rng(21)
+    N, Gmax, H, W = 3, 8, 640, 896
+    counts = [5, 0, 8]
+    gts = [rand_gts(rng, max(c, 1), H, W) for c in counts]
+    boxes = np.zeros((N, Gmax, 4), np.float32)
+    classes = np.zeros((N, Gmax), np.int32)
+    for i, (b, c) in enumerate(gts):
+        boxes[i, :counts[i]] = b[:counts[i]]
+        classes[i, :counts[i]] = c[:counts[i]]
+    blobs = RetinanetLabeler(N, Gmax, H, W)(
+        torch.as_tensor(boxes).cuda(), torch.as_tensor(classes).cuda(),
+        torch.as_tensor(np.array(counts, np.int32)).cuda())
+    ref = OA.retinanet_blobs([gts[0][0], gts[2][0]], [gts[0][1], gts[2][1]], H, W)
+    T = 9 * (128 ** 2 + 64 ** 2 + 32 ** 2 + 16 ** 2 + 8 ** 2)
+    assert float(blobs["retnet_fg_num"]) == float(ref["fg_num"])
+    assert float(blobs["retnet_bg_num"]) == float(np.float32(float(ref["bg_num"]) + (T + 1.0) * 80))
+    for lvl in range(3, 8):
+        got = blobs["retnet_cls_labels_fpn%d" % lvl].cpu().numpy()
+        assert np.array_equal(got[[0, 2]], ref["labels_fpn%d" % lvl])
+        assert not got[1].any()
+        locs = blobs["retnet_roi_fg_bbox_locs_fpn%d" % lvl].cpu().numpy().copy()
+        assert not (locs[:, 0] == 1).any()
+        locs[:, 0] = np.where(locs[:, 0] == 2, 1, locs[:, 0])
+        assert np.array_equal(locs, ref["locs_fpn%d" % lvl])
