@@ -15,8 +15,9 @@
 // MFMAs whose A operand is a linear 16-byte-per-lane stream from the
 // pre-packed filter and whose B operands are `ds_read_b64 base+imm` of V):
 //   wino_conv_kernel    one workgroup per tile, register-staged raw patch,
-//                       transform burst.  Any Cin.  (SSAD_WINO_VARIANT=0)
-//   wino_conv_z_kernel  the default for Cin % 16 == 0: persistent workgroups,
+//                       transform burst.  (SSAD_WINO_VARIANT=0, kept as the
+//                       simple reference implementation of the engine)
+//   wino_conv_z_kernel  the default: persistent workgroups,
 //                       LDS-DMA staging, transform / staging / tile bookkeeping
 //                       threaded through the MFMA steps (see its header).
 // The epilogue applies A^T M A lane-locally (the 16 xi accumulators of one
@@ -851,7 +852,7 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
   if (blocks == 0) return 0;
   a.patches = (int)blocks; a.mblocks = cdiv(Cout, BM);
   static const int variant = [] { const char* e = getenv("SSAD_WINO_VARIANT"); return e ? atoi(e) : 2; }();
-  if (variant == 2 && a.chunks * KC == Cin) {
+  if (variant == 2) {   // any Cin: channels past Cin read as zero (buffer range check, zero-padded filter)
     static const int cus2 = [] {
       int dev = 0, n = 0;
       if (hipGetDevice(&dev) != hipSuccess ||
@@ -866,7 +867,7 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
     hipLaunchKernelGGL(wino_conv_z_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
   }
-  // Cin not a multiple of 16, or SSAD_WINO_VARIANT=0: the non-persistent kernel
+  // SSAD_WINO_VARIANT=0: the non-persistent kernel
   hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)blocks, cdiv(Cout, BM)), dim3(kBlock), 0,
                      (hipStream_t)stream, a);
   return (int)hipGetLastError();

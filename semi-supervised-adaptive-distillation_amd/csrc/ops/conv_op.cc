@@ -62,12 +62,12 @@ bool IsSubnetGeometry(const ConvGeometry& g) {
 }
 
 // Algorithm choice, like cuDNN's internal one (conv_op_cudnn.cc:541-558):
-// Winograd F(2x2,3x3) for outputs >= 128 channels wide, the direct kernel
+// Winograd F(2x2,3x3) for outputs >= 32 channels wide, the direct kernel
 // otherwise; arg hip_algo = "direct" | "winograd" overrides.
 bool UseWinograd(const string& algo, int out_channels) {
   if (algo == "direct") return false;
   if (algo == "winograd") return true;
-  return out_channels >= 128;
+  return out_channels >= 32;
 }
 
 namespace {

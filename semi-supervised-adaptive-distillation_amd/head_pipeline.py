@@ -136,7 +136,7 @@ class DistillHeads(object):
     # gradient), the direct kernel for the 36-channel bbox_pred forward.
     # SSAD_CONV_ENGINE=direct forces the direct kernel everywhere.
     def _use_wino(self, cout):
-        return self.wino and cout >= 128
+        return self.wino and cout >= 32
 
     def _pack(self, w, want_fwd, want_dgrad):
         """-> (fwd_packed, dgrad_packed) in the layout of the engine that will

@@ -84,7 +84,7 @@ def main():
             print("%-18s fwd   all-levels %8.3f ms  %6.1f TF/s" % (name, t, fl / t / 1e9))
             t = timeit(lambda: K.conv3x3_forward(Xs[:1], pf, b, M, relu=True, out=Ys[:1]))
             print("%-18s fwd   P3 only    %8.3f ms  %6.1f TF/s" % (name, t, 2.0 * 9 * M * Cin * N * 8960 / t / 1e9))
-            if M >= 128:
+            if M >= 32:
                 wf, wd = K.conv_wino_pack_filter(Wt)
                 t = timeit(lambda: K.conv3x3_forward(Xs, wf, b, M, relu=True, out=Ys, wino=True))
                 print("%-18s WINO fwd all-lvl %8.3f ms  %6.1f TF/s (direct-equivalent)" % (name, t, fl / t / 1e9))
