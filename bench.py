@@ -14,7 +14,7 @@ Workloads
          kernels end to end), fed synthetic FPN features;
   full   BASELINE config "R-50 student + R-101 teacher, bs=16/GPU, 600 px":
          ResNet-FPN backbones run as a PyTorch harness (out of
-         scope as hand kernels) whose >=128-channel 3x3 convolutions call this
+         scope as hand kernels) whose stride-1 3x3 convolutions call this
          repo's Winograd / wgrad kernels (the rest is MIOpen / rocBLAS); subnets
          + losses through the HIP kernels.  This is the configuration the
          metric is quoted on.

@@ -104,13 +104,14 @@ class HipConv3x3(nn.Module):
         return _HipConv3x3Fn.apply(x, self.weight, self.bias, self.relu, cl)
 
 
-# Default: the stride-1 3x3 convolutions with >= 128 channels (res3..res5 bottlenecks, FPN
-# output convs: 49 forward + 16 backward layers per step) run on this repo's Winograd /
+# Default: every stride-1 3x3 convolution of the bottlenecks (res2..res5) and the FPN output
+# convs (55 forward + 16 backward layers per step) run on this repo's Winograd /
 # wgrad kernels with bias and ReLU fused, and the harness stays NCHW.  Measured on one
 # MI355X, bs 16: 143.9 ms/step against 150.7 ms for MIOpen-only channels-last
 # (SSAD_HARNESS_HIP3X3=0), 155.0 ms MIOpen-only NCHW, 149.3 ms HIP 3x3 inside a
 # channels-last harness (layout copies around every call).
 _HIP3X3 = os.environ.get("SSAD_HARNESS_HIP3X3", "1") == "1"
+_HIP3X3_MIN = int(os.environ.get("SSAD_HARNESS_HIP3X3_MIN", "64"))
 # bias + residual + ReLU after the MIOpen / rocBLAS convolutions of a bottleneck as one
 # fused AffineChannel pass of this repo (NCHW only) instead of three torch passes
 _FUSE_TAIL = os.environ.get("SSAD_HARNESS_FUSE_TAIL", "1") == "1"
@@ -128,7 +129,7 @@ class Bottleneck(nn.Module):
     def __init__(self, cin, cmid, cout, stride):
         super().__init__()
         self.c1 = conv_frozen_bn(cin, cmid, 1, stride=stride)
-        self.hip2 = _HIP3X3 and cmid >= 128
+        self.hip2 = _HIP3X3 and cmid >= _HIP3X3_MIN
         self.c2 = HipConv3x3(cmid, cmid, relu=True) if self.hip2 else conv_frozen_bn(cmid, cmid, 3, padding=1)
         self.c3 = conv_frozen_bn(cmid, cout, 1)
         self.proj = conv_frozen_bn(cin, cout, 1, stride=stride) if (cin != cout or stride != 1) else None
