@@ -201,8 +201,8 @@ def main():
         def step():
             model.step(images, labels, bbox_targets, fg_num)
         wl = ("R-50-FPN student + R-101-FPN teacher adaptive distillation, 600 px (3x640x896): "
-              "backbones = PyTorch harness (MIOpen/rocBLAS 1x1, 7x7, strided and 64-channel "
-              "convs; its other 3x3 convs on this repo's kernels); subnets, distillation + "
+              "backbones = PyTorch harness (MIOpen/rocBLAS 1x1, 7x7 and strided convs; its "
+              "stride-1 3x3 convs on this repo's kernels); subnets, distillation + "
               "focal + smooth-L1 losses and subnet SGD = this repo's HIP kernels")
 
     for _ in range(args.warmup):
