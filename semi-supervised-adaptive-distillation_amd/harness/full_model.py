@@ -78,6 +78,38 @@ class _BiasActFn(torch.autograd.Function):
         return dz, db, (dz if ctx.has_res else None), None
 
 
+class _Conv1x1Fn(torch.autograd.Function):
+    """Stride-1 pointwise convolution without bias.  Forward and data gradient stay on
+    MIOpen / rocBLAS; the weight gradient is one rocBLAS strided-batched GEMM
+    dW = sum_n dY[n] (M x P) . X[n]^T (P x C) instead of MIOpen's NHWC igemm, which for
+    NCHW tensors costs two layout transposes per call on top of the GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x, w, None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(
+                dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            N, M = dy.shape[0], dy.shape[1]
+            Cc = x.shape[1]
+            dw = torch.bmm(dy.view(N, M, -1), x.view(N, Cc, -1).transpose(1, 2)).sum(0).view_as(w)
+        return dx, dw
+
+
+def conv1x1(x, w):
+    if _GEMM_WGRAD and w.requires_grad and x.is_contiguous():
+        return _Conv1x1Fn.apply(x, w)
+    return F.conv2d(x, w, None)
+
+
 def bias_act(z, bias, residual=None, relu=True):
     if not (z.requires_grad or bias.requires_grad or (residual is not None and residual.requires_grad)):
         return _K().affine_channel_(z, bias.detach().contiguous(), residual=residual, relu=relu)
@@ -115,6 +147,7 @@ _HIP3X3_MIN = int(os.environ.get("SSAD_HARNESS_HIP3X3_MIN", "64"))
 # bias + residual + ReLU after the MIOpen / rocBLAS convolutions of a bottleneck as one
 # fused AffineChannel pass of this repo (NCHW only) instead of three torch passes
 _FUSE_TAIL = os.environ.get("SSAD_HARNESS_FUSE_TAIL", "1") == "1"
+_GEMM_WGRAD = os.environ.get("SSAD_HARNESS_GEMM_WGRAD", "1") == "1"
 
 
 def conv_frozen_bn(cin, cout, k, stride=1, padding=0):
@@ -138,10 +171,12 @@ class Bottleneck(nn.Module):
         sc = x if self.proj is None else self.proj(x)
         if _FUSE_TAIL and x.is_contiguous():
             # convolution without bias, then bias (+ residual) + ReLU in one pass
-            y = bias_act(F.conv2d(x, self.c1.weight, None, self.c1.stride), self.c1.bias)
+            z = conv1x1(x, self.c1.weight) if self.c1.stride == (1, 1) else \
+                F.conv2d(x, self.c1.weight, None, self.c1.stride)
+            y = bias_act(z, self.c1.bias)
             y = self.c2(y) if self.hip2 else bias_act(
                 F.conv2d(y, self.c2.weight, None, 1, 1), self.c2.bias)
-            return bias_act(F.conv2d(y, self.c3.weight, None), self.c3.bias, residual=sc)
+            return bias_act(conv1x1(y, self.c3.weight), self.c3.bias, residual=sc)
         y = F.relu(self.c1(x), inplace=True)
         y = self.c2(y) if self.hip2 else F.relu(self.c2(y), inplace=True)
         y = self.c3(y)

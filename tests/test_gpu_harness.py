@@ -91,3 +91,17 @@ def test_fused_bias_residual_relu_matches_torch(fm, relu, with_res):
     want = torch.relu(z4 + b[:8].view(1, 8, 1, 1))
     got = fm.bias_act(z4.clone(), b[:8].clone(), relu=True)
     assert torch.equal(got, want)
+
+
+def test_conv1x1_gemm_weight_gradient_matches_torch(fm):
+    torch.manual_seed(11)
+    N, C, M, H, W = 3, 48, 80, 7, 9
+    x = torch.randn(N, C, H, W, device="cuda")
+    w = torch.randn(M, C, 1, 1, device="cuda") * 0.1
+    dy = torch.randn(N, M, H, W, device="cuda")
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, wr).backward(dy)
+    xh, wh = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    fm.conv1x1(xh, wh).backward(dy)
+    assert _rel(xh.grad, xr.grad) < 1e-5
+    assert _rel(wh.grad, wr.grad) < 1e-5
