@@ -165,6 +165,48 @@ class MomentumSGDUpdateHIPOp final : public Operator<HIPContext> {
   int nesterov_;
 };
 
+// AffineChannel / AffineChannelGradient (caffe2/modules/detectron/affine_channel_op.{cc,cu}):
+// Y = X * scale[c] + bias[c];  dX = dY * scale[c].  Frozen-BN replacement of the backbone.
+class AffineChannelHIPOp final : public Operator<HIPContext> {
+ public:
+  using Operator<HIPContext>::Operator;
+  bool RunOnDevice() override {
+    auto& X = Input(0);
+    auto& scale = Input(1);
+    auto& bias = Input(2);
+    auto* Y = Output(0);
+    CAFFE_ENFORCE_EQ(X.ndim(), 4, "AffineChannel: X must be N x C x H x W");
+    CAFFE_ENFORCE_EQ(scale.size(), X.dim32(1));
+    CAFFE_ENFORCE_EQ(bias.size(), X.dim32(1));
+    Y->ResizeLike(X);
+    LAUNCH_OK(ssad_affine_channel(X.data<float>(), scale.data<float>(), bias.data<float>(), nullptr,
+                                  Y->mutable_data<float>(), X.dim32(0), X.dim32(1),
+                                  X.dim32(2) * X.dim32(3), 0, context_.hip_stream()),
+              "AffineChannel");
+    return true;
+  }
+};
+
+class AffineChannelGradientHIPOp final : public Operator<HIPContext> {
+ public:
+  using Operator<HIPContext>::Operator;
+  bool RunOnDevice() override {
+    auto& scale = Input(0);
+    auto& dY = Input(1);
+    auto* dX = Output(0);
+    CAFFE_ENFORCE_EQ(dY.ndim(), 4, "AffineChannelGradient: dY must be N x C x H x W");
+    CAFFE_ENFORCE_EQ(scale.size(), dY.dim32(1));
+    dX->ResizeLike(dY);
+    LAUNCH_OK(ssad_affine_channel(dY.data<float>(), scale.data<float>(), nullptr, nullptr,
+                                  dX->mutable_data<float>(), dY.dim32(0), dY.dim32(1),
+                                  dY.dim32(2) * dY.dim32(3), 0, context_.hip_stream()),
+              "AffineChannelGradient");
+    return true;
+  }
+};
+
+REGISTER_HIP_OPERATOR(AffineChannel, AffineChannelHIPOp);
+REGISTER_HIP_OPERATOR(AffineChannelGradient, AffineChannelGradientHIPOp);
 REGISTER_HIP_OPERATOR(Relu, ReluHIPOp);
 REGISTER_HIP_OPERATOR(ReluGradient, ReluGradientHIPOp);
 REGISTER_HIP_OPERATOR(Sigmoid, SigmoidHIPOp);
@@ -174,6 +216,8 @@ REGISTER_HIP_OPERATOR(WeightedSum, WeightedSumHIPOp);
 REGISTER_HIP_OPERATOR(ConstantFill, ConstantFillHIPOp);
 REGISTER_HIP_OPERATOR(MomentumSGDUpdate, MomentumSGDUpdateHIPOp);
 
+OPERATOR_SCHEMA(AffineChannel).NumInputs(3).NumOutputs(1).AllowInplace({{0, 0}});
+OPERATOR_SCHEMA(AffineChannelGradient).NumInputs(2).NumOutputs(1).AllowInplace({{1, 0}});
 OPERATOR_SCHEMA(Relu).NumInputs(1).NumOutputs(1).AllowInplace({{0, 0}});
 OPERATOR_SCHEMA(ReluGradient).NumInputs(2).NumOutputs(1).AllowInplace({{1, 0}});
 OPERATOR_SCHEMA(Sigmoid).NumInputs(1).NumOutputs(1).AllowInplace({{0, 0}});
@@ -192,6 +236,16 @@ class GetReluGradient : public GradientMakerBase {
   }
 };
 REGISTER_GRADIENT(Relu, GetReluGradient);
+
+// affine_channel_op.cc:66-76: only dX; scale and bias are frozen
+class GetAffineChannelGradient : public GradientMakerBase {
+  using GradientMakerBase::GradientMakerBase;
+  vector<OperatorDef> GetGradientDefs() override {
+    return SingleGradientDef("AffineChannelGradient", "", vector<string>{I(1), GO(0)},
+                             vector<string>{GI(0)}, vector<Argument>());
+  }
+};
+REGISTER_GRADIENT(AffineChannel, GetAffineChannelGradient);
 NO_GRADIENT(PowSum);
 NO_GRADIENT(ConstantFill);
 

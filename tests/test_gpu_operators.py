@@ -113,6 +113,32 @@ def test_conv_relu_operators_and_gradients():
         workspace.RunOperatorOnce(c5)
 
 
+def test_affine_channel_operator_and_gradient():
+    """The backbone's frozen-BN op (affine_channel_op.cu:27-66): y = x*scale[c] + bias[c],
+    dX = dY*scale[c]; in place allowed."""
+    rng = np.random.default_rng(29)
+    N, C, H, W = 2, 19, 7, 11
+    X = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    sc = rng.standard_normal(C).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    dY = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    feed("X", X); feed("s", sc); feed("b", b); feed("Y_grad", dY)
+    with core.DeviceScope(GPU):
+        op = core.CreateOperator("AffineChannel", ["X", "s", "b"], ["Y"])
+    workspace.RunOperatorOnce(op)
+    want = np.float32(X * sc[None, :, None, None]) + b[None, :, None, None]
+    np.testing.assert_allclose(workspace.FetchBlob("Y"), want, rtol=1e-6, atol=1e-6)
+    g, gi = core.GradientRegistry.GetGradientForOp(op, ["Y_grad"])
+    assert [o.type for o in g] == ["AffineChannelGradient"] and list(g[0].input) == ["s", "Y_grad"]
+    workspace.RunOperatorsOnce(g)
+    assert np.array_equal(workspace.FetchBlob(gi[0]), dY * sc[None, :, None, None])
+    assert gi[1] is None and gi[2] is None            # scale / bias are frozen
+    with core.DeviceScope(GPU):
+        inplace = core.CreateOperator("AffineChannel", ["X", "s", "b"], ["X"])
+    workspace.RunOperatorOnce(inplace)
+    np.testing.assert_allclose(workspace.FetchBlob("X"), want, rtol=1e-6, atol=1e-6)
+
+
 def test_sgd_update_ops_follow_optimizer_py():
     """Scale(2x) for biases / WeightedSum(g + wd*w) for weights, then
     MomentumSGDUpdate (detectron/lib/modeling/optimizer.py:115-130)."""
