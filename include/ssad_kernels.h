@@ -175,6 +175,14 @@ SSAD_API int ssad_weighted_sum(const float* const* xs_host, const float* const* 
 SSAD_API int ssad_affine_channel(const float* x, const float* scale, const float* bias,
                                  const float* residual, float* y, int N, int C, int HW,
                                  int relu, ssad_stream_t stream);
+/* UpsampleNearest (caffe2/modules/detectron/upsample_nearest_op.cu:62-151) of the FPN
+ * top-down path; x: N x C x H x W -> y: N x C x (H*scale) x (W*scale), nearest
+ * neighbour; addend (same shape as y, may be NULL, may alias y) folds the lateral Sum
+ * of FPN.py:283-306 into the pass.  The gradient sums each scale x scale block. */
+SSAD_API int ssad_upsample_nearest(const float* x, const float* addend, float* y, int N, int C,
+                                   int H, int W, int scale, ssad_stream_t stream);
+SSAD_API int ssad_upsample_nearest_grad(const float* dy, float* dx, int N, int C, int H, int W,
+                                        int scale, ssad_stream_t stream);
 /* y[i] = value (ConstantFill) */
 SSAD_API int ssad_fill(float* y, float value, int64_t n, ssad_stream_t stream);
 /* Fused parameter update (detectron/lib/modeling/optimizer.py:115-130 +

@@ -175,6 +175,46 @@ __global__ __launch_bounds__(kThreads) void affine_channel_kernel(
   }
 }
 
+// UpsampleNearest / UpsampleNearestGradient (caffe2/modules/detectron/
+// upsample_nearest_op.cu:62-151) of the FPN top-down path, with the lateral Sum
+// (detectron/lib/modeling/FPN.py:283-306) optionally folded into the forward:
+//   y[n][c][Y][X] = x[n][c][Y/s][X/s] (+ addend[n][c][Y][X]);
+//   dx[n][c][i][j] = sum_{a,b<s} dy[n][c][i*s+a][j*s+b].
+__global__ __launch_bounds__(kThreads) void upsample_nearest_kernel(
+    const float* __restrict__ x, const float* __restrict__ addend, float* __restrict__ y,
+    long long planes, int H, int W, int s) {
+  const int OW = W * s, OH = H * s;
+  const long long total = planes * OH * OW;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kThreads) {
+    const int ox = (int)(i % OW);
+    const long long r = i / OW;
+    const int oy = (int)(r % OH);
+    const long long p = r / OH;
+    float v = x[(p * H + oy / s) * W + ox / s];
+    if (addend) v += addend[i];
+    y[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void upsample_nearest_grad_kernel(
+    const float* __restrict__ dy, float* __restrict__ dx, long long planes, int H, int W, int s) {
+  const int OW = W * s;
+  const long long total = planes * H * W;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kThreads) {
+    const int j = (int)(i % W);
+    const long long r = i / W;
+    const int ii = (int)(r % H);
+    const long long p = r / H;
+    const float* src = dy + ((p * H + ii) * s) * OW + (long long)j * s;
+    float acc = 0.0f;
+    for (int a = 0; a < s; ++a)
+      for (int b = 0; b < s; ++b) acc += src[(long long)a * OW + b];
+    dx[i] = acc;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -261,6 +301,26 @@ int ssad_affine_channel(const float* x, const float* scale, const float* bias,
   while (rows / rpb > 65536) rpb *= 2;
   hipLaunchKernelGGL(affine_channel_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(kThreads), 0,
                      (hipStream_t)stream, x, scale, bias, residual, y, rows, C, HW, vec, relu, rpb);
+  return (int)hipGetLastError();
+}
+
+int ssad_upsample_nearest(const float* x, const float* addend, float* y, int N, int C, int H,
+                          int W, int scale, ssad_stream_t stream) {
+  if (!x || !y || N < 0 || C < 0 || H < 0 || W < 0 || scale < 1) return SSAD_E_BADARG;
+  const long long planes = (long long)N * C, total = planes * H * W * scale * scale;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(upsample_nearest_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, addend, y, planes, H, W, scale);
+  return (int)hipGetLastError();
+}
+
+int ssad_upsample_nearest_grad(const float* dy, float* dx, int N, int C, int H, int W, int scale,
+                               ssad_stream_t stream) {
+  if (!dy || !dx || N < 0 || C < 0 || H < 0 || W < 0 || scale < 1) return SSAD_E_BADARG;
+  const long long planes = (long long)N * C, total = planes * H * W;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(upsample_nearest_grad_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, dy, dx, planes, H, W, scale);
   return (int)hipGetLastError();
 }
 

@@ -205,6 +205,52 @@ class AffineChannelGradientHIPOp final : public Operator<HIPContext> {
   }
 };
 
+// UpsampleNearest / UpsampleNearestGradient (upsample_nearest_op.{h,cu}); arg scale (int, 2)
+class UpsampleNearestHIPOp final : public Operator<HIPContext> {
+ public:
+  UpsampleNearestHIPOp(const OperatorDef& def, Workspace* ws)
+      : Operator<HIPContext>(def, ws), scale_(GetSingleArgument<int>("scale", 2)) {
+    CAFFE_ENFORCE_GE(scale_, 1);
+  }
+  bool RunOnDevice() override {
+    auto& X = Input(0);
+    auto* Y = Output(0);
+    CAFFE_ENFORCE_EQ(X.ndim(), 4, "UpsampleNearest: X must be N x C x H x W");
+    Y->Resize(X.dim32(0), X.dim32(1), X.dim32(2) * scale_, X.dim32(3) * scale_);
+    LAUNCH_OK(ssad_upsample_nearest(X.data<float>(), nullptr, Y->mutable_data<float>(), X.dim32(0),
+                                    X.dim32(1), X.dim32(2), X.dim32(3), scale_,
+                                    context_.hip_stream()), "UpsampleNearest");
+    return true;
+  }
+ private:
+  int scale_;
+};
+
+class UpsampleNearestGradientHIPOp final : public Operator<HIPContext> {
+ public:
+  UpsampleNearestGradientHIPOp(const OperatorDef& def, Workspace* ws)
+      : Operator<HIPContext>(def, ws), scale_(GetSingleArgument<int>("scale", 2)) {
+    CAFFE_ENFORCE_GE(scale_, 1);
+  }
+  bool RunOnDevice() override {
+    auto& X = Input(0);
+    auto& dY = Input(1);
+    auto* dX = Output(0);
+    CAFFE_ENFORCE_EQ(dY.ndim(), 4);
+    CAFFE_ENFORCE_EQ(dY.dim32(2), X.dim32(2) * scale_);
+    CAFFE_ENFORCE_EQ(dY.dim32(3), X.dim32(3) * scale_);
+    dX->ResizeLike(X);
+    LAUNCH_OK(ssad_upsample_nearest_grad(dY.data<float>(), dX->mutable_data<float>(), X.dim32(0),
+                                         X.dim32(1), X.dim32(2), X.dim32(3), scale_,
+                                         context_.hip_stream()), "UpsampleNearestGradient");
+    return true;
+  }
+ private:
+  int scale_;
+};
+
+REGISTER_HIP_OPERATOR(UpsampleNearest, UpsampleNearestHIPOp);
+REGISTER_HIP_OPERATOR(UpsampleNearestGradient, UpsampleNearestGradientHIPOp);
 REGISTER_HIP_OPERATOR(AffineChannel, AffineChannelHIPOp);
 REGISTER_HIP_OPERATOR(AffineChannelGradient, AffineChannelGradientHIPOp);
 REGISTER_HIP_OPERATOR(Relu, ReluHIPOp);
@@ -216,6 +262,8 @@ REGISTER_HIP_OPERATOR(WeightedSum, WeightedSumHIPOp);
 REGISTER_HIP_OPERATOR(ConstantFill, ConstantFillHIPOp);
 REGISTER_HIP_OPERATOR(MomentumSGDUpdate, MomentumSGDUpdateHIPOp);
 
+OPERATOR_SCHEMA(UpsampleNearest).NumInputs(1).NumOutputs(1);
+OPERATOR_SCHEMA(UpsampleNearestGradient).NumInputs(2).NumOutputs(1);
 OPERATOR_SCHEMA(AffineChannel).NumInputs(3).NumOutputs(1).AllowInplace({{0, 0}});
 OPERATOR_SCHEMA(AffineChannelGradient).NumInputs(2).NumOutputs(1).AllowInplace({{1, 0}});
 OPERATOR_SCHEMA(Relu).NumInputs(1).NumOutputs(1).AllowInplace({{0, 0}});
@@ -246,6 +294,16 @@ class GetAffineChannelGradient : public GradientMakerBase {
   }
 };
 REGISTER_GRADIENT(AffineChannel, GetAffineChannelGradient);
+
+// upsample_nearest_op.cc: gradient op takes (X, dY) -> dX and inherits the arguments
+class GetUpsampleNearestGradient : public GradientMakerBase {
+  using GradientMakerBase::GradientMakerBase;
+  vector<OperatorDef> GetGradientDefs() override {
+    return SingleGradientDef("UpsampleNearestGradient", "", vector<string>{I(0), GO(0)},
+                             vector<string>{GI(0)});
+  }
+};
+REGISTER_GRADIENT(UpsampleNearest, GetUpsampleNearestGradient);
 NO_GRADIENT(PowSum);
 NO_GRADIENT(ConstantFill);
 

@@ -90,6 +90,8 @@ def lib():
     L.ssad_sum_n.argtypes = [C.POINTER(vp), i32, vp, i64, vp]
     L.ssad_scale.argtypes = [vp, vp, f32, i64, vp]
     L.ssad_affine_channel.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.ssad_upsample_nearest.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.ssad_upsample_nearest_grad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     L.ssad_momentum_sgd_update.argtypes = [vp, vp, vp, vp, f32, f32, i32, i64, vp]
     L.ssad_conv_packed_filter_floats.restype = sz
     L.ssad_conv_packed_filter_floats.argtypes = [i32, i32]
@@ -317,6 +319,29 @@ def affine_channel_(x, bias, scale=None, residual=None, relu=False):
     _check(lib().ssad_affine_channel(_ptr(x), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(x),
                                      N, Cc, hw, int(relu), _stream()), "affine_channel")
     return x
+
+
+def upsample_nearest(x, scale=2, addend=None, out=None):
+    """Nearest-neighbour upsampling of an NCHW tensor, optionally + addend (FPN's
+    lateral Sum folded in; `out` may be `addend` itself)."""
+    _f32c(x, "x")
+    N, Cc, H, W = x.shape
+    y = out if out is not None else torch.empty((N, Cc, H * scale, W * scale), dtype=torch.float32,
+                                                device="cuda")
+    if addend is not None:
+        _f32c(addend, "addend")
+    _check(lib().ssad_upsample_nearest(_ptr(x), _ptr(addend), _ptr(y), N, Cc, H, W, scale,
+                                       _stream()), "upsample_nearest")
+    return y
+
+
+def upsample_nearest_grad(dy, scale=2):
+    _f32c(dy, "dy")
+    N, Cc, OH, OW = dy.shape
+    dx = torch.empty((N, Cc, OH // scale, OW // scale), dtype=torch.float32, device="cuda")
+    _check(lib().ssad_upsample_nearest_grad(_ptr(dy), _ptr(dx), N, Cc, OH // scale, OW // scale,
+                                            scale, _stream()), "upsample_nearest_grad")
+    return dx
 
 
 def sigmoid(x, out=None):

@@ -139,6 +139,27 @@ def test_affine_channel_operator_and_gradient():
     np.testing.assert_allclose(workspace.FetchBlob("X"), want, rtol=1e-6, atol=1e-6)
 
 
+def test_upsample_nearest_operator_and_gradient():
+    """FPN top-down op (upsample_nearest_op.cu:62-151), scale argument inherited by the gradient."""
+    rng = np.random.default_rng(31)
+    for scale in (2, 3):
+        workspace.ResetWorkspace()
+        N, C, H, W = 2, 5, 4, 7
+        X = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        dY = rng.standard_normal((N, C, H * scale, W * scale)).astype(np.float32)
+        feed("X", X); feed("Y_grad", dY)
+        with core.DeviceScope(GPU):
+            op = core.CreateOperator("UpsampleNearest", ["X"], ["Y"], scale=scale)
+        workspace.RunOperatorOnce(op)
+        want = X.repeat(scale, axis=2).repeat(scale, axis=3)
+        assert np.array_equal(workspace.FetchBlob("Y"), want)
+        g, gi = core.GradientRegistry.GetGradientForOp(op, ["Y_grad"])
+        assert [o.type for o in g] == ["UpsampleNearestGradient"]
+        workspace.RunOperatorsOnce(g)
+        ref = dY.reshape(N, C, H, scale, W, scale).astype(np.float64).sum((3, 5))
+        np.testing.assert_allclose(workspace.FetchBlob(gi[0]), ref, rtol=1e-6, atol=1e-6)
+
+
 def test_sgd_update_ops_follow_optimizer_py():
     """Scale(2x) for biases / WeightedSum(g + wd*w) for weights, then
     MomentumSGDUpdate (detectron/lib/modeling/optimizer.py:115-130)."""
