@@ -291,6 +291,27 @@ SSAD_API int ssad_retinanet_anchor_labels(
     int* counts_out, float* fg_bg_out, void* workspace, size_t workspace_bytes,
     ssad_stream_t stream);
 
+/* RetinaNet inference post-processing for ONE image (detectron/lib/core/
+ * test_retinanet.py:108-206): per level the candidates with score > inference_th
+ * (0 on the coarsest level), the pre_nms_topn best of them, anchor decode
+ * (utils/boxes.py:150-190) / rescale by 1/im_scale / clip to the image
+ * (:132-147), per-class greedy NMS (utils/cython_nms.pyx:37-92), and the
+ * dets_per_im best survivors sorted by score.
+ *   cls_prob_host[l]  device float [1][A*C][H_l][W_l] (sigmoid scores)
+ *   box_pred_host[l]  device float [1][A*4][H_l][W_l]
+ *   cell_anchors      device double [levels][A][4]
+ *   dets_out          device float [dets_per_im][6] = x1, y1, x2, y2, score, class (1-based)
+ *   count_out         device int: rows produced
+ * Score ties are ordered by element index (unspecified in the reference). */
+SSAD_API size_t ssad_retinanet_detect_workspace_bytes(
+    int levels, int A, int C, const int* H_host, const int* W_host, int pre_nms_topn);
+SSAD_API int ssad_retinanet_detect(
+    const float* const* cls_prob_host, const float* const* box_pred_host,
+    const double* cell_anchors, int levels, int A, int C, int k_min, const int* H_host,
+    const int* W_host, float inference_th, int pre_nms_topn, float nms_thresh, int dets_per_im,
+    float im_scale, int im_height, int im_width, float bbox_xform_clip, float* dets_out,
+    int* count_out, void* workspace, size_t workspace_bytes, ssad_stream_t stream);
+
 /* ---------------------------------------------------------------------- */
 /* Introspection                                                           */
 /* ---------------------------------------------------------------------- */

@@ -75,3 +75,57 @@ class RetinanetLabeler(object):
             blobs["retnet_roi_fg_bbox_locs_fpn%d" % lvl] = self.locs[i][:m]
             blobs["retnet_roi_bbox_targets_fpn%d" % lvl] = self.targets[i][:m]
         return blobs
+
+
+class RetinanetDetector(object):
+    """Device replacement of `im_detect_bbox`'s post-processing
+    (detectron/lib/core/test_retinanet.py:108-206) for one image.
+
+    `__call__(cls_probs, box_preds, im_height, im_width, im_scale)` takes the per-level
+    sigmoid scores [1][A*C][H][W] and box deltas [1][A*4][H][W] (device tensors) and
+    returns float32 [n <= dets_per_im][6] = x1, y1, x2, y2, score, class."""
+
+    def __init__(self, level_shapes, cfg=AnchorConfig, inference_th=0.05, pre_nms_topn=1000,
+                 nms_thresh=0.5, dets_per_im=100, device="cuda"):
+        self.cfg = cfg
+        self.levels = len(level_shapes)
+        self.A = cfg.scales_per_octave * len(cfg.aspect_ratios)
+        self.C = cfg.num_classes - 1
+        self.th, self.topn, self.nms, self.keep = inference_th, pre_nms_topn, nms_thresh, dets_per_im
+        self.cells = torch.as_tensor(cell_anchors(cfg)[:self.levels], dtype=torch.float64,
+                                     device=device).contiguous()
+        IntArr = C.c_int * self.levels
+        self._H = IntArr(*[h for h, _ in level_shapes])
+        self._W = IntArr(*[w for _, w in level_shapes])
+        self.shapes = list(level_shapes)
+        L = K.lib()
+        L.ssad_retinanet_detect_workspace_bytes.restype = C.c_size_t
+        nb = L.ssad_retinanet_detect_workspace_bytes(self.levels, self.A, self.C, self._H, self._W,
+                                                     self.topn)
+        if nb == 0:
+            raise K.KernelError("retinanet_detect: unsupported geometry")
+        self.ws = torch.empty(int(nb), dtype=torch.uint8, device=device)
+        self.out = torch.zeros((dets_per_im, 6), dtype=torch.float32, device=device)
+        self.count = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def __call__(self, cls_probs, box_preds, im_height, im_width, im_scale):
+        for t, (h, w) in zip(cls_probs, self.shapes):
+            if tuple(t.shape) != (1, self.A * self.C, h, w) or t.dtype != torch.float32 or \
+                    not t.is_contiguous() or not t.is_cuda:
+                raise K.KernelError("cls_prob must be 1 x A*C x H x W contiguous float32 device tensors")
+        for t, (h, w) in zip(box_preds, self.shapes):
+            if tuple(t.shape) != (1, self.A * 4, h, w) or t.dtype != torch.float32 or \
+                    not t.is_contiguous() or not t.is_cuda:
+                raise K.KernelError("box_pred must be 1 x A*4 x H x W contiguous float32 device tensors")
+        PtrArr = C.c_void_p * self.levels
+        rc = K.lib().ssad_retinanet_detect(
+            PtrArr(*[t.data_ptr() for t in cls_probs]), PtrArr(*[t.data_ptr() for t in box_preds]),
+            C.c_void_p(self.cells.data_ptr()), self.levels, self.A, self.C, self.cfg.k_min, self._H,
+            self._W, C.c_float(self.th), self.topn, C.c_float(self.nms), self.keep,
+            C.c_float(im_scale), int(im_height), int(im_width),
+            C.c_float(float(np.log(1000. / 16.))), C.c_void_p(self.out.data_ptr()),
+            C.c_void_p(self.count.data_ptr()), C.c_void_p(self.ws.data_ptr()),
+            C.c_size_t(self.ws.numel()), K._stream())
+        if rc:
+            raise K.KernelError("retinanet_detect failed (%d)" % rc)
+        return self.out[:int(self.count.item())]

@@ -133,3 +133,60 @@ def test_device_labelling_image_without_ground_truth():
         assert not (locs[:, 0] == 1).any()
         locs[:, 0] = np.where(locs[:, 0] == 2, 1, locs[:, 0])
         assert np.array_equal(locs, ref["locs_fpn%d" % lvl])
+
+
+# ---------------------------------------------------------------------------
+# inference post-processing (second half of row f4)
+# ---------------------------------------------------------------------------
+
+def _detect_inputs(rng, shapes, shift):
+    """Scores are exact multiples of 2^-shift, each used once per level: distinct in
+    float32 (ties are unspecified in the reference).  shift 24: most of the finest level
+    passes the 0.05 threshold; shift 26: only part of the finest level and (threshold 0)
+    the coarsest level produce candidates."""
+    probs, deltas = [], []
+    for h, w in shapes:
+        n = 720 * h * w
+        vals = (rng.permutation(n) + 1).astype(np.float64) * 2.0 ** -shift
+        probs.append(vals.astype(np.float32).reshape(1, 720, h, w))
+        deltas.append((rng.standard_normal((1, 36, h, w)) * 0.4).astype(np.float32))
+    return probs, deltas
+
+
+def test_detect_oracle_invariants():
+    from oracle import detect as OD
+    rng = np.random.default_rng(3)
+    shapes = [(20, 28), (10, 14), (5, 7)]
+    probs, deltas = _detect_inputs(rng, shapes, 19)
+    cells = np.array([[OA.generate_cell64(l, a) for a in range(9)] for l in range(3, 6)])
+    d = OD.im_detect_bbox(probs, deltas, cells, (150, 210), 1.0)
+    assert d.shape[1] == 6 and 0 < d.shape[0] <= 100
+    assert np.all(np.diff(d[:, 4]) <= 0)                       # sorted by score
+    assert d[:, 0].min() >= 0 and d[:, 2].max() <= 209 and d[:, 3].max() <= 149
+    assert set(np.unique(d[:, 5])) <= set(range(1, 81))
+    # NMS: no two survivors of one class overlap by >= 0.5
+    for c in np.unique(d[:, 5]):
+        b = d[d[:, 5] == c]
+        assert len(OD.nms(b[:, :5], 0.5)) == len(b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["five_levels", "few_candidates"])
+def test_device_detect_matches_oracle(case):
+    import torch
+    import ssad_amd  # noqa: F401
+    from oracle import detect as OD
+    from ssad_amd.roi_data.retinanet import RetinanetDetector
+    rng = np.random.default_rng(41 if case == "five_levels" else 42)
+    shapes = [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)]
+    probs, deltas = _detect_inputs(rng, shapes, 24 if case == "five_levels" else 26)
+    cells = np.array([[OA.generate_cell64(l, a) for a in range(9)] for l in range(3, 8)])
+    im_h, im_w, scale = 600, 850, 0.9375
+    ref = OD.im_detect_bbox(probs, deltas, cells, (im_h, im_w), scale)
+    det = RetinanetDetector(shapes)
+    got = det([torch.as_tensor(p).cuda() for p in probs], [torch.as_tensor(d).cuda() for d in deltas],
+              im_h, im_w, scale).cpu().numpy()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.array_equal(got[:, 4], ref[:, 4])                # scores, in order
+    assert np.array_equal(got[:, 5], ref[:, 5])                # classes
+    np.testing.assert_allclose(got[:, :4], ref[:, :4], rtol=2e-5, atol=2e-3)
