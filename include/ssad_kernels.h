@@ -291,6 +291,35 @@ SSAD_API int ssad_retinanet_anchor_labels(
     int* counts_out, float* fg_bg_out, void* workspace, size_t workspace_bytes,
     ssad_stream_t stream);
 
+/* ---------------------------------------------------------------------- */
+/* Default convolution engine helpers and MaxPool (backbone, row f1)        */
+/* ---------------------------------------------------------------------- */
+
+/* output extent of a convolution / pooling axis (conv_pool_op_base.h:520-560, no
+ * legacy padding): floor((in + pad_a + pad_b - (dilation*(kernel-1)+1)) / stride) + 1;
+ * -1 when the window does not fit */
+SSAD_API int ssad_conv_out_size(int in, int kernel, int dilation, int pad_a, int pad_b, int stride);
+/* math::Im2col / Col2im, NCHW (caffe2/utils/math_gpu.cu): one image x[C][H][W] <->
+ * col[C*kh*kw][OH*OW]; Col2im is written in gather form (deterministic) */
+SSAD_API int ssad_im2col(const float* x, int C, int H, int W, int kh, int kw, int dil_h, int dil_w,
+                         int pad_t, int pad_l, int pad_b, int pad_r, int stride_h, int stride_w,
+                         float* col, ssad_stream_t stream);
+SSAD_API int ssad_col2im(const float* col, int C, int H, int W, int kh, int kw, int dil_h,
+                         int dil_w, int pad_t, int pad_l, int pad_b, int pad_r, int stride_h,
+                         int stride_w, float* x, ssad_stream_t stream);
+/* out[c] (+)= sum_{n,p} dy[n][c][p] (the bias gradient, conv_op_impl.h:470-486) */
+SSAD_API int ssad_channel_sum(const float* dy, int N, int C, int HW, float* out, int accumulate,
+                              ssad_stream_t stream);
+/* MaxPool / MaxPoolGradient, NCHW (caffe2/operators/pool_op.cu): windows are clipped to
+ * the image; every input equal to its window's maximum receives the gradient */
+SSAD_API int ssad_max_pool_forward(const float* x, int N, int C, int H, int W, int kh, int kw,
+                                   int stride_h, int stride_w, int pad_t, int pad_l, int pad_b,
+                                   int pad_r, float* y, ssad_stream_t stream);
+SSAD_API int ssad_max_pool_backward(const float* x, const float* y, const float* dy, int N, int C,
+                                    int H, int W, int kh, int kw, int stride_h, int stride_w,
+                                    int pad_t, int pad_l, int pad_b, int pad_r, float* dx,
+                                    ssad_stream_t stream);
+
 /* RetinaNet inference post-processing for ONE image (detectron/lib/core/
  * test_retinanet.py:108-206): per level the candidates with score > inference_th
  * (0 on the coarsest level), the pre_nms_topn best of them, anchor decode

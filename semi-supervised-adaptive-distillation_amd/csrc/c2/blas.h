@@ -1,0 +1,20 @@
+// blas.h -- plain fp32 GEMM for the default convolution engine, through rocBLAS.
+// rocBLAS is opened lazily (dlopen on first use), so a process that only runs the
+// matrix-core 3x3 engine and the loss kernels never loads it.
+#ifndef C2HIP_BLAS_H_
+#define C2HIP_BLAS_H_
+
+#include <hip/hip_runtime_api.h>
+
+#include "c2/common.h"
+
+namespace caffe2 {
+
+// Row-major C[M x N] = alpha * op(A) * op(B) + beta * C with leading dimensions in
+// elements (math::Gemm of caffe2/utils/math_gpu.cu:33-80).
+C2HIP_API void GemmRowMajor(hipStream_t stream, bool trans_a, bool trans_b, int M, int N, int K,
+                            float alpha, const float* A, int lda, const float* B, int ldb,
+                            float beta, float* C, int ldc);
+
+}  // namespace caffe2
+#endif  // C2HIP_BLAS_H_

@@ -1,0 +1,221 @@
+// im2col.hip -- the data-movement kernels of the DEFAULT convolution engine
+// (im2col + GEMM, caffe2/operators/conv_op_impl.h:31-202 and :358-577) that
+// serves every geometry the matrix-core 3x3 engine does not (the backbone's
+// 1x1, strided and 7x7 convolutions), plus MaxPool and the per-channel sum of
+// the bias gradient.  The GEMMs themselves go to rocBLAS (csrc/c2/blas.cc).
+//
+//   Im2col / Col2im NCHW    caffe2/utils/math_gpu.cu im2col_gpu_kernel_nchw /
+//                           col2im_gpu_kernel_nchw
+//   MaxPool(Gradient)       caffe2/operators/pool_op.cu MaxPoolForwardNCHW /
+//                           MaxPoolBackwardNCHW (window clipped to the image)
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ssad_kernels.h"
+
+namespace {
+
+constexpr int kT = 256;
+
+inline unsigned grid_for(long long n) {
+  long long b = (n + kT - 1) / kT;
+  if (b > 65535) b = 65535;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+struct Geo {
+  int C, H, W, kh, kw, dh, dw, pt, pl, sh, sw, OH, OW;
+};
+
+__global__ __launch_bounds__(kT) void im2col_kernel(const float* __restrict__ x, const Geo g,
+                                                    float* __restrict__ col) {
+  const long long total = (long long)g.C * g.kh * g.kw * g.OH * g.OW;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kT) {
+    const int ow = (int)(i % g.OW);
+    long long r = i / g.OW;
+    const int oh = (int)(r % g.OH);
+    r /= g.OH;
+    const int kj = (int)(r % g.kw);
+    r /= g.kw;
+    const int ki = (int)(r % g.kh);
+    const int c = (int)(r / g.kh);
+    const int h = oh * g.sh - g.pt + ki * g.dh, w = ow * g.sw - g.pl + kj * g.dw;
+    col[i] = (h >= 0 && h < g.H && w >= 0 && w < g.W) ? x[((long long)c * g.H + h) * g.W + w] : 0.0f;
+  }
+}
+
+// gather form (deterministic): each input element sums the column entries that read it
+__global__ __launch_bounds__(kT) void col2im_kernel(const float* __restrict__ col, const Geo g,
+                                                    float* __restrict__ x) {
+  const long long total = (long long)g.C * g.H * g.W;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kT) {
+    const int w = (int)(i % g.W);
+    const long long r = i / g.W;
+    const int h = (int)(r % g.H);
+    const int c = (int)(r / g.H);
+    float acc = 0.0f;
+    for (int ki = 0; ki < g.kh; ++ki) {
+      const int hh = h + g.pt - ki * g.dh;
+      if (hh < 0 || hh % g.sh) continue;
+      const int oh = hh / g.sh;
+      if (oh >= g.OH) continue;
+      for (int kj = 0; kj < g.kw; ++kj) {
+        const int ww = w + g.pl - kj * g.dw;
+        if (ww < 0 || ww % g.sw) continue;
+        const int ow = ww / g.sw;
+        if (ow >= g.OW) continue;
+        acc += col[((((long long)c * g.kh + ki) * g.kw + kj) * g.OH + oh) * g.OW + ow];
+      }
+    }
+    x[i] = acc;
+  }
+}
+
+// out[c] (+)= sum over n, p of dy[n][c][p]; one workgroup per channel, double partials
+__global__ __launch_bounds__(kT) void channel_sum_kernel(const float* __restrict__ dy, int N, int C,
+                                                         int HW, float* __restrict__ out,
+                                                         int accumulate) {
+  __shared__ double ws[kT / 64];
+  const int c = blockIdx.x;
+  double acc = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const float* p = dy + ((long long)n * C + c) * HW;
+    for (int i = threadIdx.x; i < HW; i += kT) acc += (double)p[i];
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < kT / 64; ++i) t += ws[i];
+    out[c] = accumulate ? out[c] + (float)t : (float)t;
+  }
+}
+
+struct PoolGeo {
+  long long planes;
+  int H, W, kh, kw, sh, sw, pt, pl, OH, OW;
+};
+
+__global__ __launch_bounds__(kT) void max_pool_kernel(const float* __restrict__ x, const PoolGeo g,
+                                                      float* __restrict__ y) {
+  const long long total = g.planes * g.OH * g.OW;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kT) {
+    const int ow = (int)(i % g.OW);
+    const long long r = i / g.OW;
+    const int oh = (int)(r % g.OH);
+    const long long p = r / g.OH;
+    int h0 = oh * g.sh - g.pt, w0 = ow * g.sw - g.pl;
+    const int h1 = min(h0 + g.kh, g.H), w1 = min(w0 + g.kw, g.W);
+    h0 = max(h0, 0); w0 = max(w0, 0);
+    float m = -__builtin_inff();
+    const float* xp = x + p * g.H * g.W;
+    for (int h = h0; h < h1; ++h)
+      for (int w = w0; w < w1; ++w) m = fmaxf(m, xp[h * g.W + w]);
+    y[i] = m;
+  }
+}
+
+// pool_op.cu MaxPoolBackwardNCHW: every input equal to its window's maximum receives that
+// window's gradient (gather form, deterministic)
+__global__ __launch_bounds__(kT) void max_pool_grad_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ y,
+                                                           const float* __restrict__ dy,
+                                                           const PoolGeo g, float* __restrict__ dx) {
+  const long long total = g.planes * g.H * g.W;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kT) {
+    const int w = (int)(i % g.W);
+    const long long r = i / g.W;
+    const int h = (int)(r % g.H);
+    const long long p = r / g.H;
+    const int ph0 = (h + g.pt < g.kh) ? 0 : (h + g.pt - g.kh) / g.sh + 1;
+    const int ph1 = min((h + g.pt) / g.sh + 1, g.OH);
+    const int pw0 = (w + g.pl < g.kw) ? 0 : (w + g.pl - g.kw) / g.sw + 1;
+    const int pw1 = min((w + g.pl) / g.sw + 1, g.OW);
+    const float v = x[i];
+    float acc = 0.0f;
+    for (int oh = ph0; oh < ph1; ++oh)
+      for (int ow = pw0; ow < pw1; ++ow) {
+        const long long o = (p * g.OH + oh) * g.OW + ow;
+        if (v == y[o]) acc += dy[o];
+      }
+    dx[i] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssad_conv_out_size(int in, int kernel, int dilation, int pad_a, int pad_b, int stride) {
+  const int eff = dilation * (kernel - 1) + 1;
+  if (stride < 1 || in + pad_a + pad_b < eff) return -1;
+  return (in + pad_a + pad_b - eff) / stride + 1;
+}
+
+int ssad_im2col(const float* x, int C, int H, int W, int kh, int kw, int dil_h, int dil_w, int pad_t,
+                int pad_l, int pad_b, int pad_r, int stride_h, int stride_w, float* col,
+                ssad_stream_t stream) {
+  Geo g{C, H, W, kh, kw, dil_h, dil_w, pad_t, pad_l, stride_h, stride_w,
+        ssad_conv_out_size(H, kh, dil_h, pad_t, pad_b, stride_h),
+        ssad_conv_out_size(W, kw, dil_w, pad_l, pad_r, stride_w)};
+  if (!x || !col || C < 1 || g.OH < 1 || g.OW < 1) return SSAD_E_BADARG;
+  const long long total = (long long)C * kh * kw * g.OH * g.OW;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(kT), 0, (hipStream_t)stream, x, g, col);
+  return (int)hipGetLastError();
+}
+
+int ssad_col2im(const float* col, int C, int H, int W, int kh, int kw, int dil_h, int dil_w,
+                int pad_t, int pad_l, int pad_b, int pad_r, int stride_h, int stride_w, float* x,
+                ssad_stream_t stream) {
+  Geo g{C, H, W, kh, kw, dil_h, dil_w, pad_t, pad_l, stride_h, stride_w,
+        ssad_conv_out_size(H, kh, dil_h, pad_t, pad_b, stride_h),
+        ssad_conv_out_size(W, kw, dil_w, pad_l, pad_r, stride_w)};
+  if (!x || !col || C < 1 || g.OH < 1 || g.OW < 1) return SSAD_E_BADARG;
+  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((long long)C * H * W)), dim3(kT), 0,
+                     (hipStream_t)stream, col, g, x);
+  return (int)hipGetLastError();
+}
+
+int ssad_channel_sum(const float* dy, int N, int C, int HW, float* out, int accumulate,
+                     ssad_stream_t stream) {
+  if (!dy || !out || N < 0 || C < 1 || HW < 0) return SSAD_E_BADARG;
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(kT), 0, (hipStream_t)stream, dy, N, C, HW,
+                     out, accumulate);
+  return (int)hipGetLastError();
+}
+
+int ssad_max_pool_forward(const float* x, int N, int C, int H, int W, int kh, int kw, int stride_h,
+                          int stride_w, int pad_t, int pad_l, int pad_b, int pad_r, float* y,
+                          ssad_stream_t stream) {
+  PoolGeo g{(long long)N * C, H, W, kh, kw, stride_h, stride_w, pad_t, pad_l,
+            ssad_conv_out_size(H, kh, 1, pad_t, pad_b, stride_h),
+            ssad_conv_out_size(W, kw, 1, pad_l, pad_r, stride_w)};
+  if (!x || !y || g.OH < 1 || g.OW < 1 || g.planes < 0) return SSAD_E_BADARG;
+  if (g.planes == 0) return 0;
+  hipLaunchKernelGGL(max_pool_kernel, dim3(grid_for(g.planes * g.OH * g.OW)), dim3(kT), 0,
+                     (hipStream_t)stream, x, g, y);
+  return (int)hipGetLastError();
+}
+
+int ssad_max_pool_backward(const float* x, const float* y, const float* dy, int N, int C, int H,
+                           int W, int kh, int kw, int stride_h, int stride_w, int pad_t, int pad_l,
+                           int pad_b, int pad_r, float* dx, ssad_stream_t stream) {
+  PoolGeo g{(long long)N * C, H, W, kh, kw, stride_h, stride_w, pad_t, pad_l,
+            ssad_conv_out_size(H, kh, 1, pad_t, pad_b, stride_h),
+            ssad_conv_out_size(W, kw, 1, pad_l, pad_r, stride_w)};
+  if (!x || !y || !dy || !dx || g.OH < 1 || g.OW < 1 || g.planes < 0) return SSAD_E_BADARG;
+  if (g.planes == 0) return 0;
+  hipLaunchKernelGGL(max_pool_grad_kernel, dim3(grid_for(g.planes * H * W)), dim3(kT), 0,
+                     (hipStream_t)stream, x, y, dy, g, dx);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,5 +1,6 @@
 #include "ops/conv_op.h"
 
+#include "c2/blas.h"
 #include "ssad_kernels.h"
 
 namespace caffe2 {
@@ -61,6 +62,10 @@ bool IsSubnetGeometry(const ConvGeometry& g) {
          g.pads == vector<int>{1, 1, 1, 1};
 }
 
+bool IsDefaultEngineGeometry(const ConvGeometry& g) {
+  return g.order == "NCHW" && g.group == 1 && g.kernel.size() == 2;
+}
+
 // Algorithm choice, like cuDNN's internal one (conv_op_cudnn.cc:541-558):
 // Winograd F(2x2,3x3) for outputs >= 32 channels wide, the direct kernel
 // otherwise; arg hip_algo = "direct" | "winograd" overrides.
@@ -74,6 +79,11 @@ namespace {
 enum { INPUT = 0, FILTER = 1, BIAS = 2, OUTPUT_GRAD = 2 };
 enum { FILTER_GRAD = 0, BIAS_OR_INPUT_GRAD = 1, INPUT_GRAD = 2 };
 }  // namespace
+
+template <>
+bool ConvOp<float, HIPContext>::RunDefaultEngine();
+template <>
+bool ConvGradientOp<float, HIPContext>::RunDefaultEngine();
 
 template <>
 bool ConvOp<float, HIPContext>::RunOnDevice() {
@@ -95,6 +105,7 @@ bool ConvOp<float, HIPContext>::RunOnDevice() {
     CAFFE_ENFORCE(b.dim32(0) == M);
     bias = b.data<float>();
   }
+  if (!IsSubnetGeometry(geom_)) return RunDefaultEngine();
   Y->Resize(N, M, H, W);   // 3x3 / s1 / p1 keeps the spatial size
 
   hipStream_t s = context_.hip_stream();
@@ -116,6 +127,106 @@ bool ConvOp<float, HIPContext>::RunOnDevice() {
   return true;
 }
 
+// Default engine, forward (conv_op_impl.h:31-202): per image im2col -> col[C*kh*kw][OH*OW],
+// Y[n] = filter[M][C*kh*kw] . col, then the bias; a 1x1 / stride 1 / pad 0 layer skips the
+// im2col (its col buffer IS the image).
+template <>
+bool ConvOp<float, HIPContext>::RunDefaultEngine() {
+  auto& X = Input(INPUT);
+  auto& filter = Input(FILTER);
+  auto* Y = Output(0);
+  const int N = X.dim32(0), C = X.dim32(1), H = X.dim32(2), W = X.dim32(3);
+  const int M = filter.dim32(0);
+  const int kh = geom_.kernel[0], kw = geom_.kernel[1];
+  const int OH = ssad_conv_out_size(H, kh, geom_.dilation[0], geom_.pads[0], geom_.pads[2], geom_.stride[0]);
+  const int OW = ssad_conv_out_size(W, kw, geom_.dilation[1], geom_.pads[1], geom_.pads[3], geom_.stride[1]);
+  CAFFE_ENFORCE(OH > 0 && OW > 0, "Conv: the kernel does not fit the padded input");
+  Y->Resize(N, M, OH, OW);
+  hipStream_t s = context_.hip_stream();
+  const int K = C * kh * kw, P = OH * OW;
+  const bool pointwise = kh == 1 && kw == 1 && geom_.stride == vector<int>{1, 1} &&
+                         geom_.pads == vector<int>{0, 0, 0, 0};
+  if (!pointwise) col_buffer_.Resize((TIndex)K * P);
+  const float* Wd = filter.data<float>();
+  for (int n = 0; n < N; ++n) {
+    const float* xn = X.data<float>() + (size_t)n * C * H * W;
+    const float* col = xn;
+    if (!pointwise) {
+      float* cb = col_buffer_.mutable_data<float>();
+      CAFFE_ENFORCE_EQ(ssad_im2col(xn, C, H, W, kh, kw, geom_.dilation[0], geom_.dilation[1],
+                                   geom_.pads[0], geom_.pads[1], geom_.pads[2], geom_.pads[3],
+                                   geom_.stride[0], geom_.stride[1], cb, s), 0);
+      col = cb;
+    }
+    GemmRowMajor(s, false, false, M, P, K, 1.0f, Wd, K, col, P, 0.0f,
+                 Y->mutable_data<float>() + (size_t)n * M * P, P);
+  }
+  if (InputSize() == 3 || fuse_relu_) {
+    const float* bias = InputSize() == 3 ? Input(BIAS).data<float>() : nullptr;
+    CAFFE_ENFORCE_EQ(ssad_affine_channel(Y->data<float>(), nullptr, bias, nullptr,
+                                         Y->mutable_data<float>(), N, M, P, fuse_relu_, s), 0);
+  }
+  return true;
+}
+
+// Default engine, backward (conv_op_impl.h:358-577): dfilter = sum_n dY[n] . col[n]^T,
+// dbias = channel sums of dY, dX[n] = col2im(filter^T . dY[n]).
+template <>
+bool ConvGradientOp<float, HIPContext>::RunDefaultEngine() {
+  auto& X = Input(INPUT);
+  auto& filter = Input(FILTER);
+  auto& dY = Input(OUTPUT_GRAD);
+  auto* dfilter = Output(FILTER_GRAD);
+  const int N = X.dim32(0), C = X.dim32(1), H = X.dim32(2), W = X.dim32(3);
+  const int M = filter.dim32(0);
+  const int kh = geom_.kernel[0], kw = geom_.kernel[1];
+  const int OH = ssad_conv_out_size(H, kh, geom_.dilation[0], geom_.pads[0], geom_.pads[2], geom_.stride[0]);
+  const int OW = ssad_conv_out_size(W, kw, geom_.dilation[1], geom_.pads[1], geom_.pads[3], geom_.stride[1]);
+  CAFFE_ENFORCE(dY.dim32(0) == N && dY.dim32(1) == M && dY.dim32(2) == OH && dY.dim32(3) == OW,
+                "output gradient shape does not match the convolution output");
+  CAFFE_ENFORCE(!relu_grad_on_input_, "relu_grad_on_input is an extension of the 3x3 engine");
+  dfilter->ResizeLike(filter);
+  hipStream_t s = context_.hip_stream();
+  const int K = C * kh * kw, P = OH * OW;
+  const bool pointwise = kh == 1 && kw == 1 && geom_.stride == vector<int>{1, 1} &&
+                         geom_.pads == vector<int>{0, 0, 0, 0};
+  const bool want_dx = OutputSize() == 3 || (no_bias_ && OutputSize() == 2);
+  Tensor<HIPContext>* dX = want_dx ? Output(no_bias_ ? BIAS_OR_INPUT_GRAD : INPUT_GRAD) : nullptr;
+  if (dX) dX->ResizeLike(X);
+  if (!pointwise) col_buffer_.Resize((TIndex)K * P);
+  for (int n = 0; n < N; ++n) {
+    const float* xn = X.data<float>() + (size_t)n * C * H * W;
+    const float* dyn = dY.data<float>() + (size_t)n * M * P;
+    const float* col = xn;
+    if (!pointwise) {
+      float* cb = col_buffer_.mutable_data<float>();
+      CAFFE_ENFORCE_EQ(ssad_im2col(xn, C, H, W, kh, kw, geom_.dilation[0], geom_.dilation[1],
+                                   geom_.pads[0], geom_.pads[1], geom_.pads[2], geom_.pads[3],
+                                   geom_.stride[0], geom_.stride[1], cb, s), 0);
+      col = cb;
+    }
+    // dfilter[M][K] (+)= dY[n][M][P] . col[K][P]^T
+    GemmRowMajor(s, false, true, M, K, P, 1.0f, dyn, P, col, P, n == 0 ? 0.0f : 1.0f,
+                 dfilter->mutable_data<float>(), K);
+    if (dX) {
+      float* dxn = dX->mutable_data<float>() + (size_t)n * C * H * W;
+      float* dcol = pointwise ? dxn : col_buffer_.mutable_data<float>();
+      // dcol[K][P] = filter[M][K]^T . dY[n][M][P]
+      GemmRowMajor(s, true, false, K, P, M, 1.0f, filter.data<float>(), K, dyn, P, 0.0f, dcol, P);
+      if (!pointwise)
+        CAFFE_ENFORCE_EQ(ssad_col2im(dcol, C, H, W, kh, kw, geom_.dilation[0], geom_.dilation[1],
+                                     geom_.pads[0], geom_.pads[1], geom_.pads[2], geom_.pads[3],
+                                     geom_.stride[0], geom_.stride[1], dxn, s), 0);
+    }
+  }
+  if (!no_bias_) {
+    auto* dbias = Output(BIAS_OR_INPUT_GRAD);
+    dbias->Resize(M);
+    CAFFE_ENFORCE_EQ(ssad_channel_sum(dY.data<float>(), N, M, P, dbias->mutable_data<float>(), 0, s), 0);
+  }
+  return true;
+}
+
 template <>
 bool ConvGradientOp<float, HIPContext>::RunOnDevice() {
   auto& X = Input(INPUT);
@@ -129,6 +240,7 @@ bool ConvGradientOp<float, HIPContext>::RunOnDevice() {
   CAFFE_ENFORCE(filter.dim32(1) * geom_.group == C);
   CAFFE_ENFORCE(filter.dim32(2) == geom_.kernel[0] && filter.dim32(3) == geom_.kernel[1]);
   CAFFE_ENFORCE_EQ(dY.ndim(), 4);
+  if (!IsSubnetGeometry(geom_)) return RunDefaultEngine();
   CAFFE_ENFORCE(dY.dim32(0) == N && dY.dim32(1) == M && dY.dim32(2) == H && dY.dim32(3) == W,
                 "output gradient shape does not match the convolution output");
   dfilter->ResizeLike(filter);

@@ -8,11 +8,14 @@
 // ConvGradient [X, filter, dY] -> [dfilter, dbias, (dX)] or, with
 // no_bias=1, [dfilter, (dX)].
 //
-// The HIP engine implements the geometry the RetinaNet subnets use
-// (3x3, stride 1, pad 1, dilation 1, group 1, NCHW) on the matrix cores; any
-// other geometry raises UnsupportedOperatorFeature at construction, as an
-// engine that cannot serve a definition does in the reference
-// (caffe2/core/operator.h:765-782).
+// Two engines, chosen per definition like the reference's engine fall-through
+// (caffe2/core/operator.cc:116-200): the geometry the RetinaNet subnets and the
+// ResNet bottlenecks use (3x3, stride 1, pad 1, dilation 1, group 1, NCHW) runs on
+// the matrix-core kernels of this repo; every other NCHW / group-1 geometry (the
+// backbone's 1x1, strided and 7x7 layers) runs on the DEFAULT engine of
+// conv_op_impl.h:31-202 / :358-577 -- im2col + GEMM per image, with the GEMMs on
+// rocBLAS.  NHWC and grouped convolutions raise UnsupportedOperatorFeature at
+// construction (caffe2/core/operator.h:765-782).
 //
 // Two optional arguments exist for graph-level fusion and are NOT emitted by
 // the reference graph builder (absent = reference behaviour):
@@ -37,6 +40,7 @@ struct ConvGeometry {
 // the reference does; shared by Conv and ConvGradient.
 ConvGeometry ParseConvGeometry(const OperatorBase& op);
 bool IsSubnetGeometry(const ConvGeometry& g);   // 3x3 / s1 / p1 / d1 / g1 / NCHW
+bool IsDefaultEngineGeometry(const ConvGeometry& g);   // any 2-D NCHW group-1 geometry
 bool UseWinograd(const string& algo, int out_channels);
 
 template <typename T, class Context>
@@ -48,17 +52,18 @@ class ConvOp final : public Operator<Context> {
         geom_(ParseConvGeometry(*this)),
         fuse_relu_(OperatorBase::GetSingleArgument<int>("fuse_relu", 0)),
         algo_(OperatorBase::GetSingleArgument<string>("hip_algo", "auto")) {
-    if (!IsSubnetGeometry(geom_))
-      throw UnsupportedOperatorFeature(
-          "HIP Conv engine implements kernel=3 stride=1 pad=1 dilation=1 group=1 NCHW only");
+    if (!IsDefaultEngineGeometry(geom_))
+      throw UnsupportedOperatorFeature("HIP Conv engines implement order=NCHW, group=1, 2-D only");
   }
   bool RunOnDevice() override;
 
  private:
+  bool RunDefaultEngine();
   ConvGeometry geom_;
   int fuse_relu_;
   string algo_;
   Tensor<Context> packed_filter_;
+  Tensor<Context> col_buffer_;
 };
 
 template <typename T, class Context>
@@ -73,9 +78,9 @@ class ConvGradientOp final : public Operator<Context> {
         algo_(OperatorBase::GetSingleArgument<string>("hip_algo", "auto")) {
     CAFFE_ENFORCE(!(no_bias_ && OutputSize() == 3),
                   "If bias is not present, you should not have 3 grad output.");
-    if (!IsSubnetGeometry(geom_))
+    if (!IsDefaultEngineGeometry(geom_))
       throw UnsupportedOperatorFeature(
-          "HIP ConvGradient engine implements kernel=3 stride=1 pad=1 dilation=1 group=1 NCHW only");
+          "HIP ConvGradient engines implement order=NCHW, group=1, 2-D only");
   }
   bool RunOnDevice() override;
 
@@ -84,8 +89,10 @@ class ConvGradientOp final : public Operator<Context> {
   bool no_bias_;
   int relu_grad_on_input_;
   string algo_;
+  bool RunDefaultEngine();
   Tensor<Context> packed_filter_;
   Tensor<Context> workspace_;
+  Tensor<Context> col_buffer_;
 };
 
 }  // namespace caffe2

@@ -8,6 +8,7 @@
 //   ConstantFill (float)       caffe2/operators/filler_op.h
 //   MomentumSGDUpdate          caffe2/sgd/momentum_sgd_op.h:97-131
 #include "c2/operator.h"
+#include "ops/conv_op.h"
 #include "ssad_kernels.h"
 
 namespace caffe2 {
@@ -249,6 +250,62 @@ class UpsampleNearestGradientHIPOp final : public Operator<HIPContext> {
   int scale_;
 };
 
+// MaxPool / MaxPoolGradient, NCHW (caffe2/operators/pool_op.{cc,cu}); arguments parsed as
+// ConvPoolOpBase does (kernel / stride / pad ...).  Gradient inputs [X, Y, dY] -> dX.
+class MaxPoolHIPOp final : public Operator<HIPContext> {
+ public:
+  MaxPoolHIPOp(const OperatorDef& def, Workspace* ws)
+      : Operator<HIPContext>(def, ws), geom_(ParseConvGeometry(*this)) {
+    if (geom_.order != "NCHW" || geom_.kernel.size() != 2 || geom_.dilation != vector<int>{1, 1})
+      throw UnsupportedOperatorFeature("HIP MaxPool implements order=NCHW, 2-D, dilation 1");
+  }
+  bool RunOnDevice() override {
+    auto& X = Input(0);
+    auto* Y = Output(0);
+    CAFFE_ENFORCE_EQ(X.ndim(), 4);
+    const int H = X.dim32(2), W = X.dim32(3);
+    const int OH = ssad_conv_out_size(H, geom_.kernel[0], 1, geom_.pads[0], geom_.pads[2], geom_.stride[0]);
+    const int OW = ssad_conv_out_size(W, geom_.kernel[1], 1, geom_.pads[1], geom_.pads[3], geom_.stride[1]);
+    CAFFE_ENFORCE(OH > 0 && OW > 0, "MaxPool: the window does not fit the padded input");
+    Y->Resize(X.dim32(0), X.dim32(1), OH, OW);
+    LAUNCH_OK(ssad_max_pool_forward(X.data<float>(), X.dim32(0), X.dim32(1), H, W, geom_.kernel[0],
+                                    geom_.kernel[1], geom_.stride[0], geom_.stride[1], geom_.pads[0],
+                                    geom_.pads[1], geom_.pads[2], geom_.pads[3],
+                                    Y->mutable_data<float>(), context_.hip_stream()), "MaxPool");
+    return true;
+  }
+ private:
+  ConvGeometry geom_;
+};
+
+class MaxPoolGradientHIPOp final : public Operator<HIPContext> {
+ public:
+  MaxPoolGradientHIPOp(const OperatorDef& def, Workspace* ws)
+      : Operator<HIPContext>(def, ws), geom_(ParseConvGeometry(*this)) {
+    if (geom_.order != "NCHW" || geom_.kernel.size() != 2 || geom_.dilation != vector<int>{1, 1})
+      throw UnsupportedOperatorFeature("HIP MaxPoolGradient implements order=NCHW, 2-D, dilation 1");
+  }
+  bool RunOnDevice() override {
+    auto& X = Input(0);
+    auto& Y = Input(1);
+    auto& dY = Input(2);
+    auto* dX = Output(0);
+    CAFFE_ENFORCE(dY.dims() == Y.dims(), "MaxPoolGradient: dY and Y differ in shape");
+    dX->ResizeLike(X);
+    LAUNCH_OK(ssad_max_pool_backward(X.data<float>(), Y.data<float>(), dY.data<float>(), X.dim32(0),
+                                     X.dim32(1), X.dim32(2), X.dim32(3), geom_.kernel[0],
+                                     geom_.kernel[1], geom_.stride[0], geom_.stride[1], geom_.pads[0],
+                                     geom_.pads[1], geom_.pads[2], geom_.pads[3],
+                                     dX->mutable_data<float>(), context_.hip_stream()),
+              "MaxPoolGradient");
+    return true;
+  }
+ private:
+  ConvGeometry geom_;
+};
+
+REGISTER_HIP_OPERATOR(MaxPool, MaxPoolHIPOp);
+REGISTER_HIP_OPERATOR(MaxPoolGradient, MaxPoolGradientHIPOp);
 REGISTER_HIP_OPERATOR(UpsampleNearest, UpsampleNearestHIPOp);
 REGISTER_HIP_OPERATOR(UpsampleNearestGradient, UpsampleNearestGradientHIPOp);
 REGISTER_HIP_OPERATOR(AffineChannel, AffineChannelHIPOp);
@@ -262,6 +319,8 @@ REGISTER_HIP_OPERATOR(WeightedSum, WeightedSumHIPOp);
 REGISTER_HIP_OPERATOR(ConstantFill, ConstantFillHIPOp);
 REGISTER_HIP_OPERATOR(MomentumSGDUpdate, MomentumSGDUpdateHIPOp);
 
+OPERATOR_SCHEMA(MaxPool).NumInputs(1).NumOutputs(1);
+OPERATOR_SCHEMA(MaxPoolGradient).NumInputs(3).NumOutputs(1);
 OPERATOR_SCHEMA(UpsampleNearest).NumInputs(1).NumOutputs(1);
 OPERATOR_SCHEMA(UpsampleNearestGradient).NumInputs(2).NumOutputs(1);
 OPERATOR_SCHEMA(AffineChannel).NumInputs(3).NumOutputs(1).AllowInplace({{0, 0}});
@@ -304,6 +363,16 @@ class GetUpsampleNearestGradient : public GradientMakerBase {
   }
 };
 REGISTER_GRADIENT(UpsampleNearest, GetUpsampleNearestGradient);
+
+// pool_gradient_op.cc GetPoolGradient: [X, Y, dY] -> dX, arguments inherited
+class GetMaxPoolGradient : public GradientMakerBase {
+  using GradientMakerBase::GradientMakerBase;
+  vector<OperatorDef> GetGradientDefs() override {
+    return SingleGradientDef("MaxPoolGradient", "", vector<string>{I(0), O(0), GO(0)},
+                             vector<string>{GI(0)});
+  }
+};
+REGISTER_GRADIENT(MaxPool, GetMaxPoolGradient);
 NO_GRADIENT(PowSum);
 NO_GRADIENT(ConstantFill);
 

@@ -106,11 +106,65 @@ def test_conv_relu_operators_and_gradients():
     close(workspace.FetchBlob("w_grad"), rdW, CONV_RTOL, CONV_FLOOR, "dW")
     close(workspace.FetchBlob("b_grad"), rdb, CONV_RTOL, CONV_FLOOR, "db")
     close(workspace.FetchBlob("X_grad"), rdX, CONV_RTOL, CONV_FLOOR, "dX")
-    # a geometry outside the engine's scope is refused at construction
+    # a definition neither engine serves is refused at construction
     with core.DeviceScope(GPU):
-        c5 = core.CreateOperator("Conv", ["X", "w", "b"], ["Y5"], kernel=5, pad=2, stride=1)
+        c5 = core.CreateOperator("Conv", ["X", "w", "b"], ["Y5"], kernel=3, pad=1, order="NHWC")
     with pytest.raises(Exception, match="Cannot create operator|HIP Conv engine"):
         workspace.RunOperatorOnce(c5)
+
+
+@pytest.mark.parametrize("geo", [
+    dict(kernel=1, stride=1, pad=0, cin=24, cout=40, hw=(9, 13)),      # pointwise: no im2col
+    dict(kernel=1, stride=2, pad=0, cin=16, cout=32, hw=(10, 14)),     # strided projection
+    dict(kernel=7, stride=2, pad=3, cin=3, cout=16, hw=(33, 47)),      # the stem
+    dict(kernel=3, stride=2, pad=1, cin=12, cout=20, hw=(11, 9)),      # P6 / P7
+    dict(kernel=5, stride=1, pad=2, cin=6, cout=7, hw=(8, 8))], ids=lambda g: "k%ds%d" % (g["kernel"], g["stride"]))
+def test_default_engine_conv_and_gradient(geo):
+    """Geometries outside the 3x3 engine run on the im2col + GEMM default engine
+    (conv_op_impl.h:31-202, :358-577); oracle = the same algorithm on the CPU."""
+    rng = np.random.default_rng(37 + geo["kernel"] * 10 + geo["stride"])
+    N, Cin, M = 2, geo["cin"], geo["cout"]
+    H, W = geo["hw"]
+    k, st, pd = geo["kernel"], geo["stride"], geo["pad"]
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, k, k)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    rY = oracle.conv_forward(X, Wt, b, kernel=k, stride=st, pad=pd)
+    dY = rng.standard_normal(rY.shape).astype(np.float32)
+    feed("X", X); feed("w", Wt); feed("b", b); feed("Y_grad", dY)
+    with core.DeviceScope(GPU):
+        conv = core.CreateOperator("Conv", ["X", "w", "b"], ["Y"], kernel=k, pad=pd, stride=st,
+                                   order="NCHW", engine="CUDNN")
+    workspace.RunOperatorOnce(conv)
+    close(workspace.FetchBlob("Y"), rY, CONV_RTOL, CONV_FLOOR, "default-engine Conv")
+    g, gi = core.GradientRegistry.GetGradientForOp(conv, ["Y_grad"])
+    workspace.RunOperatorsOnce(g)
+    rdW, rdb, rdX = oracle.conv_backward(X, Wt, dY, kernel=k, stride=st, pad=pd)
+    close(workspace.FetchBlob("w_grad"), rdW, CONV_RTOL, CONV_FLOOR, "dW")
+    close(workspace.FetchBlob("b_grad"), rdb, CONV_RTOL, CONV_FLOOR, "db")
+    close(workspace.FetchBlob("X_grad"), rdX, CONV_RTOL, CONV_FLOOR, "dX")
+
+
+def test_max_pool_operator_and_gradient():
+    """Stem pooling (kernel 3, stride 2, pad 1) against torch's max_pool2d (no ties in random data)."""
+    rng = np.random.default_rng(43)
+    N, C, H, W = 2, 6, 17, 22
+    X = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    feed("X", X)
+    with core.DeviceScope(GPU):
+        op = core.CreateOperator("MaxPool", ["X"], ["Y"], kernel=3, pad=1, stride=2)
+    workspace.RunOperatorOnce(op)
+    xt = torch.tensor(X, requires_grad=True)
+    yt = torch.nn.functional.max_pool2d(xt, 3, 2, 1)
+    Y = workspace.FetchBlob("Y")
+    assert np.array_equal(Y, yt.detach().numpy())
+    dY = rng.standard_normal(Y.shape).astype(np.float32)
+    feed("Y_grad", dY)
+    g, gi = core.GradientRegistry.GetGradientForOp(op, ["Y_grad"])
+    assert [o.type for o in g] == ["MaxPoolGradient"] and list(g[0].input) == ["X", "Y", "Y_grad"]
+    workspace.RunOperatorsOnce(g)
+    yt.backward(torch.tensor(dY))
+    np.testing.assert_allclose(workspace.FetchBlob(gi[0]), xt.grad.numpy(), rtol=1e-6, atol=1e-6)
 
 
 def test_affine_channel_operator_and_gradient():
