@@ -243,6 +243,8 @@ def GenerateBackward(fwd_ops, ys):
                     new = "%s_grad_autosplit_%d" % (key[0], k)
                     if oi is not None:
                         out_ops[oi].output[slot] = new
+                    else:
+                        new = gname      # an aliased gradient (Sum's SetDense): read in place
                     names.append(new)
                 total = key[0] + "_grad"
                 out_ops.append(CreateOperator("Sum", names, [total],
@@ -274,9 +276,12 @@ def GenerateBackward(fwd_ops, ys):
                 new = "%s_grad_autosplit_%d" % (key[0], k)
                 if oi is not None:
                     out_ops[oi].output[slot] = new
+                else:
+                    new = gname
                 names.append(new)
             total = key[0] + "_grad"
-            dev = out_ops[pieces[0][1]].device_option if pieces[0][1] is not None else None
+            owners = [p[1] for p in pieces if p[1] is not None]
+            dev = out_ops[owners[0]].device_option if owners else None
             out_ops.append(CreateOperator("Sum", names, [total], device_option=dev))
             grads[key] = [[total, None, None]]
     grad_map = {}

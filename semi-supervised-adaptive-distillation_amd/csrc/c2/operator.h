@@ -245,6 +245,12 @@ class C2HIP_API GradientMakerBase {
     g_input_[i].dense_ = def_.input[i] + "_grad";
     return g_input_[i].dense_;
   }
+  // the gradient of input i IS an existing blob (no op writes it), e.g. Sum passes its
+  // output gradient to every input (operator_gradient.h SetDense)
+  void SetDense(int i, const string& name) {
+    CAFFE_ENFORCE(i >= 0 && i < (int)g_input_.size());
+    g_input_[i].dense_ = name;
+  }
   string GO(int i) const {
     CAFFE_ENFORCE(i >= 0 && i < (int)g_output_.size() && g_output_[i].IsDense(),
                   "Gradient of output ", i, " of ", def_.type, " is not provided");

@@ -304,6 +304,24 @@ class MaxPoolGradientHIPOp final : public Operator<HIPContext> {
   ConvGeometry geom_;
 };
 
+// StopGradient (caffe2/operators/stop_gradient.h): identity forward, usually in place;
+// registered with NO gradient so the backward pass ends there (frozen res2).
+class StopGradientHIPOp final : public Operator<HIPContext> {
+ public:
+  using Operator<HIPContext>::Operator;
+  bool RunOnDevice() override {
+    auto& X = Input(0);
+    auto* Y = Output(0);
+    if (Y != &X) {
+      Y->ResizeLike(X);
+      context_.Copy<float, HIPContext, HIPContext>(X.size(), X.data<float>(),
+                                                   Y->mutable_data<float>());
+    }
+    return true;
+  }
+};
+
+REGISTER_HIP_OPERATOR(StopGradient, StopGradientHIPOp);
 REGISTER_HIP_OPERATOR(MaxPool, MaxPoolHIPOp);
 REGISTER_HIP_OPERATOR(MaxPoolGradient, MaxPoolGradientHIPOp);
 REGISTER_HIP_OPERATOR(UpsampleNearest, UpsampleNearestHIPOp);
@@ -319,6 +337,7 @@ REGISTER_HIP_OPERATOR(WeightedSum, WeightedSumHIPOp);
 REGISTER_HIP_OPERATOR(ConstantFill, ConstantFillHIPOp);
 REGISTER_HIP_OPERATOR(MomentumSGDUpdate, MomentumSGDUpdateHIPOp);
 
+OPERATOR_SCHEMA(StopGradient).NumInputs(1).NumOutputs(1).AllowInplace({{0, 0}});
 OPERATOR_SCHEMA(MaxPool).NumInputs(1).NumOutputs(1);
 OPERATOR_SCHEMA(MaxPoolGradient).NumInputs(3).NumOutputs(1);
 OPERATOR_SCHEMA(UpsampleNearest).NumInputs(1).NumOutputs(1);
@@ -373,7 +392,18 @@ class GetMaxPoolGradient : public GradientMakerBase {
   }
 };
 REGISTER_GRADIENT(MaxPool, GetMaxPoolGradient);
+// caffe2/operators/utility_ops.cc GetSumGradient: every input's gradient is the output
+// gradient blob itself; no operator is emitted
+class GetSumGradient : public GradientMakerBase {
+  using GradientMakerBase::GradientMakerBase;
+  vector<OperatorDef> GetGradientDefs() override {
+    for (int i = 0; i < (int)def_.input.size(); ++i) SetDense(i, GO(0));
+    return vector<OperatorDef>();
+  }
+};
+REGISTER_GRADIENT(Sum, GetSumGradient);
 NO_GRADIENT(PowSum);
+NO_GRADIENT(StopGradient);
 NO_GRADIENT(ConstantFill);
 
 }  // namespace caffe2

@@ -240,3 +240,35 @@ def test_full_backward_graph_with_supervised_losses(lib):
     # 20 shared parameters + 5 logits blobs + 5 fpn blobs (cls + bbox towers)
     assert hist["Sum"] == 30
     assert grad_map["fpn_7"] == "fpn_7_grad"
+
+
+def test_backbone_graph_matches_reference_capture():
+    """modeling/resnet_fpn.py emits, op for op and parameter for parameter, what the
+    reference's ResNet.py / FPN.py builders emit (capture: tests/golden/make_backbone_graph.py)."""
+    import json
+    import os
+    from ssad_amd.modeling import resnet_fpn as rf
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "backbone_graph_r50_fpn.json")))
+    model = rf.BodyModel(rf.BodyConfig())
+    blobs, dim, scales = rf.add_fpn_resnet_conv5_body(model)
+    assert [str(b) for b in blobs] == g["fpn_blobs"] and dim == g["fpn_dim"]
+    assert scales == g["spatial_scales"]
+    ops = model.net.Proto().op
+    assert len(ops) == len(g["ops"])
+    for mine, ref in zip(ops, g["ops"]):
+        assert mine.type == ref["type"]
+        assert list(mine.input) == ref["input"] and list(mine.output) == ref["output"], ref
+        got = {}
+        for a in mine.arg:
+            if a.HasField("i"):
+                got[a.name] = a.i
+            elif a.HasField("s"):
+                got[a.name] = a.s.decode() if isinstance(a.s, bytes) else a.s
+            elif a.HasField("f"):
+                got[a.name] = a.f
+        want = {k: (int(v) if isinstance(v, bool) else v) for k, v in ref["args"].items()}
+        engine = want.pop("engine", "")          # a field of OperatorDef, not an argument
+        assert (mine.engine or "") == engine
+        assert got == want, (ref, got)
+    mine_params = [(n, s, [i[0], i[1]]) for n, s, i in model.params]
+    assert mine_params == [(p["name"], p["shape"], p["init"]) for p in g["params"]]
