@@ -59,17 +59,7 @@ constexpr int kBlock = 512;  // 8 waves
 
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// Buffer descriptor from values the compiler must treat as wave-uniform:
-// every input goes through readfirstlane, otherwise hipcc wraps each buffer
-// load in a waterfall loop that serialises the loads.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, int bytes) {
-  const unsigned long long a = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  const int n = __builtin_amdgcn_readfirstlane(bytes);
-  void* q = (void*)(((unsigned long long)hi << 32) | lo);
-  return __builtin_amdgcn_make_buffer_rsrc(q, 0, n, 0x00020000);
-}
+using ssad_dev::uniform_rsrc;
 
 // ---------------------------------------------------------------------------
 // Filter packing

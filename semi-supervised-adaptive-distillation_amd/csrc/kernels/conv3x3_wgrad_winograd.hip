@@ -65,14 +65,7 @@ __device__ unsigned long long g_wdbg[64][8];
 
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  const unsigned n = __builtin_amdgcn_readfirstlane(bytes);
-  void* q = (void*)(((unsigned long long)hi << 32) | lo);
-  return __builtin_amdgcn_make_buffer_rsrc(q, 0, n, 0x00020000);
-}
+using ssad_dev::uniform_rsrc;
 
 struct GLevel {
   const float* x;

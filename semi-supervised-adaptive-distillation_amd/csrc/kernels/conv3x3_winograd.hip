@@ -34,6 +34,7 @@
 
 #include <type_traits>
 
+#include "conv_internal.h"
 #include "ssad_kernels.h"
 
 namespace {
@@ -58,14 +59,7 @@ constexpr int BM = 128;                  // output channels per workgroup
 
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, int bytes) {
-  const unsigned long long a = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  const int n = __builtin_amdgcn_readfirstlane(bytes);
-  void* q = (void*)(((unsigned long long)hi << 32) | lo);
-  return __builtin_amdgcn_make_buffer_rsrc(q, 0, n, 0x00020000);
-}
+using ssad_dev::uniform_rsrc;
 
 // ---------------------------------------------------------------------------
 // Filter transform + packing:  U = G g G^T, stored in MFMA A-operand order

@@ -1,4 +1,4 @@
-// Internal (not exported) entry points shared between the convolution sources.
+// Internal (not exported) declarations shared between the convolution sources.
 #ifndef SSAD_CONV_INTERNAL_H_
 #define SSAD_CONV_INTERNAL_H_
 
@@ -15,5 +15,22 @@ size_t ssad_wino_wgrad_workspace_bytes(const ssad_conv_level* lv, int n_levels, 
 int ssad_wino_wgrad_launch(const ssad_conv_level* lv, int n_levels, float* dW, int Cout, int Cin,
                            int accumulate, void* workspace, size_t workspace_bytes,
                            hipStream_t stream);
+
+namespace ssad_dev {
+
+// Buffer descriptor from values the compiler must treat as wave-uniform: every
+// input goes through readfirstlane, otherwise hipcc wraps each buffer load in a
+// waterfall loop that serialises the loads.  Loads past `bytes` return 0, stores
+// are dropped (the kernels send out-of-image lanes to offset 0x80000000).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const unsigned n = __builtin_amdgcn_readfirstlane(bytes);
+  void* q = (void*)(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, n, 0x00020000);
+}
+
+}  // namespace ssad_dev
 
 #endif  // SSAD_CONV_INTERNAL_H_
