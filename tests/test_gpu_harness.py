@@ -15,7 +15,7 @@ def fm():
 
 
 def _rel(a, b):
-    a, b = a.double(), b.double()
+    a, b = a.detach().double(), b.detach().double()
     return float((a - b).norm() / max(float(b.norm()), 1e-30))
 
 
