@@ -79,34 +79,50 @@ class _BiasActFn(torch.autograd.Function):
 
 
 class _Conv1x1Fn(torch.autograd.Function):
-    """Stride-1 pointwise convolution without bias.  Forward and data gradient stay on
-    MIOpen / rocBLAS; the weight gradient is one rocBLAS strided-batched GEMM
-    dW = sum_n dY[n] (M x P) . X[n]^T (P x C) instead of MIOpen's NHWC igemm, which for
-    NCHW tensors costs two layout transposes per call on top of the GEMM."""
+    """Stride-1 pointwise convolution without bias as three strided-batched GEMMs on the
+    NCHW tensors (batch = image): Y[n] = W . X[n], dX[n] = W^T . dY[n],
+    dW = sum_n dY[n] . X[n]^T.  MIOpen runs the same rocBLAS GEMMs for forward and data
+    gradient but picks its own solution, and its weight gradient is an NHWC igemm that
+    costs two layout transposes per call; going through torch's BLAS front end lets
+    TunableOp's per-shape pick (harness/tunableop_gfx950.csv) apply to all three."""
 
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
-        return F.conv2d(x, w, None)
+        return _mm1x1(x, w)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dw = None
+        N, M = dy.shape[0], dy.shape[1]
+        Cc = x.shape[1]
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(
-                dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            # explicit batched form: torch.matmul would fold 2-D x 3-D into one GEMM over
+            # a transposed COPY of dy
+            dx = torch.empty_like(x)
+            torch.bmm(w.view(1, M, Cc).transpose(1, 2).expand(N, Cc, M), dy.view(N, M, -1),
+                      out=dx.view(N, Cc, -1))
         if ctx.needs_input_grad[1]:
-            N, M = dy.shape[0], dy.shape[1]
-            Cc = x.shape[1]
             dw = torch.bmm(dy.view(N, M, -1), x.view(N, Cc, -1).transpose(1, 2)).sum(0).view_as(w)
         return dx, dw
 
 
+def _mm1x1(x, w):
+    N, Cc, H, W = x.shape
+    M = w.shape[0]
+    y = x.new_empty((N, M, H, W))       # a fresh tensor, not a view: the tail pass writes it in place
+    torch.bmm(w.detach().view(1, M, Cc).expand(N, M, Cc), x.detach().view(N, Cc, H * W),
+              out=y.view(N, M, H * W))
+    return y
+
+
 def conv1x1(x, w):
-    if _GEMM_WGRAD and w.requires_grad and x.is_contiguous():
-        return _Conv1x1Fn.apply(x, w)
+    if _GEMM_1X1 and x.is_contiguous():
+        if w.requires_grad or x.requires_grad:
+            return _Conv1x1Fn.apply(x, w)
+        return _mm1x1(x, w)
     return F.conv2d(x, w, None)
 
 
@@ -147,7 +163,27 @@ _HIP3X3_MIN = int(os.environ.get("SSAD_HARNESS_HIP3X3_MIN", "64"))
 # bias + residual + ReLU after the MIOpen / rocBLAS convolutions of a bottleneck as one
 # fused AffineChannel pass of this repo (NCHW only) instead of three torch passes
 _FUSE_TAIL = os.environ.get("SSAD_HARNESS_FUSE_TAIL", "1") == "1"
-_GEMM_WGRAD = os.environ.get("SSAD_HARNESS_GEMM_WGRAD", "1") == "1"
+# stride-1 pointwise convolutions as torch strided-batched GEMMs (see _Conv1x1Fn)
+_GEMM_1X1 = os.environ.get("SSAD_HARNESS_GEMM_1X1", "1") == "1"
+# TunableOp: "1" = use the committed per-shape GEMM picks when the file matches this
+# stack (its validator lines name torch / ROCm / rocBLAS / hipBLASLt / gfx arch; on a
+# mismatch torch ignores it), "tune" = search and write SSAD_TUNABLEOP_OUT, "0" = off
+_TUNABLEOP = os.environ.get("SSAD_HARNESS_TUNABLEOP", "1")
+_TUNABLEOP_CSV = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
+
+
+def setup_tunableop():
+    import torch.cuda.tunable as T
+    if _TUNABLEOP == "tune":
+        T.enable(True)
+        T.tuning_enable(True)
+        T.set_max_tuning_duration(int(os.environ.get("SSAD_TUNABLEOP_MS", "60")))
+        T.set_max_tuning_iterations(int(os.environ.get("SSAD_TUNABLEOP_ITERS", "30")))
+        T.set_filename(os.environ.get("SSAD_TUNABLEOP_OUT", "gpurun_out/tunableop_gfx950.csv"))
+    elif _TUNABLEOP == "1" and os.path.exists(_TUNABLEOP_CSV):
+        T.enable(True)
+        T.tuning_enable(False)
+        T.set_filename(_TUNABLEOP_CSV)
 
 
 def conv_frozen_bn(cin, cout, k, stride=1, padding=0):
@@ -168,15 +204,23 @@ class Bottleneck(nn.Module):
         self.proj = conv_frozen_bn(cin, cout, 1, stride=stride) if (cin != cout or stride != 1) else None
 
     def forward(self, x):
-        sc = x if self.proj is None else self.proj(x)
         if _FUSE_TAIL and x.is_contiguous():
+            b3 = self.c3.bias
+            if self.proj is None:
+                sc = x
+            else:
+                # the projection's bias rides along with c3's in the block's last pass
+                sc = conv1x1(x, self.proj.weight) if self.proj.stride == (1, 1) else \
+                    F.conv2d(x, self.proj.weight, None, self.proj.stride)
+                b3 = b3 + self.proj.bias
             # convolution without bias, then bias (+ residual) + ReLU in one pass
             z = conv1x1(x, self.c1.weight) if self.c1.stride == (1, 1) else \
                 F.conv2d(x, self.c1.weight, None, self.c1.stride)
             y = bias_act(z, self.c1.bias)
             y = self.c2(y) if self.hip2 else bias_act(
                 F.conv2d(y, self.c2.weight, None, 1, 1), self.c2.bias)
-            return bias_act(conv1x1(y, self.c3.weight), self.c3.bias, residual=sc)
+            return bias_act(conv1x1(y, self.c3.weight), b3, residual=sc)
+        sc = x if self.proj is None else self.proj(x)
         y = F.relu(self.c1(x), inplace=True)
         y = self.c2(y) if self.hip2 else F.relu(self.c2(y), inplace=True)
         y = self.c3(y)
@@ -257,6 +301,7 @@ class FullDistillModel(object):
         if self.channels_last:
             self.student = self.student.to(memory_format=torch.channels_last)
             self.teacher = self.teacher.to(memory_format=torch.channels_last)
+        setup_tunableop()
         self.two_streams = os.environ.get("SSAD_HARNESS_TWO_STREAMS", "1") == "1"
         self.side = torch.cuda.Stream() if self.two_streams else None
         self.trainable = [p for p in self.student.parameters() if p.requires_grad]

@@ -102,6 +102,38 @@ def test_conv1x1_gemm_weight_gradient_matches_torch(fm):
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     torch.nn.functional.conv2d(xr, wr).backward(dy)
     xh, wh = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-    fm.conv1x1(xh, wh).backward(dy)
+    yh = fm.conv1x1(xh, wh)
+    yh.backward(dy)
+    assert _rel(yh, torch.nn.functional.conv2d(x, w)) < 1e-5
+    assert _rel(fm.conv1x1(x, w), yh) < 1e-6          # no-grad (teacher) route
     assert _rel(xh.grad, xr.grad) < 1e-5
     assert _rel(wh.grad, wr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cmid,cout,stride", [(64, 64, 256, 1), (256, 64, 256, 1), (256, 128, 512, 2)])
+def test_bottleneck_fused_route_matches_plain_torch(fm, monkeypatch, cin, cmid, cout, stride):
+    """The block as the harness runs it (GEMM 1x1s, HIP 3x3, bias/residual/ReLU tails,
+    projection bias merged into the last pass) against the plain nn.Conv2d + F.relu
+    route over the same parameters: output and every parameter / input gradient."""
+    torch.manual_seed(5)
+    blk = fm.Bottleneck(cin, cmid, cout, stride).cuda()
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn_like(p) * (0.05 if p.dim() == 4 else 0.5))
+    x = torch.randn(2, cin, 12, 20, device="cuda")
+    dy = torch.randn(2, cout, 12 // stride, 20 // stride, device="cuda")
+
+    def run(fused):
+        monkeypatch.setattr(fm, "_FUSE_TAIL", fused)
+        blk.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        y = blk(xi)
+        y.backward(dy)
+        return y.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in blk.parameters()]
+
+    y1, dx1, g1 = run(True)
+    y0, dx0, g0 = run(False)
+    assert _rel(y1, y0) < 2e-5
+    assert _rel(dx1, dx0) < 2e-5
+    for a, b in zip(g1, g0):
+        assert _rel(a, b) < 2e-5
