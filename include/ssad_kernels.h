@@ -315,6 +315,12 @@ SSAD_API int ssad_channel_sum(const float* dy, int N, int C, int HW, float* out,
 SSAD_API int ssad_max_pool_forward(const float* x, int N, int C, int H, int W, int kh, int kw,
                                    int stride_h, int stride_w, int pad_t, int pad_l, int pad_b,
                                    int pad_r, float* y, ssad_stream_t stream);
+/* The ResNet stem's pool (detectron/lib/modeling/ResNet.py:166-168: kernel 3, stride 2,
+ * pad 1) with the AffineChannel bias and ReLU that precede it folded in:
+ * y = relu?(max(window of x) + bias[c]) -- equal to pooling relu(x + bias[c]) because both
+ * are monotonic.  bias may be NULL. */
+SSAD_API int ssad_max_pool3x3s2_bias_relu(const float* x, const float* bias, int N, int C, int H,
+                                          int W, int relu, float* y, ssad_stream_t stream);
 SSAD_API int ssad_max_pool_backward(const float* x, const float* y, const float* dy, int N, int C,
                                     int H, int W, int kh, int kw, int stride_h, int stride_w,
                                     int pad_t, int pad_l, int pad_b, int pad_r, float* dx,

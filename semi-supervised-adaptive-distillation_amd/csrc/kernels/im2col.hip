@@ -122,6 +122,45 @@ __global__ __launch_bounds__(kT) void max_pool_kernel(const float* __restrict__ 
   }
 }
 
+// The ResNet stem's pool (ResNet.py:166-168: 3x3, stride 2, pad 1) with the preceding
+// AffineChannel bias and ReLU folded in: both are monotonic per channel, so
+// relu(max(window) + b[c]) == max over the window of relu(x + b[c]).  One thread per
+// output; each row of the window is one 8-byte load plus the left neighbour.
+template <bool kVec>
+__global__ __launch_bounds__(kT) void pool3x3s2_bias_relu_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ bias,
+                                                                 long long planes, int C, int H, int W,
+                                                                 int OH, int OW, int relu,
+                                                                 float* __restrict__ y) {
+  const long long total = planes * OH * OW;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kT) {
+    const int ow = (int)(i % OW);
+    const long long r = i / OW;
+    const int oh = (int)(r % OH);
+    const long long p = r / OH;
+    const float* xp = x + p * H * W;
+    const int w0 = 2 * ow;
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int d = -1; d <= 1; ++d) {
+      const int h = 2 * oh + d;
+      if (h < 0 || h >= H) continue;
+      const float* row = xp + (long long)h * W;
+      if (kVec) {                                  // W even: w0 + 1 < W and 8-byte aligned
+        const float2 v = *reinterpret_cast<const float2*>(row + w0);
+        m = fmaxf(m, fmaxf(v.x, v.y));
+      } else {
+        m = fmaxf(m, row[w0]);
+        if (w0 + 1 < W) m = fmaxf(m, row[w0 + 1]);
+      }
+      if (w0 > 0) m = fmaxf(m, row[w0 - 1]);
+    }
+    if (bias) m += bias[(int)(p % C)];
+    y[i] = relu ? fmaxf(m, 0.0f) : m;
+  }
+}
+
 // pool_op.cu MaxPoolBackwardNCHW: every input equal to its window's maximum receives that
 // window's gradient (gather form, deterministic)
 __global__ __launch_bounds__(kT) void max_pool_grad_kernel(const float* __restrict__ x,
@@ -202,6 +241,22 @@ int ssad_max_pool_forward(const float* x, int N, int C, int H, int W, int kh, in
   if (g.planes == 0) return 0;
   hipLaunchKernelGGL(max_pool_kernel, dim3(grid_for(g.planes * g.OH * g.OW)), dim3(kT), 0,
                      (hipStream_t)stream, x, g, y);
+  return (int)hipGetLastError();
+}
+
+int ssad_max_pool3x3s2_bias_relu(const float* x, const float* bias, int N, int C, int H, int W,
+                                 int relu, float* y, ssad_stream_t stream) {
+  const int OH = ssad_conv_out_size(H, 3, 1, 1, 1, 2), OW = ssad_conv_out_size(W, 3, 1, 1, 1, 2);
+  if (!x || !y || N < 0 || C < 1 || OH < 1 || OW < 1) return SSAD_E_BADARG;
+  const long long planes = (long long)N * C;
+  if (planes == 0) return 0;
+  const dim3 grid(grid_for(planes * OH * OW));
+  if ((W & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
+    hipLaunchKernelGGL(pool3x3s2_bias_relu_kernel<true>, grid, dim3(kT), 0, (hipStream_t)stream, x,
+                       bias, planes, C, H, W, OH, OW, relu, y);
+  else
+    hipLaunchKernelGGL(pool3x3s2_bias_relu_kernel<false>, grid, dim3(kT), 0, (hipStream_t)stream, x,
+                       bias, planes, C, H, W, OH, OW, relu, y);
   return (int)hipGetLastError();
 }
 

@@ -126,6 +126,19 @@ def conv1x1(x, w):
     return F.conv2d(x, w, None)
 
 
+def conv3x3_s2_gemm(x, w, b):
+    """3x3 / stride 2 / pad 1 convolution (FPN's P6 on res5: 2048 -> 256 at 20x28) as
+    im2col + ONE GEMM with the batch folded into the columns (K = 9*Cin = 18 432);
+    MIOpen's stride-2 Winograd runs this geometry at ~20 TFLOP/s."""
+    N, Cc, H, W = x.shape
+    M = w.shape[0]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    cols = F.unfold(x, 3, padding=1, stride=2)                      # [N, 9*Cin, Ho*Wo]
+    cols = cols.permute(1, 0, 2).reshape(Cc * 9, N * Ho * Wo)
+    y = torch.mm(w.view(M, Cc * 9), cols).view(M, N, Ho, Wo).permute(1, 0, 2, 3)
+    return (y + b.view(1, M, 1, 1)).contiguous()
+
+
 def bias_act(z, bias, residual=None, relu=True):
     if not (z.requires_grad or bias.requires_grad or (residual is not None and residual.requires_grad)):
         return _K().affine_channel_(z, bias.detach().contiguous(), residual=residual, relu=relu)
@@ -205,18 +218,19 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         if _FUSE_TAIL and x.is_contiguous():
+            if self.c1.stride != (1, 1):
+                # a strided pointwise convolution is the pointwise convolution of the
+                # subsampled map; c1 and the projection share the one gather
+                x = x[:, :, ::self.c1.stride[0], ::self.c1.stride[1]].contiguous()
             b3 = self.c3.bias
             if self.proj is None:
                 sc = x
             else:
                 # the projection's bias rides along with c3's in the block's last pass
-                sc = conv1x1(x, self.proj.weight) if self.proj.stride == (1, 1) else \
-                    F.conv2d(x, self.proj.weight, None, self.proj.stride)
+                sc = conv1x1(x, self.proj.weight)
                 b3 = b3 + self.proj.bias
             # convolution without bias, then bias (+ residual) + ReLU in one pass
-            z = conv1x1(x, self.c1.weight) if self.c1.stride == (1, 1) else \
-                F.conv2d(x, self.c1.weight, None, self.c1.stride)
-            y = bias_act(z, self.c1.bias)
+            y = bias_act(conv1x1(x, self.c1.weight), self.c1.bias)
             y = self.c2(y) if self.hip2 else bias_act(
                 F.conv2d(y, self.c2.weight, None, 1, 1), self.c2.bias)
             return bias_act(conv1x1(y, self.c3.weight), b3, residual=sc)
@@ -266,15 +280,30 @@ class ResNetFPN(nn.Module):
             p.requires_grad_(False)
 
     def forward(self, x):
-        c2 = self.res2(self.stem(x))
+        if _FUSE_TAIL and x.is_contiguous() and not x.requires_grad:
+            # frozen stem: 7x7/2 convolution, then bias + ReLU + 3x3/2 pool in one pass
+            z = F.conv2d(x, self.stem[0].weight, None, 2, 3)
+            c1 = _K().max_pool3x3s2_bias_relu(z, self.stem[0].bias.detach(), relu=True)
+        else:
+            c1 = self.stem(x)
+        c2 = self.res2(c1)
         c3 = self.res3(c2)
         c4 = self.res4(c3)
         c5 = self.res5(c4)
-        t5 = self.lat[0](c5)
-        t4 = self.lat[1](c4) + F.interpolate(t5, scale_factor=2, mode="nearest")
-        t3 = self.lat[2](c3) + F.interpolate(t4, scale_factor=2, mode="nearest")
+        if _FUSE_TAIL and c5.is_contiguous():
+            # laterals as GEMMs; bias and the top-down sum in one pass
+            t5 = bias_act(conv1x1(c5, self.lat[0].weight), self.lat[0].bias, relu=False)
+            t4 = bias_act(conv1x1(c4, self.lat[1].weight), self.lat[1].bias, relu=False,
+                          residual=F.interpolate(t5, scale_factor=2, mode="nearest"))
+            t3 = bias_act(conv1x1(c3, self.lat[2].weight), self.lat[2].bias, relu=False,
+                          residual=F.interpolate(t4, scale_factor=2, mode="nearest"))
+            p6 = conv3x3_s2_gemm(c5, self.p6.weight, self.p6.bias)
+        else:
+            t5 = self.lat[0](c5)
+            t4 = self.lat[1](c4) + F.interpolate(t5, scale_factor=2, mode="nearest")
+            t3 = self.lat[2](c3) + F.interpolate(t4, scale_factor=2, mode="nearest")
+            p6 = self.p6(c5)
         p5, p4, p3 = self.out[0](t5), self.out[1](t4), self.out[2](t3)
-        p6 = self.p6(c5)
         p7 = self.p7(F.relu(p6))
         return [p3, p4, p5, p6, p7]      # finest first, matching synth.LEVEL_SHAPES_600
 

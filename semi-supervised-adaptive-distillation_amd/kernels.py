@@ -92,6 +92,7 @@ def lib():
     L.ssad_affine_channel.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.ssad_upsample_nearest.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.ssad_upsample_nearest_grad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    L.ssad_max_pool3x3s2_bias_relu.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_momentum_sgd_update.argtypes = [vp, vp, vp, vp, f32, f32, i32, i64, vp]
     L.ssad_conv_packed_filter_floats.restype = sz
     L.ssad_conv_packed_filter_floats.argtypes = [i32, i32]
@@ -332,6 +333,18 @@ def upsample_nearest(x, scale=2, addend=None, out=None):
         _f32c(addend, "addend")
     _check(lib().ssad_upsample_nearest(_ptr(x), _ptr(addend), _ptr(y), N, Cc, H, W, scale,
                                        _stream()), "upsample_nearest")
+    return y
+
+
+def max_pool3x3s2_bias_relu(x, bias=None, relu=True):
+    """relu(maxpool3x3/2,pad1(x) + bias[c]) in one pass (the ResNet stem's tail)."""
+    _f32c(x, "x")
+    N, Cc, H, W = x.shape
+    y = torch.empty((N, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device="cuda")
+    if bias is not None:
+        _f32c(bias, "bias")
+    _check(lib().ssad_max_pool3x3s2_bias_relu(_ptr(x), _ptr(bias), N, Cc, H, W, int(relu), _ptr(y),
+                                              _stream()), "max_pool3x3s2_bias_relu")
     return y
 
 

@@ -137,3 +137,61 @@ def test_bottleneck_fused_route_matches_plain_torch(fm, monkeypatch, cin, cmid, 
     assert _rel(dx1, dx0) < 2e-5
     for a, b in zip(g1, g0):
         assert _rel(a, b) < 2e-5
+
+
+@pytest.mark.parametrize("H,W", [(20, 28), (13, 17), (6, 5)])
+def test_fused_stem_pool_matches_torch(H, W):
+    from ssad_amd import kernels as K
+    torch.manual_seed(2)
+    z = torch.randn(3, 5, H, W, device="cuda")
+    b = torch.randn(5, device="cuda")
+    want = torch.nn.functional.max_pool2d(torch.relu(z + b.view(1, 5, 1, 1)), 3, 2, 1)
+    assert torch.equal(K.max_pool3x3s2_bias_relu(z, b, relu=True), want)
+    want = torch.nn.functional.max_pool2d(z, 3, 2, 1)
+    assert torch.equal(K.max_pool3x3s2_bias_relu(z, None, relu=False), want)
+
+
+def test_strided_3x3_gemm_route_matches_torch(fm):
+    torch.manual_seed(4)
+    x = torch.randn(2, 24, 9, 14, device="cuda")
+    w = torch.randn(10, 24, 3, 3, device="cuda") * 0.1
+    b = torch.randn(10, device="cuda")
+    dy = torch.randn(2, 10, 5, 7, device="cuda")
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.conv2d(xr, wr, br, 2, 1)
+    yr.backward(dy)
+    xh, wh, bh = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yh = fm.conv3x3_s2_gemm(xh, wh, bh)
+    yh.backward(dy)
+    assert yh.shape == yr.shape and yh.is_contiguous()
+    for a, c in ((yh, yr), (xh.grad, xr.grad), (wh.grad, wr.grad), (bh.grad, br.grad)):
+        assert _rel(a, c) < 1e-5
+
+
+def test_body_fused_route_matches_plain_torch(fm, monkeypatch):
+    """The whole ResNet-50-FPN body as the harness runs it against the plain
+    nn.Conv2d / F.relu / max_pool2d route over the same parameters, at 64x96:
+    the five pyramid levels and the gradients of every trainable parameter."""
+    torch.manual_seed(9)
+    net = fm.ResNetFPN(50).cuda()
+    x = torch.randn(2, 3, 64, 96, device="cuda")
+    dys = None
+
+    def run(fused):
+        nonlocal dys
+        monkeypatch.setattr(fm, "_FUSE_TAIL", fused)
+        net.zero_grad(set_to_none=True)
+        outs = net(x)
+        if dys is None:
+            dys = [torch.randn_like(o) for o in outs]
+        torch.autograd.backward(outs, dys)
+        return [o.detach().clone() for o in outs], {n: p.grad.clone() for n, p in net.named_parameters()
+                                                    if p.grad is not None}
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    for a, b in zip(o1, o0):
+        assert _rel(a, b) < 5e-5
+    assert set(g1) == set(g0) and len(g0) >= 100
+    for n in g0:
+        assert _rel(g1[n], g0[n]) < 2e-4, n

@@ -20,7 +20,7 @@ def short(name):
 
 
 def main():
-    args = [a for a in sys.argv[1:]]
+    args = [a for a in sys.argv[1:] if a != "--busy"]
     js = title = None
     if "--json" in args:
         i = args.index("--json"); js = args[i + 1]; del args[i:i + 2]
@@ -48,6 +48,28 @@ def main():
         if len(ends) > last:
             lo, hi = ends[-last - 1], ends[-1]
             rows = [r for r in rows if r[1] >= lo and r[2] <= hi]
+    busy_note = None
+    if rows:
+        # GPU occupancy of the window: union of the kernel intervals against its span,
+        # and the kernels that precede / follow the longest idle gaps
+        iv = sorted((r[1], r[2], r[0]) for r in rows)
+        span = max(r[1] for r in iv) - iv[0][0]
+        busy, cur_end, gaps, prev_name = 0, iv[0][0], [], ""
+        for st, en, nm in iv:
+            if st > cur_end:
+                gaps.append((st - cur_end, prev_name, nm))
+            busy += max(0, en - max(st, cur_end))
+            if en > cur_end:
+                cur_end, prev_name = en, nm
+        gaps.sort(reverse=True)
+        tot_gap = sum(g[0] for g in gaps)
+        busy_note = ["", "GPU busy (union of kernel intervals) %.3f ms of %.3f ms window = %.1f %%; "
+                     "%d idle gaps, %.3f ms total, %d of them > 20 us (%.3f ms)" % (
+                         busy / 1e6, span / 1e6, 100.0 * busy / max(span, 1), len(gaps), tot_gap / 1e6,
+                         sum(1 for g in gaps if g[0] > 20000), sum(g[0] for g in gaps if g[0] > 20000) / 1e6),
+                     "", "| longest idle gaps (us) | after | before |", "|---|---|---|"]
+        for g in gaps[:12]:
+            busy_note.append("| %.1f | %s | %s |" % (g[0] / 1e3, short(g[1])[:50], short(g[2])[:50]))
     agg = {}
     for n, s, e in rows:
         a = agg.setdefault(short(n), [0, 0, 1 << 62, 0])
@@ -66,6 +88,8 @@ def main():
         lines.append("| %s | %d | %.3f | %.1f | %.1f | %.1f | %.1f |" % (
             n, a[0], a[1] / 1e6, a[1] / a[0] / 1e3, a[2] / 1e3, a[3] / 1e3, 100.0 * a[1] / total))
         out["kernels"][n] = {"calls": a[0], "avg_us": a[1] / a[0] / 1e3}
+    if busy_note and "--busy" in sys.argv:
+        lines += busy_note
     try:
         q = ("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) "
              "from counters_collection group by 1, 2")
