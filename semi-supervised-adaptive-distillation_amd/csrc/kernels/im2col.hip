@@ -124,14 +124,48 @@ __global__ __launch_bounds__(kT) void max_pool_kernel(const float* __restrict__ 
 
 // The ResNet stem's pool (ResNet.py:166-168: 3x3, stride 2, pad 1) with the preceding
 // AffineChannel bias and ReLU folded in: both are monotonic per channel, so
-// relu(max(window) + b[c]) == max over the window of relu(x + b[c]).  One thread per
-// output; each row of the window is one 8-byte load plus the left neighbour.
+// relu(max(window) + b[c]) == max over the window of relu(x + b[c]).
+// kVec (W % 4 == 0): a thread makes two adjacent outputs from one 16-byte load per
+// window row; the left neighbour column comes from the previous lane's load.
 template <bool kVec>
 __global__ __launch_bounds__(kT) void pool3x3s2_bias_relu_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ bias,
                                                                  long long planes, int C, int H, int W,
                                                                  int OH, int OW, int relu,
                                                                  float* __restrict__ y) {
+  if (kVec) {
+    const int OW2 = OW >> 1;
+    const long long total = planes * OH * OW2;
+    const long long i = (long long)blockIdx.x * kT + threadIdx.x;   // grid covers total exactly
+    const bool live = i < total;
+    const long long ii = live ? i : total - 1;
+    const int j = (int)(ii % OW2);
+    const long long r = ii / OW2;
+    const int oh = (int)(r % OH);
+    const long long p = r / OH;
+    const float* xp = x + p * H * W;
+    const int lane = threadIdx.x & 63;
+    float m0 = -__builtin_inff(), m1 = m0;
+#pragma unroll
+    for (int d = -1; d <= 1; ++d) {
+      const int h = 2 * oh + d;
+      const bool ok = h >= 0 && h < H;                // uniform per output row, not per wave
+      const float* row = xp + (long long)(ok ? h : 2 * oh) * W;
+      const float4 v = *reinterpret_cast<const float4*>(row + 4 * j);
+      float left = __shfl_up(v.w, 1);
+      if (lane == 0 && j > 0) left = row[4 * j - 1];
+      if (j == 0) left = v.x;
+      if (ok) {
+        m0 = fmaxf(m0, fmaxf(left, fmaxf(v.x, v.y)));
+        m1 = fmaxf(m1, fmaxf(v.y, fmaxf(v.z, v.w)));
+      }
+    }
+    if (!live) return;
+    if (bias) { const float b = bias[(int)(p % C)]; m0 += b; m1 += b; }
+    if (relu) { m0 = fmaxf(m0, 0.0f); m1 = fmaxf(m1, 0.0f); }
+    *reinterpret_cast<float2*>(y + (p * OH + oh) * OW + 2 * j) = make_float2(m0, m1);
+    return;
+  }
   const long long total = planes * OH * OW;
   for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total;
        i += (long long)gridDim.x * kT) {
@@ -147,13 +181,8 @@ __global__ __launch_bounds__(kT) void pool3x3s2_bias_relu_kernel(const float* __
       const int h = 2 * oh + d;
       if (h < 0 || h >= H) continue;
       const float* row = xp + (long long)h * W;
-      if (kVec) {                                  // W even: w0 + 1 < W and 8-byte aligned
-        const float2 v = *reinterpret_cast<const float2*>(row + w0);
-        m = fmaxf(m, fmaxf(v.x, v.y));
-      } else {
-        m = fmaxf(m, row[w0]);
-        if (w0 + 1 < W) m = fmaxf(m, row[w0 + 1]);
-      }
+      m = fmaxf(m, row[w0]);
+      if (w0 + 1 < W) m = fmaxf(m, row[w0 + 1]);
       if (w0 > 0) m = fmaxf(m, row[w0 - 1]);
     }
     if (bias) m += bias[(int)(p % C)];
@@ -250,13 +279,15 @@ int ssad_max_pool3x3s2_bias_relu(const float* x, const float* bias, int N, int C
   if (!x || !y || N < 0 || C < 1 || OH < 1 || OW < 1) return SSAD_E_BADARG;
   const long long planes = (long long)N * C;
   if (planes == 0) return 0;
-  const dim3 grid(grid_for(planes * OH * OW));
-  if ((W & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
-    hipLaunchKernelGGL(pool3x3s2_bias_relu_kernel<true>, grid, dim3(kT), 0, (hipStream_t)stream, x,
-                       bias, planes, C, H, W, OH, OW, relu, y);
-  else
-    hipLaunchKernelGGL(pool3x3s2_bias_relu_kernel<false>, grid, dim3(kT), 0, (hipStream_t)stream, x,
-                       bias, planes, C, H, W, OH, OW, relu, y);
+  if ((W & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+    const long long pairs = planes * OH * (OW >> 1);
+    if ((pairs + kT - 1) / kT >= (1LL << 31)) return SSAD_E_BADARG;
+    hipLaunchKernelGGL(pool3x3s2_bias_relu_kernel<true>, dim3((unsigned)((pairs + kT - 1) / kT)),
+                       dim3(kT), 0, (hipStream_t)stream, x, bias, planes, C, H, W, OH, OW, relu, y);
+  } else {
+    hipLaunchKernelGGL(pool3x3s2_bias_relu_kernel<false>, dim3(grid_for(planes * OH * OW)), dim3(kT),
+                       0, (hipStream_t)stream, x, bias, planes, C, H, W, OH, OW, relu, y);
+  }
   return (int)hipGetLastError();
 }
 
