@@ -44,6 +44,11 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=16)
     ap.add_argument("--workload", default=os.environ.get("SSAD_BENCH_WORKLOAD", "full"),
                     choices=["heads", "full"])
+    # BASELINE config 3 by default; config 5's networks and image size (in fp32 -- the fp16
+    # storage path is not built): --student r101 --teacher x101-64x4d --px 500
+    ap.add_argument("--student", default="r50", choices=["r50", "r101"])
+    ap.add_argument("--teacher", default="r101", choices=["r50", "r101", "x101-64x4d"])
+    ap.add_argument("--px", type=int, default=600, choices=[600, 500])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="auto")
     return ap.parse_args()
@@ -149,7 +154,8 @@ def main():
     K.lib()   # fail loudly if the HIP extension is missing
 
     N = args.batch_per_gpu
-    shapes = synth.LEVEL_SHAPES_600
+    shapes = synth.LEVEL_SHAPES_600 if args.px == 600 else synth.LEVEL_SHAPES_500
+    image_hw = (640, 896) if args.px == 600 else (512, 768)
     cfg = HeadConfig(num_gpus=world)
     rng = np.random.default_rng(1234 + rank)
     heads = DistillHeads(cfg, N=N, shapes=shapes, device=dev,
@@ -194,15 +200,19 @@ def main():
               "on synthetic FPN features")
     else:
         from ssad_amd.harness.full_model import FullDistillModel
-        model = FullDistillModel(heads, student_depth=50, teacher_depth=101, device=dev,
+        model = FullDistillModel(heads, student_depth=args.student, teacher_depth=args.teacher, device=dev,
                                  process_group=pg, world_size=world)
-        images = torch.randn((N, 3, 640, 896), device=dev, generator=gen)
+        images = torch.randn((N, 3) + image_hw, device=dev, generator=gen)
 
         def step():
             model.step(images, labels, bbox_targets, fg_num)
-        wl = ("R-50-FPN student + R-101-FPN teacher adaptive distillation, 600 px (3x640x896): "
-              "backbones = PyTorch harness (MIOpen/rocBLAS 1x1, 7x7 and strided convs; its "
-              "stride-1 3x3 convs on this repo's kernels); subnets, distillation + "
+        wl = ("%s-FPN student + %s-FPN teacher adaptive distillation, %d px (3x%dx%d): " % (
+              args.student.upper().replace("R", "R-", 1), args.teacher.upper().replace("R", "R-", 1)
+              if args.teacher[0] == "r" else args.teacher.upper().replace("X", "X-", 1),
+              args.px, image_hw[0], image_hw[1]) +
+              "backbones = PyTorch harness (1x1 convs as rocBLAS / hipBLASLt GEMMs, MIOpen 7x7 stem, "
+              "P7 and grouped convs; its stride-1 3x3 convs, bias/residual/ReLU tails and stem pool "
+              "on this repo's kernels); subnets, distillation + "
               "focal + smooth-L1 losses and subnet SGD = this repo's HIP kernels")
 
     for _ in range(args.warmup):
@@ -253,7 +263,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(host / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl, "batch_per_gpu": N, "image": "3x640x896",
+            "config": {"workload": wl, "batch_per_gpu": N, "image": "3x%dx%d" % image_hw,
                        "fpn_levels": [list(s) for s in shapes], "anchors": 9, "classes": 80,
                        "parallelism": "dp%d" % world,
                        "distill_loss": loss_val,

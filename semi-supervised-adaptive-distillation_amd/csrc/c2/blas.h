@@ -16,5 +16,13 @@ C2HIP_API void GemmRowMajor(hipStream_t stream, bool trans_a, bool trans_b, int 
                             float alpha, const float* A, int lda, const float* B, int ldb,
                             float beta, float* C, int ldc);
 
+// The same over `batch` independent problems whose operands are `stride_*` elements apart
+// (the groups of a grouped convolution: math::GemmStridedBatched).
+C2HIP_API void GemmRowMajorStridedBatched(hipStream_t stream, bool trans_a, bool trans_b, int M, int N,
+                                          int K, float alpha, const float* A, int lda,
+                                          long long stride_a, const float* B, int ldb,
+                                          long long stride_b, float beta, float* C, int ldc,
+                                          long long stride_c, int batch);
+
 }  // namespace caffe2
 #endif  // C2HIP_BLAS_H_

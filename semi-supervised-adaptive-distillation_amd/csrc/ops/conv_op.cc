@@ -63,7 +63,7 @@ bool IsSubnetGeometry(const ConvGeometry& g) {
 }
 
 bool IsDefaultEngineGeometry(const ConvGeometry& g) {
-  return g.order == "NCHW" && g.group == 1 && g.kernel.size() == 2;
+  return g.order == "NCHW" && g.group >= 1 && g.kernel.size() == 2;
 }
 
 // Algorithm choice, like cuDNN's internal one (conv_op_cudnn.cc:541-558):
@@ -143,7 +143,12 @@ bool ConvOp<float, HIPContext>::RunDefaultEngine() {
   CAFFE_ENFORCE(OH > 0 && OW > 0, "Conv: the kernel does not fit the padded input");
   Y->Resize(N, M, OH, OW);
   hipStream_t s = context_.hip_stream();
-  const int K = C * kh * kw, P = OH * OW;
+  // groups (conv_op_impl.h:93-98,126-173; gradient :451-500,524-560): group g maps input channels [g*C/G, (g+1)*C/G) to
+  // output channels [g*M/G, (g+1)*M/G); with the col rows ordered (c, kh, kw) the groups are
+  // G independent GEMMs over contiguous row blocks -> one strided-batched call per image
+  const int G = geom_.group;
+  CAFFE_ENFORCE(M % G == 0, "the number of output channels is not divisible by group");
+  const int K = C * kh * kw, P = OH * OW, Kg = K / G, Mg = M / G;
   const bool pointwise = kh == 1 && kw == 1 && geom_.stride == vector<int>{1, 1} &&
                          geom_.pads == vector<int>{0, 0, 0, 0};
   if (!pointwise) col_buffer_.Resize((TIndex)K * P);
@@ -158,8 +163,12 @@ bool ConvOp<float, HIPContext>::RunDefaultEngine() {
                                    geom_.stride[0], geom_.stride[1], cb, s), 0);
       col = cb;
     }
-    GemmRowMajor(s, false, false, M, P, K, 1.0f, Wd, K, col, P, 0.0f,
-                 Y->mutable_data<float>() + (size_t)n * M * P, P);
+    float* yn = Y->mutable_data<float>() + (size_t)n * M * P;
+    if (G == 1)
+      GemmRowMajor(s, false, false, M, P, K, 1.0f, Wd, K, col, P, 0.0f, yn, P);
+    else
+      GemmRowMajorStridedBatched(s, false, false, Mg, P, Kg, 1.0f, Wd, Kg, (long long)Mg * Kg, col, P,
+                                 (long long)Kg * P, 0.0f, yn, P, (long long)Mg * P, G);
   }
   if (InputSize() == 3 || fuse_relu_) {
     const float* bias = InputSize() == 3 ? Input(BIAS).data<float>() : nullptr;
@@ -187,7 +196,9 @@ bool ConvGradientOp<float, HIPContext>::RunDefaultEngine() {
   CAFFE_ENFORCE(!relu_grad_on_input_, "relu_grad_on_input is an extension of the 3x3 engine");
   dfilter->ResizeLike(filter);
   hipStream_t s = context_.hip_stream();
-  const int K = C * kh * kw, P = OH * OW;
+  const int G = geom_.group;
+  CAFFE_ENFORCE(M % G == 0, "the number of output channels is not divisible by group");
+  const int K = C * kh * kw, P = OH * OW, Kg = K / G, Mg = M / G;
   const bool pointwise = kh == 1 && kw == 1 && geom_.stride == vector<int>{1, 1} &&
                          geom_.pads == vector<int>{0, 0, 0, 0};
   const bool want_dx = OutputSize() == 3 || (no_bias_ && OutputSize() == 2);
@@ -206,13 +217,23 @@ bool ConvGradientOp<float, HIPContext>::RunDefaultEngine() {
       col = cb;
     }
     // dfilter[M][K] (+)= dY[n][M][P] . col[K][P]^T
-    GemmRowMajor(s, false, true, M, K, P, 1.0f, dyn, P, col, P, n == 0 ? 0.0f : 1.0f,
-                 dfilter->mutable_data<float>(), K);
+    if (G == 1)
+      GemmRowMajor(s, false, true, M, K, P, 1.0f, dyn, P, col, P, n == 0 ? 0.0f : 1.0f,
+                   dfilter->mutable_data<float>(), K);
+    else   // per group: dfilter[g][Mg][Kg] (+)= dY[n][g][Mg][P] . col[g][Kg][P]^T
+      GemmRowMajorStridedBatched(s, false, true, Mg, Kg, P, 1.0f, dyn, P, (long long)Mg * P, col, P,
+                                 (long long)Kg * P, n == 0 ? 0.0f : 1.0f,
+                                 dfilter->mutable_data<float>(), Kg, (long long)Mg * Kg, G);
     if (dX) {
       float* dxn = dX->mutable_data<float>() + (size_t)n * C * H * W;
       float* dcol = pointwise ? dxn : col_buffer_.mutable_data<float>();
       // dcol[K][P] = filter[M][K]^T . dY[n][M][P]
-      GemmRowMajor(s, true, false, K, P, M, 1.0f, filter.data<float>(), K, dyn, P, 0.0f, dcol, P);
+      if (G == 1)
+        GemmRowMajor(s, true, false, K, P, M, 1.0f, filter.data<float>(), K, dyn, P, 0.0f, dcol, P);
+      else   // per group: dcol[g][Kg][P] = filter[g][Mg][Kg]^T . dY[n][g][Mg][P]
+        GemmRowMajorStridedBatched(s, true, false, Kg, P, Mg, 1.0f, filter.data<float>(), Kg,
+                                   (long long)Mg * Kg, dyn, P, (long long)Mg * P, 0.0f, dcol, P,
+                                   (long long)Kg * P, G);
       if (!pointwise)
         CAFFE_ENFORCE_EQ(ssad_col2im(dcol, C, H, W, kh, kw, geom_.dilation[0], geom_.dilation[1],
                                      geom_.pads[0], geom_.pads[1], geom_.pads[2], geom_.pads[3],

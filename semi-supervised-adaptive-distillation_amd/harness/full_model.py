@@ -208,31 +208,42 @@ def conv_frozen_bn(cin, cout, k, stride=1, padding=0):
 
 
 class Bottleneck(nn.Module):
-    def __init__(self, cin, cmid, cout, stride):
+    """ResNet.py:223-283.  groups > 1 with stride_1x1=False is the ResNeXt block
+    (RESNETS.NUM_GROUPS / STRIDE_1X1 of retinanet_X-101-64x4d-FPN_1x_teacher.yaml:19-24):
+    the grouped 3x3 carries the stride and runs on MIOpen."""
+
+    def __init__(self, cin, cmid, cout, stride, groups=1, stride_1x1=True):
         super().__init__()
-        self.c1 = conv_frozen_bn(cin, cmid, 1, stride=stride)
-        self.hip2 = _HIP3X3 and cmid >= _HIP3X3_MIN
-        self.c2 = HipConv3x3(cmid, cmid, relu=True) if self.hip2 else conv_frozen_bn(cmid, cmid, 3, padding=1)
+        s1, s3 = (stride, 1) if stride_1x1 else (1, stride)
+        self.c1 = conv_frozen_bn(cin, cmid, 1, stride=s1)
+        self.hip2 = _HIP3X3 and cmid >= _HIP3X3_MIN and groups == 1 and s3 == 1
+        if self.hip2:
+            self.c2 = HipConv3x3(cmid, cmid, relu=True)
+        else:
+            self.c2 = nn.Conv2d(cmid, cmid, 3, stride=s3, padding=1, groups=groups, bias=True)
         self.c3 = conv_frozen_bn(cmid, cout, 1)
         self.proj = conv_frozen_bn(cin, cout, 1, stride=stride) if (cin != cout or stride != 1) else None
 
     def forward(self, x):
         if _FUSE_TAIL and x.is_contiguous():
-            if self.c1.stride != (1, 1):
+            xs = x
+            if self.proj is not None and self.proj.stride != (1, 1):
                 # a strided pointwise convolution is the pointwise convolution of the
                 # subsampled map; c1 and the projection share the one gather
-                x = x[:, :, ::self.c1.stride[0], ::self.c1.stride[1]].contiguous()
+                xs = x[:, :, ::self.proj.stride[0], ::self.proj.stride[1]].contiguous()
+            if self.c1.stride != (1, 1):
+                x = xs
             b3 = self.c3.bias
             if self.proj is None:
                 sc = x
             else:
                 # the projection's bias rides along with c3's in the block's last pass
-                sc = conv1x1(x, self.proj.weight)
+                sc = conv1x1(xs, self.proj.weight)
                 b3 = b3 + self.proj.bias
             # convolution without bias, then bias (+ residual) + ReLU in one pass
             y = bias_act(conv1x1(x, self.c1.weight), self.c1.bias)
             y = self.c2(y) if self.hip2 else bias_act(
-                F.conv2d(y, self.c2.weight, None, 1, 1), self.c2.bias)
+                F.conv2d(y, self.c2.weight, None, self.c2.stride, 1, 1, self.c2.groups), self.c2.bias)
             return bias_act(conv1x1(y, self.c3.weight), b3, residual=sc)
         sc = x if self.proj is None else self.proj(x)
         y = F.relu(self.c1(x), inplace=True)
@@ -241,18 +252,27 @@ class Bottleneck(nn.Module):
         return F.relu(y.add_(sc), inplace=True)
 
 
+ARCHS = {   # name -> (block counts, groups, width per group, stride on the 1x1)
+    "r50": ((3, 4, 6, 3), 1, 64, True),
+    "r101": ((3, 4, 23, 3), 1, 64, True),
+    "x101-64x4d": ((3, 4, 23, 3), 64, 4, False),
+}
+
+
 class ResNetFPN(nn.Module):
     def __init__(self, depth=50, fpn_dim=256):
         super().__init__()
-        blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[depth]
+        arch = depth if isinstance(depth, str) else "r%d" % depth
+        blocks, groups, width, stride_1x1 = ARCHS[arch]
         self.stem = nn.Sequential(conv_frozen_bn(3, 64, 7, stride=2, padding=3),
                                   nn.ReLU(inplace=True), nn.MaxPool2d(3, stride=2, padding=1))
         stages, cin = [], 64
         for i, n in enumerate(blocks):
-            cmid, cout = 64 * 2 ** i, 256 * 2 ** i
+            cmid, cout = groups * width * 2 ** i, 256 * 2 ** i
             layers = []
             for j in range(n):
-                layers.append(Bottleneck(cin, cmid, cout, 2 if (j == 0 and i > 0) else 1))
+                layers.append(Bottleneck(cin, cmid, cout, 2 if (j == 0 and i > 0) else 1,
+                                         groups=groups, stride_1x1=stride_1x1))
                 cin = cout
             stages.append(nn.Sequential(*layers))
         self.res2, self.res3, self.res4, self.res5 = stages

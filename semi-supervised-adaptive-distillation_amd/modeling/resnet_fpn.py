@@ -25,6 +25,8 @@ class BodyConfig:
     block_counts: tuple = (3, 4, 6, 3)        # ResNet-50; ResNet-101: (3, 4, 23, 3)
     freeze_at: int = 2                        # TRAIN.FREEZE_AT
     stride_1x1: bool = True                   # RESNETS.STRIDE_1X1
+    num_groups: int = 1                       # RESNETS.NUM_GROUPS (ResNeXt: 64)
+    width_per_group: int = 64                 # RESNETS.WIDTH_PER_GROUP (ResNeXt-101-64x4d: 4)
     fpn_dim: int = 256                        # FPN.DIM
     k_min: int = 3                            # FPN.RPN_MIN_LEVEL
     k_max: int = 7                            # FPN.RPN_MAX_LEVEL
@@ -48,13 +50,16 @@ class BodyModel:
         return kw
 
     def Conv(self, blob_in, blob_out, dim_in, dim_out, kernel, weight_init=None, bias_init=None,
-             no_bias=0, **kw):
-        """CNNModelHelper.Conv (caffe2/python/helpers/conv.py:28-149)."""
+             no_bias=0, group=1, **kw):
+        """CNNModelHelper.Conv (caffe2/python/helpers/conv.py:28-149): the filter of a grouped
+        convolution is [dim_out, dim_in / group, k, k]; `group` is an argument only when != 1."""
         kw = self._engine(kw)
         if self.cfg.use_cudnn_engine:
             kw["exhaustive_search"] = False
+        if group != 1:
+            kw["group"] = group
         w = blob_out + "_w"
-        self.params.append((w, [dim_out, dim_in, kernel, kernel], weight_init or XAVIER))
+        self.params.append((w, [dim_out, dim_in // group, kernel, kernel], weight_init or XAVIER))
         ins = [blob_in, w]
         if not no_bias:
             b = blob_out + "_b"
@@ -117,7 +122,7 @@ def add_residual_block(model, prefix, blob_in, dim_in, dim_out, dim_inner, dilat
     """ResNet.py:158-197."""
     stride = stride_init if (dim_in != dim_out and dim_in != 64 and dilation == 1) else 1
     tr = bottleneck_transformation(model, blob_in, dim_in, dim_out, stride, prefix, dim_inner,
-                                   group=1, dilation=dilation)
+                                   group=model.cfg.num_groups, dilation=dilation)
     sc = add_shortcut(model, prefix, blob_in, dim_in, dim_out, stride)
     s = model.net.Sum([tr, sc], tr if inplace_sum else prefix + "_sum")
     return model.Relu(s, s)
@@ -139,7 +144,7 @@ def add_resnet_conv5_body(model):
     p = model.AffineChannel(p, "res_conv1_bn", dim=64, inplace=True)
     p = model.Relu(p, p)
     p = model.MaxPool(p, "pool1", kernel=3, pad=1, stride=2)
-    dim_in, dim_bottleneck = 64, 64
+    dim_in, dim_bottleneck = 64, cfg.num_groups * cfg.width_per_group      # ResNet.py:99
     n1, n2, n3, n4 = cfg.block_counts
     stage_out = {}
     s, dim_in = add_stage(model, "res2", p, n1, dim_in, 256, dim_bottleneck, 1)

@@ -9,7 +9,7 @@ the stubs of make_head_graph.py).  The recording model restates what
 CNNModelHelper.Conv / MaxPool (caffe2/python/helpers/{conv,pooling}.py with
 use_cudnn=True, order=NCHW) and DetectionModelHelper.AffineChannel / ConvAffine
 (detectron/lib/modeling/detector.py:83-107, 559-587) hand to the net.
-Output: tests/golden/backbone_graph_r50_fpn.json (data only).
+Output: tests/golden/backbone_graph_{r50,x101_64x4d}_fpn.json (data only).
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_backbone_graph.py
 """
@@ -22,16 +22,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import make_head_graph as mh  # noqa: E402
 
-OUT = os.path.join(HERE, "backbone_graph_r50_fpn.json")
 
 
 class RecBackboneModel(mh.RecModel):
     def Conv(self, blob_in, blob_out, dim_in, dim_out, kernel, weight_init=None, bias_init=None,
-             no_bias=0, **kwargs):
+             no_bias=0, group=1, **kwargs):
         kwargs = self._cudnn_kwargs(kwargs)
+        if group != 1:                                                   # helpers/conv.py:124-125
+            kwargs["group"] = group
         w = self.net._scoped(blob_out + "_w")
-        winit = weight_init if weight_init else ("XavierFill", {})       # helpers/conv.py:60-75
-        self.params.append({"name": w, "shape": [dim_out, dim_in, kernel, kernel],
+        winit = weight_init if weight_init else ("XavierFill", {})       # helpers/conv.py:83-93
+        self.params.append({"name": w, "shape": [dim_out, int(dim_in / group), kernel, kernel],
                             "init": [winit[0], mh.plain(winit[1])]})
         ins = [blob_in, w]
         if not no_bias:
@@ -82,12 +83,26 @@ def install_backbone_stubs():
     sys.modules["modeling.generate_anchors"] = ga
 
 
+CASES = {
+    # output file -> (yaml the settings come from, body builder, RESNETS overrides)
+    "backbone_graph_r50_fpn.json": (
+        "configs/focal_distillation/retinanet_R-50-FPN_distillation.yaml (body)",
+        "add_fpn_ResNet50_conv5_body", {}),
+    # the ResNeXt teacher (yaml :3,:19-24): stride on the 3x3, 64 groups of width 4
+    "backbone_graph_x101_64x4d_fpn.json": (
+        "configs/focal_distillation/retinanet_X-101-64x4d-FPN_1x_teacher.yaml (body)",
+        "add_fpn_ResNet101_conv5_body",
+        {"STRIDE_1X1": False, "NUM_GROUPS": 64, "WIDTH_PER_GROUP": 4}),
+}
+
+
 def main():
     mh.install_stubs()
     sys.path.insert(0, mh.REF)
     install_backbone_stubs()
     from core.config import cfg
     import modeling.FPN as FPN
+    from collections import Counter
 
     cfg.FPN.FPN_ON = True
     cfg.FPN.MULTILEVEL_RPN = True
@@ -97,22 +112,26 @@ def main():
     cfg.RETINANET.RETINANET_ON = True
     # the py2 config stores names as bytes; under py3 the lookup key must be text
     cfg.RESNETS.TRANS_FUNC = "bottleneck_transformation"
+    defaults = {k: getattr(cfg.RESNETS, k) for k in ("STRIDE_1X1", "NUM_GROUPS", "WIDTH_PER_GROUP")}
 
-    model = RecBackboneModel(train=True)
-    blobs, dim, scales = FPN.add_fpn_ResNet50_conv5_body(model)
-    from collections import Counter
-    out = {
-        "config": "configs/focal_distillation/retinanet_R-50-FPN_distillation.yaml (body)",
-        "ops": model.ops,
-        "params": model.params,
-        "fpn_blobs": [str(b) for b in blobs],
-        "fpn_dim": int(dim),
-        "spatial_scales": [float(s) for s in scales],
-        "op_histogram": dict(Counter(o["type"] for o in model.ops)),
-    }
-    with open(OUT, "w") as f:
-        json.dump(out, f, indent=1, sort_keys=True)
-    print(out["op_histogram"], len(model.params), out["fpn_blobs"], out["spatial_scales"])
+    for fname, (config, builder, overrides) in CASES.items():
+        for k, v in defaults.items():
+            setattr(cfg.RESNETS, k, overrides.get(k, v))
+        model = RecBackboneModel(train=True)
+        blobs, dim, scales = getattr(FPN, builder)(model)
+        out = {
+            "config": config,
+            "resnets": {k: getattr(cfg.RESNETS, k) for k in defaults},
+            "ops": model.ops,
+            "params": model.params,
+            "fpn_blobs": [str(b) for b in blobs],
+            "fpn_dim": int(dim),
+            "spatial_scales": [float(s) for s in scales],
+            "op_histogram": dict(Counter(o["type"] for o in model.ops)),
+        }
+        with open(os.path.join(HERE, fname), "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+        print(fname, out["op_histogram"], len(model.params), out["fpn_blobs"], out["spatial_scales"])
 
 
 if __name__ == "__main__":

@@ -242,14 +242,21 @@ def test_full_backward_graph_with_supervised_losses(lib):
     assert grad_map["fpn_7"] == "fpn_7_grad"
 
 
-def test_backbone_graph_matches_reference_capture():
+@pytest.mark.parametrize("capture,cfg_kw", [
+    ("backbone_graph_r50_fpn.json", {}),
+    # the ResNeXt-101-64x4d teacher body (configs/focal_distillation/
+    # retinanet_X-101-64x4d-FPN_1x_teacher.yaml:3,19-24)
+    ("backbone_graph_x101_64x4d_fpn.json",
+     dict(block_counts=(3, 4, 23, 3), stride_1x1=False, num_groups=64, width_per_group=4)),
+])
+def test_backbone_graph_matches_reference_capture(capture, cfg_kw):
     """modeling/resnet_fpn.py emits, op for op and parameter for parameter, what the
     reference's ResNet.py / FPN.py builders emit (capture: tests/golden/make_backbone_graph.py)."""
     import json
     import os
     from ssad_amd.modeling import resnet_fpn as rf
-    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "backbone_graph_r50_fpn.json")))
-    model = rf.BodyModel(rf.BodyConfig())
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", capture)))
+    model = rf.BodyModel(rf.BodyConfig(**cfg_kw))
     blobs, dim, scales = rf.add_fpn_resnet_conv5_body(model)
     assert [str(b) for b in blobs] == g["fpn_blobs"] and dim == g["fpn_dim"]
     assert scales == g["spatial_scales"]

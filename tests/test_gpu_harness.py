@@ -110,13 +110,15 @@ def test_conv1x1_gemm_weight_gradient_matches_torch(fm):
     assert _rel(wh.grad, wr.grad) < 1e-5
 
 
-@pytest.mark.parametrize("cin,cmid,cout,stride", [(64, 64, 256, 1), (256, 64, 256, 1), (256, 128, 512, 2)])
-def test_bottleneck_fused_route_matches_plain_torch(fm, monkeypatch, cin, cmid, cout, stride):
+@pytest.mark.parametrize("cin,cmid,cout,stride,groups", [
+    (64, 64, 256, 1, 1), (256, 64, 256, 1, 1), (256, 128, 512, 2, 1),
+    (64, 256, 256, 1, 64), (256, 512, 512, 2, 64)])         # ResNeXt-101-64x4d res2 / res3 entry
+def test_bottleneck_fused_route_matches_plain_torch(fm, monkeypatch, cin, cmid, cout, stride, groups):
     """The block as the harness runs it (GEMM 1x1s, HIP 3x3, bias/residual/ReLU tails,
     projection bias merged into the last pass) against the plain nn.Conv2d + F.relu
     route over the same parameters: output and every parameter / input gradient."""
     torch.manual_seed(5)
-    blk = fm.Bottleneck(cin, cmid, cout, stride).cuda()
+    blk = fm.Bottleneck(cin, cmid, cout, stride, groups=groups, stride_1x1=groups == 1).cuda()
     with torch.no_grad():
         for p in blk.parameters():
             p.copy_(torch.randn_like(p) * (0.05 if p.dim() == 4 else 0.5))
@@ -168,12 +170,13 @@ def test_strided_3x3_gemm_route_matches_torch(fm):
         assert _rel(a, c) < 1e-5
 
 
-def test_body_fused_route_matches_plain_torch(fm, monkeypatch):
+@pytest.mark.parametrize("arch", [50, "x101-64x4d"])
+def test_body_fused_route_matches_plain_torch(fm, monkeypatch, arch):
     """The whole ResNet-50-FPN body as the harness runs it against the plain
     nn.Conv2d / F.relu / max_pool2d route over the same parameters, at 64x96:
     the five pyramid levels and the gradients of every trainable parameter."""
     torch.manual_seed(9)
-    net = fm.ResNetFPN(50).cuda()
+    net = fm.ResNetFPN(arch).cuda()
     x = torch.randn(2, 3, 64, 96, device="cuda")
     dys = None
 
@@ -193,5 +196,8 @@ def test_body_fused_route_matches_plain_torch(fm, monkeypatch):
     for a, b in zip(o1, o0):
         assert _rel(a, b) < 5e-5
     assert set(g1) == set(g0) and len(g0) >= 100
+    # fp32 round-off of two summation orders compounds over the depth of the backward
+    # pass (16 blocks / 33 blocks)
+    tol = 2e-4 if arch == 50 else 1e-3
     for n in g0:
-        assert _rel(g1[n], g0[n]) < 2e-4, n
+        assert _rel(g1[n], g0[n]) < tol, n

@@ -145,6 +145,47 @@ def test_default_engine_conv_and_gradient(geo):
     close(workspace.FetchBlob("X_grad"), rdX, CONV_RTOL, CONV_FLOOR, "dX")
 
 
+@pytest.mark.parametrize("geo", [
+    dict(kernel=3, stride=1, pad=1, cin=16, cout=24, group=4, hw=(9, 12)),    # ResNeXt 3x3
+    dict(kernel=3, stride=2, pad=1, cin=32, cout=32, group=8, hw=(12, 10)),   # ... carrying the stride
+    dict(kernel=1, stride=1, pad=0, cin=12, cout=18, group=3, hw=(7, 9)),     # grouped pointwise
+    dict(kernel=3, stride=1, pad=1, cin=8, cout=8, group=8, hw=(6, 6))],      # depthwise
+    ids=lambda g: "k%ds%dg%d" % (g["kernel"], g["stride"], g["group"]))
+def test_default_engine_grouped_conv_and_gradient(geo):
+    """`group` > 1 (conv_op_impl.h:93-98,126-173 and :451-500): the default engine runs the
+    groups as one strided-batched GEMM per image; reference = torch's grouped conv2d on the CPU."""
+    rng = np.random.default_rng(61 + geo["group"])
+    N, Cin, M, G = 2, geo["cin"], geo["cout"], geo["group"]
+    H, W = geo["hw"]
+    k, st, pd = geo["kernel"], geo["stride"], geo["pad"]
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin // G, k, k)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    xt, wt, bt = (torch.tensor(v, requires_grad=True) for v in (X, Wt, b))
+    yt = torch.nn.functional.conv2d(xt, wt, bt, st, pd, 1, G)
+    dY = rng.standard_normal(tuple(yt.shape)).astype(np.float32)
+    yt.backward(torch.tensor(dY))
+    feed("X", X); feed("w", Wt); feed("b", b); feed("Y_grad", dY)
+    with core.DeviceScope(GPU):
+        conv = core.CreateOperator("Conv", ["X", "w", "b"], ["Y"], kernel=k, pad=pd, stride=st,
+                                   group=G, order="NCHW", engine="CUDNN")
+    workspace.RunOperatorOnce(conv)
+    close(workspace.FetchBlob("Y"), yt.detach().numpy(), CONV_RTOL, CONV_FLOOR, "grouped Conv")
+    g, gi = core.GradientRegistry.GetGradientForOp(conv, ["Y_grad"])
+    workspace.RunOperatorsOnce(g)
+    close(workspace.FetchBlob("w_grad"), wt.grad.numpy(), CONV_RTOL, CONV_FLOOR, "dW")
+    close(workspace.FetchBlob("b_grad"), bt.grad.numpy(), CONV_RTOL, CONV_FLOOR, "db")
+    close(workspace.FetchBlob("X_grad"), xt.grad.numpy(), CONV_RTOL, CONV_FLOOR, "dX")
+    # channel counts that do not divide are refused like the reference does
+    feed("wbad", np.zeros((M + 1, Cin // G, k, k), np.float32))
+    with core.DeviceScope(GPU):
+        bad = core.CreateOperator("Conv", ["X", "wbad"], ["Ybad"], kernel=k, pad=pd, stride=st,
+                                  group=G, order="NCHW")
+    if (M + 1) % G:
+        with pytest.raises(Exception, match="divisible by group"):
+            workspace.RunOperatorOnce(bad)
+
+
 def test_max_pool_operator_and_gradient():
     """Stem pooling (kernel 3, stride 2, pad 1) against torch's max_pool2d (no ties in random data)."""
     rng = np.random.default_rng(43)
@@ -395,7 +436,8 @@ def _torch_run(ops, blobs):
         i = [blobs[n] for n in op.input]
         if op.type == "Conv":
             y = F.conv2d(i[0], i[1], i[2] if len(i) > 2 else None, stride=a.get("stride", 1),
-                         padding=a.get("pad", 0), dilation=a.get("dilation", 1))
+                         padding=a.get("pad", 0), dilation=a.get("dilation", 1),
+                         groups=a.get("group", 1))
         elif op.type == "AffineChannel":
             y = i[0] * i[1].view(1, -1, 1, 1) + i[2].view(1, -1, 1, 1)
         elif op.type == "Relu":
@@ -414,14 +456,20 @@ def _torch_run(ops, blobs):
     return blobs
 
 
-def test_resnet_fpn_body_graph_through_workspace_vs_torch():
+@pytest.mark.parametrize("cfg_kw", [
+    dict(),
+    # ResNeXt style (the X-101-64x4d teacher's settings at a quarter of the groups):
+    # grouped 3x3 convolutions carrying the stride, on the default engine
+    dict(stride_1x1=False, num_groups=16, width_per_group=4)], ids=["resnet", "resnext"])
+def test_resnet_fpn_body_graph_through_workspace_vs_torch(cfg_kw):
     """The reference-identical ResNet-FPN body graph (modeling/resnet_fpn.py, one block per
     stage to keep it small) forward and backward through the HIP operator surface -- 3x3/s1
-    convs on the matrix-core engine, 1x1 / 7x7 / strided on the default engine, AffineChannel,
-    MaxPool, UpsampleNearest, Sum, StopGradient, autograd Sum accumulation -- against torch."""
+    convs on the matrix-core engine, 1x1 / 7x7 / strided / grouped on the default engine,
+    AffineChannel, MaxPool, UpsampleNearest, Sum, StopGradient, autograd Sum accumulation --
+    against torch."""
     from ssad_amd.modeling import resnet_fpn as rf
     rng = np.random.default_rng(53)
-    model = rf.BodyModel(rf.BodyConfig(block_counts=(1, 1, 1, 1)))
+    model = rf.BodyModel(rf.BodyConfig(block_counts=(1, 1, 1, 1), **cfg_kw))
     with core.DeviceScope(GPU):
         fpn_blobs, dim, _ = rf.add_fpn_resnet_conv5_body(model)
     fwd_ops = list(model.net.Proto().op)
