@@ -59,6 +59,72 @@ class BucketedAllReduce(object):
             dist.broadcast(t, src=src, group=self.pg)
 
 
+class GradBuckets(object):
+    """Flat gradient buckets for autograd-owned parameters (the backbone of the full
+    model): `groups` lists the parameters bucket by bucket in the order the backward pass
+    finishes them (FPN, res5, res4, res3 -- cf. SURVEY 8e "backbone 4-6 buckets").  A
+    post-accumulate hook counts a bucket down; the moment its last gradient exists the
+    bucket is gathered into its slice of one flat buffer (one multi-tensor copy), its
+    all-reduce is started -- so the exchange of the late stages overlaps the backward pass
+    of the early ones -- and every .grad of the bucket is pointed at its view of the
+    reduced buffer for the optimizer.  Autograd itself writes fresh gradients (no
+    per-parameter accumulate kernels, no buffer clear)."""
+
+    def __init__(self, groups, dp):
+        self.dp = dp
+        self.groups = [list(g) for g in groups if len(g)]
+        first = self.groups[0][0]
+        n = sum(p.numel() for g in self.groups for p in g)
+        self.flat = torch.zeros(n, device=first.device, dtype=first.dtype)
+        self.slices, self.views, off = [], [], 0
+        for gi, g in enumerate(self.groups):
+            start, vs = off, []
+            for p in g:
+                vs.append(self.flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+                p.register_post_accumulate_grad_hook(self._hook(gi))
+            self.views.append(vs)
+            self.slices.append(self.flat[start:off])
+        self.sizes = [len(g) for g in self.groups]
+        self.begin()
+
+    def _hook(self, gi):
+        def ready(_param):
+            self._left[gi] -= 1
+            if self._left[gi] == 0:
+                self._exchange(gi)
+        return ready
+
+    def _exchange(self, gi):
+        if self._issued[gi]:
+            return
+        self._issued[gi] = True
+        with torch.no_grad():
+            have = [(v, p.grad) for v, p in zip(self.views[gi], self.groups[gi]) if p.grad is not None]
+            if len(have) < len(self.groups[gi]):
+                self.slices[gi].zero_()            # a parameter without gradient contributes 0
+            if have:
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            for v, p in zip(self.views[gi], self.groups[gi]):
+                p.grad = v
+        self.dp.issue(self.slices[gi])
+
+    def begin(self):
+        """Before backward: drop last step's gradients so autograd assigns, not accumulates."""
+        for g in self.groups:
+            for p in g:
+                p.grad = None
+        self._left = list(self.sizes)
+        self._issued = [False] * len(self.sizes)
+
+    def finish(self):
+        """After backward: exchange whatever a hook did not (a bucket with a parameter that
+        received no gradient this step), then wait for all of them."""
+        for gi in range(len(self.groups)):
+            self._exchange(gi)
+        self.dp.wait()
+
+
 def shard_images(global_batch, rank, world_size):
     """Contiguous image shard of a global batch: independent units = images."""
     per = global_batch // world_size

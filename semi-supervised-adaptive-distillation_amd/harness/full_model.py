@@ -361,13 +361,17 @@ class FullDistillModel(object):
             import torch.distributed as dist
             for p in self.student.parameters():
                 dist.broadcast(p.data, src=0, group=self.pg)
-            # one flat gradient bucket for the backbone: few, large all-reduces
-            n = sum(p.numel() for p in self.trainable)
-            self.flat_grad = torch.zeros(n, device=device)
-            off = 0
-            for p in self.trainable:
-                p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
-                off += p.numel()
+            # flat gradient buckets in backward-completion order (FPN, res5, res4, res3):
+            # few, large all-reduces, each started by the hook of its last gradient
+            from ..data_parallel import BucketedAllReduce, GradBuckets
+            st = self.student
+            fpn = list(st.lat.parameters()) + list(st.out.parameters()) + \
+                list(st.p6.parameters()) + list(st.p7.parameters())
+            groups = [[p for p in g if p.requires_grad] for g in
+                      (fpn, st.res5.parameters(), st.res4.parameters(), st.res3.parameters(),
+                       st.res2.parameters(), st.stem.parameters())]
+            assert sum(len(g) for g in groups) == len(self.trainable)
+            self.buckets = GradBuckets(groups, BucketedAllReduce(self.pg, world_size))
 
     def _mark(self, name):
         if self._timing is not None:
@@ -422,14 +426,13 @@ class FullDistillModel(object):
                 g = g.contiguous(memory_format=torch.channels_last)
             grads.append(g)
         if self.dist_on:
-            self.flat_grad.zero_()
+            self.buckets.begin()
         else:
             self.opt.zero_grad(set_to_none=True)
         torch.autograd.backward(s_fpn, grads)
         self._mark("student backbone bwd")
         if self.dist_on:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+            self.buckets.finish()
         h.sgd_step()
         self.opt.step()
         self._mark("all-reduce + SGD")

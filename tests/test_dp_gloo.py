@@ -81,3 +81,78 @@ def test_image_sharding():
     assert [shard_images(128, r, 8) for r in (0, 7)] == [(0, 16), (112, 128)]
     with pytest.raises(AssertionError):
         shard_images(10, 0, 4)
+
+
+def _bucket_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssad_amd.data_parallel import GradBuckets
+    torch.manual_seed(3)                                   # same replica on every rank
+    stages = [torch.nn.Sequential(torch.nn.Linear(6, 6), torch.nn.Tanh()) for _ in range(4)]
+    unused = torch.nn.Linear(3, 3)                         # a bucket no gradient ever reaches
+    order = []
+
+    class Spy(BucketedAllReduce):
+        def issue(self, bucket):
+            order.append(int(bucket.numel()) * 1000 + int(bucket.data_ptr() % 997))
+            return super().issue(bucket)
+
+    dp = Spy(dist.group.WORLD, world)
+    # backward finishes the LAST stage first
+    groups = [list(s.parameters()) for s in reversed(stages)] + [list(unused.parameters())]
+    gb = GradBuckets(groups, dp)
+    out = {}
+    for step in range(2):                                  # hooks must re-arm every step
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(10 * step + rank))
+        gb.begin()
+        issued_before = len(order)
+        y = x
+        for s in stages:
+            y = s(y)
+        y.square().sum().backward()
+        issued_in_backward = len(order) - issued_before
+        gb.finish()
+        assert issued_in_backward == 4                     # one per stage, from the hooks
+        assert len(order) - issued_before == 5             # + the unused bucket, in finish()
+        out["flat%d" % step] = gb.flat.clone().numpy()
+        # the rank-local gradient of the same step, for the sum check
+        loc = []
+        for g in groups[:-1]:
+            for p in g:
+                loc.append(torch.autograd.grad(
+                    _replay(stages, x), p, retain_graph=False)[0].reshape(-1))
+        out["local%d" % step] = torch.cat(loc).numpy()
+    for s in stages:                                       # .grad stayed a view of the flat buffer
+        for p in s.parameters():
+            assert p.grad.data_ptr() >= gb.flat.data_ptr()
+            assert p.grad.data_ptr() < gb.flat.data_ptr() + gb.flat.numel() * 4
+    np.savez(os.path.join(outdir, "b%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _replay(stages, x):
+    y = x
+    for s in stages:
+        y = s(y)
+    return y.square().sum()
+
+
+def test_two_rank_hook_driven_gradient_buckets():
+    """GradBuckets (the backbone's exchange in the full model): every bucket's all-reduce is
+    started by the hook of its last gradient during backward, buckets re-arm each step, a
+    bucket without gradients is still exchanged, and both ranks end with the bitwise
+    identical sum of the rank-local gradients."""
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_bucket_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        r = [np.load(os.path.join(d, "b%d.npz" % i)) for i in range(world)]
+    for step in range(2):
+        k = "flat%d" % step
+        assert np.array_equal(r[0][k], r[1][k])
+        n = r[0]["local%d" % step].size
+        want = r[0]["local%d" % step] + r[1]["local%d" % step]
+        assert np.allclose(r[0][k][:n], want, rtol=1e-6, atol=1e-7)
+        assert np.all(r[0][k][n:] == 0) and np.any(want != 0)
+    assert not np.array_equal(r[0]["flat0"], r[0]["flat1"])
