@@ -348,6 +348,31 @@ SSAD_API int ssad_retinanet_detect(
     int* count_out, void* workspace, size_t workspace_bytes, ssad_stream_t stream);
 
 /* ---------------------------------------------------------------------- */
+/* fp16 storage / fp32 accumulation (BASELINE config 5's precision)        */
+/* ---------------------------------------------------------------------- */
+/* The reference's fp16 route is CudnnConvOp<float16> with fp32 math
+ * (caffe2/operators/conv_op_cudnn.cc:631-636).  Activations between the subnet layers
+ * are channel-blocked fp16, Xb[n][ceil(C/8)][H][W][8] (a tail block is zero padded), so
+ * one 16-byte load is a v_mfma_f32_32x32x16_f16 operand for every filter tap. */
+SSAD_API int ssad_f16_pack_activations(const float* x_nchw, int N, int C, int H, int W,
+                                       void* x_blocked, ssad_stream_t stream);
+SSAD_API int ssad_f16_unpack_activations(const void* x_blocked, int N, int C, int H, int W,
+                                         float* x_nchw, ssad_stream_t stream);
+/* halves to allocate for either packed form of an [M][C][3][3] filter */
+SSAD_API size_t ssad_f16_filter_halves(int M, int C);
+/* w [M][C][3][3] fp32 -> packed_fwd [9][ceil(C/8)][M][8] and / or packed_dgrad
+ * [9][ceil(M/8)][C][8] (flipped taps, roles of M and C exchanged); either may be NULL */
+SSAD_API int ssad_f16_pack_filter(const float* w, int M, int C, void* packed_fwd,
+                                  void* packed_dgrad, ssad_stream_t stream);
+#define SSAD_F16_OUT_NCHW_F32 16   /* prediction layers: write y as NCHW fp32 for the loss kernels */
+/* y = conv3x3(x_blocked, packed) (+ bias[M], fp32) (ReLU with SSAD_CONV_RELU); y is blocked
+ * fp16 [N][M/8][H][W][8] (M % 8 == 0) or, with SSAD_F16_OUT_NCHW_F32, float [N][M][H][W].
+ * Data gradient: the same call with packed_dgrad, C and M exchanged, bias NULL. */
+SSAD_API int ssad_conv3x3_forward_f16(const void* x_blocked, const void* packed, const float* bias,
+                                      int N, int C, int H, int W, int M, int flags, void* y,
+                                      ssad_stream_t stream);
+
+/* ---------------------------------------------------------------------- */
 /* Introspection                                                           */
 /* ---------------------------------------------------------------------- */
 SSAD_API const char* ssad_kernels_arch(void);   /* "gfx950" */

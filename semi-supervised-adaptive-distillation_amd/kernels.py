@@ -93,6 +93,12 @@ def lib():
     L.ssad_upsample_nearest.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.ssad_upsample_nearest_grad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     L.ssad_max_pool3x3s2_bias_relu.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    L.ssad_f16_pack_activations.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    L.ssad_f16_unpack_activations.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    L.ssad_f16_filter_halves.restype = sz
+    L.ssad_f16_filter_halves.argtypes = [i32, i32]
+    L.ssad_f16_pack_filter.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.ssad_conv3x3_forward_f16.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_momentum_sgd_update.argtypes = [vp, vp, vp, vp, f32, f32, i32, i64, vp]
     L.ssad_conv_packed_filter_floats.restype = sz
     L.ssad_conv_packed_filter_floats.argtypes = [i32, i32]
@@ -494,3 +500,55 @@ def conv3x3_wgrad(xs, dys, Cout, *, want_db=True, accumulate=False, dW=None, db=
                                 Cin, int(accumulate), _ptr(ws), nb, _stream()),
            "conv3x3_wgrad")
     return dW, db
+
+
+# ---- fp16 storage / fp32 accumulation (config 5's precision) ---------------------------
+
+F16_OUT_NCHW_F32 = 16
+
+
+def f16_pack_activations(x):
+    """NCHW float32 -> channel-blocked float16 [N][ceil(C/8)][H][W][8] (zero padded tail)."""
+    _f32c(x, "x")
+    N, Cc, H, W = x.shape
+    xb = torch.empty((N, (Cc + 7) // 8, H, W, 8), dtype=torch.float16, device="cuda")
+    _check(lib().ssad_f16_pack_activations(_ptr(x), N, Cc, H, W, _ptr(xb), _stream()), "f16_pack_activations")
+    return xb
+
+
+def f16_unpack_activations(xb, channels):
+    """channel-blocked float16 -> NCHW float32 with `channels` channels."""
+    N, CB, H, W, _ = xb.shape
+    assert xb.dtype == torch.float16 and xb.is_contiguous() and CB == (channels + 7) // 8
+    x = torch.empty((N, channels, H, W), dtype=torch.float32, device="cuda")
+    _check(lib().ssad_f16_unpack_activations(_ptr(xb), N, channels, H, W, _ptr(x), _stream()),
+           "f16_unpack_activations")
+    return x
+
+
+def f16_pack_filter(w, fwd=True, dgrad=False):
+    """[M][C][3][3] float32 -> (packed_fwd, packed_dgrad) float16 (None when not asked for)."""
+    _f32c(w, "w")
+    M, Cc = w.shape[0], w.shape[1]
+    n = lib().ssad_f16_filter_halves(M, Cc)
+    wf = torch.empty(n, dtype=torch.float16, device="cuda") if fwd else None
+    wd = torch.empty(n, dtype=torch.float16, device="cuda") if dgrad else None
+    _check(lib().ssad_f16_pack_filter(_ptr(w), M, Cc, _ptr(wf), _ptr(wd), _stream()), "f16_pack_filter")
+    return wf, wd
+
+
+def conv3x3_forward_f16(xb, packed, bias, Cin, Cout, *, relu=False, out_nchw_f32=False):
+    """3x3 / stride 1 / pad 1 convolution of a channel-blocked fp16 tensor; fp32 accumulation.
+    Output: blocked fp16 [N][Cout/8][H][W][8], or NCHW float32 for the prediction layers."""
+    N, CB, H, W, _ = xb.shape
+    assert xb.dtype == torch.float16 and xb.is_contiguous() and CB == (Cin + 7) // 8
+    if out_nchw_f32:
+        y = torch.empty((N, Cout, H, W), dtype=torch.float32, device="cuda")
+    else:
+        y = torch.empty((N, Cout // 8, H, W, 8), dtype=torch.float16, device="cuda")
+    if bias is not None:
+        _f32c(bias, "bias")
+    flags = (CONV_RELU if relu else 0) | (F16_OUT_NCHW_F32 if out_nchw_f32 else 0)
+    _check(lib().ssad_conv3x3_forward_f16(_ptr(xb), _ptr(packed), _ptr(bias), N, Cin, H, W, Cout, flags,
+                                          _ptr(y), _stream()), "conv3x3_forward_f16")
+    return y

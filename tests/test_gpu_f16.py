@@ -1,0 +1,87 @@
+"""fp16 storage / fp32 accumulation subnet convolution (BASELINE config 5's precision)
+against the oracle's fp64 convolution of the SAME fp16-rounded operands: what is left is
+the fp32 accumulation order and the one rounding of a stored fp16 result."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    import ssad_amd  # noqa: F401
+    from ssad_amd import kernels
+    kernels.lib()
+    return kernels
+
+
+def _r16(a):
+    return a.astype(np.float16).astype(np.float64)
+
+
+def _conv64(x, w, b):
+    """float64 cross-correlation, 3x3 / pad 1 (oracle.conv_forward's definition)."""
+    N, C, H, W = x.shape
+    xp = np.zeros((N, C, H + 2, W + 2))
+    xp[:, :, 1:-1, 1:-1] = x
+    y = np.zeros((N, w.shape[0], H, W))
+    for ky in range(3):
+        for kx in range(3):
+            y += np.einsum("mc,nchw->nmhw", w[:, :, ky, kx], xp[:, :, ky:ky + H, kx:kx + W])
+    return y + (b.reshape(1, -1, 1, 1) if b is not None else 0.0)
+
+
+def test_blocked_layout_round_trip(K):
+    rng = np.random.default_rng(1)
+    for C in (8, 20, 36, 64):
+        x = rng.standard_normal((2, C, 5, 7)).astype(np.float32)
+        xb = K.f16_pack_activations(torch.from_numpy(x).cuda())
+        assert xb.shape == (2, (C + 7) // 8, 5, 7, 8)
+        host = xb.cpu().numpy()
+        want = np.zeros((2, (C + 7) // 8 * 8, 5, 7), np.float16)
+        want[:, :C] = x.astype(np.float16)
+        assert np.array_equal(host, want.reshape(2, -1, 8, 5, 7).transpose(0, 1, 3, 4, 2))
+        back = K.f16_unpack_activations(xb, C).cpu().numpy()
+        assert np.array_equal(back, x.astype(np.float16).astype(np.float32))
+
+
+@pytest.mark.parametrize("N,C,M,H,W,relu,nchw", [
+    (2, 32, 32, 16, 16, False, False),      # one chunk, one tile
+    (1, 64, 128, 20, 28, True, False),      # ragged tiles (P5 geometry), two chunks
+    (2, 256, 256, 10, 14, True, False),     # tower layer at P6
+    (1, 256, 720, 10, 14, False, True),     # cls_pred: 720 outputs, NCHW fp32 for the loss
+    (1, 256, 36, 5, 7, False, True),        # bbox_pred
+    (1, 48, 40, 9, 33, False, False),       # K tail of 16 channels, M tail inside a 128 block
+])
+def test_f16_forward_vs_float64(K, N, C, M, H, W, relu, nchw):
+    rng = np.random.default_rng(100 + C + M)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((M, C, 3, 3)) * (2.0 / (9 * C)) ** 0.5).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32) * 0.1
+    want = _conv64(_r16(x), _r16(w), b.astype(np.float64))
+    if relu:
+        want = np.maximum(want, 0.0)
+    xb = K.f16_pack_activations(torch.from_numpy(x).cuda())
+    wf, _ = K.f16_pack_filter(torch.from_numpy(w).cuda(), True, False)
+    y = K.conv3x3_forward_f16(xb, wf, torch.from_numpy(b).cuda(), C, M, relu=relu, out_nchw_f32=nchw)
+    got = (y if nchw else K.f16_unpack_activations(y, M)).cpu().numpy().astype(np.float64)
+    scale = np.abs(want).max()
+    tol = 2e-5 if nchw else 6e-4          # fp32 result / one fp16 rounding of the stored result
+    assert np.abs(got - want).max() <= tol * scale, np.abs(got - want).max() / scale
+
+
+def test_f16_data_gradient_is_the_adjoint(K):
+    """<conv(x), dy> == <x, dgrad(dy)> with both sides evaluated from the fp16-rounded
+    operands in float64 (the packed_dgrad filter is the flipped, transposed filter)."""
+    rng = np.random.default_rng(7)
+    N, C, M, H, W = 2, 64, 72, 12, 19          # M = 72: the data gradient's K has a 8-channel tail
+    w = (rng.standard_normal((M, C, 3, 3)) * 0.05).astype(np.float32)
+    dy = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    _, wd = K.f16_pack_filter(torch.from_numpy(w).cuda(), False, True)
+    dyb = K.f16_pack_activations(torch.from_numpy(dy).cuda())
+    dxb = K.conv3x3_forward_f16(dyb, wd, None, M, C)
+    dx = K.f16_unpack_activations(dxb, C).cpu().numpy().astype(np.float64)
+    wt = np.ascontiguousarray(_r16(w)[:, :, ::-1, ::-1].transpose(1, 0, 2, 3))
+    want = _conv64(_r16(dy), wt, None)
+    assert np.abs(dx - want).max() <= 6e-4 * np.abs(want).max()
