@@ -372,6 +372,15 @@ SSAD_API int ssad_conv3x3_forward_f16(const void* x_blocked, const void* packed,
                                       int N, int C, int H, int W, int M, int flags, void* y,
                                       ssad_stream_t stream);
 
+/* Filter and bias gradient from channel-blocked fp16 x [N][ceil(C/8)][H][W][8] and dy
+ * [N][ceil(M/8)][H][W][8] (conv_op_impl.h:451-510): dw [M][C][3][3] and db [M] in fp32,
+ * overwritten, or added to when accumulate != 0 (the five FPN levels share one filter:
+ * caffe2/python/core.py:706-741 sums their gradients).  db may be NULL.  Deterministic. */
+SSAD_API size_t ssad_conv3x3_wgrad_f16_workspace_bytes(int N, int C, int H, int W, int M);
+SSAD_API int ssad_conv3x3_wgrad_f16(const void* x_blocked, const void* dy_blocked, int N, int C, int H,
+                                    int W, int M, int accumulate, float* dw, float* db,
+                                    void* workspace, size_t workspace_bytes, ssad_stream_t stream);
+
 /* ---------------------------------------------------------------------- */
 /* Introspection                                                           */
 /* ---------------------------------------------------------------------- */

@@ -22,7 +22,9 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
+#include "conv_internal.h"
 #include "ssad_kernels.h"
 
 namespace {
@@ -53,7 +55,8 @@ __device__ __forceinline__ half8 as_half8(const uint4& v) {
   return __builtin_bit_cast(half8, v);
 }
 
-__global__ __launch_bounds__(kThreads) void conv3x3_f16_kernel(const F16Conv p) {
+template <int DBG>   // ablation switches for tools/f16_probe.py: 1 no halo fetch, 2 no filter reload, 4 no LDS reads
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Conv p) {
   __shared__ uint4 lds[2 * SLOTS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wo = wave & 1, wp = wave >> 1;
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(kThreads) void conv3x3_f16_kernel(const F16Conv p) 
   const long long plane = (long long)p.H * p.W;
 
   // ---- staging plan: slot s = tid + 256 i  ->  (block, row, col) of the halo tile
-  long long goff[NLD];
+  int goff[NLD];                           // 16-byte slots; the launcher checks the tensor fits 2^31
   bool gok[NLD];
   int gcb[NLD];
 #pragma unroll
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(kThreads) void conv3x3_f16_kernel(const F16Conv p) 
     gcb[i] = cbl;
     const int gy = y0 - 1 + r / HS, gx = x0 - 1 + r % HS;
     gok[i] = s < SLOTS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    goff[i] = ((long long)n * CB + cbl) * plane + (long long)gy * p.W + gx;
+    goff[i] = (int)(((long long)n * CB + cbl) * plane + (long long)gy * p.W + gx);
   }
   uint4 stage[NLD];
   auto fetch = [&](int chunk) {
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(kThreads) void conv3x3_f16_kernel(const F16Conv p) 
     for (int i = 0; i < NLD; ++i) {
       stage[i] = make_uint4(0u, 0u, 0u, 0u);
       if (gok[i] && chunk * CBC + gcb[i] < CB)        // beyond the last block: K padding = 0
-        stage[i] = p.x[goff[i] + (long long)chunk * CBC * plane];
+        stage[i] = p.x[goff[i] + chunk * CBC * (int)plane];
     }
   };
   auto stash = [&](int buf) {
@@ -126,37 +129,60 @@ __global__ __launch_bounds__(kThreads) void conv3x3_f16_kernel(const F16Conv p) 
       for (int r = 0; r < 16; ++r) acc[i][tt][r] = 0.0f;
 
   const int nchunks = (CB + CBC - 1) / CBC;
+  // Filter ring, AD = 9 K-steps deep: vector-memory results return in order, so a filter load
+  // issued behind the halo fetch (an HBM-latency load) is only needed 9 steps (> 2000 MFMA
+  // cycles) later; a one-step prefetch stalls every chunk for the whole fetch latency.
+  constexpr int AD = 3;
+  half8 ar[AD][2];
+#pragma unroll
+  for (int q = 0; q < AD; ++q) load_a(0, q, ar[q]);
   fetch(0);
   stash(0);
   __syncthreads();
-  half8 a_cur[2], a_nxt[2];
-  load_a(0, 0, a_cur);
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
-    if (more) fetch(c + 1);
     const uint4* tile = lds + (c & 1) * SLOTS;
-#pragma unroll
-    for (int q = 0; q < 18; ++q) {
+    half8 b[2][4];
+    auto read_b = [&](int q, half8 (&bb)[4]) {
       const int ks = q / 9, tap = q % 9, dy = tap / 3, dx = tap % 3;
-      if (q + 1 < 18) load_a(c, q + 1, a_nxt);
-      else if (more) load_a(c + 1, 0, a_nxt);
-      half8 b[4];
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
-        b[tt] = as_half8(tile[bbase + ((2 * ks) * HS + 2 * tt + dy) * HS + dx]);
+        bb[tt] = as_half8(tile[bbase + ((2 * ks) * HS + 2 * tt + dy) * HS + dx]);
+    };
+    read_b(0, b[0]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int q = 0; q < 18; ++q) {
+      if (q + 1 < 18 && !(DBG & 4)) read_b(q + 1, b[(q + 1) & 1]);
+      half8 a0 = ar[q % AD][0], a1 = ar[q % AD][1];
+      // refill this ring slot with the filter of step q + AD
+      if (!(DBG & 2)) {
+        if (q + AD < 18) load_a(c, q + AD, ar[q % AD]);
+        else if (more) load_a(c + 1, q + AD - 18, ar[q % AD]);
+      }
+      if (q == 0 && more && !(DBG & 1)) fetch(c + 1);      // behind the ring's loads of this step
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-          acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[i], b[tt], acc[i][tt], 0, 0, 0);
-      a_cur[0] = a_nxt[0];
-      a_cur[1] = a_nxt[1];
+      for (int tt = 0; tt < 4; ++tt) {
+        acc[0][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[q & 1][tt], acc[0][tt], 0, 0, 0);
+        acc[1][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[q & 1][tt], acc[1][tt], 0, 0, 0);
+      }
     }
     if (more) stash((c + 1) & 1);
     __syncthreads();
   }
 
-  // ---- epilogue: C/D row = (r & 3) + 8 (r >> 2) + 4 h, column = j
+  // ---- epilogue: C/D row = (r & 3) + 8 (r >> 2) + 4 h, column = j.
+  // All bias values first: a load issued between stores would wait (in-order vmcnt) for
+  // every store before it -- one HBM write latency per store.
+  float bv[2][4][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int oc = ocb + wo * 64 + i * 32 + 8 * g + 4 * h + e;
+        bv[i][g][e] = (p.bias && oc < p.M) ? p.bias[oc] : 0.0f;
+      }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int oc0 = ocb + wo * 64 + i * 32;
@@ -170,8 +196,7 @@ __global__ __launch_bounds__(kThreads) void conv3x3_f16_kernel(const F16Conv p) 
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = acc[i][tt][4 * g + e];
-          if (p.bias && oc + e < p.M) v[e] += p.bias[oc + e];
+          v[e] = acc[i][tt][4 * g + e] + bv[i][g][e];
           if (p.relu) v[e] = fmaxf(v[e], 0.0f);
         }
         if (p.out_nchw_f32) {
@@ -318,9 +343,293 @@ int ssad_conv3x3_forward_f16(const void* xb, const void* wp, const float* bias, 
   p.relu = (flags & SSAD_CONV_RELU) != 0;
   p.out_nchw_f32 = nchw;
   const long long tiles = (long long)N * p.tiles_x * p.tiles_y;
-  if (tiles >= (1LL << 31)) return SSAD_E_BADARG;
-  hipLaunchKernelGGL(conv3x3_f16_kernel, dim3((unsigned)tiles, (unsigned)((M + MT - 1) / MT)),
-                     dim3(kThreads), 0, (hipStream_t)stream, p);
+  if (tiles >= (1LL << 31) || (long long)N * ((C + 7) / 8 + CBC) * H * W >= (1LL << 31)) return SSAD_E_BADARG;
+  const dim3 grid((unsigned)tiles, (unsigned)((M + MT - 1) / MT));
+  static const int dbg = getenv("SSAD_F16_DBG") ? atoi(getenv("SSAD_F16_DBG")) : 0;
+  switch (dbg) {
+    case 1: hipLaunchKernelGGL(conv3x3_f16_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, p); break;
+    case 2: hipLaunchKernelGGL(conv3x3_f16_kernel<2>, grid, dim3(kThreads), 0, (hipStream_t)stream, p); break;
+    case 4: hipLaunchKernelGGL(conv3x3_f16_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, p); break;
+    case 7: hipLaunchKernelGGL(conv3x3_f16_kernel<7>, grid, dim3(kThreads), 0, (hipStream_t)stream, p); break;
+    default: hipLaunchKernelGGL(conv3x3_f16_kernel<0>, grid, dim3(kThreads), 0, (hipStream_t)stream, p);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"
+
+// =========================================================================================
+// Filter gradient, fp16 operands / fp32 accumulation (conv_op_impl.h:451-500 computes
+// dW = sum_n dY[n] . col[n]^T; here the same sums as GEMMs over PIXELS per filter tap):
+//     dW[m][c][ky][kx] = sum_{n,y,x} dY[n][m][y][x] * X[n][c][y + ky - 1][x + kx - 1].
+// Both MFMA operands need 8 consecutive K = pixels per lane while the blocked layout keeps
+// 8 CHANNELS contiguous -- exactly the case of gfx950's LDS transpose read: a 16-lane group
+// of ds_read_b64_tr_b16 turns a [4 pixels][16 channels] block (each lane addressing 4
+// contiguous channels of one pixel, any 8-byte-aligned address) into 4 pixels of one channel
+// per lane, and a tap's +-1 pixel shift is a whole slot, so every tap stays aligned.
+//
+// Workgroup = 4 waves, tile 128 output x 128 input channels x the 3 taps of one filter row
+// (blockIdx.z = ky); wave (wo, wc) owns 64 x 64 x 3 = 12 accumulator tiles (192 AGPRs: with
+// all nine taps a wave would need 18 tiles = 288 registers and hipcc shuttles the excess
+// between register files around every MFMA).  K runs over stages of 8 rows x 16 pixels; a
+// stage's dY tile and X tile (rows y + ky - 1, 18 of 20 columns used) land in LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds; no staging registers, no ds_write), double buffered.  LDS
+// image: two channel blocks interleaved per pixel, [block pair][row][pixel][2][8], pair pitch
+// skewed by 8 slots, which makes both 32-lane halves of a transpose read conflict free.
+// Per K-step (a row of 16 pixels): 4 + 12 transpose-read pairs feed 12 MFMAs.  The pixel
+// range is split over gridDim.y workgroups; partial sums go to a [split][tap][M][C] fp32
+// workspace that f16_wgrad_reduce_kernel folds (deterministically) into dW[M][C][3][3].
+constexpr int WR = 8;                        // rows per stage
+constexpr int WPX = 16;                      // pixels per row segment = one K-step
+constexpr int XPW = 20;                      // X tile columns: x0 - 1 .. x0 + 18 (18 used)
+constexpr int W_OT = 128, W_CT = 128;        // workgroup tile: output x input channels
+constexpr int X_PAIR = WR * XPW * 2;         // slots per X block pair (320 = 5 DMA pieces)
+constexpr int Y_PAIR = WR * WPX * 2;         // slots per dY block pair (256 = 4 DMA pieces)
+constexpr int X_PITCH = X_PAIR + 8;          // +8 slots = +32 banks between pairs
+constexpr int Y_PITCH = Y_PAIR + 8;
+constexpr int X_PAIRS = W_CT / 16, Y_PAIRS = W_OT / 16;
+constexpr int Y_BASE = X_PAIRS * X_PITCH;                // 2624
+constexpr int W_STAGE = Y_BASE + Y_PAIRS * Y_PITCH;      // 4736 slots = 74 KiB per stage
+constexpr int X_PIECES = X_PAIRS * (X_PAIR / 64);        // 40
+constexpr int Y_PIECES = Y_PAIRS * (Y_PAIR / 64);        // 32
+
+struct F16Wgrad {
+  const uint4* x;      // blocked fp16 [N][CB][H][W]
+  const uint4* dy;     // blocked fp16 [N][MB][H][W]
+  float* part;         // [split][9][M][C]
+  int N, C, H, W, M;
+  int seg_x, seg_y;    // row segments per row, row groups per image
+  int stages;          // N * seg_y * seg_x
+  int cblocks;         // ceil(C / 128)
+};
+
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+// 8 consecutive pixels of one channel: two transpose reads 4 pixels (8 slots) apart
+__device__ __forceinline__ half8 tr_pair(__attribute__((address_space(3))) short4v* p0, int off_slots) {
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0 + off_slots * 2);
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0 + (off_slots + 8) * 2);
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(half8, v);
+}
+
+__global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wgrad p) {
+  extern __shared__ uint4 lds[];                           // 2 stages
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wo = wave & 1, wc = wave >> 1;
+  const int ky = blockIdx.z;
+  const int ocb = (blockIdx.x / p.cblocks) * W_OT, ccb = (blockIdx.x % p.cblocks) * (W_CT / 8);
+  const int CB = (p.C + 7) >> 3, MB = (p.M + 7) >> 3;
+  const int plane = p.H * p.W;
+  // this workgroup's share of the pixel stages
+  const int per = (p.stages + gridDim.y - 1) / gridDim.y;
+  const int s0 = blockIdx.y * per, s1 = min(s0 + per, p.stages);
+
+  const __amdgpu_buffer_rsrc_t xrs = ssad_dev::uniform_rsrc(p.x, (unsigned)((long long)p.N * CB * plane * 16));
+  const __amdgpu_buffer_rsrc_t yrs = ssad_dev::uniform_rsrc(p.dy, (unsigned)((long long)p.N * MB * plane * 16));
+  constexpr unsigned kOob = 0x80000000u;
+  // lane's place inside a 64-slot DMA piece: slot = 2 * pixel + (block & 1)
+  const int lpix = lane >> 1, lodd = lane & 1;
+  auto fetch = [&](int s, int buf) {
+    int t = s;
+    const int sx = t % p.seg_x; t /= p.seg_x;
+    const int sy = t % p.seg_y;
+    const int n = t / p.seg_y;
+    const int y0 = sy * WR, x0 = sx * WPX;
+    auto* dst = (__attribute__((address_space(3))) uint4*)lds + buf * W_STAGE;
+#pragma unroll
+    for (int i = 0; i < X_PIECES / 4; ++i) {
+      const int piece = i * 4 + wave;                       // pair = piece / 5, 32 pixels each
+      const int pair = piece / (X_PAIR / 64), q = piece % (X_PAIR / 64);
+      const int pix = q * 32 + lpix;                        // row * 20 + column
+      const int gy = y0 + ky - 1 + pix / XPW, gx = x0 - 1 + pix % XPW;
+      const int cb = ccb + pair * 2 + lodd;
+      unsigned off = kOob;
+      if (cb < CB && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+        off = (unsigned)(((n * CB + cb) * plane + gy * p.W + gx) * 16);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          xrs, (__attribute__((address_space(3))) void*)(dst + pair * X_PITCH + q * 64), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < Y_PIECES / 4; ++i) {
+      const int piece = i * 4 + wave;
+      const int pair = piece / (Y_PAIR / 64), q = piece % (Y_PAIR / 64);
+      const int pix = q * 32 + lpix;                        // row * 16 + column
+      const int gy = y0 + pix / WPX, gx = x0 + pix % WPX;
+      const int mb = (ocb >> 3) + pair * 2 + lodd;
+      unsigned off = kOob;
+      if (mb < MB && gy < p.H && gx < p.W) off = (unsigned)(((n * MB + mb) * plane + gy * p.W + gx) * 16);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          yrs, (__attribute__((address_space(3))) void*)(dst + Y_BASE + pair * Y_PITCH + q * 64), 16, off, 0, 0,
+          0);
+    }
+  };
+
+  // ---- transpose-read addressing (tools/_tmp/tr.hip): lane l of a 16-lane group addresses
+  // pixel (l & 15) >> 2, channel quad l & 3 of its group's 16 channels = one block pair
+  const int g = lane >> 4, i16 = lane & 15;
+  const int quad = i16 & 3, pj = i16 >> 2;
+  const int kpx = 8 * (g >> 1) + pj;                       // pixel within the 16-pixel K-step
+  const int in_pair = (quad >> 1) * 8 + (quad & 1) * 4;    // halves: block of the pair, half slot
+  // 32-channel MFMA tile = 2 pairs; group g & 1 takes the second
+  const int xb_base = (((wc * 4 + (g & 1)) * X_PITCH + kpx * 2) * 8) + in_pair;          // + tile * 2 pairs
+  const int ya_base = ((Y_BASE + (wo * 4 + (g & 1)) * Y_PITCH + kpx * 2) * 8) + in_pair;
+
+  float16v acc[2][2][3];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][u][kx][r] = 0.0f;
+
+  if (s0 < s1) fetch(s0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int s = s0; s < s1; ++s) {
+    const int buf = (s - s0) & 1;
+    if (s + 1 < s1) fetch(s + 1, buf ^ 1);
+    auto* base = reinterpret_cast<__attribute__((address_space(3))) _Float16*>(
+        (__attribute__((address_space(3))) uint4*)lds + buf * W_STAGE);
+    auto* xa = reinterpret_cast<__attribute__((address_space(3))) short4v*>(base + xb_base);
+    auto* ya = reinterpret_cast<__attribute__((address_space(3))) short4v*>(base + ya_base);
+#pragma unroll
+    for (int row = 0; row < WR; ++row) {
+      half8 a[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) a[t] = tr_pair(ya, t * 2 * Y_PITCH + row * WPX * 2);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const half8 b = tr_pair(xa, u * 2 * X_PITCH + (row * XPW + kx) * 2);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[t][u][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], b, acc[t][u][kx], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);                     // bound the operands in flight
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- partial sums: part[split][tap][m][c], c contiguous across lanes
+  const int h = lane >> 5;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int c = ccb * 8 + wc * 64 + u * 32 + (lane & 31);
+    if (c >= p.C) continue;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = ocb + wo * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < p.M)
+            p.part[(((long long)blockIdx.y * 9 + ky * 3 + kx) * p.M + m) * p.C + c] = acc[t][u][kx][r];
+        }
+  }
+}
+
+// dW[m][c][tap] (+)= sum_split part[split][tap][m][c]
+__global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_kernel(const float* __restrict__ part,
+                                                                    int splits, int M, int C,
+                                                                    int accumulate,
+                                                                    float* __restrict__ dw) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;       // over [tap][m][c]
+  const int total = 9 * M * C;
+  if (i >= total) return;
+  float s = 0.0f;
+  for (int k = 0; k < splits; ++k) s += part[(long long)k * total + i];
+  const int c = i % C, m = (i / C) % M, tap = i / (C * M);
+  float* o = dw + ((long long)m * C + c) * 9 + tap;
+  *o = accumulate ? *o + s : s;
+}
+
+// db[m] (+)= sum over n, y, x of the blocked fp16 dY (one workgroup per channel block)
+__global__ __launch_bounds__(kThreads) void f16_bias_grad_kernel(const uint4* __restrict__ dy, int N,
+                                                                 int M, int plane, int accumulate,
+                                                                 float* __restrict__ db) {
+  __shared__ float red[kThreads / 64][8];
+  const int MB = (M + 7) >> 3, mb = blockIdx.x;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int n = 0; n < N; ++n) {
+    const uint4* src = dy + ((long long)n * MB + mb) * plane;
+    for (int i = threadIdx.x; i < plane; i += kThreads) {
+      const half8 v = as_half8(src[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = s[e];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][e] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && mb * 8 + threadIdx.x < M) {
+    float v = 0.0f;
+    for (int w = 0; w < kThreads / 64; ++w) v += red[w][threadIdx.x];
+    float* o = db + mb * 8 + threadIdx.x;
+    *o = accumulate ? *o + v : v;
+  }
+}
+
+namespace {
+int wgrad_splits(int blocks, int stages) {
+  int s = (512 + 3 * blocks - 1) / (3 * blocks);   // ~2 workgroups per CU (x 3 filter rows)
+  if (s > stages) s = stages;
+  return s < 1 ? 1 : s;
+}
+}  // namespace
+
+extern "C" {
+
+size_t ssad_conv3x3_wgrad_f16_workspace_bytes(int N, int C, int H, int W, int M) {
+  const int blocks = ((M + W_OT - 1) / W_OT) * ((C + W_CT - 1) / W_CT);
+  const int stages = N * ((H + WR - 1) / WR) * ((W + WPX - 1) / WPX);
+  return (size_t)wgrad_splits(blocks, stages) * 9 * (size_t)M * (size_t)C * sizeof(float);
+}
+
+int ssad_conv3x3_wgrad_f16(const void* x_blocked, const void* dy_blocked, int N, int C, int H, int W,
+                           int M, int accumulate, float* dw, float* db, void* workspace,
+                           size_t workspace_bytes, ssad_stream_t stream) {
+  if (!x_blocked || !dy_blocked || !dw || N < 0 || C < 1 || M < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
+  if ((long long)N * (((C > M ? C : M) + 7) / 8) * H * W >= (1LL << 31)) return SSAD_E_BADARG;
+  if (workspace_bytes < ssad_conv3x3_wgrad_f16_workspace_bytes(N, C, H, W, M) || !workspace)
+    return SSAD_E_WORKSPACE;
+  F16Wgrad p;
+  p.x = static_cast<const uint4*>(x_blocked);
+  p.dy = static_cast<const uint4*>(dy_blocked);
+  p.part = static_cast<float*>(workspace);
+  p.N = N; p.C = C; p.H = H; p.W = W; p.M = M;
+  p.seg_x = (W + WPX - 1) / WPX;
+  p.seg_y = (H + WR - 1) / WR;
+  p.stages = N * p.seg_y * p.seg_x;
+  p.cblocks = (C + W_CT - 1) / W_CT;
+  const int blocks = ((M + W_OT - 1) / W_OT) * p.cblocks;
+  const int splits = wgrad_splits(blocks, p.stages > 0 ? p.stages : 1);
+  hipStream_t s = (hipStream_t)stream;
+  if (N > 0) {
+    static const bool attr = [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE * 16) == hipSuccess;
+    }();
+    if (!attr) return SSAD_E_BADARG;
+    hipLaunchKernelGGL(conv3x3_wgrad_f16_kernel, dim3(blocks, splits, 3), dim3(kThreads), 2 * W_STAGE * 16, s,
+                       p);
+  }
+  hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3((9 * M * C + kThreads - 1) / kThreads), dim3(kThreads),
+                     0, s, p.part, N > 0 ? splits : 0, M, C, accumulate, dw);
+  if (db)
+    hipLaunchKernelGGL(f16_bias_grad_kernel, dim3((M + 7) / 8), dim3(kThreads), 0, s, p.dy, N, M, H * W,
+                       accumulate, db);
   return (int)hipGetLastError();
 }
 

@@ -99,6 +99,9 @@ def lib():
     L.ssad_f16_filter_halves.argtypes = [i32, i32]
     L.ssad_f16_pack_filter.argtypes = [vp, i32, i32, vp, vp, vp]
     L.ssad_conv3x3_forward_f16.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.ssad_conv3x3_wgrad_f16_workspace_bytes.restype = sz
+    L.ssad_conv3x3_wgrad_f16_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    L.ssad_conv3x3_wgrad_f16.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]
     L.ssad_momentum_sgd_update.argtypes = [vp, vp, vp, vp, f32, f32, i32, i64, vp]
     L.ssad_conv_packed_filter_floats.restype = sz
     L.ssad_conv_packed_filter_floats.argtypes = [i32, i32]
@@ -552,3 +555,21 @@ def conv3x3_forward_f16(xb, packed, bias, Cin, Cout, *, relu=False, out_nchw_f32
     _check(lib().ssad_conv3x3_forward_f16(_ptr(xb), _ptr(packed), _ptr(bias), N, Cin, H, W, Cout, flags,
                                           _ptr(y), _stream()), "conv3x3_forward_f16")
     return y
+
+
+def conv3x3_wgrad_f16(xbs, dybs, Cin, Cout, *, bias_grad=True):
+    """dW [Cout][Cin][3][3] and db [Cout] (float32) summed over the given levels; xbs / dybs are
+    lists of channel-blocked fp16 tensors (one per FPN level sharing the filter)."""
+    dW = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device="cuda")
+    db = torch.empty((Cout,), dtype=torch.float32, device="cuda") if bias_grad else None
+    L = lib()
+    for i, (xb, dyb) in enumerate(zip(xbs, dybs)):
+        N, CB, H, W, _ = xb.shape
+        assert xb.dtype == torch.float16 and dyb.dtype == torch.float16
+        assert xb.is_contiguous() and dyb.is_contiguous()
+        assert CB == (Cin + 7) // 8 and dyb.shape == (N, (Cout + 7) // 8, H, W, 8)
+        nbytes = L.ssad_conv3x3_wgrad_f16_workspace_bytes(N, Cin, H, W, Cout)
+        ws = _workspace(nbytes, "wgrad_f16")
+        _check(L.ssad_conv3x3_wgrad_f16(_ptr(xb), _ptr(dyb), N, Cin, H, W, Cout, int(i > 0), _ptr(dW),
+                                        _ptr(db), _ptr(ws), nbytes, _stream()), "conv3x3_wgrad_f16")
+    return dW, db

@@ -85,3 +85,35 @@ def test_f16_data_gradient_is_the_adjoint(K):
     wt = np.ascontiguousarray(_r16(w)[:, :, ::-1, ::-1].transpose(1, 0, 2, 3))
     want = _conv64(_r16(dy), wt, None)
     assert np.abs(dx - want).max() <= 6e-4 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("N,C,M,H,W", [
+    (1, 16, 16, 8, 16),         # one stage, one workgroup per filter row
+    (2, 128, 128, 16, 32),      # full 128 x 128 tile, several stages
+    (2, 256, 256, 10, 14),      # tower layer at P6: ragged rows and columns, 2 x 2 channel blocks
+    (1, 256, 36, 20, 28),       # bbox_pred: M tail (36 -> 5 blocks)
+    (1, 72, 720, 9, 21),        # cls_pred-like: 6 output blocks, C tail
+])
+def test_f16_filter_gradient_vs_float64(K, N, C, M, H, W):
+    rng = np.random.default_rng(300 + C + M)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    dy = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    xr, dyr = _r16(x), _r16(dy)
+    xp = np.zeros((N, C, H + 2, W + 2))
+    xp[:, :, 1:-1, 1:-1] = xr
+    want = np.zeros((M, C, 3, 3))
+    for ky in range(3):
+        for kx in range(3):
+            want[:, :, ky, kx] = np.einsum("nmhw,nchw->mc", dyr, xp[:, :, ky:ky + H, kx:kx + W])
+    want_db = dyr.sum((0, 2, 3))
+    xb = K.f16_pack_activations(torch.from_numpy(x).cuda())
+    dyb = K.f16_pack_activations(torch.from_numpy(dy).cuda())
+    dW, db = K.conv3x3_wgrad_f16([xb], [dyb], C, M)
+    got = dW.cpu().numpy().astype(np.float64)
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), np.abs(got - want).max() / np.abs(want).max()
+    assert np.abs(db.cpu().numpy() - want_db).max() <= 2e-5 * np.abs(want_db).max()
+    # two levels accumulate, and the result is deterministic
+    dW2, db2 = K.conv3x3_wgrad_f16([xb, xb], [dyb, dyb], C, M)
+    assert np.abs(dW2.cpu().numpy() - 2 * want).max() <= 4e-5 * np.abs(want).max()
+    dW3, _ = K.conv3x3_wgrad_f16([xb, xb], [dyb, dyb], C, M)
+    assert torch.equal(dW2, dW3)

@@ -39,6 +39,10 @@ def main():
         m_f = timeit(lambda: F.conv2d(x, w, b, 1, 1))
         m_b = timeit(lambda: torch.ops.aten.convolution_backward(
             dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, True, False]))
+        xb = K.f16_pack_activations(x)
+        w16, _ = K.f16_pack_filter(w, True, False)
+        t_h = timeit(lambda: K.conv3x3_forward_f16(xb, w16, b, ci, co, relu=True, out_nchw_f32=co % 8 != 0))
+        print("      fp16 storage forward %.3f ms %5.0f TF/s" % (t_h, fl / t_h), flush=True)
         print("%3d->%3d @%3dx%3d %6.1f GF | fwd %.3f ms %5.0f TF/s (miopen %.3f) | dgrad %.3f %5.0f | wgrad %.3f %5.0f | "
               "miopen dgrad+wgrad %.3f" % (ci, co, H, W, fl, t_f, fl / t_f, m_f, t_d, fl / t_d, t_w, fl / t_w, m_b),
               flush=True)
