@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--student", default="r50", choices=["r50", "r101"])
     ap.add_argument("--teacher", default="r101", choices=["r50", "r101", "x101-64x4d"])
     ap.add_argument("--px", type=int, default=600, choices=[600, 500])
+    # subnet precision: f32 (the metric's precision, default) or fp16 storage / fp32 accumulation
+    # (config 5; backbones stay fp32).  An f16 line is NOT the headline number.
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="auto")
     return ap.parse_args()
@@ -96,6 +99,12 @@ class KernelTimer(object):
                   if Cout > 64 else None)
             return timed_call(o2, fl, (problems, Cout), kw)
         K.conv3x3_forward, K.conv3x3_forward_multi = fwd, multi
+        o3 = K.conv3x3_forward_f16
+
+        def fwd16(xb, packed, bias, Cin, Cout, **kw):
+            fl = 2.0 * 9 * Cout * Cin * xb.shape[0] * xb.shape[2] * xb.shape[3] if min(Cin, Cout) > 64 else None
+            return timed_call(o3, fl, (xb, packed, bias, Cin, Cout), kw)
+        K.conv3x3_forward_f16 = fwd16
 
     def summary(self):
         if not self.records:
@@ -154,7 +163,7 @@ def main():
 
     import ssad_amd  # noqa: F401
     from ssad_amd import kernels as K, synth
-    from ssad_amd.head_pipeline import DistillHeads
+    from ssad_amd.head_pipeline import DistillHeads, DistillHeadsF16
     from ssad_amd.modeling.retinanet_heads import HeadConfig
     K.lib()   # fail loudly if the HIP extension is missing
 
@@ -163,7 +172,8 @@ def main():
     image_hw = (640, 896) if args.px == 600 else (512, 768)
     cfg = HeadConfig(num_gpus=world)
     rng = np.random.default_rng(1234 + rank)
-    heads = DistillHeads(cfg, N=N, shapes=shapes, device=dev,
+    f16 = args.precision == "f16"
+    heads = (DistillHeadsF16 if f16 else DistillHeads)(cfg, N=N, shapes=shapes, device=dev,
                          student_init=synth.head_params(np.random.default_rng(1)),
                          teacher_init=synth.head_params(np.random.default_rng(2)),
                          process_group=pg, world_size=world, lr=1e-4)
@@ -267,7 +277,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(host / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 storage / f32 accumulate in the subnets (backbones f32)" if f16 else "f32",
+            "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": N, "image": "3x%dx%d" % image_hw,
                        "fpn_levels": [list(s) for s in shapes], "anchors": 9, "classes": 80,
                        "parallelism": "dp%d" % world,
@@ -290,6 +302,13 @@ def main():
                 "avg_launch_ms": round(ks["avg_ms"], 4) if ks else None,
                 "flops_per_launch": ks["flops_per_launch"] if ks else None},
         }
+        if f16:
+            out["roofline"].update({
+                "kernel": "conv3x3_f16_kernel (subnet conv3x3 fwd / data-grad, v_mfma_f32_32x32x16_f16)",
+                "achieved_note": "algorithmic direct-form FLOP/s; the kernel executes exactly these",
+                "mfma_tflops_executed": round(ks["tflops"], 2) if ks else None,
+                "peak": 2500.0, "frac": round(ks["tflops"] / 2500.0, 4) if ks else None,
+                "traffic": None, "traffic_note": None})
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(out))

@@ -354,9 +354,11 @@ SSAD_API int ssad_retinanet_detect(
  * (caffe2/operators/conv_op_cudnn.cc:631-636).  Activations between the subnet layers
  * are channel-blocked fp16, Xb[n][ceil(C/8)][H][W][8] (a tail block is zero padded), so
  * one 16-byte load is a v_mfma_f32_32x32x16_f16 operand for every filter tap. */
-SSAD_API int ssad_f16_pack_activations(const float* x_nchw, int N, int C, int H, int W,
+/* x_blocked = fp16(x_nchw * scale) / x_nchw = float(x_blocked) * scale: the scale carries the
+ * loss scaling of a mixed-precision backward pass (gradients of the logits are ~1e-6) */
+SSAD_API int ssad_f16_pack_activations(const float* x_nchw, int N, int C, int H, int W, float scale,
                                        void* x_blocked, ssad_stream_t stream);
-SSAD_API int ssad_f16_unpack_activations(const void* x_blocked, int N, int C, int H, int W,
+SSAD_API int ssad_f16_unpack_activations(const void* x_blocked, int N, int C, int H, int W, float scale,
                                          float* x_nchw, ssad_stream_t stream);
 /* halves to allocate for either packed form of an [M][C][3][3] filter */
 SSAD_API size_t ssad_f16_filter_halves(int M, int C);
@@ -365,20 +367,23 @@ SSAD_API size_t ssad_f16_filter_halves(int M, int C);
 SSAD_API int ssad_f16_pack_filter(const float* w, int M, int C, void* packed_fwd,
                                   void* packed_dgrad, ssad_stream_t stream);
 #define SSAD_F16_OUT_NCHW_F32 16   /* prediction layers: write y as NCHW fp32 for the loss kernels */
-/* y = conv3x3(x_blocked, packed) (+ bias[M], fp32) (ReLU with SSAD_CONV_RELU); y is blocked
- * fp16 [N][M/8][H][W][8] (M % 8 == 0) or, with SSAD_F16_OUT_NCHW_F32, float [N][M][H][W].
- * Data gradient: the same call with packed_dgrad, C and M exchanged, bias NULL. */
+/* y = conv3x3(x_blocked, packed) (+ bias[M], fp32) (ReLU with SSAD_CONV_RELU, sigmoid with
+ * SSAD_CONV_SIGMOID); y is blocked fp16 [N][M/8][H][W][8] (M % 8 == 0) or, with
+ * SSAD_F16_OUT_NCHW_F32, float [N][M][H][W].  Data gradient: the same call with packed_dgrad,
+ * C and M exchanged, bias NULL, and with SSAD_CONV_MASK_AUX the fused ReluGradient
+ * y = aux > 0 ? y : 0 (aux blocked fp16 like y, else NULL). */
 SSAD_API int ssad_conv3x3_forward_f16(const void* x_blocked, const void* packed, const float* bias,
-                                      int N, int C, int H, int W, int M, int flags, void* y,
-                                      ssad_stream_t stream);
+                                      const void* aux, int N, int C, int H, int W, int M, int flags,
+                                      void* y, ssad_stream_t stream);
 
 /* Filter and bias gradient from channel-blocked fp16 x [N][ceil(C/8)][H][W][8] and dy
  * [N][ceil(M/8)][H][W][8] (conv_op_impl.h:451-510): dw [M][C][3][3] and db [M] in fp32,
  * overwritten, or added to when accumulate != 0 (the five FPN levels share one filter:
- * caffe2/python/core.py:706-741 sums their gradients).  db may be NULL.  Deterministic. */
+ * caffe2/python/core.py:706-741 sums their gradients); both are multiplied by `scale` (the
+ * inverse loss scale) on the way out.  db may be NULL.  Deterministic. */
 SSAD_API size_t ssad_conv3x3_wgrad_f16_workspace_bytes(int N, int C, int H, int W, int M);
 SSAD_API int ssad_conv3x3_wgrad_f16(const void* x_blocked, const void* dy_blocked, int N, int C, int H,
-                                    int W, int M, int accumulate, float* dw, float* db,
+                                    int W, int M, int accumulate, float scale, float* dw, float* db,
                                     void* workspace, size_t workspace_bytes, ssad_stream_t stream);
 
 /* ---------------------------------------------------------------------- */

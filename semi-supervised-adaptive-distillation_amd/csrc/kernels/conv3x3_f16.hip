@@ -45,10 +45,11 @@ struct F16Conv {
   const uint4* x;        // blocked fp16 input
   const uint4* w;        // packed filter [9][C/8][M] x 16 B
   const float* bias;     // [M] or null
+  const _Float16* aux;   // blocked fp16 like y, or null: y = aux > 0 ? y : 0 (fused ReluGradient)
   void* y;               // blocked fp16 or NCHW fp32
   int N, C, H, W, M;
   int tiles_x, tiles_y;
-  int relu, out_nchw_f32;
+  int relu, sigmoid, out_nchw_f32;
 };
 
 __device__ __forceinline__ half8 as_half8(const uint4& v) {
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Conv 
         for (int e = 0; e < 4; ++e) {
           v[e] = acc[i][tt][4 * g + e] + bv[i][g][e];
           if (p.relu) v[e] = fmaxf(v[e], 0.0f);
+          if (p.sigmoid) v[e] = 1.0f / (1.0f + __expf(-v[e]));     // sigmoid_op.cu:25-29
         }
         if (p.out_nchw_f32) {
           float* yo = static_cast<float*>(p.y);
@@ -205,11 +207,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Conv 
           for (int e = 0; e < 4; ++e)
             if (oc + e < p.M) yo[(((long long)n * p.M + oc + e) * p.H + gy) * p.W + gx] = v[e];
         } else if (oc < p.M) {                        // M % 8 == 0 on this path
+          const long long slot = ((long long)n * (p.M >> 3) + (oc >> 3)) * plane + (long long)gy * p.W + gx;
           half4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+          if (p.aux) {                                // relu_op.cu:44-53: dX = Y > 0 ? dY : 0
+            const half4 m = *reinterpret_cast<const half4*>(p.aux + slot * 8 + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = m[e] > (_Float16)0.0f ? o[e] : (_Float16)0.0f;
+          }
           _Float16* yo = static_cast<_Float16*>(p.y);
-          const long long slot = ((long long)n * (p.M >> 3) + (oc >> 3)) * plane + (long long)gy * p.W + gx;
           *reinterpret_cast<half4*>(yo + slot * 8 + 4 * h) = o;
         }
       }
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Conv 
 // NCHW fp32 -> blocked fp16 (round to nearest even), one thread per 16-byte slot
 __global__ __launch_bounds__(kThreads) void f16_pack_kernel(const float* __restrict__ x,
                                                             uint4* __restrict__ xb, int N, int C,
-                                                            long long plane) {
+                                                            long long plane, float scale) {
   const int CB = (C + 7) >> 3;
   const long long total = (long long)N * CB * plane;
   for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total;
@@ -230,7 +237,8 @@ __global__ __launch_bounds__(kThreads) void f16_pack_kernel(const float* __restr
     const float* src = x + ((ncb / CB) * C + cb * 8) * plane + px;
     half8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = cb * 8 + e < C ? (_Float16)src[e * plane] : (_Float16)0.0f;
+    for (int e = 0; e < 8; ++e)
+      o[e] = cb * 8 + e < C ? (_Float16)(src[e * plane] * scale) : (_Float16)0.0f;
     xb[i] = __builtin_bit_cast(uint4, o);
   }
 }
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void f16_pack_kernel(const float* __restr
 // blocked fp16 -> NCHW fp32: one thread per (n, cb, pixel); 8 strided 4-byte stores
 __global__ __launch_bounds__(kThreads) void f16_unpack_kernel(const uint4* __restrict__ xb,
                                                               float* __restrict__ x, int N, int C,
-                                                              long long plane) {
+                                                              long long plane, float scale) {
   const int CB = (C + 7) >> 3;
   const long long total = (long long)N * CB * plane;
   for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total;
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(kThreads) void f16_unpack_kernel(const uint4* __res
     float* dst = x + ((ncb / CB) * C + cb * 8) * plane + px;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      if (cb * 8 + e < C) dst[e * plane] = (float)v[e];
+      if (cb * 8 + e < C) dst[e * plane] = (float)v[e] * scale;
   }
 }
 
@@ -289,24 +297,24 @@ inline unsigned grid_for(long long n) {
 
 extern "C" {
 
-int ssad_f16_pack_activations(const float* x, int N, int C, int H, int W, void* xb,
+int ssad_f16_pack_activations(const float* x, int N, int C, int H, int W, float scale, void* xb,
                               ssad_stream_t stream) {
   if (!x || !xb || N < 0 || C < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
   if (N == 0) return 0;
   const long long plane = (long long)H * W;
   hipLaunchKernelGGL(f16_pack_kernel, dim3(grid_for((long long)N * ((C + 7) >> 3) * plane)), dim3(kThreads),
-                     0, (hipStream_t)stream, x, static_cast<uint4*>(xb), N, C, plane);
+                     0, (hipStream_t)stream, x, static_cast<uint4*>(xb), N, C, plane, scale);
   return (int)hipGetLastError();
 }
 
-int ssad_f16_unpack_activations(const void* xb, int N, int C, int H, int W, float* x,
+int ssad_f16_unpack_activations(const void* xb, int N, int C, int H, int W, float scale, float* x,
                                 ssad_stream_t stream) {
   if (!x || !xb || N < 0 || C < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
   if (N == 0) return 0;
   const long long plane = (long long)H * W;
   hipLaunchKernelGGL(f16_unpack_kernel, dim3(grid_for((long long)N * ((C + 7) >> 3) * plane)),
                      dim3(kThreads), 0, (hipStream_t)stream, static_cast<const uint4*>(xb), x, N, C,
-                     plane);
+                     plane, scale);
   return (int)hipGetLastError();
 }
 
@@ -325,22 +333,25 @@ int ssad_f16_pack_filter(const float* w, int M, int C, void* wf, void* wd, ssad_
   return (int)hipGetLastError();
 }
 
-int ssad_conv3x3_forward_f16(const void* xb, const void* wp, const float* bias, int N, int C, int H,
-                             int W, int M, int flags, void* y, ssad_stream_t stream) {
+int ssad_conv3x3_forward_f16(const void* xb, const void* wp, const float* bias, const void* aux, int N,
+                             int C, int H, int W, int M, int flags, void* y, ssad_stream_t stream) {
   if (!xb || !wp || !y || N < 0 || M < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
   if (C < 1) return SSAD_E_BADARG;
   const int nchw = (flags & SSAD_F16_OUT_NCHW_F32) != 0;
   if (!nchw && (M & 7)) return SSAD_E_BADARG;                   // blocked output: whole 8-blocks
+  if (((flags & SSAD_CONV_MASK_AUX) != 0) != (aux != nullptr) || (aux && nchw)) return SSAD_E_BADARG;
   if (N == 0) return 0;
   F16Conv p;
   p.x = static_cast<const uint4*>(xb);
   p.w = static_cast<const uint4*>(wp);
   p.bias = bias;
+  p.aux = static_cast<const _Float16*>(aux);
   p.y = y;
   p.N = N; p.C = C; p.H = H; p.W = W; p.M = M;
   p.tiles_x = (W + TS - 1) / TS;
   p.tiles_y = (H + TS - 1) / TS;
   p.relu = (flags & SSAD_CONV_RELU) != 0;
+  p.sigmoid = (flags & SSAD_CONV_SIGMOID) != 0;
   p.out_nchw_f32 = nchw;
   const long long tiles = (long long)N * p.tiles_x * p.tiles_y;
   if (tiles >= (1LL << 31) || (long long)N * ((C + 7) / 8 + CBC) * H * W >= (1LL << 31)) return SSAD_E_BADARG;
@@ -539,13 +550,14 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
 // dW[m][c][tap] (+)= sum_split part[split][tap][m][c]
 __global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_kernel(const float* __restrict__ part,
                                                                     int splits, int M, int C,
-                                                                    int accumulate,
+                                                                    int accumulate, float scale,
                                                                     float* __restrict__ dw) {
   const int i = blockIdx.x * kThreads + threadIdx.x;       // over [tap][m][c]
   const int total = 9 * M * C;
   if (i >= total) return;
   float s = 0.0f;
   for (int k = 0; k < splits; ++k) s += part[(long long)k * total + i];
+  s *= scale;
   const int c = i % C, m = (i / C) % M, tap = i / (C * M);
   float* o = dw + ((long long)m * C + c) * 9 + tap;
   *o = accumulate ? *o + s : s;
@@ -554,7 +566,7 @@ __global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_kernel(const float*
 // db[m] (+)= sum over n, y, x of the blocked fp16 dY (one workgroup per channel block)
 __global__ __launch_bounds__(kThreads) void f16_bias_grad_kernel(const uint4* __restrict__ dy, int N,
                                                                  int M, int plane, int accumulate,
-                                                                 float* __restrict__ db) {
+                                                                 float scale, float* __restrict__ db) {
   __shared__ float red[kThreads / 64][8];
   const int MB = (M + 7) >> 3, mb = blockIdx.x;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -576,6 +588,7 @@ __global__ __launch_bounds__(kThreads) void f16_bias_grad_kernel(const uint4* __
   if (threadIdx.x < 8 && mb * 8 + threadIdx.x < M) {
     float v = 0.0f;
     for (int w = 0; w < kThreads / 64; ++w) v += red[w][threadIdx.x];
+    v *= scale;
     float* o = db + mb * 8 + threadIdx.x;
     *o = accumulate ? *o + v : v;
   }
@@ -598,7 +611,7 @@ size_t ssad_conv3x3_wgrad_f16_workspace_bytes(int N, int C, int H, int W, int M)
 }
 
 int ssad_conv3x3_wgrad_f16(const void* x_blocked, const void* dy_blocked, int N, int C, int H, int W,
-                           int M, int accumulate, float* dw, float* db, void* workspace,
+                           int M, int accumulate, float scale, float* dw, float* db, void* workspace,
                            size_t workspace_bytes, ssad_stream_t stream) {
   if (!x_blocked || !dy_blocked || !dw || N < 0 || C < 1 || M < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
   if ((long long)N * (((C > M ? C : M) + 7) / 8) * H * W >= (1LL << 31)) return SSAD_E_BADARG;
@@ -626,10 +639,10 @@ int ssad_conv3x3_wgrad_f16(const void* x_blocked, const void* dy_blocked, int N,
                        p);
   }
   hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3((9 * M * C + kThreads - 1) / kThreads), dim3(kThreads),
-                     0, s, p.part, N > 0 ? splits : 0, M, C, accumulate, dw);
+                     0, s, p.part, N > 0 ? splits : 0, M, C, accumulate, scale, dw);
   if (db)
     hipLaunchKernelGGL(f16_bias_grad_kernel, dim3((M + 7) / 8), dim3(kThreads), 0, s, p.dy, N, M, H * W,
-                       accumulate, db);
+                       accumulate, scale, db);
   return (int)hipGetLastError();
 }
 

@@ -103,10 +103,14 @@ class DistillHeads(object):
         self.bbox_losses = None
         self.preserved = OrderedDict()     # blobs of a loaded weights file the subnets do not own
 
-        def lv(ch):
-            return [torch.empty((N, ch, h, w), dtype=torch.float32, device=device)
-                    for (h, w) in self.shapes]
-        D = self.D
+        self._alloc_buffers()
+
+    def _lv(self, ch):
+        return [torch.empty((self.N, ch, h, w), dtype=torch.float32, device=self.device)
+                for (h, w) in self.shapes]
+
+    def _alloc_buffers(self):
+        cfg, lv, D = self.cfg, self._lv, self.D
         # student activations (kept for backward) and their gradients
         self.act = {t: [lv(D) for _ in range(cfg.num_convs)] for t in ("cls", "bbox")}
         self.cls_logits, self.bbox_pred = lv(self.A * self.C), lv(4 * self.A)
@@ -117,7 +121,7 @@ class DistillHeads(object):
         # teacher scratch: two ping-pong feature sets per tower + probabilities
         self.t_buf = {"cls": [lv(D), lv(D)], "bbox": [lv(D), lv(D)]}
         self.t_prob = lv(self.A * self.C)
-        self.t_bbox = lv(4 * self.A) if teacher_bbox_tower else None
+        self.t_bbox = lv(4 * self.A) if self.teacher_bbox_tower else None
         # packed filters (rebuilt every step from the current weights)
         self.packed = {}
         self.t_packed = None
@@ -348,3 +352,119 @@ class DistillHeads(object):
         else:
             self.wait_gradients()
         return self.losses
+
+
+class DistillHeadsF16(DistillHeads):
+    """The same iteration with fp16 storage and fp32 accumulation in the subnet convolutions
+    (BASELINE config 5's precision; the reference's only fp16 route is CudnnConvOp<float16>
+    with fp32 math, caffe2/operators/conv_op_cudnn.cc:631-636).  Mixed precision in the usual
+    arrangement: fp32 master parameters, momentum and parameter gradients (FlatParams, SGD and
+    the all-reduce are unchanged); filters re-rounded to fp16 every step; activations between
+    the layers channel-blocked fp16; prediction layers write NCHW fp32 for the fp32 loss
+    kernels; the gradient of the logits is multiplied by LOSS_SCALE before it is rounded to
+    fp16 (its elements are ~1e-6) and every result leaving the fp16 domain -- filter / bias
+    gradients, the gradient w.r.t. the FPN levels -- is divided by it again."""
+
+    LOSS_SCALE = 8192.0
+
+    def _blk(self, ch):
+        return [torch.empty((self.N, (ch + 7) // 8, h, w, 8), dtype=torch.float16, device=self.device)
+                for (h, w) in self.shapes]
+
+    def _alloc_buffers(self):
+        cfg, lv, blk, D = self.cfg, self._lv, self._blk, self.D
+        self.act = {t: [blk(D) for _ in range(cfg.num_convs)] for t in ("cls", "bbox")}
+        self.cls_logits, self.bbox_pred = lv(self.A * self.C), lv(4 * self.A)
+        self.d_cls_logits, self.d_bbox_pred = lv(self.A * self.C), lv(4 * self.A)
+        self.dy_pred = {"cls": blk(self.A * self.C), "bbox": blk(4 * self.A)}
+        self.dbuf = {"cls": [blk(D), blk(D)], "bbox": [blk(D), blk(D)]}
+        self.d_fpn = {t: lv(D) for t in ("cls", "bbox")}
+        self.t_buf = {"cls": [blk(D), blk(D)], "bbox": [blk(D), blk(D)]}
+        self.in_blk = {"student": blk(D), "teacher": blk(D)}
+        self.t_prob = lv(self.A * self.C)
+        self.t_bbox = lv(4 * self.A) if self.teacher_bbox_tower else None
+        self.packed = {}
+        self.t_packed = None
+        self.losses = None
+        self.normalizer = None
+
+    def _pack(self, w, want_fwd, want_dgrad):
+        return K.f16_pack_filter(w, want_fwd, want_dgrad)
+
+    def forward_all(self, teacher_fpn, student_fpn):
+        if self.t_packed is None:
+            self.pack_teacher()
+        cfg, D = self.cfg, self.D
+        for x, xb in zip(student_fpn, self.in_blk["student"]):
+            K.f16_pack_activations(x, out=xb)
+        for x, xb in zip(teacher_fpn, self.in_blk["teacher"]):
+            K.f16_pack_activations(x, out=xb)
+        self.fpn_in = self.in_blk["student"]
+        tx = {"cls": self.in_blk["teacher"], "bbox": self.in_blk["teacher"]}
+        sx = {"cls": self.fpn_in, "bbox": self.fpn_in}
+        nlev = len(self.shapes)
+        for i in range(cfg.num_convs):
+            for t in ("cls", "bbox"):
+                name = self._layers(t)[i]
+                if t == "cls" or self.teacher_bbox_tower:
+                    out = self.t_buf[t][i & 1]
+                    for l in range(nlev):
+                        K.conv3x3_forward_f16(tx[t][l], self.t_packed[name], self.teacher[name + "_b"], D, D,
+                                              relu=True, out=out[l])
+                    tx[t] = out
+                out = self.act[t][i]
+                for l in range(nlev):
+                    K.conv3x3_forward_f16(sx[t][l], self.packed[name][0], self.params[name + "_b"], D, D,
+                                          relu=True, out=out[l])
+                sx[t] = out
+        cp, bp = self._layers("cls")[-1], self._layers("bbox")[-1]
+        AC, A4 = self.A * self.C, 4 * self.A
+        for l in range(nlev):
+            K.conv3x3_forward_f16(tx["cls"][l], self.t_packed[cp], self.teacher[cp + "_b"], D, AC,
+                                  sigmoid=True, out_nchw_f32=True, out=self.t_prob[l])
+            K.conv3x3_forward_f16(sx["cls"][l], self.packed[cp][0], self.params[cp + "_b"], D, AC,
+                                  out_nchw_f32=True, out=self.cls_logits[l])
+            K.conv3x3_forward_f16(sx["bbox"][l], self.packed[bp][0], self.params[bp + "_b"], D, A4,
+                                  out_nchw_f32=True, out=self.bbox_pred[l])
+            if self.teacher_bbox_tower:
+                K.conv3x3_forward_f16(tx["bbox"][l], self.t_packed[bp], self.teacher[bp + "_b"], D, A4,
+                                      out_nchw_f32=True, out=self.t_bbox[l])
+        return self.cls_logits, self.bbox_pred
+
+    def backward(self, d_bbox_pred):
+        cfg, D, S = self.cfg, self.D, self.LOSS_SCALE
+        nl, nlev = cfg.num_convs, len(self.shapes)
+        dy = {}
+        for t, src in (("cls", self.d_cls_logits), ("bbox", d_bbox_pred)):
+            for l in range(nlev):
+                K.f16_pack_activations(src[l], scale=S, out=self.dy_pred[t][l])
+            dy[t] = self.dy_pred[t]
+        for t in ("cls", "bbox"):
+            name = self._layers(t)[-1]
+            x_in = self.act[t][nl - 1]
+            Cout = self.params[name + "_b"].numel()
+            K.conv3x3_wgrad_f16(x_in, dy[t], D, Cout, scale=1.0 / S, dW=self.grads[name + "_w"],
+                                db=self.grads[name + "_b"])
+            out = self.dbuf[t][nl & 1]
+            for l in range(nlev):
+                K.conv3x3_forward_f16(dy[t][l], self.packed[name][1], None, Cout, D, mask_by=x_in[l],
+                                      out=out[l])
+            dy[t] = out
+        for li in range(nl - 1, -1, -1):
+            for t in ("cls", "bbox"):
+                name = self._layers(t)[li]
+                x_in = self.act[t][li - 1] if li > 0 else self.fpn_in
+                K.conv3x3_wgrad_f16(x_in, dy[t], D, D, scale=1.0 / S, dW=self.grads[name + "_w"],
+                                    db=self.grads[name + "_b"])
+                out = self.dbuf[t][li & 1]
+                for l in range(nlev):
+                    K.conv3x3_forward_f16(dy[t][l], self.packed[name][1], None, D, D,
+                                          mask_by=x_in[l] if li > 0 else None, out=out[l])
+                dy[t] = out
+            if li == nl // 2:
+                self._allreduce_async("late")
+        for t in ("cls", "bbox"):
+            for l in range(nlev):
+                K.f16_unpack_activations(dy[t][l], D, scale=1.0 / S, out=self.d_fpn[t][l])
+        self._allreduce_async("early")
+        return self.d_fpn

@@ -93,15 +93,15 @@ def lib():
     L.ssad_upsample_nearest.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.ssad_upsample_nearest_grad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     L.ssad_max_pool3x3s2_bias_relu.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
-    L.ssad_f16_pack_activations.argtypes = [vp, i32, i32, i32, i32, vp, vp]
-    L.ssad_f16_unpack_activations.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    L.ssad_f16_pack_activations.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
+    L.ssad_f16_unpack_activations.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
     L.ssad_f16_filter_halves.restype = sz
     L.ssad_f16_filter_halves.argtypes = [i32, i32]
     L.ssad_f16_pack_filter.argtypes = [vp, i32, i32, vp, vp, vp]
-    L.ssad_conv3x3_forward_f16.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.ssad_conv3x3_forward_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_conv3x3_wgrad_f16_workspace_bytes.restype = sz
     L.ssad_conv3x3_wgrad_f16_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
-    L.ssad_conv3x3_wgrad_f16.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]
+    L.ssad_conv3x3_wgrad_f16.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, sz, vp]
     L.ssad_momentum_sgd_update.argtypes = [vp, vp, vp, vp, f32, f32, i32, i64, vp]
     L.ssad_conv_packed_filter_floats.restype = sz
     L.ssad_conv_packed_filter_floats.argtypes = [i32, i32]
@@ -510,21 +510,24 @@ def conv3x3_wgrad(xs, dys, Cout, *, want_db=True, accumulate=False, dW=None, db=
 F16_OUT_NCHW_F32 = 16
 
 
-def f16_pack_activations(x):
-    """NCHW float32 -> channel-blocked float16 [N][ceil(C/8)][H][W][8] (zero padded tail)."""
+def f16_pack_activations(x, scale=1.0, out=None):
+    """NCHW float32 -> channel-blocked float16 [N][ceil(C/8)][H][W][8] of x * scale (zero
+    padded tail)."""
     _f32c(x, "x")
     N, Cc, H, W = x.shape
-    xb = torch.empty((N, (Cc + 7) // 8, H, W, 8), dtype=torch.float16, device="cuda")
-    _check(lib().ssad_f16_pack_activations(_ptr(x), N, Cc, H, W, _ptr(xb), _stream()), "f16_pack_activations")
+    xb = out if out is not None else torch.empty((N, (Cc + 7) // 8, H, W, 8), dtype=torch.float16,
+                                                 device="cuda")
+    _check(lib().ssad_f16_pack_activations(_ptr(x), N, Cc, H, W, float(scale), _ptr(xb), _stream()),
+           "f16_pack_activations")
     return xb
 
 
-def f16_unpack_activations(xb, channels):
-    """channel-blocked float16 -> NCHW float32 with `channels` channels."""
+def f16_unpack_activations(xb, channels, scale=1.0, out=None):
+    """channel-blocked float16 -> NCHW float32 (times scale) with `channels` channels."""
     N, CB, H, W, _ = xb.shape
     assert xb.dtype == torch.float16 and xb.is_contiguous() and CB == (channels + 7) // 8
-    x = torch.empty((N, channels, H, W), dtype=torch.float32, device="cuda")
-    _check(lib().ssad_f16_unpack_activations(_ptr(xb), N, channels, H, W, _ptr(x), _stream()),
+    x = out if out is not None else torch.empty((N, channels, H, W), dtype=torch.float32, device="cuda")
+    _check(lib().ssad_f16_unpack_activations(_ptr(xb), N, channels, H, W, float(scale), _ptr(x), _stream()),
            "f16_unpack_activations")
     return x
 
@@ -540,28 +543,37 @@ def f16_pack_filter(w, fwd=True, dgrad=False):
     return wf, wd
 
 
-def conv3x3_forward_f16(xb, packed, bias, Cin, Cout, *, relu=False, out_nchw_f32=False):
+def conv3x3_forward_f16(xb, packed, bias, Cin, Cout, *, relu=False, sigmoid=False, mask_by=None,
+                        out_nchw_f32=False, out=None):
     """3x3 / stride 1 / pad 1 convolution of a channel-blocked fp16 tensor; fp32 accumulation.
-    Output: blocked fp16 [N][Cout/8][H][W][8], or NCHW float32 for the prediction layers."""
+    Output: blocked fp16 [N][Cout/8][H][W][8], or NCHW float32 for the prediction layers.
+    mask_by (blocked fp16 like the output): y = mask_by > 0 ? y : 0 (fused ReluGradient)."""
     N, CB, H, W, _ = xb.shape
     assert xb.dtype == torch.float16 and xb.is_contiguous() and CB == (Cin + 7) // 8
-    if out_nchw_f32:
+    if out is not None:
+        y = out
+    elif out_nchw_f32:
         y = torch.empty((N, Cout, H, W), dtype=torch.float32, device="cuda")
     else:
         y = torch.empty((N, Cout // 8, H, W, 8), dtype=torch.float16, device="cuda")
     if bias is not None:
         _f32c(bias, "bias")
-    flags = (CONV_RELU if relu else 0) | (F16_OUT_NCHW_F32 if out_nchw_f32 else 0)
-    _check(lib().ssad_conv3x3_forward_f16(_ptr(xb), _ptr(packed), _ptr(bias), N, Cin, H, W, Cout, flags,
-                                          _ptr(y), _stream()), "conv3x3_forward_f16")
+    if mask_by is not None:
+        assert mask_by.dtype == torch.float16 and mask_by.is_contiguous() and mask_by.shape == y.shape
+    flags = ((CONV_RELU if relu else 0) | (CONV_SIGMOID if sigmoid else 0)
+             | (CONV_MASK_AUX if mask_by is not None else 0) | (F16_OUT_NCHW_F32 if out_nchw_f32 else 0))
+    _check(lib().ssad_conv3x3_forward_f16(_ptr(xb), _ptr(packed), _ptr(bias), _ptr(mask_by), N, Cin, H, W,
+                                          Cout, flags, _ptr(y), _stream()), "conv3x3_forward_f16")
     return y
 
 
-def conv3x3_wgrad_f16(xbs, dybs, Cin, Cout, *, bias_grad=True):
-    """dW [Cout][Cin][3][3] and db [Cout] (float32) summed over the given levels; xbs / dybs are
-    lists of channel-blocked fp16 tensors (one per FPN level sharing the filter)."""
-    dW = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device="cuda")
-    db = torch.empty((Cout,), dtype=torch.float32, device="cuda") if bias_grad else None
+def conv3x3_wgrad_f16(xbs, dybs, Cin, Cout, *, scale=1.0, dW=None, db=None, bias_grad=True):
+    """dW [Cout][Cin][3][3] and db [Cout] (float32, times scale) summed over the given levels;
+    xbs / dybs are lists of channel-blocked fp16 tensors (one per FPN level sharing the filter)."""
+    if dW is None:
+        dW = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device="cuda")
+    if db is None and bias_grad:
+        db = torch.empty((Cout,), dtype=torch.float32, device="cuda")
     L = lib()
     for i, (xb, dyb) in enumerate(zip(xbs, dybs)):
         N, CB, H, W, _ = xb.shape
@@ -570,6 +582,6 @@ def conv3x3_wgrad_f16(xbs, dybs, Cin, Cout, *, bias_grad=True):
         assert CB == (Cin + 7) // 8 and dyb.shape == (N, (Cout + 7) // 8, H, W, 8)
         nbytes = L.ssad_conv3x3_wgrad_f16_workspace_bytes(N, Cin, H, W, Cout)
         ws = _workspace(nbytes, "wgrad_f16")
-        _check(L.ssad_conv3x3_wgrad_f16(_ptr(xb), _ptr(dyb), N, Cin, H, W, Cout, int(i > 0), _ptr(dW),
-                                        _ptr(db), _ptr(ws), nbytes, _stream()), "conv3x3_wgrad_f16")
+        _check(L.ssad_conv3x3_wgrad_f16(_ptr(xb), _ptr(dyb), N, Cin, H, W, Cout, int(i > 0), float(scale),
+                                        _ptr(dW), _ptr(db), _ptr(ws), nbytes, _stream()), "conv3x3_wgrad_f16")
     return dW, db

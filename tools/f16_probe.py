@@ -33,6 +33,13 @@ def main():
         fl = 2.0 * 9 * N * H * W * ci * co / 1e9
         print("%3d->%3d @%3dx%3d %6.1f GF  fp16 forward %.3f ms  %5.0f TF/s (%.1f %% of 2500)"
               % (ci, co, H, W, fl, t, fl / t, fl / t / 25.0), flush=True)
+    for (ci, co, H, W) in [(256, 256, 80, 112), (256, 256, 40, 56), (256, 720, 80, 112), (256, 36, 80, 112)]:
+        xb = K.f16_pack_activations(torch.randn(N, ci, H, W, device="cuda"))
+        dyb = K.f16_pack_activations(torch.randn(N, co, H, W, device="cuda"))
+        t = timeit(lambda: K.conv3x3_wgrad_f16([xb], [dyb], ci, co))
+        fl = 2.0 * 9 * N * H * W * ci * co / 1e9
+        print("%3d->%3d @%3dx%3d %6.1f GF  fp16 wgrad   %.3f ms  %5.0f TF/s (%.1f %% of 2500)"
+              % (ci, co, H, W, fl, t, fl / t, fl / t / 25.0), flush=True)
     x = torch.randn(N, 256, 80, 112, device="cuda")
     t = timeit(lambda: K.f16_pack_activations(x))
     print("pack 147 MB fp32 -> blocked fp16: %.3f ms" % t)
