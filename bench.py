@@ -105,6 +105,13 @@ class KernelTimer(object):
             fl = 2.0 * 9 * Cout * Cin * xb.shape[0] * xb.shape[2] * xb.shape[3] if min(Cin, Cout) > 64 else None
             return timed_call(o3, fl, (xb, packed, bias, Cin, Cout), kw)
         K.conv3x3_forward_f16 = fwd16
+        o4 = K.conv3x3_forward_f16_levels
+
+        def lev16(xbs, packed, bias, Cin, Cout, outs, **kw):
+            fl = (2.0 * 9 * Cout * Cin * sum(x.shape[0] * x.shape[2] * x.shape[3] for x in xbs)
+                  if min(Cin, Cout) > 64 else None)
+            return timed_call(o4, fl, (xbs, packed, bias, Cin, Cout, outs), kw)
+        K.conv3x3_forward_f16_levels = lev16
 
     def summary(self):
         if not self.records:

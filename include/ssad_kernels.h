@@ -375,6 +375,18 @@ SSAD_API int ssad_f16_pack_filter(const float* w, int M, int C, void* packed_fwd
 SSAD_API int ssad_conv3x3_forward_f16(const void* x_blocked, const void* packed, const float* bias,
                                       const void* aux, int N, int C, int H, int W, int M, int flags,
                                       void* y, ssad_stream_t stream);
+/* The same for every FPN level sharing the filter in ONE launch (n_levels <=
+ * SSAD_MAX_F16_LEVELS); aux per level, all NULL or (with SSAD_CONV_MASK_AUX) all set. */
+#define SSAD_MAX_F16_LEVELS 8
+typedef struct ssad_f16_level {
+  const void* x;      /* blocked fp16 [N][ceil(C/8)][H][W][8] */
+  void* y;            /* blocked fp16 [N][M/8][H][W][8] or float [N][M][H][W] */
+  const void* aux;    /* blocked fp16 like y, or NULL */
+  int N, H, W;
+} ssad_f16_level;
+SSAD_API int ssad_conv3x3_forward_f16_levels(const ssad_f16_level* levels_host, int n_levels,
+                                             const void* packed, const float* bias, int C, int M,
+                                             int flags, ssad_stream_t stream);
 
 /* Filter and bias gradient from channel-blocked fp16 x [N][ceil(C/8)][H][W][8] and dy
  * [N][ceil(M/8)][H][W][8] (conv_op_impl.h:451-510): dw [M][C][3][3] and db [M] in fp32,

@@ -52,17 +52,39 @@ struct F16Conv {
   int relu, sigmoid, out_nchw_f32;
 };
 
+// every FPN level that shares the filter, in one launch (the small levels alone cannot fill
+// the chip: P5..P7 are 64 / 16 / 16 workgroups at batch 16)
+struct F16Levels {
+  const uint4* x[SSAD_MAX_F16_LEVELS];
+  void* y[SSAD_MAX_F16_LEVELS];
+  const _Float16* aux[SSAD_MAX_F16_LEVELS];
+  int N[SSAD_MAX_F16_LEVELS], H[SSAD_MAX_F16_LEVELS], W[SSAD_MAX_F16_LEVELS];
+  int tile0[SSAD_MAX_F16_LEVELS + 1];      // first workgroup (blockIdx.x) of each level
+  int n_levels;
+  const uint4* w;
+  const float* bias;
+  int C, M, relu, sigmoid, out_nchw_f32;
+};
+
 __device__ __forceinline__ half8 as_half8(const uint4& v) {
   return __builtin_bit_cast(half8, v);
 }
 
 template <int DBG>   // ablation switches for tools/f16_probe.py: 1 no halo fetch, 2 no filter reload, 4 no LDS reads
-__global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Conv p) {
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Levels q) {
   __shared__ uint4 lds[2 * SLOTS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wo = wave & 1, wp = wave >> 1;
   const int j = lane & 31, h = lane >> 5;
-  int t = blockIdx.x;
+  int lv = 0;
+  for (int l = 1; l < q.n_levels; ++l)
+    if ((int)blockIdx.x >= q.tile0[l]) lv = l;
+  F16Conv p;
+  p.x = q.x[lv]; p.w = q.w; p.bias = q.bias; p.aux = q.aux[lv]; p.y = q.y[lv];
+  p.N = q.N[lv]; p.C = q.C; p.H = q.H[lv]; p.W = q.W[lv]; p.M = q.M;
+  p.tiles_x = (p.W + TS - 1) / TS; p.tiles_y = (p.H + TS - 1) / TS;
+  p.relu = q.relu; p.sigmoid = q.sigmoid; p.out_nchw_f32 = q.out_nchw_f32;
+  int t = blockIdx.x - q.tile0[lv];
   const int tx = t % p.tiles_x; t /= p.tiles_x;
   const int ty = t % p.tiles_y;
   const int n = t / p.tiles_y;
@@ -333,38 +355,55 @@ int ssad_f16_pack_filter(const float* w, int M, int C, void* wf, void* wd, ssad_
   return (int)hipGetLastError();
 }
 
-int ssad_conv3x3_forward_f16(const void* xb, const void* wp, const float* bias, const void* aux, int N,
-                             int C, int H, int W, int M, int flags, void* y, ssad_stream_t stream) {
-  if (!xb || !wp || !y || N < 0 || M < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
-  if (C < 1) return SSAD_E_BADARG;
+int ssad_conv3x3_forward_f16_levels(const ssad_f16_level* levels, int n_levels, const void* wp,
+                                    const float* bias, int C, int M, int flags, ssad_stream_t stream) {
+  if (!levels || n_levels < 1 || n_levels > SSAD_MAX_F16_LEVELS || !wp || M < 1 || C < 1)
+    return SSAD_E_BADARG;
   const int nchw = (flags & SSAD_F16_OUT_NCHW_F32) != 0;
+  const int masked = (flags & SSAD_CONV_MASK_AUX) != 0;
   if (!nchw && (M & 7)) return SSAD_E_BADARG;                   // blocked output: whole 8-blocks
-  if (((flags & SSAD_CONV_MASK_AUX) != 0) != (aux != nullptr) || (aux && nchw)) return SSAD_E_BADARG;
-  if (N == 0) return 0;
-  F16Conv p;
-  p.x = static_cast<const uint4*>(xb);
-  p.w = static_cast<const uint4*>(wp);
-  p.bias = bias;
-  p.aux = static_cast<const _Float16*>(aux);
-  p.y = y;
-  p.N = N; p.C = C; p.H = H; p.W = W; p.M = M;
-  p.tiles_x = (W + TS - 1) / TS;
-  p.tiles_y = (H + TS - 1) / TS;
-  p.relu = (flags & SSAD_CONV_RELU) != 0;
-  p.sigmoid = (flags & SSAD_CONV_SIGMOID) != 0;
-  p.out_nchw_f32 = nchw;
-  const long long tiles = (long long)N * p.tiles_x * p.tiles_y;
-  if (tiles >= (1LL << 31) || (long long)N * ((C + 7) / 8 + CBC) * H * W >= (1LL << 31)) return SSAD_E_BADARG;
+  if (masked && nchw) return SSAD_E_BADARG;
+  F16Levels q;
+  long long tiles = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const ssad_f16_level& L = levels[l];
+    if (!L.x || !L.y || L.N < 0 || L.H < 1 || L.W < 1 || masked != (L.aux != nullptr)) return SSAD_E_BADARG;
+    if ((long long)L.N * ((C + 7) / 8 + CBC) * L.H * L.W >= (1LL << 31)) return SSAD_E_BADARG;
+    q.x[l] = static_cast<const uint4*>(L.x);
+    q.y[l] = L.y;
+    q.aux[l] = static_cast<const _Float16*>(L.aux);
+    q.N[l] = L.N; q.H[l] = L.H; q.W[l] = L.W;
+    q.tile0[l] = (int)tiles;
+    tiles += (long long)L.N * ((L.W + TS - 1) / TS) * ((L.H + TS - 1) / TS);
+    if (tiles >= (1LL << 31)) return SSAD_E_BADARG;
+  }
+  for (int l = n_levels; l <= SSAD_MAX_F16_LEVELS; ++l) q.tile0[l] = (int)tiles;
+  if (tiles == 0) return 0;
+  q.n_levels = n_levels;
+  q.w = static_cast<const uint4*>(wp);
+  q.bias = bias;
+  q.C = C; q.M = M;
+  q.relu = (flags & SSAD_CONV_RELU) != 0;
+  q.sigmoid = (flags & SSAD_CONV_SIGMOID) != 0;
+  q.out_nchw_f32 = nchw;
   const dim3 grid((unsigned)tiles, (unsigned)((M + MT - 1) / MT));
   static const int dbg = getenv("SSAD_F16_DBG") ? atoi(getenv("SSAD_F16_DBG")) : 0;
   switch (dbg) {
-    case 1: hipLaunchKernelGGL(conv3x3_f16_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, p); break;
-    case 2: hipLaunchKernelGGL(conv3x3_f16_kernel<2>, grid, dim3(kThreads), 0, (hipStream_t)stream, p); break;
-    case 4: hipLaunchKernelGGL(conv3x3_f16_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, p); break;
-    case 7: hipLaunchKernelGGL(conv3x3_f16_kernel<7>, grid, dim3(kThreads), 0, (hipStream_t)stream, p); break;
-    default: hipLaunchKernelGGL(conv3x3_f16_kernel<0>, grid, dim3(kThreads), 0, (hipStream_t)stream, p);
+    case 1: hipLaunchKernelGGL(conv3x3_f16_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, q); break;
+    case 2: hipLaunchKernelGGL(conv3x3_f16_kernel<2>, grid, dim3(kThreads), 0, (hipStream_t)stream, q); break;
+    case 4: hipLaunchKernelGGL(conv3x3_f16_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, q); break;
+    case 7: hipLaunchKernelGGL(conv3x3_f16_kernel<7>, grid, dim3(kThreads), 0, (hipStream_t)stream, q); break;
+    default: hipLaunchKernelGGL(conv3x3_f16_kernel<0>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
   }
   return (int)hipGetLastError();
+}
+
+int ssad_conv3x3_forward_f16(const void* xb, const void* wp, const float* bias, const void* aux, int N,
+                             int C, int H, int W, int M, int flags, void* y, ssad_stream_t stream) {
+  if (((flags & SSAD_CONV_MASK_AUX) != 0) != (aux != nullptr)) return SSAD_E_BADARG;
+  ssad_f16_level L;
+  L.x = xb; L.y = y; L.aux = aux; L.N = N; L.H = H; L.W = W;
+  return ssad_conv3x3_forward_f16_levels(&L, 1, wp, bias, C, M, flags, stream);
 }
 
 }  // extern "C"
@@ -547,36 +586,49 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
   }
 }
 
-// dW[m][c][tap] (+)= sum_split part[split][tap][m][c]
+// dW[m][c][tap] (+)= scale * sum_split part[split][tap][m][c]; the threads past 9 M C fold the
+// bias-gradient partials the same way: db[m] (+)= scale * sum_split dbpart[split][m]
+constexpr int kDbSplits = 64;
 __global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_kernel(const float* __restrict__ part,
                                                                     int splits, int M, int C,
                                                                     int accumulate, float scale,
-                                                                    float* __restrict__ dw) {
-  const int i = blockIdx.x * kThreads + threadIdx.x;       // over [tap][m][c]
+                                                                    float* __restrict__ dw,
+                                                                    const float* __restrict__ dbpart,
+                                                                    float* __restrict__ db) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;       // over [tap][m][c], then [m]
   const int total = 9 * M * C;
-  if (i >= total) return;
-  float s = 0.0f;
-  for (int k = 0; k < splits; ++k) s += part[(long long)k * total + i];
-  s *= scale;
-  const int c = i % C, m = (i / C) % M, tap = i / (C * M);
-  float* o = dw + ((long long)m * C + c) * 9 + tap;
-  *o = accumulate ? *o + s : s;
+  if (i < total) {
+    float s = 0.0f;
+    for (int k = 0; k < splits; ++k) s += part[(long long)k * total + i];
+    s *= scale;
+    const int c = i % C, m = (i / C) % M, tap = i / (C * M);
+    float* o = dw + ((long long)m * C + c) * 9 + tap;
+    *o = accumulate ? *o + s : s;
+  } else if (db && i < total + M) {
+    const int m = i - total, Mp = (M + 7) & ~7;
+    float s = 0.0f;
+    for (int k = 0; k < kDbSplits; ++k) s += dbpart[k * Mp + m];
+    s *= scale;
+    db[m] = accumulate ? db[m] + s : s;
+  }
 }
 
-// db[m] (+)= sum over n, y, x of the blocked fp16 dY (one workgroup per channel block)
+// dbpart[split][m] = sum of the blocked fp16 dY over the split's share of the N * H * W pixels
+// (grid: channel blocks x kDbSplits)
 __global__ __launch_bounds__(kThreads) void f16_bias_grad_kernel(const uint4* __restrict__ dy, int N,
-                                                                 int M, int plane, int accumulate,
-                                                                 float scale, float* __restrict__ db) {
+                                                                 int M, int plane,
+                                                                 float* __restrict__ dbpart) {
   __shared__ float red[kThreads / 64][8];
   const int MB = (M + 7) >> 3, mb = blockIdx.x;
+  const long long total = (long long)N * plane;
+  const long long per = (total + kDbSplits - 1) / kDbSplits;
+  const long long p0 = blockIdx.y * per, p1 = p0 + per < total ? p0 + per : total;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int n = 0; n < N; ++n) {
-    const uint4* src = dy + ((long long)n * MB + mb) * plane;
-    for (int i = threadIdx.x; i < plane; i += kThreads) {
-      const half8 v = as_half8(src[i]);
+  for (long long i = p0 + threadIdx.x; i < p1; i += kThreads) {
+    const long long n = i / plane, px = i % plane;
+    const half8 v = as_half8(dy[(n * MB + mb) * plane + px]);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
-    }
+    for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -585,12 +637,10 @@ __global__ __launch_bounds__(kThreads) void f16_bias_grad_kernel(const uint4* __
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][e] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 8 && mb * 8 + threadIdx.x < M) {
+  if (threadIdx.x < 8) {
     float v = 0.0f;
     for (int w = 0; w < kThreads / 64; ++w) v += red[w][threadIdx.x];
-    v *= scale;
-    float* o = db + mb * 8 + threadIdx.x;
-    *o = accumulate ? *o + v : v;
+    dbpart[blockIdx.y * (MB * 8) + mb * 8 + threadIdx.x] = v;
   }
 }
 
@@ -607,7 +657,8 @@ extern "C" {
 size_t ssad_conv3x3_wgrad_f16_workspace_bytes(int N, int C, int H, int W, int M) {
   const int blocks = ((M + W_OT - 1) / W_OT) * ((C + W_CT - 1) / W_CT);
   const int stages = N * ((H + WR - 1) / WR) * ((W + WPX - 1) / WPX);
-  return (size_t)wgrad_splits(blocks, stages) * 9 * (size_t)M * (size_t)C * sizeof(float);
+  return ((size_t)wgrad_splits(blocks, stages) * 9 * (size_t)M * (size_t)C +
+          (size_t)kDbSplits * (size_t)((M + 7) & ~7)) * sizeof(float);
 }
 
 int ssad_conv3x3_wgrad_f16(const void* x_blocked, const void* dy_blocked, int N, int C, int H, int W,
@@ -638,11 +689,12 @@ int ssad_conv3x3_wgrad_f16(const void* x_blocked, const void* dy_blocked, int N,
     hipLaunchKernelGGL(conv3x3_wgrad_f16_kernel, dim3(blocks, splits, 3), dim3(kThreads), 2 * W_STAGE * 16, s,
                        p);
   }
-  hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3((9 * M * C + kThreads - 1) / kThreads), dim3(kThreads),
-                     0, s, p.part, N > 0 ? splits : 0, M, C, accumulate, scale, dw);
+  float* dbpart = p.part + (size_t)splits * 9 * (size_t)M * (size_t)C;
   if (db)
-    hipLaunchKernelGGL(f16_bias_grad_kernel, dim3((M + 7) / 8), dim3(kThreads), 0, s, p.dy, N, M, H * W,
-                       accumulate, scale, db);
+    hipLaunchKernelGGL(f16_bias_grad_kernel, dim3((M + 7) / 8, kDbSplits), dim3(kThreads), 0, s, p.dy, N, M,
+                       H * W, dbpart);
+  hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3((9 * M * C + M + kThreads - 1) / kThreads), dim3(kThreads),
+                     0, s, p.part, N > 0 ? splits : 0, M, C, accumulate, scale, dw, dbpart, db);
   return (int)hipGetLastError();
 }
 

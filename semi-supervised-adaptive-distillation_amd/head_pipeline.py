@@ -402,33 +402,25 @@ class DistillHeadsF16(DistillHeads):
         self.fpn_in = self.in_blk["student"]
         tx = {"cls": self.in_blk["teacher"], "bbox": self.in_blk["teacher"]}
         sx = {"cls": self.fpn_in, "bbox": self.fpn_in}
-        nlev = len(self.shapes)
+        F = K.conv3x3_forward_f16_levels          # all five levels of a layer in one launch
         for i in range(cfg.num_convs):
             for t in ("cls", "bbox"):
                 name = self._layers(t)[i]
                 if t == "cls" or self.teacher_bbox_tower:
                     out = self.t_buf[t][i & 1]
-                    for l in range(nlev):
-                        K.conv3x3_forward_f16(tx[t][l], self.t_packed[name], self.teacher[name + "_b"], D, D,
-                                              relu=True, out=out[l])
+                    F(tx[t], self.t_packed[name], self.teacher[name + "_b"], D, D, out, relu=True)
                     tx[t] = out
                 out = self.act[t][i]
-                for l in range(nlev):
-                    K.conv3x3_forward_f16(sx[t][l], self.packed[name][0], self.params[name + "_b"], D, D,
-                                          relu=True, out=out[l])
+                F(sx[t], self.packed[name][0], self.params[name + "_b"], D, D, out, relu=True)
                 sx[t] = out
         cp, bp = self._layers("cls")[-1], self._layers("bbox")[-1]
         AC, A4 = self.A * self.C, 4 * self.A
-        for l in range(nlev):
-            K.conv3x3_forward_f16(tx["cls"][l], self.t_packed[cp], self.teacher[cp + "_b"], D, AC,
-                                  sigmoid=True, out_nchw_f32=True, out=self.t_prob[l])
-            K.conv3x3_forward_f16(sx["cls"][l], self.packed[cp][0], self.params[cp + "_b"], D, AC,
-                                  out_nchw_f32=True, out=self.cls_logits[l])
-            K.conv3x3_forward_f16(sx["bbox"][l], self.packed[bp][0], self.params[bp + "_b"], D, A4,
-                                  out_nchw_f32=True, out=self.bbox_pred[l])
-            if self.teacher_bbox_tower:
-                K.conv3x3_forward_f16(tx["bbox"][l], self.t_packed[bp], self.teacher[bp + "_b"], D, A4,
-                                      out_nchw_f32=True, out=self.t_bbox[l])
+        F(tx["cls"], self.t_packed[cp], self.teacher[cp + "_b"], D, AC, self.t_prob, sigmoid=True,
+          out_nchw_f32=True)
+        F(sx["cls"], self.packed[cp][0], self.params[cp + "_b"], D, AC, self.cls_logits, out_nchw_f32=True)
+        F(sx["bbox"], self.packed[bp][0], self.params[bp + "_b"], D, A4, self.bbox_pred, out_nchw_f32=True)
+        if self.teacher_bbox_tower:
+            F(tx["bbox"], self.t_packed[bp], self.teacher[bp + "_b"], D, A4, self.t_bbox, out_nchw_f32=True)
         return self.cls_logits, self.bbox_pred
 
     def backward(self, d_bbox_pred):
@@ -446,9 +438,7 @@ class DistillHeadsF16(DistillHeads):
             K.conv3x3_wgrad_f16(x_in, dy[t], D, Cout, scale=1.0 / S, dW=self.grads[name + "_w"],
                                 db=self.grads[name + "_b"])
             out = self.dbuf[t][nl & 1]
-            for l in range(nlev):
-                K.conv3x3_forward_f16(dy[t][l], self.packed[name][1], None, Cout, D, mask_by=x_in[l],
-                                      out=out[l])
+            K.conv3x3_forward_f16_levels(dy[t], self.packed[name][1], None, Cout, D, out, mask_bys=x_in)
             dy[t] = out
         for li in range(nl - 1, -1, -1):
             for t in ("cls", "bbox"):
@@ -457,9 +447,8 @@ class DistillHeadsF16(DistillHeads):
                 K.conv3x3_wgrad_f16(x_in, dy[t], D, D, scale=1.0 / S, dW=self.grads[name + "_w"],
                                     db=self.grads[name + "_b"])
                 out = self.dbuf[t][li & 1]
-                for l in range(nlev):
-                    K.conv3x3_forward_f16(dy[t][l], self.packed[name][1], None, D, D,
-                                          mask_by=x_in[l] if li > 0 else None, out=out[l])
+                K.conv3x3_forward_f16_levels(dy[t], self.packed[name][1], None, D, D, out,
+                                             mask_bys=x_in if li > 0 else None)
                 dy[t] = out
             if li == nl // 2:
                 self._allreduce_async("late")

@@ -47,6 +47,11 @@ class ConvLevel(C.Structure):
                 ("packed", C.c_void_p), ("bias", C.c_void_p)]
 
 
+class F16Level(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("aux", C.c_void_p),
+                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int)]
+
+
 _lib = None
 
 
@@ -99,6 +104,7 @@ def lib():
     L.ssad_f16_filter_halves.argtypes = [i32, i32]
     L.ssad_f16_pack_filter.argtypes = [vp, i32, i32, vp, vp, vp]
     L.ssad_conv3x3_forward_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.ssad_conv3x3_forward_f16_levels.argtypes = [C.POINTER(F16Level), i32, vp, vp, i32, i32, i32, vp]
     L.ssad_conv3x3_wgrad_f16_workspace_bytes.restype = sz
     L.ssad_conv3x3_wgrad_f16_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     L.ssad_conv3x3_wgrad_f16.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, sz, vp]
@@ -565,6 +571,28 @@ def conv3x3_forward_f16(xb, packed, bias, Cin, Cout, *, relu=False, sigmoid=Fals
     _check(lib().ssad_conv3x3_forward_f16(_ptr(xb), _ptr(packed), _ptr(bias), _ptr(mask_by), N, Cin, H, W,
                                           Cout, flags, _ptr(y), _stream()), "conv3x3_forward_f16")
     return y
+
+
+def conv3x3_forward_f16_levels(xbs, packed, bias, Cin, Cout, outs, *, relu=False, sigmoid=False,
+                               mask_bys=None, out_nchw_f32=False):
+    """conv3x3_forward_f16 for every FPN level sharing the filter in one launch; `outs`
+    (and `mask_bys`) are per-level lists."""
+    n = len(xbs)
+    arr = (F16Level * n)()
+    for i, (xb, y) in enumerate(zip(xbs, outs)):
+        N, CB, H, W, _ = xb.shape
+        assert xb.dtype == torch.float16 and xb.is_contiguous() and CB == (Cin + 7) // 8
+        assert y.is_contiguous() and y.dtype == (torch.float32 if out_nchw_f32 else torch.float16)
+        arr[i].x, arr[i].y = xb.data_ptr(), y.data_ptr()
+        arr[i].aux = mask_bys[i].data_ptr() if mask_bys is not None else None
+        arr[i].N, arr[i].H, arr[i].W = N, H, W
+    if bias is not None:
+        _f32c(bias, "bias")
+    flags = ((CONV_RELU if relu else 0) | (CONV_SIGMOID if sigmoid else 0)
+             | (CONV_MASK_AUX if mask_bys is not None else 0) | (F16_OUT_NCHW_F32 if out_nchw_f32 else 0))
+    _check(lib().ssad_conv3x3_forward_f16_levels(arr, n, _ptr(packed), _ptr(bias), Cin, Cout, flags,
+                                                 _stream()), "conv3x3_forward_f16_levels")
+    return outs
 
 
 def conv3x3_wgrad_f16(xbs, dybs, Cin, Cout, *, scale=1.0, dW=None, db=None, bias_grad=True):
