@@ -223,6 +223,7 @@ def main():
     else:
         from ssad_amd.harness.full_model import FullDistillModel
         model = FullDistillModel(heads, student_depth=args.student, teacher_depth=args.teacher, device=dev,
+                                 backbone_f16=f16,
                                  process_group=pg, world_size=world)
         images = torch.randn((N, 3) + image_hw, device=dev, generator=gen)
 
@@ -285,7 +286,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(host / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 storage / f32 accumulate in the subnets (backbones f32)" if f16 else "f32",
+            "dtype": ("f16 storage / f32 accumulate (subnets: this repo's kernels; backbones: torch "
+                      "autocast on MIOpen / rocBLAS)" if f16 else "f32"),
             "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": N, "image": "3x%dx%d" % image_hw,
                        "fpn_levels": [list(s) for s in shapes], "anchors": 9, "classes": 80,

@@ -332,7 +332,16 @@ class FullDistillModel(object):
     """One distillation iteration of the whole detector on one GPU."""
 
     def __init__(self, heads, student_depth=50, teacher_depth=101, device="cuda",
-                 process_group=None, world_size=1, lr=1e-5, momentum=0.9, weight_decay=1e-4):
+                 process_group=None, world_size=1, lr=1e-5, momentum=0.9, weight_decay=1e-4,
+                 backbone_f16=False):
+        """backbone_f16: run both backbones under torch.autocast(float16) on MIOpen / rocBLAS
+        (fp32 master weights; config 5's precision for the part of the model this repo does not
+        own).  This repo's fp32 backbone kernels are then out of the picture: the plain
+        nn.Conv2d route, channels-last."""
+        global _HIP3X3, _FUSE_TAIL, _GEMM_1X1
+        self.backbone_f16 = backbone_f16
+        if backbone_f16:
+            _HIP3X3 = _FUSE_TAIL = _GEMM_1X1 = False
         self.heads = heads
         self.pg, self.world = process_group, world_size
         g = torch.Generator().manual_seed(7)
@@ -347,6 +356,8 @@ class FullDistillModel(object):
         if os.environ.get("SSAD_HARNESS_BENCHMARK", "0") == "1":
             torch.backends.cudnn.benchmark = True
         self.channels_last = os.environ.get("SSAD_HARNESS_NHWC", "0" if _HIP3X3 else "1") == "1"
+        self._cast = (lambda: torch.autocast("cuda", dtype=torch.float16)) if backbone_f16 else \
+            (lambda: torch.autocast("cuda", enabled=False))
         if self.channels_last:
             self.student = self.student.to(memory_format=torch.channels_last)
             self.teacher = self.teacher.to(memory_format=torch.channels_last)
@@ -394,20 +405,22 @@ class FullDistillModel(object):
             cur = torch.cuda.current_stream()
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
-                with torch.no_grad():
-                    t_fpn = [t.contiguous() for t in self.teacher(images)]
-            s_fpn = self.student(images)
-            s_in = [t.detach().contiguous() for t in s_fpn]
+                with torch.no_grad(), self._cast():
+                    t_fpn = [t.float().contiguous() for t in self.teacher(images)]
+            with self._cast():
+                s_fpn = self.student(images)
+            s_in = [t.detach().float().contiguous() for t in s_fpn]
             cur.wait_stream(self.side)
             for t in t_fpn:
                 t.record_stream(cur)
             self._mark("teacher + student backbone fwd (two streams)")
         else:
-            with torch.no_grad():
-                t_fpn = [t.contiguous() for t in self.teacher(images)]
+            with torch.no_grad(), self._cast():
+                t_fpn = [t.float().contiguous() for t in self.teacher(images)]
             self._mark("teacher backbone fwd")
-            s_fpn = self.student(images)
-            s_in = [t.detach().contiguous() for t in s_fpn]
+            with self._cast():
+                s_fpn = self.student(images)
+            s_in = [t.detach().float().contiguous() for t in s_fpn]
             self._mark("student backbone fwd")
         h.forward_all(t_fpn, s_in)
         self._mark("subnets fwd (teacher+student)")
@@ -421,7 +434,7 @@ class FullDistillModel(object):
         # MIOpen's backward to its slow non-packed fallback kernels)
         grads = []
         for a, b, f in zip(d_fpn["cls"], d_fpn["bbox"], s_fpn):
-            g = a + b
+            g = (a + b).to(f.dtype)
             if self.channels_last:
                 g = g.contiguous(memory_format=torch.channels_last)
             grads.append(g)
