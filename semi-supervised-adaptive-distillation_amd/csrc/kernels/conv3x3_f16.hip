@@ -125,7 +125,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Level
 
   // ---- operand addressing
   // B (pixels): MFMA column j -> tile row 2 tt + (j >> 4) of this wave's 8 rows, column j & 15
-  const int brow = wp * 8 + (j >> 4), bcol = j & 15;
+  // The second row's columns are rotated by 2: ds_read_b128 is serviced in the 16-lane groups
+  // {0-3,12-15,20-27} and {4-11,16-19,28-31} (+32), and with the natural order the two rows of
+  // a group (18 slots apart) collide on two 16-byte bank slots -- 2x the LDS cycles.
+  const int brow = wp * 8 + (j >> 4), bcol = (j & 16) ? ((j - 2) & 15) : j;
   const int bbase = (h * HS + brow) * HS + bcol;           // + ((2 ks) * HS + 2 tt + dy) * HS + dx
   // A (filter): row = output channel, clamped into range (rows beyond M are never stored)
   int aoc[2];
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Level
     const int oc0 = ocb + wo * 64 + i * 32;
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
-      const int gy = y0 + wp * 8 + 2 * tt + (j >> 4), gx = x0 + (j & 15);
+      const int gy = y0 + wp * 8 + 2 * tt + (j >> 4), gx = x0 + bcol;
       if (gy >= p.H || gx >= p.W) continue;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {

@@ -103,6 +103,27 @@ def main():
             t = timeit(lambda: K.conv_pack_filter(Wt))
             print("%-18s pack             %8.3f ms" % (name, t))
             del Xs, dYs, Ys, dXs
+    if "f16" in a.what:
+        for (M, Cin, name) in ((256, 256, "tower 256->256"), (720, 256, "cls_pred 256->720")):
+            Xb = [K.f16_pack_activations(torch.randn((N, Cin, h, w), device=dev)) for h, w in shapes]
+            dYb = [K.f16_pack_activations(torch.randn((N, M, h, w), device=dev)) for h, w in shapes]
+            Wt = torch.randn((M, Cin, 3, 3), device=dev) * 0.01
+            b = torch.zeros(M, device=dev)
+            wf, wd = K.f16_pack_filter(Wt, True, True)
+            px = sum(N * h * w for h, w in shapes)
+            fl = 2.0 * 9 * M * Cin * px
+            nchw = M == 720
+            Ys = [torch.empty((N, M, h, w), device=dev) if nchw else
+                  torch.empty((N, M // 8, h, w, 8), device=dev, dtype=torch.float16) for h, w in shapes]
+            dXs = [torch.empty_like(x) for x in Xb]
+            t = timeit(lambda: K.conv3x3_forward_f16_levels(Xb, wf, b, Cin, M, Ys, relu=not nchw,
+                                                            out_nchw_f32=nchw))
+            print("%-18s F16 fwd all-lvl  %8.3f ms  %6.1f TF/s" % (name, t, fl / t / 1e9))
+            t = timeit(lambda: K.conv3x3_forward_f16_levels(dYb, wd, None, M, Cin, dXs))
+            print("%-18s F16 dgrad all    %8.3f ms  %6.1f TF/s" % (name, t, fl / t / 1e9))
+            t = timeit(lambda: K.conv3x3_wgrad_f16(Xb, dYb, Cin, M))
+            print("%-18s F16 wgrad all    %8.3f ms  %6.1f TF/s (incl. reduce + dbias)" % (name, t, fl / t / 1e9))
+            del Xb, dYb, Ys, dXs
 
 
 if __name__ == "__main__":

@@ -19,13 +19,15 @@ def main():
     dst = os.path.join(ROOT, "profiles")
     out = {}
     for name, rename in (("pmc_fetch", {"FETCH_SIZE": "FETCH_SIZE_KB_raw"}),
-                         ("pmc_write", {"WRITE_SIZE": "WRITE_SIZE_KB"}), ("pmc_mfma", {})):
+                         ("pmc_write", {"WRITE_SIZE": "WRITE_SIZE_KB"}), ("pmc_mfma", {}), ("pmc_mfma_f16", {})):
+        if not os.path.exists(os.path.join(src, name + ".json")):
+            continue
         d = json.load(open(os.path.join(src, name + ".json")))
         for k, c in d["counters"].items():
             e = out.setdefault(k, {})
             for cn, v in c.items():
                 e[rename.get(cn, cn)] = v
-        if name == "pmc_mfma":
+        if name in ("pmc_mfma", "pmc_mfma_f16"):
             for k, t in d["kernels"].items():
                 if k in out:
                     out[k]["avg_us_mfma_pass"] = t["avg_us"]

@@ -29,6 +29,8 @@ run bench_full_trace "rocprofv3 --kernel-trace --stats: python bench.py --steps 
     --kernel-trace --stats -d /tmp/prof_bench_full_trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline
 run bench_heads_trace "rocprofv3 --kernel-trace --stats: python bench.py --workload heads --steps 5 --warmup 2, the 5 timed steps" \
     --kernel-trace --stats -d /tmp/prof_bench_heads_trace -o t -- python bench.py --workload heads --steps 5 --warmup 2 --no-cpu-baseline
+run bench_heads_f16_trace "rocprofv3 --kernel-trace --stats: python bench.py --workload heads --precision f16 --steps 5 --warmup 2 (fp16 storage subnets; not the headline precision), the 5 timed steps" \
+    --kernel-trace --stats -d /tmp/prof_bench_heads_f16_trace -o t -- python bench.py --workload heads --precision f16 --steps 5 --warmup 2 --no-cpu-baseline
 SUMMARY_ARGS=""
 run pmc_fetch "PMC pass 1 (FETCH_SIZE, KB): python tools/kbench.py" \
     --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_pmc_fetch -o t -- python tools/kbench.py
@@ -36,4 +38,6 @@ run pmc_write "PMC pass 2 (WRITE_SIZE, KB): python tools/kbench.py" \
     --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_pmc_write -o t -- python tools/kbench.py
 run pmc_mfma "PMC pass 3 (MFMA / LDS): python tools/kbench.py --what conv" \
     --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES -d /tmp/prof_pmc_mfma -o t -- python tools/kbench.py --what conv
+run pmc_mfma_f16 "PMC pass 4 (MFMA / LDS, fp16 kernels): python tools/kbench.py --what f16" \
+    --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES -d /tmp/prof_pmc_mfma_f16 -o t -- python tools/kbench.py --what f16
 ls -la $O
