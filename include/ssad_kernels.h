@@ -397,6 +397,18 @@ SSAD_API size_t ssad_conv3x3_wgrad_f16_workspace_bytes(int N, int C, int H, int 
 SSAD_API int ssad_conv3x3_wgrad_f16(const void* x_blocked, const void* dy_blocked, int N, int C, int H,
                                     int W, int M, int accumulate, float scale, float* dw, float* db,
                                     void* workspace, size_t workspace_bytes, ssad_stream_t stream);
+/* The same summed over every FPN level sharing the filter, in one launch */
+typedef struct ssad_f16_wgrad_level {
+  const void* x;      /* blocked fp16 [N][ceil(C/8)][H][W][8] */
+  const void* dy;     /* blocked fp16 [N][ceil(M/8)][H][W][8] */
+  int N, H, W;
+} ssad_f16_wgrad_level;
+SSAD_API size_t ssad_conv3x3_wgrad_f16_levels_workspace_bytes(const ssad_f16_wgrad_level* levels_host,
+                                                              int n_levels, int C, int M);
+SSAD_API int ssad_conv3x3_wgrad_f16_levels(const ssad_f16_wgrad_level* levels_host, int n_levels, int C,
+                                           int M, int accumulate, float scale, float* dw, float* db,
+                                           void* workspace, size_t workspace_bytes,
+                                           ssad_stream_t stream);
 
 /* ---------------------------------------------------------------------- */
 /* Introspection                                                           */

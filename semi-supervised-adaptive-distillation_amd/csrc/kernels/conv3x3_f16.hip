@@ -446,13 +446,15 @@ constexpr int W_STAGE = Y_BASE + Y_PAIRS * Y_PITCH;      // 4736 slots = 74 KiB 
 constexpr int X_PIECES = X_PAIRS * (X_PAIR / 64);        // 40
 constexpr int Y_PIECES = Y_PAIRS * (Y_PAIR / 64);        // 32
 
-struct F16Wgrad {
-  const uint4* x;      // blocked fp16 [N][CB][H][W]
-  const uint4* dy;     // blocked fp16 [N][MB][H][W]
+struct F16Wgrad {           // all FPN levels sharing the filter: their stages form one list
+  const uint4* x[SSAD_MAX_F16_LEVELS];      // blocked fp16 [N][CB][H][W]
+  const uint4* dy[SSAD_MAX_F16_LEVELS];     // blocked fp16 [N][MB][H][W]
+  int N[SSAD_MAX_F16_LEVELS], H[SSAD_MAX_F16_LEVELS], W[SSAD_MAX_F16_LEVELS];
+  int stage0[SSAD_MAX_F16_LEVELS + 1];      // first stage of each level
+  int n_levels;
   float* part;         // [split][9][M][C]
-  int N, C, H, W, M;
-  int seg_x, seg_y;    // row segments per row, row groups per image
-  int stages;          // N * seg_y * seg_x
+  int C, M;
+  int stages;          // sum over levels of N * row groups * row segments
   int cblocks;         // ceil(C / 128)
 };
 
@@ -474,21 +476,27 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
   const int ky = blockIdx.z;
   const int ocb = (blockIdx.x / p.cblocks) * W_OT, ccb = (blockIdx.x % p.cblocks) * (W_CT / 8);
   const int CB = (p.C + 7) >> 3, MB = (p.M + 7) >> 3;
-  const int plane = p.H * p.W;
   // this workgroup's share of the pixel stages
   const int per = (p.stages + gridDim.y - 1) / gridDim.y;
   const int s0 = blockIdx.y * per, s1 = min(s0 + per, p.stages);
 
-  const __amdgpu_buffer_rsrc_t xrs = ssad_dev::uniform_rsrc(p.x, (unsigned)((long long)p.N * CB * plane * 16));
-  const __amdgpu_buffer_rsrc_t yrs = ssad_dev::uniform_rsrc(p.dy, (unsigned)((long long)p.N * MB * plane * 16));
   constexpr unsigned kOob = 0x80000000u;
   // lane's place inside a 64-slot DMA piece: slot = 2 * pixel + (block & 1)
   const int lpix = lane >> 1, lodd = lane & 1;
   auto fetch = [&](int s, int buf) {
-    int t = s;
-    const int sx = t % p.seg_x; t /= p.seg_x;
-    const int sy = t % p.seg_y;
-    const int n = t / p.seg_y;
+    int lv = 0;
+    for (int l = 1; l < p.n_levels; ++l)
+      if (s >= p.stage0[l]) lv = l;
+    const int H = p.H[lv], W = p.W[lv], plane = H * W;
+    const int seg_x = (W + WPX - 1) / WPX, seg_y = (H + WR - 1) / WR;
+    const __amdgpu_buffer_rsrc_t xrs =
+        ssad_dev::uniform_rsrc(p.x[lv], (unsigned)((long long)p.N[lv] * CB * plane * 16));
+    const __amdgpu_buffer_rsrc_t yrs =
+        ssad_dev::uniform_rsrc(p.dy[lv], (unsigned)((long long)p.N[lv] * MB * plane * 16));
+    int t = s - p.stage0[lv];
+    const int sx = t % seg_x; t /= seg_x;
+    const int sy = t % seg_y;
+    const int n = t / seg_y;
     const int y0 = sy * WR, x0 = sx * WPX;
     auto* dst = (__attribute__((address_space(3))) uint4*)lds + buf * W_STAGE;
 #pragma unroll
@@ -499,8 +507,8 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
       const int gy = y0 + ky - 1 + pix / XPW, gx = x0 - 1 + pix % XPW;
       const int cb = ccb + pair * 2 + lodd;
       unsigned off = kOob;
-      if (cb < CB && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-        off = (unsigned)(((n * CB + cb) * plane + gy * p.W + gx) * 16);
+      if (cb < CB && gy >= 0 && gy < H && gx >= 0 && gx < W)
+        off = (unsigned)(((n * CB + cb) * plane + gy * W + gx) * 16);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           xrs, (__attribute__((address_space(3))) void*)(dst + pair * X_PITCH + q * 64), 16, off, 0, 0, 0);
     }
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
       const int gy = y0 + pix / WPX, gx = x0 + pix % WPX;
       const int mb = (ocb >> 3) + pair * 2 + lodd;
       unsigned off = kOob;
-      if (mb < MB && gy < p.H && gx < p.W) off = (unsigned)(((n * MB + mb) * plane + gy * p.W + gx) * 16);
+      if (mb < MB && gy < H && gx < W) off = (unsigned)(((n * MB + mb) * plane + gy * W + gx) * 16);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           yrs, (__attribute__((address_space(3))) void*)(dst + Y_BASE + pair * Y_PITCH + q * 64), 16, off, 0, 0,
           0);
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_kernel(const float*
                                                                     int accumulate, float scale,
                                                                     float* __restrict__ dw,
                                                                     const float* __restrict__ dbpart,
-                                                                    float* __restrict__ db) {
+                                                                    int dbparts, float* __restrict__ db) {
   const int i = blockIdx.x * kThreads + threadIdx.x;       // over [tap][m][c], then [m]
   const int total = 9 * M * C;
   if (i < total) {
@@ -610,7 +618,7 @@ __global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_kernel(const float*
   } else if (db && i < total + M) {
     const int m = i - total, Mp = (M + 7) & ~7;
     float s = 0.0f;
-    for (int k = 0; k < kDbSplits; ++k) s += dbpart[k * Mp + m];
+    for (int k = 0; k < dbparts; ++k) s += dbpart[k * Mp + m];
     s *= scale;
     db[m] = accumulate ? db[m] + s : s;
   }
@@ -657,33 +665,53 @@ int wgrad_splits(int blocks, int stages) {
 
 extern "C" {
 
-size_t ssad_conv3x3_wgrad_f16_workspace_bytes(int N, int C, int H, int W, int M) {
+namespace {
+int wgrad_stages(const ssad_f16_wgrad_level* levels, int n_levels) {
+  long long st = 0;
+  for (int l = 0; l < n_levels; ++l)
+    st += (long long)levels[l].N * ((levels[l].H + WR - 1) / WR) * ((levels[l].W + WPX - 1) / WPX);
+  return st > 0x7fffffff ? 0x7fffffff : (int)st;
+}
+}  // namespace
+
+size_t ssad_conv3x3_wgrad_f16_levels_workspace_bytes(const ssad_f16_wgrad_level* levels, int n_levels, int C,
+                                                     int M) {
+  if (!levels || n_levels < 1) return 0;
   const int blocks = ((M + W_OT - 1) / W_OT) * ((C + W_CT - 1) / W_CT);
-  const int stages = N * ((H + WR - 1) / WR) * ((W + WPX - 1) / WPX);
-  return ((size_t)wgrad_splits(blocks, stages) * 9 * (size_t)M * (size_t)C +
-          (size_t)kDbSplits * (size_t)((M + 7) & ~7)) * sizeof(float);
+  const int stages = wgrad_stages(levels, n_levels);
+  return ((size_t)wgrad_splits(blocks, stages > 0 ? stages : 1) * 9 * (size_t)M * (size_t)C +
+          (size_t)n_levels * kDbSplits * (size_t)((M + 7) & ~7)) * sizeof(float);
 }
 
-int ssad_conv3x3_wgrad_f16(const void* x_blocked, const void* dy_blocked, int N, int C, int H, int W,
-                           int M, int accumulate, float scale, float* dw, float* db, void* workspace,
-                           size_t workspace_bytes, ssad_stream_t stream) {
-  if (!x_blocked || !dy_blocked || !dw || N < 0 || C < 1 || M < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
-  if ((long long)N * (((C > M ? C : M) + 7) / 8) * H * W >= (1LL << 31)) return SSAD_E_BADARG;
-  if (workspace_bytes < ssad_conv3x3_wgrad_f16_workspace_bytes(N, C, H, W, M) || !workspace)
-    return SSAD_E_WORKSPACE;
+int ssad_conv3x3_wgrad_f16_levels(const ssad_f16_wgrad_level* levels, int n_levels, int C, int M,
+                                  int accumulate, float scale, float* dw, float* db, void* workspace,
+                                  size_t workspace_bytes, ssad_stream_t stream) {
+  if (!levels || n_levels < 1 || n_levels > SSAD_MAX_F16_LEVELS || !dw || C < 1 || M < 1) return SSAD_E_BADARG;
   F16Wgrad p;
-  p.x = static_cast<const uint4*>(x_blocked);
-  p.dy = static_cast<const uint4*>(dy_blocked);
+  long long stages = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const ssad_f16_wgrad_level& L = levels[l];
+    if (!L.x || !L.dy || L.N < 0 || L.H < 1 || L.W < 1) return SSAD_E_BADARG;
+    if ((long long)L.N * (((C > M ? C : M) + 7) / 8) * L.H * L.W >= (1LL << 31)) return SSAD_E_BADARG;
+    p.x[l] = static_cast<const uint4*>(L.x);
+    p.dy[l] = static_cast<const uint4*>(L.dy);
+    p.N[l] = L.N; p.H[l] = L.H; p.W[l] = L.W;
+    p.stage0[l] = (int)stages;
+    stages += (long long)L.N * ((L.H + WR - 1) / WR) * ((L.W + WPX - 1) / WPX);
+    if (stages >= (1LL << 31)) return SSAD_E_BADARG;
+  }
+  for (int l = n_levels; l <= SSAD_MAX_F16_LEVELS; ++l) p.stage0[l] = (int)stages;
+  if (workspace_bytes < ssad_conv3x3_wgrad_f16_levels_workspace_bytes(levels, n_levels, C, M) || !workspace)
+    return SSAD_E_WORKSPACE;
+  p.n_levels = n_levels;
   p.part = static_cast<float*>(workspace);
-  p.N = N; p.C = C; p.H = H; p.W = W; p.M = M;
-  p.seg_x = (W + WPX - 1) / WPX;
-  p.seg_y = (H + WR - 1) / WR;
-  p.stages = N * p.seg_y * p.seg_x;
+  p.C = C; p.M = M;
+  p.stages = (int)stages;
   p.cblocks = (C + W_CT - 1) / W_CT;
   const int blocks = ((M + W_OT - 1) / W_OT) * p.cblocks;
   const int splits = wgrad_splits(blocks, p.stages > 0 ? p.stages : 1);
   hipStream_t s = (hipStream_t)stream;
-  if (N > 0) {
+  if (p.stages > 0) {
     static const bool attr = [] {
       return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE * 16) == hipSuccess;
@@ -693,12 +721,30 @@ int ssad_conv3x3_wgrad_f16(const void* x_blocked, const void* dy_blocked, int N,
                        p);
   }
   float* dbpart = p.part + (size_t)splits * 9 * (size_t)M * (size_t)C;
+  const size_t Mp = (size_t)((M + 7) & ~7);
   if (db)
-    hipLaunchKernelGGL(f16_bias_grad_kernel, dim3((M + 7) / 8, kDbSplits), dim3(kThreads), 0, s, p.dy, N, M,
-                       H * W, dbpart);
+    for (int l = 0; l < n_levels; ++l)
+      hipLaunchKernelGGL(f16_bias_grad_kernel, dim3((M + 7) / 8, kDbSplits), dim3(kThreads), 0, s, p.dy[l],
+                         p.N[l], M, p.H[l] * p.W[l], dbpart + (size_t)l * kDbSplits * Mp);
   hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3((9 * M * C + M + kThreads - 1) / kThreads), dim3(kThreads),
-                     0, s, p.part, N > 0 ? splits : 0, M, C, accumulate, scale, dw, dbpart, db);
+                     0, s, p.part, p.stages > 0 ? splits : 0, M, C, accumulate, scale, dw, dbpart,
+                     n_levels * kDbSplits, db);
   return (int)hipGetLastError();
+}
+
+size_t ssad_conv3x3_wgrad_f16_workspace_bytes(int N, int C, int H, int W, int M) {
+  ssad_f16_wgrad_level L;
+  L.x = L.dy = nullptr; L.N = N; L.H = H; L.W = W;
+  return ssad_conv3x3_wgrad_f16_levels_workspace_bytes(&L, 1, C, M);
+}
+
+int ssad_conv3x3_wgrad_f16(const void* x_blocked, const void* dy_blocked, int N, int C, int H, int W,
+                           int M, int accumulate, float scale, float* dw, float* db, void* workspace,
+                           size_t workspace_bytes, ssad_stream_t stream) {
+  ssad_f16_wgrad_level L;
+  L.x = x_blocked; L.dy = dy_blocked; L.N = N; L.H = H; L.W = W;
+  return ssad_conv3x3_wgrad_f16_levels(&L, 1, C, M, accumulate, scale, dw, db, workspace, workspace_bytes,
+                                       stream);
 }
 
 }  // extern "C"

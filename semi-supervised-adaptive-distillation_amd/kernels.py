@@ -47,6 +47,10 @@ class ConvLevel(C.Structure):
                 ("packed", C.c_void_p), ("bias", C.c_void_p)]
 
 
+class F16WgradLevel(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int)]
+
+
 class F16Level(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("aux", C.c_void_p),
                 ("N", C.c_int), ("H", C.c_int), ("W", C.c_int)]
@@ -108,6 +112,10 @@ def lib():
     L.ssad_conv3x3_wgrad_f16_workspace_bytes.restype = sz
     L.ssad_conv3x3_wgrad_f16_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     L.ssad_conv3x3_wgrad_f16.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, sz, vp]
+    L.ssad_conv3x3_wgrad_f16_levels_workspace_bytes.restype = sz
+    L.ssad_conv3x3_wgrad_f16_levels_workspace_bytes.argtypes = [C.POINTER(F16WgradLevel), i32, i32, i32]
+    L.ssad_conv3x3_wgrad_f16_levels.argtypes = [C.POINTER(F16WgradLevel), i32, i32, i32, i32, f32, vp, vp,
+                                                vp, sz, vp]
     L.ssad_momentum_sgd_update.argtypes = [vp, vp, vp, vp, f32, f32, i32, i64, vp]
     L.ssad_conv_packed_filter_floats.restype = sz
     L.ssad_conv_packed_filter_floats.argtypes = [i32, i32]
@@ -603,13 +611,16 @@ def conv3x3_wgrad_f16(xbs, dybs, Cin, Cout, *, scale=1.0, dW=None, db=None, bias
     if db is None and bias_grad:
         db = torch.empty((Cout,), dtype=torch.float32, device="cuda")
     L = lib()
+    n = len(xbs)
+    arr = (F16WgradLevel * n)()
     for i, (xb, dyb) in enumerate(zip(xbs, dybs)):
         N, CB, H, W, _ = xb.shape
         assert xb.dtype == torch.float16 and dyb.dtype == torch.float16
         assert xb.is_contiguous() and dyb.is_contiguous()
         assert CB == (Cin + 7) // 8 and dyb.shape == (N, (Cout + 7) // 8, H, W, 8)
-        nbytes = L.ssad_conv3x3_wgrad_f16_workspace_bytes(N, Cin, H, W, Cout)
-        ws = _workspace(nbytes, "wgrad_f16")
-        _check(L.ssad_conv3x3_wgrad_f16(_ptr(xb), _ptr(dyb), N, Cin, H, W, Cout, int(i > 0), float(scale),
-                                        _ptr(dW), _ptr(db), _ptr(ws), nbytes, _stream()), "conv3x3_wgrad_f16")
+        arr[i].x, arr[i].dy, arr[i].N, arr[i].H, arr[i].W = xb.data_ptr(), dyb.data_ptr(), N, H, W
+    nbytes = L.ssad_conv3x3_wgrad_f16_levels_workspace_bytes(arr, n, Cin, Cout)
+    ws = _workspace(nbytes, "wgrad_f16")
+    _check(L.ssad_conv3x3_wgrad_f16_levels(arr, n, Cin, Cout, 0, float(scale), _ptr(dW), _ptr(db), _ptr(ws),
+                                           nbytes, _stream()), "conv3x3_wgrad_f16_levels")
     return dW, db
