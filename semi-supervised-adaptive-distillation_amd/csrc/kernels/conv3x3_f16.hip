@@ -527,7 +527,7 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
     }
   };
 
-  // ---- transpose-read addressing (tools/_tmp/tr.hip): lane l of a 16-lane group addresses
+  // ---- transpose-read addressing (tools/tr16_probe.hip): lane l of a 16-lane group addresses
   // pixel (l & 15) >> 2, channel quad l & 3 of its group's 16 channels = one block pair
   const int g = lane >> 4, i16 = lane & 15;
   const int quad = i16 & 3, pj = i16 >> 2;

@@ -1,3 +1,9 @@
+// Lane -> element map of gfx950's LDS transpose read (ds_read_b64_tr_b16), printed from the
+// device: lane i of a 16-lane group loads the 4 contiguous 16-bit elements at element offset
+// 4 i; lane l receives elements (l & 15) + 16 j (+ 64 per group), j = 0..3 -- i.e. output
+// element j of lane l comes from source lane 4 j + (l & 15) / 4, element (l & 15) % 4.
+// conv3x3_wgrad_f16_kernel's operand addressing is built on this map.
+//   hipcc -O3 --offload-arch=gfx950 tools/tr16_probe.hip -o /tmp/tr16_probe && /tmp/tr16_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef short short4v __attribute__((ext_vector_type(4)));
