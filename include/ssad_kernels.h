@@ -360,6 +360,14 @@ SSAD_API int ssad_f16_pack_activations(const float* x_nchw, int N, int C, int H,
                                        void* x_blocked, ssad_stream_t stream);
 SSAD_API int ssad_f16_unpack_activations(const void* x_blocked, int N, int C, int H, int W, float scale,
                                          float* x_nchw, ssad_stream_t stream);
+/* The same layout change for float16 NCHW blobs (the operator surface's Conv on
+ * TensorProto::FLOAT16 tensors), and plain element casts (round to nearest even) */
+SSAD_API int ssad_f16_block_activations(const void* x_nchw_f16, int N, int C, int H, int W,
+                                        void* x_blocked, ssad_stream_t stream);
+SSAD_API int ssad_f16_unblock_activations(const void* x_blocked, int N, int C, int H, int W,
+                                          void* x_nchw_f16, ssad_stream_t stream);
+SSAD_API int ssad_cast_f16_to_f32(const void* in_f16, float* out, long long n, ssad_stream_t stream);
+SSAD_API int ssad_cast_f32_to_f16(const float* in, void* out_f16, long long n, ssad_stream_t stream);
 /* halves to allocate for either packed form of an [M][C][3][3] filter */
 SSAD_API size_t ssad_f16_filter_halves(int M, int C);
 /* w [M][C][3][3] fp32 -> packed_fwd [9][ceil(C/8)][M][8] and / or packed_dgrad

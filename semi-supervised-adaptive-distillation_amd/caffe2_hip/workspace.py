@@ -7,8 +7,9 @@ import numpy as np
 
 from . import _capi, caffe2_pb2, core
 
+# TensorProto::DataType ids (caffe2.proto:33-49); float16 blobs carry fp16 storage for Conv
 _DT = {np.dtype(np.float32): 1, np.dtype(np.int32): 2, np.dtype(np.int64): 10,
-       np.dtype(np.float64): 13}
+       np.dtype(np.float16): 12, np.dtype(np.float64): 13}
 _NP = {v: k for k, v in _DT.items()}
 
 _ws = None

@@ -40,7 +40,12 @@ struct TypeMeta {
   bool operator==(const TypeMeta& o) const { return id == o.id; }
   bool operator!=(const TypeMeta& o) const { return id != o.id; }
 };
+// storage tag of TensorProto::FLOAT16 blobs (caffe2/core/types.h: struct float16 { uint16_t x; })
+struct float16 {
+  uint16_t x;
+};
 template <> inline TypeMeta TypeMeta::Make<float>() { return {DataType::FLOAT, 4}; }
+template <> inline TypeMeta TypeMeta::Make<float16>() { return {DataType::FLOAT16, 2}; }
 template <> inline TypeMeta TypeMeta::Make<int>() { return {DataType::INT32, 4}; }
 template <> inline TypeMeta TypeMeta::Make<int64_t>() { return {DataType::INT64, 8}; }
 template <> inline TypeMeta TypeMeta::Make<double>() { return {DataType::DOUBLE, 8}; }

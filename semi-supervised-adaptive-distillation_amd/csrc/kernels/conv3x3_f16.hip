@@ -250,7 +250,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Level
 }
 
 // NCHW fp32 -> blocked fp16 (round to nearest even), one thread per 16-byte slot
-__global__ __launch_bounds__(kThreads) void f16_pack_kernel(const float* __restrict__ x,
+template <typename T>   // T = float (the subnet pipeline) or _Float16 (float16 blobs of the operator surface)
+__global__ __launch_bounds__(kThreads) void f16_pack_kernel(const T* __restrict__ x,
                                                             uint4* __restrict__ xb, int N, int C,
                                                             long long plane, float scale) {
   const int CB = (C + 7) >> 3;
@@ -259,18 +260,19 @@ __global__ __launch_bounds__(kThreads) void f16_pack_kernel(const float* __restr
        i += (long long)gridDim.x * kThreads) {
     const long long px = i % plane, ncb = i / plane;      // ncb = n * CB + cb
     const int cb = (int)(ncb % CB);
-    const float* src = x + ((ncb / CB) * C + cb * 8) * plane + px;
+    const T* src = x + ((ncb / CB) * C + cb * 8) * plane + px;
     half8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      o[e] = cb * 8 + e < C ? (_Float16)(src[e * plane] * scale) : (_Float16)0.0f;
+      o[e] = cb * 8 + e < C ? (_Float16)((float)src[e * plane] * scale) : (_Float16)0.0f;
     xb[i] = __builtin_bit_cast(uint4, o);
   }
 }
 
 // blocked fp16 -> NCHW fp32: one thread per (n, cb, pixel); 8 strided 4-byte stores
+template <typename T>
 __global__ __launch_bounds__(kThreads) void f16_unpack_kernel(const uint4* __restrict__ xb,
-                                                              float* __restrict__ x, int N, int C,
+                                                              T* __restrict__ x, int N, int C,
                                                               long long plane, float scale) {
   const int CB = (C + 7) >> 3;
   const long long total = (long long)N * CB * plane;
@@ -279,10 +281,10 @@ __global__ __launch_bounds__(kThreads) void f16_unpack_kernel(const uint4* __res
     const long long px = i % plane, ncb = i / plane;
     const int cb = (int)(ncb % CB);
     const half8 v = as_half8(xb[i]);
-    float* dst = x + ((ncb / CB) * C + cb * 8) * plane + px;
+    T* dst = x + ((ncb / CB) * C + cb * 8) * plane + px;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      if (cb * 8 + e < C) dst[e * plane] = (float)v[e] * scale;
+      if (cb * 8 + e < C) dst[e * plane] = (T)((float)v[e] * scale);
   }
 }
 
@@ -313,6 +315,13 @@ __global__ __launch_bounds__(kThreads) void f16_pack_filter_kernel(const float* 
   }
 }
 
+template <typename A, typename B>
+__global__ __launch_bounds__(kThreads) void cast_kernel(const A* __restrict__ in, B* __restrict__ out,
+                                                        long long n) {
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads)
+    out[i] = (B)(float)in[i];
+}
+
 inline unsigned grid_for(long long n) {
   const long long b = (n + kThreads - 1) / kThreads;
   return (unsigned)(b < 1 ? 1 : (b > 65535 * 16 ? 65535 * 16 : b));
@@ -327,8 +336,8 @@ int ssad_f16_pack_activations(const float* x, int N, int C, int H, int W, float 
   if (!x || !xb || N < 0 || C < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
   if (N == 0) return 0;
   const long long plane = (long long)H * W;
-  hipLaunchKernelGGL(f16_pack_kernel, dim3(grid_for((long long)N * ((C + 7) >> 3) * plane)), dim3(kThreads),
-                     0, (hipStream_t)stream, x, static_cast<uint4*>(xb), N, C, plane, scale);
+  hipLaunchKernelGGL(f16_pack_kernel<float>, dim3(grid_for((long long)N * ((C + 7) >> 3) * plane)),
+                     dim3(kThreads), 0, (hipStream_t)stream, x, static_cast<uint4*>(xb), N, C, plane, scale);
   return (int)hipGetLastError();
 }
 
@@ -337,9 +346,47 @@ int ssad_f16_unpack_activations(const void* xb, int N, int C, int H, int W, floa
   if (!x || !xb || N < 0 || C < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
   if (N == 0) return 0;
   const long long plane = (long long)H * W;
-  hipLaunchKernelGGL(f16_unpack_kernel, dim3(grid_for((long long)N * ((C + 7) >> 3) * plane)),
+  hipLaunchKernelGGL(f16_unpack_kernel<float>, dim3(grid_for((long long)N * ((C + 7) >> 3) * plane)),
                      dim3(kThreads), 0, (hipStream_t)stream, static_cast<const uint4*>(xb), x, N, C,
                      plane, scale);
+  return (int)hipGetLastError();
+}
+
+int ssad_f16_block_activations(const void* x_nchw_f16, int N, int C, int H, int W, void* xb,
+                               ssad_stream_t stream) {
+  if (!x_nchw_f16 || !xb || N < 0 || C < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
+  if (N == 0) return 0;
+  const long long plane = (long long)H * W;
+  hipLaunchKernelGGL(f16_pack_kernel<_Float16>, dim3(grid_for((long long)N * ((C + 7) >> 3) * plane)),
+                     dim3(kThreads), 0, (hipStream_t)stream, static_cast<const _Float16*>(x_nchw_f16),
+                     static_cast<uint4*>(xb), N, C, plane, 1.0f);
+  return (int)hipGetLastError();
+}
+
+int ssad_f16_unblock_activations(const void* xb, int N, int C, int H, int W, void* x_nchw_f16,
+                                 ssad_stream_t stream) {
+  if (!x_nchw_f16 || !xb || N < 0 || C < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
+  if (N == 0) return 0;
+  const long long plane = (long long)H * W;
+  hipLaunchKernelGGL(f16_unpack_kernel<_Float16>, dim3(grid_for((long long)N * ((C + 7) >> 3) * plane)),
+                     dim3(kThreads), 0, (hipStream_t)stream, static_cast<const uint4*>(xb),
+                     static_cast<_Float16*>(x_nchw_f16), N, C, plane, 1.0f);
+  return (int)hipGetLastError();
+}
+
+int ssad_cast_f16_to_f32(const void* in, float* out, long long n, ssad_stream_t stream) {
+  if (n < 0 || (n > 0 && (!in || !out))) return SSAD_E_BADARG;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL((cast_kernel<_Float16, float>), dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream,
+                     static_cast<const _Float16*>(in), out, n);
+  return (int)hipGetLastError();
+}
+
+int ssad_cast_f32_to_f16(const float* in, void* out, long long n, ssad_stream_t stream) {
+  if (n < 0 || (n > 0 && (!in || !out))) return SSAD_E_BADARG;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL((cast_kernel<float, _Float16>), dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, in,
+                     static_cast<_Float16*>(out), n);
   return (int)hipGetLastError();
 }
 

@@ -84,12 +84,23 @@ template <>
 bool ConvOp<float, HIPContext>::RunDefaultEngine();
 template <>
 bool ConvGradientOp<float, HIPContext>::RunDefaultEngine();
+template <>
+bool ConvOp<float, HIPContext>::RunFloat16();
+template <>
+bool ConvGradientOp<float, HIPContext>::RunFloat16();
+
+namespace {
+size_t BlockedHalves(int N, int C, int H, int W) {
+  return (size_t)N * (size_t)((C + 7) / 8) * 8 * (size_t)H * (size_t)W;
+}
+}  // namespace
 
 template <>
 bool ConvOp<float, HIPContext>::RunOnDevice() {
   auto& X = Input(INPUT);
   auto& filter = Input(FILTER);
   auto* Y = Output(0);
+  if (X.IsType<float16>()) return RunFloat16();
   CAFFE_ENFORCE_EQ(X.ndim(), 4);
   CAFFE_ENFORCE_EQ(X.ndim(), filter.ndim());
   const int N = X.dim32(0), C = X.dim32(1), H = X.dim32(2), W = X.dim32(3);
@@ -254,6 +265,7 @@ bool ConvGradientOp<float, HIPContext>::RunOnDevice() {
   auto& filter = Input(FILTER);
   auto& dY = Input(OUTPUT_GRAD);
   auto* dfilter = Output(FILTER_GRAD);
+  if (X.IsType<float16>()) return RunFloat16();
   CAFFE_ENFORCE_EQ(X.ndim(), 4);
   CAFFE_ENFORCE_EQ(X.ndim(), filter.ndim());
   const int N = X.dim32(0), C = X.dim32(1), H = X.dim32(2), W = X.dim32(3);
@@ -299,6 +311,135 @@ bool ConvGradientOp<float, HIPContext>::RunOnDevice() {
       rc = ssad_conv3x3_forward(&dl, 1, packed, nullptr, C, M, flags, s);
     }
     CAFFE_ENFORCE_EQ(rc, 0, "ConvGradient (data) launch failed");
+  }
+  return true;
+}
+
+// float16 blobs, forward: X, filter, (bias) and Y in fp16, accumulation in fp32.
+template <>
+bool ConvOp<float, HIPContext>::RunFloat16() {
+  auto& X = Input(INPUT);
+  auto& filter = Input(FILTER);
+  auto* Y = Output(0);
+  CAFFE_ENFORCE(IsSubnetGeometry(geom_),
+                "float16 Conv: the HIP engine implements kernel 3, stride 1, pad 1, group 1, NCHW");
+  CAFFE_ENFORCE(filter.IsType<float16>(), "float16 Conv: the filter must be float16 too");
+  CAFFE_ENFORCE_EQ(X.ndim(), 4);
+  CAFFE_ENFORCE_EQ(filter.ndim(), 4);
+  const int N = X.dim32(0), C = X.dim32(1), H = X.dim32(2), W = X.dim32(3);
+  const int M = filter.dim32(0);
+  CAFFE_ENFORCE(C == filter.dim32(1) && filter.dim32(2) == 3 && filter.dim32(3) == 3);
+  hipStream_t s = context_.hip_stream();
+  // filter: fp16 [M][C][3][3] -> fp32 -> packed fp16; bias -> fp32
+  auto& wf32 = f16_scratch_[0];
+  wf32.Resize((TIndex)filter.size());
+  CAFFE_ENFORCE_EQ(ssad_cast_f16_to_f32(filter.raw_data(), wf32.mutable_data<float>(), filter.size(), s), 0);
+  packed_filter_.Resize((TIndex)((ssad_f16_filter_halves(M, C) + 1) / 2));
+  float* packed = packed_filter_.mutable_data<float>();
+  CAFFE_ENFORCE_EQ(ssad_f16_pack_filter(wf32.data<float>(), M, C, packed, nullptr, s), 0);
+  const float* bias = nullptr;
+  if (InputSize() == 3) {
+    auto& b = Input(BIAS);
+    CAFFE_ENFORCE(b.IsType<float16>() && b.ndim() == 1 && b.dim32(0) == M);
+    auto& b32 = f16_scratch_[1];
+    b32.Resize(M);
+    CAFFE_ENFORCE_EQ(ssad_cast_f16_to_f32(b.raw_data(), b32.mutable_data<float>(), M, s), 0);
+    bias = b32.data<float>();
+  }
+  // activations: NCHW fp16 -> channel-blocked -> convolution -> NCHW fp16
+  auto& xb = f16_scratch_[2];
+  xb.Resize((TIndex)((BlockedHalves(N, C, H, W) + 1) / 2));
+  CAFFE_ENFORCE_EQ(ssad_f16_block_activations(X.raw_data(), N, C, H, W, xb.mutable_data<float>(), s), 0);
+  Y->Resize(N, M, H, W);
+  void* y = Y->raw_mutable_data(TypeMeta::Make<float16>());
+  const int flags = fuse_relu_ ? SSAD_CONV_RELU : 0;
+  if (M % 8 == 0) {
+    auto& yb = f16_scratch_[3];
+    yb.Resize((TIndex)((BlockedHalves(N, M, H, W) + 1) / 2));
+    CAFFE_ENFORCE_EQ(ssad_conv3x3_forward_f16(xb.data<float>(), packed, bias, nullptr, N, C, H, W, M, flags,
+                                              yb.mutable_data<float>(), s), 0, "float16 Conv launch failed");
+    CAFFE_ENFORCE_EQ(ssad_f16_unblock_activations(yb.data<float>(), N, M, H, W, y, s), 0);
+  } else {   // an output width that is not a multiple of 8 (bbox_pred: 36) leaves through fp32
+    auto& y32 = f16_scratch_[3];
+    y32.Resize((TIndex)Y->size());
+    CAFFE_ENFORCE_EQ(ssad_conv3x3_forward_f16(xb.data<float>(), packed, bias, nullptr, N, C, H, W, M,
+                                              flags | SSAD_F16_OUT_NCHW_F32, y32.mutable_data<float>(), s),
+                     0, "float16 Conv launch failed");
+    CAFFE_ENFORCE_EQ(ssad_cast_f32_to_f16(y32.data<float>(), y, Y->size(), s), 0);
+  }
+  return true;
+}
+
+// float16 blobs, gradient: X, filter, dY in fp16 -> dfilter, dbias, dX in fp16; sums in fp32.
+template <>
+bool ConvGradientOp<float, HIPContext>::RunFloat16() {
+  auto& X = Input(INPUT);
+  auto& filter = Input(FILTER);
+  auto& dY = Input(OUTPUT_GRAD);
+  auto* dfilter = Output(FILTER_GRAD);
+  CAFFE_ENFORCE(IsSubnetGeometry(geom_),
+                "float16 ConvGradient: the HIP engine implements kernel 3, stride 1, pad 1, group 1, NCHW");
+  CAFFE_ENFORCE(filter.IsType<float16>() && dY.IsType<float16>(),
+                "float16 ConvGradient: filter and output gradient must be float16 too");
+  CAFFE_ENFORCE(!relu_grad_on_input_, "relu_grad_on_input is an extension of the fp32 3x3 engine");
+  const int N = X.dim32(0), C = X.dim32(1), H = X.dim32(2), W = X.dim32(3);
+  const int M = filter.dim32(0);
+  CAFFE_ENFORCE(C == filter.dim32(1) && filter.dim32(2) == 3 && filter.dim32(3) == 3);
+  CAFFE_ENFORCE(dY.ndim() == 4 && dY.dim32(0) == N && dY.dim32(1) == M && dY.dim32(2) == H &&
+                    dY.dim32(3) == W,
+                "output gradient shape does not match the convolution output");
+  hipStream_t s = context_.hip_stream();
+  auto& xb = f16_scratch_[0];
+  auto& dyb = f16_scratch_[1];
+  xb.Resize((TIndex)((BlockedHalves(N, C, H, W) + 1) / 2));
+  dyb.Resize((TIndex)((BlockedHalves(N, M, H, W) + 1) / 2));
+  CAFFE_ENFORCE_EQ(ssad_f16_block_activations(X.raw_data(), N, C, H, W, xb.mutable_data<float>(), s), 0);
+  CAFFE_ENFORCE_EQ(ssad_f16_block_activations(dY.raw_data(), N, M, H, W, dyb.mutable_data<float>(), s), 0);
+  // filter / bias gradient in fp32, stored as fp16 (conv_op_cudnn.cc:1037: overwrite)
+  auto& dw32 = f16_scratch_[2];
+  auto& db32 = f16_scratch_[3];
+  dw32.Resize((TIndex)filter.size());
+  db32.Resize(M);
+  const size_t wsb = ssad_conv3x3_wgrad_f16_workspace_bytes(N, C, H, W, M);
+  workspace_.Resize((TIndex)wsb);
+  CAFFE_ENFORCE_EQ(ssad_conv3x3_wgrad_f16(xb.data<float>(), dyb.data<float>(), N, C, H, W, M, 0, 1.0f,
+                                          dw32.mutable_data<float>(),
+                                          no_bias_ ? nullptr : db32.mutable_data<float>(),
+                                          workspace_.mutable_data<uint8_t>(), wsb, s),
+                   0, "float16 ConvGradient (filter) launch failed");
+  dfilter->ResizeLike(filter);
+  CAFFE_ENFORCE_EQ(ssad_cast_f32_to_f16(dw32.data<float>(), dfilter->raw_mutable_data(TypeMeta::Make<float16>()),
+                                        filter.size(), s), 0);
+  if (!no_bias_) {
+    auto* dbias = Output(BIAS_OR_INPUT_GRAD);
+    dbias->Resize(M);
+    CAFFE_ENFORCE_EQ(ssad_cast_f32_to_f16(db32.data<float>(), dbias->raw_mutable_data(TypeMeta::Make<float16>()),
+                                          M, s), 0);
+  }
+  if (OutputSize() == 3 || (no_bias_ && OutputSize() == 2)) {
+    auto* dX = Output(no_bias_ ? BIAS_OR_INPUT_GRAD : INPUT_GRAD);
+    dX->ResizeLike(X);
+    auto& wf32 = f16_scratch_[4];
+    wf32.Resize((TIndex)filter.size());
+    CAFFE_ENFORCE_EQ(ssad_cast_f16_to_f32(filter.raw_data(), wf32.mutable_data<float>(), filter.size(), s), 0);
+    packed_filter_.Resize((TIndex)((ssad_f16_filter_halves(M, C) + 1) / 2));
+    float* packed = packed_filter_.mutable_data<float>();
+    CAFFE_ENFORCE_EQ(ssad_f16_pack_filter(wf32.data<float>(), M, C, nullptr, packed, s), 0);
+    void* dx = dX->raw_mutable_data(TypeMeta::Make<float16>());
+    auto& out = f16_scratch_[5];
+    if (C % 8 == 0) {
+      out.Resize((TIndex)((BlockedHalves(N, C, H, W) + 1) / 2));
+      CAFFE_ENFORCE_EQ(ssad_conv3x3_forward_f16(dyb.data<float>(), packed, nullptr, nullptr, N, M, H, W, C, 0,
+                                                out.mutable_data<float>(), s), 0,
+                       "float16 ConvGradient (data) launch failed");
+      CAFFE_ENFORCE_EQ(ssad_f16_unblock_activations(out.data<float>(), N, C, H, W, dx, s), 0);
+    } else {
+      out.Resize((TIndex)X.size());
+      CAFFE_ENFORCE_EQ(ssad_conv3x3_forward_f16(dyb.data<float>(), packed, nullptr, nullptr, N, M, H, W, C,
+                                                SSAD_F16_OUT_NCHW_F32, out.mutable_data<float>(), s), 0,
+                       "float16 ConvGradient (data) launch failed");
+      CAFFE_ENFORCE_EQ(ssad_cast_f32_to_f16(out.data<float>(), dx, X.size(), s), 0);
+    }
   }
   return true;
 }

@@ -17,6 +17,11 @@
 // rocBLAS.  NHWC and grouped convolutions raise UnsupportedOperatorFeature at
 // construction (caffe2/core/operator.h:765-782).
 //
+// float16 blobs (TensorProto::FLOAT16) dispatch like CudnnConvOp's DoRunWithType<float16, ...>
+// (conv_op_cudnn.cc:631-636, :1115-1124): fp16 storage for X, filter, bias, Y and all
+// gradients, fp32 math -- on the fp16 matrix-core kernels of kernels/conv3x3_f16.hip, for the
+// 3x3 / stride 1 / pad 1 geometry.
+//
 // Two optional arguments exist for graph-level fusion and are NOT emitted by
 // the reference graph builder (absent = reference behaviour):
 //   Conv          fuse_relu=1             Y = max(conv, 0)  (Conv + in-place Relu)
@@ -59,11 +64,13 @@ class ConvOp final : public Operator<Context> {
 
  private:
   bool RunDefaultEngine();
+  bool RunFloat16();
   ConvGeometry geom_;
   int fuse_relu_;
   string algo_;
   Tensor<Context> packed_filter_;
   Tensor<Context> col_buffer_;
+  Tensor<Context> f16_scratch_[4];
 };
 
 template <typename T, class Context>
@@ -90,9 +97,11 @@ class ConvGradientOp final : public Operator<Context> {
   int relu_grad_on_input_;
   string algo_;
   bool RunDefaultEngine();
+  bool RunFloat16();
   Tensor<Context> packed_filter_;
   Tensor<Context> workspace_;
   Tensor<Context> col_buffer_;
+  Tensor<Context> f16_scratch_[6];
 };
 
 }  // namespace caffe2

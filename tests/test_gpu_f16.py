@@ -172,3 +172,48 @@ def test_f16_pipeline_tracks_the_fp32_pipeline(K):
     for a, b in zip(out["f16"]["d_fpn"], out["f32"]["d_fpn"]):
         cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
         assert cos > 0.995 and rel(a, b) < 0.1, (cos, rel(a, b))
+
+
+@pytest.mark.parametrize("M", [32, 36])
+def test_float16_blobs_through_the_conv_operators(M):
+    """Conv / ConvGradient on TensorProto::FLOAT16 blobs (the reference's CudnnConvOp dispatches
+    DoRunWithType<float16, ...> with fp32 math, conv_op_cudnn.cc:631-636, :1115-1124): fp16
+    X / filter / bias / dY in, fp16 Y / dfilter / dbias / dX out, against float64 evaluations of
+    the same fp16 values; M = 36 takes the route whose output width is not a multiple of 8."""
+    from ssad_amd.caffe2_hip import caffe2_pb2, core, workspace
+    rng = np.random.default_rng(500 + M)
+    N, C, H, W = 2, 40, 9, 13
+    X = rng.standard_normal((N, C, H, W)).astype(np.float16)
+    Wt = (rng.standard_normal((M, C, 3, 3)) * 0.1).astype(np.float16)
+    b = rng.standard_normal(M).astype(np.float16)
+    dY = rng.standard_normal((N, M, H, W)).astype(np.float16)
+    gpu = core.DeviceOption(caffe2_pb2.HIP, 0)
+    for name, arr in (("X", X), ("w", Wt), ("b", b), ("Y_grad", dY)):
+        workspace.FeedBlob(name, arr, gpu)
+    with core.DeviceScope(gpu):
+        conv = core.CreateOperator("Conv", ["X", "w", "b"], ["Y"], kernel=3, pad=1, stride=1,
+                                   order="NCHW", engine="CUDNN")
+    workspace.RunOperatorOnce(conv)
+    Y = workspace.FetchBlob("Y")
+    assert Y.dtype == np.float16 and Y.shape == (N, M, H, W)
+    x64, w64, dy64 = X.astype(np.float64), Wt.astype(np.float64), dY.astype(np.float64)
+    want = _conv64(x64, w64, b.astype(np.float64))
+    assert np.abs(Y.astype(np.float64) - want).max() <= 1e-3 * np.abs(want).max()
+    g, gi = core.GradientRegistry.GetGradientForOp(conv, ["Y_grad"])
+    workspace.RunOperatorsOnce(g)
+    dW, db, dX = (workspace.FetchBlob(n) for n in ("w_grad", "b_grad", "X_grad"))
+    assert dW.dtype == db.dtype == dX.dtype == np.float16
+    xp = np.zeros((N, C, H + 2, W + 2))
+    xp[:, :, 1:-1, 1:-1] = x64
+    want_dw = np.zeros((M, C, 3, 3))
+    for ky in range(3):
+        for kx in range(3):
+            want_dw[:, :, ky, kx] = np.einsum("nmhw,nchw->mc", dy64, xp[:, :, ky:ky + H, kx:kx + W])
+    want_dx = _conv64(dy64, np.ascontiguousarray(w64[:, :, ::-1, ::-1].transpose(1, 0, 2, 3)), None)
+    for got, ref in ((dW, want_dw), (db, dy64.sum((0, 2, 3))), (dX, want_dx)):
+        assert np.abs(got.astype(np.float64) - ref).max() <= 1e-3 * np.abs(ref).max()
+    # geometries outside the fp16 engine are refused, not silently run in another precision
+    with core.DeviceScope(gpu):
+        bad = core.CreateOperator("Conv", ["X", "w"], ["Y1"], kernel=3, pad=1, stride=2, order="NCHW")
+    with pytest.raises(Exception, match="float16 Conv"):
+        workspace.RunOperatorOnce(bad)
