@@ -279,3 +279,18 @@ def test_backbone_graph_matches_reference_capture(capture, cfg_kw):
         assert got == want, (ref, got)
     mine_params = [(n, s, [i[0], i[1]]) for n, s, i in model.params]
     assert mine_params == [(p["name"], p["shape"], p["init"]) for p in g["params"]]
+
+
+def test_tuned_gemm_picks_file_is_well_formed():
+    """harness/tunableop_gfx950.csv (the per-shape rocBLAS / hipBLASLt picks bench.py loads, never
+    searches): validator lines for this stack first, then one pick per GEMM key."""
+    import csv
+    path = os.path.join(os.path.dirname(ssad_amd.__file__), "harness", "tunableop_gfx950.csv")
+    rows = list(csv.reader(open(path)))
+    validators = {r[1]: r[2] for r in rows if r[0] == "Validator"}
+    assert {"PT_VERSION", "ROCBLAS_VERSION", "HIPBLASLT_VERSION", "GCN_ARCH_NAME"} <= set(validators)
+    assert validators["GCN_ARCH_NAME"].startswith("gfx950")
+    picks = [r for r in rows if r[0] != "Validator"]
+    assert len(picks) >= 40 and len({(r[0], r[1]) for r in picks}) == len(picks)
+    for op, key, solution, ms in picks:
+        assert op.startswith("Gemm") and solution.startswith("Gemm_") and float(ms) > 0
