@@ -604,21 +604,29 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
         (__attribute__((address_space(3))) uint4*)lds + buf * W_STAGE);
     auto* xa = reinterpret_cast<__attribute__((address_space(3))) short4v*>(base + xb_base);
     auto* ya = reinterpret_cast<__attribute__((address_space(3))) short4v*>(base + ya_base);
+    // operands of row r + 1 are fetched while the MFMAs of row r run (the transpose reads'
+    // latency is otherwise exposed once per row: one wave per SIMD, nothing else to issue)
+    half8 a[2][2], b[2][2][3];
+    auto load_row = [&](int row, half8 (&aa)[2], half8 (&bb)[2][3]) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) aa[t] = tr_pair(ya, t * 2 * Y_PITCH + row * WPX * 2);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) bb[u][kx] = tr_pair(xa, u * 2 * X_PITCH + (row * XPW + kx) * 2);
+    };
+    load_row(0, a[0], b[0]);
 #pragma unroll
     for (int row = 0; row < WR; ++row) {
-      half8 a[2];
+      if (row + 1 < WR) load_row(row + 1, a[(row + 1) & 1], b[(row + 1) & 1]);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) a[t] = tr_pair(ya, t * 2 * Y_PITCH + row * WPX * 2);
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const half8 b = tr_pair(xa, u * 2 * X_PITCH + (row * XPW + kx) * 2);
+        for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
           for (int t = 0; t < 2; ++t)
-            acc[t][u][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], b, acc[t][u][kx], 0, 0, 0);
-        }
-      }
+            acc[t][u][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[row & 1][t], b[row & 1][u][kx],
+                                                                   acc[t][u][kx], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);                     // bound the operands in flight
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -704,7 +712,19 @@ __global__ __launch_bounds__(kThreads) void f16_bias_grad_kernel(const uint4* __
 
 namespace {
 int wgrad_splits(int blocks, int stages) {
-  int s = (512 + 3 * blocks - 1) / (3 * blocks);   // ~2 workgroups per CU (x 3 filter rows)
+  // one workgroup per CU at a time (148 KiB of LDS): whole rounds only -- 516 workgroups on 256
+  // CUs take three rounds where 504 take two -- and ONE round measures best (tower layer, all
+  // levels: 0.424 / 0.449 / 0.485 / 0.523 ms for 1 / 2 / 3 / 4 rounds: the per-workgroup prologue
+  // and the 2.4 MB of partial sums per split are not hidden at this occupancy)
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+      n = 256;
+    return n;
+  }();
+  static const int rounds = getenv("SSAD_F16_WGRAD_ROUNDS") ? atoi(getenv("SSAD_F16_WGRAD_ROUNDS")) : 1;
+  int s = (rounds * cus) / (3 * blocks);       // whole rounds; x 3 filter rows
   if (s > stages) s = stages;
   return s < 1 ? 1 : s;
 }
