@@ -320,7 +320,10 @@ def main():
                 "traffic": None, "traffic_note": None})
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, cfg)
-        print(json.dumps(out))
+        # the ONE result line, last on rank 0's stdout (with NCCL_DEBUG=VERSION in the environment
+        # RCCL prints its version banner to stdout when the communicator is created, i.e. earlier)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if pg is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
