@@ -294,3 +294,33 @@ def test_tuned_gemm_picks_file_is_well_formed():
     assert len(picks) >= 40 and len({(r[0], r[1]) for r in picks}) == len(picks)
     for op, key, solution, ms in picks:
         assert op.startswith("Gemm") and solution.startswith("Gemm_") and float(ms) > 0
+
+
+def test_kernel_entry_points_refuse_bad_arguments_without_a_device(lib):
+    """The launchers validate their arguments before they touch the GPU: inconsistent calls
+    return SSAD_E_BADARG (-1) / SSAD_E_WORKSPACE (-2) on a machine without a device too."""
+    raw = ctypes.CDLL(_capi.LIB_PATH)
+    vp, i32, f32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    one = ctypes.create_string_buffer(64)
+    p = ctypes.cast(one, vp)
+    raw.ssad_conv3x3_forward_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    # blocked output needs whole 8-channel blocks
+    assert raw.ssad_conv3x3_forward_f16(p, p, None, None, 1, 32, 4, 4, 36, 0, p, None) == -1
+    # the mask flag and the mask pointer go together
+    assert raw.ssad_conv3x3_forward_f16(p, p, None, None, 1, 32, 4, 4, 32, 2, p, None) == -1
+    assert raw.ssad_conv3x3_forward_f16(None, p, None, None, 1, 32, 4, 4, 32, 0, p, None) == -1
+    raw.ssad_conv3x3_wgrad_f16.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, sz, vp]
+    raw.ssad_conv3x3_wgrad_f16_workspace_bytes.restype = sz
+    raw.ssad_conv3x3_wgrad_f16_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    need = raw.ssad_conv3x3_wgrad_f16_workspace_bytes(2, 256, 10, 14, 256)
+    assert need >= 9 * 256 * 256 * 4
+    assert raw.ssad_conv3x3_wgrad_f16(p, p, 2, 256, 10, 14, 256, 0, 1.0, p, None, p, need - 1, None) == -2
+    assert raw.ssad_conv3x3_wgrad_f16(p, None, 2, 256, 10, 14, 256, 0, 1.0, p, None, p, need, None) == -1
+    raw.ssad_f16_pack_activations.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
+    assert raw.ssad_f16_pack_activations(p, 1, 0, 4, 4, 1.0, p, None) == -1
+    raw.ssad_max_pool3x3s2_bias_relu.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    assert raw.ssad_max_pool3x3s2_bias_relu(None, None, 1, 4, 8, 8, 1, p, None) == -1
+    raw.ssad_affine_channel.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    assert raw.ssad_affine_channel(p, None, None, None, p, 1, 0, 16, 1, None) == -1
+    raw.ssad_conv_out_size.argtypes = [i32] * 6
+    assert raw.ssad_conv_out_size(7, 3, 1, 1, 1, 2) == 4 and raw.ssad_conv_out_size(2, 7, 1, 0, 0, 1) == -1
