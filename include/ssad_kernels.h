@@ -310,6 +310,11 @@ SSAD_API int ssad_col2im(const float* col, int C, int H, int W, int kh, int kw, 
 /* out[c] (+)= sum_{n,p} dy[n][c][p] (the bias gradient, conv_op_impl.h:470-486) */
 SSAD_API int ssad_channel_sum(const float* dy, int N, int C, int HW, float* out, int accumulate,
                               ssad_stream_t stream);
+/* ReluGradient (caffe2/operators/relu_op.cu:44-53) of an NCHW tensor fused with the plane sums
+ * a per-channel bias gradient needs: dx = y > 0 ? dy : 0 (y NULL: dx = dy, and dx may then be
+ * NULL = sums only) and rowsum[n][c] = sum over H*W of dx; db[c] = sum_n rowsum[n][c]. */
+SSAD_API int ssad_relu_grad_rowsum(const float* y, const float* dy, float* dx, float* rowsum, int N,
+                                   int C, int HW, ssad_stream_t stream);
 /* MaxPool / MaxPoolGradient, NCHW (caffe2/operators/pool_op.cu): windows are clipped to
  * the image; every input equal to its window's maximum receives the gradient */
 SSAD_API int ssad_max_pool_forward(const float* x, int N, int C, int H, int W, int kh, int kw,

@@ -175,6 +175,48 @@ __global__ __launch_bounds__(kThreads) void affine_channel_kernel(
   }
 }
 
+// ReluGradient (relu_op.cu:44-53: dX = Y > 0 ? dY : 0) of a bottleneck's fused bias + ReLU tail
+// together with the bias gradient of the AffineChannel before it: the same pass also leaves
+// rowsum[n][c] = sum over the plane of dX, so the per-channel sum no longer re-reads dX.
+// One workgroup per (n, c) row; y == nullptr = no ReLU (dX = dY is not written, only summed).
+__global__ __launch_bounds__(kThreads) void relu_grad_rowsum_kernel(const float* __restrict__ y,
+                                                                    const float* __restrict__ dy,
+                                                                    float* __restrict__ dx,
+                                                                    float* __restrict__ rowsum,
+                                                                    long long rows, int HW, int vec) {
+  __shared__ float red[kThreads / 64];
+  const long long row = blockIdx.x;
+  const float* yr = y ? y + row * HW : nullptr;
+  const float* gr = dy + row * HW;
+  float* xr = dx ? dx + row * HW : nullptr;
+  float s = 0.0f;
+  const int n4 = vec ? (HW >> 2) : 0;
+  for (int i = threadIdx.x; i < n4; i += kThreads) {
+    float4 g = reinterpret_cast<const float4*>(gr)[i];
+    if (yr) {
+      const float4 v = reinterpret_cast<const float4*>(yr)[i];
+      g.x = v.x > 0.f ? g.x : 0.f; g.y = v.y > 0.f ? g.y : 0.f;
+      g.z = v.z > 0.f ? g.z : 0.f; g.w = v.w > 0.f ? g.w : 0.f;
+    }
+    if (xr) reinterpret_cast<float4*>(xr)[i] = g;
+    s += (g.x + g.y) + (g.z + g.w);
+  }
+  for (int i = n4 * 4 + threadIdx.x; i < HW; i += kThreads) {
+    float g = gr[i];
+    if (yr) g = yr[i] > 0.f ? g : 0.f;
+    if (xr) xr[i] = g;
+    s += g;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (int w = 0; w < kThreads / 64; ++w) t += red[w];
+    rowsum[row] = t;
+  }
+}
+
 // UpsampleNearest / UpsampleNearestGradient (caffe2/modules/detectron/
 // upsample_nearest_op.cu:62-151) of the FPN top-down path, with the lateral Sum
 // (detectron/lib/modeling/FPN.py:283-306) optionally folded into the forward:
@@ -301,6 +343,18 @@ int ssad_affine_channel(const float* x, const float* scale, const float* bias,
   while (rows / rpb > 65536) rpb *= 2;
   hipLaunchKernelGGL(affine_channel_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(kThreads), 0,
                      (hipStream_t)stream, x, scale, bias, residual, y, rows, C, HW, vec, relu, rpb);
+  return (int)hipGetLastError();
+}
+
+int ssad_relu_grad_rowsum(const float* y, const float* dy, float* dx, float* rowsum, int N, int C, int HW,
+                          ssad_stream_t stream) {
+  if (!dy || !rowsum || N < 0 || C <= 0 || HW < 0 || (y && !dx)) return SSAD_E_BADARG;
+  const long long rows = (long long)N * C;
+  if (rows == 0) return 0;
+  if (rows >= (1LL << 31)) return SSAD_E_BADARG;
+  const int vec = !(HW & 3) && aligned16(dy, dx ? dx : dy, y);
+  hipLaunchKernelGGL(relu_grad_rowsum_kernel, dim3((unsigned)rows), dim3(kThreads), 0, (hipStream_t)stream, y, dy,
+                     dx, rowsum, rows, HW, vec);
   return (int)hipGetLastError();
 }
 

@@ -72,9 +72,13 @@ class _BiasActFn(torch.autograd.Function):
         K = _K()
         (y,) = ctx.saved_tensors
         dz = dy.contiguous()
-        if ctx.relu:
+        db = None
+        if ctx.needs_input_grad[1]:
+            # ReluGradient and the bias gradient's plane sums in one pass over dy
+            dz, rs = K.relu_grad_rowsum(y if ctx.relu else None, dz)
+            db = rs.sum(0)
+        elif ctx.relu:
             dz = K.relu_grad(y, dz)
-        db = dz.sum((0, 2, 3)) if ctx.needs_input_grad[1] else None
         return dz, db, (dz if ctx.has_res else None), None
 
 

@@ -102,6 +102,7 @@ def lib():
     L.ssad_upsample_nearest.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.ssad_upsample_nearest_grad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     L.ssad_max_pool3x3s2_bias_relu.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    L.ssad_relu_grad_rowsum.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.ssad_f16_pack_activations.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
     L.ssad_f16_unpack_activations.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
     L.ssad_f16_filter_halves.restype = sz
@@ -330,6 +331,19 @@ def relu_grad(y, dy, out=None):
     _check(lib().ssad_relu_grad(_ptr(_f32c(y, "y")), _ptr(_f32c(dy, "dy")), _ptr(dx),
                                 y.numel(), _stream()), "relu_grad")
     return dx
+
+
+def relu_grad_rowsum(y, dy, want_dx=True):
+    """(dx, rowsum[N][C]): dx = y > 0 ? dy : 0 (y None: dx = dy itself) and the plane sums of dx
+    in the same pass; a bias gradient is rowsum.sum(0)."""
+    _f32c(dy, "dy")
+    N, Cc = dy.shape[0], dy.shape[1]
+    hw = dy.numel() // max(N * Cc, 1)
+    dx = torch.empty_like(dy) if (y is not None and want_dx) else None
+    rs = torch.empty((N, Cc), dtype=torch.float32, device="cuda")
+    _check(lib().ssad_relu_grad_rowsum(_ptr(_f32c(y, "y")) if y is not None else _ptr(None), _ptr(dy),
+                                       _ptr(dx), _ptr(rs), N, Cc, hw, _stream()), "relu_grad_rowsum")
+    return (dx if y is not None else dy), rs
 
 
 def affine_channel_(x, bias, scale=None, residual=None, relu=False):

@@ -202,3 +202,17 @@ def test_body_fused_route_matches_plain_torch(fm, monkeypatch, arch):
     tol = 1e-3 if arch == 50 else 1e-2
     for n in g0:
         assert _rel(g1[n], g0[n]) < tol, n
+
+
+@pytest.mark.parametrize("hw", [(7, 8), (5, 3)])
+def test_relu_grad_with_row_sums(hw):
+    from ssad_amd import kernels as K
+    torch.manual_seed(6)
+    y = torch.relu(torch.randn(3, 5, *hw, device="cuda"))
+    dy = torch.randn(3, 5, *hw, device="cuda")
+    dx, rs = K.relu_grad_rowsum(y, dy)
+    want = torch.where(y > 0, dy, torch.zeros_like(dy))
+    assert torch.equal(dx, want)
+    assert _rel(rs, want.sum((2, 3))) < 1e-6
+    same, rs2 = K.relu_grad_rowsum(None, dy)
+    assert same is dy and _rel(rs2, dy.sum((2, 3))) < 1e-6
