@@ -113,6 +113,37 @@ class _Conv1x1Fn(torch.autograd.Function):
         return dx, dw
 
 
+class _Conv1x1ShortcutFn(torch.autograd.Function):
+    """c1 of a bottleneck together with the tap for the block's shortcut: returns
+    (conv1x1(x, w), x).  Autograd would add the two gradients reaching x -- the shortcut's and
+    c1's data gradient -- in a pass of its own (read two tensors, write a third); here c1's data
+    gradient GEMM accumulates onto the shortcut's gradient in place (beta = 1)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return _mm1x1(x, w), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dz, dsc):
+        x, w = ctx.saved_tensors
+        N, M = dz.shape[0], dz.shape[1]
+        Cc = x.shape[1]
+        dz = dz.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = w.view(1, M, Cc).transpose(1, 2).expand(N, Cc, M)
+            if dsc is None:
+                dx = torch.empty_like(x)
+                torch.bmm(wt, dz.view(N, M, -1), out=dx.view(N, Cc, -1))
+            else:
+                dx = dsc if dsc.is_contiguous() else dsc.contiguous()
+                dx.view(N, Cc, -1).baddbmm_(wt, dz.view(N, M, -1))
+        if ctx.needs_input_grad[1]:
+            dw = torch.bmm(dz.view(N, M, -1), x.view(N, Cc, -1).transpose(1, 2)).sum(0).view_as(w)
+        return dx, dw
+
+
 def _mm1x1(x, w):
     N, Cc, H, W = x.shape
     M = w.shape[0]
@@ -238,14 +269,19 @@ class Bottleneck(nn.Module):
             if self.c1.stride != (1, 1):
                 x = xs
             b3 = self.c3.bias
+            if _GEMM_1X1 and x.requires_grad and x is xs:
+                # c1 and the shortcut tap in one node: their gradients meet inside c1's GEMM
+                z1, xs = _Conv1x1ShortcutFn.apply(x, self.c1.weight)
+            else:
+                z1 = conv1x1(x, self.c1.weight)
             if self.proj is None:
-                sc = x
+                sc = xs
             else:
                 # the projection's bias rides along with c3's in the block's last pass
                 sc = conv1x1(xs, self.proj.weight)
                 b3 = b3 + self.proj.bias
             # convolution without bias, then bias (+ residual) + ReLU in one pass
-            y = bias_act(conv1x1(x, self.c1.weight), self.c1.bias)
+            y = bias_act(z1, self.c1.bias)
             y = self.c2(y) if self.hip2 else bias_act(
                 F.conv2d(y, self.c2.weight, None, self.c2.stride, 1, 1, self.c2.groups), self.c2.bias)
             return bias_act(conv1x1(y, self.c3.weight), b3, residual=sc)
