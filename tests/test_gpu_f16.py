@@ -217,3 +217,36 @@ def test_float16_blobs_through_the_conv_operators(M):
         bad = core.CreateOperator("Conv", ["X", "w"], ["Y1"], kernel=3, pad=1, stride=2, order="NCHW")
     with pytest.raises(Exception, match="float16 Conv"):
         workspace.RunOperatorOnce(bad)
+
+
+def test_f16_full_size_adjoint_identities(K):
+    """BASELINE sizes (bs 16, a 256 -> 256 tower layer on P3 and P4 in one launch): the three
+    kernels are adjoint views of one trilinear form, <conv(x; w), dy> = <x, dgrad(dy; w)> =
+    <w, wgrad(x, dy)>, whatever the size; with fp16 storage the three evaluations agree to the
+    rounding of the stored fp16 results (each a sum of ~4e7 terms of random sign)."""
+    torch.manual_seed(21)
+    N, C, M = 16, 256, 256
+    shapes = [(80, 112), (40, 56)]
+    w = torch.randn(M, C, 3, 3, device="cuda") * 0.02
+    wf, wd = K.f16_pack_filter(w, True, True)
+    w16 = w.half().float()
+    xs = [torch.randn(N, C, h, ww, device="cuda") for h, ww in shapes]
+    dys = [torch.randn(N, M, h, ww, device="cuda") for h, ww in shapes]
+    xb = [K.f16_pack_activations(x) for x in xs]
+    dyb = [K.f16_pack_activations(d) for d in dys]
+    yb = [torch.empty((N, M // 8, h, ww, 8), dtype=torch.float16, device="cuda") for h, ww in shapes]
+    dxb = [torch.empty((N, C // 8, h, ww, 8), dtype=torch.float16, device="cuda") for h, ww in shapes]
+    K.conv3x3_forward_f16_levels(xb, wf, None, C, M, yb)
+    K.conv3x3_forward_f16_levels(dyb, wd, None, M, C, dxb)
+    dW, _ = K.conv3x3_wgrad_f16(xb, dyb, C, M)
+    s1 = sum(float((K.f16_unpack_activations(y, M).double() * K.f16_unpack_activations(d, M).double()).sum())
+             for y, d in zip(yb, dyb))
+    s2 = sum(float((K.f16_unpack_activations(x, C).double() * K.f16_unpack_activations(dx, C).double()).sum())
+             for x, dx in zip(xb, dxb))
+    s3 = float((dW.double() * w16.double()).sum())
+    scale = max(abs(s1), abs(s2), abs(s3))
+    # an independent yardstick for the size of the form: its root-sum-square over the levels
+    rss = float(sum((K.f16_unpack_activations(y, M).double() ** 2).sum() for y in yb) ** 0.5 *
+                sum((d.double() ** 2).sum() for d in dys) ** 0.5)
+    assert abs(s1 - s2) <= 2e-3 * max(scale, 1e-3 * rss), (s1, s2, s3)
+    assert abs(s1 - s3) <= 2e-3 * max(scale, 1e-3 * rss), (s1, s2, s3)
