@@ -1,0 +1,272 @@
+// conv1x1_fused.hip -- pointwise convolution with the bottleneck tail in its epilogue:
+//     Y[n][m][p] = act( sum_c W[m][c] X[n][c][p] + bias[m] (+ R[n][m][p]) ),  NCHW fp32,
+// i.e. Conv(kernel=1) -> AffineChannel (folded into W / bias) -> Sum with the shortcut -> Relu
+// (detectron/lib/modeling/ResNet.py:176-197, :223-283) in ONE pass over the tensors.
+//
+// Why a kernel of its own: at the early stages (res2: 64 / 256 channels on 160 x 224, res3:
+// 128 / 512 on 80 x 112) these layers are HBM bound -- 2 K flop per output element against 12 B
+// of traffic -- and the library route pays the output twice: the GEMM writes Z, the fused tail
+// pass reads Z and the shortcut and writes Y.  Here Z never exists: X (small) is staged through
+// LDS, W stays in LDS for the whole workgroup, and the accumulators meet bias, shortcut and
+// ReLU in registers.  The arithmetic is exact fp32 MFMA (v_mfma_f32_32x32x2f32).
+//
+// Workgroup = 4 waves, tile 128 output channels x 128 pixels (wave = 64 x 64 = 2 x 2 MFMA
+// tiles); K is processed in chunks of 64 input channels: W chunk [64][128] and X chunk [64][128]
+// in LDS (64 KiB -> 2 workgroups per CU).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ssad_kernels.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int TM = 128, TP = 128, KC = 64;
+
+struct PwArgs {
+  const float* x;      // [N][C][P]
+  const float* w;      // [M][C]
+  const float* bias;   // [M] or null
+  const float* res;    // [N][M][P] or null
+  float* y;            // [N][M][P]
+  int N, C, P, M, relu;
+  int ptiles;          // ceil(P / 128)
+};
+
+__global__ __launch_bounds__(kThreads, 2) void conv1x1_fused_kernel(const PwArgs a) {
+  __shared__ float wl[KC][TM];        // W^T chunk: [k][m]
+  __shared__ float xl[KC][TP];        // X chunk:   [k][p]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wp = wave >> 1;
+  const int j = lane & 31, h = lane >> 5;
+  const int pt = blockIdx.x % a.ptiles, n = blockIdx.x / a.ptiles;
+  const int m0 = blockIdx.y * TM, p0 = pt * TP;
+  const float* xn = a.x + (long long)n * a.C * a.P;
+
+  // The accumulators start from the shortcut (and the bias): its 64 loads per lane are in
+  // flight while W and X are staged and stay so into the MFMA loop -- the kernel is HBM bound,
+  // a shortcut fetched in the epilogue would leave the memory pipe idle during the K loop.
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int p = p0 + wp * 64 + t * 32 + j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        acc[i][t][r] = (a.res && p < a.P) ? a.res[((long long)n * a.M + m) * a.P + p] : 0.0f;
+      }
+    }
+
+  for (int k0 = 0; k0 < a.C; k0 += KC) {
+    if (k0) __syncthreads();
+    // W chunk: thread -> (m = tid & 127, k half); 64 x 128 floats, transposed into [k][m]
+    {
+      const int m = tid & 127, kh = tid >> 7;
+      const float4* src = reinterpret_cast<const float4*>(a.w + (long long)(m0 + m) * a.C + k0 + kh * 32);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 v = src[q];
+        const int k = kh * 32 + q * 4;
+        wl[k][m] = v.x; wl[k + 1][m] = v.y; wl[k + 2][m] = v.z; wl[k + 3][m] = v.w;
+      }
+    }
+    // X chunk: 64 rows x 128 pixels = 2048 float4; thread -> 8 of them
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = tid + kThreads * q;
+      const int k = e >> 5, c4 = e & 31;
+      const int p = p0 + c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < a.P) v = *reinterpret_cast<const float4*>(xn + (long long)(k0 + k) * a.P + p);
+      *reinterpret_cast<float4*>(&xl[k][c4 * 4]) = v;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int ks = 0; ks < KC / 2; ++ks) {
+      const int k = 2 * ks + h;
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = wl[k][wm * 64 + i * 32 + j];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bv[t] = xl[k][wp * 64 + t * 32 + j];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[t], acc[i][t], 0, 0, 0);
+    }
+  }
+
+  // epilogue: C/D row = (r & 3) + 8 (r >> 2) + 4 h (output channel), column = j (pixel)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float bvv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      bvv[r] = a.bias ? a.bias[m] : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int p = p0 + wp * 64 + t * 32 + j;
+      if (p >= a.P) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[i][t][r] + bvv[r];
+        if (a.relu) v = fmaxf(v, 0.0f);
+        a.y[((long long)n * a.M + m) * a.P + p] = v;
+      }
+    }
+  }
+}
+
+// ---- 64 input channels (res2's c3): persistent workgroups --------------------------------
+// The layer is HBM bound (12 B per 128 flop), so what matters is bytes in flight: a workgroup
+// keeps its W^T block [64][128] in LDS for its whole life and walks over (image, 64-pixel)
+// tiles; while tile i is multiplied and stored, tile i+1's X block (-> registers -> the other
+// LDS buffer) and shortcut block (-> the next accumulators) are already on their way.
+constexpr int PT = 64;        // pixels per tile
+__global__ __launch_bounds__(kThreads, 2) void conv1x1_fused_c64_kernel(const PwArgs a, int tiles) {
+  __shared__ float wl[64][TM];
+  __shared__ float xl[2][64][PT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * TM, mw = m0 + wave * 32;       // this wave's 32 output channels
+  {   // W^T block, once
+    const int m = tid & 127, kh = tid >> 7;
+    const float4* src = reinterpret_cast<const float4*>(a.w + (long long)(m0 + m) * 64 + kh * 32);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 v = src[q];
+      const int k = kh * 32 + q * 4;
+      wl[k][m] = v.x; wl[k + 1][m] = v.y; wl[k + 2][m] = v.z; wl[k + 3][m] = v.w;
+    }
+  }
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = a.bias ? a.bias[mw + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.0f;
+
+  // X tile: 64 rows x 64 pixels = 1024 float4, 4 per thread: row e >> 4, float4 column e & 15
+  float4 xr[4];
+  f32x16 acc[2], nxt[2];
+  auto fetch_x = [&](int t) {
+    const int n = t / a.ptiles, p0 = (t % a.ptiles) * PT;
+    const float* xn = a.x + (long long)n * 64 * a.P;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + kThreads * q;
+      const int k = e >> 4, p = p0 + (e & 15) * 4;
+      xr[q] = p < a.P ? *reinterpret_cast<const float4*>(xn + (long long)k * a.P + p)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash_x = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + kThreads * q;
+      *reinterpret_cast<float4*>(&xl[buf][e >> 4][(e & 15) * 4]) = xr[q];
+    }
+  };
+  auto fetch_r = [&](int t, f32x16 (&dst)[2]) {
+    const int n = t / a.ptiles, p0 = (t % a.ptiles) * PT;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int p = p0 + c * 32 + j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * h;
+        dst[c][r] = (a.res && p < a.P) ? a.res[((long long)n * a.M + m) * a.P + p] : 0.0f;
+      }
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t < tiles) {
+    fetch_x(t);
+    fetch_r(t, acc);
+    stash_x(0);
+  }
+  __syncthreads();
+  for (int it = 0; t < tiles; t += gridDim.x, ++it) {
+    const int cur = it & 1;
+    const int tn = t + gridDim.x;
+    if (tn < tiles) {
+      fetch_x(tn);
+      fetch_r(tn, nxt);
+    }
+#pragma unroll 8
+    for (int ks = 0; ks < 32; ++ks) {
+      const int k = 2 * ks + h;
+      const float av = wl[k][wave * 32 + j];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xl[cur][k][c * 32 + j], acc[c], 0, 0, 0);
+    }
+    {
+      const int n = t / a.ptiles, p0 = (t % a.ptiles) * PT;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int p = p0 + c * 32 + j;
+        if (p >= a.P) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float v = acc[c][r] + bv[r];
+          if (a.relu) v = fmaxf(v, 0.0f);
+          a.y[((long long)n * a.M + m) * a.P + p] = v;
+        }
+      }
+    }
+    if (tn < tiles) {
+      stash_x(cur ^ 1);
+      acc[0] = nxt[0];
+      acc[1] = nxt[1];
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssad_conv1x1_bias_act(const float* x, const float* w, const float* bias, const float* residual,
+                          float* y, int N, int C, int P, int M, int relu, ssad_stream_t stream) {
+  if (!x || !w || !y || N < 0 || C < KC || (C % KC) || M < TM || (M % TM) || P < 4 || (P & 3))
+    return SSAD_E_BADARG;
+  if (((uintptr_t)x | (uintptr_t)w) & 15) return SSAD_E_BADARG;
+  if (N == 0) return 0;
+  PwArgs a;
+  a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
+  a.N = N; a.C = C; a.P = P; a.M = M; a.relu = relu;
+  if (C == 64) {
+    a.ptiles = (P + PT - 1) / PT;
+    const long long tiles = (long long)N * a.ptiles;
+    if (tiles >= (1LL << 31)) return SSAD_E_BADARG;
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+        n = 256;
+      return n;
+    }();
+    const int mblocks = M / TM;
+    long long g = (2LL * cus + mblocks - 1) / mblocks;      // two workgroups per CU in total
+    if (g > tiles) g = tiles;
+    hipLaunchKernelGGL(conv1x1_fused_c64_kernel, dim3((unsigned)g, (unsigned)mblocks), dim3(kThreads), 0,
+                       (hipStream_t)stream, a, (int)tiles);
+    return (int)hipGetLastError();
+  }
+  a.ptiles = (P + TP - 1) / TP;
+  if ((long long)N * a.ptiles >= (1LL << 31)) return SSAD_E_BADARG;
+  hipLaunchKernelGGL(conv1x1_fused_kernel, dim3((unsigned)(N * a.ptiles), (unsigned)(M / TM)), dim3(kThreads), 0,
+                     (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

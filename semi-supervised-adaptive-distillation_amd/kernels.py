@@ -103,6 +103,7 @@ def lib():
     L.ssad_upsample_nearest_grad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     L.ssad_max_pool3x3s2_bias_relu.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_relu_grad_rowsum.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    L.ssad_conv1x1_bias_act.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.ssad_f16_pack_activations.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
     L.ssad_f16_unpack_activations.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
     L.ssad_f16_filter_halves.restype = sz
@@ -331,6 +332,22 @@ def relu_grad(y, dy, out=None):
     _check(lib().ssad_relu_grad(_ptr(_f32c(y, "y")), _ptr(_f32c(dy, "dy")), _ptr(dx),
                                 y.numel(), _stream()), "relu_grad")
     return dx
+
+
+def conv1x1_bias_act(x, w, bias=None, residual=None, relu=True):
+    """act(conv1x1(x, w) + bias[m] (+ residual)) in one pass (NCHW float32)."""
+    _f32c(x, "x")
+    N, Cc, H, W = x.shape
+    M = w.shape[0]
+    w2 = _f32c(w.reshape(M, Cc), "w")
+    y = torch.empty((N, M, H, W), dtype=torch.float32, device="cuda")
+    if bias is not None:
+        _f32c(bias, "bias")
+    if residual is not None:
+        _f32c(residual, "residual")
+    _check(lib().ssad_conv1x1_bias_act(_ptr(x), _ptr(w2), _ptr(bias), _ptr(residual), _ptr(y), N, Cc, H * W, M,
+                                       int(relu), _stream()), "conv1x1_bias_act")
+    return y
 
 
 def relu_grad_rowsum(y, dy, want_dx=True):

@@ -216,3 +216,30 @@ def test_relu_grad_with_row_sums(hw):
     assert _rel(rs, want.sum((2, 3))) < 1e-6
     same, rs2 = K.relu_grad_rowsum(None, dy)
     assert same is dy and _rel(rs2, dy.sum((2, 3))) < 1e-6
+
+
+@pytest.mark.parametrize("C,M,H,W,res", [(64, 256, 10, 24, True), (64, 128, 7, 12, False),
+                                         (128, 512, 9, 20, True), (192, 256, 6, 8, True)])
+def test_fused_pointwise_tail_matches_torch(fm, C, M, H, W, res):
+    """ssad_conv1x1_bias_act (both the persistent 64-channel kernel and the chunked one) and its
+    autograd wrapper against conv2d + add + relu."""
+    from ssad_amd import kernels as K
+    torch.manual_seed(13)
+    x = torch.randn(3, C, H, W, device="cuda")
+    w = torch.randn(M, C, 1, 1, device="cuda") * 0.1
+    b = torch.randn(M, device="cuda")
+    r = torch.randn(3, M, H, W, device="cuda") if res else None
+    want = torch.relu(torch.nn.functional.conv2d(x, w, b) + (r if res else 0))
+    got = K.conv1x1_bias_act(x, w, b, r, relu=True)
+    assert _rel(got, want) < 2e-6
+    if not res or C not in (64, 128):
+        return
+    dy = torch.randn_like(want)
+    xr, wr, br, rr = (t.clone().requires_grad_(True) for t in (x, w, b, r))
+    torch.relu(torch.nn.functional.conv2d(xr, wr, br) + rr).backward(dy)
+    xh, wh, bh, rh = (t.clone().requires_grad_(True) for t in (x, w, b, r))
+    yh = fm.conv1x1_tail(xh, wh, bh, rh)
+    assert _rel(yh, want) < 2e-6
+    yh.backward(dy)
+    for a, c in ((xh.grad, xr.grad), (wh.grad, wr.grad), (bh.grad, br.grad), (rh.grad, rr.grad)):
+        assert _rel(a, c) < 1e-5
