@@ -125,25 +125,33 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_fused_kernel(const PwArgs
   }
 }
 
-// ---- 64 input channels (res2's c3): persistent workgroups --------------------------------
-// The layer is HBM bound (12 B per 128 flop), so what matters is bytes in flight: a workgroup
-// keeps its W^T block [64][128] in LDS for its whole life and walks over (image, 64-pixel)
-// tiles; while tile i is multiplied and stored, tile i+1's X block (-> registers -> the other
-// LDS buffer) and shortcut block (-> the next accumulators) are already on their way.
+// ---- 64 / 128 input channels (the last layers of res2 / res3): persistent workgroups -------
+// The layer is HBM bound (12 B against 2 C flop per output element), so what matters is bytes
+// in flight: a workgroup keeps its W^T block [C][128] in LDS for its whole life and walks over
+// (image, 64-pixel) tiles; while tile i is multiplied and stored, tile i+1's X block
+// (-> registers -> the other LDS buffer) and shortcut block (-> the next accumulators) are
+// already on their way.  C = 64: 4 waves, 64 KiB of LDS, 2 workgroups per CU; C = 128: 8 waves,
+// 128 KiB, one workgroup per CU.
 constexpr int PT = 64;        // pixels per tile
-__global__ __launch_bounds__(kThreads, 2) void conv1x1_fused_c64_kernel(const PwArgs a, int tiles) {
-  __shared__ float wl[64][TM];
-  __shared__ float xl[2][64][PT];
+template <int C_, int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv1x1_fused_persistent_kernel(const PwArgs a, int tiles) {
+  extern __shared__ float smem[];
+  float (*wl)[TM] = reinterpret_cast<float (*)[TM]>(smem);                       // [C_][128]
+  float (*xl)[C_][PT] = reinterpret_cast<float (*)[C_][PT]>(smem + C_ * TM);     // [2][C_][64]
+  constexpr int CT = (PT / 32) / (NT / 256);      // 32-pixel column tiles per wave
+  constexpr int XQ = C_ * PT / 4 / NT;            // float4 of the X tile per thread
+  constexpr int WK = C_ / (NT / 128);             // consecutive k per thread in the W^T staging
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * TM, mw = m0 + wave * 32;       // this wave's 32 output channels
+  const int wm = wave & 3, c0 = (wave >> 2) * CT;
+  const int m0 = blockIdx.y * TM, mw = m0 + wm * 32;         // this wave's 32 output channels
   {   // W^T block, once
     const int m = tid & 127, kh = tid >> 7;
-    const float4* src = reinterpret_cast<const float4*>(a.w + (long long)(m0 + m) * 64 + kh * 32);
+    const float4* src = reinterpret_cast<const float4*>(a.w + (long long)(m0 + m) * C_ + kh * WK);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < WK / 4; ++q) {
       const float4 v = src[q];
-      const int k = kh * 32 + q * 4;
+      const int k = kh * WK + q * 4;
       wl[k][m] = v.x; wl[k + 1][m] = v.y; wl[k + 2][m] = v.z; wl[k + 3][m] = v.w;
     }
   }
@@ -151,15 +159,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_fused_c64_kernel(const Pw
 #pragma unroll
   for (int r = 0; r < 16; ++r) bv[r] = a.bias ? a.bias[mw + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.0f;
 
-  // X tile: 64 rows x 64 pixels = 1024 float4, 4 per thread: row e >> 4, float4 column e & 15
-  float4 xr[4];
-  f32x16 acc[2], nxt[2];
+  float4 xr[XQ];
+  f32x16 acc[CT], nxt[CT];
   auto fetch_x = [&](int t) {
     const int n = t / a.ptiles, p0 = (t % a.ptiles) * PT;
-    const float* xn = a.x + (long long)n * 64 * a.P;
+    const float* xn = a.x + (long long)n * C_ * a.P;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = tid + kThreads * q;
+    for (int q = 0; q < XQ; ++q) {
+      const int e = tid + NT * q;
       const int k = e >> 4, p = p0 + (e & 15) * 4;
       xr[q] = p < a.P ? *reinterpret_cast<const float4*>(xn + (long long)k * a.P + p)
                       : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -167,16 +174,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_fused_c64_kernel(const Pw
   };
   auto stash_x = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = tid + kThreads * q;
+    for (int q = 0; q < XQ; ++q) {
+      const int e = tid + NT * q;
       *reinterpret_cast<float4*>(&xl[buf][e >> 4][(e & 15) * 4]) = xr[q];
     }
   };
-  auto fetch_r = [&](int t, f32x16 (&dst)[2]) {
+  auto fetch_r = [&](int t, f32x16 (&dst)[CT]) {
     const int n = t / a.ptiles, p0 = (t % a.ptiles) * PT;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int p = p0 + c * 32 + j;
+    for (int c = 0; c < CT; ++c) {
+      const int p = p0 + (c0 + c) * 32 + j;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -200,18 +207,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_fused_c64_kernel(const Pw
       fetch_r(tn, nxt);
     }
 #pragma unroll 8
-    for (int ks = 0; ks < 32; ++ks) {
+    for (int ks = 0; ks < C_ / 2; ++ks) {
       const int k = 2 * ks + h;
-      const float av = wl[k][wave * 32 + j];
+      const float av = wl[k][wm * 32 + j];
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xl[cur][k][c * 32 + j], acc[c], 0, 0, 0);
+      for (int c = 0; c < CT; ++c)
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xl[cur][k][(c0 + c) * 32 + j], acc[c], 0, 0, 0);
     }
     {
       const int n = t / a.ptiles, p0 = (t % a.ptiles) * PT;
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int p = p0 + c * 32 + j;
+      for (int c = 0; c < CT; ++c) {
+        const int p = p0 + (c0 + c) * 32 + j;
         if (p >= a.P) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -224,8 +231,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_fused_c64_kernel(const Pw
     }
     if (tn < tiles) {
       stash_x(cur ^ 1);
-      acc[0] = nxt[0];
-      acc[1] = nxt[1];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[c] = nxt[c];
     }
     __syncthreads();
   }
@@ -244,7 +251,7 @@ int ssad_conv1x1_bias_act(const float* x, const float* w, const float* bias, con
   PwArgs a;
   a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
   a.N = N; a.C = C; a.P = P; a.M = M; a.relu = relu;
-  if (C == 64) {
+  if (C == 64 || C == 128) {
     a.ptiles = (P + PT - 1) / PT;
     const long long tiles = (long long)N * a.ptiles;
     if (tiles >= (1LL << 31)) return SSAD_E_BADARG;
@@ -256,10 +263,26 @@ int ssad_conv1x1_bias_act(const float* x, const float* w, const float* bias, con
       return n;
     }();
     const int mblocks = M / TM;
-    long long g = (2LL * cus + mblocks - 1) / mblocks;      // two workgroups per CU in total
+    const int per_cu = C == 64 ? 2 : 1;
+    long long g = ((long long)per_cu * cus + mblocks - 1) / mblocks;
     if (g > tiles) g = tiles;
-    hipLaunchKernelGGL(conv1x1_fused_c64_kernel, dim3((unsigned)g, (unsigned)mblocks), dim3(kThreads), 0,
-                       (hipStream_t)stream, a, (int)tiles);
+    const size_t lds = (size_t)(C * TM + 2 * C * PT) * sizeof(float);
+    const dim3 grid((unsigned)g, (unsigned)mblocks);
+    if (C == 64) {
+      static const bool ok = hipFuncSetAttribute(
+          reinterpret_cast<const void*>(conv1x1_fused_persistent_kernel<64, 256>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (64 * TM + 2 * 64 * PT) * 4) == hipSuccess;
+      if (!ok) return SSAD_E_BADARG;
+      hipLaunchKernelGGL((conv1x1_fused_persistent_kernel<64, 256>), grid, dim3(256), lds, (hipStream_t)stream,
+                         a, (int)tiles);
+    } else {
+      static const bool ok = hipFuncSetAttribute(
+          reinterpret_cast<const void*>(conv1x1_fused_persistent_kernel<128, 512>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (128 * TM + 2 * 128 * PT) * 4) == hipSuccess;
+      if (!ok) return SSAD_E_BADARG;
+      hipLaunchKernelGGL((conv1x1_fused_persistent_kernel<128, 512>), grid, dim3(512), lds, (hipStream_t)stream,
+                         a, (int)tiles);
+    }
     return (int)hipGetLastError();
   }
   a.ptiles = (P + TP - 1) / TP;
