@@ -323,6 +323,13 @@ SSAD_API int ssad_relu_grad_rowsum(const float* y, const float* dy, float* dx, f
 SSAD_API int ssad_conv1x1_bias_act(const float* x, const float* w, const float* bias,
                                    const float* residual, float* y, int N, int C, int P, int M,
                                    int relu, ssad_stream_t stream);
+/* The same with the input channels split over two tensors, x [N][C1][P] and x2 [N][C2][P]
+ * (C1 + C2 = 128, w [M][C1 + C2]): a bottleneck's last layer and its projection shortcut
+ * (ResNet.py:199-213) as ONE product, y = act([W3 | Wproj] . [y2 ; x] + bias) -- the
+ * projection's output is never written. */
+SSAD_API int ssad_conv1x1_bias_act2(const float* x, int C1, const float* x2, int C2, const float* w,
+                                    const float* bias, const float* residual, float* y, int N, int P,
+                                    int M, int relu, ssad_stream_t stream);
 /* MaxPool / MaxPoolGradient, NCHW (caffe2/operators/pool_op.cu): windows are clipped to
  * the image; every input equal to its window's maximum receives the gradient */
 SSAD_API int ssad_max_pool_forward(const float* x, int N, int C, int H, int W, int kh, int kw,

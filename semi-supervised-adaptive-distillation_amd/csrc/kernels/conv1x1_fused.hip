@@ -26,7 +26,9 @@ constexpr int kThreads = 256;
 constexpr int TM = 128, TP = 128, KC = 64;
 
 struct PwArgs {
-  const float* x;      // [N][C][P]
+  const float* x2;     // optional second input [N][C - C1][P]: input channels C1.. come from it
+  int C1;              // channels taken from x (= C when x2 is null)
+  const float* x;      // [N][C1][P]
   const float* w;      // [M][C]
   const float* bias;   // [M] or null
   const float* res;    // [N][M][P] or null
@@ -163,13 +165,14 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv1x1_fused_persisten
   f32x16 acc[CT], nxt[CT];
   auto fetch_x = [&](int t) {
     const int n = t / a.ptiles, p0 = (t % a.ptiles) * PT;
-    const float* xn = a.x + (long long)n * C_ * a.P;
+    const float* xn = a.x + (long long)n * a.C1 * a.P;
+    const float* xn2 = a.x2 ? a.x2 + (long long)n * (C_ - a.C1) * a.P : nullptr;
 #pragma unroll
     for (int q = 0; q < XQ; ++q) {
       const int e = tid + NT * q;
       const int k = e >> 4, p = p0 + (e & 15) * 4;
-      xr[q] = p < a.P ? *reinterpret_cast<const float4*>(xn + (long long)k * a.P + p)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* row = k < a.C1 ? xn + (long long)k * a.P : xn2 + (long long)(k - a.C1) * a.P;
+      xr[q] = p < a.P ? *reinterpret_cast<const float4*>(row + p) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto stash_x = [&](int buf) {
@@ -242,14 +245,28 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv1x1_fused_persisten
 
 extern "C" {
 
+int ssad_conv1x1_bias_act2(const float* x, int C1, const float* x2, int C2, const float* w, const float* bias,
+                           const float* residual, float* y, int N, int P, int M, int relu,
+                           ssad_stream_t stream);
+
 int ssad_conv1x1_bias_act(const float* x, const float* w, const float* bias, const float* residual,
                           float* y, int N, int C, int P, int M, int relu, ssad_stream_t stream) {
-  if (!x || !w || !y || N < 0 || C < KC || (C % KC) || M < TM || (M % TM) || P < 4 || (P & 3))
+  return ssad_conv1x1_bias_act2(x, C, nullptr, 0, w, bias, residual, y, N, P, M, relu, stream);
+}
+
+int ssad_conv1x1_bias_act2(const float* x, int C1, const float* x2, int C2, const float* w, const float* bias,
+                           const float* residual, float* y, int N, int P, int M, int relu,
+                           ssad_stream_t stream) {
+  const int C = C1 + C2;
+  if (!x || !w || !y || N < 0 || C1 < 1 || C2 < 0 || C < KC || (C % KC) || M < TM || (M % TM) || P < 4 ||
+      (P & 3))
     return SSAD_E_BADARG;
-  if (((uintptr_t)x | (uintptr_t)w) & 15) return SSAD_E_BADARG;
+  if ((x2 != nullptr) != (C2 > 0)) return SSAD_E_BADARG;
+  if (x2 && C != 128) return SSAD_E_BADARG;            // two inputs: the 128-channel persistent kernel only
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)x2) & 15) return SSAD_E_BADARG;
   if (N == 0) return 0;
   PwArgs a;
-  a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
+  a.x = x; a.x2 = x2; a.C1 = C1; a.w = w; a.bias = bias; a.res = residual; a.y = y;
   a.N = N; a.C = C; a.P = P; a.M = M; a.relu = relu;
   if (C == 64 || C == 128) {
     a.ptiles = (P + PT - 1) / PT;

@@ -301,6 +301,7 @@ class Bottleneck(nn.Module):
             self.c2 = nn.Conv2d(cmid, cmid, 3, stride=s3, padding=1, groups=groups, bias=True)
         self.c3 = conv_frozen_bn(cmid, cout, 1)
         self.proj = conv_frozen_bn(cin, cout, 1, stride=stride) if (cin != cout or stride != 1) else None
+        self._w12 = self._b12 = None      # frozen [W3 | Wproj] and bias sum (see forward)
 
     def forward(self, x):
         if _FUSE_TAIL and x.is_contiguous():
@@ -312,6 +313,20 @@ class Bottleneck(nn.Module):
             if self.c1.stride != (1, 1):
                 x = xs
             b3 = self.c3.bias
+            frozen = not (x.requires_grad or self.c3.weight.requires_grad)
+            if (_FUSED_PW and frozen and self.proj is not None and x is xs and self.hip2
+                    and self.c3.weight.shape[1] + self.proj.weight.shape[1] == 128
+                    and self.c3.weight.shape[0] % 128 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0):
+                # res2's first block, frozen: last layer and projection shortcut as ONE product
+                # [W3 | Wproj] . [y2 ; x] -- the projection's output is never written
+                if self._w12 is None:
+                    M = self.c3.weight.shape[0]
+                    self._w12 = torch.cat([self.c3.weight.detach().view(M, -1),
+                                           self.proj.weight.detach().view(M, -1)], 1).contiguous()
+                    self._b12 = (self.c3.bias + self.proj.bias).detach().contiguous()
+                y = bias_act(conv1x1(x, self.c1.weight), self.c1.bias)
+                y = self.c2(y)
+                return _K().conv1x1_bias_act2(y, x, self._w12, self._b12, relu=True)
             if _GEMM_1X1 and x.requires_grad and x is xs:
                 # c1 and the shortcut tap in one node: their gradients meet inside c1's GEMM
                 z1, xs = _Conv1x1ShortcutFn.apply(x, self.c1.weight)

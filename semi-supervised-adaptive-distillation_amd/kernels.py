@@ -104,6 +104,7 @@ def lib():
     L.ssad_max_pool3x3s2_bias_relu.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_relu_grad_rowsum.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.ssad_conv1x1_bias_act.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.ssad_conv1x1_bias_act2.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.ssad_f16_pack_activations.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
     L.ssad_f16_unpack_activations.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
     L.ssad_f16_filter_halves.restype = sz
@@ -347,6 +348,21 @@ def conv1x1_bias_act(x, w, bias=None, residual=None, relu=True):
         _f32c(residual, "residual")
     _check(lib().ssad_conv1x1_bias_act(_ptr(x), _ptr(w2), _ptr(bias), _ptr(residual), _ptr(y), N, Cc, H * W, M,
                                        int(relu), _stream()), "conv1x1_bias_act")
+    return y
+
+
+def conv1x1_bias_act2(x1, x2, w12, bias=None, relu=True):
+    """act([W1 | W2] . [x1 ; x2] + bias): two pointwise convolutions into one output (a
+    bottleneck's last layer + its projection shortcut); w12 is [M][C1 + C2]."""
+    _f32c(x1, "x1"); _f32c(x2, "x2"); _f32c(w12, "w12")
+    N, C1, H, W = x1.shape
+    C2, M = x2.shape[1], w12.shape[0]
+    assert x2.shape[0] == N and x2.shape[2:] == x1.shape[2:] and w12.shape[1] == C1 + C2
+    y = torch.empty((N, M, H, W), dtype=torch.float32, device="cuda")
+    if bias is not None:
+        _f32c(bias, "bias")
+    _check(lib().ssad_conv1x1_bias_act2(_ptr(x1), C1, _ptr(x2), C2, _ptr(w12), _ptr(bias), _ptr(None), _ptr(y),
+                                        N, H * W, M, int(relu), _stream()), "conv1x1_bias_act2")
     return y
 
 
