@@ -318,7 +318,7 @@ SSAD_API int ssad_relu_grad_rowsum(const float* y, const float* dy, float* dx, f
 /* Pointwise convolution with the bottleneck tail in its epilogue (detectron/lib/modeling/
  * ResNet.py:176-197, :223-283: Conv(kernel=1) -> AffineChannel, folded into w / bias -> Sum with
  * the shortcut -> Relu):  y[n][m][p] = act(sum_c w[m][c] x[n][c][p] + bias[m] (+ residual[n][m][p])).
- * NCHW fp32, exact fp32 MFMA.  C % 64 == 0, M % 128 == 0, P % 4 == 0 (else SSAD_E_BADARG: use
+ * NCHW fp32, exact fp32 MFMA.  C % 32 == 0, M % 128 == 0, P % 4 == 0 (else SSAD_E_BADARG: use
  * the default engine).  bias / residual may be NULL. */
 SSAD_API int ssad_conv1x1_bias_act(const float* x, const float* w, const float* bias,
                                    const float* residual, float* y, int N, int C, int P, int M,

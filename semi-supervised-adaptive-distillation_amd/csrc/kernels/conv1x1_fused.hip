@@ -10,11 +10,12 @@
 // LDS, W stays in LDS for the whole workgroup, and the accumulators meet bias, shortcut and
 // ReLU in registers.  The arithmetic is exact fp32 MFMA (v_mfma_f32_32x32x2f32).
 //
-// Workgroup = 4 waves, tile 128 output channels x 128 pixels (wave = 64 x 64 = 2 x 2 MFMA
-// tiles); K is processed in chunks of 64 input channels: W chunk [64][128] and X chunk [64][128]
-// in LDS (64 KiB -> 2 workgroups per CU).
+// Two kernels: persistent, prefetching workgroups with W^T resident in LDS for 64 / 128 input
+// channels (the HBM-bound cases this exists for), and a generic one (any multiple of 32 input
+// channels): 4 waves, tile 128 output channels x 128 pixels, K in double-buffered chunks of 32.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ssad_kernels.h"
 
@@ -23,7 +24,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
-constexpr int TM = 128, TP = 128, KC = 64;
+constexpr int TM = 128, TP = 128;
 
 struct PwArgs {
   const float* x2;     // optional second input [N][C - C1][P]: input channels C1.. come from it
@@ -37,9 +38,13 @@ struct PwArgs {
   int ptiles;          // ceil(P / 128)
 };
 
-__global__ __launch_bounds__(kThreads, 2) void conv1x1_fused_kernel(const PwArgs a) {
-  __shared__ float wl[KC][TM];        // W^T chunk: [k][m]
-  __shared__ float xl[KC][TP];        // X chunk:   [k][p]
+// ---- any other channel count (multiples of 32): K in double-buffered chunks of 32 -----------
+// The next chunk's W and X blocks travel global -> registers while the current one is
+// multiplied, then registers -> the other LDS buffer; one barrier per chunk.
+constexpr int KP = 32;
+__global__ __launch_bounds__(kThreads, 2) void conv1x1_fused_pipelined_kernel(const PwArgs a) {
+  __shared__ float wl[2][KP][TM];
+  __shared__ float xl[2][KP][TP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wp = wave >> 1;
   const int j = lane & 31, h = lane >> 5;
@@ -47,9 +52,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_fused_kernel(const PwArgs
   const int m0 = blockIdx.y * TM, p0 = pt * TP;
   const float* xn = a.x + (long long)n * a.C * a.P;
 
-  // The accumulators start from the shortcut (and the bias): its 64 loads per lane are in
-  // flight while W and X are staged and stay so into the MFMA loop -- the kernel is HBM bound,
-  // a shortcut fetched in the epilogue would leave the memory pipe idle during the K loop.
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -63,47 +65,59 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_fused_kernel(const PwArgs
       }
     }
 
-  for (int k0 = 0; k0 < a.C; k0 += KC) {
-    if (k0) __syncthreads();
-    // W chunk: thread -> (m = tid & 127, k half); 64 x 128 floats, transposed into [k][m]
-    {
-      const int m = tid & 127, kh = tid >> 7;
-      const float4* src = reinterpret_cast<const float4*>(a.w + (long long)(m0 + m) * a.C + k0 + kh * 32);
+  float4 wr[4], xr[4];
+  const int w_m = tid & 127, w_kh = tid >> 7;              // W: row m, 16 consecutive k
+  auto fetch = [&](int k0) {
+    const float4* src = reinterpret_cast<const float4*>(a.w + (long long)(m0 + w_m) * a.C + k0 + w_kh * 16);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float4 v = src[q];
-        const int k = kh * 32 + q * 4;
-        wl[k][m] = v.x; wl[k + 1][m] = v.y; wl[k + 2][m] = v.z; wl[k + 3][m] = v.w;
-      }
-    }
-    // X chunk: 64 rows x 128 pixels = 2048 float4; thread -> 8 of them
+    for (int q = 0; q < 4; ++q) wr[q] = src[q];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 4; ++q) {
       const int e = tid + kThreads * q;
-      const int k = e >> 5, c4 = e & 31;
-      const int p = p0 + c4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < a.P) v = *reinterpret_cast<const float4*>(xn + (long long)(k0 + k) * a.P + p);
-      *reinterpret_cast<float4*>(&xl[k][c4 * 4]) = v;
+      const int k = e >> 5, p = p0 + (e & 31) * 4;
+      xr[q] = p < a.P ? *reinterpret_cast<const float4*>(xn + (long long)(k0 + k) * a.P + p)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    __syncthreads();
-#pragma unroll 8
-    for (int ks = 0; ks < KC / 2; ++ks) {
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = w_kh * 16 + q * 4;
+      wl[buf][k][w_m] = wr[q].x; wl[buf][k + 1][w_m] = wr[q].y;
+      wl[buf][k + 2][w_m] = wr[q].z; wl[buf][k + 3][w_m] = wr[q].w;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + kThreads * q;
+      *reinterpret_cast<float4*>(&xl[buf][e >> 5][(e & 31) * 4]) = xr[q];
+    }
+  };
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  const int chunks = a.C / KP;
+  for (int c = 0; c < chunks; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < chunks) fetch((c + 1) * KP);
+#pragma unroll
+    for (int ks = 0; ks < KP / 2; ++ks) {
       const int k = 2 * ks + h;
       float av[2], bv[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) av[i] = wl[k][wm * 64 + i * 32 + j];
+      for (int i = 0; i < 2; ++i) av[i] = wl[cur][k][wm * 64 + i * 32 + j];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) bv[t] = xl[k][wp * 64 + t * 32 + j];
+      for (int t = 0; t < 2; ++t) bv[t] = xl[cur][k][wp * 64 + t * 32 + j];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
           acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[t], acc[i][t], 0, 0, 0);
     }
+    if (c + 1 < chunks) stash(cur ^ 1);
+    __syncthreads();
   }
 
-  // epilogue: C/D row = (r & 3) + 8 (r >> 2) + 4 h (output channel), column = j (pixel)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     float bvv[16];
@@ -258,7 +272,7 @@ int ssad_conv1x1_bias_act2(const float* x, int C1, const float* x2, int C2, cons
                            const float* residual, float* y, int N, int P, int M, int relu,
                            ssad_stream_t stream) {
   const int C = C1 + C2;
-  if (!x || !w || !y || N < 0 || C1 < 1 || C2 < 0 || C < KC || (C % KC) || M < TM || (M % TM) || P < 4 ||
+  if (!x || !w || !y || N < 0 || C1 < 1 || C2 < 0 || C < KP || (C % KP) || M < TM || (M % TM) || P < 4 ||
       (P & 3))
     return SSAD_E_BADARG;
   if ((x2 != nullptr) != (C2 > 0)) return SSAD_E_BADARG;
@@ -304,8 +318,8 @@ int ssad_conv1x1_bias_act2(const float* x, int C1, const float* x2, int C2, cons
   }
   a.ptiles = (P + TP - 1) / TP;
   if ((long long)N * a.ptiles >= (1LL << 31)) return SSAD_E_BADARG;
-  hipLaunchKernelGGL(conv1x1_fused_kernel, dim3((unsigned)(N * a.ptiles), (unsigned)(M / TM)), dim3(kThreads), 0,
-                     (hipStream_t)stream, a);
+  hipLaunchKernelGGL(conv1x1_fused_pipelined_kernel, dim3((unsigned)(N * a.ptiles), (unsigned)(M / TM)),
+                     dim3(kThreads), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

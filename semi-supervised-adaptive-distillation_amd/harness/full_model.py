@@ -177,7 +177,7 @@ def conv1x1_tail(y, w, bias, sc):
     """relu(conv1x1(y, w) + bias + sc): fused kernel where it wins (64 / 128 input channels,
     i.e. res2 / res3), GEMM + fused tail pass elsewhere."""
     cin, cout = w.shape[1], w.shape[0]
-    if (_FUSED_PW and cin in (64, 128) and cout % 128 == 0 and (y.shape[2] * y.shape[3]) % 4 == 0
+    if (_FUSED_PW and cin in _FUSED_PW_CIN and cout % 128 == 0 and (y.shape[2] * y.shape[3]) % 4 == 0
             and y.is_contiguous() and sc.is_contiguous()):
         if y.requires_grad or w.requires_grad or bias.requires_grad or sc.requires_grad:
             return _Conv1x1TailFn.apply(y, w, bias, sc)
@@ -256,6 +256,7 @@ _FUSE_TAIL = os.environ.get("SSAD_HARNESS_FUSE_TAIL", "1") == "1"
 _GEMM_1X1 = os.environ.get("SSAD_HARNESS_GEMM_1X1", "1") == "1"
 # last layer of the res2 / res3 bottlenecks as one fused kernel (see _Conv1x1TailFn)
 _FUSED_PW = os.environ.get("SSAD_HARNESS_FUSED_PW", "1") == "1"
+_FUSED_PW_CIN = tuple(int(v) for v in os.environ.get("SSAD_HARNESS_FUSED_PW_CIN", "64,128").split(","))
 # TunableOp: "1" = use the committed per-shape GEMM picks when the file matches this
 # stack (its validator lines name torch / ROCm / rocBLAS / hipBLASLt / gfx arch; on a
 # mismatch torch ignores it), "tune" = search and write SSAD_TUNABLEOP_OUT, "0" = off

@@ -219,7 +219,7 @@ def test_relu_grad_with_row_sums(hw):
 
 
 @pytest.mark.parametrize("C,M,H,W,res", [(64, 256, 10, 24, True), (64, 128, 7, 12, False),
-                                         (128, 512, 9, 20, True), (192, 256, 6, 8, True)])
+                                         (128, 512, 9, 20, True), (192, 256, 6, 8, True), (96, 128, 5, 12, False)])
 def test_fused_pointwise_tail_matches_torch(fm, C, M, H, W, res):
     """ssad_conv1x1_bias_act (both the persistent 64-channel kernel and the chunked one) and its
     autograd wrapper against conv2d + add + relu."""
