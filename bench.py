@@ -112,6 +112,13 @@ class KernelTimer(object):
                   if min(Cin, Cout) > 64 else None)
             return timed_call(o4, fl, (xbs, packed, bias, Cin, Cout, outs), kw)
         K.conv3x3_forward_f16_levels = lev16
+        o5 = K.conv3x3_forward_f16_multi
+
+        def multi16(problems, Cin, Cout, **kw):
+            px16 = sum(x.shape[0] * x.shape[2] * x.shape[3] for p in problems for x in p["xs"])
+            fl = 2.0 * 9 * Cout * Cin * px16 if min(Cin, Cout) > 64 else None
+            return timed_call(o5, fl, (problems, Cin, Cout), kw)
+        K.conv3x3_forward_f16_multi = multi16
 
     def summary(self):
         if not self.records:

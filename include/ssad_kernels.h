@@ -403,14 +403,19 @@ SSAD_API int ssad_f16_pack_filter(const float* w, int M, int C, void* packed_fwd
 SSAD_API int ssad_conv3x3_forward_f16(const void* x_blocked, const void* packed, const float* bias,
                                       const void* aux, int N, int C, int H, int W, int M, int flags,
                                       void* y, ssad_stream_t stream);
-/* The same for every FPN level sharing the filter in ONE launch (n_levels <=
- * SSAD_MAX_F16_LEVELS); aux per level, all NULL or (with SSAD_CONV_MASK_AUX) all set. */
-#define SSAD_MAX_F16_LEVELS 8
+/* The same for every FPN level sharing the filter -- and for several such problems of equal
+ * (C, M), see the per-entry packed / bias -- in ONE launch (n_levels <= SSAD_MAX_F16_LEVELS);
+ * aux per level, all NULL or (with SSAD_CONV_MASK_AUX) all set. */
+#define SSAD_MAX_F16_LEVELS 24
 typedef struct ssad_f16_level {
   const void* x;      /* blocked fp16 [N][ceil(C/8)][H][W][8] */
   void* y;            /* blocked fp16 [N][M/8][H][W][8] or float [N][M][H][W] */
   const void* aux;    /* blocked fp16 like y, or NULL */
   int N, H, W;
+  /* optional per-entry filter / bias (NULL = the call's): independent convolutions of one
+   * (C, M) -- teacher and student, cls and bbox tower layers of equal depth -- in one launch */
+  const void* packed;
+  const float* bias;
 } ssad_f16_level;
 SSAD_API int ssad_conv3x3_forward_f16_levels(const ssad_f16_level* levels_host, int n_levels,
                                              const void* packed, const float* bias, int C, int M,

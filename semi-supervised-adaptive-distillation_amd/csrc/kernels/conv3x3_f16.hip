@@ -60,9 +60,9 @@ struct F16Levels {
   const _Float16* aux[SSAD_MAX_F16_LEVELS];
   int N[SSAD_MAX_F16_LEVELS], H[SSAD_MAX_F16_LEVELS], W[SSAD_MAX_F16_LEVELS];
   int tile0[SSAD_MAX_F16_LEVELS + 1];      // first workgroup (blockIdx.x) of each level
+  const uint4* w[SSAD_MAX_F16_LEVELS];     // per entry: independent problems share a launch
+  const float* bias[SSAD_MAX_F16_LEVELS];
   int n_levels;
-  const uint4* w;
-  const float* bias;
   int C, M, relu, sigmoid, out_nchw_f32;
 };
 
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Level
   for (int l = 1; l < q.n_levels; ++l)
     if ((int)blockIdx.x >= q.tile0[l]) lv = l;
   F16Conv p;
-  p.x = q.x[lv]; p.w = q.w; p.bias = q.bias; p.aux = q.aux[lv]; p.y = q.y[lv];
+  p.x = q.x[lv]; p.w = q.w[lv]; p.bias = q.bias[lv]; p.aux = q.aux[lv]; p.y = q.y[lv];
   p.N = q.N[lv]; p.C = q.C; p.H = q.H[lv]; p.W = q.W[lv]; p.M = q.M;
   p.tiles_x = (p.W + TS - 1) / TS; p.tiles_y = (p.H + TS - 1) / TS;
   p.relu = q.relu; p.sigmoid = q.sigmoid; p.out_nchw_f32 = q.out_nchw_f32;
@@ -407,8 +407,7 @@ int ssad_f16_pack_filter(const float* w, int M, int C, void* wf, void* wd, ssad_
 
 int ssad_conv3x3_forward_f16_levels(const ssad_f16_level* levels, int n_levels, const void* wp,
                                     const float* bias, int C, int M, int flags, ssad_stream_t stream) {
-  if (!levels || n_levels < 1 || n_levels > SSAD_MAX_F16_LEVELS || !wp || M < 1 || C < 1)
-    return SSAD_E_BADARG;
+  if (!levels || n_levels < 1 || n_levels > SSAD_MAX_F16_LEVELS || M < 1 || C < 1) return SSAD_E_BADARG;
   const int nchw = (flags & SSAD_F16_OUT_NCHW_F32) != 0;
   const int masked = (flags & SSAD_CONV_MASK_AUX) != 0;
   if (!nchw && (M & 7)) return SSAD_E_BADARG;                   // blocked output: whole 8-blocks
@@ -423,6 +422,9 @@ int ssad_conv3x3_forward_f16_levels(const ssad_f16_level* levels, int n_levels, 
     q.y[l] = L.y;
     q.aux[l] = static_cast<const _Float16*>(L.aux);
     q.N[l] = L.N; q.H[l] = L.H; q.W[l] = L.W;
+    q.w[l] = static_cast<const uint4*>(L.packed ? L.packed : wp);
+    q.bias[l] = L.packed ? L.bias : bias;
+    if (!q.w[l]) return SSAD_E_BADARG;
     q.tile0[l] = (int)tiles;
     tiles += (long long)L.N * ((L.W + TS - 1) / TS) * ((L.H + TS - 1) / TS);
     if (tiles >= (1LL << 31)) return SSAD_E_BADARG;
@@ -430,8 +432,6 @@ int ssad_conv3x3_forward_f16_levels(const ssad_f16_level* levels, int n_levels, 
   for (int l = n_levels; l <= SSAD_MAX_F16_LEVELS; ++l) q.tile0[l] = (int)tiles;
   if (tiles == 0) return 0;
   q.n_levels = n_levels;
-  q.w = static_cast<const uint4*>(wp);
-  q.bias = bias;
   q.C = C; q.M = M;
   q.relu = (flags & SSAD_CONV_RELU) != 0;
   q.sigmoid = (flags & SSAD_CONV_SIGMOID) != 0;
@@ -453,6 +453,7 @@ int ssad_conv3x3_forward_f16(const void* xb, const void* wp, const float* bias, 
   if (((flags & SSAD_CONV_MASK_AUX) != 0) != (aux != nullptr)) return SSAD_E_BADARG;
   ssad_f16_level L;
   L.x = xb; L.y = y; L.aux = aux; L.N = N; L.H = H; L.W = W;
+  L.packed = nullptr; L.bias = nullptr;
   return ssad_conv3x3_forward_f16_levels(&L, 1, wp, bias, C, M, flags, stream);
 }
 

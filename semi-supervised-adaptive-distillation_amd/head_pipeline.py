@@ -404,15 +404,21 @@ class DistillHeadsF16(DistillHeads):
         sx = {"cls": self.fpn_in, "bbox": self.fpn_in}
         F = K.conv3x3_forward_f16_levels          # all five levels of a layer in one launch
         for i in range(cfg.num_convs):
+            # the four tower layers of equal depth (teacher / student x cls / bbox) are independent
+            # convolutions of one shape: ONE launch of 20 (level, filter) problems, as on the fp32 path
+            probs = []
             for t in ("cls", "bbox"):
                 name = self._layers(t)[i]
                 if t == "cls" or self.teacher_bbox_tower:
                     out = self.t_buf[t][i & 1]
-                    F(tx[t], self.t_packed[name], self.teacher[name + "_b"], D, D, out, relu=True)
+                    probs.append(dict(xs=tx[t], packed=self.t_packed[name], bias=self.teacher[name + "_b"],
+                                      out=out))
                     tx[t] = out
                 out = self.act[t][i]
-                F(sx[t], self.packed[name][0], self.params[name + "_b"], D, D, out, relu=True)
+                probs.append(dict(xs=sx[t], packed=self.packed[name][0], bias=self.params[name + "_b"],
+                                  out=out))
                 sx[t] = out
+            K.conv3x3_forward_f16_multi(probs, D, D, relu=True)
         cp, bp = self._layers("cls")[-1], self._layers("bbox")[-1]
         AC, A4 = self.A * self.C, 4 * self.A
         F(tx["cls"], self.t_packed[cp], self.teacher[cp + "_b"], D, AC, self.t_prob, sigmoid=True,
@@ -441,15 +447,17 @@ class DistillHeadsF16(DistillHeads):
             K.conv3x3_forward_f16_levels(dy[t], self.packed[name][1], None, Cout, D, out, mask_bys=x_in)
             dy[t] = out
         for li in range(nl - 1, -1, -1):
+            probs = []
             for t in ("cls", "bbox"):
                 name = self._layers(t)[li]
                 x_in = self.act[t][li - 1] if li > 0 else self.fpn_in
                 K.conv3x3_wgrad_f16(x_in, dy[t], D, D, scale=1.0 / S, dW=self.grads[name + "_w"],
                                     db=self.grads[name + "_b"])
                 out = self.dbuf[t][li & 1]
-                K.conv3x3_forward_f16_levels(dy[t], self.packed[name][1], None, D, D, out,
-                                             mask_bys=x_in if li > 0 else None)
+                probs.append(dict(xs=dy[t], packed=self.packed[name][1], bias=None, out=out,
+                                  mask_by=x_in if li > 0 else None))
                 dy[t] = out
+            K.conv3x3_forward_f16_multi(probs, D, D)      # both towers' data gradients: one launch
             if li == nl // 2:
                 self._allreduce_async("late")
         for t in ("cls", "bbox"):

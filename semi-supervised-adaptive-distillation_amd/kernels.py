@@ -53,7 +53,8 @@ class F16WgradLevel(C.Structure):
 
 class F16Level(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("aux", C.c_void_p),
-                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int)]
+                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("packed", C.c_void_p), ("bias", C.c_void_p)]
 
 
 _lib = None
@@ -648,6 +649,34 @@ def conv3x3_forward_f16_levels(xbs, packed, bias, Cin, Cout, outs, *, relu=False
     _check(lib().ssad_conv3x3_forward_f16_levels(arr, n, _ptr(packed), _ptr(bias), Cin, Cout, flags,
                                                  _stream()), "conv3x3_forward_f16_levels")
     return outs
+
+
+def conv3x3_forward_f16_multi(problems, Cin, Cout, *, relu=False, sigmoid=False, out_nchw_f32=False):
+    """Independent fp16 convolutions of equal (Cin, Cout) in ONE launch.  problems: dicts
+    {xs, packed, bias, out, mask_by(optional, all or none)} -- e.g. the cls- and bbox-tower layer
+    of the same depth for teacher and student."""
+    n = sum(len(p["xs"]) for p in problems)
+    arr = (F16Level * n)()
+    masked = [p.get("mask_by") is not None for p in problems]
+    assert all(masked) or not any(masked)
+    i = 0
+    for p in problems:
+        if p.get("bias") is not None:
+            _f32c(p["bias"], "bias")
+        for l, (xb, y) in enumerate(zip(p["xs"], p["out"])):
+            N, CB, H, W, _ = xb.shape
+            assert xb.dtype == torch.float16 and xb.is_contiguous() and CB == (Cin + 7) // 8
+            assert y.is_contiguous() and y.dtype == (torch.float32 if out_nchw_f32 else torch.float16)
+            arr[i].x, arr[i].y = xb.data_ptr(), y.data_ptr()
+            arr[i].aux = p["mask_by"][l].data_ptr() if masked[0] else None
+            arr[i].N, arr[i].H, arr[i].W = N, H, W
+            arr[i].packed = p["packed"].data_ptr()
+            arr[i].bias = p["bias"].data_ptr() if p.get("bias") is not None else None
+            i += 1
+    flags = ((CONV_RELU if relu else 0) | (CONV_SIGMOID if sigmoid else 0)
+             | (CONV_MASK_AUX if masked[0] else 0) | (F16_OUT_NCHW_F32 if out_nchw_f32 else 0))
+    _check(lib().ssad_conv3x3_forward_f16_levels(arr, n, None, None, Cin, Cout, flags, _stream()),
+           "conv3x3_forward_f16_multi")
 
 
 def conv3x3_wgrad_f16(xbs, dybs, Cin, Cout, *, scale=1.0, dW=None, db=None, bias_grad=True):
