@@ -662,33 +662,27 @@ __global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_kernel(const float*
                                                                     float* __restrict__ dw,
                                                                     const float* __restrict__ dbpart,
                                                                     int dbparts, float* __restrict__ db) {
-  // one thread per (m, c): nine taps = nine independent load chains over the splits (coalesced
-  // across the threads of a tap plane), nine contiguous floats written; then the threads past
-  // M C fold the bias partials
+  // one thread per (tap, m, c) element -- 590 K threads for a tower layer; a thread per (m, c)
+  // with nine chains measured 3x slower: too few waves to cover the load latency -- four
+  // independent chains over the splits; then the threads past 9 M C fold the bias partials
   const int i = blockIdx.x * kThreads + threadIdx.x;
-  const int mc = M * C;
-  if (i < mc) {
-    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int total = 9 * M * C;
+  if (i < total) {
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     int k = 0;
-    for (; k + 3 < splits; k += 4) {          // 36 loads in flight per thread: the loop is latency bound
-      float v[4][9];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) v[u][tap] = part[((long long)(k + u) * 9 + tap) * mc + i];
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) acc[tap] += (v[0][tap] + v[1][tap]) + (v[2][tap] + v[3][tap]);
+    for (; k + 3 < splits; k += 4) {
+      s0 += part[(long long)k * total + i];
+      s1 += part[(long long)(k + 1) * total + i];
+      s2 += part[(long long)(k + 2) * total + i];
+      s3 += part[(long long)(k + 3) * total + i];
     }
-    for (; k < splits; ++k) {
-      const float* src = part + (long long)k * 9 * mc + i;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) acc[tap] += src[(long long)tap * mc];
-    }
-    float* o = dw + (long long)i * 9;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) o[tap] = accumulate ? o[tap] + acc[tap] * scale : acc[tap] * scale;
-  } else if (db && i < mc + M) {
-    const int m = i - mc, Mp = (M + 7) & ~7;
+    for (; k < splits; ++k) s0 += part[(long long)k * total + i];
+    const float s = ((s0 + s1) + (s2 + s3)) * scale;
+    const int c = i % C, m = (i / C) % M, tap = i / (C * M);
+    float* o = dw + ((long long)m * C + c) * 9 + tap;
+    *o = accumulate ? *o + s : s;
+  } else if (db && i < total + M) {
+    const int m = i - total, Mp = (M + 7) & ~7;
     float s = 0.0f;
     for (int k = 0; k < dbparts; ++k) s += dbpart[k * Mp + m];
     s *= scale;
@@ -810,7 +804,7 @@ int ssad_conv3x3_wgrad_f16_levels(const ssad_f16_wgrad_level* levels, int n_leve
     for (int l = 0; l < n_levels; ++l)
       hipLaunchKernelGGL(f16_bias_grad_kernel, dim3((M + 7) / 8, kDbSplits), dim3(kThreads), 0, s, p.dy[l],
                          p.N[l], M, p.H[l] * p.W[l], dbpart + (size_t)l * kDbSplits * Mp);
-  hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3((M * C + M + kThreads - 1) / kThreads), dim3(kThreads),
+  hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3((9 * M * C + M + kThreads - 1) / kThreads), dim3(kThreads),
                      0, s, p.part, p.stages > 0 ? splits : 0, M, C, accumulate, scale, dw, dbpart,
                      n_levels * kDbSplits, db);
   return (int)hipGetLastError();
