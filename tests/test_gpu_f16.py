@@ -250,3 +250,37 @@ def test_f16_full_size_adjoint_identities(K):
                 sum((d.double() ** 2).sum() for d in dys) ** 0.5)
     assert abs(s1 - s2) <= 2e-3 * max(scale, 1e-3 * rss), (s1, s2, s3)
     assert abs(s1 - s3) <= 2e-3 * max(scale, 1e-3 * rss), (s1, s2, s3)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_f16_kernels_random_geometries(K, seed):
+    """Random small geometries (odd sizes, channel tails, several tiles / stages / splits) for the
+    three fp16 kernels against float64 on the same fp16-rounded operands."""
+    rng = np.random.default_rng(9000 + seed)
+    N = int(rng.integers(1, 4))
+    C = int(rng.integers(1, 12)) * 8
+    M = int(rng.integers(1, 12)) * 8
+    H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((M, C, 3, 3)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    dy = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    xr, wr, dyr = _r16(x), _r16(w), _r16(dy)
+    xb = K.f16_pack_activations(torch.from_numpy(x).cuda())
+    dyb = K.f16_pack_activations(torch.from_numpy(dy).cuda())
+    wf, wd = K.f16_pack_filter(torch.from_numpy(w).cuda(), True, True)
+    y = K.f16_unpack_activations(K.conv3x3_forward_f16(xb, wf, torch.from_numpy(b).cuda(), C, M), M)
+    want = _conv64(xr, wr, b.astype(np.float64))
+    assert np.abs(y.cpu().numpy() - want).max() <= 8e-4 * max(np.abs(want).max(), 1e-6), (N, C, M, H, W)
+    dx = K.f16_unpack_activations(K.conv3x3_forward_f16(dyb, wd, None, M, C), C)
+    want_dx = _conv64(dyr, np.ascontiguousarray(wr[:, :, ::-1, ::-1].transpose(1, 0, 2, 3)), None)
+    assert np.abs(dx.cpu().numpy() - want_dx).max() <= 8e-4 * max(np.abs(want_dx).max(), 1e-6), (N, C, M, H, W)
+    dW, db = K.conv3x3_wgrad_f16([xb], [dyb], C, M)
+    xp = np.zeros((N, C, H + 2, W + 2))
+    xp[:, :, 1:-1, 1:-1] = xr
+    want_dw = np.zeros((M, C, 3, 3))
+    for ky in range(3):
+        for kx in range(3):
+            want_dw[:, :, ky, kx] = np.einsum("nmhw,nchw->mc", dyr, xp[:, :, ky:ky + H, kx:kx + W])
+    assert np.abs(dW.cpu().numpy() - want_dw).max() <= 3e-5 * max(np.abs(want_dw).max(), 1e-6), (N, C, M, H, W)
+    assert np.abs(db.cpu().numpy() - dyr.sum((0, 2, 3))).max() <= 3e-5 * max(np.abs(dyr.sum((0, 2, 3))).max(), 1e-6)

@@ -243,3 +243,27 @@ def test_fused_pointwise_tail_matches_torch(fm, C, M, H, W, res):
     yh.backward(dy)
     for a, c in ((xh.grad, xr.grad), (wh.grad, wr.grad), (bh.grad, br.grad), (rh.grad, rr.grad)):
         assert _rel(a, c) < 1e-5
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fused_pointwise_random_geometries(seed):
+    from ssad_amd import kernels as K
+    g = torch.Generator().manual_seed(500 + seed)
+    N = int(torch.randint(1, 4, (1,), generator=g))
+    C = [32, 64, 96, 128, 160, 64][seed]
+    M = 128 * int(torch.randint(1, 4, (1,), generator=g))
+    H, W = int(torch.randint(1, 30, (1,), generator=g)), 4 * int(torch.randint(1, 12, (1,), generator=g))
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    w = (torch.randn(M, C, 1, 1, generator=g) * 0.1).cuda()
+    b = torch.randn(M, generator=g).cuda()
+    r = torch.randn(N, M, H, W, generator=g).cuda()
+    for res, relu in ((r, True), (None, True), (r, False)):
+        want = torch.nn.functional.conv2d(x, w, b) + (res if res is not None else 0)
+        want = torch.relu(want) if relu else want
+        got = K.conv1x1_bias_act(x, w, b, res, relu=relu)
+        assert _rel(got, want) < 3e-6, (N, C, M, H, W)
+    if C == 64:
+        x2 = torch.randn(N, 64, H, W, generator=g).cuda()
+        w2 = (torch.randn(M, 128, generator=g) * 0.1).cuda()
+        want = torch.relu(torch.nn.functional.conv2d(torch.cat([x, x2], 1), w2.view(M, 128, 1, 1), b))
+        assert _rel(K.conv1x1_bias_act2(x, x2, w2, b, relu=True), want) < 3e-6
