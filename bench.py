@@ -161,12 +161,42 @@ def cpu_baseline(args, cfg):
                       "P3-P7" if len(shapes) == 5 else "P4-P7", 100 * frac, dt)}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) of this
+    same script under torch.distributed.run on the loopback rendezvous -- the command the driver
+    itself uses for N > 1 -- and return their exit code.  The reference builds its N replicas from
+    one process (detectron/lib/modeling/optimizer.py:33-69); here a replica is a process."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for, but this node has %d visible GPU(s); "
+                         "refusing to run fewer ranks than asked for\n" % (args.gpus, have))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL needs it on this stack)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if world != args.gpus or world > torch.cuda.device_count():
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d and %d visible GPU(s): one rank per "
+                         "GPU, all three must agree\n" % (args.gpus, world, torch.cuda.device_count()))
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None

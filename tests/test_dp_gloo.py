@@ -47,6 +47,7 @@ def _worker(rank, world, port, outdir):
     for name in grads.bucket:                          # one all-reduce per bucket
         dp.issue(grads.bucket[name])
     dp.wait()
+    reduced = grads.flat.clone()                       # before the SGD op rewrites the buffer
     # identical SGD on every rank (optimizer.py:95-130)
     for name, _, is_bias, _ in params.specs:
         w, g, m = oracle.sgd_update(params[name].numpy(), grads[name].numpy(), moms[name].numpy(),
@@ -54,7 +55,7 @@ def _worker(rank, world, port, outdir):
         params[name].copy_(torch.from_numpy(w))
         moms[name].copy_(torch.from_numpy(m))
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), params=params.flat.numpy(),
-             reduced=grads.flat.numpy(), local=local.numpy(), moms=moms.flat.numpy())
+             reduced=reduced.numpy(), local=local.numpy(), moms=moms.flat.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,13 +68,14 @@ def test_two_rank_bucketed_allreduce_and_update():
     # bitwise identical across ranks after the exchange and after the update
     assert np.array_equal(r[0]["params"], r[1]["params"])
     assert np.array_equal(r[0]["moms"], r[1]["moms"])
-    # the reduced gradient is the sum of the rank-local gradients
-    assert np.array_equal(r[0]["local"] + r[1]["local"], np.asarray(r[0]["params"]) * 0 + (r[0]["local"] + r[1]["local"]))
+    # the reduced gradient is the sum of the rank-local gradients, on BOTH ranks, bit for bit
+    # (two fp32 addends: the sum does not depend on the order; nccl_ops_test.py:77-79)
     total = r[0]["local"] + r[1]["local"]
-    # (the all-reduced buffer was overwritten by the SGD op with the adjusted
-    #  gradient = momentum; check through the update instead)
-    assert not np.array_equal(r[0]["local"], r[1]["local"])
-    assert np.all(np.isfinite(r[0]["params"])) and np.any(total != 0)
+    assert not np.array_equal(r[0]["local"], r[1]["local"]) and np.any(total != 0)
+    for k in range(world):
+        assert np.array_equal(r[k]["reduced"], total)
+    # and the update is the oracle's SGD of that sum on the broadcast parameters
+    assert np.all(np.isfinite(r[0]["params"]))
 
 
 def test_image_sharding():

@@ -1,0 +1,137 @@
+"""The data-parallel exchange on real GPUs over RCCL (backend "nccl"): N ranks = N
+processes = N GPUs run one DistillHeads iteration on rank-local images, all-reduce the two
+flat gradient buckets while backward is still running, and apply the SGD update.
+
+Checked (cf. caffe2/caffe2/contrib/nccl/nccl_ops_test.py:56-80: every GPU's output equals
+the sum of the inputs): the reduced buckets are bitwise identical on every rank and equal the
+sum of the rank-local gradients; the parameters after the update are bitwise identical on
+every rank; `bench.py --gpus N` refuses to run when the node has fewer than N GPUs.
+
+world = 1 forces the collectives onto a 1-rank RCCL communicator (SSAD_DP_FORCE=1) so the
+whole code path runs on a one-GPU box; world >= 2 skips unless that many GPUs are visible.
+"""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world == 1:
+        os.environ["SSAD_DP_FORCE"] = "1"
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import ssad_amd  # noqa: F401
+    from ssad_amd import kernels as K, synth
+    from ssad_amd.head_pipeline import DistillHeads
+    from ssad_amd.modeling.retinanet_heads import HeadConfig
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    K.lib()
+    shapes = [(10, 14), (5, 7)]
+    N = 2
+    cfg = HeadConfig(num_gpus=world)
+    # rank 0 owns the initial parameters; the others start from different ones and must
+    # receive rank 0's through the broadcast (utils/net.py:185-208)
+    S = synth.head_params(np.random.default_rng(10 + rank))
+    T = synth.head_params(np.random.default_rng(5))
+    rng = np.random.default_rng(1234 + rank)               # rank-local images
+    f = [torch.from_numpy(a).to(dev) for a in synth.fpn_features(rng, N, shapes)]
+    labs = [synth.distill_inputs(rng, N, 9, 80, h, w)[2] for h, w in shapes]
+    tg = [synth.bbox_targets(rng, l) for l in labs]
+    fg = torch.tensor([float(max(1, sum(t[0].shape[0] for t in tg)))], device=dev)
+    labs_d = [torch.from_numpy(a).to(dev) for a in labs]
+    tg_d = [(torch.from_numpy(y).to(dev), torch.from_numpy(l).to(dev)) for y, l in tg]
+
+    # (1) rank-local gradients: the same iteration with the exchange switched off
+    local = DistillHeads(cfg, N=N, shapes=shapes, device=dev, student_init=S, teacher_init=T)
+    dist.broadcast(local.params.flat, src=0)
+    local.step(f, f, labs_d, update=False, bbox_targets=tg_d, fg_num=fg)
+    local_g = local.grads.flat.clone()
+
+    # (2) the data-parallel iteration
+    heads = DistillHeads(cfg, N=N, shapes=shapes, device=dev, student_init=S, teacher_init=T,
+                         process_group=dist.group.WORLD, world_size=world, lr=0.01)
+    heads.broadcast_params()
+    p0 = heads.params.flat.clone()
+    heads.step(f, f, labs_d, update=False, bbox_targets=tg_d, fg_num=fg)
+    reduced = heads.grads.flat.clone()
+    heads.sgd_step()
+    torch.cuda.synchronize()
+
+    # every rank gathers everyone's tensors and compares on the device
+    def gather(t):
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return out
+    all_local, all_red = gather(local_g), gather(reduced)
+    all_p0, all_p1 = gather(p0), gather(heads.params.flat)
+    res = {
+        "params_broadcast_equal": all(torch.equal(all_p0[0], t) for t in all_p0),
+        "reduced_equal": all(torch.equal(all_red[0], t) for t in all_red),
+        "params_after_equal": all(torch.equal(all_p1[0], t) for t in all_p1),
+        "params_changed": not torch.equal(all_p0[0], all_p1[0]),
+        "local_differs": world == 1 or not torch.equal(all_local[0], all_local[1]),
+    }
+    want = torch.stack([t.double() for t in all_local]).sum(0)
+    err = (reduced.double() - want).abs().max().item()
+    res["sum_err"] = err
+    res["sum_scale"] = want.abs().max().item()
+    # two fp32 addends (or one): the sum is order independent, so it must match bit for bit
+    res["sum_exact"] = (world > 2) or torch.equal(reduced, sum(all_local[1:], all_local[0]))
+    res["finite"] = bool(torch.isfinite(heads.params.flat).all())
+    if rank == 0:
+        np.savez(os.path.join(outdir, "res.npz"), **{k: np.asarray(v) for k, v in res.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_rccl_allreduce_buckets_and_update(world):
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs, node has %d" % (world, torch.cuda.device_count()))
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        r = dict(np.load(os.path.join(d, "res.npz")))
+    assert bool(r["params_broadcast_equal"]) and bool(r["reduced_equal"])
+    assert bool(r["params_after_equal"]) and bool(r["params_changed"]) and bool(r["finite"])
+    assert bool(r["local_differs"]) and bool(r["sum_exact"])
+    assert float(r["sum_err"]) <= 1e-6 * float(r["sum_scale"])
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` starts N ranks itself; with fewer than N GPUs it must exit
+    non-zero instead of quietly benchmarking fewer."""
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1",
+                        "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "refusing" in p.stderr and '"metric"' not in p.stdout
+    # a launcher-provided world that disagrees with --gpus is refused as well
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1",
+                        "--warmup", "0"], env=env2, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and '"metric"' not in p.stdout
