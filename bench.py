@@ -49,10 +49,12 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=16)
     ap.add_argument("--workload", default=os.environ.get("SSAD_BENCH_WORKLOAD", "full"),
                     choices=["heads", "full"])
-    # BASELINE config 3 by default; config 5's networks and image size (in fp32 -- the fp16
-    # storage path is not built): --student r101 --teacher x101-64x4d --px 500
+    # BASELINE config 3 by default; config 5: --student r101 --teacher x101-64x4d --px 500
+    # --precision f16
     ap.add_argument("--student", default="r50", choices=["r50", "r101"])
-    ap.add_argument("--teacher", default="r101", choices=["r50", "r101", "x101-64x4d"])
+    # --teacher none: plain RetinaNet training of the student (BASELINE config 2: with
+    # --student r50 --batch-per-gpu 2), no teacher network, no distillation loss
+    ap.add_argument("--teacher", default="r101", choices=["none", "r50", "r101", "x101-64x4d"])
     ap.add_argument("--px", type=int, default=600, choices=[600, 500])
     # subnet precision: f32 (the metric's precision, default) or fp16 storage / fp32 accumulation
     # (config 5; backbones stay fp32).  An f16 line is NOT the headline number.
@@ -62,74 +64,59 @@ def parse():
     return ap.parse_args()
 
 
-class KernelTimer(object):
-    """HIP events around every launch of one kernel family inside the timed
-    region, on the stream the kernels are launched on (torch's current
-    stream is the launch stream of kernels.py)."""
+def kernel_report(classes, steps):
+    """Per kernel family (timing class of the native program, program.KLASS): launches per
+    step, average launch duration (HIP events on the launch stream, taken by
+    ssad_program_run inside the timed region), achieved rate and fraction of the bound's peak.
+    MFMA-bound families report EXECUTED flops (the Winograd engine runs 1/2.25 of the
+    direct-form flops of SURVEY.md 8d) against the dense fp32 MFMA peak; the direct-form
+    equivalent is given beside it."""
+    from ssad_amd import program as PR
+    out = []
+    for k in sorted(classes):
+        c, meta = classes[k], PR.KLASS.get(k, dict(name="class %d" % k, bound=None))
+        if c["launches"] == 0 or c["ms"] <= 0:
+            continue
+        row = {"class": k, "kernel": meta["name"], "bound": meta["bound"],
+               "launches_per_step": round(c["launches"] / float(steps), 2),
+               "avg_launch_ms": round(c["ms"] / c["launches"], 4),
+               "ms_per_step": round(c["ms"] / steps, 4)}
+        rate = c["work"] / (c["ms"] * 1e-3)
+        if meta["bound"] in ("mfma", "mfma16"):
+            executed = rate / 2.25 if meta.get("wino") else rate
+            row.update(unit="TFLOP/s", achieved=round(executed / 1e12, 2),
+                       direct_equiv_tflops=round(rate / 1e12, 2), peak=PR.PEAK[meta["bound"]] / 1e12,
+                       frac=round(executed / PR.PEAK[meta["bound"]], 4),
+                       flops_per_launch=c["work"] / c["launches"])
+        elif meta["bound"] == "hbm":
+            row.update(unit="GB/s", achieved=round(rate / 1e9, 1), peak=PR.PEAK["hbm"] / 1e9,
+                       frac=round(rate / PR.PEAK["hbm"], 4), bytes_per_launch=c["work"] / c["launches"])
+        out.append(row)
+    return out
 
-    def __init__(self):
-        self.records = []      # (start_event, end_event, flops)
-        self.enabled = False
 
-    def wrap(self, K):
-        timer = self
-
-        def timed_call(orig, flops, args, kw):
-            if not timer.enabled or flops is None:
-                return orig(*args, **kw)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig(*args, **kw)
-            e1.record()
-            timer.records.append((e0, e1, flops, bool(kw.get("wino"))))
-            return out
-
-        def px(xs):
-            return sum(x.shape[0] * x.shape[2] * x.shape[3] for x in xs)
-
-        o1, o2 = K.conv3x3_forward, K.conv3x3_forward_multi
-
-        def fwd(xs, packed, bias, Cout, **kw):
-            fl = 2.0 * 9 * Cout * xs[0].shape[1] * px(xs) if Cout > 64 else None
-            return timed_call(o1, fl, (xs, packed, bias, Cout), kw)
-
-        def multi(problems, Cout, **kw):
-            fl = (sum(2.0 * 9 * Cout * p["xs"][0].shape[1] * px(p["xs"]) for p in problems)
-                  if Cout > 64 else None)
-            return timed_call(o2, fl, (problems, Cout), kw)
-        K.conv3x3_forward, K.conv3x3_forward_multi = fwd, multi
-        o3 = K.conv3x3_forward_f16
-
-        def fwd16(xb, packed, bias, Cin, Cout, **kw):
-            fl = 2.0 * 9 * Cout * Cin * xb.shape[0] * xb.shape[2] * xb.shape[3] if min(Cin, Cout) > 64 else None
-            return timed_call(o3, fl, (xb, packed, bias, Cin, Cout), kw)
-        K.conv3x3_forward_f16 = fwd16
-        o4 = K.conv3x3_forward_f16_levels
-
-        def lev16(xbs, packed, bias, Cin, Cout, outs, **kw):
-            fl = (2.0 * 9 * Cout * Cin * sum(x.shape[0] * x.shape[2] * x.shape[3] for x in xbs)
-                  if min(Cin, Cout) > 64 else None)
-            return timed_call(o4, fl, (xbs, packed, bias, Cin, Cout, outs), kw)
-        K.conv3x3_forward_f16_levels = lev16
-        o5 = K.conv3x3_forward_f16_multi
-
-        def multi16(problems, Cin, Cout, **kw):
-            px16 = sum(x.shape[0] * x.shape[2] * x.shape[3] for p in problems for x in p["xs"])
-            fl = 2.0 * 9 * Cout * Cin * px16 if min(Cin, Cout) > 64 else None
-            return timed_call(o5, fl, (problems, Cin, Cout), kw)
-        K.conv3x3_forward_f16_multi = multi16
-
-    def summary(self):
-        if not self.records:
-            return None
-        ms = [a.elapsed_time(b) for a, b, _, _ in self.records]
-        fl = [f for _, _, f, _ in self.records]
-        wino = [w for _, _, _, w in self.records]
-        tf = sum(fl) / (sum(ms) * 1e-3) / 1e12
-        executed = sum(f / 2.25 if w else f for f, w in zip(fl, wino)) / (sum(ms) * 1e-3) / 1e12
-        return dict(launches=len(ms), avg_ms=sum(ms) / len(ms), tflops=tf, executed_tflops=executed,
-                    flops_per_launch=sum(fl) / len(fl), wino=all(wino))
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of one kernel from the committed PMC passes (profiles/README.md:
+    FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc runs; FETCH x2 where the
+    calibration pass says so)."""
+    try:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+        pm = json.load(open(files[-1]))
+        ks = [v for k, v in pm["kernels"].items() if k.startswith(kernel_prefix)]
+        if not ks:
+            return None, None
+        f = pm.get("fetch_calibration", {}).get(kernel_prefix)
+        fetch = [v.get("FETCH_SIZE_KB_raw", 0) * 1024 * (f if f else 1.0) for v in ks]
+        write = [v.get("WRITE_SIZE_KB", 0) * 1024 for v in ks]
+        note = ("FETCH_SIZE (x%.2f: calibrated on a known byte count in this kernel's access pattern, "
+                "profiles/README.md) + WRITE_SIZE per dispatch, separate rocprofv3 --pmc passes, file %s"
+                % (f, os.path.basename(files[-1]))) if f else (
+                "FETCH_SIZE + WRITE_SIZE per dispatch from separate rocprofv3 --pmc passes (%s); FETCH "
+                "uncalibrated for this kernel (true read side between 1x and 2x)" % os.path.basename(files[-1]))
+        return int(sum(fetch) / len(fetch) + sum(write) / len(write)), note
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(args, cfg):
@@ -206,7 +193,7 @@ def main():
         pg = dist.group.WORLD
 
     import ssad_amd  # noqa: F401
-    from ssad_amd import kernels as K, synth
+    from ssad_amd import kernels as K, synth, program as PR
     from ssad_amd.head_pipeline import DistillHeads, DistillHeadsF16
     from ssad_amd.modeling.retinanet_heads import HeadConfig
     K.lib()   # fail loudly if the HIP extension is missing
@@ -217,10 +204,11 @@ def main():
     cfg = HeadConfig(num_gpus=world)
     rng = np.random.default_rng(1234 + rank)
     f16 = args.precision == "f16"
+    distill = args.teacher != "none"
     heads = (DistillHeadsF16 if f16 else DistillHeads)(cfg, N=N, shapes=shapes, device=dev,
                          student_init=synth.head_params(np.random.default_rng(1)),
-                         teacher_init=synth.head_params(np.random.default_rng(2)),
-                         process_group=pg, world_size=world, lr=1e-4)
+                         teacher_init=synth.head_params(np.random.default_rng(2)) if distill else None,
+                         process_group=pg, world_size=world, lr=1e-4, distill=distill)
     heads.broadcast_params()
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     labels = [torch.from_numpy(synth.distill_inputs(rng, N, 9, 80, h, w)[2]).to(dev)
@@ -245,35 +233,34 @@ def main():
         n_fg += Lc.shape[0]
     fg_num = torch.tensor([float(max(n_fg, 1))], device=dev)
 
-    timer = KernelTimer()
-    timer.wrap(K)
-
+    losses_txt = ("PowSum + SigmoidAdaptiveDistillLoss + SigmoidFocalLoss + SelectSmoothL1Loss"
+                  if distill else "SigmoidFocalLoss + SelectSmoothL1Loss")
     if args.workload == "heads":
         s_fpn = [torch.randn((N, 256, h, w), device=dev, generator=gen) for h, w in shapes]
-        t_fpn = [torch.randn((N, 256, h, w), device=dev, generator=gen) for h, w in shapes]
+        t_fpn = [torch.randn((N, 256, h, w), device=dev, generator=gen) for h, w in shapes] if distill else s_fpn
 
         def step():
             heads.step(s_fpn, t_fpn, labels, bbox_targets=bbox_targets, fg_num=fg_num)
-        wl = ("heads-only: RetinaNet cls+bbox subnets (teacher fwd, student fwd+bwd) + PowSum + "
-              "SigmoidAdaptiveDistillLoss + SigmoidFocalLoss + SelectSmoothL1Loss fwd/bwd + SGD "
-              "on synthetic FPN features")
+        wl = ("heads-only: RetinaNet cls+bbox subnets (%sstudent fwd+bwd) + %s fwd/bwd + SGD on synthetic "
+              "FPN features; the whole step is one native program of this repo's HIP kernels" % (
+                  "teacher fwd, " if distill else "", losses_txt))
     else:
         from ssad_amd.harness.full_model import FullDistillModel
-        model = FullDistillModel(heads, student_depth=args.student, teacher_depth=args.teacher, device=dev,
-                                 backbone_f16=f16,
-                                 process_group=pg, world_size=world)
+        model = FullDistillModel(heads, student_depth=args.student,
+                                 teacher_depth=args.teacher if distill else None, device=dev,
+                                 backbone_f16=f16, process_group=pg, world_size=world)
         images = torch.randn((N, 3) + image_hw, device=dev, generator=gen)
 
         def step():
             model.step(images, labels, bbox_targets, fg_num)
-        wl = ("%s-FPN student + %s-FPN teacher adaptive distillation, %d px (3x%dx%d): " % (
-              args.student.upper().replace("R", "R-", 1), args.teacher.upper().replace("R", "R-", 1)
-              if args.teacher[0] == "r" else args.teacher.upper().replace("X", "X-", 1),
-              args.px, image_hw[0], image_hw[1]) +
-              "backbones = PyTorch harness (1x1 convs as rocBLAS / hipBLASLt GEMMs, MIOpen 7x7 stem, "
-              "P7 and grouped convs; its stride-1 3x3 convs, bias/residual/ReLU tails and stem pool "
-              "on this repo's kernels); subnets, distillation + "
-              "focal + smooth-L1 losses and subnet SGD = this repo's HIP kernels")
+
+        def pretty(a):
+            return a.upper().replace("R", "R-", 1) if a[0] == "r" else a.upper().replace("X", "X-", 1)
+        wl = ("%s-FPN student%s, %d px (3x%dx%d): " % (
+              pretty(args.student), (" + %s-FPN teacher adaptive distillation" % pretty(args.teacher))
+              if distill else " only (plain RetinaNet training, BASELINE config 2)",
+              args.px, image_hw[0], image_hw[1]) + model.describe() +
+              "; subnets, %s and subnet SGD = one native program of this repo's HIP kernels" % losses_txt)
 
     for _ in range(args.warmup):
         step()
@@ -281,7 +268,10 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    timing = PR.Timing()
+    heads.timing = timing
+    if args.workload == "full":
+        model.timing = timing
     t0 = time.perf_counter()
     host = 0.0                      # time the launching thread spends inside step()
     for _ in range(args.steps):
@@ -293,30 +283,24 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    timer.enabled = False
+    heads.timing = None
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax[0])
     loss_val = [float(v) for v in heads.losses.cpu()]
     assert all(np.isfinite(loss_val)), "non-finite distillation loss: %r" % (loss_val,)
+    assert bool(torch.isfinite(heads.params.flat).all()), "non-finite subnet parameters after the run"
 
     if rank == 0:
-        ks = timer.summary()
-        traffic, traffic_note = None, None
-        try:   # HBM bytes per launch from the committed PMC passes (profiles/README.md)
-            import glob
-            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]))
-            want = "wino_conv_z_kernel" if ks and ks["wino"] else "conv3x3_kernel<8, 1"
-            ks_ = [v for k, v in pm["kernels"].items() if k.startswith(want)]
-            if ks_:
-                traffic = int(sum((v.get("FETCH_SIZE_KB_raw", 0) + v.get("WRITE_SIZE_KB", 0)) * 1024
-                                  for v in ks_) / len(ks_))
-                traffic_note = ("FETCH_SIZE+WRITE_SIZE per dispatch from separate rocprofv3 --pmc "
-                                "passes (profiles/); FETCH uncalibrated for this kernel's mixed "
-                                "4-B/16-B loads (true value between 1x and 2x)")
-        except Exception:
-            pass
+        classes = timing.collect()
+        rows = kernel_report(classes, args.steps)
+        by = {r["class"]: r for r in rows}
+        dom_k = 34 if f16 else (2 if 2 in by else 18)
+        dom = by.get(dom_k)
+        prefix = "conv3x3_f16_kernel" if f16 else ("wino_conv_z_kernel" if dom_k == 2 else "conv3x3_kernel<8, 1")
+        traffic, traffic_note = pmc_traffic(prefix)
+        heads_ms = sum(r["ms_per_step"] for r in rows if r["class"] < 48)
         out = {
             "metric": METRIC, "value": round(world * N * args.steps / dt, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -332,31 +316,33 @@ def main():
                        "distill_loss": loss_val,
                        "focal_loss": [float(v) for v in heads.focal_losses.cpu()],
                        "bbox_loss": [float(v) for v in heads.bbox_losses.cpu()]},
-            "roofline": {
-                "kernel": ("wino_conv_z_kernel (subnet conv3x3 fwd / data-grad, Winograd F(2x2,3x3) on "
-                           "fp32 MFMA)" if ks and ks["wino"] else
-                           "conv3x3_kernel<8,1,*> (subnet conv3x3 fwd / data-grad, fp32 MFMA)"),
-                "bound": "mfma", "achieved": round(ks["tflops"], 2) if ks else None,
-                "achieved_note": ("algorithmic direct-form FLOP/s (2*9*Cout*Cin per output pixel, "
-                                  "SURVEY 8d); the Winograd engine executes 1/2.25 of them, so frac is "
-                                  "measured against the direct-form MFMA ceiling and can exceed it"),
-                "mfma_tflops_executed": round(ks["executed_tflops"], 2) if ks else None,
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ks["tflops"] / PEAK_F32_MFMA_TFLOPS, 4) if ks else None,
-                "traffic": traffic, "traffic_note": traffic_note,
-                "launches_timed": ks["launches"] if ks else 0,
-                "avg_launch_ms": round(ks["avg_ms"], 4) if ks else None,
-                "flops_per_launch": ks["flops_per_launch"] if ks else None},
+            # the dominant kernel: frac = EXECUTED MFMA flops / dense peak (a hardware fraction)
+            "roofline": dict(kernel=dom["kernel"], bound="mfma", achieved=dom["achieved"], peak=dom["peak"],
+                             unit="TFLOP/s", frac=dom["frac"], traffic=traffic, traffic_note=traffic_note,
+                             direct_equiv_tflops=dom["direct_equiv_tflops"],
+                             achieved_note=("executed MFMA FLOP/s: algorithmic direct-form flops (2*9*Cout*Cin "
+                                            "per output pixel, SURVEY 8d) / 2.25 for the Winograd F(2x2,3x3) "
+                                            "engine; direct_equiv_tflops is the direct-form rate" if not f16
+                                            else "algorithmic direct-form FLOP/s; the kernel executes exactly these"),
+                             launches_per_step=dom["launches_per_step"], avg_launch_ms=dom["avg_launch_ms"],
+                             flops_per_launch=dom["flops_per_launch"]) if dom else None,
+            "kernels": rows,
+            "subnets_ms_per_step": round(heads_ms, 3),
         }
-        if f16:
-            out["roofline"].update({
-                "kernel": "conv3x3_f16_kernel (subnet conv3x3 fwd / data-grad, v_mfma_f32_32x32x16_f16)",
-                "achieved_note": "algorithmic direct-form FLOP/s; the kernel executes exactly these",
-                "mfma_tflops_executed": round(ks["tflops"], 2) if ks else None,
-                "peak": 2500.0, "frac": round(ks["tflops"] / 2500.0, 4) if ks else None,
-                "traffic": None, "traffic_note": None})
-        if not args.no_cpu_baseline and world == 1:     # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, cfg)
+        for key, k in (("roofline_loss", 9 if distill else 15), ("roofline_pow_sum", 8)):
+            r = by.get(k)
+            if r:
+                out[key] = dict(kernel=r["kernel"], bound="hbm", achieved=r["achieved"], peak=r["peak"],
+                                unit="GB/s", frac=r["frac"], launches_per_step=r["launches_per_step"],
+                                avg_launch_ms=r["avg_launch_ms"], bytes_per_launch=r["bytes_per_launch"],
+                                traffic=None)
+        if not args.no_cpu_baseline and world == 1 and distill:     # rank 0 at N=1 only
+            cb = cpu_baseline(args, cfg)
+            # the same scope on the GPU: subnets + losses + SGD of this run (kernel time per step)
+            cb["gpu_same_scope_images_per_s"] = round(N / (heads_ms * 1e-3), 2) if heads_ms > 0 else None
+            cb["scope_note"] = ("value and gpu_same_scope_images_per_s both cover subnets + losses (no backbone); "
+                                "the headline `value` covers the whole step")
+            out["cpu_baseline"] = cb
         # the ONE result line, last on rank 0's stdout (with NCCL_DEBUG=VERSION in the environment
         # RCCL prints its version banner to stdout when the communicator is created, i.e. earlier)
         sys.stdout.flush()

@@ -122,15 +122,37 @@ SSAD_API int ssad_cls_losses_fused(
     void* workspace, size_t workspace_bytes, ssad_stream_t stream);
 
 /* Y_hat N x D x H x W box predictions; Y M x 4 targets; L M x 4 float rows
- * (n, c, y, x) locating each foreground box; S device scalar (#fg). */
+ * (n, c, y, x) locating each foreground box; S device scalar (#fg).  List entries that fall
+ * outside the prediction map contribute nothing (the reference reads out of bounds there).
+ * workspace: ssad_select_smooth_l1_workspace_bytes(1) bytes, caller provided -- the launchers
+ * allocate nothing, so a step built from them can be captured in a HIP graph. */
+SSAD_API size_t ssad_select_smooth_l1_workspace_bytes(int n_levels);
 SSAD_API int ssad_select_smooth_l1_forward(
     const float* Y_hat, const float* Y, const float* L, const float* S, int N, int D, int H,
-    int W, int M, float beta, float scale, float* loss, ssad_stream_t stream);
+    int W, int M, float beta, float scale, float* loss, void* workspace, size_t workspace_bytes,
+    ssad_stream_t stream);
 /* dY_hat must be zero-filled by the caller (the operator does it, as the
  * reference's math::Set); writes the M*4 non-zero entries. */
 SSAD_API int ssad_select_smooth_l1_backward(
     const float* Y_hat, const float* Y, const float* L, const float* S, const float* dloss,
     int N, int D, int H, int W, int M, float beta, float scale, float* dY_hat,
+    ssad_stream_t stream);
+/* The training step's form: every FPN level in one launch each for the forward, its
+ * fixed-order finalize, the zero fill of dY_hat and the gradient scatter (4 launches
+ * instead of the reference's 5 x {kernel, Sum, Scale, Set, kernel, Scale}).
+ * want_forward != 0: loss[l] written; dloss != NULL: dY_hat[l] = full gradient (zero filled
+ * here).  M may be 0 for a level. */
+typedef struct ssad_smooth_l1_level {
+  const float* Y_hat;   /* N x D x H x W */
+  const float* Y;       /* M x 4 */
+  const float* L;       /* M x 4 */
+  float* loss;          /* device scalar (forward) */
+  float* dY_hat;        /* N x D x H x W (gradient), or NULL */
+  int N, D, H, W, M;
+} ssad_smooth_l1_level;
+SSAD_API int ssad_select_smooth_l1_levels(
+    const ssad_smooth_l1_level* levels_host, int n_levels, const float* S, const float* dloss,
+    float beta, float scale, int want_forward, void* workspace, size_t workspace_bytes,
     ssad_stream_t stream);
 
 /* ---------------------------------------------------------------------- */
@@ -191,6 +213,28 @@ SSAD_API int ssad_fill(float* y, float value, int64_t n, ssad_stream_t stream);
 SSAD_API int ssad_momentum_sgd_update(
     float* w, float* g, float* m, const float* lr, float momentum,
     float weight_decay, int is_bias, int64_t n, ssad_stream_t stream);
+/* The same update for a whole model in ONE launch: w, g, m are flat buffers holding every
+ * parameter, `segments_host` lists the parameters (element offset, length, bias or weight).
+ * skip_flag (device int, may be NULL): when non-zero at execution time nothing is updated
+ * (the step is dropped: a mixed-precision gradient overflowed, see ssad_check_finite). */
+#define SSAD_MAX_SGD_SEGMENTS 64
+typedef struct ssad_sgd_segment {
+  int64_t offset, n;
+  int is_bias;
+} ssad_sgd_segment;
+SSAD_API int ssad_momentum_sgd_flat(
+    float* w, float* g, float* m, const float* lr, float momentum, float weight_decay,
+    const ssad_sgd_segment* segments_host, int n_segments, const int* skip_flag,
+    ssad_stream_t stream);
+/* flag[0] |= 1 when any of x[0..n) is Inf or NaN (flag is NOT cleared here) */
+SSAD_API int ssad_check_finite(const float* x, int64_t n, int* flag, ssad_stream_t stream);
+/* Dynamic loss scaling, entirely on the device (no host round trip in the step):
+ * state = {scale, 1/scale} floats; counters = {overflow flag, good steps} ints.
+ * overflow: scale *= backoff, good = 0; else ++good and, at `growth_interval`, scale *= growth.
+ * scale stays within [min_scale, max_scale]; the flag is cleared for the next step. */
+SSAD_API int ssad_loss_scale_update(float* state, int* counters, float growth, float backoff,
+                                    int growth_interval, float min_scale, float max_scale,
+                                    ssad_stream_t stream);
 
 /* ---------------------------------------------------------------------- */
 /* Conv 3x3 / stride 1 / pad 1, NCHW fp32, exact-fp32 MFMA                 */
@@ -248,6 +292,17 @@ SSAD_API int ssad_conv_wino_pack_filter(
 SSAD_API int ssad_conv3x3_forward_wino(
     const ssad_conv_level* levels_host, int n_levels, const float* packed,
     const float* bias, int Cout, int Cin, int flags, ssad_stream_t stream);
+/* ssad_conv_wino_pack_filter for a whole table of filters in one launch (the training step
+ * repacks every filter after each update: 20 student filters x {forward, data gradient}). */
+#define SSAD_MAX_PACK_ENTRIES 32   /* per launch; longer tables are chunked */
+typedef struct ssad_pack_entry {
+  const float* w;          /* [Cout][Cin][3][3] */
+  int Cout, Cin;
+  float* packed_fwd;       /* or NULL */
+  float* packed_dgrad;     /* or NULL */
+} ssad_pack_entry;
+SSAD_API int ssad_conv_wino_pack_filters(const ssad_pack_entry* entries_host, int n_entries,
+                                         ssad_stream_t stream);
 
 SSAD_API size_t ssad_conv3x3_wgrad_workspace_bytes(
     const ssad_conv_level* levels_host, int n_levels, int Cout, int Cin);
@@ -380,6 +435,12 @@ SSAD_API int ssad_f16_pack_activations(const float* x_nchw, int N, int C, int H,
                                        void* x_blocked, ssad_stream_t stream);
 SSAD_API int ssad_f16_unpack_activations(const void* x_blocked, int N, int C, int H, int W, float scale,
                                          float* x_nchw, ssad_stream_t stream);
+/* The same with a further factor read from device memory at execution time (scale_dev[0], or
+ * NULL): the DYNAMIC loss scale of ssad_loss_scale_update and its reciprocal never visit the host */
+SSAD_API int ssad_f16_pack_activations_dyn(const float* x_nchw, int N, int C, int H, int W, float scale,
+                                           const float* scale_dev, void* x_blocked, ssad_stream_t stream);
+SSAD_API int ssad_f16_unpack_activations_dyn(const void* x_blocked, int N, int C, int H, int W, float scale,
+                                             const float* scale_dev, float* x_nchw, ssad_stream_t stream);
 /* The same layout change for float16 NCHW blobs (the operator surface's Conv on
  * TensorProto::FLOAT16 tensors), and plain element casts (round to nearest even) */
 SSAD_API int ssad_f16_block_activations(const void* x_nchw_f16, int N, int C, int H, int W,
@@ -442,6 +503,12 @@ SSAD_API int ssad_conv3x3_wgrad_f16_levels(const ssad_f16_wgrad_level* levels_ho
                                            int M, int accumulate, float scale, float* dw, float* db,
                                            void* workspace, size_t workspace_bytes,
                                            ssad_stream_t stream);
+/* ... times scale_dev[0] read on the device (the reciprocal of the dynamic loss scale), or NULL */
+SSAD_API int ssad_conv3x3_wgrad_f16_levels_dyn(const ssad_f16_wgrad_level* levels_host, int n_levels,
+                                               int C, int M, int accumulate, float scale,
+                                               const float* scale_dev, float* dw, float* db,
+                                               void* workspace, size_t workspace_bytes,
+                                               ssad_stream_t stream);
 
 /* ---------------------------------------------------------------------- */
 /* Introspection                                                           */

@@ -1,0 +1,157 @@
+/*
+ * ssad_program.h -- the native step driver: a training iteration as a flat PROGRAM of kernel
+ * launches that ONE C-ABI call enqueues on a HIP stream.
+ *
+ * The reference's analogue is Caffe2's C++ net executor (caffe2/caffe2/core/net_simple.cc: a
+ * vector of operators run in order on the net's stream; net_dag.cc:181-270 for the DAG
+ * form): Python builds the net once, C++ runs it every iteration.  Here the host (Python,
+ * as in the reference) builds an array of `ssad_op` records once -- every pointer, shape
+ * and scalar of every launch of the iteration, over buffers allocated once -- and each
+ * iteration is `ssad_program_run(ops, n, stream, timing)`: no interpreter, no allocation,
+ * no per-launch FFI crossing between the kernels, so the launching thread stays far ahead
+ * of the GPU.  A data-parallel step is a few program SEGMENTS with the RCCL all-reduce of a
+ * gradient bucket issued between them.  Because a segment only enqueues launches on
+ * `stream`, it can also be captured into a hipGraph by the caller.
+ *
+ * An op record maps 1:1 onto a raw launcher of ssad_kernels.h (same arguments, same error
+ * codes); the executor adds nothing to the arithmetic.
+ *
+ * Timing: with a `ssad_timing` the executor brackets every op with HIP events ON THE LAUNCH
+ * STREAM and, after the caller has synchronised, reports per timing class (`klass`, chosen
+ * by the program builder: one class per kernel family) the number of launches, their
+ * summed duration and their summed algorithmic work -- bench.py's rooflines come from here.
+ */
+#ifndef SSAD_PROGRAM_H_
+#define SSAD_PROGRAM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ssad_kernels.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Argument slots per op code: i[] ints, f[] floats, l[] 64-bit ints (sizes), p[] pointers
+ * (device pointers, or pointers to HOST descriptor arrays that must outlive the program:
+ * names ending in _host). */
+enum ssad_opcode {
+  /* ssad_conv_wino_pack_filters(p0 = entries_host, i0 = n) */
+  SSAD_OP_WINO_PACK_FILTERS = 1,
+  /* ssad_conv_pack_filter(p0 = w, i0 = Cout, i1 = Cin, p1 = packed_fwd, p2 = packed_dgrad) */
+  SSAD_OP_PACK_FILTER = 2,
+  /* ssad_conv3x3_forward[_wino](p0 = levels_host, i0 = n, p1 = packed, p2 = bias, i1 = Cout,
+   * i2 = Cin, i3 = flags); i4 != 0 selects the Winograd engine */
+  SSAD_OP_CONV3X3 = 3,
+  /* ssad_conv3x3_wgrad(p0 = levels_host, i0 = n, p1 = dW, p2 = db, i1 = Cout, i2 = Cin,
+   * i3 = accumulate, p3 = workspace, l0 = workspace_bytes) */
+  SSAD_OP_CONV3X3_WGRAD = 4,
+  /* ssad_pow_sum(p0 = inputs_host, p1 = sizes_host, i0 = n, f0 = power, p2 = out,
+   * p3 = workspace, l0 = workspace_bytes) */
+  SSAD_OP_POW_SUM = 5,
+  /* ssad_cls_losses_fused(p0 = levels_host, i0 = n, p1 = normalizer, p2 = fg_num,
+   * p3 = distill_params_host, p4 = focal_params_host, p5 = distill_losses, p6 = focal_losses,
+   * p7 = workspace, l0 = workspace_bytes) */
+  SSAD_OP_CLS_LOSSES_FUSED = 6,
+  /* ssad_distill_loss_forward(p0 = levels_host, i0 = n, p1 = normalizer, p2 = params_host,
+   * p3 = workspace, l0 = workspace_bytes) */
+  SSAD_OP_DISTILL_FWD = 7,
+  /* ssad_distill_loss_backward(p0 = levels_host, i0 = n, p1 = normalizer, p2 = dloss,
+   * i1 = dloss_stride, p3 = params_host) */
+  SSAD_OP_DISTILL_BWD = 8,
+  /* ssad_focal_loss_forward(p0 = levels_host, i0 = n, p1 = fg_num, p2 = params_host,
+   * p3 = workspace, l0 = workspace_bytes) */
+  SSAD_OP_FOCAL_FWD = 9,
+  /* ssad_focal_loss_backward(p0 = levels_host, i0 = n, p1 = fg_num, p2 = dloss,
+   * i1 = dloss_stride, p3 = params_host) */
+  SSAD_OP_FOCAL_BWD = 10,
+  /* ssad_select_smooth_l1_levels(p0 = levels_host, i0 = n, p1 = S, p2 = dloss, f0 = beta,
+   * f1 = scale, i1 = want_forward, p3 = workspace, l0 = workspace_bytes) */
+  SSAD_OP_SMOOTH_L1 = 11,
+  /* ssad_momentum_sgd_flat(p0 = w, p1 = g, p2 = m, p3 = lr, f0 = momentum, f1 = weight_decay,
+   * p4 = segments_host, i0 = n_segments, p5 = skip_flag) */
+  SSAD_OP_SGD_FLAT = 12,
+  /* ssad_fill(p0 = y, f0 = value, l0 = n) */
+  SSAD_OP_FILL = 13,
+  /* ssad_scale(p0 = x, p1 = y, f0 = alpha, l0 = n) */
+  SSAD_OP_SCALE = 14,
+  /* ssad_sum_n(p0 = inputs_host, i0 = n_inputs, p1 = out, l0 = n) */
+  SSAD_OP_SUM_N = 15,
+  /* ssad_check_finite(p0 = x, l0 = n, p1 = flag) */
+  SSAD_OP_CHECK_FINITE = 16,
+  /* ssad_loss_scale_update(p0 = state, p1 = counters, f0 = growth, f1 = backoff,
+   * i0 = growth_interval, f2 = min_scale, f3 = max_scale) */
+  SSAD_OP_LOSS_SCALE_UPDATE = 17,
+
+  /* fp16 storage path */
+  /* ssad_f16_pack_activations_dyn(p0 = x, i0..i3 = N, C, H, W, f0 = scale, p1 = scale_dev,
+   * p2 = x_blocked) */
+  SSAD_OP_F16_PACK_ACT = 32,
+  /* ssad_f16_unpack_activations_dyn(p0 = x_blocked, i0..i3 = N, C, H, W, f0 = scale,
+   * p1 = scale_dev, p2 = x) */
+  SSAD_OP_F16_UNPACK_ACT = 33,
+  /* ssad_f16_pack_filter(p0 = w, i0 = M, i1 = C, p1 = packed_fwd, p2 = packed_dgrad) */
+  SSAD_OP_F16_PACK_FILTER = 34,
+  /* ssad_conv3x3_forward_f16_levels(p0 = levels_host, i0 = n, p1 = packed, p2 = bias, i1 = C,
+   * i2 = M, i3 = flags) */
+  SSAD_OP_F16_CONV3X3 = 35,
+  /* ssad_conv3x3_wgrad_f16_levels_dyn(p0 = levels_host, i0 = n, i1 = C, i2 = M, i3 = accumulate,
+   * f0 = scale, p1 = scale_dev, p2 = dw, p3 = db, p4 = workspace, l0 = workspace_bytes) */
+  SSAD_OP_F16_WGRAD = 36,
+
+  /* backbone (row f1) */
+  /* ssad_affine_channel(p0 = x, p1 = scale, p2 = bias, p3 = residual, p4 = y, i0 = N, i1 = C,
+   * i2 = HW, i3 = relu) */
+  SSAD_OP_AFFINE_CHANNEL = 48,
+  /* ssad_upsample_nearest(p0 = x, p1 = addend, p2 = y, i0..i3 = N, C, H, W, i4 = scale) */
+  SSAD_OP_UPSAMPLE = 49,
+  /* ssad_upsample_nearest_grad(p0 = dy, p1 = dx, i0..i3 = N, C, H, W, i4 = scale) */
+  SSAD_OP_UPSAMPLE_GRAD = 50,
+  /* ssad_max_pool3x3s2_bias_relu(p0 = x, p1 = bias, i0..i3 = N, C, H, W, i4 = relu, p2 = y) */
+  SSAD_OP_STEM_POOL = 51,
+  /* ssad_relu_grad_rowsum(p0 = y, p1 = dy, p2 = dx, p3 = rowsum, i0 = N, i1 = C, i2 = HW) */
+  SSAD_OP_RELU_GRAD_ROWSUM = 52,
+  /* ssad_relu_grad(p0 = y, p1 = dy, p2 = dx, l0 = n) */
+  SSAD_OP_RELU_GRAD = 53,
+  /* ssad_channel_sum(p0 = dy, i0 = N, i1 = C, i2 = HW, p1 = out, i3 = accumulate) */
+  SSAD_OP_CHANNEL_SUM = 55
+};
+
+typedef struct ssad_op {
+  int32_t code;        /* enum ssad_opcode */
+  int32_t klass;       /* timing class chosen by the builder (>= 0) */
+  int32_t i[8];
+  float f[4];
+  int64_t l[2];
+  const void* p[8];
+  double work;         /* algorithmic work of this launch: FLOPs for MFMA-bound classes, bytes
+                          for HBM-bound ones (SURVEY.md 8d per-unit figures x units) */
+} ssad_op;
+
+typedef struct ssad_timing ssad_timing;     /* opaque: event pool + records */
+
+typedef struct ssad_timing_class {
+  int32_t klass;
+  int32_t launches;
+  double ms;           /* summed duration of the class's ops (HIP events on the launch stream) */
+  double work;         /* summed ssad_op.work */
+} ssad_timing_class;
+
+SSAD_API ssad_timing* ssad_timing_create(void);
+SSAD_API void ssad_timing_destroy(ssad_timing* t);
+/* forget the records taken so far (events are kept for reuse) */
+SSAD_API void ssad_timing_reset(ssad_timing* t);
+/* The caller must have synchronised the stream(s).  Writes up to max_out classes (ascending
+ * klass) and returns how many there are, or a negative hipError_t. */
+SSAD_API int ssad_timing_collect(ssad_timing* t, ssad_timing_class* out, int max_out);
+
+/* Enqueue ops[0..n_ops) on `stream` in order.  Returns 0, or the first failing launcher's code
+ * with *failed_index (may be NULL) set to the op's index.  timing may be NULL. */
+SSAD_API int ssad_program_run(const ssad_op* ops, int n_ops, ssad_stream_t stream, ssad_timing* timing,
+                              int* failed_index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSAD_PROGRAM_H_ */

@@ -56,21 +56,30 @@ def head_step(student, teacher, fpn_student, fpn_teacher, labels, d_bbox_pred=No
     (SigmoidFocalLoss + SelectSmoothL1Loss, retinanet_heads.py:259-307) join
     the distillation loss, as in the reference graph."""
     loss_scale = scale if loss_scale is None else loss_scale
-    t_logits = tower_forward(teacher, "cls", fpn_teacher)
-    t_prob = [oracle.sigmoid(x) for x in t_logits]
-    if teacher_bbox_tower:
-        tower_forward(teacher, "bbox", fpn_teacher)
+    distill = teacher is not None
+    t_prob, norm64 = None, None
+    if distill:
+        t_logits = tower_forward(teacher, "cls", fpn_teacher)
+        t_prob = [oracle.sigmoid(x) for x in t_logits]
+        if teacher_bbox_tower:
+            tower_forward(teacher, "bbox", fpn_teacher)
     acts = {"cls": [], "bbox": []}
     cls_logits = tower_forward(student, "cls", fpn_student, acts["cls"])
     bbox_pred = tower_forward(student, "bbox", fpn_student, acts["bbox"])
-    norm32, norm64 = oracle.pow_sum(t_prob, power)
-    kw = dict(gamma=gamma, alpha=alpha, beta=beta, num_classes=num_classes,
-              ignored_label=ignored_label, scale=scale)
     losses, d_logits = [], []
-    for x, q, g in zip(cls_logits, t_prob, labels):
-        _, l64, _ = oracle.distill_loss_forward(x, q, g, norm32, **kw)
-        losses.append(l64)
-        d_logits.append(oracle.distill_loss_backward(x, q, g, norm32, 1.0, **kw))
+    if distill:
+        norm32, norm64 = oracle.pow_sum(t_prob, power)
+        kw = dict(gamma=gamma, alpha=alpha, beta=beta, num_classes=num_classes,
+                  ignored_label=ignored_label, scale=scale)
+        for x, q, g in zip(cls_logits, t_prob, labels):
+            _, l64, _ = oracle.distill_loss_forward(x, q, g, norm32, **kw)
+            losses.append(l64)
+            d_logits.append(oracle.distill_loss_backward(x, q, g, norm32, 1.0, **kw))
+    else:
+        # plain RetinaNet (model_builder.py:98-100,413: `retinanet` without the distillation
+        # wrapper; BASELINE config 2): only the supervised losses drive the subnets
+        assert bbox_targets is not None, "student-only training needs the supervised losses"
+        d_logits = [np.zeros_like(x) for x in cls_logits]
     focal_losses, bbox_losses = [], []
     if bbox_targets is not None:
         fkw = dict(gamma=focal_gamma, alpha=focal_alpha, num_classes=num_classes, scale=loss_scale)

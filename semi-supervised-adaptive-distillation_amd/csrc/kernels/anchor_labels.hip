@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kT) void al_iou_max_kernel(const ALArgs p) {
   const int t = blockIdx.x * kT + threadIdx.x;
   if (t >= p.T) return;
   const Anchor b = anchor_of(p, t);
-  const int G = p.gt_counts[n];
+  const int G = min(max(p.gt_counts[n], 0), p.Gmax);   // a count beyond the padded width would read past gt_boxes
   const float* gts = p.gt_boxes + (long long)n * p.Gmax * 4;
   float best = 0.0f;
   int arg = 0;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kT) void al_assign_kernel(const ALArgs p) {
   const int t = blockIdx.x * kT + threadIdx.x;
   if (t < p.T) {
     const Anchor b = anchor_of(p, t);
-    const int G = p.gt_counts[n];
+    const int G = min(max(p.gt_counts[n], 0), p.Gmax);
     const float* gts = p.gt_boxes + (long long)n * p.Gmax * 4;
     const float best = p.a_max[(long long)n * p.T + t];
     const int arg = p.a_arg[(long long)n * p.T + t];

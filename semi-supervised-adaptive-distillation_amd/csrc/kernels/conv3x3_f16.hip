@@ -253,7 +253,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Level
 template <typename T>   // T = float (the subnet pipeline) or _Float16 (float16 blobs of the operator surface)
 __global__ __launch_bounds__(kThreads) void f16_pack_kernel(const T* __restrict__ x,
                                                             uint4* __restrict__ xb, int N, int C,
-                                                            long long plane, float scale) {
+                                                            long long plane, float scale,
+                                                            const float* __restrict__ scale_dev) {
+  if (scale_dev) scale *= scale_dev[0];     // dynamic loss scale, kept on the device
   const int CB = (C + 7) >> 3;
   const long long total = (long long)N * CB * plane;
   for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total;
@@ -273,7 +275,9 @@ __global__ __launch_bounds__(kThreads) void f16_pack_kernel(const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(kThreads) void f16_unpack_kernel(const uint4* __restrict__ xb,
                                                               T* __restrict__ x, int N, int C,
-                                                              long long plane, float scale) {
+                                                              long long plane, float scale,
+                                                              const float* __restrict__ scale_dev) {
+  if (scale_dev) scale *= scale_dev[0];
   const int CB = (C + 7) >> 3;
   const long long total = (long long)N * CB * plane;
   for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total;
@@ -331,24 +335,35 @@ inline unsigned grid_for(long long n) {
 
 extern "C" {
 
-int ssad_f16_pack_activations(const float* x, int N, int C, int H, int W, float scale, void* xb,
-                              ssad_stream_t stream) {
+int ssad_f16_pack_activations_dyn(const float* x, int N, int C, int H, int W, float scale,
+                                  const float* scale_dev, void* xb, ssad_stream_t stream) {
   if (!x || !xb || N < 0 || C < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
   if (N == 0) return 0;
   const long long plane = (long long)H * W;
   hipLaunchKernelGGL(f16_pack_kernel<float>, dim3(grid_for((long long)N * ((C + 7) >> 3) * plane)),
-                     dim3(kThreads), 0, (hipStream_t)stream, x, static_cast<uint4*>(xb), N, C, plane, scale);
+                     dim3(kThreads), 0, (hipStream_t)stream, x, static_cast<uint4*>(xb), N, C, plane, scale,
+                     scale_dev);
   return (int)hipGetLastError();
+}
+
+int ssad_f16_pack_activations(const float* x, int N, int C, int H, int W, float scale, void* xb,
+                              ssad_stream_t stream) {
+  return ssad_f16_pack_activations_dyn(x, N, C, H, W, scale, nullptr, xb, stream);
 }
 
 int ssad_f16_unpack_activations(const void* xb, int N, int C, int H, int W, float scale, float* x,
                                 ssad_stream_t stream) {
+  return ssad_f16_unpack_activations_dyn(xb, N, C, H, W, scale, nullptr, x, stream);
+}
+
+int ssad_f16_unpack_activations_dyn(const void* xb, int N, int C, int H, int W, float scale,
+                                    const float* scale_dev, float* x, ssad_stream_t stream) {
   if (!x || !xb || N < 0 || C < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
   if (N == 0) return 0;
   const long long plane = (long long)H * W;
   hipLaunchKernelGGL(f16_unpack_kernel<float>, dim3(grid_for((long long)N * ((C + 7) >> 3) * plane)),
                      dim3(kThreads), 0, (hipStream_t)stream, static_cast<const uint4*>(xb), x, N, C,
-                     plane, scale);
+                     plane, scale, scale_dev);
   return (int)hipGetLastError();
 }
 
@@ -359,7 +374,7 @@ int ssad_f16_block_activations(const void* x_nchw_f16, int N, int C, int H, int 
   const long long plane = (long long)H * W;
   hipLaunchKernelGGL(f16_pack_kernel<_Float16>, dim3(grid_for((long long)N * ((C + 7) >> 3) * plane)),
                      dim3(kThreads), 0, (hipStream_t)stream, static_cast<const _Float16*>(x_nchw_f16),
-                     static_cast<uint4*>(xb), N, C, plane, 1.0f);
+                     static_cast<uint4*>(xb), N, C, plane, 1.0f, (const float*)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -370,7 +385,7 @@ int ssad_f16_unblock_activations(const void* xb, int N, int C, int H, int W, voi
   const long long plane = (long long)H * W;
   hipLaunchKernelGGL(f16_unpack_kernel<_Float16>, dim3(grid_for((long long)N * ((C + 7) >> 3) * plane)),
                      dim3(kThreads), 0, (hipStream_t)stream, static_cast<const uint4*>(xb),
-                     static_cast<_Float16*>(x_nchw_f16), N, C, plane, 1.0f);
+                     static_cast<_Float16*>(x_nchw_f16), N, C, plane, 1.0f, (const float*)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -659,9 +674,11 @@ constexpr int kDbSplits = 64;
 __global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_kernel(const float* __restrict__ part,
                                                                     int splits, int M, int C,
                                                                     int accumulate, float scale,
+                                                                    const float* __restrict__ scale_dev,
                                                                     float* __restrict__ dw,
                                                                     const float* __restrict__ dbpart,
                                                                     int dbparts, float* __restrict__ db) {
+  if (scale_dev) scale *= scale_dev[0];
   // one thread per (tap, m, c) element -- 590 K threads for a tower layer; a thread per (m, c)
   // with nine chains measured 3x slower: too few waves to cover the load latency -- four
   // independent chains over the splits; then the threads past 9 M C fold the bias partials
@@ -764,6 +781,14 @@ size_t ssad_conv3x3_wgrad_f16_levels_workspace_bytes(const ssad_f16_wgrad_level*
 int ssad_conv3x3_wgrad_f16_levels(const ssad_f16_wgrad_level* levels, int n_levels, int C, int M,
                                   int accumulate, float scale, float* dw, float* db, void* workspace,
                                   size_t workspace_bytes, ssad_stream_t stream) {
+  return ssad_conv3x3_wgrad_f16_levels_dyn(levels, n_levels, C, M, accumulate, scale, nullptr, dw, db,
+                                           workspace, workspace_bytes, stream);
+}
+
+int ssad_conv3x3_wgrad_f16_levels_dyn(const ssad_f16_wgrad_level* levels, int n_levels, int C, int M,
+                                      int accumulate, float scale, const float* scale_dev, float* dw,
+                                      float* db, void* workspace, size_t workspace_bytes,
+                                      ssad_stream_t stream) {
   if (!levels || n_levels < 1 || n_levels > SSAD_MAX_F16_LEVELS || !dw || C < 1 || M < 1) return SSAD_E_BADARG;
   F16Wgrad p;
   long long stages = 0;
@@ -805,7 +830,7 @@ int ssad_conv3x3_wgrad_f16_levels(const ssad_f16_wgrad_level* levels, int n_leve
       hipLaunchKernelGGL(f16_bias_grad_kernel, dim3((M + 7) / 8, kDbSplits), dim3(kThreads), 0, s, p.dy[l],
                          p.N[l], M, p.H[l] * p.W[l], dbpart + (size_t)l * kDbSplits * Mp);
   hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3((9 * M * C + M + kThreads - 1) / kThreads), dim3(kThreads),
-                     0, s, p.part, p.stages > 0 ? splits : 0, M, C, accumulate, scale, dw, dbpart,
+                     0, s, p.part, p.stages > 0 ? splits : 0, M, C, accumulate, scale, scale_dev, dw, dbpart,
                      n_levels * kDbSplits, db);
   return (int)hipGetLastError();
 }

@@ -79,9 +79,9 @@ __device__ __forceinline__ float wino_u(const float* g, int xi) {
                        : b == 2 ? 0.5f * (r[0] - r[1] + r[2]) : r[2];
 }
 
-__global__ void wino_pack_kernel(const float* __restrict__ w, int Cout, int Cin,
-                                 float* __restrict__ pf, float* __restrict__ pd) {
-  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void wino_pack_body(const float* __restrict__ w, int Cout, int Cin,
+                                               float* __restrict__ pf, float* __restrict__ pd,
+                                               long long tid) {
   for (int pass = 0; pass < 2; ++pass) {
     float* dst = pass == 0 ? pf : pd;
     if (!dst) continue;
@@ -107,6 +107,26 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, int Cout, int Cin,
     }
     dst[tid] = v;
   }
+}
+
+__global__ void wino_pack_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                 float* __restrict__ pf, float* __restrict__ pd) {
+  wino_pack_body(w, Cout, Cin, pf, pd, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// every filter of a model in ONE launch (blockIdx.y = filter): the training step repacks all
+// of its filters after each parameter update
+struct PackTable {
+  ssad_pack_entry e[SSAD_MAX_PACK_ENTRIES];
+};
+__global__ void wino_pack_multi_kernel(const PackTable t) {
+  const ssad_pack_entry& e = t.e[blockIdx.y];
+  const size_t nf = e.packed_fwd ? (size_t)cdiv(e.Cout, 16) * cdiv(e.Cin, KC) * STEPS * 256 + 1024 : 0;
+  const size_t nd = e.packed_dgrad ? (size_t)cdiv(e.Cin, 16) * cdiv(e.Cout, KC) * STEPS * 256 + 1024 : 0;
+  const long long n = (long long)(nf > nd ? nf : nd);
+  for (long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x; tid < n;
+       tid += (long long)gridDim.x * blockDim.x)
+    wino_pack_body(e.w, e.Cout, e.Cin, e.packed_fwd, e.packed_dgrad, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -815,6 +835,31 @@ int ssad_conv_wino_pack_filter(const float* w, int Cout, int Cin, float* packed_
   const size_t n = nf > nd ? nf : nd;
   hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, w, Cout, Cin, packed_fwd, packed_dgrad);
+  return (int)hipGetLastError();
+}
+
+int ssad_conv_wino_pack_filters(const ssad_pack_entry* entries_host, int n_entries, ssad_stream_t stream) {
+  if (n_entries < 0 || (n_entries > 0 && !entries_host)) return SSAD_E_BADARG;
+  for (int base = 0; base < n_entries; base += SSAD_MAX_PACK_ENTRIES) {
+    const int cnt = n_entries - base < SSAD_MAX_PACK_ENTRIES ? n_entries - base : SSAD_MAX_PACK_ENTRIES;
+    PackTable t;
+    size_t nmax = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const ssad_pack_entry& e = entries_host[base + i];
+      if (e.Cout <= 0 || e.Cin <= 0 || !e.w) return SSAD_E_BADARG;
+      t.e[i] = e;
+      const size_t nf = e.packed_fwd ? ssad_conv_wino_filter_floats(e.Cout, e.Cin) : 0;
+      const size_t nd = e.packed_dgrad ? ssad_conv_wino_filter_floats(e.Cin, e.Cout) : 0;
+      nmax = nf > nmax ? nf : nmax;
+      nmax = nd > nmax ? nd : nmax;
+    }
+    for (int i = cnt; i < SSAD_MAX_PACK_ENTRIES; ++i) t.e[i] = ssad_pack_entry{};
+    if (nmax == 0) continue;
+    size_t bx = (nmax + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(wino_pack_multi_kernel, dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0,
+                       (hipStream_t)stream, t);
+  }
   return (int)hipGetLastError();
 }
 

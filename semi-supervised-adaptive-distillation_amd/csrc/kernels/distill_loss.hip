@@ -472,63 +472,79 @@ __global__ __launch_bounds__(kThreads) void fused_finalize_kernel(
 // M foreground boxes x 4 coordinates, gathered through the location list: two
 // dependent global round trips per element, so the pass is latency-bound and
 // wants many workgroups (64K boxes on the finest level of a 16-image batch took
-// 480 us in one workgroup).  Per-workgroup double partials go to a
-// stream-ordered scratch allocation and are summed in index order by one
-// workgroup, so the result does not depend on the launch geometry's timing.
-__device__ __forceinline__ float smooth_l1_term(const float* __restrict__ Y_hat,
-                                                const float* __restrict__ Y,
-                                                const float* __restrict__ Lc, int e, int D, int H,
-                                                int W, float beta, double s) {
+// 480 us in one workgroup).  All FPN levels run in ONE launch (blockIdx.y = level);
+// per-workgroup double partials go to a caller-provided workspace (nothing is
+// allocated here, so the step can be captured in a graph) and are summed in index
+// order by one workgroup per level: the result does not depend on timing.
+constexpr int kSl1Blocks = 512;     // partial slots per level
+
+struct Sl1Args {
+  ssad_smooth_l1_level lv[SSAD_MAX_LEVELS];
+  int n_levels;
+};
+
+// element e = 4*i + j of a level's list -> index into Y_hat, or -1 when the entry is to be
+// skipped.  The reference's labelling can list anchors of the full anchor field that lie
+// outside the (cropped) prediction map (roi_data/retinanet.py:278-293) and would read out of
+// bounds there; any entry outside [0,N) x [0,D) x [0,H) x [0,W) contributes nothing here.
+__device__ __forceinline__ long long sl1_index(const ssad_smooth_l1_level& L, int e) {
   const int i = e >> 2, j = e & 3;
-  const int n = (int)Lc[i * 4], c = (int)Lc[i * 4 + 1], y = (int)Lc[i * 4 + 2], x = (int)Lc[i * 4 + 3];
-  // the reference's labelling can list anchors of the full anchor field that lie outside
-  // the (cropped) prediction map (roi_data/retinanet.py:278-293); it would read out of
-  // bounds there -- such entries contribute nothing here
-  if (y >= H || x >= W || y < 0 || x < 0) return 0.0f;
-  const size_t ind = ((size_t)n * D + c + j) * H * W + (size_t)y * W + x;
-  const float val = Y_hat[ind] - Y[e];
-  const float a = fabsf(val);
-  return a < beta ? (float)((0.5 * (double)val * (double)val / (double)beta) / s)
-                  : (float)(((double)a - 0.5 * (double)beta) / s);
+  const int n = (int)L.L[i * 4], c = (int)L.L[i * 4 + 1], y = (int)L.L[i * 4 + 2], x = (int)L.L[i * 4 + 3];
+  if (n < 0 || n >= L.N || c < 0 || c + j >= L.D || y < 0 || y >= L.H || x < 0 || x >= L.W) return -1;
+  return ((long long)n * L.D + c + j) * L.H * L.W + (long long)y * L.W + x;
 }
 
 __global__ __launch_bounds__(kThreads) void smooth_l1_fwd_kernel(
-    const float* __restrict__ Y_hat, const float* __restrict__ Y, const float* __restrict__ Lc,
-    const float* __restrict__ S, int D, int H, int W, int M, float beta,
-    double* __restrict__ partials) {
+    const Sl1Args args, const float* __restrict__ S, float beta, double* __restrict__ partials) {
+  const ssad_smooth_l1_level& L = args.lv[blockIdx.y];
   const double s = (double)fmaxf(S[0], 1.0f);
   double acc = 0.0;
-  for (int e = blockIdx.x * kThreads + threadIdx.x; e < M * 4; e += gridDim.x * kThreads)
-    acc += (double)smooth_l1_term(Y_hat, Y, Lc, e, D, H, W, beta, s);
+  for (int e = blockIdx.x * kThreads + threadIdx.x; e < L.M * 4; e += gridDim.x * kThreads) {
+    const long long ind = sl1_index(L, e);
+    if (ind < 0) continue;
+    const float val = L.Y_hat[ind] - L.Y[e];
+    const float a = fabsf(val);
+    acc += (double)(a < beta ? (float)((0.5 * (double)val * (double)val / (double)beta) / s)
+                             : (float)(((double)a - 0.5 * (double)beta) / s));
+  }
   const double t = block_sum(acc);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  if (threadIdx.x == 0) partials[blockIdx.y * kSl1Blocks + blockIdx.x] = t;
 }
 
 __global__ __launch_bounds__(kThreads) void smooth_l1_finalize_kernel(
-    const double* __restrict__ partials, int n, float scale, float* __restrict__ out) {
+    const Sl1Args args, const double* __restrict__ partials, int n, float scale) {
   double v = 0.0;
-  for (int i = threadIdx.x; i < n; i += kThreads) v += partials[i];
+  for (int i = threadIdx.x; i < n; i += kThreads) v += partials[blockIdx.x * kSl1Blocks + i];
   const double t = block_sum(v);
-  if (threadIdx.x == 0) out[0] = (float)t * scale;
+  if (threadIdx.x == 0) args.lv[blockIdx.x].loss[0] = (float)t * scale;
 }
 
-// dY_hat must be zero-filled first (the op does that, as the reference's
-// math::Set, .cu:143-145); this scatters the M*4 non-zero entries.
+// zero fill of every level's dY_hat (the reference's math::Set, .cu:143-145) in one launch
+__global__ __launch_bounds__(kThreads) void smooth_l1_zero_kernel(const Sl1Args args) {
+  const ssad_smooth_l1_level& L = args.lv[blockIdx.y];
+  const long long n = (long long)L.N * L.D * L.H * L.W;
+  float* __restrict__ o = L.dY_hat;
+  const long long n4 = (((uintptr_t)o & 15) == 0) ? (n >> 2) : 0;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long long)gridDim.x * kThreads)
+    reinterpret_cast<float4*>(o)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long i = n4 * 4 + (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads)
+    o[i] = 0.0f;
+}
+
+// scatters the M*4 non-zero entries into the zero-filled dY_hat
 __global__ __launch_bounds__(kThreads) void smooth_l1_bwd_kernel(
-    const float* __restrict__ Y_hat, const float* __restrict__ Y, const float* __restrict__ Lc,
-    const float* __restrict__ S, const float* __restrict__ dloss, int D, int H, int W, int M,
-    float beta, float scale, float* __restrict__ dY_hat) {
+    const Sl1Args args, const float* __restrict__ S, const float* __restrict__ dloss, float beta,
+    float scale) {
+  const ssad_smooth_l1_level& L = args.lv[blockIdx.y];
   const float s = fmaxf(S[0], 1.0f);
   const float nd = scale * dloss[0];
-  for (int e = blockIdx.x * kThreads + threadIdx.x; e < M * 4; e += gridDim.x * kThreads) {
-    const int i = e >> 2, j = e & 3;
-    const int n = (int)Lc[i * 4], c = (int)Lc[i * 4 + 1], y = (int)Lc[i * 4 + 2], x = (int)Lc[i * 4 + 3];
-    if (y >= H || x >= W || y < 0 || x < 0) continue;     // see smooth_l1_term
-    const size_t ind = ((size_t)n * D + c + j) * H * W + (size_t)y * W + x;
-    const float val = Y_hat[ind] - Y[e];
+  for (int e = blockIdx.x * kThreads + threadIdx.x; e < L.M * 4; e += gridDim.x * kThreads) {
+    const long long ind = sl1_index(L, e);
+    if (ind < 0) continue;
+    const float val = L.Y_hat[ind] - L.Y[e];
     const float a = fabsf(val);
     const float sign = (float)((0.0f < val) - (val < 0.0f));
-    dY_hat[ind] = a < beta ? nd * val / beta / s : nd * sign / s;
+    L.dY_hat[ind] = a < beta ? nd * val / beta / s : nd * sign / s;
   }
 }
 
@@ -657,7 +673,11 @@ int build_args(const ssad_distill_level* lv, int n_levels,
     total_items += items;
   }
   // distribute at most kMaxBlocks blocks proportionally to the work
-  static const int max_blocks = [] { const char* e = getenv("SSAD_LOSS_MAXBLOCKS"); return e ? atoi(e) : kMaxBlocks; }();
+  // tuning override, clamped: the workspace holds kMaxBlocks partial slots (the fused kernel's
+  // focal partials start at slot kMaxBlocks) and every level owns at least one block
+  static const int max_blocks_env = [] { const char* e = getenv("SSAD_LOSS_MAXBLOCKS"); return e ? atoi(e) : kMaxBlocks; }();
+  const int lo = 2 * n_levels + 1;
+  const int max_blocks = max_blocks_env > kMaxBlocks ? kMaxBlocks : (max_blocks_env < lo ? lo : max_blocks_env);
   int start = 0;
   for (int l = 0; l < n_levels; ++l) {
     LevelArgs& L = a.lv[l];
@@ -829,37 +849,84 @@ int ssad_cls_losses_fused(const ssad_distill_level* levels_host, int n_levels,
   return (int)hipGetLastError();
 }
 
+size_t ssad_select_smooth_l1_workspace_bytes(int n_levels) {
+  return sizeof(double) * kSl1Blocks * (size_t)(n_levels > 0 ? n_levels : 1);
+}
+
+static int sl1_args(const ssad_smooth_l1_level* lv, int n_levels, float beta, float scale, Sl1Args* a,
+                    int* max_m, long long* max_n) {
+  if (n_levels < 1 || n_levels > SSAD_MAX_LEVELS || !lv || !(beta > 0.0f) || !(scale >= 0.0f))
+    return SSAD_E_BADARG;
+  a->n_levels = n_levels;
+  *max_m = 0; *max_n = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const ssad_smooth_l1_level& s = lv[l];
+    if (s.N < 0 || s.D < 0 || s.H < 0 || s.W < 0 || s.M < 0 || s.M >= (1 << 29)) return SSAD_E_BADARG;
+    a->lv[l] = s;
+    if (s.M > *max_m) *max_m = s.M;
+    const long long n = (long long)s.N * s.D * s.H * s.W;
+    if (n > *max_n) *max_n = n;
+  }
+  return 0;
+}
+
+int ssad_select_smooth_l1_levels(const ssad_smooth_l1_level* levels_host, int n_levels, const float* S,
+                                 const float* dloss, float beta, float scale, int want_forward,
+                                 void* workspace, size_t workspace_bytes, ssad_stream_t stream) {
+  Sl1Args a;
+  int max_m = 0;
+  long long max_n = 0;
+  const int rc = sl1_args(levels_host, n_levels, beta, scale, &a, &max_m, &max_n);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  int grid = (max_m * 4 + kThreads - 1) / kThreads;
+  if (grid < 1) grid = 1;
+  if (grid > kSl1Blocks) grid = kSl1Blocks;
+  if (want_forward) {
+    if (!workspace || workspace_bytes < ssad_select_smooth_l1_workspace_bytes(n_levels)) return SSAD_E_WORKSPACE;
+    for (int l = 0; l < n_levels; ++l) if (!a.lv[l].loss) return SSAD_E_BADARG;
+    double* partials = (double*)workspace;
+    hipLaunchKernelGGL(smooth_l1_fwd_kernel, dim3(grid, n_levels), dim3(kThreads), 0, st, a, S, beta, partials);
+    hipLaunchKernelGGL(smooth_l1_finalize_kernel, dim3(n_levels), dim3(kThreads), 0, st, a,
+                       (const double*)partials, grid, scale);
+  }
+  if (dloss) {
+    for (int l = 0; l < n_levels; ++l) if (!a.lv[l].dY_hat) return SSAD_E_BADARG;
+    if (max_n > 0) {
+      long long zb = (max_n / 4 + kThreads - 1) / kThreads;
+      if (zb < 1) zb = 1;
+      if (zb > 2048) zb = 2048;
+      hipLaunchKernelGGL(smooth_l1_zero_kernel, dim3((int)zb, n_levels), dim3(kThreads), 0, st, a);
+    }
+    if (max_m > 0)
+      hipLaunchKernelGGL(smooth_l1_bwd_kernel, dim3(grid > 256 ? 256 : grid, n_levels), dim3(kThreads), 0, st,
+                         a, S, dloss, beta, scale);
+  }
+  return (int)hipGetLastError();
+}
+
 int ssad_select_smooth_l1_forward(const float* Y_hat, const float* Y, const float* L,
                                   const float* S, int N, int D, int H, int W, int M, float beta,
-                                  float scale, float* loss, ssad_stream_t stream) {
-  if (N < 0 || D < 0 || H < 0 || W < 0 || M < 0 || !(beta > 0.0f) || !(scale >= 0.0f))
-    return SSAD_E_BADARG;
-  hipStream_t st = (hipStream_t)stream;
-  int grid = (M * 4 + kThreads - 1) / kThreads;
-  if (grid < 1) grid = 1;
-  if (grid > 512) grid = 512;
-  double* partials = nullptr;
-  hipError_t err = hipMallocAsync((void**)&partials, sizeof(double) * grid, st);
-  if (err != hipSuccess) return (int)err;
-  hipLaunchKernelGGL(smooth_l1_fwd_kernel, dim3(grid), dim3(kThreads), 0, st, Y_hat, Y, L, S, D, H,
-                     W, M, beta, partials);
-  hipLaunchKernelGGL(smooth_l1_finalize_kernel, dim3(1), dim3(kThreads), 0, st, partials, grid,
-                     scale, loss);
-  err = hipFreeAsync(partials, st);
-  if (err != hipSuccess) return (int)err;
-  return (int)hipGetLastError();
+                                  float scale, float* loss, void* workspace, size_t workspace_bytes,
+                                  ssad_stream_t stream) {
+  const ssad_smooth_l1_level lv{Y_hat, Y, L, loss, nullptr, N, D, H, W, M};
+  return ssad_select_smooth_l1_levels(&lv, 1, S, nullptr, beta, scale, 1, workspace, workspace_bytes, stream);
 }
 
 int ssad_select_smooth_l1_backward(const float* Y_hat, const float* Y, const float* L,
                                    const float* S, const float* dloss, int N, int D, int H, int W,
                                    int M, float beta, float scale, float* dY_hat,
                                    ssad_stream_t stream) {
-  if (N < 0 || D < 0 || H < 0 || W < 0 || M < 0 || !(beta > 0.0f) || !(scale >= 0.0f))
+  if (N < 0 || D < 0 || H < 0 || W < 0 || M < 0 || !(beta > 0.0f) || !(scale >= 0.0f) || !dloss)
     return SSAD_E_BADARG;
   if (M == 0) return 0;
+  // dY_hat zero-filled by the caller (the operator does it with its own math::Set)
+  Sl1Args a;
+  a.n_levels = 1;
+  a.lv[0] = ssad_smooth_l1_level{Y_hat, Y, L, nullptr, dY_hat, N, D, H, W, M};
   const int grid = (M * 4 + kThreads - 1) / kThreads;
-  hipLaunchKernelGGL(smooth_l1_bwd_kernel, dim3(grid > 256 ? 256 : grid), dim3(kThreads), 0,
-                     (hipStream_t)stream, Y_hat, Y, L, S, dloss, D, H, W, M, beta, scale, dY_hat);
+  hipLaunchKernelGGL(smooth_l1_bwd_kernel, dim3(grid > 256 ? 256 : grid, 1), dim3(kThreads), 0,
+                     (hipStream_t)stream, a, S, dloss, beta, scale);
   return (int)hipGetLastError();
 }
 

@@ -131,6 +131,55 @@ __global__ __launch_bounds__(kThreads) void sgd_kernel(
   }
 }
 
+// the whole model's update in one launch: blockIdx.y = parameter (segment of the flat buffers)
+struct SgdTable {
+  ssad_sgd_segment seg[SSAD_MAX_SGD_SEGMENTS];
+};
+__global__ __launch_bounds__(kThreads) void sgd_flat_kernel(
+    float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
+    const float* __restrict__ lr_p, float mu, float wd, const SgdTable t,
+    const int* __restrict__ skip_flag) {
+  if (skip_flag && skip_flag[0] != 0) return;     // dropped step (gradient overflow)
+  const ssad_sgd_segment sg = t.seg[blockIdx.y];
+  const float lr = lr_p[0];
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long k = (long long)blockIdx.x * kThreads + threadIdx.x; k < sg.n; k += stride) {
+    const long long i = sg.offset + k;
+    const float wi = w[i];
+    float gi = g[i];
+    gi = sg.is_bias ? gi * 2.0f : gi + wd * wi;
+    const float mi = lr * gi + mu * m[i];
+    m[i] = mi;
+    g[i] = mi;
+    w[i] = wi - mi;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void check_finite_kernel(const float* __restrict__ x, long long n,
+                                                                int* __restrict__ flag) {
+  const long long stride = (long long)gridDim.x * kThreads;
+  int bad = 0;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    const unsigned u = __float_as_uint(x[i]);
+    bad |= ((u & 0x7f800000u) == 0x7f800000u);      // exponent all ones: Inf or NaN
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+__global__ void loss_scale_update_kernel(float* __restrict__ state, int* __restrict__ counters, float growth,
+                                         float backoff, int interval, float lo, float hi) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = state[0];
+  int good = counters[1];
+  if (counters[0] != 0) { s *= backoff; good = 0; }
+  else if (++good >= interval) { s *= growth; good = 0; }
+  s = fminf(fmaxf(s, lo), hi);
+  state[0] = s;
+  state[1] = 1.0f / s;
+  counters[0] = 0;
+  counters[1] = good;
+}
+
 template <class F, bool BINARY>
 int launch_map(const float* a, const float* b, float* y, int64_t n, F f, ssad_stream_t stream) {
   if (n < 0) return SSAD_E_BADARG;
@@ -304,6 +353,47 @@ int ssad_momentum_sgd_update(float* w, float* g, float* m, const float* lr, floa
   return (int)hipGetLastError();
 }
 
+int ssad_momentum_sgd_flat(float* w, float* g, float* m, const float* lr, float momentum,
+                           float weight_decay, const ssad_sgd_segment* segments_host, int n_segments,
+                           const int* skip_flag, ssad_stream_t stream) {
+  if (n_segments < 0 || (n_segments > 0 && (!segments_host || !w || !g || !m || !lr))) return SSAD_E_BADARG;
+  for (int base = 0; base < n_segments; base += SSAD_MAX_SGD_SEGMENTS) {
+    const int cnt = n_segments - base < SSAD_MAX_SGD_SEGMENTS ? n_segments - base : SSAD_MAX_SGD_SEGMENTS;
+    SgdTable t;
+    int64_t nmax = 0;
+    for (int i = 0; i < cnt; ++i) {
+      t.seg[i] = segments_host[base + i];
+      if (t.seg[i].n < 0 || t.seg[i].offset < 0) return SSAD_E_BADARG;
+      nmax = t.seg[i].n > nmax ? t.seg[i].n : nmax;
+    }
+    for (int i = cnt; i < SSAD_MAX_SGD_SEGMENTS; ++i) t.seg[i] = ssad_sgd_segment{0, 0, 0};
+    if (nmax == 0) continue;
+    int64_t bx = (nmax + kThreads - 1) / kThreads;
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(sgd_flat_kernel, dim3((unsigned)bx, (unsigned)cnt), dim3(kThreads), 0,
+                       (hipStream_t)stream, w, g, m, lr, momentum, weight_decay, t, skip_flag);
+  }
+  return (int)hipGetLastError();
+}
+
+int ssad_check_finite(const float* x, int64_t n, int* flag, ssad_stream_t stream) {
+  if (n < 0 || !flag || (n > 0 && !x)) return SSAD_E_BADARG;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(check_finite_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, x,
+                     (long long)n, flag);
+  return (int)hipGetLastError();
+}
+
+int ssad_loss_scale_update(float* state, int* counters, float growth, float backoff, int growth_interval,
+                           float min_scale, float max_scale, ssad_stream_t stream) {
+  if (!state || !counters || !(growth >= 1.0f) || !(backoff > 0.0f && backoff <= 1.0f) ||
+      growth_interval < 1 || !(min_scale > 0.0f) || !(max_scale >= min_scale))
+    return SSAD_E_BADARG;
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, counters,
+                     growth, backoff, growth_interval, min_scale, max_scale);
+  return (int)hipGetLastError();
+}
+
 int ssad_weighted_sum(const float* const* xs_host, const float* const* ws_host, int n_pairs,
                       float* out, int64_t n, ssad_stream_t stream) {
   if (n_pairs < 1 || n_pairs > kMaxSum || n < 0) return SSAD_E_BADARG;
@@ -328,7 +418,7 @@ int ssad_fill(float* y, float value, int64_t n, ssad_stream_t stream) {
 }
 
 const char* ssad_kernels_arch(void) { return "gfx950"; }
-int ssad_kernels_abi_version(void) { return 1; }
+int ssad_kernels_abi_version(void) { return 2; }
 
 int ssad_affine_channel(const float* x, const float* scale, const float* bias,
                         const float* residual, float* y, int N, int C, int HW, int relu,

@@ -11,11 +11,14 @@
 // Two engines, chosen per definition like the reference's engine fall-through
 // (caffe2/core/operator.cc:116-200): the geometry the RetinaNet subnets and the
 // ResNet bottlenecks use (3x3, stride 1, pad 1, dilation 1, group 1, NCHW) runs on
-// the matrix-core kernels of this repo; every other NCHW / group-1 geometry (the
-// backbone's 1x1, strided and 7x7 layers) runs on the DEFAULT engine of
+// the matrix-core kernels of this repo; every other 2-D NCHW geometry (the
+// backbone's 1x1, strided and 7x7 layers, and `group` > 1 -- ResNeXt's grouped 3x3 --
+// as one strided-batched GEMM per image) runs on the DEFAULT engine of
 // conv_op_impl.h:31-202 / :358-577 -- im2col + GEMM per image, with the GEMMs on
-// rocBLAS.  NHWC and grouped convolutions raise UnsupportedOperatorFeature at
-// construction (caffe2/core/operator.h:765-782).
+// rocBLAS.  NHWC and non-2-D convolutions raise UnsupportedOperatorFeature at
+// construction (caffe2/core/operator.h:765-782).  The operator packs its filter on
+// every RunOnDevice (the filter blob may have been updated in between, as under
+// training); the fused step (head_pipeline) packs once per parameter update instead.
 //
 // float16 blobs (TensorProto::FLOAT16) dispatch like CudnnConvOp's DoRunWithType<float16, ...>
 // (conv_op_cudnn.cc:631-636, :1115-1124): fp16 storage for X, filter, bias, Y and all
@@ -45,7 +48,7 @@ struct ConvGeometry {
 // the reference does; shared by Conv and ConvGradient.
 ConvGeometry ParseConvGeometry(const OperatorBase& op);
 bool IsSubnetGeometry(const ConvGeometry& g);   // 3x3 / s1 / p1 / d1 / g1 / NCHW
-bool IsDefaultEngineGeometry(const ConvGeometry& g);   // any 2-D NCHW group-1 geometry
+bool IsDefaultEngineGeometry(const ConvGeometry& g);   // any 2-D NCHW geometry (group >= 1)
 bool UseWinograd(const string& algo, int out_channels);
 
 template <typename T, class Context>
@@ -58,7 +61,7 @@ class ConvOp final : public Operator<Context> {
         fuse_relu_(OperatorBase::GetSingleArgument<int>("fuse_relu", 0)),
         algo_(OperatorBase::GetSingleArgument<string>("hip_algo", "auto")) {
     if (!IsDefaultEngineGeometry(geom_))
-      throw UnsupportedOperatorFeature("HIP Conv engines implement order=NCHW, group=1, 2-D only");
+      throw UnsupportedOperatorFeature("HIP Conv engines implement order=NCHW, 2-D only");
   }
   bool RunOnDevice() override;
 
@@ -87,7 +90,7 @@ class ConvGradientOp final : public Operator<Context> {
                   "If bias is not present, you should not have 3 grad output.");
     if (!IsDefaultEngineGeometry(geom_))
       throw UnsupportedOperatorFeature(
-          "HIP ConvGradient engines implement order=NCHW, group=1, 2-D only");
+          "HIP ConvGradient engines implement order=NCHW, 2-D only");
   }
   bool RunOnDevice() override;
 

@@ -130,6 +130,7 @@ class SelectSmoothL1LossOp final : public Operator<Context> {
  protected:
   float beta_;    // transition point from L1 to L2 loss
   float scale_;   // scale the loss by scale_
+  Tensor<Context> partials_;   // reduction scratch (the reference's buff_, select_smooth_l1_loss_op.h)
 };
 
 template <typename T, class Context>
@@ -167,9 +168,12 @@ bool SelectSmoothL1LossOp<float, HIPContext>::RunOnDevice() {
   CAFFE_ENFORCE_EQ(Y_hat.ndim(), 4);
   CAFFE_ENFORCE_EQ(L.size(), Y.size(), "one (n, c, y, x) row per target row");
   const int M = (int)(Y.size() / 4);
+  const size_t wsb = ssad_select_smooth_l1_workspace_bytes(1);
+  partials_.Resize((TIndex)wsb);
   Launched(ssad_select_smooth_l1_forward(Y_hat.data<float>(), Y.data<float>(), L.data<float>(),
                                          S.data<float>(), Y_hat.dim32(0), Y_hat.dim32(1),
-                                         Y_hat.dim32(2), Y_hat.dim32(3), M, beta_, scale_, out, s),
+                                         Y_hat.dim32(2), Y_hat.dim32(3), M, beta_, scale_, out,
+                                         partials_.mutable_data<uint8_t>(), wsb, s),
            "SelectSmoothL1Loss");
   return true;
 }

@@ -1,0 +1,192 @@
+// The native step driver (include/ssad_program.h): walks an array of op records and calls the
+// raw launchers of ssad_kernels.h -- the counterpart of Caffe2's SimpleNet::Run
+// (caffe2/caffe2/core/net_simple.cc), which walks a vector of operators on the net's stream.
+// With a ssad_timing every op is bracketed by HIP events recorded on the launch stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <map>
+#include <vector>
+
+#include "ssad_program.h"
+
+struct ssad_timing {
+  std::vector<hipEvent_t> pool;     // events, reused across resets
+  size_t used = 0;
+  struct Rec { int klass; double work; size_t e0, e1; };
+  std::vector<Rec> recs;
+  hipEvent_t get() {
+    if (used == pool.size()) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+};
+
+namespace {
+
+int run_op(const ssad_op& o, ssad_stream_t s) {
+  const void* const* p = o.p;
+  const int32_t* i = o.i;
+  const float* f = o.f;
+  switch (o.code) {
+    case SSAD_OP_WINO_PACK_FILTERS:
+      return ssad_conv_wino_pack_filters((const ssad_pack_entry*)p[0], i[0], s);
+    case SSAD_OP_PACK_FILTER:
+      return ssad_conv_pack_filter((const float*)p[0], i[0], i[1], (float*)p[1], (float*)p[2], s);
+    case SSAD_OP_CONV3X3:
+      return (i[4] ? ssad_conv3x3_forward_wino : ssad_conv3x3_forward)(
+          (const ssad_conv_level*)p[0], i[0], (const float*)p[1], (const float*)p[2], i[1], i[2], i[3], s);
+    case SSAD_OP_CONV3X3_WGRAD:
+      return ssad_conv3x3_wgrad((const ssad_conv_level*)p[0], i[0], (float*)p[1], (float*)p[2], i[1], i[2],
+                                i[3], (void*)p[3], (size_t)o.l[0], s);
+    case SSAD_OP_POW_SUM:
+      return ssad_pow_sum((const float* const*)p[0], (const int64_t*)p[1], i[0], f[0], (float*)p[2],
+                          (void*)p[3], (size_t)o.l[0], s);
+    case SSAD_OP_CLS_LOSSES_FUSED:
+      return ssad_cls_losses_fused((const ssad_distill_level*)p[0], i[0], (const float*)p[1],
+                                   (const float*)p[2], (const ssad_distill_params*)p[3],
+                                   (const ssad_focal_params*)p[4], (float*)p[5], (float*)p[6],
+                                   (void*)p[7], (size_t)o.l[0], s);
+    case SSAD_OP_DISTILL_FWD:
+      return ssad_distill_loss_forward((const ssad_distill_level*)p[0], i[0], (const float*)p[1],
+                                       (const ssad_distill_params*)p[2], (void*)p[3], (size_t)o.l[0], s);
+    case SSAD_OP_DISTILL_BWD:
+      return ssad_distill_loss_backward((const ssad_distill_level*)p[0], i[0], (const float*)p[1],
+                                        (const float*)p[2], i[1], (const ssad_distill_params*)p[3], s);
+    case SSAD_OP_FOCAL_FWD:
+      return ssad_focal_loss_forward((const ssad_distill_level*)p[0], i[0], (const float*)p[1],
+                                     (const ssad_focal_params*)p[2], (void*)p[3], (size_t)o.l[0], s);
+    case SSAD_OP_FOCAL_BWD:
+      return ssad_focal_loss_backward((const ssad_distill_level*)p[0], i[0], (const float*)p[1],
+                                      (const float*)p[2], i[1], (const ssad_focal_params*)p[3], s);
+    case SSAD_OP_SMOOTH_L1:
+      return ssad_select_smooth_l1_levels((const ssad_smooth_l1_level*)p[0], i[0], (const float*)p[1],
+                                          (const float*)p[2], f[0], f[1], i[1], (void*)p[3],
+                                          (size_t)o.l[0], s);
+    case SSAD_OP_SGD_FLAT:
+      return ssad_momentum_sgd_flat((float*)p[0], (float*)p[1], (float*)p[2], (const float*)p[3], f[0], f[1],
+                                    (const ssad_sgd_segment*)p[4], i[0], (const int*)p[5], s);
+    case SSAD_OP_FILL:
+      return ssad_fill((float*)p[0], f[0], o.l[0], s);
+    case SSAD_OP_SCALE:
+      return ssad_scale((const float*)p[0], (float*)p[1], f[0], o.l[0], s);
+    case SSAD_OP_SUM_N:
+      return ssad_sum_n((const float* const*)p[0], i[0], (float*)p[1], o.l[0], s);
+    case SSAD_OP_CHECK_FINITE:
+      return ssad_check_finite((const float*)p[0], o.l[0], (int*)p[1], s);
+    case SSAD_OP_LOSS_SCALE_UPDATE:
+      return ssad_loss_scale_update((float*)p[0], (int*)p[1], f[0], f[1], i[0], f[2], f[3], s);
+    case SSAD_OP_F16_PACK_ACT:
+      return ssad_f16_pack_activations_dyn((const float*)p[0], i[0], i[1], i[2], i[3], f[0],
+                                           (const float*)p[1], (void*)p[2], s);
+    case SSAD_OP_F16_UNPACK_ACT:
+      return ssad_f16_unpack_activations_dyn(p[0], i[0], i[1], i[2], i[3], f[0], (const float*)p[1],
+                                             (float*)p[2], s);
+    case SSAD_OP_F16_PACK_FILTER:
+      return ssad_f16_pack_filter((const float*)p[0], i[0], i[1], (void*)p[1], (void*)p[2], s);
+    case SSAD_OP_F16_CONV3X3:
+      return ssad_conv3x3_forward_f16_levels((const ssad_f16_level*)p[0], i[0], p[1], (const float*)p[2],
+                                             i[1], i[2], i[3], s);
+    case SSAD_OP_F16_WGRAD:
+      return ssad_conv3x3_wgrad_f16_levels_dyn((const ssad_f16_wgrad_level*)p[0], i[0], i[1], i[2], i[3],
+                                               f[0], (const float*)p[1], (float*)p[2], (float*)p[3],
+                                               (void*)p[4], (size_t)o.l[0], s);
+    case SSAD_OP_AFFINE_CHANNEL:
+      return ssad_affine_channel((const float*)p[0], (const float*)p[1], (const float*)p[2],
+                                 (const float*)p[3], (float*)p[4], i[0], i[1], i[2], i[3], s);
+    case SSAD_OP_UPSAMPLE:
+      return ssad_upsample_nearest((const float*)p[0], (const float*)p[1], (float*)p[2], i[0], i[1], i[2],
+                                   i[3], i[4], s);
+    case SSAD_OP_UPSAMPLE_GRAD:
+      return ssad_upsample_nearest_grad((const float*)p[0], (float*)p[1], i[0], i[1], i[2], i[3], i[4], s);
+    case SSAD_OP_STEM_POOL:
+      return ssad_max_pool3x3s2_bias_relu((const float*)p[0], (const float*)p[1], i[0], i[1], i[2], i[3],
+                                          i[4], (float*)p[2], s);
+    case SSAD_OP_RELU_GRAD_ROWSUM:
+      return ssad_relu_grad_rowsum((const float*)p[0], (const float*)p[1], (float*)p[2], (float*)p[3], i[0],
+                                   i[1], i[2], s);
+    case SSAD_OP_RELU_GRAD:
+      return ssad_relu_grad((const float*)p[0], (const float*)p[1], (float*)p[2], o.l[0], s);
+    case SSAD_OP_CHANNEL_SUM:
+      return ssad_channel_sum((const float*)p[0], i[0], i[1], i[2], (float*)p[1], i[3], s);
+    default:
+      return SSAD_E_BADARG;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+ssad_timing* ssad_timing_create(void) { return new ssad_timing(); }
+
+void ssad_timing_destroy(ssad_timing* t) {
+  if (!t) return;
+  for (hipEvent_t e : t->pool) (void)hipEventDestroy(e);
+  delete t;
+}
+
+void ssad_timing_reset(ssad_timing* t) {
+  if (!t) return;
+  t->used = 0;
+  t->recs.clear();
+}
+
+int ssad_timing_collect(ssad_timing* t, ssad_timing_class* out, int max_out) {
+  if (!t) return SSAD_E_BADARG;
+  std::map<int, ssad_timing_class> acc;
+  for (const auto& r : t->recs) {
+    float ms = 0.0f;
+    const hipError_t err = hipEventElapsedTime(&ms, t->pool[r.e0], t->pool[r.e1]);
+    if (err != hipSuccess) return -(int)err;
+    ssad_timing_class& c = acc[r.klass];
+    c.klass = r.klass;
+    c.launches += 1;
+    c.ms += (double)ms;
+    c.work += r.work;
+  }
+  int n = 0;
+  for (const auto& kv : acc) {
+    if (out && n < max_out) out[n] = kv.second;
+    ++n;
+  }
+  return n;
+}
+
+int ssad_program_run(const ssad_op* ops, int n_ops, ssad_stream_t stream, ssad_timing* timing,
+                     int* failed_index) {
+  if (n_ops < 0 || (n_ops > 0 && !ops)) return SSAD_E_BADARG;
+  hipStream_t hs = (hipStream_t)stream;
+  // consecutive ops share an event: op k runs between event k and event k + 1 on the stream
+  hipEvent_t prev = nullptr;
+  size_t prev_idx = 0;
+  if (timing && n_ops > 0) {
+    prev = timing->get();
+    if (!prev) return SSAD_E_BADARG;
+    prev_idx = timing->used - 1;
+    const hipError_t e = hipEventRecord(prev, hs);
+    if (e != hipSuccess) return (int)e;
+  }
+  for (int k = 0; k < n_ops; ++k) {
+    const int rc = run_op(ops[k], stream);
+    if (rc != 0) {
+      if (failed_index) *failed_index = k;
+      return rc;
+    }
+    if (timing) {
+      hipEvent_t e1 = timing->get();
+      if (!e1) return SSAD_E_BADARG;
+      const hipError_t e = hipEventRecord(e1, hs);
+      if (e != hipSuccess) return (int)e;
+      timing->recs.push_back({ops[k].klass, ops[k].work, prev_idx, timing->used - 1});
+      prev = e1;
+      prev_idx = timing->used - 1;
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -442,15 +442,20 @@ class FullDistillModel(object):
         if backbone_f16:
             _HIP3X3 = _FUSE_TAIL = _GEMM_1X1 = False
         self.heads = heads
+        self.timing = None
         self.pg, self.world = process_group, world_size
-        g = torch.Generator().manual_seed(7)
+        # teacher_depth None / "none": plain RetinaNet training of the student (BASELINE config 2,
+        # detectron/lib/modeling/model_builder.py:98-100,413 without the distillation wrapper)
+        self.has_teacher = teacher_depth not in (None, "none")
+        assert self.has_teacher == bool(getattr(heads, "distill", True)), \
+            "the subnet pipeline and the full model must agree on distillation"
         with torch.random.fork_rng():
             torch.manual_seed(7)
             self.student = ResNetFPN(student_depth).to(device)
-            self.teacher = ResNetFPN(teacher_depth).to(device).eval()
-        del g
-        for p in self.teacher.parameters():
-            p.requires_grad_(False)
+            self.teacher = ResNetFPN(teacher_depth).to(device).eval() if self.has_teacher else None
+        if self.has_teacher:
+            for p in self.teacher.parameters():
+                p.requires_grad_(False)
         # harness tuning knobs (A/B via env): MIOpen solver search and NHWC layout
         if os.environ.get("SSAD_HARNESS_BENCHMARK", "0") == "1":
             torch.backends.cudnn.benchmark = True
@@ -459,9 +464,10 @@ class FullDistillModel(object):
             (lambda: torch.autocast("cuda", enabled=False))
         if self.channels_last:
             self.student = self.student.to(memory_format=torch.channels_last)
-            self.teacher = self.teacher.to(memory_format=torch.channels_last)
+            if self.has_teacher:
+                self.teacher = self.teacher.to(memory_format=torch.channels_last)
         setup_tunableop()
-        self.two_streams = os.environ.get("SSAD_HARNESS_TWO_STREAMS", "1") == "1"
+        self.two_streams = os.environ.get("SSAD_HARNESS_TWO_STREAMS", "1") == "1" and self.has_teacher
         self.side = torch.cuda.Stream() if self.two_streams else None
         self.trainable = [p for p in self.student.parameters() if p.requires_grad]
         self.opt = torch.optim.SGD(self.trainable, lr=lr, momentum=momentum,
@@ -483,6 +489,14 @@ class FullDistillModel(object):
             assert sum(len(g) for g in groups) == len(self.trainable)
             self.buckets = GradBuckets(groups, BucketedAllReduce(self.pg, world_size))
 
+    def describe(self):
+        """What runs where in the backbones (for bench.py's workload string)."""
+        if self.backbone_f16:
+            return "backbones = PyTorch harness under autocast(float16) on MIOpen / rocBLAS"
+        return ("backbones = PyTorch harness (1x1 convs as rocBLAS / hipBLASLt GEMMs, MIOpen 7x7 stem, "
+                "P7 and grouped convs; its stride-1 3x3 convs, bias/residual/ReLU tails and stem pool "
+                "on this repo's kernels)")
+
     def _mark(self, name):
         if self._timing is not None:
             e = torch.cuda.Event(enable_timing=True)
@@ -496,7 +510,13 @@ class FullDistillModel(object):
         if self.channels_last:
             images = images.contiguous(memory_format=torch.channels_last)
         h.pack_student()
-        if self.two_streams:
+        if not self.has_teacher:
+            t_fpn = None
+            with self._cast():
+                s_fpn = self.student(images)
+            s_in = [t.detach().float().contiguous() for t in s_fpn]
+            self._mark("student backbone fwd")
+        elif self.two_streams:
             # teacher and student backbones are independent: on two streams the
             # last partial round of CUs of one network's kernel is filled by the
             # other network's next kernel (persistent / few-round launches leave

@@ -26,7 +26,10 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
+import ctypes as C
+
 from . import kernels as K
+from . import program as PR
 from . import synth
 from .data_parallel import BucketedAllReduce
 from .modeling.retinanet_heads import HeadConfig
@@ -62,6 +65,7 @@ class FlatParams(object):
         total = sum(int(np.prod(s)) for _, s, _, _ in self.specs)
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.views = OrderedDict()
+        self.offsets = {}
         self.bucket = {}
         off = 0
         starts = {}
@@ -69,6 +73,7 @@ class FlatParams(object):
             n = int(np.prod(shape))
             starts.setdefault(tower, off)
             self.views[name] = self.flat[off:off + n].view(shape)
+            self.offsets[name] = off
             off += n
             self.bucket[tower] = self.flat[starts[tower]:off]
         if init is not None:
@@ -80,12 +85,21 @@ class FlatParams(object):
 
 
 class DistillHeads(object):
+    """One training iteration of the RetinaNet subnets as a native program
+    (program.Program -> ssad_program_run).  distill=False is plain RetinaNet training
+    (BASELINE config 2: model_builder.py:98-100,413 without the distillation wrapper): no
+    teacher, no PowSum / SigmoidAdaptiveDistillLoss, only SigmoidFocalLoss + SelectSmoothL1Loss."""
+
+    F16 = False
+
     def __init__(self, cfg=None, N=2, shapes=synth.LEVEL_SHAPES_600, device="cuda",
                  student_init=None, teacher_init=None, teacher_bbox_tower=True,
-                 lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, world_size=1):
+                 lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, world_size=1,
+                 distill=True):
         self.cfg = cfg or HeadConfig()
         self.N, self.shapes, self.device = N, list(shapes), device
-        self.teacher_bbox_tower = teacher_bbox_tower
+        self.distill = bool(distill)
+        self.teacher_bbox_tower = teacher_bbox_tower and self.distill
         import os
         self.wino = os.environ.get("SSAD_CONV_ENGINE", "winograd").lower() != "direct"
         self.momentum, self.weight_decay = momentum, weight_decay
@@ -94,23 +108,38 @@ class DistillHeads(object):
         cfg = self.cfg
         self.A, self.C, self.D = cfg.num_anchors, cfg.num_classes - 1, cfg.fpn_dim
         self.params = FlatParams(cfg, device, student_init)
-        self.teacher = FlatParams(cfg, device, teacher_init)
+        self.teacher = FlatParams(cfg, device, teacher_init) if self.distill else None
         self.grads = FlatParams(cfg, device)
         self.moms = FlatParams(cfg, device)
-        self.lr = torch.full((1,), lr, dtype=torch.float32, device=device)
-        self.one = torch.ones(len(self.shapes), dtype=torch.float32, device=device)
-        self.focal_losses = None
-        self.bbox_losses = None
+        nlev = len(self.shapes)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.lr = torch.full((1,), lr, **f32)
+        self.one = torch.ones(nlev, **f32)
+        self.losses = torch.zeros(nlev, **f32)           # distillation loss per level
+        self.focal_losses = torch.zeros(nlev, **f32)
+        self.bbox_losses = torch.zeros(nlev, **f32)
+        self.normalizer = torch.zeros(1, **f32)
+        self.fg_num = torch.ones(1, **f32)               # bound copy of the step's fg_num
         self.preserved = OrderedDict()     # blobs of a loaded weights file the subnets do not own
-
+        self.timing = None                 # program.Timing while bench.py measures
+        self.t_packed = None
+        self._teacher_packed = False
         self._alloc_buffers()
+        self._build_programs()
 
+    # -- buffers ------------------------------------------------------------------
     def _lv(self, ch):
         return [torch.empty((self.N, ch, h, w), dtype=torch.float32, device=self.device)
                 for (h, w) in self.shapes]
 
     def _alloc_buffers(self):
         cfg, lv, D = self.cfg, self._lv, self.D
+        # inputs are bound per step (the FPN tensors belong to the caller); these placeholders
+        # give the level tables valid addresses until the first bind
+        self.fpn_in = lv(D)
+        self.t_fpn_in = self.fpn_in
+        self.labels = [torch.zeros((self.N, self.A, h, w), dtype=torch.int32, device=self.device)
+                       for (h, w) in self.shapes]
         # student activations (kept for backward) and their gradients
         self.act = {t: [lv(D) for _ in range(cfg.num_convs)] for t in ("cls", "bbox")}
         self.cls_logits, self.bbox_pred = lv(self.A * self.C), lv(4 * self.A)
@@ -118,178 +147,402 @@ class DistillHeads(object):
         self.d_bbox_pred = lv(4 * self.A)
         self.dbuf = {"cls": [lv(D), lv(D)], "bbox": [lv(D), lv(D)]}   # ping-pong tower gradients
         self.d_fpn = {t: lv(D) for t in ("cls", "bbox")}
-        # teacher scratch: two ping-pong feature sets per tower + probabilities
-        self.t_buf = {"cls": [lv(D), lv(D)], "bbox": [lv(D), lv(D)]}
-        self.t_prob = lv(self.A * self.C)
-        self.t_bbox = lv(4 * self.A) if self.teacher_bbox_tower else None
-        # packed filters (rebuilt every step from the current weights)
-        self.packed = {}
-        self.t_packed = None
-        self.losses = None
-        self.normalizer = None
+        if self.distill:
+            # teacher scratch: two ping-pong feature sets per tower + probabilities
+            self.t_buf = {"cls": [lv(D), lv(D)], "bbox": [lv(D), lv(D)]}
+            self.t_prob = lv(self.A * self.C)
+            self.t_bbox = lv(4 * self.A) if self.teacher_bbox_tower else None
 
-    # -- parameters -----------------------------------------------------------
+    # -- layer bookkeeping ----------------------------------------------------------
     def _layers(self, tower):
         cfg = self.cfg
         names = ["retnet_%s_conv_n%d_fpn%d" % (tower, i, cfg.k_min) for i in range(cfg.num_convs)]
         names.append("retnet_%s_pred_fpn%d" % (tower, cfg.k_min))
         return names
 
-    # Engine choice per convolution: the Winograd F(2x2,3x3) kernel wherever the
-    # output is >= 128 channels wide (all tower layers, cls_pred, every data
-    # gradient), the direct kernel for the 36-channel bbox_pred forward.
-    # SSAD_CONV_ENGINE=direct forces the direct kernel everywhere.
+    # Engine choice per convolution: the Winograd F(2x2,3x3) kernel wherever the output is
+    # >= 32 channels wide (every layer of the reference configuration), the direct kernel
+    # below that.  SSAD_CONV_ENGINE=direct forces the direct kernel everywhere.
     def _use_wino(self, cout):
         return self.wino and cout >= 32
 
-    def _pack(self, w, want_fwd, want_dgrad):
-        """-> (fwd_packed, dgrad_packed) in the layout of the engine that will
-        consume each (forward: Cout outputs; data gradient: Cin outputs)."""
-        cout, cin = w.shape[0], w.shape[1]
-        pf = pd = None
-        if want_fwd:
-            pf = (K.conv_wino_pack_filter(w, True, False)[0] if self._use_wino(cout)
-                  else K.conv_pack_filter(w, True, False)[0])
-        if want_dgrad:
-            pd = (K.conv_wino_pack_filter(w, False, True)[1] if self._use_wino(cin)
-                  else K.conv_pack_filter(w, False, True)[1])
-        return pf, pd
+    def _px(self):
+        return self.N * sum(h * w for h, w in self.shapes)
 
-    def pack_student(self, want_dgrad=True):
+    # -- program construction ---------------------------------------------------------
+    def _conv_table(self, problems):
+        """problems: [(xs, outs, masks or None, packed or None, bias or None)] -> ssad_conv_level[]"""
+        n = sum(len(p[0]) for p in problems)
+        arr = (K.ConvLevel * n)()
+        k = 0
+        for xs, outs, masks, packed, bias in problems:
+            for l, x in enumerate(xs):
+                arr[k] = K.ConvLevel(x.data_ptr(), outs[l].data_ptr() if outs is not None else 0,
+                                     masks[l].data_ptr() if masks is not None else 0,
+                                     x.shape[0], x.shape[2], x.shape[3],
+                                     packed.data_ptr() if packed is not None else 0,
+                                     bias.data_ptr() if bias is not None else 0)
+                k += 1
+        return arr
+
+    def _emit_conv(self, P, problems, Cout, Cin, flags, klass):
+        """One launch of independent convolutions of equal (Cout, Cin)."""
+        arr = self._conv_table(problems)
+        px = sum(x.shape[0] * x.shape[2] * x.shape[3] for p in problems for x in p[0])
+        wino = self._use_wino(Cout)
+        if not wino and klass in (2, 3, 4):
+            klass = 18
+        idx = P.add(PR.CONV3X3, klass, i=(len(arr), Cout, Cin, flags, int(wino)), p=(arr, None, None),
+                    work=2.0 * 9 * Cout * Cin * px,
+                    keep=[t for p in problems for t in (list(p[0]) + list(p[1] or []) + list(p[2] or []))
+                          ] + [t for p in problems for t in p[3:] if t is not None])
+        return idx, arr
+
+    def _emit_wgrad(self, P, xs, dys, name, Cout, klass):
+        arr = self._conv_table([(xs, None, dys, None, None)])
+        nb = K.lib().ssad_conv3x3_wgrad_workspace_bytes(arr, len(arr), Cout, self.D)
+        self._wgrad_ws_need = max(getattr(self, "_wgrad_ws_need", 0), nb)
+        px = sum(x.shape[0] * x.shape[2] * x.shape[3] for x in xs)
+        idx = P.add(PR.CONV3X3_WGRAD, klass if self._use_wino(Cout) else 19,
+                    i=(len(arr), Cout, self.D, 0), l=(nb,),
+                    p=(arr, self.grads[name + "_w"], self.grads[name + "_b"], None),
+                    work=2.0 * 9 * Cout * self.D * px, keep=list(xs) + list(dys))
+        self._wgrad_ops.append(idx)
+        return idx, arr
+
+    def _alloc_packed(self, params, want_dgrad):
+        """Packed-filter buffers per layer in the layout of the engine that consumes them:
+        -> ({name: (fwd, dgrad)}, wino pack entries, direct pack ops)."""
+        L = K.lib()
+        packed, entries, direct = {}, [], []
         for tower in ("cls", "bbox"):
             for name in self._layers(tower):
-                self.packed[name] = self._pack(self.params[name + "_w"], True, want_dgrad)
+                w = params[name + "_w"]
+                cout, cin = w.shape[0], w.shape[1]
+                pf = pd = None
+                fw, dw = self._use_wino(cout), self._use_wino(cin)
+                nf = (L.ssad_conv_wino_filter_floats if fw else L.ssad_conv_packed_filter_floats)(cout, cin)
+                pf = torch.empty(nf, dtype=torch.float32, device=self.device)
+                if want_dgrad:
+                    nd = (L.ssad_conv_wino_filter_floats if dw else L.ssad_conv_packed_filter_floats)(cin, cout)
+                    pd = torch.empty(nd, dtype=torch.float32, device=self.device)
+                packed[name] = (pf, pd)
+                wf, wd = (pf if fw else None), (pd if (dw and want_dgrad) else None)
+                if wf is not None or wd is not None:
+                    entries.append((w, cout, cin, wf, wd))
+                df, dd = (pf if not fw else None), (pd if (not dw and want_dgrad) else None)
+                if df is not None or dd is not None:
+                    direct.append((w, cout, cin, df, dd))
+        return packed, entries, direct
 
-    def pack_teacher(self):
-        """The teacher is frozen: pack once."""
-        self.t_packed = {}
-        for tower in ("cls", "bbox"):
-            for name in self._layers(tower):
-                self.t_packed[name] = self._pack(self.teacher[name + "_w"], True, False)[0]
+    def _emit_pack(self, P, entries, direct):
+        if entries:
+            tab = (K.PackEntry * len(entries))()
+            nbytes = 0
+            for k, (w, cout, cin, pf, pd) in enumerate(entries):
+                tab[k] = K.PackEntry(w.data_ptr(), cout, cin, pf.data_ptr() if pf is not None else 0,
+                                     pd.data_ptr() if pd is not None else 0)
+                nbytes += 4 * (w.numel() + (pf.numel() if pf is not None else 0)
+                               + (pd.numel() if pd is not None else 0))
+            P.add(PR.WINO_PACK_FILTERS, 1, i=(len(entries),), p=(tab,), work=nbytes,
+                  keep=[t for e in entries for t in e if isinstance(t, torch.Tensor)])
+        for w, cout, cin, pf, pd in direct:
+            P.add(PR.PACK_FILTER, 1, i=(cout, cin), p=(w, pf, pd),
+                  work=4 * (w.numel() + (pf.numel() if pf is not None else 0)
+                            + (pd.numel() if pd is not None else 0)))
 
-    # -- forward ----------------------------------------------------------------
-    def forward_all(self, teacher_fpn, student_fpn):
-        """Teacher (test mode) and student subnets.  The four tower layers of
-        equal depth (teacher/student x cls/bbox) are independent convolutions
-        of the same shape, so each depth is ONE launch of 20 (level, filter)
-        problems: 12 480 equal workgroups fill the 256 CUs to 99 % where five
-        separate launches would each leave a partial last wave.  Teacher
-        cls_pred carries the Sigmoid epilogue (retinanet_heads.py:153-163)."""
-        if self.t_packed is None:
-            self.pack_teacher()
-        self.fpn_in = student_fpn
-        cfg = self.cfg
-        tx = {"cls": teacher_fpn, "bbox": teacher_fpn}
-        sx = {"cls": student_fpn, "bbox": student_fpn}
+    def _build_programs(self):
+        self._wgrad_ops, self._wgrad_ws_need = [], 0
+        self._in_slots = []          # (table, index, which): entries that read the bound inputs
+        # filters (the teacher's are frozen: packed by a program of their own, run when they change)
+        self.packed, s_entries, s_direct = self._alloc_packed(self.params, True)
+        if self.distill:
+            self.t_packed_pairs, t_entries, t_direct = self._alloc_packed(self.teacher, False)
+            self.t_packed = {k: v[0] for k, v in self.t_packed_pairs.items()}
+            T = self.prog_teacher_pack = PR.Program()
+            self._emit_pack(T, t_entries, t_direct)
+            T.build()
+        P = self.prog = PR.Program()
+        P.mark("pack")
+        self._emit_pack(P, s_entries, s_direct)
+        P.mark("forward")
+        self._emit_forward(P)
+        P.mark("losses")
+        self._emit_losses(P)
+        P.mark("backward")
+        self._emit_backward(P)
+        P.mark("sgd")
+        self._emit_sgd(P)
+        P.mark("end")
+        # the distillation-only variant of the loss segment (no supervised losses: the caller
+        # supplies the gradient of the box predictions)
+        if self.distill:
+            Q = self.prog_distill_only = PR.Program()
+            self._emit_losses(Q, supervised=False)
+            Q.build()
+        self._finish_workspaces(P)
+        P.build()
+
+    def _finish_workspaces(self, P):
+        self.wgrad_ws = torch.empty(max(self._wgrad_ws_need, 16), dtype=torch.uint8, device=self.device)
+        for idx in self._wgrad_ops:
+            P.set_ptr(idx, 3, self.wgrad_ws)
+
+    # -- forward --------------------------------------------------------------------------
+    def _emit_forward(self, P):
+        """Teacher (test mode) and student subnets.  The tower layers of equal depth
+        (teacher/student x cls/bbox) are independent convolutions of the same shape, so each
+        depth is ONE launch of up to 20 (level, filter) problems: 12 480 equal workgroups fill
+        the 256 CUs to 99 % where five separate launches would each leave a partial last wave.
+        Teacher cls_pred carries the Sigmoid epilogue (retinanet_heads.py:153-163)."""
+        cfg, D = self.cfg, self.D
+        AC, A4 = self.A * self.C, 4 * self.A
+        tx = {"cls": self.t_fpn_in, "bbox": self.t_fpn_in}
+        sx = {"cls": self.fpn_in, "bbox": self.fpn_in}
         for i in range(cfg.num_convs):
-            probs = []
+            probs, who = [], []
             for t in ("cls", "bbox"):
                 name = self._layers(t)[i]
-                if t == "cls" or self.teacher_bbox_tower:
+                if self.distill and (t == "cls" or self.teacher_bbox_tower):
                     out = self.t_buf[t][i & 1]
-                    probs.append(dict(xs=tx[t], packed=self.t_packed[name],
-                                      bias=self.teacher[name + "_b"], out=out))
+                    probs.append((tx[t], out, None, self.t_packed_for(name), self.teacher[name + "_b"]))
+                    who.append("teacher")
                     tx[t] = out
                 out = self.act[t][i]
-                probs.append(dict(xs=sx[t], packed=self.packed[name][0],
-                                  bias=self.params[name + "_b"], out=out))
+                probs.append((sx[t], out, None, self.packed[name][0], self.params[name + "_b"]))
+                who.append("student")
                 sx[t] = out
-            K.conv3x3_forward_multi(probs, self.D, relu=True, wino=self._use_wino(self.D))
-        cp = self._layers("cls")[-1]
-        wn = self._use_wino(self.A * self.C)
-        K.conv3x3_forward(tx["cls"], self.t_packed[cp], self.teacher[cp + "_b"], self.A * self.C,
-                          sigmoid=True, out=self.t_prob, wino=wn)
-        K.conv3x3_forward(sx["cls"], self.packed[cp][0], self.params[cp + "_b"], self.A * self.C,
-                          out=self.cls_logits, wino=wn)
-        bp = self._layers("bbox")[-1]
-        probs = [dict(xs=sx["bbox"], packed=self.packed[bp][0], bias=self.params[bp + "_b"],
-                      out=self.bbox_pred)]
+            _, arr = self._emit_conv(P, probs, D, D, K.CONV_RELU, 2)
+            if i == 0:
+                k = 0
+                for (xs, _, _, _, _), w in zip(probs, who):
+                    for l in range(len(xs)):
+                        self._in_slots.append((arr, k, w, l))
+                        k += 1
+        cp, bp = self._layers("cls")[-1], self._layers("bbox")[-1]
+        if self.distill:
+            self._emit_conv(P, [(tx["cls"], self.t_prob, None, self.t_packed_for(cp), self.teacher[cp + "_b"])],
+                            AC, D, K.CONV_SIGMOID, 3)
+        self._emit_conv(P, [(sx["cls"], self.cls_logits, None, self.packed[cp][0], self.params[cp + "_b"])],
+                        AC, D, 0, 3)
+        probs = [(sx["bbox"], self.bbox_pred, None, self.packed[bp][0], self.params[bp + "_b"])]
         if self.teacher_bbox_tower:
-            probs.append(dict(xs=tx["bbox"], packed=self.t_packed[bp],
-                              bias=self.teacher[bp + "_b"], out=self.t_bbox))
-        K.conv3x3_forward_multi(probs, 4 * self.A, wino=self._use_wino(4 * self.A))
-        return self.cls_logits, self.bbox_pred
+            probs.append((tx["bbox"], self.t_bbox, None, self.t_packed_for(bp), self.teacher[bp + "_b"]))
+        self._emit_conv(P, probs, A4, D, 0, 4)
 
-    # -- losses -------------------------------------------------------------------
-    def distill_loss(self, labels):
-        """PowSum normaliser + the five SigmoidAdaptiveDistillLoss, forward and
-        gradient w.r.t. the student logits (loss gradient = 1.0,
-        utils/blob.py:166-172)."""
-        cfg = self.cfg
-        kw = dict(gamma=cfg.distill_gamma, alpha=cfg.distill_alpha, beta=cfg.distill_beta,
-                  num_classes=self.C, ignored_label=cfg.ignored_label,
-                  scale=cfg.loss_scale * cfg.temperature * cfg.temperature)
-        self.normalizer = K.pow_sum(self.t_prob, cfg.logits_power).reshape(1)
-        levels = list(zip(self.cls_logits, self.t_prob, labels))
-        self.losses = K.distill_loss_forward(levels, self.normalizer, **kw)
-        K.distill_loss_backward(levels, self.normalizer, self.one, out=self.d_cls_logits, **kw)
-        return self.losses
+    def t_packed_for(self, name):
+        return self.t_packed[name]
 
+    # -- losses -----------------------------------------------------------------------------
     def _distill_kw(self):
         cfg = self.cfg
         return dict(gamma=cfg.distill_gamma, alpha=cfg.distill_alpha, beta=cfg.distill_beta,
                     num_classes=self.C, ignored_label=cfg.ignored_label,
                     scale=cfg.loss_scale * cfg.temperature * cfg.temperature)
 
-    def cls_losses(self, labels, fg_num):
-        """Both classification losses of the student (SigmoidFocalLoss,
-        retinanet_heads.py:282-297, and SigmoidAdaptiveDistillLoss, :331-348) and
-        their summed gradient w.r.t. the logits in ONE pass (the reference:
-        2 forward ops + 2 gradient ops + an autograd Sum per level)."""
-        cfg = self.cfg
-        self.normalizer = K.pow_sum(self.t_prob, cfg.logits_power).reshape(1)
-        levels = list(zip(self.cls_logits, self.t_prob, labels))
-        focal_kw = dict(gamma=cfg.focal_gamma, alpha=cfg.focal_alpha, num_classes=self.C,
-                        scale=cfg.loss_scale)
-        self.losses, self.focal_losses, _ = K.cls_losses_fused(
-            levels, self.normalizer, fg_num, self._distill_kw(), focal_kw, out=self.d_cls_logits)
-        return self.losses, self.focal_losses
+    def _cls_table(self, outs):
+        arr = (K.DistillLevel * len(self.shapes))()
+        for l, x in enumerate(self.cls_logits):
+            N, Dd, H, W = x.shape
+            arr[l] = K.DistillLevel(x.data_ptr(), self.t_prob[l].data_ptr() if self.distill else 0,
+                                    self.labels[l].data_ptr(), outs[l].data_ptr(), N, Dd, H, W)
+        self._label_tables.append(arr)
+        return arr
 
-    def bbox_losses_fwd_bwd(self, bbox_targets, fg_num):
-        """SelectSmoothL1Loss per level (retinanet_heads.py:268-280) and its
-        gradient w.r.t. the box predictions.  bbox_targets: [(Y [M,4], L [M,4])]."""
-        cfg = self.cfg
-        kw = dict(beta=cfg.bbox_reg_beta, scale=cfg.loss_scale * cfg.bbox_reg_weight)
-        losses = []
-        for pred, (Y, Lc), dst in zip(self.bbox_pred, bbox_targets, self.d_bbox_pred):
-            losses.append(K.select_smooth_l1_forward(pred, Y, Lc, fg_num, **kw))
-            K.select_smooth_l1_backward(pred, Y, Lc, fg_num, self.one[:1], out=dst, **kw)
-        self.bbox_losses = torch.stack(losses)
-        return self.d_bbox_pred
+    def _emit_losses(self, P, supervised=True):
+        """PowSum normaliser (adaptive: computed from the teacher's probabilities,
+        retinanet_heads.py:325-329) and the classification / box losses with their gradients
+        w.r.t. the predictions (loss gradients = 1.0, utils/blob.py:166-172).  With the
+        supervised losses present, both classification losses of the student and their summed
+        gradient come from ONE pass over the logits (the reference: 2 forward ops + 2 gradient
+        ops + an autograd Sum per level)."""
+        cfg, L = self.cfg, K.lib()
+        if not hasattr(self, "_label_tables"):
+            self._label_tables, self._sl1_tables = [], []
+        nlev = len(self.shapes)
+        n_logits = sum(x.numel() for x in self.cls_logits)
+        n_labels = sum(x.numel() for x in self.labels)
+        if self.distill:
+            ptrs = (C.c_void_p * nlev)(*[t.data_ptr() for t in self.t_prob])
+            sizes = (C.c_int64 * nlev)(*[t.numel() for t in self.t_prob])
+            nb = L.ssad_pow_sum_workspace_bytes(nlev)
+            ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            P.add(PR.POW_SUM, 8, i=(nlev,), f=(cfg.logits_power,), l=(nb,), p=(ptrs, sizes, self.normalizer, ws),
+                  work=4.0 * n_logits, keep=list(self.t_prob))
+        DP = K.DistillParams(**{k: v for k, v in self._distill_kw().items()})
+        FP = K.FocalParams(cfg.focal_gamma, cfg.focal_alpha, self.C, cfg.loss_scale)
+        if self.distill and supervised:
+            if cfg.focal_gamma != 2.0:
+                raise K.KernelError("the fused distillation + focal pass specialises focal gamma == 2")
+            arr = self._cls_table(self.d_cls_logits)
+            nb = L.ssad_cls_losses_fused_workspace_bytes(nlev)
+            ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            P.add(PR.CLS_LOSSES_FUSED, 9, i=(nlev,), l=(nb,),
+                  p=(arr, self.normalizer, self.fg_num, DP, FP, self.losses, self.focal_losses, ws),
+                  work=12.0 * n_logits + 4.0 * n_labels)
+        elif self.distill:
+            nb = L.ssad_distill_loss_workspace_bytes(nlev)
+            ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            arr_f = self._cls_table([self.losses[l:l + 1] for l in range(nlev)])
+            P.add(PR.DISTILL_FWD, 12, i=(nlev,), l=(nb,), p=(arr_f, self.normalizer, DP, ws),
+                  work=8.0 * n_logits + 4.0 * n_labels)
+            arr_b = self._cls_table(self.d_cls_logits)
+            P.add(PR.DISTILL_BWD, 13, i=(nlev, 1), p=(arr_b, self.normalizer, self.one, DP),
+                  work=12.0 * n_logits + 4.0 * n_labels)
+        else:
+            nb = L.ssad_distill_loss_workspace_bytes(nlev)
+            ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            arr_f = self._cls_table([self.focal_losses[l:l + 1] for l in range(nlev)])
+            P.add(PR.FOCAL_FWD, 14, i=(nlev,), l=(nb,), p=(arr_f, self.fg_num, FP, ws),
+                  work=4.0 * n_logits + 4.0 * n_labels)
+            arr_b = self._cls_table(self.d_cls_logits)
+            P.add(PR.FOCAL_BWD, 15, i=(nlev, 1), p=(arr_b, self.fg_num, self.one, FP),
+                  work=8.0 * n_logits + 4.0 * n_labels)
+        if supervised:
+            # SelectSmoothL1Loss per level (retinanet_heads.py:268-280) and its gradient
+            tab = (K.SmoothL1Level * nlev)()
+            for l, pred in enumerate(self.bbox_pred):
+                N, Dd, H, W = pred.shape
+                tab[l] = K.SmoothL1Level(pred.data_ptr(), 0, 0, self.bbox_losses[l:l + 1].data_ptr(),
+                                         self.d_bbox_pred[l].data_ptr(), N, Dd, H, W, 0)
+            self._sl1_tables.append(tab)
+            nb = L.ssad_select_smooth_l1_workspace_bytes(nlev)
+            ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            P.add(PR.SMOOTH_L1, 10, i=(nlev, 1), f=(cfg.bbox_reg_beta, cfg.loss_scale * cfg.bbox_reg_weight),
+                  l=(nb,), p=(tab, self.fg_num, self.one, ws),
+                  work=4.0 * sum(x.numel() for x in self.d_bbox_pred),
+                  keep=list(self.bbox_pred) + list(self.d_bbox_pred))
 
-    # -- backward -------------------------------------------------------------------
-    def backward(self, d_bbox_pred):
-        """Backward of both subnets, depth by depth from the prediction layers
-        down.  Per depth: the two weight gradients (each already one workgroup
-        per CU) and ONE data-gradient launch for both towers.  For tower
-        layers the data gradient carries the ReluGradient mask, which is the
-        layer's own post-ReLU input.  Each gradient bucket is all-reduced as
-        soon as its last weight gradient is enqueued."""
-        cfg = self.cfg
+    # -- backward -------------------------------------------------------------------------------
+    def _emit_backward(self, P):
+        """Backward of both subnets, depth by depth from the prediction layers down.  Per depth:
+        the two weight gradients (each already one workgroup per CU) and ONE data-gradient
+        launch for both towers.  For tower layers the data gradient carries the ReluGradient
+        mask, which is the layer's own post-ReLU input.  The program is cut where a gradient
+        bucket is complete (mark "backward_late_done"): its all-reduce is issued there."""
+        cfg, D = self.cfg, self.D
         nl = cfg.num_convs
-        dy = {"cls": self.d_cls_logits, "bbox": d_bbox_pred}
-        # prediction layers (different widths: separate launches)
-        for t in ("cls", "bbox"):
+        dy = {"cls": self.d_cls_logits, "bbox": self.d_bbox_pred}
+        for t, klass_w in (("cls", 6), ("bbox", 7)):
             name = self._layers(t)[-1]
             x_in = self.act[t][nl - 1]
             Cout = self.params[name + "_b"].numel()
-            K.conv3x3_wgrad(x_in, dy[t], Cout, dW=self.grads[name + "_w"], db=self.grads[name + "_b"])
-            dy[t] = K.conv3x3_forward(dy[t], self.packed[name][1], None, self.D, mask_by=x_in,
-                                      out=self.dbuf[t][nl & 1], wino=self._use_wino(self.D))
+            self._emit_wgrad(P, x_in, dy[t], name, Cout, klass_w)
+            out = self.dbuf[t][nl & 1]
+            self._emit_conv(P, [(dy[t], out, x_in, self.packed[name][1], None)], D, Cout, K.CONV_MASK_AUX, 2)
+            dy[t] = out
         for li in range(nl - 1, -1, -1):
             probs = []
             for t in ("cls", "bbox"):
                 name = self._layers(t)[li]
                 x_in = self.act[t][li - 1] if li > 0 else self.fpn_in
-                K.conv3x3_wgrad(x_in, dy[t], self.D, dW=self.grads[name + "_w"],
-                                db=self.grads[name + "_b"])
+                _, arr = self._emit_wgrad(P, x_in, dy[t], name, D, 5)
+                if li == 0:
+                    for l in range(len(x_in)):
+                        self._in_slots.append((arr, l, "student", l))
                 out = self.dbuf[t][li & 1] if li > 0 else self.d_fpn[t]
-                probs.append(dict(xs=dy[t], packed=self.packed[name][1], bias=None, out=out,
-                                  mask_by=x_in if li > 0 else None))
+                probs.append((dy[t], out, x_in if li > 0 else None, self.packed[name][1], None))
                 dy[t] = out
-            K.conv3x3_forward_multi(probs, self.D, wino=self._use_wino(self.D))
+            self._emit_conv(P, probs, D, D, K.CONV_MASK_AUX if li > 0 else 0, 2)
             if li == nl // 2:
-                self._allreduce_async("late")
+                P.mark("backward_late_done")
+        if "backward_late_done" not in P.marks:
+            P.mark("backward_late_done")
+
+    # -- update -----------------------------------------------------------------------------------
+    def _emit_sgd(self, P):
+        specs = self.params.specs
+        tab = (K.SgdSegment * len(specs))()
+        for k, (name, shape, is_bias, _) in enumerate(specs):
+            tab[k] = K.SgdSegment(self.params.offsets[name], int(np.prod(shape)), int(is_bias))
+        P.add(PR.SGD_FLAT, 11, i=(len(specs),), f=(self.momentum, self.weight_decay),
+              p=(self.params.flat, self.grads.flat, self.moms.flat, self.lr, tab, None),
+              work=4.0 * 6 * self.params.flat.numel())
+
+    # -- input binding ------------------------------------------------------------------------------
+    def _bind(self, student_fpn=None, teacher_fpn=None, labels=None, bbox_targets=None, fg_num=None):
+        """Point the program at this step's input tensors (they belong to the caller and may
+        move between steps); only entries whose address changed are rewritten."""
+        if student_fpn is not None or teacher_fpn is not None:
+            s = list(student_fpn) if student_fpn is not None else self.fpn_in
+            t = list(teacher_fpn) if teacher_fpn is not None else self.t_fpn_in
+            dev_type = torch.device(self.device).type
+            for x in list(s) + list(t if self.distill else []):
+                if x.dtype != torch.float32 or not x.is_contiguous() or x.device.type != dev_type:
+                    raise K.KernelError("FPN levels must be contiguous float32 tensors on %s" % dev_type)
+            if any(tuple(a.shape) != tuple(b.shape) for a, b in zip(s, self.fpn_in)):
+                raise K.KernelError("FPN levels do not match the shapes this pipeline was built for")
+            self._rebind_inputs(s, t)
+            self.fpn_in, self.t_fpn_in = s, t
+            self._bound_in = (s, t)                     # keep the tensors alive
+        if labels is not None:
+            for l, g in enumerate(labels):
+                if g.dtype != torch.int32 or not g.is_contiguous() or tuple(g.shape) != tuple(self.labels[l].shape):
+                    raise K.KernelError("labels[%d] must be contiguous int32 %r" % (l, tuple(self.labels[l].shape)))
+            for arr in self._label_tables:
+                for l, g in enumerate(labels):
+                    arr[l].labels = g.data_ptr()
+            self.labels = list(labels)
+        if fg_num is not None:
+            self.fg_num.copy_(fg_num.reshape(1), non_blocking=True)
+        if bbox_targets is not None:
+            for tab in self._sl1_tables:
+                for l, (Y, Lc) in enumerate(bbox_targets):
+                    M = Y.shape[0] if Y.numel() else 0
+                    if M:
+                        K._f32c(Y, "Y"); K._f32c(Lc, "L")
+                        if tuple(Y.shape) != (M, 4) or tuple(Lc.shape) != (M, 4):
+                            raise K.KernelError("bbox targets must be (Y [M,4], L [M,4])")
+                    tab[l].Y = Y.data_ptr() if M else 0
+                    tab[l].L = Lc.data_ptr() if M else 0
+                    tab[l].M = M
+            self._bound_targets = bbox_targets
+
+    def _rebind_inputs(self, s, t):
+        for arr, k, who, l in self._in_slots:
+            arr[k].x = (s if who == "student" else t)[l].data_ptr()
+
+    # -- segments (the names the full model drives) ---------------------------------------------------
+    def pack_student(self, want_dgrad=True):
+        self.prog.run("pack", "forward", timing=self.timing)
+
+    def pack_teacher(self):
+        """The teacher is frozen: packed once (and again after its weights are loaded)."""
+        if self.distill:
+            self.prog_teacher_pack.run()
+            self._teacher_packed = True
+
+    def forward_all(self, teacher_fpn, student_fpn):
+        if self.distill and not self._teacher_packed:
+            self.pack_teacher()
+        self._bind(student_fpn=student_fpn, teacher_fpn=teacher_fpn if self.distill else None)
+        self.prog.run("forward", "losses", timing=self.timing)
+        return self.cls_logits, self.bbox_pred
+
+    def cls_losses(self, labels, fg_num):
+        """With bbox_losses_fwd_bwd: the full reference loss set (kept as two calls for the
+        full model's driver; both run in the one "losses" segment)."""
+        self._pending_labels, self._pending_fg = labels, fg_num
+        return self.losses, self.focal_losses
+
+    def bbox_losses_fwd_bwd(self, bbox_targets, fg_num):
+        self._bind(labels=self._pending_labels, bbox_targets=bbox_targets, fg_num=fg_num)
+        self.prog.run("losses", "backward", timing=self.timing)
+        return self.d_bbox_pred
+
+    def distill_loss(self, labels):
+        """Distillation loss only (forward + gradient w.r.t. the logits)."""
+        self._bind(labels=labels)
+        self.prog_distill_only.run(timing=self.timing)
+        return self.losses
+
+    def backward(self, d_bbox_pred=None):
+        if d_bbox_pred is not None and d_bbox_pred is not self.d_bbox_pred:
+            for dst, src in zip(self.d_bbox_pred, d_bbox_pred):
+                dst.copy_(src)
+        self.prog.run("backward", "backward_late_done", timing=self.timing)
+        self._allreduce_async("late")
+        self.prog.run("backward_late_done", "sgd", timing=self.timing)
         self._allreduce_async("early")
         return self.d_fpn
 
@@ -305,7 +558,6 @@ class DistillHeads(object):
         """Initial parameter sync (detectron/lib/utils/net.py:185-208)."""
         self.dp.broadcast([self.params.flat, self.moms.flat], src=src)
 
-    # -- update -------------------------------------------------------------------------
     # -- learning rate (detector.py:594-648) ------------------------------------------
     SCALE_MOMENTUM = True             # cfg.SOLVER.SCALE_MOMENTUM (config.py:634)
     SCALE_MOMENTUM_THRESHOLD = 1.1    # config.py:638
@@ -327,23 +579,24 @@ class DistillHeads(object):
         return new_lr
 
     def sgd_step(self):
+        """Wait for the reduced gradients, then the whole model's update in one launch."""
         self.wait_gradients()
-        for name, _, is_bias, _ in self.params.specs:
-            K.momentum_sgd_update_(self.params[name], self.grads[name], self.moms[name], self.lr,
-                                   self.momentum, self.weight_decay, is_bias)
+        self.prog.run("sgd", "end", timing=self.timing)
 
     # -- one iteration --------------------------------------------------------------------
     def step(self, student_fpn, teacher_fpn, labels, d_bbox_pred=None, update=True,
              bbox_targets=None, fg_num=None):
-        """One iteration.  With `bbox_targets` and `fg_num` the student's
-        supervised losses are part of the step (the full reference graph);
-        without them only the distillation loss drives the cls subnet and
-        `d_bbox_pred` must supply the box-subnet gradient."""
+        """One iteration.  With `bbox_targets` and `fg_num` the student's supervised losses are
+        part of the step (the full reference graph); without them only the distillation loss
+        drives the cls subnet and `d_bbox_pred` must supply the box-subnet gradient."""
+        if bbox_targets is None and not self.distill:
+            raise K.KernelError("student-only training needs bbox_targets and fg_num")
         self.pack_student()
         self.forward_all(teacher_fpn, student_fpn)
         if bbox_targets is not None:
             self.cls_losses(labels, fg_num)
-            d_bbox_pred = self.bbox_losses_fwd_bwd(bbox_targets, fg_num)
+            self.bbox_losses_fwd_bwd(bbox_targets, fg_num)
+            d_bbox_pred = None
         else:
             self.distill_loss(labels)
         self.backward(d_bbox_pred)
@@ -361,11 +614,20 @@ class DistillHeadsF16(DistillHeads):
     arrangement: fp32 master parameters, momentum and parameter gradients (FlatParams, SGD and
     the all-reduce are unchanged); filters re-rounded to fp16 every step; activations between
     the layers channel-blocked fp16; prediction layers write NCHW fp32 for the fp32 loss
-    kernels; the gradient of the logits is multiplied by LOSS_SCALE before it is rounded to
+    kernels; the gradient of the logits is multiplied by a loss scale before it is rounded to
     fp16 (its elements are ~1e-6) and every result leaving the fp16 domain -- filter / bias
-    gradients, the gradient w.r.t. the FPN levels -- is divided by it again."""
+    gradients, the gradient w.r.t. the FPN levels -- is divided by it again.
 
-    LOSS_SCALE = 8192.0
+    The loss scale is DYNAMIC and lives on the device (ssad_loss_scale_update): after the
+    gradient all-reduce one pass checks the flat fp32 gradient buffer for Inf / NaN; on
+    overflow the SGD launch drops the step (every rank sees the same reduced buffer, so all
+    ranks drop it together) and the scale is halved, after LOSS_SCALE_GROWTH_INTERVAL clean
+    steps it is doubled.  Nothing of this visits the host."""
+
+    F16 = True
+    LOSS_SCALE = 8192.0                 # initial value
+    LOSS_SCALE_GROWTH_INTERVAL = 2000
+    LOSS_SCALE_MIN, LOSS_SCALE_MAX = 1.0, 65536.0
 
     def _blk(self, ch):
         return [torch.empty((self.N, (ch + 7) // 8, h, w, 8), dtype=torch.float16, device=self.device)
@@ -373,95 +635,179 @@ class DistillHeadsF16(DistillHeads):
 
     def _alloc_buffers(self):
         cfg, lv, blk, D = self.cfg, self._lv, self._blk, self.D
+        self.fpn_in = lv(D)
+        self.t_fpn_in = self.fpn_in
+        self.labels = [torch.zeros((self.N, self.A, h, w), dtype=torch.int32, device=self.device)
+                       for (h, w) in self.shapes]
         self.act = {t: [blk(D) for _ in range(cfg.num_convs)] for t in ("cls", "bbox")}
         self.cls_logits, self.bbox_pred = lv(self.A * self.C), lv(4 * self.A)
         self.d_cls_logits, self.d_bbox_pred = lv(self.A * self.C), lv(4 * self.A)
         self.dy_pred = {"cls": blk(self.A * self.C), "bbox": blk(4 * self.A)}
         self.dbuf = {"cls": [blk(D), blk(D)], "bbox": [blk(D), blk(D)]}
         self.d_fpn = {t: lv(D) for t in ("cls", "bbox")}
-        self.t_buf = {"cls": [blk(D), blk(D)], "bbox": [blk(D), blk(D)]}
-        self.in_blk = {"student": blk(D), "teacher": blk(D)}
-        self.t_prob = lv(self.A * self.C)
-        self.t_bbox = lv(4 * self.A) if self.teacher_bbox_tower else None
-        self.packed = {}
-        self.t_packed = None
-        self.losses = None
-        self.normalizer = None
+        self.in_blk = {"student": blk(D)}
+        if self.distill:
+            self.in_blk["teacher"] = blk(D)
+            self.t_buf = {"cls": [blk(D), blk(D)], "bbox": [blk(D), blk(D)]}
+            self.t_prob = lv(self.A * self.C)
+            self.t_bbox = lv(4 * self.A) if self.teacher_bbox_tower else None
+        # {scale, 1/scale} and {overflow flag, clean steps}
+        self.ls_state = torch.tensor([self.LOSS_SCALE, 1.0 / self.LOSS_SCALE], dtype=torch.float32,
+                                     device=self.device)
+        self.ls_counters = torch.zeros(2, dtype=torch.int32, device=self.device)
 
-    def _pack(self, w, want_fwd, want_dgrad):
-        return K.f16_pack_filter(w, want_fwd, want_dgrad)
+    @property
+    def loss_scale(self):
+        return float(self.ls_state[0])
 
-    def forward_all(self, teacher_fpn, student_fpn):
-        if self.t_packed is None:
-            self.pack_teacher()
+    def _alloc_packed(self, params, want_dgrad):
+        packed, ops = {}, []
+        for tower in ("cls", "bbox"):
+            for name in self._layers(tower):
+                w = params[name + "_w"]
+                M, Cc = w.shape[0], w.shape[1]
+                n = K.lib().ssad_f16_filter_halves(M, Cc)
+                wf = torch.empty(n, dtype=torch.float16, device=self.device)
+                wd = torch.empty(n, dtype=torch.float16, device=self.device) if want_dgrad else None
+                packed[name] = (wf, wd)
+                ops.append((w, M, Cc, wf, wd))
+        return packed, ops, []
+
+    def _emit_pack(self, P, entries, direct):
+        for w, M, Cc, wf, wd in entries:
+            P.add(PR.F16_PACK_FILTER, 33, i=(M, Cc), p=(w, wf, wd),
+                  work=4.0 * w.numel() + 2.0 * (wf.numel() + (wd.numel() if wd is not None else 0)))
+
+    def _f16_table(self, problems):
+        """problems: [(xs, outs, masks or None, packed or None, bias or None)] -> ssad_f16_level[]"""
+        n = sum(len(p[0]) for p in problems)
+        arr = (K.F16Level * n)()
+        k = 0
+        for xs, outs, masks, packed, bias in problems:
+            for l, xb in enumerate(xs):
+                arr[k].x, arr[k].y = xb.data_ptr(), outs[l].data_ptr()
+                arr[k].aux = masks[l].data_ptr() if masks is not None else None
+                arr[k].N, arr[k].H, arr[k].W = xb.shape[0], xb.shape[2], xb.shape[3]
+                arr[k].packed = packed.data_ptr() if packed is not None else None
+                arr[k].bias = bias.data_ptr() if bias is not None else None
+                k += 1
+        return arr
+
+    def _emit_conv16(self, P, problems, Cin, Cout, flags, klass):
+        arr = self._f16_table(problems)
+        px = sum(x.shape[0] * x.shape[2] * x.shape[3] for p in problems for x in p[0])
+        P.add(PR.F16_CONV3X3, klass, i=(len(arr), Cin, Cout, flags), p=(arr, None, None),
+              work=2.0 * 9 * Cout * Cin * px,
+              keep=[t for p in problems for t in (list(p[0]) + list(p[1]) + list(p[2] or []))] +
+                   [t for p in problems for t in p[3:] if t is not None])
+
+    def _emit_forward(self, P):
         cfg, D = self.cfg, self.D
-        for x, xb in zip(student_fpn, self.in_blk["student"]):
-            K.f16_pack_activations(x, out=xb)
-        for x, xb in zip(teacher_fpn, self.in_blk["teacher"]):
-            K.f16_pack_activations(x, out=xb)
-        self.fpn_in = self.in_blk["student"]
-        tx = {"cls": self.in_blk["teacher"], "bbox": self.in_blk["teacher"]}
-        sx = {"cls": self.fpn_in, "bbox": self.fpn_in}
-        F = K.conv3x3_forward_f16_levels          # all five levels of a layer in one launch
+        AC, A4 = self.A * self.C, 4 * self.A
+        self._in_ops = []
+        act_bytes = lambda x: 6.0 * x.numel()
+        for who in ("student", "teacher") if self.distill else ("student",):
+            src = self.fpn_in if who == "student" else self.t_fpn_in
+            for l, (x, xb) in enumerate(zip(src, self.in_blk[who])):
+                idx = P.add(PR.F16_PACK_ACT, 32, i=(x.shape[0], x.shape[1], x.shape[2], x.shape[3]), f=(1.0,),
+                            p=(x, None, xb), work=act_bytes(x))
+                self._in_ops.append((idx, who, l))
+        tx = {"cls": self.in_blk.get("teacher"), "bbox": self.in_blk.get("teacher")}
+        sx = {"cls": self.in_blk["student"], "bbox": self.in_blk["student"]}
         for i in range(cfg.num_convs):
-            # the four tower layers of equal depth (teacher / student x cls / bbox) are independent
-            # convolutions of one shape: ONE launch of 20 (level, filter) problems, as on the fp32 path
+            # the tower layers of equal depth (teacher / student x cls / bbox) are independent
+            # convolutions of one shape: ONE launch of up to 20 (level, filter) problems
             probs = []
             for t in ("cls", "bbox"):
                 name = self._layers(t)[i]
-                if t == "cls" or self.teacher_bbox_tower:
+                if self.distill and (t == "cls" or self.teacher_bbox_tower):
                     out = self.t_buf[t][i & 1]
-                    probs.append(dict(xs=tx[t], packed=self.t_packed[name], bias=self.teacher[name + "_b"],
-                                      out=out))
+                    probs.append((tx[t], out, None, self.t_packed_for(name), self.teacher[name + "_b"]))
                     tx[t] = out
                 out = self.act[t][i]
-                probs.append(dict(xs=sx[t], packed=self.packed[name][0], bias=self.params[name + "_b"],
-                                  out=out))
+                probs.append((sx[t], out, None, self.packed[name][0], self.params[name + "_b"]))
                 sx[t] = out
-            K.conv3x3_forward_f16_multi(probs, D, D, relu=True)
+            self._emit_conv16(P, probs, D, D, K.CONV_RELU, 34)
         cp, bp = self._layers("cls")[-1], self._layers("bbox")[-1]
-        AC, A4 = self.A * self.C, 4 * self.A
-        F(tx["cls"], self.t_packed[cp], self.teacher[cp + "_b"], D, AC, self.t_prob, sigmoid=True,
-          out_nchw_f32=True)
-        F(sx["cls"], self.packed[cp][0], self.params[cp + "_b"], D, AC, self.cls_logits, out_nchw_f32=True)
-        F(sx["bbox"], self.packed[bp][0], self.params[bp + "_b"], D, A4, self.bbox_pred, out_nchw_f32=True)
+        F32 = K.F16_OUT_NCHW_F32
+        if self.distill:
+            self._emit_conv16(P, [(tx["cls"], self.t_prob, None, self.t_packed_for(cp), self.teacher[cp + "_b"])],
+                              D, AC, K.CONV_SIGMOID | F32, 35)
+        self._emit_conv16(P, [(sx["cls"], self.cls_logits, None, self.packed[cp][0], self.params[cp + "_b"])],
+                          D, AC, F32, 35)
+        self._emit_conv16(P, [(sx["bbox"], self.bbox_pred, None, self.packed[bp][0], self.params[bp + "_b"])],
+                          D, A4, F32, 36)
         if self.teacher_bbox_tower:
-            F(tx["bbox"], self.t_packed[bp], self.teacher[bp + "_b"], D, A4, self.t_bbox, out_nchw_f32=True)
-        return self.cls_logits, self.bbox_pred
+            self._emit_conv16(P, [(tx["bbox"], self.t_bbox, None, self.t_packed_for(bp), self.teacher[bp + "_b"])],
+                              D, A4, F32, 36)
 
-    def backward(self, d_bbox_pred):
-        cfg, D, S = self.cfg, self.D, self.LOSS_SCALE
+    def _emit_wgrad16(self, P, xbs, dybs, name, Cin, Cout):
+        n = len(xbs)
+        arr = (K.F16WgradLevel * n)()
+        for l, (xb, dyb) in enumerate(zip(xbs, dybs)):
+            arr[l].x, arr[l].dy = xb.data_ptr(), dyb.data_ptr()
+            arr[l].N, arr[l].H, arr[l].W = xb.shape[0], xb.shape[2], xb.shape[3]
+        nb = K.lib().ssad_conv3x3_wgrad_f16_levels_workspace_bytes(arr, n, Cin, Cout)
+        self._wgrad_ws_need = max(self._wgrad_ws_need, nb)
+        px = sum(x.shape[0] * x.shape[2] * x.shape[3] for x in xbs)
+        idx = P.add(PR.F16_WGRAD, 37, i=(n, Cin, Cout, 0), f=(1.0,), l=(nb,),
+                    p=(arr, self.ls_state[1:2], self.grads[name + "_w"], self.grads[name + "_b"], None),
+                    work=2.0 * 9 * Cout * Cin * px, keep=list(xbs) + list(dybs))
+        self._wgrad_ops.append(idx)
+
+    def _finish_workspaces(self, P):
+        self.wgrad_ws = torch.empty(max(self._wgrad_ws_need, 16), dtype=torch.uint8, device=self.device)
+        for idx in self._wgrad_ops:
+            P.set_ptr(idx, 4, self.wgrad_ws)
+
+    def _emit_backward(self, P):
+        cfg, D = self.cfg, self.D
         nl, nlev = cfg.num_convs, len(self.shapes)
+        S, Sinv = self.ls_state[0:1], self.ls_state[1:2]
         dy = {}
-        for t, src in (("cls", self.d_cls_logits), ("bbox", d_bbox_pred)):
+        for t, src in (("cls", self.d_cls_logits), ("bbox", self.d_bbox_pred)):
             for l in range(nlev):
-                K.f16_pack_activations(src[l], scale=S, out=self.dy_pred[t][l])
+                x = src[l]
+                P.add(PR.F16_PACK_ACT, 32, i=tuple(x.shape), f=(1.0,), p=(x, S, self.dy_pred[t][l]),
+                      work=6.0 * x.numel())
             dy[t] = self.dy_pred[t]
-        for t in ("cls", "bbox"):
+        for t, klass in (("cls", 35), ("bbox", 36)):
             name = self._layers(t)[-1]
             x_in = self.act[t][nl - 1]
             Cout = self.params[name + "_b"].numel()
-            K.conv3x3_wgrad_f16(x_in, dy[t], D, Cout, scale=1.0 / S, dW=self.grads[name + "_w"],
-                                db=self.grads[name + "_b"])
+            self._emit_wgrad16(P, x_in, dy[t], name, D, Cout)
             out = self.dbuf[t][nl & 1]
-            K.conv3x3_forward_f16_levels(dy[t], self.packed[name][1], None, Cout, D, out, mask_bys=x_in)
+            self._emit_conv16(P, [(dy[t], out, x_in, self.packed[name][1], None)], Cout, D,
+                              K.CONV_MASK_AUX, klass)
             dy[t] = out
         for li in range(nl - 1, -1, -1):
             probs = []
             for t in ("cls", "bbox"):
                 name = self._layers(t)[li]
-                x_in = self.act[t][li - 1] if li > 0 else self.fpn_in
-                K.conv3x3_wgrad_f16(x_in, dy[t], D, D, scale=1.0 / S, dW=self.grads[name + "_w"],
-                                    db=self.grads[name + "_b"])
+                x_in = self.act[t][li - 1] if li > 0 else self.in_blk["student"]
+                self._emit_wgrad16(P, x_in, dy[t], name, D, D)
                 out = self.dbuf[t][li & 1]
-                probs.append(dict(xs=dy[t], packed=self.packed[name][1], bias=None, out=out,
-                                  mask_by=x_in if li > 0 else None))
+                probs.append((dy[t], out, x_in if li > 0 else None, self.packed[name][1], None))
                 dy[t] = out
-            K.conv3x3_forward_f16_multi(probs, D, D)      # both towers' data gradients: one launch
+            self._emit_conv16(P, probs, D, D, K.CONV_MASK_AUX if li > 0 else 0, 34)
             if li == nl // 2:
-                self._allreduce_async("late")
+                P.mark("backward_late_done")
         for t in ("cls", "bbox"):
             for l in range(nlev):
-                K.f16_unpack_activations(dy[t][l], D, scale=1.0 / S, out=self.d_fpn[t][l])
-        self._allreduce_async("early")
-        return self.d_fpn
+                xb, x = dy[t][l], self.d_fpn[t][l]
+                P.add(PR.F16_UNPACK_ACT, 32, i=tuple(x.shape), f=(1.0,), p=(xb, Sinv, x), work=6.0 * x.numel())
+        if "backward_late_done" not in P.marks:
+            P.mark("backward_late_done")
+
+    def _emit_sgd(self, P):
+        n = self.grads.flat.numel()
+        P.add(PR.CHECK_FINITE, 38, l=(n,), p=(self.grads.flat, self.ls_counters), work=4.0 * n)
+        idx = len(P.ops)
+        DistillHeads._emit_sgd(self, P)
+        P.set_ptr(idx, 5, self.ls_counters)            # the update is skipped on overflow
+        P.add(PR.LOSS_SCALE_UPDATE, 38, i=(self.LOSS_SCALE_GROWTH_INTERVAL,),
+              f=(2.0, 0.5, self.LOSS_SCALE_MIN, self.LOSS_SCALE_MAX), p=(self.ls_state, self.ls_counters))
+
+    def _rebind_inputs(self, s, t):
+        for idx, who, l in self._in_ops:
+            self.prog.set_ptr(idx, 0, (s if who == "student" else t)[l])

@@ -41,6 +41,21 @@ class DistillLevel(C.Structure):
                 ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int)]
 
 
+class SmoothL1Level(C.Structure):
+    _fields_ = [("Y_hat", C.c_void_p), ("Y", C.c_void_p), ("L", C.c_void_p), ("loss", C.c_void_p),
+                ("dY_hat", C.c_void_p), ("N", C.c_int), ("D", C.c_int), ("H", C.c_int),
+                ("W", C.c_int), ("M", C.c_int)]
+
+
+class PackEntry(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("Cout", C.c_int), ("Cin", C.c_int), ("packed_fwd", C.c_void_p),
+                ("packed_dgrad", C.c_void_p)]
+
+
+class SgdSegment(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("n", C.c_int64), ("is_bias", C.c_int)]
+
+
 class ConvLevel(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("aux", C.c_void_p),
                 ("N", C.c_int), ("H", C.c_int), ("W", C.c_int),
@@ -86,8 +101,12 @@ def lib():
     L.ssad_cls_losses_fused.argtypes = [
         C.POINTER(DistillLevel), i32, vp, vp, C.POINTER(DistillParams), C.POINTER(FocalParams),
         vp, vp, vp, sz, vp]
+    L.ssad_select_smooth_l1_workspace_bytes.restype = sz
+    L.ssad_select_smooth_l1_workspace_bytes.argtypes = [i32]
     L.ssad_select_smooth_l1_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32,
-                                                vp, vp]
+                                                vp, vp, sz, vp]
+    L.ssad_select_smooth_l1_levels.argtypes = [C.POINTER(SmoothL1Level), i32, vp, vp, f32, f32, i32,
+                                               vp, sz, vp]
     L.ssad_select_smooth_l1_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32,
                                                  f32, vp, vp]
     L.ssad_fill.argtypes = [vp, f32, i64, vp]
@@ -121,6 +140,10 @@ def lib():
     L.ssad_conv3x3_wgrad_f16_levels.argtypes = [C.POINTER(F16WgradLevel), i32, i32, i32, i32, f32, vp, vp,
                                                 vp, sz, vp]
     L.ssad_momentum_sgd_update.argtypes = [vp, vp, vp, vp, f32, f32, i32, i64, vp]
+    L.ssad_momentum_sgd_flat.argtypes = [vp, vp, vp, vp, f32, f32, C.POINTER(SgdSegment), i32, vp, vp]
+    L.ssad_check_finite.argtypes = [vp, i64, vp, vp]
+    L.ssad_loss_scale_update.argtypes = [vp, vp, f32, f32, i32, f32, f32, vp]
+    L.ssad_conv_wino_pack_filters.argtypes = [C.POINTER(PackEntry), i32, vp]
     L.ssad_conv_packed_filter_floats.restype = sz
     L.ssad_conv_packed_filter_floats.argtypes = [i32, i32]
     L.ssad_conv_pack_filter.argtypes = [vp, i32, i32, vp, vp, vp]
@@ -181,11 +204,15 @@ def _distill_levels(levels, outs):
         _f32c(x, "logits")
         if q is not None:
             _f32c(q, "teacher_prob")
-        if g.dtype != torch.int32 or not g.is_contiguous():
-            raise KernelError("labels must be contiguous int32")
+        if g.dtype != torch.int32 or not g.is_contiguous() or not g.is_cuda:
+            raise KernelError("labels must be a contiguous int32 device tensor")
         if x.dim() != 4 or (q is not None and q.shape != x.shape):
             raise KernelError("logits/teacher must be 4-D and equal-shaped")
         N, D, H, W = x.shape
+        if g.dim() != 4 or g.shape[0] != N or tuple(g.shape[2:]) != (H, W) or g.shape[1] == 0 \
+                or D % g.shape[1] != 0:
+            raise KernelError("labels must be N x A x H x W with A dividing the logits' channels, "
+                              "got %r for logits %r" % (tuple(g.shape), tuple(x.shape)))
         arr[i] = DistillLevel(x.data_ptr(), q.data_ptr() if q is not None else 0, g.data_ptr(),
                               o.data_ptr(), N, D, H, W)
     return arr
@@ -280,10 +307,52 @@ def select_smooth_l1_forward(Y_hat, Y, Lc, S, *, beta=1.0, scale=1.0):
     if M == 0:
         return out
     N, D, H, W = Y_hat.shape
+    nb = lib().ssad_select_smooth_l1_workspace_bytes(1)
+    ws = _workspace(nb, "smoothl1")
     _check(lib().ssad_select_smooth_l1_forward(
         _ptr(_f32c(Y_hat, "Y_hat")), _ptr(_f32c(Y, "Y")), _ptr(_f32c(Lc, "L")), _ptr(S), N, D, H,
-        W, M, beta, scale, _ptr(out), _stream()), "select_smooth_l1_forward")
+        W, M, beta, scale, _ptr(out), _ptr(ws), nb, _stream()), "select_smooth_l1_forward")
     return out
+
+
+def smooth_l1_levels_array(preds, targets, losses, d_preds):
+    """ctypes level table of ssad_select_smooth_l1_levels: preds [N,D,H,W] per level, targets
+    [(Y [M,4], L [M,4])], losses a float32 [n_levels] tensor (or None), d_preds per-level
+    gradients (or None)."""
+    n = len(preds)
+    arr = (SmoothL1Level * n)()
+    for i, (p, (Y, Lc)) in enumerate(zip(preds, targets)):
+        _f32c(p, "Y_hat")
+        M = Y.shape[0] if Y.numel() else 0
+        if M:
+            _f32c(Y, "Y"); _f32c(Lc, "L")
+            if tuple(Lc.shape) != (M, 4) or tuple(Y.shape) != (M, 4):
+                raise KernelError("Y and L must be [M, 4]")
+        N, D, H, W = p.shape
+        if d_preds is not None and d_preds[i].shape != p.shape:
+            raise KernelError("gradient must have the prediction's shape")
+        arr[i] = SmoothL1Level(p.data_ptr(), Y.data_ptr() if M else 0, Lc.data_ptr() if M else 0,
+                               losses[i:i + 1].data_ptr() if losses is not None else 0,
+                               _f32c(d_preds[i], "dY_hat").data_ptr() if d_preds is not None else 0,
+                               N, D, H, W, M)
+    return arr
+
+
+def select_smooth_l1_levels(preds, targets, S, dloss=None, *, beta=1.0, scale=1.0, losses=None,
+                            d_preds=None):
+    """SelectSmoothL1Loss of every FPN level in one launch sequence: losses [n_levels] and, with
+    dloss (device scalar), the full gradients d_preds (zero filled here)."""
+    n = len(preds)
+    if losses is None:
+        losses = torch.empty(n, dtype=torch.float32, device="cuda")
+    if dloss is not None and d_preds is None:
+        d_preds = [torch.empty_like(p) for p in preds]
+    arr = smooth_l1_levels_array(preds, targets, losses, d_preds if dloss is not None else None)
+    nb = lib().ssad_select_smooth_l1_workspace_bytes(n)
+    ws = _workspace(nb, "smoothl1")
+    _check(lib().ssad_select_smooth_l1_levels(arr, n, _ptr(S), _ptr(dloss), beta, scale, 1, _ptr(ws), nb,
+                                              _stream()), "select_smooth_l1_levels")
+    return losses, d_preds
 
 
 def select_smooth_l1_backward(Y_hat, Y, Lc, S, dloss, *, beta=1.0, scale=1.0, out=None):

@@ -75,11 +75,13 @@ def initialize_from_weights_file(store, weights_file, teacher_weights_file=None)
             missing.append(name)
             continue
         used.add(name)
-        if _feed(store.params, name, src[name]):
-            loaded.append(name)
         mname = name + "_momentum"
         if mname in src:
             used.add(mname)
+        if not _feed(store.params, name, src[name]):
+            continue            # net.py:106-109: a mismatching blob is skipped, momentum included
+        loaded.append(name)
+        if mname in src:
             _feed(store.moms, name, src[mname])
     for name, _, _, _ in store.teacher.specs:
         tname = "teacher/" + name
@@ -111,6 +113,13 @@ def save_model_to_weights_file(weights_file, store, cfg_yaml=""):
         blobs[name] = store.params[name].detach().cpu().numpy().copy()
     for name, _, _, _ in store.params.specs:
         blobs[name + "_momentum"] = store.moms[name].detach().cpu().numpy().copy()
+    # the reference saves every blob of model.params, the teacher/ scope included (net.py:145-152
+    # walks model.params, which holds the teacher's parameters in a distillation model), so a
+    # file written here resumes distillation without the separate teacher file
+    teacher = getattr(store, "teacher", None)
+    if teacher is not None and getattr(store, "distill", True):
+        for name, _, _, _ in teacher.specs:
+            blobs["teacher/" + name] = teacher[name].detach().cpu().numpy().copy()
     for k, v in getattr(store, "preserved", {}).items():
         if k not in blobs:
             blobs[k] = v

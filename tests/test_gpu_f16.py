@@ -284,3 +284,106 @@ def test_f16_kernels_random_geometries(K, seed):
             want_dw[:, :, ky, kx] = np.einsum("nmhw,nchw->mc", dyr, xp[:, :, ky:ky + H, kx:kx + W])
     assert np.abs(dW.cpu().numpy() - want_dw).max() <= 3e-5 * max(np.abs(want_dw).max(), 1e-6), (N, C, M, H, W)
     assert np.abs(db.cpu().numpy() - dyr.sum((0, 2, 3))).max() <= 3e-5 * max(np.abs(dyr.sum((0, 2, 3))).max(), 1e-6)
+
+
+def test_f16_config5_level_shapes_bs16(K):
+    """BASELINE config 5's own workload: 500 px -> 3x512x768 -> levels 64x96, 32x48, 16x24, 8x12,
+    4x6 at bs 16, all five levels of a tower layer in one launch (forward, data gradient) and one
+    filter-gradient launch.  Checked by the three adjoint identities over the whole batch and, per
+    level, one image against float64 on the same fp16-rounded operands; the filter gradient by
+    linearity with only that image's dy non-zero."""
+    from ssad_amd import synth
+    torch.manual_seed(55)
+    N, C, M = 16, 256, 256
+    shapes = synth.LEVEL_SHAPES_500
+    w = torch.randn(M, C, 3, 3, device="cuda") * 0.02
+    wf, wd = K.f16_pack_filter(w, True, True)
+    w16 = w.half().double().cpu().numpy()
+    xs = [torch.randn(N, C, h, ww, device="cuda") for h, ww in shapes]
+    dys = [torch.randn(N, M, h, ww, device="cuda") for h, ww in shapes]
+    xb = [K.f16_pack_activations(x) for x in xs]
+    dyb = [K.f16_pack_activations(d) for d in dys]
+    yb = [torch.empty((N, M // 8, h, ww, 8), dtype=torch.float16, device="cuda") for h, ww in shapes]
+    dxb = [torch.empty((N, C // 8, h, ww, 8), dtype=torch.float16, device="cuda") for h, ww in shapes]
+    K.conv3x3_forward_f16_levels(xb, wf, None, C, M, yb)
+    K.conv3x3_forward_f16_levels(dyb, wd, None, M, C, dxb)
+    dW, _ = K.conv3x3_wgrad_f16(xb, dyb, C, M)
+    un = K.f16_unpack_activations
+    s1 = sum(float((un(y, M).double() * un(d, M).double()).sum()) for y, d in zip(yb, dyb))
+    s2 = sum(float((un(x, C).double() * un(dx, C).double()).sum()) for x, dx in zip(xb, dxb))
+    s3 = float((dW.double() * w.half().double()).sum())
+    rss = float(sum((un(y, M).double() ** 2).sum() for y in yb) ** 0.5 *
+                sum((d.double() ** 2).sum() for d in dys) ** 0.5)
+    scale = max(abs(s1), abs(s2), abs(s3), 1e-3 * rss)
+    assert abs(s1 - s2) <= 2e-3 * scale and abs(s1 - s3) <= 2e-3 * scale, (s1, s2, s3)
+    n0 = 9
+    wt = np.ascontiguousarray(w16[:, :, ::-1, ::-1].transpose(1, 0, 2, 3))
+    for l in (0, 2, 4):              # P3 (largest), P5, P7 (a 4 x 6 map: one ragged tile)
+        x1 = un(xb[l], C)[n0:n0 + 1].double().cpu().numpy()           # the fp16-rounded operands
+        d1 = un(dyb[l], M)[n0:n0 + 1].double().cpu().numpy()
+        want = _conv64(x1, w16, None)
+        got = un(yb[l], M)[n0:n0 + 1].double().cpu().numpy()
+        assert np.abs(got - want).max() <= 6e-4 * np.abs(want).max(), ("fwd", l)
+        want = _conv64(d1, wt, None)
+        got = un(dxb[l], C)[n0:n0 + 1].double().cpu().numpy()
+        assert np.abs(got - want).max() <= 6e-4 * np.abs(want).max(), ("dgrad", l)
+    # filter gradient, all five levels in the launch, only image n0 of P4 contributing
+    l = 1
+    zeros = [torch.zeros_like(d) for d in dyb]
+    zeros[l][n0].copy_(dyb[l][n0])
+    dW1, db1 = K.conv3x3_wgrad_f16(xb, zeros, C, M)
+    x1 = un(xb[l], C)[n0].double().cpu().numpy()
+    d1 = un(dyb[l], M)[n0].double().cpu().numpy()
+    h, ww = shapes[l]
+    xp = np.zeros((C, h + 2, ww + 2))
+    xp[:, 1:-1, 1:-1] = x1
+    want = np.zeros((M, C, 3, 3))
+    for ky in range(3):
+        for kx in range(3):
+            want[:, :, ky, kx] = np.einsum("mhw,chw->mc", d1, xp[:, ky:ky + h, kx:kx + ww])
+    assert np.abs(dW1.double().cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max()
+    assert np.abs(db1.double().cpu().numpy() - d1.sum((1, 2))).max() <= 2e-5 * np.abs(d1.sum((1, 2))).max()
+
+
+def test_f16_dynamic_loss_scale_drops_overflowing_steps(K):
+    """Mixed-precision safety: when the scaled gradient overflows fp16 the flat fp32 gradient
+    buffer turns non-finite; the step must then leave parameters and momentum untouched and
+    halve the loss scale -- on the device, with no host round trip -- and a following clean step
+    must update normally.  (A fixed scale would write Inf/NaN into the master weights.)"""
+    from ssad_amd import synth
+    from ssad_amd.head_pipeline import DistillHeadsF16
+    from ssad_amd.modeling import retinanet_heads as rh
+    rng = np.random.default_rng(5)
+    shapes = [(10, 14), (5, 7)]
+    N = 2
+    cfg = rh.HeadConfig(num_gpus=1)
+    S, T = synth.head_params(rng), synth.head_params(rng)
+    fs, ft = synth.fpn_features(rng, N, shapes), synth.fpn_features(rng, N, shapes)
+    labs = [synth.distill_inputs(rng, N, 9, 80, h, w)[2] for h, w in shapes]
+    tg = [synth.bbox_targets(rng, l) for l in labs]
+    dev = torch.device("cuda", 0)
+    t = lambda arrs: [torch.from_numpy(a).to(dev) for a in arrs]
+    h = DistillHeadsF16(cfg, N=N, shapes=shapes, device=dev, student_init=S, teacher_init=T, lr=0.01)
+    assert h.loss_scale == 8192.0
+    # fg_num = 1e-3 is clamped to 1 by the losses: gradients of the logits are then ~1e3 x larger
+    # than with the true count, and x 8192 they overflow fp16 in the tower data gradients
+    args = dict(bbox_targets=[tuple(t(p)) for p in tg])
+    # provoke an overflow: an absurd initial scale
+    h.ls_state.copy_(torch.tensor([2.0 ** 40, 2.0 ** -40], device=dev))
+    p0, m0 = h.params.flat.clone(), h.moms.flat.clone()
+    h.step(t(fs), t(ft), t(labs), fg_num=torch.tensor([50.0], device=dev), **args)
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(h.grads.flat).all())          # the overflow is real
+    assert torch.equal(h.params.flat, p0) and torch.equal(h.moms.flat, m0)       # step dropped
+    assert h.loss_scale == 65536.0          # halved, then clamped into [1, 65536]
+    assert int(h.ls_counters[0]) == 0 and int(h.ls_counters[1]) == 0
+    # a clean step at a sane scale updates, counts, and keeps the scale
+    h.ls_state.copy_(torch.tensor([8192.0, 1.0 / 8192.0], device=dev))
+    h.step(t(fs), t(ft), t(labs), fg_num=torch.tensor([50.0], device=dev), **args)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(h.params.flat).all()) and not torch.equal(h.params.flat, p0)
+    assert h.loss_scale == 8192.0 and int(h.ls_counters[1]) == 1
+    # growth after the interval
+    h.ls_counters[1] = h.LOSS_SCALE_GROWTH_INTERVAL - 1
+    h.step(t(fs), t(ft), t(labs), fg_num=torch.tensor([50.0], device=dev), **args)
+    assert h.loss_scale == 16384.0 and int(h.ls_counters[1]) == 0

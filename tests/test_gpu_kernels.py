@@ -576,3 +576,89 @@ def test_winograd_wgrad_multilevel_matches_direct_full_size(K, wgrad_engine):
     # deterministic
     dW2, _ = K.conv3x3_wgrad(Xs, dYs, M, want_db=False)
     assert torch.equal(dW2, dWw)
+
+
+# ---------------------------------------------------------------------------
+# The DEFAULT engine (Winograd forward / data gradient / filter gradient) at the headline
+# size, bs 16 on P3 (80 x 112), against the oracle -- not against another HIP kernel
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("M", [256, 720])
+def test_default_engine_headline_size_vs_oracle_and_adjoints(K, wgrad_engine, M):
+    """BASELINE config 3's dominant launches (bs = 16, 256 -> 256 tower layer and 256 -> 720
+    cls_pred at P3) on the engine the step uses by default:
+      * forward and data gradient of one image against the oracle (the launch covers all 16);
+      * the filter gradient against the oracle by linearity: with dY zero outside image `n0` the
+        bs-16 launch must return exactly the oracle's one-image gradient;
+      * the adjoint identities <conv(X,W),dY> = <X,dgrad(dY)> = <W,wgrad(X,dY)> on full random
+        data, which tie all 16 images of the three kernels together."""
+    wgrad_engine("winograd")
+    gen = torch.Generator(device="cuda").manual_seed(40 + M)
+    N, C, H, W = 16, 256, 80, 112
+    n0 = 11
+    X = torch.randn((N, C, H, W), device="cuda", generator=gen)
+    dY = torch.randn((N, M, H, W), device="cuda", generator=gen)
+    Wt = torch.randn((M, C, 3, 3), device="cuda", generator=gen) * 0.02
+    b = torch.randn(M, device="cuda", generator=gen)
+    wf, wd = K.conv_wino_pack_filter(Wt)
+    Y = K.conv3x3_forward([X], wf, b, M, wino=True)[0]
+    dX = K.conv3x3_forward([dY], wd, None, C, wino=True)[0]
+    dW, db = K.conv3x3_wgrad([X], [dY], M)
+    # adjoints (bias excluded: subtract it)
+    Yl = Y.double() - b.double().view(1, M, 1, 1)
+    a = float((Yl * dY.double()).sum())
+    bb = float((X.double() * dX.double()).sum())
+    c = float((Wt.double() * dW.double()).sum())
+    scale = float((Yl.abs() * dY.double().abs()).sum())
+    assert abs(a - bb) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, bb, c, scale)
+    close(db.cpu().numpy(), dY.double().sum((0, 2, 3)).cpu().numpy(), CONV_RTOL, CONV_FLOOR, "db")
+    # one image against the oracle
+    x1, dy1, w_np = X[n0:n0 + 1].cpu().numpy(), dY[n0:n0 + 1].cpu().numpy(), Wt.cpu().numpy()
+    close(Y[n0:n0 + 1].cpu().numpy(), oracle.conv_forward(x1, w_np, b.cpu().numpy()), CONV_RTOL, CONV_FLOOR,
+          "headline fwd slice")
+    ref_dW, ref_db, ref_dX = oracle.conv_backward(x1, w_np, dy1)
+    close(dX[n0:n0 + 1].cpu().numpy(), ref_dX, CONV_RTOL, CONV_FLOOR, "headline dgrad slice")
+    # filter gradient of the full launch with only image n0 contributing
+    dY0 = torch.zeros_like(dY)
+    dY0[n0].copy_(dY[n0])
+    dW0, db0 = K.conv3x3_wgrad([X], [dY0], M)
+    close(dW0.cpu().numpy(), ref_dW, CONV_RTOL, CONV_FLOOR, "headline wgrad (one contributing image)")
+    close(db0.cpu().numpy(), ref_db, CONV_RTOL, CONV_FLOOR, "headline db")
+
+
+def test_smooth_l1_levels_launcher_matches_per_level_calls(K):
+    """ssad_select_smooth_l1_levels (every FPN level in one launch each: forward, finalize, zero
+    fill, scatter; caller-provided workspace) against the per-level launchers and the oracle,
+    with an empty level and list entries outside the map."""
+    rng = np.random.default_rng(77)
+    N, A = 2, 9
+    shapes = [(10, 14), (5, 7), (3, 4)]
+    preds = [rng.standard_normal((N, 4 * A, h, w)).astype(np.float32) for h, w in shapes]
+    tg = []
+    for l, (h, w) in enumerate(shapes):
+        if l == 2:
+            tg.append((np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32)))      # no foreground
+            continue
+        M = 23 + l
+        flat = rng.choice(N * A * h * w, size=M, replace=False)        # distinct anchors
+        n_, a_, y_, x_ = np.unravel_index(flat, (N, A, h, w))
+        Lc = np.stack([n_, 4 * a_, y_, x_], 1).astype(np.float32)
+        Lc[3] = [0, 0, h + 2, 1]          # outside the map: contributes nothing
+        Lc[4] = [N, 0, 0, 0]              # image index out of range: skipped, not read
+        tg.append(((rng.standard_normal((M, 4)) * 0.5).astype(np.float32), Lc))
+    S = dev(np.array([41.0], np.float32))
+    one = dev(np.array([1.0], np.float32))
+    tp = [dev(p) for p in preds]
+    tt = [(dev(y), dev(l)) for y, l in tg]
+    losses, dps = K.select_smooth_l1_levels(tp, tt, S, one, beta=0.11, scale=0.5)
+    for l in range(len(shapes)):
+        Y, Lc = tg[l]
+        ok = np.ones(len(Y), bool)
+        if len(Y):
+            ok = (Lc[:, 0] < N) & (Lc[:, 2] < shapes[l][0]) & (Lc[:, 3] < shapes[l][1])
+        _, l64 = oracle.select_smooth_l1_forward(preds[l], Y[ok], Lc[ok], np.array([41.0], np.float32),
+                                                 beta=0.11, scale=0.5)
+        close(losses[l:l + 1].cpu().numpy(), l64, LOSS_RTOL, 1e-9, "levels loss %d" % l)
+        ref = oracle.select_smooth_l1_backward(preds[l], Y[ok], Lc[ok], np.array([41.0], np.float32), 1.0,
+                                               beta=0.11, scale=0.5)
+        close(dps[l].cpu().numpy(), ref, DX_RTOL, DX_FLOOR, "levels dY_hat %d" % l)

@@ -518,3 +518,114 @@ def test_resnet_fpn_body_graph_through_workspace_vs_torch(cfg_kw):
         assert float(np.abs(got - ref).max()) <= 2e-3 * scale, name
         checked += 1
     assert checked >= 28      # res3..res5 conv + projection filters, FPN filters and biases
+
+
+# ---------------------------------------------------------------------------
+# north_star's 1e-4 on the whole chain, with ReLU masks that cannot flip
+# ---------------------------------------------------------------------------
+
+def mask_safe_problem(seed=41, N=2):
+    """The head problem of small_problem() with the student's tower biases chosen so that no
+    pre-activation lies near zero: layer by layer (oracle forward) every output channel gets the
+    bias +-1.5 x max|conv output|, alternating in sign (and the layer is rescaled to keep the
+    activations O(1)).  Half of the channels are then clearly
+    active (pre-activation in [0.5, 2.5] x max), half clearly inactive -- the ReluGradient masks
+    are exercised in both states, but two implementations that agree to fp32 round-off cannot
+    disagree on a mask.  What remains is the arithmetic, which must then meet 1e-4."""
+    cfg, S, T, fs, ft, labs, tg, fg = small_problem(seed, N)
+    margin = np.inf
+    for tower in ("cls", "bbox"):
+        xs = fs
+        for i in range(cfg.num_convs):
+            name = "retnet_%s_conv_n%d_fpn3" % (tower, i)
+            zs = [oracle.conv_forward(x, S[name + "_w"], np.zeros_like(S[name + "_b"])) for x in xs]
+            top = np.stack([np.abs(z).max(axis=(0, 2, 3)) for z in zs]).max(0)        # per channel
+            sign = np.where(np.arange(top.size) % 2 == 0, 1.0, -1.0)
+            S[name + "_b"] = (1.5 * top * sign).astype(np.float32)
+            pre = [z + S[name + "_b"].reshape(1, -1, 1, 1) for z in zs]
+            margin = min(margin, min(float(np.abs(p_).min() / np.abs(p_).max()) for p_ in pre))
+            # ReLU is positively homogeneous: rescaling the layer keeps every mask and keeps the
+            # activations O(1) through the tower (logits stay in the sigmoid's working range)
+            k = np.float32(2.0 / max(float(np.abs(p_).max()) for p_ in pre))
+            S[name + "_w"] = (S[name + "_w"] * k).astype(np.float32)
+            S[name + "_b"] = (S[name + "_b"] * k).astype(np.float32)
+            xs = [oracle.relu(oracle.conv_forward(x, S[name + "_w"], S[name + "_b"])) for x in xs]
+    assert margin > 1e-2, margin          # every pre-activation is >= 1 % of the layer's range from 0
+    return cfg, S, T, fs, ft, labs, tg, fg
+
+
+def close_1e4(got, ref, what):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape and np.all(np.isfinite(got)), what
+    num, den = np.linalg.norm(got - ref), np.linalg.norm(ref)
+    assert num <= 1e-4 * den + 1e-30, "%s: rel L2 %.3e" % (what, num / max(den, 1e-300))
+    assert np.max(np.abs(got - ref)) <= 1e-4 * np.max(np.abs(ref)) + 1e-30, \
+        "%s: max abs err %.3e of max %.3e" % (what, np.max(np.abs(got - ref)), np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("distill", [True, False], ids=["distill", "student_only"])
+def test_fused_step_meets_1e4_when_masks_cannot_flip(distill):
+    """The whole iteration (teacher + student subnets, all losses, backward through 5 conv
+    layers per tower) against the oracle at north_star's 1e-4 on EVERY parameter gradient and
+    the gradient w.r.t. the FPN levels; student-only = BASELINE config 2's loss set."""
+    from ssad_amd.head_pipeline import DistillHeads
+    cfg, S, T, fs, ft, labs, tg, fg = mask_safe_problem()
+    dev = torch.device("cuda", 0)
+    t = lambda arrs: [torch.from_numpy(a).to(dev) for a in arrs]
+    heads = DistillHeads(cfg, N=fs[0].shape[0], shapes=SHAPES, device=dev, student_init=S,
+                         teacher_init=T if distill else None, distill=distill)
+    heads.step(t(fs), t(ft) if distill else None, t(labs), update=False,
+               bbox_targets=[tuple(t(p)) for p in tg], fg_num=torch.from_numpy(fg).to(dev))
+    ref = head_step.head_step(S, T if distill else None, fs, ft, labs, scale=1.0, bbox_targets=tg, fg_num=fg)
+    if distill:
+        close(heads.losses.cpu().numpy(), ref["losses"], LOSS_RTOL, 0, "distill losses")
+        close(heads.normalizer.cpu().numpy(), ref["normalizer"], 1e-5, 0, "normalizer")
+    close(heads.focal_losses.cpu().numpy(), ref["focal_losses"], LOSS_RTOL, 0, "focal losses")
+    close(heads.bbox_losses.cpu().numpy(), ref["bbox_losses"], LOSS_RTOL, 1e-9, "bbox losses")
+    for name, g in ref["grads"].items():
+        close_1e4(heads.grads[name].cpu().numpy(), g, "grad " + name)
+    for tower in ("cls", "bbox"):
+        for i in range(len(SHAPES)):
+            close_1e4(heads.d_fpn[tower][i].cpu().numpy(), ref["d_fpn"][tower][i], "d_fpn %s %d" % (tower, i))
+
+
+def test_config2_student_only_step_bs2_600px_vs_oracle():
+    """BASELINE config 2: RetinaNet R-50-FPN student only, bs = 2, 600 px -- the subnets on the
+    five real level shapes (80x112 ... 5x7), SigmoidFocalLoss + SelectSmoothL1Loss, backward
+    and SGD, against oracle/head_step.py (model_builder.py:98-100,413: `retinanet` without the
+    distillation wrapper)."""
+    from ssad_amd.head_pipeline import DistillHeads
+    rng = np.random.default_rng(202)
+    cfg = rh.HeadConfig(num_gpus=1)
+    N, shapes = 2, synth.LEVEL_SHAPES_600
+    S = synth.head_params(rng)
+    fs = synth.fpn_features(rng, N, shapes)
+    labs = [synth.distill_inputs(rng, N, 9, 80, h, w)[2] for h, w in shapes]
+    tg = [synth.bbox_targets(rng, l) for l in labs]
+    fg = np.array([float(max(1, sum(t_[0].shape[0] for t_ in tg)))], np.float32)
+    dev = torch.device("cuda", 0)
+    t = lambda arrs: [torch.from_numpy(a).to(dev) for a in arrs]
+    heads = DistillHeads(cfg, N=N, shapes=shapes, device=dev, student_init=S, distill=False, lr=0.01)
+    heads.step(t(fs), None, t(labs), update=False, bbox_targets=[tuple(t(p)) for p in tg],
+               fg_num=torch.from_numpy(fg).to(dev))
+    oracle.set_num_threads(min(64, __import__("os").cpu_count() or 1))
+    ref = head_step.head_step(S, None, fs, None, labs, scale=1.0, bbox_targets=tg, fg_num=fg)
+    assert ref["losses"].size == 0 and float(heads.losses.abs().sum()) == 0.0      # no distillation
+    close(heads.focal_losses.cpu().numpy(), ref["focal_losses"], LOSS_RTOL, 0, "focal losses")
+    close(heads.bbox_losses.cpu().numpy(), ref["bbox_losses"], LOSS_RTOL, 1e-9, "bbox losses")
+    errs = []
+    for name, g in ref["grads"].items():
+        close_chain(heads.grads[name].cpu().numpy(), g, "cfg2 grad " + name, errs)
+    assert_typical(errs, "cfg2 parameter gradients")
+    for tower in ("cls", "bbox"):
+        for i in range(len(shapes)):
+            close_chain(heads.d_fpn[tower][i].cpu().numpy(), ref["d_fpn"][tower][i], "cfg2 d_fpn")
+    # and the update (one launch over the flat buffers) against the oracle's SGD
+    before = {k: heads.params[k].cpu().numpy().copy() for k, _, _, _ in heads.params.specs}
+    gsum = {k: heads.grads[k].cpu().numpy().copy() for k, _, _, _ in heads.params.specs}
+    heads.sgd_step()
+    for name, _, is_bias, _ in heads.params.specs:
+        w, _, m = oracle.sgd_update(before[name], gsum[name], np.zeros_like(before[name]), 0.01, 0.9, 1e-4,
+                                    is_bias)
+        close(heads.params[name].cpu().numpy(), w, 1e-6, 1e-7, "cfg2 sgd " + name)
+        close(heads.moms[name].cpu().numpy(), m, 1e-6, 1e-9, "cfg2 momentum " + name)

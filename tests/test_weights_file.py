@@ -57,7 +57,13 @@ def test_round_trip_and_python2_layout(tmp_path):
         assert np.array_equal(saved["blobs"][name], blobs[name])
         assert np.array_equal(saved["blobs"][name + "_momentum"], blobs[name + "_momentum"])
     assert np.array_equal(saved["blobs"]["conv1_w"], blobs["conv1_w"])
-    assert not any(k.startswith("teacher/") for k in saved["blobs"])
+    # the teacher/ scope is saved with the model (net.py:145-152 walks model.params, which holds
+    # the teacher's parameters): the file alone resumes distillation
+    for name, _, _, _ in st.teacher.specs:
+        assert np.array_equal(saved["blobs"]["teacher/" + name], blobs["teacher/" + name])
+    st2 = Store(cfg)
+    _, missing2 = net.initialize_from_weights_file(st2, out)
+    assert not missing2 and torch.equal(st2.teacher.flat, st.teacher.flat)
 
 
 def test_bare_dict_missing_and_mismatched_blobs(tmp_path):
@@ -82,6 +88,28 @@ def test_bare_dict_missing_and_mismatched_blobs(tmp_path):
     for name in tblobs:
         assert np.array_equal(st.teacher[name].numpy(), tblobs[name])
     assert float(st.moms.flat.abs().sum()) == 0.0                        # no history in the file
+
+
+def test_mismatched_blob_skips_its_momentum_too(tmp_path):
+    """net.py:106-109: on a shape mismatch the reference `continue`s before it feeds either the
+    parameter or `<name>_momentum`."""
+    cfg = HeadConfig(num_convs=1)
+    rng = np.random.default_rng(2)
+    blobs = _random_blobs(cfg, rng)
+    bad = "retnet_cls_pred_fpn3_b"
+    for k in list(blobs):
+        blobs[k + "_momentum"] = rng.standard_normal(blobs[k].shape).astype(np.float32)
+    blobs[bad] = np.zeros(7, np.float32)
+    blobs[bad + "_momentum"] = np.ones(blobs[bad + "_momentum"].shape, np.float32)   # right shape
+    path = str(tmp_path / "m.pkl")
+    pickle.dump(dict(blobs=blobs), open(path, "wb"), protocol=2)
+    st = Store(cfg)
+    loaded, _ = net.initialize_from_weights_file(st, path)
+    assert bad not in loaded
+    assert float(st.moms[bad].abs().sum()) == 0.0            # its momentum was not fed
+    other = "retnet_bbox_pred_fpn3_b"
+    assert np.array_equal(st.moms[other].numpy(), blobs[other + "_momentum"])
+    assert bad + "_momentum" not in st.preserved
 
 
 @pytest.mark.gpu
