@@ -404,3 +404,55 @@ def ref_smoothl1_elems(Y_hat, Y, L, S, dloss, *, beta, norm):
     lib.ref_smoothl1_grad_kernel(D, H, W, Y.shape[0], Y_hat, Y.ravel(), L.ravel(), dy, go, norm,
                                  S, beta)
     return buf, dy
+
+
+# ---- the reference's own CPU Conv / ConvGradient operators (container build) ----------
+# oracle/_ref/libref_conv.so = ConvOp<float, CPUContext> / ConvGradientOp<float, CPUContext>
+# (caffe2/operators/conv_op_impl.h:31-202, :358-577 + utils/math_cpu.cc on the vendored Eigen)
+# compiled from /root/reference by oracle/build_ref_conv.sh.  Used to PIN conv_forward /
+# conv_backward above and to generate tests/golden/conv_ref.npz.
+
+_REFCONV = None
+
+
+def load_ref_conv():
+    """The reference's compiled CPU convolution operators, or None when not built."""
+    global _REFCONV
+    if _REFCONV is not None:
+        return _REFCONV
+    path = os.path.join(_HERE, "_ref", "libref_conv.so")
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path)
+    lib.ref_conv_forward.argtypes = [f32p, f32p, C.c_void_p] + [C.c_int] * 9 + [f32p]
+    lib.ref_conv_backward.argtypes = [f32p, f32p, f32p] + [C.c_int] * 9 + [f32p, f32p, f32p]
+    _REFCONV = lib
+    return lib
+
+
+def ref_conv_forward(X, Wt, bias=None, *, kernel=3, stride=1, pad=1, group=1):
+    lib = load_ref_conv()
+    X, Wt = _c(X, np.float32), _c(Wt, np.float32)
+    N, Cin, H, W = X.shape
+    M = Wt.shape[0]
+    oh, ow = (H + 2 * pad - kernel) // stride + 1, (W + 2 * pad - kernel) // stride + 1
+    Y = np.empty((N, M, oh, ow), np.float32)
+    b = _c(bias, np.float32) if bias is not None else None
+    rc = lib.ref_conv_forward(X, Wt, b.ctypes.data if b is not None else None, N, Cin, H, W, M,
+                              kernel, pad, stride, group, Y)
+    if rc != 0:
+        raise RuntimeError("reference Conv failed (%d)" % rc)
+    return Y
+
+
+def ref_conv_backward(X, Wt, dY, *, kernel=3, stride=1, pad=1, group=1):
+    """(dW, db, dX) of the reference's ConvGradient."""
+    lib = load_ref_conv()
+    X, Wt, dY = _c(X, np.float32), _c(Wt, np.float32), _c(dY, np.float32)
+    N, Cin, H, W = X.shape
+    M = Wt.shape[0]
+    dW, db, dX = np.empty_like(Wt), np.empty(M, np.float32), np.empty_like(X)
+    rc = lib.ref_conv_backward(X, Wt, dY, N, Cin, H, W, M, kernel, pad, stride, group, dW, db, dX)
+    if rc != 0:
+        raise RuntimeError("reference ConvGradient failed (%d)" % rc)
+    return dW, db, dX

@@ -21,6 +21,8 @@ Fixtures:
                       reference kernels (row f2)
   powsum.npz          5 random tensors, power 1.8: float64 numpy answer
   conv_small.npz      3x3 convs fwd/bwd, float64 torch (independent impl.)
+  conv_ref.npz        the same cases + the backbone's geometries (1x1, strided, 7x7, grouped)
+                      through the reference's own compiled Conv / ConvGradient CPU operators
 """
 import os
 import sys
@@ -189,6 +191,48 @@ def make_conv():
     np.savez_compressed(os.path.join(OUT, "conv_small.npz"), **out)
 
 
+# geometries beyond the subnets' 3x3: the backbone's layers (row f1) -- pointwise, strided
+# pointwise, 3x3 / stride 2 (P6, P7), the 7x7 / stride 2 stem, ResNeXt's grouped 3x3
+# (name, N, Cin, M, H, W, kernel, stride, pad, group)
+CONV_REF_GEOMS = [("k1s1", 2, 24, 40, 9, 13, 1, 1, 0, 1), ("k1s2", 2, 32, 16, 10, 14, 1, 2, 0, 1),
+                  ("k3s2", 2, 16, 24, 10, 13, 3, 2, 1, 1), ("k7s2", 1, 3, 16, 21, 29, 7, 2, 3, 1),
+                  ("k3g4", 2, 32, 32, 9, 11, 3, 1, 1, 4), ("k3g8s2", 1, 64, 64, 12, 10, 3, 2, 1, 8)]
+
+
+def conv_ref_inputs(seed, N, Cin, M, H, W, kernel=3, stride=1, pad=1, group=1):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin // group, kernel, kernel)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    oh, ow = (H + 2 * pad - kernel) // stride + 1, (W + 2 * pad - kernel) // stride + 1
+    dY = rng.standard_normal((N, M, oh, ow)).astype(np.float32)
+    return X, Wt, b, dY
+
+
+def make_conv_ref():
+    """conv_ref.npz: outputs of the REFERENCE'S OWN Conv / ConvGradient CPU operators
+    (oracle/_ref/libref_conv.so, built from /root/reference by oracle/build_ref_conv.sh) on
+    seeded inputs: the subnets' 3x3 cases of CONV_CASES and the backbone geometries of
+    CONV_REF_GEOMS.  float32, up to 4096 sampled entries per tensor (indices stored)."""
+    assert oracle.load_ref_conv() is not None, "make -C oracle refconv first"
+    out = {}
+    cases = [(n, N, Ci, M, H, W, 3, 1, 1, 1) for (n, N, Ci, M, H, W) in CONV_CASES] + CONV_REF_GEOMS
+    for ci, (name, N, Cin, M, H, W, k, s, p, g) in enumerate(cases):
+        seed = 100 + ci if ci < len(CONV_CASES) else 500 + ci
+        X, Wt, b, dY = conv_ref_inputs(seed, N, Cin, M, H, W, k, s, p, g)
+        Y = oracle.ref_conv_forward(X, Wt, b, kernel=k, stride=s, pad=p, group=g)
+        dW, db, dX = oracle.ref_conv_backward(X, Wt, dY, kernel=k, stride=s, pad=p, group=g)
+        srng = np.random.default_rng(2000 + ci)
+        for key, arr in (("Y", Y), ("dW", dW), ("dX", dX)):
+            kk = min(4096, arr.size)
+            idx = np.sort(srng.choice(arr.size, kk, replace=False)).astype(np.int64)
+            out["%s_%s_idx" % (name, key)] = idx
+            out["%s_%s" % (name, key)] = arr.ravel()[idx].astype(np.float32)
+        out[name + "_db"] = db
+        out[name + "_dims"] = np.array([seed, N, Cin, M, H, W, k, s, p, g])
+    np.savez_compressed(os.path.join(OUT, "conv_ref.npz"), **out)
+
+
 if __name__ == "__main__":
     oracle.build(ref=True)
     assert oracle.load_ref() is not None
@@ -198,6 +242,7 @@ if __name__ == "__main__":
     make_powsum()
     make_focal_smoothl1()
     make_conv()
+    make_conv_ref()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

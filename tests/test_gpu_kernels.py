@@ -658,7 +658,33 @@ def test_smooth_l1_levels_launcher_matches_per_level_calls(K):
             ok = (Lc[:, 0] < N) & (Lc[:, 2] < shapes[l][0]) & (Lc[:, 3] < shapes[l][1])
         _, l64 = oracle.select_smooth_l1_forward(preds[l], Y[ok], Lc[ok], np.array([41.0], np.float32),
                                                  beta=0.11, scale=0.5)
-        close(losses[l:l + 1].cpu().numpy(), l64, LOSS_RTOL, 1e-9, "levels loss %d" % l)
+        close(float(losses[l]), l64, LOSS_RTOL, 1e-9, "levels loss %d" % l)
         ref = oracle.select_smooth_l1_backward(preds[l], Y[ok], Lc[ok], np.array([41.0], np.float32), 1.0,
                                                beta=0.11, scale=0.5)
         close(dps[l].cpu().numpy(), ref, DX_RTOL, DX_FLOOR, "levels dY_hat %d" % l)
+
+
+# ---------------------------------------------------------------------------
+# HIP convolution engines against the REFERENCE operator's own outputs
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("engine", ["winograd", "direct"])
+@pytest.mark.parametrize("case", mg.CONV_CASES, ids=[c[0] for c in mg.CONV_CASES])
+def test_conv_engines_vs_reference_operator_golden(K, golden_dir, wgrad_engine, case, engine):
+    """Forward, data gradient and filter gradient of both 3x3 engines against
+    tests/golden/conv_ref.npz = outputs of the reference's compiled ConvOp / ConvGradientOp
+    <float, CPUContext> on the same seeded inputs (1e-4 rel + 1e-5 of the tensor's scale)."""
+    g = np.load(os.path.join(golden_dir, "conv_ref.npz"))
+    name = case[0]
+    seed, N, Cin, M, H, W, k, s, p, grp = [int(v) for v in g[name + "_dims"]]
+    X, Wt, b, dY = mg.conv_ref_inputs(seed, N, Cin, M, H, W, k, s, p, grp)
+    wino = engine == "winograd"
+    wgrad_engine(engine)
+    pf, pd = (K.conv_wino_pack_filter if wino else K.conv_pack_filter)(dev(Wt))
+    Y = K.conv3x3_forward([dev(X)], pf, dev(b), M, wino=wino)[0].cpu().numpy()
+    dX = K.conv3x3_forward([dev(dY)], pd, None, Cin, wino=wino)[0].cpu().numpy()
+    dW, db = K.conv3x3_wgrad([dev(X)], [dev(dY)], M)
+    for key, arr in (("Y", Y), ("dW", dW.cpu().numpy()), ("dX", dX)):
+        ref = g["%s_%s" % (name, key)]
+        close(arr.ravel()[g["%s_%s_idx" % (name, key)]], ref, CONV_RTOL, CONV_FLOOR, "%s %s %s" % (engine, name, key))
+    close(db.cpu().numpy(), g[name + "_db"], CONV_RTOL, CONV_FLOOR, name + " db")

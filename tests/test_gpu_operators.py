@@ -18,6 +18,11 @@ from test_gpu_kernels import (CONV_FLOOR, CONV_RTOL, DX_FLOOR, DX_RTOL, LOSS_RTO
 
 pytestmark = pytest.mark.gpu
 
+
+def mg_ref_geoms():
+    import make_golden as mg
+    return list(mg.CONV_REF_GEOMS)
+
 # the reference graph says CUDA; the HIP registry serves it
 GPU = core.DeviceOption(caffe2_pb2.CUDA, 0)
 
@@ -524,15 +529,17 @@ def test_resnet_fpn_body_graph_through_workspace_vs_torch(cfg_kw):
 # north_star's 1e-4 on the whole chain, with ReLU masks that cannot flip
 # ---------------------------------------------------------------------------
 
-def mask_safe_problem(seed=41, N=2):
-    """The head problem of small_problem() with the student's tower biases chosen so that no
-    pre-activation lies near zero: layer by layer (oracle forward) every output channel gets the
-    bias +-1.5 x max|conv output|, alternating in sign (and the layer is rescaled to keep the
-    activations O(1)).  Half of the channels are then clearly
+def make_mask_safe(cfg, S, fs):
+    """Choose the student's tower biases so that no pre-activation lies near zero: layer by
+    layer (oracle forward) every output channel gets the bias +-1.5 x max|conv output|,
+    alternating in sign (and the layer is rescaled to keep the activations O(1): ReLU is
+    positively homogeneous, so that keeps every mask).  Half of the channels are then clearly
     active (pre-activation in [0.5, 2.5] x max), half clearly inactive -- the ReluGradient masks
     are exercised in both states, but two implementations that agree to fp32 round-off cannot
-    disagree on a mask.  What remains is the arithmetic, which must then meet 1e-4."""
-    cfg, S, T, fs, ft, labs, tg, fg = small_problem(seed, N)
+    disagree on a mask.  What remains is the arithmetic, which must then meet 1e-4.
+    (With free-running random activations a bs-2 600 px step has ~2 pre-activations per layer
+    within the convolution's round-off of zero; each flipped mask moves a 1/256 slice of the
+    layer's gradients by ~1/sqrt(pixels), i.e. 4e-4..1e-3 relative L2 -- measured.)"""
     margin = np.inf
     for tower in ("cls", "bbox"):
         xs = fs
@@ -541,17 +548,20 @@ def mask_safe_problem(seed=41, N=2):
             zs = [oracle.conv_forward(x, S[name + "_w"], np.zeros_like(S[name + "_b"])) for x in xs]
             top = np.stack([np.abs(z).max(axis=(0, 2, 3)) for z in zs]).max(0)        # per channel
             sign = np.where(np.arange(top.size) % 2 == 0, 1.0, -1.0)
-            S[name + "_b"] = (1.5 * top * sign).astype(np.float32)
-            pre = [z + S[name + "_b"].reshape(1, -1, 1, 1) for z in zs]
+            b = (1.5 * top * sign).astype(np.float32)
+            pre = [z + b.reshape(1, -1, 1, 1) for z in zs]
             margin = min(margin, min(float(np.abs(p_).min() / np.abs(p_).max()) for p_ in pre))
-            # ReLU is positively homogeneous: rescaling the layer keeps every mask and keeps the
-            # activations O(1) through the tower (logits stay in the sigmoid's working range)
             k = np.float32(2.0 / max(float(np.abs(p_).max()) for p_ in pre))
             S[name + "_w"] = (S[name + "_w"] * k).astype(np.float32)
-            S[name + "_b"] = (S[name + "_b"] * k).astype(np.float32)
-            xs = [oracle.relu(oracle.conv_forward(x, S[name + "_w"], S[name + "_b"])) for x in xs]
+            S[name + "_b"] = (b * k).astype(np.float32)
+            xs = [np.maximum(p_ * k, 0).astype(np.float32) for p_ in pre]
     assert margin > 1e-2, margin          # every pre-activation is >= 1 % of the layer's range from 0
-    return cfg, S, T, fs, ft, labs, tg, fg
+    return S
+
+
+def mask_safe_problem(seed=41, N=2):
+    cfg, S, T, fs, ft, labs, tg, fg = small_problem(seed, N)
+    return cfg, make_mask_safe(cfg, S, fs), T, fs, ft, labs, tg, fg
 
 
 def close_1e4(got, ref, what):
@@ -593,13 +603,15 @@ def test_config2_student_only_step_bs2_600px_vs_oracle():
     """BASELINE config 2: RetinaNet R-50-FPN student only, bs = 2, 600 px -- the subnets on the
     five real level shapes (80x112 ... 5x7), SigmoidFocalLoss + SelectSmoothL1Loss, backward
     and SGD, against oracle/head_step.py (model_builder.py:98-100,413: `retinanet` without the
-    distillation wrapper)."""
+    distillation wrapper) at north_star's 1e-4 on every gradient (tower biases chosen so that no
+    ReLU mask can flip, see make_mask_safe)."""
     from ssad_amd.head_pipeline import DistillHeads
     rng = np.random.default_rng(202)
     cfg = rh.HeadConfig(num_gpus=1)
     N, shapes = 2, synth.LEVEL_SHAPES_600
-    S = synth.head_params(rng)
+    oracle.set_num_threads(min(64, __import__("os").cpu_count() or 1))
     fs = synth.fpn_features(rng, N, shapes)
+    S = make_mask_safe(cfg, synth.head_params(rng), fs)
     labs = [synth.distill_inputs(rng, N, 9, 80, h, w)[2] for h, w in shapes]
     tg = [synth.bbox_targets(rng, l) for l in labs]
     fg = np.array([float(max(1, sum(t_[0].shape[0] for t_ in tg)))], np.float32)
@@ -608,18 +620,15 @@ def test_config2_student_only_step_bs2_600px_vs_oracle():
     heads = DistillHeads(cfg, N=N, shapes=shapes, device=dev, student_init=S, distill=False, lr=0.01)
     heads.step(t(fs), None, t(labs), update=False, bbox_targets=[tuple(t(p)) for p in tg],
                fg_num=torch.from_numpy(fg).to(dev))
-    oracle.set_num_threads(min(64, __import__("os").cpu_count() or 1))
     ref = head_step.head_step(S, None, fs, None, labs, scale=1.0, bbox_targets=tg, fg_num=fg)
     assert ref["losses"].size == 0 and float(heads.losses.abs().sum()) == 0.0      # no distillation
     close(heads.focal_losses.cpu().numpy(), ref["focal_losses"], LOSS_RTOL, 0, "focal losses")
     close(heads.bbox_losses.cpu().numpy(), ref["bbox_losses"], LOSS_RTOL, 1e-9, "bbox losses")
-    errs = []
     for name, g in ref["grads"].items():
-        close_chain(heads.grads[name].cpu().numpy(), g, "cfg2 grad " + name, errs)
-    assert_typical(errs, "cfg2 parameter gradients")
+        close_1e4(heads.grads[name].cpu().numpy(), g, "cfg2 grad " + name)
     for tower in ("cls", "bbox"):
         for i in range(len(shapes)):
-            close_chain(heads.d_fpn[tower][i].cpu().numpy(), ref["d_fpn"][tower][i], "cfg2 d_fpn")
+            close_1e4(heads.d_fpn[tower][i].cpu().numpy(), ref["d_fpn"][tower][i], "cfg2 d_fpn")
     # and the update (one launch over the flat buffers) against the oracle's SGD
     before = {k: heads.params[k].cpu().numpy().copy() for k, _, _, _ in heads.params.specs}
     gsum = {k: heads.grads[k].cpu().numpy().copy() for k, _, _, _ in heads.params.specs}
@@ -629,3 +638,29 @@ def test_config2_student_only_step_bs2_600px_vs_oracle():
                                     is_bias)
         close(heads.params[name].cpu().numpy(), w, 1e-6, 1e-7, "cfg2 sgd " + name)
         close(heads.moms[name].cpu().numpy(), m, 1e-6, 1e-9, "cfg2 momentum " + name)
+
+
+@pytest.mark.parametrize("case", mg_ref_geoms(), ids=lambda c: c[0])
+def test_default_engine_vs_reference_operator_golden(golden_dir, case):
+    """The backbone's convolution geometries (pointwise, strided pointwise, 3x3 / stride 2, the
+    7x7 / stride 2 stem, ResNeXt's grouped 3x3) through the Conv / ConvGradient operators for
+    HIPContext against the stored outputs of the reference's own compiled CPU operators
+    (tests/golden/conv_ref.npz)."""
+    import make_golden as mg
+    g = np.load(__import__("os").path.join(golden_dir, "conv_ref.npz"))
+    name = case[0]
+    seed, N, Cin, M, H, W, k, s, p, grp = [int(v) for v in g[name + "_dims"]]
+    X, Wt, b, dY = mg.conv_ref_inputs(seed, N, Cin, M, H, W, k, s, p, grp)
+    feed("X", X); feed("w", Wt); feed("b", b); feed("Y_grad", dY)
+    kw = dict(kernel=k, pad=p, stride=s, order="NCHW", engine="CUDNN")
+    if grp != 1:
+        kw["group"] = grp
+    with core.DeviceScope(GPU):
+        conv = core.CreateOperator("Conv", ["X", "w", "b"], ["Y"], **kw)
+    workspace.RunOperatorOnce(conv)
+    gops, _ = core.GradientRegistry.GetGradientForOp(conv, ["Y_grad"])
+    workspace.RunOperatorsOnce(gops)
+    for key, blob in (("Y", "Y"), ("dW", "w_grad"), ("dX", "X_grad")):
+        got = workspace.FetchBlob(blob).ravel()[g["%s_%s_idx" % (name, key)]]
+        close(got, g["%s_%s" % (name, key)], CONV_RTOL, CONV_FLOOR, "%s %s" % (name, key))
+    close(workspace.FetchBlob("b_grad"), g[name + "_db"], CONV_RTOL, CONV_FLOOR, name + " db")

@@ -201,3 +201,67 @@ def test_select_smooth_l1_oracle_vs_reference_kernels(golden_dir):
     e = np.zeros((0, 4), np.float32)
     assert oracle.select_smooth_l1_forward(Yh, e, e, 3.0)[1] == 0.0
     assert not oracle.select_smooth_l1_backward(Yh, e, e, 3.0).any()
+
+
+# ---------------------------------------------------------------------------
+# The convolution oracle PINNED by the reference's own compiled CPU operators
+# ---------------------------------------------------------------------------
+# tests/golden/conv_ref.npz holds outputs of ConvOp<float, CPUContext> /
+# ConvGradientOp<float, CPUContext> (caffe2/operators/conv_op_impl.h + utils/math_cpu.cc)
+# built from /root/reference by oracle/build_ref_conv.sh and run on seeded inputs
+# (tests/golden/make_golden.py:make_conv_ref).
+
+def _ref_cases():
+    cases = [(n, N, Ci, M, H, W, 3, 1, 1, 1) for (n, N, Ci, M, H, W) in mg.CONV_CASES] + list(mg.CONV_REF_GEOMS)
+    return cases
+
+
+@pytest.mark.parametrize("case", [c for c in _ref_cases() if c[-1] == 1], ids=lambda c: c[0])
+def test_conv_oracle_vs_reference_operator_outputs(golden_dir, case):
+    """oracle.conv_forward / conv_backward against the stored outputs of the reference's own
+    operators: same algorithm (per-image im2col + GEMM, conv_op_impl.h:126-173), so the
+    agreement is fp32 round-off of a differently ordered dot product -- 1e-5 of the tensor's
+    scale -- for the 3x3 subnet cases and the backbone's 1x1 / strided / 7x7 geometries."""
+    g = np.load(os.path.join(golden_dir, "conv_ref.npz"))
+    name = case[0]
+    seed, N, Cin, M, H, W, k, s, p, grp = [int(v) for v in g[name + "_dims"]]
+    X, Wt, b, dY = mg.conv_ref_inputs(seed, N, Cin, M, H, W, k, s, p, grp)
+    Y = oracle.conv_forward(X, Wt, b, kernel=k, stride=s, pad=p)
+    dW, db, dX = oracle.conv_backward(X, Wt, dY, kernel=k, stride=s, pad=p)
+    for key, arr in (("Y", Y), ("dW", dW), ("dX", dX)):
+        ref = g["%s_%s" % (name, key)]
+        got = arr.ravel()[g["%s_%s_idx" % (name, key)]]
+        assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref)), (name, key)
+    assert np.max(np.abs(db - g[name + "_db"])) <= 1e-5 * np.max(np.abs(g[name + "_db"]))
+
+
+def test_conv_golden_is_what_the_reference_operators_compute(golden_dir):
+    """Container only (needs oracle/_ref/libref_conv.so): the committed fixture is reproduced
+    bit for bit by running the reference's operators again, and on fresh random shapes the
+    oracle tracks them to fp32 round-off."""
+    if oracle.load_ref_conv() is None:
+        pytest.skip("oracle/_ref/libref_conv.so not built (needs /root/reference)")
+    g = np.load(os.path.join(golden_dir, "conv_ref.npz"))
+    for case in _ref_cases():
+        name = case[0]
+        seed, N, Cin, M, H, W, k, s, p, grp = [int(v) for v in g[name + "_dims"]]
+        X, Wt, b, dY = mg.conv_ref_inputs(seed, N, Cin, M, H, W, k, s, p, grp)
+        Y = oracle.ref_conv_forward(X, Wt, b, kernel=k, stride=s, pad=p, group=grp)
+        dW, db, dX = oracle.ref_conv_backward(X, Wt, dY, kernel=k, stride=s, pad=p, group=grp)
+        for key, arr in (("Y", Y), ("dW", dW), ("dX", dX)):
+            assert np.array_equal(arr.ravel()[g["%s_%s_idx" % (name, key)]], g["%s_%s" % (name, key)]), (name, key)
+        assert np.array_equal(db, g[name + "_db"])
+    rng = np.random.default_rng(31)
+    for _ in range(6):
+        N, Cin, M = int(rng.integers(1, 3)), int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        H, W = int(rng.integers(3, 20)), int(rng.integers(3, 20))
+        k, s = [(3, 1), (1, 1), (3, 2), (1, 2)][int(rng.integers(0, 4))]
+        p = k // 2
+        X, Wt, b, dY = mg.conv_ref_inputs(int(rng.integers(1 << 30)), N, Cin, M, H, W, k, s, p, 1)
+        Y = oracle.conv_forward(X, Wt, b, kernel=k, stride=s, pad=p)
+        Yr = oracle.ref_conv_forward(X, Wt, b, kernel=k, stride=s, pad=p)
+        assert np.max(np.abs(Y - Yr)) <= 1e-5 * np.max(np.abs(Yr))
+        got = oracle.conv_backward(X, Wt, dY, kernel=k, stride=s, pad=p)
+        ref = oracle.ref_conv_backward(X, Wt, dY, kernel=k, stride=s, pad=p)
+        for a, r in zip(got, ref):
+            assert np.max(np.abs(a - r)) <= 1e-5 * max(np.max(np.abs(r)), 1e-30)

@@ -137,6 +137,7 @@ def test_update_lr_rescales_update_history_and_checkpoint_round_trip(tmp_path):
     net.save_model_to_weights_file(path, heads)
     other = DistillHeads(cfg=cfg, N=1, shapes=[(8, 8), (4, 4)], lr=0.01)
     loaded, missing = net.initialize_from_weights_file(other, path)
-    assert not missing and len(loaded) == len(heads.params.specs)
+    assert not missing and len(loaded) == 2 * len(heads.params.specs)      # student + teacher/ scope
+    assert torch.equal(other.teacher.flat, heads.teacher.flat)
     assert torch.equal(other.params.flat, heads.params.flat)
     assert torch.equal(other.moms.flat, heads.moms.flat)
