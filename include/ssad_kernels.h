@@ -385,6 +385,45 @@ SSAD_API int ssad_conv1x1_bias_act(const float* x, const float* w, const float* 
 SSAD_API int ssad_conv1x1_bias_act2(const float* x, int C1, const float* x2, int C2, const float* w,
                                     const float* bias, const float* residual, float* y, int N, int P,
                                     int M, int relu, ssad_stream_t stream);
+/* Pointwise (1x1) convolution as an exact-fp32 MFMA GEMM over the whole batch (row f1: the
+ * bottleneck's 1x1 layers, projection shortcuts, FPN laterals; detectron/lib/modeling/
+ * ResNet.py:221-283, FPN.py:116-250; algorithm caffe2/operators/conv_op_impl.h:126-173 with the
+ * identity im2col of a 1x1 kernel):
+ *     y[n][m][p] = act( sum_k a[k][m] x[n][k][p] + bias[m] + residual[n][m][p] )
+ * forward:        a = W^T, [K = Cin][lda >= M = Cout] from ssad_transpose_filter (zero padded);
+ * data gradient:  a = W itself ([K = Cout][lda = M = Cin]), x = dY, y = dX, no bias.
+ * mask (may be NULL): y = mask[n][m][p] > 0 ? y : 0 -- the ReluGradient of the layer below fused
+ * into the data gradient.  SSAD_GEMM_ACCUMULATE: y += result (a shortcut's gradient meeting the
+ * main branch's; bias / residual must be NULL then).  Requires P % 4 == 0, lda % 4 == 0 and
+ * 16-byte aligned a / x; tensors below 2 GiB.  Stride-2 pointwise layers run on the output of
+ * ssad_subsample (a strided pointwise convolution is the pointwise convolution of the subsampled
+ * map). */
+#define SSAD_GEMM_RELU 1
+#define SSAD_GEMM_ACCUMULATE 8
+typedef struct ssad_gemm_conv {
+  const float* a;          /* [K][lda] */
+  const float* x;          /* [N][K][P] */
+  float* y;                /* [N][M][P] */
+  const float* bias;       /* [M] or NULL */
+  const float* residual;   /* [N][M][P] or NULL */
+  const float* mask;       /* [N][M][P] or NULL */
+  int lda, N, K, P, M, flags;
+} ssad_gemm_conv;
+SSAD_API int ssad_conv1x1_gemm(const ssad_gemm_conv* desc_host, ssad_stream_t stream);
+/* wt[k][m] = w[m][k], rows padded with zeros to ldm >= M (ldm % 4 == 0) */
+SSAD_API int ssad_transpose_filter(const float* w, int M, int K, int ldm, float* wt, ssad_stream_t stream);
+/* dw[m][c] (+)= sum_{n,p} dy[n][m][p] x[n][c][p]  (conv_op_impl.h:451-500 for a 1x1 kernel);
+ * deterministic split reduction through the caller's workspace.  P % 16 == 0. */
+SSAD_API size_t ssad_conv1x1_wgrad_workspace_bytes(int N, int C, int P, int M);
+SSAD_API int ssad_conv1x1_wgrad(const float* x, const float* dy, int N, int C, int P, int M, float* dw,
+                                int accumulate, void* workspace, size_t workspace_bytes,
+                                ssad_stream_t stream);
+/* y[n][c][oy][ox] = x[n][c][oy*stride][ox*stride], OH = (H-1)/stride + 1; and its gradient
+ * dx (+)= scatter(dy) (zero off the sampled grid) */
+SSAD_API int ssad_subsample(const float* x, int N, int C, int H, int W, int stride, float* y,
+                            ssad_stream_t stream);
+SSAD_API int ssad_subsample_grad(const float* dy, int N, int C, int H, int W, int stride, int accumulate,
+                                 float* dx, ssad_stream_t stream);
 /* MaxPool / MaxPoolGradient, NCHW (caffe2/operators/pool_op.cu): windows are clipped to
  * the image; every input equal to its window's maximum receives the gradient */
 SSAD_API int ssad_max_pool_forward(const float* x, int N, int C, int H, int W, int kh, int kw,

@@ -114,8 +114,19 @@ enum ssad_opcode {
   SSAD_OP_RELU_GRAD_ROWSUM = 52,
   /* ssad_relu_grad(p0 = y, p1 = dy, p2 = dx, l0 = n) */
   SSAD_OP_RELU_GRAD = 53,
+  /* ssad_conv1x1_gemm(p0 = desc_host) */
+  SSAD_OP_GEMM_CONV = 54,
   /* ssad_channel_sum(p0 = dy, i0 = N, i1 = C, i2 = HW, p1 = out, i3 = accumulate) */
-  SSAD_OP_CHANNEL_SUM = 55
+  SSAD_OP_CHANNEL_SUM = 55,
+  /* ssad_conv1x1_wgrad(p0 = x, p1 = dy, i0..i3 = N, C, P, M, p2 = dw, i4 = accumulate,
+   * p3 = workspace, l0 = workspace_bytes) */
+  SSAD_OP_CONV1X1_WGRAD = 56,
+  /* ssad_transpose_filter(p0 = w, i0 = M, i1 = K, i2 = ldm, p1 = wt) */
+  SSAD_OP_TRANSPOSE_FILTER = 57,
+  /* ssad_subsample(p0 = x, i0..i3 = N, C, H, W, i4 = stride, p1 = y) */
+  SSAD_OP_SUBSAMPLE = 58,
+  /* ssad_subsample_grad(p0 = dy, i0..i3 = N, C, H, W, i4 = stride, i5 = accumulate, p1 = dx) */
+  SSAD_OP_SUBSAMPLE_GRAD = 59
 };
 
 typedef struct ssad_op {

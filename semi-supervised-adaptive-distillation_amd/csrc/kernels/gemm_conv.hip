@@ -1,0 +1,556 @@
+// gemm_conv.hip -- pointwise (1x1) convolution of an NCHW fp32 tensor as an exact-fp32 MFMA
+// GEMM with the ResNet bottleneck's tail in its epilogue, its data gradient and its filter
+// gradient.  This is the backbone's dominant non-3x3 work (row f1): the bottleneck's 1x1
+// layers, the projection shortcuts and FPN's lateral convolutions
+// (detectron/lib/modeling/ResNet.py:221-283, FPN.py:116-250; reference algorithm
+// caffe2/operators/conv_op_impl.h:126-173 -- for a 1x1 kernel im2col is the identity and the
+// layer is Y[n] = W . X[n]).
+//
+//   forward        Y[n][m][p]  = act( sum_k Wt[k][m] X[n][k][p] + bias[m] + R[n][m][p] )
+//   data gradient  dX[n][c][p] (+)= mask( sum_m W[m][c] dY[n][m][p] )      (same kernel: the
+//                  filter in its natural [M][C] layout IS the [K][M'] operand of this product)
+//   filter grad.   dW[m][c]    = sum_{n,p} dY[n][m][p] X[n][c][p]          (gemm_nt below)
+//
+// Design for MI355X (gfx950):
+//  * v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles per instruction per SIMD); a wave owns a
+//    64 x 64 output block = 2 x 2 MFMA tiles (64 accumulator registers), a workgroup of four
+//    waves a 128 x 128 tile (64 x 128 for 64-wide outputs), three workgroups per CU.
+//  * The batch is flattened into the GEMM's column dimension (q = n * P + p): a 20 x 28 map
+//    (P = 560) does not waste the last 128-column tile of every image and 16 images of it
+//    fill exactly 70 tiles.
+//  * Operands travel HBM -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: no staging
+//    registers, no ds_write), in K chunks of 16 through a three-deep ring; the loads of two
+//    chunks stay in flight across the one barrier per chunk (raw s_barrier + counted vmcnt).
+//    Both tiles are [k][128] rows in LDS, so an MFMA operand is one ds_read of 32 consecutive
+//    floats per half-wave (conflict free) and one ds_read2_b32 serves both row tiles.
+//  * Tile order is XCD-aware: consecutive tiles (same columns, next 128 output channels) run
+//    on the same XCD, so the activation tile is fetched from HBM once and re-read from L2.
+//  * Bias, residual, ReLU, the ReluGradient mask and accumulation happen in registers: the
+//    pre-activation tensor is never written.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "conv_internal.h"
+#include "ssad_kernels.h"
+
+namespace {
+
+using ssad_dev::uniform_rsrc;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+constexpr int kThreads = 256;
+constexpr unsigned kOob = 0x80000000u;     // buffer offset past any descriptor: loads 0, stores dropped
+constexpr int BN = 128;                    // columns (flattened pixels) per tile
+constexpr int BK = 16;                     // reduction chunk
+constexpr int NSTAGE = 3;
+
+struct GemmArgs {
+  const float* a;        // [K][lda]
+  const float* x;        // [N][K][P]
+  float* y;              // [N][M][P]
+  const float* bias;     // [M] or null
+  const float* res;      // [N][M][P] or null
+  const float* mask;     // [N][M][P] or null
+  int lda, N, K, P, M, flags;
+  int mtiles, ctiles;    // tiles along M and along the flattened columns
+  long long Q;           // N * P
+};
+
+// the b32 buffer builtins move 32-bit INTEGERS: floats go through a bit cast, not a conversion
+__device__ __forceinline__ float ldf(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+}
+__device__ __forceinline__ void stf(float v, __amdgpu_buffer_rsrc_t rs, unsigned off) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, 0);
+}
+
+// bijective XCD-aware remap: workgroup b runs on XCD b % 8 (observed dispatch order; speed
+// only), so give XCD x the contiguous range of tile indices [start_x, start_x + count_x)
+__device__ __forceinline__ int xcd_remap(int b, int total) {
+  const int q = total >> 3, r = total & 7;
+  const int xcd = b & 7, k = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <int BM>
+__global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArgs g) {
+  constexpr int TI = BM / 64;                  // 32-row MFMA tiles per wave along M (wave = BM/2 rows)
+  constexpr int A_STAGE = BK * BM;             // floats
+  constexpr int B_STAGE = BK * BN;
+  constexpr int STAGE = A_STAGE + B_STAGE;
+  constexpr int A_ROW_LANES = BM / 4;          // lanes that cover one A row with 16 B each
+  constexpr int A_ROWS_PER_INSTR = 64 / A_ROW_LANES;          // 2 (BM = 128) or 4 (BM = 64)
+  constexpr int A_INSTR = BK / A_ROWS_PER_INSTR;              // wave-instructions per stage: 8 or 4
+  constexpr int B_INSTR = BK / 2;                             // 8
+  constexpr int A_PER_WAVE = A_INSTR / 4, B_PER_WAVE = B_INSTR / 4;      // 2|1 and 2
+  constexpr int LOADS = A_PER_WAVE + B_PER_WAVE;              // per wave per stage
+  __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int j = lane & 31, h = lane >> 5;
+  const int tile = xcd_remap(blockIdx.x, g.mtiles * g.ctiles);
+  const int mt = tile % g.mtiles, ct = tile / g.mtiles;
+  const int m0 = mt * BM;
+  const long long q0 = (long long)ct * BN;
+  const int K = g.K, P = g.P;
+
+  const __amdgpu_buffer_rsrc_t ars = uniform_rsrc(g.a, (unsigned)((long long)K * g.lda * 4));
+  const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(g.x, (unsigned)((long long)g.N * K * P * 4));
+
+  // ---- per-lane DMA sources (fixed for the tile; the chunk moves them by a uniform offset) ----
+  // A: wave-instruction `ia` (0..A_INSTR) covers rows ia * A_ROWS_PER_INSTR + lane / A_ROW_LANES
+  const int a_row = lane / A_ROW_LANES, a_col = (lane % A_ROW_LANES) * 4;
+  unsigned a_voff = (unsigned)((a_row * g.lda + m0 + a_col) * 4);
+  if (m0 + a_col >= g.lda) a_voff = kOob;
+  // B: wave-instruction `ib` covers rows 2 * ib + (lane >> 5), columns (lane & 31) * 4 .. + 3
+  const long long qb = q0 + (lane & 31) * 4;
+  unsigned b_voff = kOob;
+  if (qb < g.Q) {
+    const int n = (int)(qb / P), p = (int)(qb - (long long)n * P);
+    b_voff = (unsigned)((((long long)n * K + h) * P + p) * 4);
+  }
+  auto issue = [&](int chunk, int buf) {
+    const int k0 = chunk * BK;
+    float* base = lds + buf * STAGE;
+#pragma unroll
+    for (int u = 0; u < A_PER_WAVE; ++u) {
+      const int ia = wave * A_PER_WAVE + u;
+      const int row = k0 + ia * A_ROWS_PER_INSTR;                  // first row of this instruction
+      const unsigned vo = (row + a_row < K) ? a_voff : kOob;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_ptr)(base + ia * 256), 16, vo, row * g.lda * 4, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < B_PER_WAVE; ++u) {
+      const int ib = wave * B_PER_WAVE + u;
+      const int row = k0 + ib * 2;
+      const unsigned vo = (row + h < K) ? b_voff : kOob;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr)(base + A_STAGE + ib * 256), 16, vo, row * P * 4, 0, 0);
+    }
+  };
+
+  f32x16 acc[TI][2];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.0f;
+
+  const int chunks = (K + BK - 1) / BK;
+  issue(0, 0);
+  if (chunks > 1) issue(1, 1);
+  const int a_rd = wm * (BM / 2) + j;          // + k * BM (+ 32 for the second row tile)
+  const int b_rd = A_STAGE + wn * 64 + j;      // + k * BN (+ 32)
+  int buf = 0;
+  for (int c = 0; c < chunks; ++c) {
+    // this wave's loads of chunk c have landed (those of chunk c + 1 may still fly) ...
+    if (c + 1 < chunks) {
+      if constexpr (LOADS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // ... and after the barrier everybody's have; every wave is also done with chunk c - 1,
+    // whose buffer the next DMA overwrites
+    __builtin_amdgcn_s_barrier();
+    if (c + 2 < chunks) issue(c + 2, buf == 0 ? 2 : buf - 1);
+    const float* s = lds + buf * STAGE;
+    // operands of step ks + 1 are requested before the MFMAs of step ks are issued
+    float av[2][TI], bv[2][2];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) av[0][i] = s[a_rd + h * BM + i * 32];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bv[0][t] = s[b_rd + h * BN + t * 32];
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < BK / 2) {
+        const int k = 2 * (ks + 1) + h;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) av[nxt][i] = s[a_rd + k * BM + i * 32];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bv[nxt][t] = s[b_rd + k * BN + t * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of this step's MFMAs
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][t], acc[i][t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++buf == NSTAGE) buf = 0;
+  }
+
+  // ---- epilogue: bias, residual, ReLU, ReluGradient mask, accumulate -- in registers ----------
+  const bool relu = g.flags & SSAD_GEMM_RELU, accum = g.flags & SSAD_GEMM_ACCUMULATE;
+  const long long ybytes = (long long)g.N * g.M * P * 4;
+  const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(g.y, (unsigned)ybytes);
+  const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(g.res ? g.res : g.y, (unsigned)ybytes);
+  const __amdgpu_buffer_rsrc_t krs = uniform_rsrc(g.mask ? g.mask : g.y, (unsigned)ybytes);
+  // Every optional term is applied to a whole 32 x 32 tile (16 values per lane) under ONE
+  // wave-uniform branch, so its 16 loads are issued back to back and waited for once (a
+  // per-element "load or not" makes hipcc branch and drain vmcnt per element).
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    float bvv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bvv[r] = 0.0f;
+    if (g.bias) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        bvv[r] = g.bias[m < g.M ? m : g.M - 1];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const long long q = q0 + wn * 64 + t * 32 + j;
+      long long col = -1;                         // element offset of (n, m = 0, p), or -1 outside
+      if (q < g.Q) {
+        const int n = (int)(q / P), p = (int)(q - (long long)n * P);
+        col = (long long)n * g.M * P + p;
+      }
+      unsigned off[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        off[r] = (col >= 0 && m < g.M) ? (unsigned)((col + (long long)m * P) * 4) : kOob;
+      }
+      f32x16 v = acc[i][t];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += bvv[r];
+      if (g.res) {
+        float tmp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmp[r] = ldf(rrs, off[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += tmp[r];
+      }
+      if (relu) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+      }
+      if (g.mask) {
+        float tmp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmp[r] = ldf(krs, off[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = tmp[r] > 0.0f ? v[r] : 0.0f;
+      }
+      if (accum) {
+        float tmp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmp[r] = ldf(yrs, off[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += tmp[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stf(v[r], yrs, off[r]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Filter gradient: dW[m][c] = sum over q = (n, p) of dY[n][m][p] X[n][c][p].  Both operands have
+// the reduction index contiguous in memory, so both LDS tiles are [row][16] blocks read with
+// ds_read_b128 (four reduction steps per read); the reduction order inside a chunk is permuted
+// identically for both operands, which a dot product does not care about.  The DMA writes LDS
+// lane-linearly, so the bank swizzle is applied on the SOURCE side (which 16-byte piece of the
+// row a lane fetches) and undone by the reader: piece c of row r lives in slot c ^ ((r >> 2) & 3).
+// Split over the columns: gridDim.y workgroups each reduce a contiguous range of 16-column
+// chunks into their own [M][C] slab; a second kernel adds the slabs in a fixed order.
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* x;     // [N][C][P]
+  const float* dy;    // [N][M][P]
+  float* part;        // [splits][M][C]
+  int N, C, P, M;
+  int mtiles, ctiles;
+  int chunks;         // total 16-column chunks = N * P / 16
+  int per_split;      // chunks per split
+};
+
+__global__ __launch_bounds__(kThreads, 3) void gemm_conv_nt_kernel(const WgradArgs g) {
+  constexpr int TSTAGE = 128 * BK;              // floats per operand per stage
+  constexpr int STAGE = 2 * TSTAGE;
+  __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int j = lane & 31, h = lane >> 5;
+  const int tile = blockIdx.x;
+  const int mt = tile % g.mtiles, ct = tile / g.mtiles;
+  const int m0 = mt * 128, c0 = ct * 128;
+  const int P = g.P;
+  const int ch0 = blockIdx.y * g.per_split;
+  const int ch1 = min(ch0 + g.per_split, g.chunks);
+  const int nch = ch1 - ch0;
+
+  const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(g.dy, (unsigned)((long long)g.N * g.M * P * 4));
+  const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(g.x, (unsigned)((long long)g.N * g.C * P * 4));
+
+  // a wave-instruction covers 16 rows x 64 B: lane -> row (lane >> 2), slot (lane & 3), which
+  // holds source piece slot ^ ((row >> 2) & 3)
+  const int d_row = lane >> 2, d_slot = lane & 3;
+  auto issue = [&](int chunk, int buf) {
+    const long long q = (long long)(ch0 + chunk) * BK;            // first column of the chunk
+    const int n = (int)(q / P), p = (int)(q - (long long)n * P);  // 16 | P: a chunk stays in one image
+    float* base = lds + buf * STAGE;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int inst = wave * 2 + u;                               // 8 instructions per operand
+      const int row = inst * 16 + d_row;
+      const int piece = d_slot ^ ((row >> 2) & 3);
+      const unsigned vy = (m0 + row < g.M) ? (unsigned)((((long long)n * g.M + m0 + row) * P + p + piece * 4) * 4) : kOob;
+      const unsigned vx = (c0 + row < g.C) ? (unsigned)((((long long)n * g.C + c0 + row) * P + p + piece * 4) * 4) : kOob;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrs, (lds_ptr)(base + inst * 256), 16, vy, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr)(base + TSTAGE + inst * 256), 16, vx, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.0f;
+
+  if (nch > 0) issue(0, 0);
+  if (nch > 1) issue(1, 1);
+  int buf = 0;
+  for (int c = 0; c < nch; ++c) {
+    if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (c + 2 < nch) issue(c + 2, buf == 0 ? 2 : buf - 1);
+    const float* s = lds + buf * STAGE;
+    // lane (j, h) reads the two pieces 2 * u + h of its row: reduction steps (u, e), e = 0..3
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float4 av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wm * 64 + i * 32 + j;
+        av[i] = *reinterpret_cast<const float4*>(s + row * BK + (((2 * u + h) ^ ((row >> 2) & 3)) << 2));
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = wn * 64 + t * 32 + j;
+        bv[t] = *reinterpret_cast<const float4*>(s + TSTAGE + row * BK + (((2 * u + h) ^ ((row >> 2) & 3)) << 2));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[t][e], acc[i][t], 0, 0, 0);
+    }
+    if (++buf == NSTAGE) buf = 0;
+  }
+
+  float* slab = g.part + (long long)blockIdx.y * g.M * g.C;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int c = c0 + wn * 64 + t * 32 + j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < g.M && c < g.C) slab[(long long)m * g.C + c] = acc[i][t][r];
+      }
+    }
+}
+
+// dW (+)= sum of the slabs in index order (deterministic); optionally also the transposed copy
+// Wt-shaped gradient is not needed: SGD runs on the natural layout.
+__global__ __launch_bounds__(kThreads) void gemm_conv_wgrad_reduce_kernel(const float* __restrict__ part,
+                                                                          int splits, long long n,
+                                                                          int accumulate,
+                                                                          float* __restrict__ dw) {
+  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.0f, s1 = 0.0f;
+  int k = 0;
+  for (; k + 1 < splits; k += 2) {
+    s0 += part[(long long)k * n + i];
+    s1 += part[(long long)(k + 1) * n + i];
+  }
+  if (k < splits) s0 += part[(long long)k * n + i];
+  const float s = s0 + s1;
+  dw[i] = accumulate ? dw[i] + s : s;
+}
+
+// Wt[k][m] = W[m][k] (the forward's A operand), rows padded to `ldm` with zeros
+__global__ __launch_bounds__(kThreads) void transpose_filter_kernel(const float* __restrict__ w, int M, int K,
+                                                                    int ldm, float* __restrict__ wt) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int m = m0 + r, k = k0 + tx;
+    tile[r][tx] = (m < M && k < K) ? w[(long long)m * K + k] : 0.0f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, m = m0 + tx;
+    if (k < K && m < ldm) wt[(long long)k * ldm + m] = tile[tx][r];
+  }
+}
+
+// y[n][c][oy][ox] = x[n][c][oy * s][ox * s] (the input of a strided pointwise convolution) and
+// its gradient (dx zero except at the sampled positions)
+__global__ __launch_bounds__(kThreads) void subsample_kernel(const float* __restrict__ x, long long planes,
+                                                             int H, int W, int s, int OH, int OW,
+                                                             float* __restrict__ y) {
+  const long long total = planes * OH * OW;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+    const int ox = (int)(i % OW);
+    const long long t = i / OW;
+    const int oy = (int)(t % OH);
+    const long long pl = t / OH;
+    y[i] = x[(pl * H + (long long)oy * s) * W + (long long)ox * s];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void subsample_grad_kernel(const float* __restrict__ dy, long long planes,
+                                                                  int H, int W, int s, int OH, int OW,
+                                                                  int accumulate, float* __restrict__ dx) {
+  const long long total = planes * H * W;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+    const int xw = (int)(i % W);
+    const long long t = i / W;
+    const int yh = (int)(t % H);
+    const long long pl = t / H;
+    float v = 0.0f;
+    if (yh % s == 0 && xw % s == 0 && yh / s < OH && xw / s < OW)
+      v = dy[(pl * OH + yh / s) * OW + xw / s];
+    dx[i] = accumulate ? dx[i] + v : v;
+  }
+}
+
+int pick_splits(int tiles, int chunks) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  // about three workgroups per CU, at least 8 chunks (128 columns) each
+  int s = (3 * cus + tiles - 1) / tiles;
+  const int cap = chunks / 8 > 0 ? chunks / 8 : 1;
+  if (s > cap) s = cap;
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssad_conv1x1_gemm(const ssad_gemm_conv* d, ssad_stream_t stream) {
+  if (!d || !d->a || !d->x || !d->y || d->N < 0 || d->K < 1 || d->P < 1 || d->M < 1) return SSAD_E_BADARG;
+  if (d->lda < d->M || (d->lda & 3) || (d->P & 3)) return SSAD_E_BADARG;        // 16-byte DMA pieces
+  if (((uintptr_t)d->a | (uintptr_t)d->x) & 15) return SSAD_E_BADARG;
+  if ((d->flags & SSAD_GEMM_ACCUMULATE) && (d->bias || d->residual)) return SSAD_E_BADARG;
+  const long long Q = (long long)d->N * d->P;
+  if (Q == 0) return 0;
+  const long long big = (long long)d->N * (d->K > d->M ? d->K : d->M) * d->P * 4;
+  if (big >= (1LL << 31) || (long long)d->K * d->lda * 4 >= (1LL << 31)) return SSAD_E_BADARG;
+  GemmArgs g;
+  g.a = d->a; g.x = d->x; g.y = d->y; g.bias = d->bias; g.res = d->residual; g.mask = d->mask;
+  g.lda = d->lda; g.N = d->N; g.K = d->K; g.P = d->P; g.M = d->M; g.flags = d->flags;
+  g.Q = Q;
+  g.ctiles = (int)((Q + BN - 1) / BN);
+  hipStream_t s = (hipStream_t)stream;
+  // 64-row tiles for 64-wide outputs, and wherever 128-row tiles would leave the chip with
+  // fewer than two workgroups per CU (res5 at bs 16 is 70 column tiles: 280 tiles of 128 rows
+  // put two workgroups on 24 CUs and one on the rest, i.e. the launch takes twice its share)
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  static const int force_bm = [] { const char* e = getenv("SSAD_GEMM_BM"); return e ? atoi(e) : 0; }();
+  const bool small = (long long)((d->M + 127) / 128) * g.ctiles < 2LL * cus;
+  if (force_bm == 64 || (force_bm != 128 && (d->M <= 64 || small))) {
+    g.mtiles = (d->M + 63) / 64;
+    hipLaunchKernelGGL(gemm_conv_nn_kernel<64>, dim3(g.mtiles * g.ctiles), dim3(kThreads), 0, s, g);
+  } else {
+    g.mtiles = (d->M + 127) / 128;
+    hipLaunchKernelGGL(gemm_conv_nn_kernel<128>, dim3(g.mtiles * g.ctiles), dim3(kThreads), 0, s, g);
+  }
+  return (int)hipGetLastError();
+}
+
+int ssad_transpose_filter(const float* w, int M, int K, int ldm, float* wt, ssad_stream_t stream) {
+  if (!w || !wt || M < 1 || K < 1 || ldm < M) return SSAD_E_BADARG;
+  hipLaunchKernelGGL(transpose_filter_kernel, dim3((K + 31) / 32, (ldm + 31) / 32), dim3(kThreads), 0,
+                     (hipStream_t)stream, w, M, K, ldm, wt);
+  return (int)hipGetLastError();
+}
+
+size_t ssad_conv1x1_wgrad_workspace_bytes(int N, int C, int P, int M) {
+  if (N < 1 || C < 1 || P < 1 || M < 1) return 0;
+  const int tiles = ((M + 127) / 128) * ((C + 127) / 128);
+  const int chunks = (int)(((long long)N * P) / BK);
+  return (size_t)pick_splits(tiles, chunks) * (size_t)M * (size_t)C * sizeof(float);
+}
+
+int ssad_conv1x1_wgrad(const float* x, const float* dy, int N, int C, int P, int M, float* dw,
+                       int accumulate, void* workspace, size_t workspace_bytes, ssad_stream_t stream) {
+  if (!x || !dy || !dw || N < 1 || C < 1 || P < 1 || M < 1) return SSAD_E_BADARG;
+  if ((P % BK) || (((uintptr_t)x | (uintptr_t)dy) & 15)) return SSAD_E_BADARG;
+  if ((long long)N * (C > M ? C : M) * P * 4 >= (1LL << 31)) return SSAD_E_BADARG;
+  if (!workspace || workspace_bytes < ssad_conv1x1_wgrad_workspace_bytes(N, C, P, M)) return SSAD_E_WORKSPACE;
+  WgradArgs g;
+  g.x = x; g.dy = dy; g.part = (float*)workspace;
+  g.N = N; g.C = C; g.P = P; g.M = M;
+  g.mtiles = (M + 127) / 128; g.ctiles = (C + 127) / 128;
+  g.chunks = (int)(((long long)N * P) / BK);
+  const int splits = pick_splits(g.mtiles * g.ctiles, g.chunks);
+  g.per_split = (g.chunks + splits - 1) / splits;
+  const int used = (g.chunks + g.per_split - 1) / g.per_split;        // splits that own >= 1 chunk
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gemm_conv_nt_kernel, dim3(g.mtiles * g.ctiles, used), dim3(kThreads), 0, s, g);
+  const long long n = (long long)M * C;
+  hipLaunchKernelGGL(gemm_conv_wgrad_reduce_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)),
+                     dim3(kThreads), 0, s, (const float*)g.part, used, n, accumulate, dw);
+  return (int)hipGetLastError();
+}
+
+int ssad_subsample(const float* x, int N, int C, int H, int W, int stride, float* y, ssad_stream_t stream) {
+  if (!x || !y || N < 0 || C < 1 || H < 1 || W < 1 || stride < 1) return SSAD_E_BADARG;
+  const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  const long long total = (long long)N * C * OH * OW;
+  if (total == 0) return 0;
+  long long b = (total + kThreads - 1) / kThreads;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)b), dim3(kThreads), 0, (hipStream_t)stream, x,
+                     (long long)N * C, H, W, stride, OH, OW, y);
+  return (int)hipGetLastError();
+}
+
+int ssad_subsample_grad(const float* dy, int N, int C, int H, int W, int stride, int accumulate, float* dx,
+                        ssad_stream_t stream) {
+  if (!dy || !dx || N < 0 || C < 1 || H < 1 || W < 1 || stride < 1) return SSAD_E_BADARG;
+  const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  const long long total = (long long)N * C * H * W;
+  if (total == 0) return 0;
+  long long b = (total + kThreads - 1) / kThreads;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(subsample_grad_kernel, dim3((unsigned)b), dim3(kThreads), 0, (hipStream_t)stream, dy,
+                     (long long)N * C, H, W, stride, OH, OW, accumulate, dx);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

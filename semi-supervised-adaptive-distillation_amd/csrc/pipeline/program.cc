@@ -110,6 +110,17 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
                                    i[1], i[2], s);
     case SSAD_OP_RELU_GRAD:
       return ssad_relu_grad((const float*)p[0], (const float*)p[1], (float*)p[2], o.l[0], s);
+    case SSAD_OP_GEMM_CONV:
+      return ssad_conv1x1_gemm((const ssad_gemm_conv*)p[0], s);
+    case SSAD_OP_CONV1X1_WGRAD:
+      return ssad_conv1x1_wgrad((const float*)p[0], (const float*)p[1], i[0], i[1], i[2], i[3], (float*)p[2],
+                                i[4], (void*)p[3], (size_t)o.l[0], s);
+    case SSAD_OP_TRANSPOSE_FILTER:
+      return ssad_transpose_filter((const float*)p[0], i[0], i[1], i[2], (float*)p[1], s);
+    case SSAD_OP_SUBSAMPLE:
+      return ssad_subsample((const float*)p[0], i[0], i[1], i[2], i[3], i[4], (float*)p[1], s);
+    case SSAD_OP_SUBSAMPLE_GRAD:
+      return ssad_subsample_grad((const float*)p[0], i[0], i[1], i[2], i[3], i[4], i[5], (float*)p[1], s);
     case SSAD_OP_CHANNEL_SUM:
       return ssad_channel_sum((const float*)p[0], i[0], i[1], i[2], (float*)p[1], i[3], s);
     default:

@@ -56,6 +56,12 @@ class SgdSegment(C.Structure):
     _fields_ = [("offset", C.c_int64), ("n", C.c_int64), ("is_bias", C.c_int)]
 
 
+class GemmConv(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p), ("bias", C.c_void_p),
+                ("residual", C.c_void_p), ("mask", C.c_void_p), ("lda", C.c_int), ("N", C.c_int),
+                ("K", C.c_int), ("P", C.c_int), ("M", C.c_int), ("flags", C.c_int)]
+
+
 class ConvLevel(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("aux", C.c_void_p),
                 ("N", C.c_int), ("H", C.c_int), ("W", C.c_int),
@@ -155,6 +161,13 @@ def lib():
     L.ssad_conv3x3_wgrad_workspace_bytes.restype = sz
     L.ssad_conv3x3_wgrad_workspace_bytes.argtypes = [C.POINTER(ConvLevel), i32, i32, i32]
     L.ssad_conv3x3_wgrad.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp, sz, vp]
+    L.ssad_conv1x1_gemm.argtypes = [C.POINTER(GemmConv), vp]
+    L.ssad_transpose_filter.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.ssad_conv1x1_wgrad_workspace_bytes.restype = sz
+    L.ssad_conv1x1_wgrad_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.ssad_conv1x1_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]
+    L.ssad_subsample.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+    L.ssad_subsample_grad.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_kernels_arch.restype = C.c_char_p
     L.ssad_kernels_abi_version.restype = i32
     _lib = L
@@ -769,3 +782,83 @@ def conv3x3_wgrad_f16(xbs, dybs, Cin, Cout, *, scale=1.0, dW=None, db=None, bias
     _check(L.ssad_conv3x3_wgrad_f16_levels(arr, n, Cin, Cout, 0, float(scale), _ptr(dW), _ptr(db), _ptr(ws),
                                            nbytes, _stream()), "conv3x3_wgrad_f16_levels")
     return dW, db
+
+
+# ---- pointwise convolution as an fp32-MFMA GEMM (row f1) -------------------------------------
+
+GEMM_RELU = 1
+GEMM_ACCUMULATE = 8
+
+
+def transpose_filter(w, out=None):
+    """[M][K](x1x1) -> W^T [K][ldm] with ldm = M rounded up to 4 (zero padded): the forward's A operand."""
+    M, Kc = w.shape[0], w.shape[1]
+    w2 = _f32c(w.reshape(M, Kc), "w")
+    ldm = (M + 3) // 4 * 4
+    wt = out if out is not None else torch.empty((Kc, ldm), dtype=torch.float32, device="cuda")
+    _check(lib().ssad_transpose_filter(_ptr(w2), M, Kc, ldm, _ptr(wt), _stream()), "transpose_filter")
+    return wt
+
+
+def gemm_conv_desc(a, lda, x, y, K, M, bias=None, residual=None, mask=None, relu=False, accumulate=False):
+    N = x.shape[0]
+    P = x.numel() // max(N * K, 1)
+    return GemmConv(a.data_ptr(), x.data_ptr(), y.data_ptr(), bias.data_ptr() if bias is not None else 0,
+                    residual.data_ptr() if residual is not None else 0,
+                    mask.data_ptr() if mask is not None else 0, lda, N, K, P, M,
+                    (GEMM_RELU if relu else 0) | (GEMM_ACCUMULATE if accumulate else 0))
+
+
+def conv1x1_forward(x, wt, M, bias=None, residual=None, relu=False, out=None):
+    """act(conv1x1(x, W) + bias (+ residual)) with W^T from transpose_filter (x: N x K x H x W)."""
+    _f32c(x, "x"); _f32c(wt, "wt")
+    N, Kc, H, W = x.shape
+    y = out if out is not None else torch.empty((N, M, H, W), dtype=torch.float32, device="cuda")
+    d = gemm_conv_desc(wt, wt.shape[1], x, y, Kc, M, bias, residual, None, relu, False)
+    _check(lib().ssad_conv1x1_gemm(C.byref(d), _stream()), "conv1x1_gemm")
+    return y
+
+
+def conv1x1_dgrad(dy, w, mask=None, accumulate_into=None):
+    """dX = W^T . dY (w: [M][C](x1x1) natural layout), optionally masked by mask > 0, optionally
+    added onto `accumulate_into`."""
+    _f32c(dy, "dy")
+    N, M, H, W = dy.shape
+    Cc = w.shape[1]
+    w2 = _f32c(w.reshape(M, Cc), "w")
+    dx = accumulate_into if accumulate_into is not None else torch.empty((N, Cc, H, W), dtype=torch.float32,
+                                                                     device="cuda")
+    d = gemm_conv_desc(w2, Cc, dy, dx, M, Cc, None, None, mask, False, accumulate_into is not None)
+    _check(lib().ssad_conv1x1_gemm(C.byref(d), _stream()), "conv1x1_gemm (dgrad)")
+    return dx
+
+
+def conv1x1_wgrad(x, dy, out=None, accumulate=False):
+    """dW [M][C] = sum_{n,p} dy[n][m][p] x[n][c][p]."""
+    _f32c(x, "x"); _f32c(dy, "dy")
+    N, Cc, H, W = x.shape
+    M = dy.shape[1]
+    dw = out if out is not None else torch.empty((M, Cc), dtype=torch.float32, device="cuda")
+    nb = lib().ssad_conv1x1_wgrad_workspace_bytes(N, Cc, H * W, M)
+    ws = _workspace(nb, "wgrad1x1")
+    _check(lib().ssad_conv1x1_wgrad(_ptr(x), _ptr(dy), N, Cc, H * W, M, _ptr(dw), int(accumulate), _ptr(ws), nb,
+                                    _stream()), "conv1x1_wgrad")
+    return dw
+
+
+def subsample(x, stride=2):
+    _f32c(x, "x")
+    N, Cc, H, W = x.shape
+    y = torch.empty((N, Cc, (H - 1) // stride + 1, (W - 1) // stride + 1), dtype=torch.float32, device="cuda")
+    _check(lib().ssad_subsample(_ptr(x), N, Cc, H, W, stride, _ptr(y), _stream()), "subsample")
+    return y
+
+
+def subsample_grad(dy, H, W, stride=2, accumulate_into=None):
+    _f32c(dy, "dy")
+    N, Cc = dy.shape[0], dy.shape[1]
+    dx = accumulate_into if accumulate_into is not None else torch.empty((N, Cc, H, W), dtype=torch.float32,
+                                                                     device="cuda")
+    _check(lib().ssad_subsample_grad(_ptr(dy), N, Cc, H, W, stride, int(accumulate_into is not None), _ptr(dx),
+                                     _stream()), "subsample_grad")
+    return dx

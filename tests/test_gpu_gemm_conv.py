@@ -1,0 +1,113 @@
+"""Pointwise convolution as an fp32-MFMA GEMM (csrc/kernels/gemm_conv.hip; row f1): forward with
+the bottleneck tail in the epilogue, data gradient (mask / accumulate), filter gradient, the
+strided variant through ssad_subsample -- against the oracle (which restates
+caffe2/operators/conv_op_impl.h and is pinned by the reference's compiled operators,
+tests/test_oracle_golden.py) and against the stored outputs of the reference operators."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ssad_amd  # noqa: F401
+from oracle import oracle
+import make_golden as mg
+from test_gpu_kernels import CONV_FLOOR, CONV_RTOL, close, dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from ssad_amd import kernels
+    kernels.lib()
+    return kernels
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 64, 64, 12, 16),       # 64-wide output: the 64 x 128 tile
+    (2, 24, 40, 9, 12),        # K tail (24), M tail (40), P = 108: columns flattened across images
+    (3, 256, 128, 10, 14),     # P = 140: a tile spans two images
+    (1, 128, 512, 20, 28),     # res3 c3 at small size, 4 M tiles
+    (2, 2048, 512, 5, 8),      # res5 c1: 128 K chunks
+    (1, 16, 8, 2, 2),          # tiny: one partial tile, P = 4
+], ids=lambda s: "N%d_C%d_M%d_%dx%d" % s)
+def test_gemm_conv_forward_dgrad_wgrad_vs_oracle(K, shape):
+    N, Cin, M, H, W = shape
+    rng = np.random.default_rng(sum(shape))
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, 1, 1)) * (1.0 / np.sqrt(Cin))).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    R = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    dY = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    tw, tx = dev(Wt), dev(X)
+    wt = K.transpose_filter(tw)
+    ref = oracle.conv_forward(X, Wt, b, kernel=1, stride=1, pad=0)
+    close(K.conv1x1_forward(tx, wt, M, dev(b)).cpu().numpy(), ref, CONV_RTOL, CONV_FLOOR, "Y")
+    close(K.conv1x1_forward(tx, wt, M, dev(b), dev(R), relu=True).cpu().numpy(), np.maximum(ref + R, 0), CONV_RTOL,
+          CONV_FLOOR, "relu(Y + R)")
+    close(K.conv1x1_forward(tx, wt, M).cpu().numpy(), oracle.conv_forward(X, Wt, None, kernel=1, stride=1, pad=0),
+          CONV_RTOL, CONV_FLOOR, "Y no bias")
+    if (H * W) % 16 == 0 or True:
+        rdW, rdb, rdX = oracle.conv_backward(X, Wt, dY, kernel=1, stride=1, pad=0)
+        tdy = dev(dY)
+        close(K.conv1x1_dgrad(tdy, tw).cpu().numpy(), rdX, CONV_RTOL, CONV_FLOOR, "dX")
+        # fused ReluGradient mask and accumulation onto an existing gradient
+        mask = np.maximum(rng.standard_normal(X.shape), 0).astype(np.float32)
+        close(K.conv1x1_dgrad(tdy, tw, mask=dev(mask)).cpu().numpy(), np.where(mask > 0, rdX, 0), CONV_RTOL,
+              CONV_FLOOR, "masked dX")
+        base = rng.standard_normal(X.shape).astype(np.float32)
+        got = K.conv1x1_dgrad(tdy, tw, accumulate_into=dev(base)).cpu().numpy()
+        close(got, base + rdX, CONV_RTOL, CONV_FLOOR, "dX accumulated")
+        if (H * W) % 16 == 0:
+            dW = K.conv1x1_wgrad(tx, tdy)
+            close(dW.cpu().numpy(), rdW.reshape(M, Cin), CONV_RTOL, CONV_FLOOR, "dW")
+            dW2 = K.conv1x1_wgrad(tx, tdy, out=dW.clone(), accumulate=True)
+            close(dW2.cpu().numpy(), 2 * rdW.reshape(M, Cin), CONV_RTOL, CONV_FLOOR, "dW accumulate")
+            assert torch.equal(K.conv1x1_wgrad(tx, tdy), dW)            # deterministic
+
+
+def test_gemm_conv_vs_reference_operator_golden(K, golden_dir):
+    """k1s1 and k1s2 of tests/golden/conv_ref.npz (outputs of the reference's compiled
+    ConvOp / ConvGradientOp): the strided layer = the pointwise layer on the subsampled map."""
+    g = np.load(os.path.join(golden_dir, "conv_ref.npz"))
+    for name in ("k1s1", "k1s2"):
+        seed, N, Cin, M, H, W, k, s, p, grp = [int(v) for v in g[name + "_dims"]]
+        X, Wt, b, dY = mg.conv_ref_inputs(seed, N, Cin, M, H, W, k, s, p, grp)
+        tx, tw = dev(X), dev(Wt)
+        oh, ow = (H - 1) // s + 1, (W - 1) // s + 1
+        if (oh * ow) % 4:            # the GEMM kernel wants 16-byte pixel rows (every backbone map has)
+            with pytest.raises(K.KernelError):
+                K.conv1x1_forward(tx, K.transpose_filter(tw), M)
+            continue
+        xs = K.subsample(tx, s) if s > 1 else tx
+        if s > 1:
+            assert np.array_equal(xs.cpu().numpy(), X[:, :, ::s, ::s])
+        wt = K.transpose_filter(tw)
+        Y = K.conv1x1_forward(xs, wt, M, dev(b)).cpu().numpy()
+        close(Y.ravel()[g[name + "_Y_idx"]], g[name + "_Y"], CONV_RTOL, CONV_FLOOR, name + " Y")
+        dxs = K.conv1x1_dgrad(dev(dY), tw)
+        dX = K.subsample_grad(dxs, H, W, s) if s > 1 else dxs
+        close(dX.cpu().numpy().ravel()[g[name + "_dX_idx"]], g[name + "_dX"], CONV_RTOL, CONV_FLOOR, name + " dX")
+
+
+def test_gemm_conv_full_size_adjoints(K):
+    """res4's 1024 -> 256 layer at bs 16 (P = 40 x 56): <conv(X), dY> = <X, dgrad(dY)> = <W, wgrad>,
+    plus one image against the oracle."""
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    N, Cin, M, H, W = 16, 1024, 256, 40, 56
+    X = torch.randn((N, Cin, H, W), device="cuda", generator=gen)
+    dY = torch.randn((N, M, H, W), device="cuda", generator=gen)
+    Wt = torch.randn((M, Cin, 1, 1), device="cuda", generator=gen) * 0.03
+    wt = K.transpose_filter(Wt)
+    Y = K.conv1x1_forward(X, wt, M)
+    dX = K.conv1x1_dgrad(dY, Wt)
+    dW = K.conv1x1_wgrad(X, dY)
+    a = float((Y.double() * dY.double()).sum())
+    b = float((X.double() * dX.double()).sum())
+    c = float((Wt.view(M, Cin).double() * dW.double()).sum())
+    scale = float((Y.double().abs() * dY.double().abs()).sum())
+    assert abs(a - b) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, b, c, scale)
+    n0 = 13
+    ref = oracle.conv_forward(X[n0:n0 + 1].cpu().numpy(), Wt.cpu().numpy(), None, kernel=1, stride=1, pad=0)
+    close(Y[n0:n0 + 1].cpu().numpy(), ref, CONV_RTOL, CONV_FLOOR, "full-size slice")
