@@ -59,6 +59,9 @@ def parse():
     # subnet precision: f32 (the metric's precision, default) or fp16 storage / fp32 accumulation
     # (config 5; backbones stay fp32).  An f16 line is NOT the headline number.
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"])
+    # backbones: "native" = programs of this repo's kernels (ResNet-50/101, fp32);
+    # "harness" = the PyTorch harness (MIOpen / rocBLAS; needed for ResNeXt and the fp16 run)
+    ap.add_argument("--backbone", default="auto", choices=["auto", "native", "harness"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="auto")
     return ap.parse_args()
@@ -245,10 +248,20 @@ def main():
               "FPN features; the whole step is one native program of this repo's HIP kernels" % (
                   "teacher fwd, " if distill else "", losses_txt))
     else:
-        from ssad_amd.harness.full_model import FullDistillModel
-        model = FullDistillModel(heads, student_depth=args.student,
-                                 teacher_depth=args.teacher if distill else None, device=dev,
-                                 backbone_f16=f16, process_group=pg, world_size=world)
+        native_ok = (not f16) and args.student in ("r50", "r101") and args.teacher in ("none", "r50", "r101")
+        if args.backbone == "native" and not native_ok:
+            sys.stderr.write("bench.py: --backbone native covers ResNet-50/101 in fp32\n")
+            sys.exit(2)
+        if args.backbone == "native" or (args.backbone == "auto" and native_ok):
+            from ssad_amd.backbone_pipeline import NativeDistillModel
+            model = NativeDistillModel(heads, student_arch=args.student,
+                                       teacher_arch=args.teacher if distill else None, N=N, image_hw=image_hw,
+                                       device=dev, process_group=pg, world_size=world)
+        else:
+            from ssad_amd.harness.full_model import FullDistillModel
+            model = FullDistillModel(heads, student_depth=args.student,
+                                     teacher_depth=args.teacher if distill else None, device=dev,
+                                     backbone_f16=f16, process_group=pg, world_size=world)
         images = torch.randn((N, 3) + image_hw, device=dev, generator=gen)
 
         def step():
@@ -301,6 +314,7 @@ def main():
         prefix = "conv3x3_f16_kernel" if f16 else ("wino_conv_z_kernel" if dom_k == 2 else "conv3x3_kernel<8, 1")
         traffic, traffic_note = pmc_traffic(prefix)
         heads_ms = sum(r["ms_per_step"] for r in rows if r["class"] < 48)
+        backbone_ms = sum(r["ms_per_step"] for r in rows if r["class"] >= 48)
         out = {
             "metric": METRIC, "value": round(world * N * args.steps / dt, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -328,6 +342,7 @@ def main():
                              flops_per_launch=dom["flops_per_launch"]) if dom else None,
             "kernels": rows,
             "subnets_ms_per_step": round(heads_ms, 3),
+            "backbone_kernels_ms_per_step": round(backbone_ms, 3),
         }
         for key, k in (("roofline_loss", 9 if distill else 15), ("roofline_pow_sum", 8)):
             r = by.get(k)

@@ -359,6 +359,9 @@ SSAD_API int ssad_conv_out_size(int in, int kernel, int dilation, int pad_a, int
 SSAD_API int ssad_im2col(const float* x, int C, int H, int W, int kh, int kw, int dil_h, int dil_w,
                          int pad_t, int pad_l, int pad_b, int pad_r, int stride_h, int stride_w,
                          float* col, ssad_stream_t stream);
+/* Im2col of a whole batch, square kernel / stride / pad: col[n][C*k*k][OH*OW] */
+SSAD_API int ssad_im2col_batched(const float* x, int N, int C, int H, int W, int kernel, int stride,
+                                 int pad, float* col, ssad_stream_t stream);
 SSAD_API int ssad_col2im(const float* col, int C, int H, int W, int kh, int kw, int dil_h,
                          int dil_w, int pad_t, int pad_l, int pad_b, int pad_r, int stride_h,
                          int stride_w, float* x, ssad_stream_t stream);

@@ -126,7 +126,11 @@ enum ssad_opcode {
   /* ssad_subsample(p0 = x, i0..i3 = N, C, H, W, i4 = stride, p1 = y) */
   SSAD_OP_SUBSAMPLE = 58,
   /* ssad_subsample_grad(p0 = dy, i0..i3 = N, C, H, W, i4 = stride, i5 = accumulate, p1 = dx) */
-  SSAD_OP_SUBSAMPLE_GRAD = 59
+  SSAD_OP_SUBSAMPLE_GRAD = 59,
+  /* ssad_relu(p0 = x, p1 = y, l0 = n) */
+  SSAD_OP_RELU = 60,
+  /* ssad_im2col_batched(p0 = x, i0..i3 = N, C, H, W, i4 = kernel, i5 = stride, i6 = pad, p1 = col) */
+  SSAD_OP_IM2COL_BATCHED = 61
 };
 
 typedef struct ssad_op {

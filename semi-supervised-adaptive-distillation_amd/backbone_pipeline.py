@@ -1,0 +1,564 @@
+"""ResNet-FPN backbone (row f1) as a native program of this repo's kernels -- forward, backward
+through res3..res5 + FPN, and the SGD update, with no torch operator in the step.
+
+Structure of the network: detectron/lib/modeling/ResNet.py:85-130,221-283 (bottleneck stages
+3-4-{6,23}-3, stride on the first 1x1 as with the MSRA weights, frozen BN = AffineChannel,
+folded into the convolution that precedes it: W' = s W, bias = b; stem + res2 frozen,
+TRAIN.FREEZE_CONV_BODY / FREEZE_AT = 2) and FPN.py:116-250 for RetinaNet (laterals on
+res3..res5, top-down nearest upsampling + Sum, 3x3 output convs, P6 = conv3x3/2 on res5,
+P7 = conv3x3/2 on relu(P6)).
+
+Kernels:
+  * every pointwise convolution (bottleneck 1x1s, projection shortcuts, laterals): the fp32-MFMA
+    GEMM of csrc/kernels/gemm_conv.hip with bias / shortcut Sum / ReLU in its epilogue (forward),
+    the ReluGradient mask and gradient accumulation in its epilogue (data gradient), and the
+    split-reduction filter gradient;
+  * every 3x3 / stride 1 convolution: the Winograd engine of the subnets (forward, data
+    gradient with the fused ReluGradient mask, filter + bias gradient);
+  * the stride-2 pointwise layers run on ssad_subsample's output (shared by c1 and the
+    projection); P6 / P7 (3x3 / stride 2) = the stride-1 convolution followed by subsampling --
+    the outputs at even positions are exactly the strided convolution's -- which costs 4x the
+    flops of two small layers and needs no further kernel;
+  * the 7x7 / stride 2 stem: batched im2col + the same GEMM, then bias + ReLU + 3x3/2 max pool
+    in one pass (ssad_max_pool3x3s2_bias_relu).
+
+All activations, gradients and packed filters are allocated once; the step is
+Program.run() calls (ssad_program_run) -- a few segments when data parallel, so that a stage's
+gradient bucket is all-reduced while the earlier stages are still in backward.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import program as PR
+from .data_parallel import BucketedAllReduce
+
+ARCHS = {"r50": (3, 4, 6, 3), "r101": (3, 4, 23, 3)}
+
+
+class _Layer(object):
+    __slots__ = ("name", "k", "cin", "cout", "stride", "train", "w", "b", "gw", "gb", "wt", "pf", "pd")
+
+    def __init__(self, name, k, cin, cout, stride, train):
+        self.name, self.k, self.cin, self.cout, self.stride, self.train = name, k, cin, cout, stride, train
+        self.w = self.b = self.gw = self.gb = self.wt = self.pf = self.pd = None
+
+
+class NativeResNetFPN(object):
+    def __init__(self, arch="r50", N=2, image_hw=(640, 896), device="cuda", train=True, src=None,
+                 fpn_dim=256, lr=1e-5, momentum=0.9, weight_decay=1e-4, process_group=None, world_size=1):
+        if arch not in ARCHS:
+            raise K.KernelError("native backbone: architectures %s (ResNeXt's grouped 3x3 runs on the harness)"
+                                % sorted(ARCHS))
+        self.arch, self.N, self.hw, self.device, self.train = arch, N, tuple(image_hw), device, train
+        self.D = fpn_dim
+        self.momentum, self.weight_decay = momentum, weight_decay
+        self.dp = BucketedAllReduce(process_group, world_size)
+        self.timing = None
+        H, W = self.hw
+        if H % 128 or W % 128:
+            raise K.KernelError("native backbone: image sides must be multiples of 128 (16-pixel-multiple "
+                                "maps down to res5; 640x896 and 512x768 are)")
+        self._layers = OrderedDict()
+        self._define_layers()
+        self._alloc_params(src)
+        self.lr = torch.full((1,), lr, dtype=torch.float32, device=device)
+        self._build()
+
+    # -- network definition -------------------------------------------------------------
+    def _define_layers(self):
+        L = self._layers
+
+        def add(name, k, cin, cout, stride=1, train=True):
+            L[name] = _Layer(name, k, cin, cout, stride, train and self.train)
+        add("stem.0", 7, 3, 64, 2, train=False)
+        cin = 64
+        self.blocks = []                       # (stage, j, cin, cmid, cout, stride, has_proj, trainable)
+        for si, nblk in enumerate(ARCHS[self.arch]):
+            stage = si + 2
+            cmid, cout = 64 * 2 ** si, 256 * 2 ** si
+            tr = stage > 2                     # FREEZE_AT = 2: the stem and res2 stay frozen
+            for j in range(nblk):
+                stride = 2 if (j == 0 and si > 0) else 1
+                pre = "res%d.%d" % (stage, j)
+                add(pre + ".c1", 1, cin, cmid, stride, tr)
+                add(pre + ".c2", 3, cmid, cmid, 1, tr)
+                add(pre + ".c3", 1, cmid, cout, 1, tr)
+                proj = cin != cout or stride != 1
+                if proj:
+                    add(pre + ".proj", 1, cin, cout, stride, tr)
+                self.blocks.append((stage, j, cin, cmid, cout, stride, proj, tr and self.train))
+                cin = cout
+        for i, c in enumerate((2048, 1024, 512)):
+            add("lat.%d" % i, 1, c, self.D)
+        for i in range(3):
+            add("out.%d" % i, 3, self.D, self.D)
+        add("p6", 3, 2048, self.D, 2)
+        add("p7", 3, self.D, self.D, 2)
+
+    def _bucket_order(self):
+        """Trainable layers in the order the backward pass finishes them, grouped into the
+        all-reduce buckets FPN, res5, res4, res3 ("backbone 4-6 buckets")."""
+        groups = OrderedDict([("fpn", []), ("res5", []), ("res4", []), ("res3", [])])
+        for name in ("p7", "p6", "out.0", "out.1", "out.2", "lat.0", "lat.1", "lat.2"):
+            groups["fpn"].append(name)
+        for stage in (5, 4, 3):
+            n = ARCHS[self.arch][stage - 2]
+            for j in range(n - 1, -1, -1):
+                for part in ("c3", "proj", "c2", "c1"):
+                    name = "res%d.%d.%s" % (stage, j, part)
+                    if name in self._layers:
+                        groups["res%d" % stage].append(name)
+        return groups
+
+    def _alloc_params(self, src):
+        dev = self.device
+        L = self._layers
+        if src is None:
+            from .harness.full_model import ResNetFPN
+            with torch.random.fork_rng():
+                torch.manual_seed(7)
+                src = ResNetFPN(self.arch, self.D)
+        sd = {k: v.detach() for k, v in src.state_dict().items()}
+        frozen = [l for l in L.values() if not l.train]
+        groups = self._bucket_order() if self.train else OrderedDict()
+        order = [L[n] for g in groups.values() for n in g]
+        assert len(order) + len(frozen) == len(L) or not self.train
+
+        def size(l):
+            return l.cout * l.cin * l.k * l.k + l.cout
+
+        self.frozen_flat = torch.empty(sum(size(l) for l in frozen), dtype=torch.float32, device=dev)
+        off = 0
+        for l in frozen:
+            nw = l.cout * l.cin * l.k * l.k
+            l.w = self.frozen_flat[off:off + nw].view(l.cout, l.cin, l.k, l.k)
+            l.b = self.frozen_flat[off + nw:off + nw + l.cout]
+            off += nw + l.cout
+        n_train = sum(size(l) for l in order)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.params_flat = torch.empty(n_train, **f32)
+        self.grads_flat = torch.zeros(n_train, **f32)
+        self.moms_flat = torch.zeros(n_train, **f32)
+        self.bucket, self.segments = OrderedDict(), []
+        off = 0
+        for gname, names in groups.items():
+            start = off
+            for n in names:
+                l = L[n]
+                nw = l.cout * l.cin * l.k * l.k
+                l.w = self.params_flat[off:off + nw].view(l.cout, l.cin, l.k, l.k)
+                l.gw = self.grads_flat[off:off + nw].view(l.cout, l.cin, l.k, l.k)
+                self.segments.append((off, nw, 0))
+                off += nw
+                l.b = self.params_flat[off:off + l.cout]
+                l.gb = self.grads_flat[off:off + l.cout]
+                self.segments.append((off, l.cout, 1))
+                off += l.cout
+            self.bucket[gname] = self.grads_flat[start:off]
+        for l in L.values():
+            l.w.copy_(sd[l.name + ".weight"].to(dev))
+            l.b.copy_(sd[l.name + ".bias"].to(dev))
+
+    def load_from(self, module):
+        """Copy the parameters of a harness ResNetFPN (same layer names)."""
+        sd = module.state_dict()
+        for l in self._layers.values():
+            l.w.copy_(sd[l.name + ".weight"])
+            l.b.copy_(sd[l.name + ".bias"])
+        self._packed_frozen = False
+
+    # -- small emit helpers -------------------------------------------------------------------
+    def _t(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _gemm(self, P, a, lda, x, y, Kc, M, bias=None, res=None, mask=None, relu=False, acc=False, klass=50):
+        d = K.gemm_conv_desc(a, lda, x, y, Kc, M, bias, res, mask, relu, acc)
+        px = x.numel() // Kc
+        P.add(PR.GEMM_CONV, klass, p=(d,), work=2.0 * px * Kc * M,
+              keep=[t for t in (a, x, y, bias, res, mask) if t is not None])
+
+    def _conv3(self, P, probs, Cout, Cin, flags, klass=48):
+        """probs: [(x, y, mask or None, packed, bias or None)]: independent 3x3 convolutions of one
+        (Cout, Cin) in one launch."""
+        arr = (K.ConvLevel * len(probs))()
+        for i, (x, y, mask, packed, bias) in enumerate(probs):
+            arr[i] = K.ConvLevel(x.data_ptr(), y.data_ptr(), mask.data_ptr() if mask is not None else 0,
+                                 x.shape[0], x.shape[2], x.shape[3], packed.data_ptr(),
+                                 bias.data_ptr() if bias is not None else 0)
+        px = sum(p[0].shape[0] * p[0].shape[2] * p[0].shape[3] for p in probs)
+        P.add(PR.CONV3X3, klass, i=(len(probs), Cout, Cin, flags, 1), p=(arr, None, None),
+              work=2.0 * 9 * Cout * Cin * px, keep=[t for p in probs for t in p if t is not None])
+
+    def _wgrad3(self, P, x, dy, layer):
+        arr = (K.ConvLevel * 1)()
+        arr[0] = K.ConvLevel(x.data_ptr(), 0, dy.data_ptr(), x.shape[0], x.shape[2], x.shape[3], 0, 0)
+        nb = K.lib().ssad_conv3x3_wgrad_workspace_bytes(arr, 1, layer.cout, layer.cin)
+        self._ws_need = max(self._ws_need, nb)
+        idx = P.add(PR.CONV3X3_WGRAD, 49, i=(1, layer.cout, layer.cin, 0), l=(nb,),
+                    p=(arr, layer.gw, layer.gb, None),
+                    work=2.0 * 9 * layer.cout * layer.cin * x.shape[0] * x.shape[2] * x.shape[3], keep=[x, dy])
+        self._ws_ops.append((idx, 3))
+
+    def _wgrad1(self, P, x, dy, layer):
+        N, Cc = x.shape[0], x.shape[1]
+        pix = x.shape[2] * x.shape[3]
+        nb = K.lib().ssad_conv1x1_wgrad_workspace_bytes(N, Cc, pix, layer.cout)
+        self._ws_need = max(self._ws_need, nb)
+        idx = P.add(PR.CONV1X1_WGRAD, 52, i=(N, Cc, pix, layer.cout, 0), l=(nb,),
+                    p=(x, dy, layer.gw, None), work=2.0 * N * pix * Cc * layer.cout, keep=[x, dy])
+        self._ws_ops.append((idx, 3))
+
+    def _bias_grad(self, P, dz, layer, rowsum=None):
+        """db[c] = sum over n, pixels of dz; from the [N][C] plane sums when a ReluGradient pass
+        already produced them."""
+        if rowsum is not None:
+            P.add(PR.CHANNEL_SUM, 51, i=(rowsum.shape[0], rowsum.shape[1], 1, 0), p=(rowsum, layer.gb),
+                  work=4.0 * rowsum.numel())
+        else:
+            N, Cc = dz.shape[0], dz.shape[1]
+            P.add(PR.CHANNEL_SUM, 51, i=(N, Cc, dz.shape[2] * dz.shape[3], 0), p=(dz, layer.gb),
+                  work=4.0 * dz.numel())
+
+    def _ew(self, P, code, i=(), p=(), l=(), f=(), nbytes=0.0):
+        P.add(code, 51, i=i, p=p, l=l, f=f, work=nbytes)
+
+    # -- program construction ----------------------------------------------------------------------
+    def _build(self):
+        self._ws_need, self._ws_ops = 0, []
+        L = self._layers
+        dev = self.device
+        lib = K.lib()
+        # packed filters: frozen layers once (prepare program), trainable layers every step (pack segment)
+        prep, P = PR.Program(), PR.Program()
+        self.prep, self.prog = prep, P
+        wino_frozen, wino_train = [], []
+        P.mark("pack")
+        for l in L.values():
+            tgt = P if l.train else prep
+            if l.k == 1:
+                ldm = (l.cout + 3) // 4 * 4
+                l.wt = self._t(l.cin, ldm)
+                tgt.add(PR.TRANSPOSE_FILTER, 54, i=(l.cout, l.cin, ldm), p=(l.w, l.wt),
+                        work=8.0 * l.cout * l.cin)
+            elif l.k == 3:
+                l.pf = self._t(lib.ssad_conv_wino_filter_floats(l.cout, l.cin))
+                need_pd = l.train                  # every trainable 3x3 sends a gradient further down
+                l.pd = self._t(lib.ssad_conv_wino_filter_floats(l.cin, l.cout)) if need_pd else None
+                (wino_train if l.train else wino_frozen).append(l)
+            else:                                                    # stem: [147][64]
+                l.wt = self._t(l.cin * l.k * l.k, l.cout)
+                tgt.add(PR.TRANSPOSE_FILTER, 54, i=(l.cout, l.cin * l.k * l.k, l.cout), p=(l.w, l.wt),
+                        work=8.0 * l.w.numel())
+        for tgt, ls in ((prep, wino_frozen), (P, wino_train)):
+            if ls:
+                tab = (K.PackEntry * len(ls))()
+                for i, l in enumerate(ls):
+                    tab[i] = K.PackEntry(l.w.data_ptr(), l.cout, l.cin, l.pf.data_ptr(),
+                                         l.pd.data_ptr() if l.pd is not None else 0)
+                tgt.add(PR.WINO_PACK_FILTERS, 54, i=(len(ls),), p=(tab,),
+                        work=4.0 * sum(l.w.numel() + l.pf.numel() + (l.pd.numel() if l.pd is not None else 0)
+                                       for l in ls))
+        prep.build()
+        self._packed_frozen = False
+        P.mark("forward")
+        self._emit_forward(P)
+        P.mark("backward")
+        if self.train:
+            self._emit_backward(P)
+            P.mark("sgd")
+            tab = (K.SgdSegment * len(self.segments))()
+            for i, (off, n, isb) in enumerate(self.segments):
+                tab[i] = K.SgdSegment(off, n, isb)
+            P.add(PR.SGD_FLAT, 55, i=(len(self.segments),), f=(self.momentum, self.weight_decay),
+                  p=(self.params_flat, self.grads_flat, self.moms_flat, self.lr, tab, None),
+                  work=4.0 * 6 * self.params_flat.numel())
+        P.mark("end")
+        self.ws = torch.empty(max(self._ws_need, 16), dtype=torch.uint8, device=dev)
+        for idx, slot in self._ws_ops:
+            P.set_ptr(idx, slot, self.ws)
+        P.build()
+
+    # -- forward ----------------------------------------------------------------------------------------
+    def _emit_forward(self, P):
+        L, N = self._layers, self.N
+        H, W = self.hw
+        self.image = self._t(N, 3, H, W)
+        # stem: im2col + GEMM (K = 147), then bias + ReLU + 3x3/2 max pool in one pass.  The column
+        # buffer of the whole batch is ~1.35 GB at 640x896 x 16: processed in image groups below 2 GiB.
+        st = L["stem.0"]
+        oh, ow = H // 2, W // 2
+        kk = 3 * 49
+        per = kk * oh * ow * 4
+        grp = max(1, min(N, int((1 << 31) - 1) // max(per, st.cout * oh * ow * 4)))
+        self.stem_col = self._t(grp, kk, oh, ow)
+        self.stem_z = self._t(N, 64, oh, ow)
+        for n0 in range(0, N, grp):
+            n1 = min(N, n0 + grp)
+            P.add(PR.IM2COL_BATCHED, 53, i=(n1 - n0, 3, H, W, 7, 2, 3), p=(self.image[n0:n1], self.stem_col),
+                  work=0.0)
+            self._gemm(P, st.wt, st.cout, self.stem_col[:n1 - n0], self.stem_z[n0:n1], kk, st.cout, klass=53)
+        c1 = self._t(N, 64, oh // 2, ow // 2)
+        self._ew(P, PR.STEM_POOL, i=(N, 64, oh, ow, 1), p=(self.stem_z, st.b, c1), nbytes=4.0 * 1.25 * self.stem_z.numel())
+        x = c1
+        self.saved = {}
+        stage_out = {}
+        for (stage, j, cin, cmid, cout, stride, proj, tr) in self.blocks:
+            pre = "res%d.%d" % (stage, j)
+            l1, l2, l3 = L[pre + ".c1"], L[pre + ".c2"], L[pre + ".c3"]
+            h, w = x.shape[2] // stride, x.shape[3] // stride
+            xs = x
+            if stride != 1:
+                xs = self._t(N, cin, h, w)
+                self._ew(P, PR.SUBSAMPLE, i=(N, cin, x.shape[2], x.shape[3], stride), p=(x, xs), nbytes=8.0 * xs.numel())
+            y1, y2, y = self._t(N, cmid, h, w), self._t(N, cmid, h, w), self._t(N, cout, h, w)
+            self._gemm(P, l1.wt, l1.wt.shape[1], xs, y1, cin, cmid, bias=l1.b, relu=True)
+            self._conv3(P, [(y1, y2, None, l2.pf, l2.b)], cmid, cmid, K.CONV_RELU)
+            sc = xs
+            if proj:
+                lp = L[pre + ".proj"]
+                sc = self._t(N, cout, h, w)
+                self._gemm(P, lp.wt, lp.wt.shape[1], xs, sc, cin, cout, bias=lp.b)
+            self._gemm(P, l3.wt, l3.wt.shape[1], y2, y, cmid, cout, bias=l3.b, res=sc, relu=True)
+            self.saved[pre] = dict(x=x, xs=xs, y1=y1, y2=y2, y=y)
+            x = y
+            stage_out[stage] = y
+        c3, c4, c5 = stage_out[3], stage_out[4], stage_out[5]
+        self.c345 = (c3, c4, c5)
+        D = self.D
+        # FPN: laterals (GEMM + bias), top-down nearest upsampling + Sum in place
+        t5 = self._t(N, D, c5.shape[2], c5.shape[3])
+        t4 = self._t(N, D, c4.shape[2], c4.shape[3])
+        t3 = self._t(N, D, c3.shape[2], c3.shape[3])
+        for t, c, name in ((t5, c5, "lat.0"), (t4, c4, "lat.1"), (t3, c3, "lat.2")):
+            l = L[name]
+            self._gemm(P, l.wt, l.wt.shape[1], c, t, l.cin, D, bias=l.b)
+            if t is not t5:
+                src = t5 if t is t4 else t4
+                self._ew(P, PR.UPSAMPLE, i=(N, D, src.shape[2], src.shape[3], 2), p=(src, t, t), nbytes=9.0 * t.numel())
+        p5, p4, p3 = (torch.empty_like(t) for t in (t5, t4, t3))
+        self._conv3(P, [(t, p, None, L[name].pf, L[name].b)                # three filters, one launch
+                        for t, p, name in ((t5, p5, "out.0"), (t4, p4, "out.1"), (t3, p3, "out.2"))], D, D, 0)
+        # P6 / P7: stride-1 convolution, then the even positions
+        l6, l7 = L["p6"], L["p7"]
+        p6f = self._t(N, D, c5.shape[2], c5.shape[3])
+        self._conv3(P, [(c5, p6f, None, l6.pf, l6.b)], D, l6.cin, 0)
+        p6 = self._t(N, D, c5.shape[2] // 2, c5.shape[3] // 2)
+        self._ew(P, PR.SUBSAMPLE, i=(N, D, c5.shape[2], c5.shape[3], 2), p=(p6f, p6), nbytes=8.0 * p6.numel())
+        r6 = torch.empty_like(p6)
+        self._ew(P, PR.RELU, p=(p6, r6), l=(p6.numel(),), nbytes=8.0 * p6.numel())
+        p7f = torch.empty_like(p6)
+        self._conv3(P, [(r6, p7f, None, l7.pf, l7.b)], D, D, 0)
+        p7 = self._t(N, D, (p6.shape[2] + 1) // 2, (p6.shape[3] + 1) // 2)
+        self._ew(P, PR.SUBSAMPLE, i=(N, D, p6.shape[2], p6.shape[3], 2), p=(p7f, p7), nbytes=8.0 * p7.numel())
+        self.fpn = [p3, p4, p5, p6, p7]                   # finest first (synth.LEVEL_SHAPES_*)
+        self._fpn_saved = dict(t3=t3, t4=t4, t5=t5, r6=r6, p6f=p6f, p7f=p7f)
+
+    # -- backward ------------------------------------------------------------------------------------------
+    def _emit_backward(self, P):
+        L, N, D = self._layers, self.N, self.D
+        c3, c4, c5 = self.c345
+        S = self._fpn_saved
+        t3, t4, t5, r6 = S["t3"], S["t4"], S["t5"], S["r6"]
+        # gradient w.r.t. every FPN level, written by the caller (subnet gradients, summed)
+        self.d_fpn = [torch.empty_like(p) for p in self.fpn]
+        d3, d4, d5, d6, d7 = self.d_fpn
+        l6, l7 = L["p6"], L["p7"]
+        # P7 = sub(conv(relu(p6)))
+        d7f = torch.empty_like(S["p7f"])
+        self._ew(P, PR.SUBSAMPLE_GRAD, i=(N, D, d7f.shape[2], d7f.shape[3], 2, 0), p=(d7, d7f), nbytes=4.0 * d7f.numel())
+        self._wgrad3(P, r6, d7f, l7)
+        dr6 = torch.empty_like(r6)
+        self._conv3(P, [(d7f, dr6, r6, l7.pd, None)], D, D, K.CONV_MASK_AUX)          # masked by p6 > 0
+        ptrs = (C.c_void_p * 2)(d6.data_ptr(), dr6.data_ptr())
+        P.add(PR.SUM_N, 51, i=(2,), l=(d6.numel(),), p=(ptrs, d6), work=12.0 * d6.numel(), keep=[d6, dr6])
+        # P6 = sub(conv(c5))
+        d6f = torch.empty_like(S["p6f"])
+        self._ew(P, PR.SUBSAMPLE_GRAD, i=(N, D, d6f.shape[2], d6f.shape[3], 2, 0), p=(d6, d6f), nbytes=4.0 * d6f.numel())
+        self._wgrad3(P, c5, d6f, l6)
+        dc5 = torch.empty_like(c5)
+        self._conv3(P, [(d6f, dc5, None, l6.pd, None)], l6.cin, D, 0)
+        # output convs: filter gradients and the three data gradients in one launch
+        dt5, dt4, dt3 = torch.empty_like(t5), torch.empty_like(t4), torch.empty_like(t3)
+        for t, d, name in ((t5, d5, "out.0"), (t4, d4, "out.1"), (t3, d3, "out.2")):
+            self._wgrad3(P, t, d, L[name])
+        self._conv3(P, [(d, dt, None, L[name].pd, None)
+                        for d, dt, name in ((d5, dt5, "out.0"), (d4, dt4, "out.1"), (d3, dt3, "out.2"))], D, D, 0)
+        # top-down path: t3 = lat2(c3) + up(t4), t4 = lat1(c4) + up(t5)
+        up4, up5 = torch.empty_like(t4), torch.empty_like(t5)
+        self._ew(P, PR.UPSAMPLE_GRAD, i=(N, D, t4.shape[2], t4.shape[3], 2), p=(dt3, up4), nbytes=5.0 * dt3.numel())
+        ptrs4 = (C.c_void_p * 2)(dt4.data_ptr(), up4.data_ptr())
+        P.add(PR.SUM_N, 51, i=(2,), l=(dt4.numel(),), p=(ptrs4, dt4), work=12.0 * dt4.numel(), keep=[dt4, up4])
+        self._ew(P, PR.UPSAMPLE_GRAD, i=(N, D, t5.shape[2], t5.shape[3], 2), p=(dt4, up5), nbytes=5.0 * dt4.numel())
+        ptrs5 = (C.c_void_p * 2)(dt5.data_ptr(), up5.data_ptr())
+        P.add(PR.SUM_N, 51, i=(2,), l=(dt5.numel(),), p=(ptrs5, dt5), work=12.0 * dt5.numel(), keep=[dt5, up5])
+        # laterals: filter / bias gradients; data gradients meet the stage outputs' other consumers
+        dc4, dc3 = torch.empty_like(c4), torch.empty_like(c3)
+        for c, dt, dc, name, acc in ((c5, dt5, dc5, "lat.0", True), (c4, dt4, dc4, "lat.1", False),
+                                     (c3, dt3, dc3, "lat.2", False)):
+            l = L[name]
+            self._wgrad1(P, c, dt, l)
+            self._bias_grad(P, dt, l)
+            self._gemm(P, l.w.view(l.cout, l.cin), l.cin, dt, dc, l.cout, l.cin, acc=acc)
+        P.mark("bwd_fpn_done")
+        grads_into = {5: dc5, 4: dc4, 3: dc3}
+        dy = None
+        for (stage, j, cin, cmid, cout, stride, proj, tr) in reversed(self.blocks):
+            if not tr:
+                break
+            pre = "res%d.%d" % (stage, j)
+            l1, l2, l3 = L[pre + ".c1"], L[pre + ".c2"], L[pre + ".c3"]
+            sv = self.saved[pre]
+            x, xs, y1, y2, y = sv["x"], sv["xs"], sv["y1"], sv["y2"], sv["y"]
+            last_of_stage = j == ARCHS[self.arch][stage - 2] - 1
+            if last_of_stage:
+                # the stage's output feeds the lateral (already in grads_into) and, for res3 / res4,
+                # the next stage's first block, whose input gradient was accumulated onto it
+                dy = grads_into[stage]
+            h, w = y.shape[2], y.shape[3]
+            # dz = ReluGradient(y, dy) and the plane sums for the bias gradient(s)
+            dz = torch.empty_like(y)
+            rows = self._t(N, cout)
+            self._ew(P, PR.RELU_GRAD_ROWSUM, i=(N, cout, h * w), p=(y, dy, dz, rows), nbytes=12.0 * y.numel())
+            self._bias_grad(P, dz, l3, rows)
+            self._wgrad1(P, y2, dz, l3)
+            dz2 = torch.empty_like(y2)
+            self._gemm(P, l3.w.view(cout, cmid), cmid, dz, dz2, cout, cmid, mask=y2)
+            self._wgrad3(P, y1, dz2, l2)                                   # + bias gradient of c2
+            dz1 = torch.empty_like(y1)
+            self._conv3(P, [(dz2, dz1, y1, l2.pd, None)], cmid, cmid, K.CONV_MASK_AUX)
+            self._wgrad1(P, xs, dz1, l1)
+            self._bias_grad(P, dz1, l1)
+            first_trainable = (stage == 3 and j == 0)
+            if proj:
+                lp = L[pre + ".proj"]
+                self._bias_grad(P, dz, lp, rows)
+                self._wgrad1(P, xs, dz, lp)
+                if not first_trainable:
+                    dxs = torch.empty_like(xs)
+                    self._gemm(P, l1.w.view(cmid, cin), cin, dz1, dxs, cmid, cin)
+                    self._gemm(P, lp.w.view(cout, cin), cin, dz, dxs, cout, cin, acc=True)
+                    # into the previous stage's output gradient (which already holds the lateral's part)
+                    tgt = grads_into[stage - 1]
+                    self._ew(P, PR.SUBSAMPLE_GRAD, i=(N, cin, x.shape[2], x.shape[3], stride, 1), p=(dxs, tgt),
+                             nbytes=12.0 * tgt.numel())
+                dy = None
+            else:
+                # identity shortcut: dx = dz + W1^T dz1, accumulated in place on dz
+                self._gemm(P, l1.w.view(cmid, cin), cin, dz1, dz, cmid, cin, acc=True)
+                dy = dz
+            if j == 0:
+                P.mark("bwd_res%d_done" % stage)
+
+    # -- running ---------------------------------------------------------------------------------------------
+    def prepare(self):
+        """Pack the frozen filters (once, and again after load_from)."""
+        if not self._packed_frozen:
+            self.prep.run(timing=None)
+            self._packed_frozen = True
+
+    def pack(self):
+        self.prepare()
+        self.prog.run("pack", "forward", timing=self.timing)
+
+    def forward(self, images):
+        """images: [N, 3, H, W] float32.  Returns the five FPN levels (finest first)."""
+        if images.data_ptr() != self.image.data_ptr():
+            self.image.copy_(images)
+        self.prepare()
+        self.prog.run("forward", "backward", timing=self.timing)
+        return self.fpn
+
+    def backward(self, d_fpn=None):
+        """d_fpn: gradients w.r.t. the five levels (or already written into self.d_fpn).  Each
+        stage's gradient bucket is all-reduced as soon as its last filter gradient is enqueued."""
+        if d_fpn is not None:
+            for dst, src in zip(self.d_fpn, d_fpn):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+        marks = ["backward", "bwd_fpn_done", "bwd_res5_done", "bwd_res4_done", "bwd_res3_done"]
+        names = ["fpn", "res5", "res4", "res3"]
+        for k in range(4):
+            self.prog.run(marks[k], marks[k + 1], timing=self.timing)
+            self.dp.issue(self.bucket[names[k]])
+        # (the program has nothing between bwd_res3_done and sgd)
+
+    def sgd_step(self):
+        self.dp.wait()
+        self.prog.run("sgd", "end", timing=self.timing)
+
+    def broadcast_params(self, src=0):
+        self.dp.broadcast([self.params_flat, self.moms_flat], src=src)
+
+
+class NativeDistillModel(object):
+    """One iteration of the whole detector on one GPU with native backbones: teacher forward
+    (its own stream), student forward, subnets + losses (head_pipeline.DistillHeads), student
+    backward, gradient all-reduce (when data parallel) and both SGD updates -- every launch one
+    of this repo's kernels, enqueued by ssad_program_run."""
+
+    def __init__(self, heads, student_arch="r50", teacher_arch="r101", N=16, image_hw=(640, 896), device="cuda",
+                 process_group=None, world_size=1, lr=1e-5, momentum=0.9, weight_decay=1e-4, two_streams=True):
+        self.heads = heads
+        self.has_teacher = teacher_arch not in (None, "none")
+        assert self.has_teacher == bool(getattr(heads, "distill", True))
+        self.student = NativeResNetFPN(student_arch, N, image_hw, device, train=True, lr=lr, momentum=momentum,
+                                       weight_decay=weight_decay, process_group=process_group,
+                                       world_size=world_size)
+        self.teacher = NativeResNetFPN(teacher_arch, N, image_hw, device, train=False) if self.has_teacher else None
+        self.student.broadcast_params()
+        self.side = torch.cuda.Stream() if (two_streams and self.has_teacher) else None
+        # gradient w.r.t. an FPN level = cls-subnet part + bbox-subnet part
+        Q = self.sum_prog = PR.Program()
+        self._ptrs = []
+        for a, b, d in zip(heads.d_fpn["cls"], heads.d_fpn["bbox"], self.student.d_fpn):
+            ptrs = (C.c_void_p * 2)(a.data_ptr(), b.data_ptr())
+            Q.add(PR.SUM_N, 51, i=(2,), l=(d.numel(),), p=(ptrs, d), work=12.0 * d.numel(), keep=[a, b, d])
+        Q.build()
+        self._timing = None
+
+    @property
+    def timing(self):
+        return self._timing
+
+    @timing.setter
+    def timing(self, t):
+        self._timing = t
+        self.student.timing = t
+        if self.teacher is not None:
+            self.teacher.timing = t if self.side is None else None   # one timing object per stream
+
+    def describe(self):
+        return ("backbones = native programs of this repo's kernels (pointwise convs: fp32-MFMA GEMM with fused "
+                "bias / shortcut / ReLU; 3x3: Winograd engine; stem: im2col + GEMM + fused bias/ReLU/pool; "
+                "no torch operator in the step)")
+
+    def step(self, images, labels, bbox_targets, fg_num):
+        h, st, te = self.heads, self.student, self.teacher
+        h.pack_student()
+        st.pack()
+        if te is not None:
+            if self.side is not None:
+                cur = torch.cuda.current_stream()
+                self.side.wait_stream(cur)
+                with torch.cuda.stream(self.side):
+                    t_fpn = te.forward(images)
+            else:
+                t_fpn = te.forward(images)
+        else:
+            t_fpn = None
+        s_fpn = st.forward(images)
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+        h.forward_all(t_fpn, s_fpn)
+        h.cls_losses(labels, fg_num)
+        h.bbox_losses_fwd_bwd(bbox_targets, fg_num)
+        h.backward()
+        self.sum_prog.run(timing=self._timing)
+        st.backward()
+        h.sgd_step()
+        st.sgd_step()
+        return h.losses

@@ -240,6 +240,20 @@ int ssad_im2col(const float* x, int C, int H, int W, int kh, int kw, int dil_h, 
   return (int)hipGetLastError();
 }
 
+// the same for a whole batch: col[n][C*kh*kw][OH*OW] (the X operand of ssad_conv1x1_gemm for a
+// k x k convolution: the ResNet stem's 7x7 / stride 2)
+int ssad_im2col_batched(const float* x, int N, int C, int H, int W, int kernel, int stride, int pad,
+                        float* col, ssad_stream_t stream) {
+  Geo g{C, H, W, kernel, kernel, 1, 1, pad, pad, stride, stride,
+        ssad_conv_out_size(H, kernel, 1, pad, pad, stride), ssad_conv_out_size(W, kernel, 1, pad, pad, stride)};
+  if (!x || !col || N < 0 || C < 1 || g.OH < 1 || g.OW < 1) return SSAD_E_BADARG;
+  const long long per = (long long)C * kernel * kernel * g.OH * g.OW;
+  for (int n = 0; n < N; ++n)
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(per)), dim3(kT), 0, (hipStream_t)stream,
+                       x + (long long)n * C * H * W, g, col + (long long)n * per);
+  return (int)hipGetLastError();
+}
+
 int ssad_col2im(const float* col, int C, int H, int W, int kh, int kw, int dil_h, int dil_w,
                 int pad_t, int pad_l, int pad_b, int pad_r, int stride_h, int stride_w, float* x,
                 ssad_stream_t stream) {

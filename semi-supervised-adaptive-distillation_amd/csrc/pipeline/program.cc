@@ -121,6 +121,10 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
       return ssad_subsample((const float*)p[0], i[0], i[1], i[2], i[3], i[4], (float*)p[1], s);
     case SSAD_OP_SUBSAMPLE_GRAD:
       return ssad_subsample_grad((const float*)p[0], i[0], i[1], i[2], i[3], i[4], i[5], (float*)p[1], s);
+    case SSAD_OP_RELU:
+      return ssad_relu((const float*)p[0], (float*)p[1], o.l[0], s);
+    case SSAD_OP_IM2COL_BATCHED:
+      return ssad_im2col_batched((const float*)p[0], i[0], i[1], i[2], i[3], i[4], i[5], i[6], (float*)p[1], s);
     case SSAD_OP_CHANNEL_SUM:
       return ssad_channel_sum((const float*)p[0], i[0], i[1], i[2], (float*)p[1], i[3], s);
     default:

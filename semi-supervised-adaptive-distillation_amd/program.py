@@ -21,6 +21,8 @@ FILL, SCALE, SUM_N, CHECK_FINITE, LOSS_SCALE_UPDATE = 13, 14, 15, 16, 17
 F16_PACK_ACT, F16_UNPACK_ACT, F16_PACK_FILTER, F16_CONV3X3, F16_WGRAD = 32, 33, 34, 35, 36
 AFFINE_CHANNEL, UPSAMPLE, UPSAMPLE_GRAD, STEM_POOL, RELU_GRAD_ROWSUM, RELU_GRAD, CHANNEL_SUM = \
     48, 49, 50, 51, 52, 53, 55
+GEMM_CONV, CONV1X1_WGRAD, TRANSPOSE_FILTER, SUBSAMPLE, SUBSAMPLE_GRAD, RELU, IM2COL_BATCHED = \
+    54, 56, 57, 58, 59, 60, 61
 
 # timing classes: one per kernel family.  bound "mfma": work = direct-form FLOPs
 # (2*9*Cout*Cin per output pixel; the Winograd engine executes 1/2.25 of them);
@@ -58,8 +60,14 @@ KLASS = {
     # backbone (row f1)
     48: dict(name="backbone conv3x3 fwd/dgrad (wino_conv_z_kernel)", bound="mfma", wino=True),
     49: dict(name="backbone conv3x3 filter gradient (wino_wgrad_kernel)", bound="mfma", wino=True),
-    50: dict(name="backbone pointwise conv (gemm_conv_kernel)", bound="mfma", wino=False),
-    51: dict(name="backbone elementwise tails / pool / upsample", bound="hbm"),
+    50: dict(name="backbone pointwise conv fwd / data gradient (gemm_conv_nn_kernel)", bound="mfma", wino=False),
+    51: dict(name="backbone elementwise: subsample / scatter, ReluGradient + bias sums, upsample, pool, adds",
+             bound="hbm"),
+    52: dict(name="backbone pointwise conv filter gradient (gemm_conv_nt_kernel + reduce)", bound="mfma",
+             wino=False),
+    53: dict(name="stem 7x7/2 conv (im2col + gemm_conv_nn_kernel)", bound="mfma", wino=False),
+    54: dict(name="backbone filter packs (transpose / Winograd)", bound="hbm"),
+    55: dict(name="backbone momentum SGD (sgd_flat_kernel)", bound="hbm"),
 }
 
 PEAK = {"mfma": 157.3e12, "mfma16": 2.5e15, "hbm": 8.0e12}      # MI355X_MICROARCH.md chip table

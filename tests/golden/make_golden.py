@@ -196,7 +196,10 @@ def make_conv():
 # (name, N, Cin, M, H, W, kernel, stride, pad, group)
 CONV_REF_GEOMS = [("k1s1", 2, 24, 40, 9, 13, 1, 1, 0, 1), ("k1s2", 2, 32, 16, 10, 14, 1, 2, 0, 1),
                   ("k3s2", 2, 16, 24, 10, 13, 3, 2, 1, 1), ("k7s2", 1, 3, 16, 21, 29, 7, 2, 3, 1),
-                  ("k3g4", 2, 32, 32, 9, 11, 3, 1, 1, 4), ("k3g8s2", 1, 64, 64, 12, 10, 3, 2, 1, 8)]
+                  ("k3g4", 2, 32, 32, 9, 11, 3, 1, 1, 4), ("k3g8s2", 1, 64, 64, 12, 10, 3, 2, 1, 8),
+                  # pointwise layers with 16-pixel-multiple maps (what the GEMM kernels take)
+                  ("k1s1p96", 2, 24, 40, 8, 12, 1, 1, 0, 1), ("k1s2p96", 2, 32, 16, 16, 24, 1, 2, 0, 1),
+                  ("k1s1c160", 3, 160, 72, 4, 8, 1, 1, 0, 1)]
 
 
 def conv_ref_inputs(seed, N, Cin, M, H, W, kernel=3, stride=1, pad=1, group=1):

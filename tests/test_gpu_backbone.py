@@ -1,0 +1,89 @@
+"""The native ResNet-FPN backbone program (backbone_pipeline.NativeResNetFPN, row f1) against
+the same network written with torch's own convolutions on the same weights: FPN outputs,
+every parameter gradient of res3..res5 + FPN, and the SGD update."""
+import numpy as np
+import pytest
+import torch
+
+import ssad_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_reference(arch):
+    """harness.full_model.ResNetFPN on plain torch operators (MIOpen / rocBLAS), no kernel of
+    this repo: the independent implementation."""
+    from ssad_amd.harness import full_model as fm
+    fm._HIP3X3 = fm._FUSE_TAIL = fm._GEMM_1X1 = fm._FUSED_PW = False
+    with torch.random.fork_rng():
+        torch.manual_seed(11)
+        m = fm.ResNetFPN(arch).cuda()
+    # biases away from zero so that every bias path is exercised
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith("bias"):
+                p.normal_(0.0, 0.05)
+    return m
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
+
+
+@pytest.mark.parametrize("arch", ["r50"])
+def test_native_backbone_forward_backward_vs_torch(arch):
+    from ssad_amd.backbone_pipeline import NativeResNetFPN
+    ref = _torch_reference(arch)
+    N, hw = 2, (256, 384)
+    nat = NativeResNetFPN(arch, N, hw, "cuda", train=True, src=ref, lr=0.01)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    images = torch.randn((N, 3) + hw, device="cuda", generator=gen)
+    nat.pack()
+    got = nat.forward(images)
+    want = ref(images)
+    assert [tuple(t.shape) for t in got] == [tuple(t.shape) for t in want]
+    for g, w in zip(got, want):
+        assert rel(g, w.detach()) < 2e-5, rel(g, w.detach())
+    d_fpn = [torch.randn(t.shape, device="cuda", generator=gen) for t in want]
+    torch.autograd.backward(want, d_fpn)
+    nat.backward(d_fpn)
+    torch.cuda.synchronize()
+    errs = {}
+    for name, p in ref.named_parameters():
+        lname, kind = name.rsplit(".", 1)
+        layer = nat._layers[lname]
+        if not layer.train:
+            assert p.grad is None, name
+            continue
+        g = layer.gw if kind == "weight" else layer.gb
+        errs[name] = rel(g, p.grad)
+    worst = max(errs, key=errs.get)
+    # ReLU masks can differ on activations within round-off of zero between two implementations
+    # (tests/test_gpu_operators.py:make_mask_safe): typical tensors agree to ~1e-6, a flipped mask
+    # moves single tensors by up to ~1e-3
+    assert float(np.median(list(errs.values()))) < 2e-5, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert errs[worst] < 3e-3, (worst, errs[worst])
+    # SGD: weights g + wd * w, biases 2 g, momentum (optimizer.py:115-130)
+    p0 = nat.params_flat.clone()
+    g0 = nat.grads_flat.clone()
+    nat.sgd_step()
+    isb = torch.zeros_like(p0, dtype=torch.bool)
+    for off, n, b in nat.segments:
+        if b:
+            isb[off:off + n] = True
+    gg = torch.where(isb, 2.0 * g0, g0 + 1e-4 * p0)
+    assert torch.allclose(nat.params_flat, p0 - 0.01 * gg, rtol=1e-5, atol=1e-8)
+
+
+def test_native_backbone_frozen_teacher_matches_torch_r101_small():
+    from ssad_amd.backbone_pipeline import NativeResNetFPN
+    ref = _torch_reference("r101")
+    N, hw = 1, (128, 256)
+    nat = NativeResNetFPN("r101", N, hw, "cuda", train=False, src=ref)
+    assert nat.params_flat.numel() == 0 and "sgd" not in nat.prog.marks
+    images = torch.randn((N, 3) + hw, device="cuda")
+    got = nat.forward(images)
+    with torch.no_grad():
+        want = ref(images)
+    for g, w in zip(got, want):
+        assert rel(g, w) < 3e-5

@@ -71,15 +71,10 @@ def test_gemm_conv_vs_reference_operator_golden(K, golden_dir):
     """k1s1 and k1s2 of tests/golden/conv_ref.npz (outputs of the reference's compiled
     ConvOp / ConvGradientOp): the strided layer = the pointwise layer on the subsampled map."""
     g = np.load(os.path.join(golden_dir, "conv_ref.npz"))
-    for name in ("k1s1", "k1s2"):
+    for name in ("k1s1p96", "k1s2p96", "k1s1c160"):
         seed, N, Cin, M, H, W, k, s, p, grp = [int(v) for v in g[name + "_dims"]]
         X, Wt, b, dY = mg.conv_ref_inputs(seed, N, Cin, M, H, W, k, s, p, grp)
         tx, tw = dev(X), dev(Wt)
-        oh, ow = (H - 1) // s + 1, (W - 1) // s + 1
-        if (oh * ow) % 4:            # the GEMM kernel wants 16-byte pixel rows (every backbone map has)
-            with pytest.raises(K.KernelError):
-                K.conv1x1_forward(tx, K.transpose_filter(tw), M)
-            continue
         xs = K.subsample(tx, s) if s > 1 else tx
         if s > 1:
             assert np.array_equal(xs.cpu().numpy(), X[:, :, ::s, ::s])
@@ -89,6 +84,11 @@ def test_gemm_conv_vs_reference_operator_golden(K, golden_dir):
         dxs = K.conv1x1_dgrad(dev(dY), tw)
         dX = K.subsample_grad(dxs, H, W, s) if s > 1 else dxs
         close(dX.cpu().numpy().ravel()[g[name + "_dX_idx"]], g[name + "_dX"], CONV_RTOL, CONV_FLOOR, name + " dX")
+        dW = K.conv1x1_wgrad(xs, dev(dY))
+        close(dW.cpu().numpy().ravel()[g[name + "_dW_idx"]], g[name + "_dW"], CONV_RTOL, CONV_FLOOR, name + " dW")
+    # maps whose pixel count is not a multiple of 4 are refused (no backbone layer has one)
+    with pytest.raises(K.KernelError):
+        K.conv1x1_forward(torch.zeros(1, 8, 3, 3, device="cuda"), torch.zeros(8, 8, device="cuda"), 8)
 
 
 def test_gemm_conv_full_size_adjoints(K):
