@@ -510,6 +510,8 @@ class NativeDistillModel(object):
                                        world_size=world_size)
         self.teacher = NativeResNetFPN(teacher_arch, N, image_hw, device, train=False) if self.has_teacher else None
         self.student.broadcast_params()
+        import os
+        two_streams = two_streams and os.environ.get("SSAD_NATIVE_TWO_STREAMS", "1") == "1"
         self.side = torch.cuda.Stream() if (two_streams and self.has_teacher) else None
         # gradient w.r.t. an FPN level = cls-subnet part + bbox-subnet part
         Q = self.sum_prog = PR.Program()

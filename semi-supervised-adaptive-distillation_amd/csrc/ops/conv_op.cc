@@ -138,6 +138,20 @@ bool ConvOp<float, HIPContext>::RunOnDevice() {
   return true;
 }
 
+// A pointwise layer the GEMM kernels take: 1x1, no padding, no dilation, equal strides, one group,
+// 16-byte pixel rows, 16-byte aligned channel rows (C % 4), tensors below 2 GiB.
+// hip_algo = "blas" keeps the rocBLAS route.
+static bool PointwiseGemmEligible(const ConvGeometry& g, int N, int C, int M, int P) {
+  static const bool off = [] { const char* e = getenv("SSAD_CONV1X1_ENGINE"); return e && std::string(e) == "blas"; }();
+  if (off) return false;
+  if (g.kernel[0] != 1 || g.kernel[1] != 1 || g.group != 1) return false;
+  if (g.pads != vector<int>{0, 0, 0, 0} || g.dilation != vector<int>{1, 1}) return false;
+  if (g.stride[0] != g.stride[1] || g.stride[0] < 1) return false;
+  if ((P & 3) || (C & 3) || N < 1) return false;
+  const long long big = (long long)N * (C > M ? C : M) * P * 4;
+  return big < (1LL << 31) && (long long)C * ((M + 3) / 4 * 4) * 4 < (1LL << 31);
+}
+
 // Default engine, forward (conv_op_impl.h:31-202): per image im2col -> col[C*kh*kw][OH*OW],
 // Y[n] = filter[M][C*kh*kw] . col, then the bias; a 1x1 / stride 1 / pad 0 layer skips the
 // im2col (its col buffer IS the image).
@@ -162,6 +176,28 @@ bool ConvOp<float, HIPContext>::RunDefaultEngine() {
   const int K = C * kh * kw, P = OH * OW, Kg = K / G, Mg = M / G;
   const bool pointwise = kh == 1 && kw == 1 && geom_.stride == vector<int>{1, 1} &&
                          geom_.pads == vector<int>{0, 0, 0, 0};
+  // Pointwise layers (the bottleneck 1x1s, projection shortcuts, FPN laterals; stride 1 or the
+  // stride-2 first blocks): this repo's fp32-MFMA GEMM over the whole batch with the bias (and a
+  // fused Relu) in its epilogue (kernels/gemm_conv.hip) instead of N rocBLAS calls + a bias pass.
+  // A strided pointwise convolution is the pointwise convolution of the subsampled map.
+  if (PointwiseGemmEligible(geom_, N, C, M, P)) {
+    const int st = geom_.stride[0];
+    const float* xin = X.data<float>();
+    if (st > 1) {
+      col_buffer_.Resize((TIndex)N * C * P);
+      CAFFE_ENFORCE_EQ(ssad_subsample(xin, N, C, H, W, st, col_buffer_.mutable_data<float>(), s), 0);
+      xin = col_buffer_.data<float>();
+    }
+    const int ldm = (M + 3) / 4 * 4;
+    packed_filter_.Resize((TIndex)C * ldm);
+    float* wt = packed_filter_.mutable_data<float>();
+    CAFFE_ENFORCE_EQ(ssad_transpose_filter(filter.data<float>(), M, C, ldm, wt, s), 0);
+    const ssad_gemm_conv d{wt, xin, Y->mutable_data<float>(),
+                           InputSize() == 3 ? Input(BIAS).data<float>() : nullptr, nullptr, nullptr,
+                           ldm, N, C, P, M, fuse_relu_ ? SSAD_GEMM_RELU : 0};
+    CAFFE_ENFORCE_EQ(ssad_conv1x1_gemm(&d, s), 0, "pointwise Conv launch failed");
+    return true;
+  }
   if (!pointwise) col_buffer_.Resize((TIndex)K * P);
   const float* Wd = filter.data<float>();
   for (int n = 0; n < N; ++n) {
@@ -215,6 +251,35 @@ bool ConvGradientOp<float, HIPContext>::RunDefaultEngine() {
   const bool want_dx = OutputSize() == 3 || (no_bias_ && OutputSize() == 2);
   Tensor<HIPContext>* dX = want_dx ? Output(no_bias_ ? BIAS_OR_INPUT_GRAD : INPUT_GRAD) : nullptr;
   if (dX) dX->ResizeLike(X);
+  if (PointwiseGemmEligible(geom_, N, C, M, P) && P % 16 == 0) {
+    // dfilter = sum_{n,p} dY X^T (split reduction), dX = filter^T . dY on the GEMM kernels
+    const int st = geom_.stride[0];
+    const float* xin = X.data<float>();
+    if (st > 1) {
+      col_buffer_.Resize((TIndex)N * C * P);
+      CAFFE_ENFORCE_EQ(ssad_subsample(xin, N, C, H, W, st, col_buffer_.mutable_data<float>(), s), 0);
+      xin = col_buffer_.data<float>();
+    }
+    const size_t wsb = ssad_conv1x1_wgrad_workspace_bytes(N, C, P, M);
+    workspace_.Resize((TIndex)wsb);
+    CAFFE_ENFORCE_EQ(ssad_conv1x1_wgrad(xin, dY.data<float>(), N, C, P, M, dfilter->mutable_data<float>(), 0,
+                                        workspace_.mutable_data<uint8_t>(), wsb, s), 0);
+    if (dX) {
+      float* dxs = dX->mutable_data<float>();
+      if (st > 1) dxs = col_buffer_.mutable_data<float>();     // X's subsampled copy is no longer needed
+      const ssad_gemm_conv d{filter.data<float>(), dY.data<float>(), dxs, nullptr, nullptr, nullptr,
+                             C, N, M, P, C, 0};
+      CAFFE_ENFORCE_EQ(ssad_conv1x1_gemm(&d, s), 0, "pointwise ConvGradient launch failed");
+      if (st > 1)
+        CAFFE_ENFORCE_EQ(ssad_subsample_grad(dxs, N, C, H, W, st, 0, dX->mutable_data<float>(), s), 0);
+    }
+    if (!no_bias_) {
+      auto* dbias = Output(BIAS_OR_INPUT_GRAD);
+      dbias->Resize(M);
+      CAFFE_ENFORCE_EQ(ssad_channel_sum(dY.data<float>(), N, M, P, dbias->mutable_data<float>(), 0, s), 0);
+    }
+    return true;
+  }
   if (!pointwise) col_buffer_.Resize((TIndex)K * P);
   for (int n = 0; n < N; ++n) {
     const float* xn = X.data<float>() + (size_t)n * C * H * W;
