@@ -63,6 +63,7 @@ class NativeResNetFPN(object):
             raise K.KernelError("native backbone: image sides must be multiples of 128 (16-pixel-multiple "
                                 "maps down to res5; 640x896 and 512x768 are)")
         self._layers = OrderedDict()
+        self._bufs = []
         self._define_layers()
         self._alloc_params(src)
         self.lr = torch.full((1,), lr, dtype=torch.float32, device=device)
@@ -173,7 +174,22 @@ class NativeResNetFPN(object):
 
     # -- small emit helpers -------------------------------------------------------------------
     def _t(self, *shape):
-        return torch.empty(shape, dtype=torch.float32, device=self.device)
+        t = torch.empty(shape, dtype=torch.float32, device=self.device)
+        self._bufs.append(t)
+        return t
+
+    def _like(self, t):
+        u = torch.empty_like(t)
+        self._bufs.append(u)
+        return u
+
+    def poison(self, value=float("nan")):
+        """Fill every activation / gradient / scratch buffer (debugging aid: anything the step
+        reads before it writes shows up as NaN in the results)."""
+        for t in self._bufs:
+            t.fill_(value)
+        self.ws.view(torch.float32)[: self.ws.numel() // 4].fill_(value)
+        self._packed_frozen = False
 
     def _gemm(self, P, a, lda, x, y, Kc, M, bias=None, res=None, mask=None, relu=False, acc=False, klass=50):
         d = K.gemm_conv_desc(a, lda, x, y, Kc, M, bias, res, mask, relu, acc)
@@ -339,7 +355,7 @@ class NativeResNetFPN(object):
             if t is not t5:
                 src = t5 if t is t4 else t4
                 self._ew(P, PR.UPSAMPLE, i=(N, D, src.shape[2], src.shape[3], 2), p=(src, t, t), nbytes=9.0 * t.numel())
-        p5, p4, p3 = (torch.empty_like(t) for t in (t5, t4, t3))
+        p5, p4, p3 = (self._like(t) for t in (t5, t4, t3))
         self._conv3(P, [(t, p, None, L[name].pf, L[name].b)                # three filters, one launch
                         for t, p, name in ((t5, p5, "out.0"), (t4, p4, "out.1"), (t3, p3, "out.2"))], D, D, 0)
         # P6 / P7: stride-1 convolution, then the even positions
@@ -348,9 +364,9 @@ class NativeResNetFPN(object):
         self._conv3(P, [(c5, p6f, None, l6.pf, l6.b)], D, l6.cin, 0)
         p6 = self._t(N, D, c5.shape[2] // 2, c5.shape[3] // 2)
         self._ew(P, PR.SUBSAMPLE, i=(N, D, c5.shape[2], c5.shape[3], 2), p=(p6f, p6), nbytes=8.0 * p6.numel())
-        r6 = torch.empty_like(p6)
+        r6 = self._like(p6)
         self._ew(P, PR.RELU, p=(p6, r6), l=(p6.numel(),), nbytes=8.0 * p6.numel())
-        p7f = torch.empty_like(p6)
+        p7f = self._like(p6)
         self._conv3(P, [(r6, p7f, None, l7.pf, l7.b)], D, D, 0)
         p7 = self._t(N, D, (p6.shape[2] + 1) // 2, (p6.shape[3] + 1) // 2)
         self._ew(P, PR.SUBSAMPLE, i=(N, D, p6.shape[2], p6.shape[3], 2), p=(p7f, p7), nbytes=8.0 * p7.numel())
@@ -364,31 +380,31 @@ class NativeResNetFPN(object):
         S = self._fpn_saved
         t3, t4, t5, r6 = S["t3"], S["t4"], S["t5"], S["r6"]
         # gradient w.r.t. every FPN level, written by the caller (subnet gradients, summed)
-        self.d_fpn = [torch.empty_like(p) for p in self.fpn]
+        self.d_fpn = [self._like(p) for p in self.fpn]
         d3, d4, d5, d6, d7 = self.d_fpn
         l6, l7 = L["p6"], L["p7"]
         # P7 = sub(conv(relu(p6)))
-        d7f = torch.empty_like(S["p7f"])
+        d7f = self._like(S["p7f"])
         self._ew(P, PR.SUBSAMPLE_GRAD, i=(N, D, d7f.shape[2], d7f.shape[3], 2, 0), p=(d7, d7f), nbytes=4.0 * d7f.numel())
         self._wgrad3(P, r6, d7f, l7)
-        dr6 = torch.empty_like(r6)
+        dr6 = self._like(r6)
         self._conv3(P, [(d7f, dr6, r6, l7.pd, None)], D, D, K.CONV_MASK_AUX)          # masked by p6 > 0
         ptrs = (C.c_void_p * 2)(d6.data_ptr(), dr6.data_ptr())
         P.add(PR.SUM_N, 51, i=(2,), l=(d6.numel(),), p=(ptrs, d6), work=12.0 * d6.numel(), keep=[d6, dr6])
         # P6 = sub(conv(c5))
-        d6f = torch.empty_like(S["p6f"])
+        d6f = self._like(S["p6f"])
         self._ew(P, PR.SUBSAMPLE_GRAD, i=(N, D, d6f.shape[2], d6f.shape[3], 2, 0), p=(d6, d6f), nbytes=4.0 * d6f.numel())
         self._wgrad3(P, c5, d6f, l6)
-        dc5 = torch.empty_like(c5)
+        dc5 = self._like(c5)
         self._conv3(P, [(d6f, dc5, None, l6.pd, None)], l6.cin, D, 0)
         # output convs: filter gradients and the three data gradients in one launch
-        dt5, dt4, dt3 = torch.empty_like(t5), torch.empty_like(t4), torch.empty_like(t3)
+        dt5, dt4, dt3 = self._like(t5), self._like(t4), self._like(t3)
         for t, d, name in ((t5, d5, "out.0"), (t4, d4, "out.1"), (t3, d3, "out.2")):
             self._wgrad3(P, t, d, L[name])
         self._conv3(P, [(d, dt, None, L[name].pd, None)
                         for d, dt, name in ((d5, dt5, "out.0"), (d4, dt4, "out.1"), (d3, dt3, "out.2"))], D, D, 0)
         # top-down path: t3 = lat2(c3) + up(t4), t4 = lat1(c4) + up(t5)
-        up4, up5 = torch.empty_like(t4), torch.empty_like(t5)
+        up4, up5 = self._like(t4), self._like(t5)
         self._ew(P, PR.UPSAMPLE_GRAD, i=(N, D, t4.shape[2], t4.shape[3], 2), p=(dt3, up4), nbytes=5.0 * dt3.numel())
         ptrs4 = (C.c_void_p * 2)(dt4.data_ptr(), up4.data_ptr())
         P.add(PR.SUM_N, 51, i=(2,), l=(dt4.numel(),), p=(ptrs4, dt4), work=12.0 * dt4.numel(), keep=[dt4, up4])
@@ -396,7 +412,7 @@ class NativeResNetFPN(object):
         ptrs5 = (C.c_void_p * 2)(dt5.data_ptr(), up5.data_ptr())
         P.add(PR.SUM_N, 51, i=(2,), l=(dt5.numel(),), p=(ptrs5, dt5), work=12.0 * dt5.numel(), keep=[dt5, up5])
         # laterals: filter / bias gradients; data gradients meet the stage outputs' other consumers
-        dc4, dc3 = torch.empty_like(c4), torch.empty_like(c3)
+        dc4, dc3 = self._like(c4), self._like(c3)
         for c, dt, dc, name, acc in ((c5, dt5, dc5, "lat.0", True), (c4, dt4, dc4, "lat.1", False),
                                      (c3, dt3, dc3, "lat.2", False)):
             l = L[name]
@@ -420,15 +436,15 @@ class NativeResNetFPN(object):
                 dy = grads_into[stage]
             h, w = y.shape[2], y.shape[3]
             # dz = ReluGradient(y, dy) and the plane sums for the bias gradient(s)
-            dz = torch.empty_like(y)
+            dz = self._like(y)
             rows = self._t(N, cout)
             self._ew(P, PR.RELU_GRAD_ROWSUM, i=(N, cout, h * w), p=(y, dy, dz, rows), nbytes=12.0 * y.numel())
             self._bias_grad(P, dz, l3, rows)
             self._wgrad1(P, y2, dz, l3)
-            dz2 = torch.empty_like(y2)
+            dz2 = self._like(y2)
             self._gemm(P, l3.w.view(cout, cmid), cmid, dz, dz2, cout, cmid, mask=y2)
             self._wgrad3(P, y1, dz2, l2)                                   # + bias gradient of c2
-            dz1 = torch.empty_like(y1)
+            dz1 = self._like(y1)
             self._conv3(P, [(dz2, dz1, y1, l2.pd, None)], cmid, cmid, K.CONV_MASK_AUX)
             self._wgrad1(P, xs, dz1, l1)
             self._bias_grad(P, dz1, l1)
@@ -438,7 +454,7 @@ class NativeResNetFPN(object):
                 self._bias_grad(P, dz, lp, rows)
                 self._wgrad1(P, xs, dz, lp)
                 if not first_trainable:
-                    dxs = torch.empty_like(xs)
+                    dxs = self._like(xs)
                     self._gemm(P, l1.w.view(cmid, cin), cin, dz1, dxs, cmid, cin)
                     self._gemm(P, lp.w.view(cout, cin), cin, dz, dxs, cout, cin, acc=True)
                     # into the previous stage's output gradient (which already holds the lateral's part)

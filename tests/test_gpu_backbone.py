@@ -10,19 +10,20 @@ import ssad_amd  # noqa: F401
 pytestmark = pytest.mark.gpu
 
 
-def _torch_reference(arch):
+def _torch_reference(arch, seed=11):
     """harness.full_model.ResNetFPN on plain torch operators (MIOpen / rocBLAS), no kernel of
     this repo: the independent implementation."""
     from ssad_amd.harness import full_model as fm
     fm._HIP3X3 = fm._FUSE_TAIL = fm._GEMM_1X1 = fm._FUSED_PW = False
     with torch.random.fork_rng():
-        torch.manual_seed(11)
+        torch.manual_seed(seed)
         m = fm.ResNetFPN(arch).cuda()
-    # biases away from zero so that every bias path is exercised
-    with torch.no_grad():
-        for name, p in m.named_parameters():
-            if name.endswith("bias"):
-                p.normal_(0.0, 0.05)
+        # biases away from zero so that every bias path is exercised (inside the forked RNG: the
+        # test's data must not depend on what ran before it)
+        with torch.no_grad():
+            for name, p in m.named_parameters():
+                if name.endswith("bias"):
+                    p.normal_(0.0, 0.05)
     return m
 
 
@@ -61,10 +62,14 @@ def test_native_backbone_forward_backward_vs_torch(arch):
         g = layer.gw if kind == "weight" else layer.gb
         errs[name] = rel(g, p.grad)
     worst = max(errs, key=errs.get)
-    # ReLU masks can differ on activations within round-off of zero between two implementations
-    # (tests/test_gpu_operators.py:make_mask_safe): typical tensors agree to ~1e-6, a flipped mask
-    # moves single tensors by up to ~1e-3
-    assert float(np.median(list(errs.values()))) < 2e-5, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    # The FPN's own parameters sit above every ReLU of the body: no mask can flip underneath them
+    fpn = [v for k, v in errs.items() if k.split(".")[0] in ("lat", "out", "p6")]
+    assert max(fpn) < 2e-5, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    # Body: an activation within fp32 round-off of zero takes the other side of a ReLU mask than in
+    # the float64 reference, and on these small maps (res5 is 8 x 12) one flipped element of the last
+    # block's gradient moves every gradient below it by ~sqrt(1 / elements) ~ 1e-3 (measured 6e-4 with
+    # one seed, 1e-6 with another; tests/test_gpu_operators.py:make_mask_safe shows 1e-4 is met when
+    # no mask can flip).  Bound: 3e-3 per tensor.
     assert errs[worst] < 3e-3, (worst, errs[worst])
     # SGD: weights g + wd * w, biases 2 g, momentum (optimizer.py:115-130)
     p0 = nat.params_flat.clone()
