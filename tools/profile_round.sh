@@ -40,4 +40,10 @@ run pmc_mfma "PMC pass 3 (MFMA / LDS): python tools/kbench.py --what conv" \
     --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES -d /tmp/prof_pmc_mfma -o t -- python tools/kbench.py --what conv
 run pmc_mfma_f16 "PMC pass 4 (MFMA / LDS, fp16 kernels): python tools/kbench.py --what f16" \
     --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES -d /tmp/prof_pmc_mfma_f16 -o t -- python tools/kbench.py --what f16
+run pmc_mfma_gemm "PMC pass 5 (MFMA / LDS / stalls, pointwise-convolution GEMM kernels): python tools/gemm_pmc.py" \
+    --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES -d /tmp/prof_pmc_mfma_gemm -o t -- python tools/gemm_pmc.py
+# FETCH_SIZE calibration on known byte counts in this repo's access patterns (tools/fetch_calib.hip)
+hipcc --offload-arch=gfx950 -O3 -w tools/fetch_calib.hip -o /tmp/fetch_calib > /dev/null 2>&1
+run pmc_fetch_calib "FETCH_SIZE calibration (KB per dispatch for a 1 GiB = 1048576 KB single pass): /tmp/fetch_calib" \
+    --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_pmc_fetch_calib -o t -- /tmp/fetch_calib
 ls -la $O
