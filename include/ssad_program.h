@@ -129,6 +129,15 @@ enum ssad_opcode {
   SSAD_OP_SUBSAMPLE_GRAD = 59,
   /* ssad_relu(p0 = x, p1 = y, l0 = n) */
   SSAD_OP_RELU = 60,
+  /* Concurrency inside a program (HIP streams + events, no kernel): independent launches -- the
+   * filter gradients of a layer beside the data-gradient chain that continues below it -- run on an
+   * auxiliary stream so that one kernel's last partial round of workgroups is filled by another's.
+   *   FORK(i0 = k): aux stream k waits for everything enqueued so far on the main stream;
+   *   JOIN(i0 = k): the main stream waits for everything enqueued so far on aux stream k.
+   * ssad_program_run joins every auxiliary stream it used before it returns, so a program segment
+   * is always complete on the main stream when the next one (or an RCCL all-reduce) is enqueued. */
+  SSAD_OP_FORK = 62,
+  SSAD_OP_JOIN = 63,
   /* ssad_im2col_batched(p0 = x, i0..i3 = N, C, H, W, i4 = kernel, i5 = stride, i6 = pad, p1 = col) */
   SSAD_OP_IM2COL_BATCHED = 61
 };
@@ -136,6 +145,9 @@ enum ssad_opcode {
 typedef struct ssad_op {
   int32_t code;        /* enum ssad_opcode */
   int32_t klass;       /* timing class chosen by the builder (>= 0) */
+  int32_t stream;      /* 0 = the stream ssad_program_run was given; 1..SSAD_MAX_AUX_STREAMS = one
+                          of the executor's auxiliary streams (see SSAD_OP_FORK / SSAD_OP_JOIN) */
+  int32_t reserved;
   int32_t i[8];
   float f[4];
   int64_t l[2];
@@ -143,6 +155,8 @@ typedef struct ssad_op {
   double work;         /* algorithmic work of this launch: FLOPs for MFMA-bound classes, bytes
                           for HBM-bound ones (SURVEY.md 8d per-unit figures x units) */
 } ssad_op;
+
+#define SSAD_MAX_AUX_STREAMS 3
 
 typedef struct ssad_timing ssad_timing;     /* opaque: event pool + records */
 

@@ -27,6 +27,40 @@ struct ssad_timing {
 
 namespace {
 
+// auxiliary streams of the executor (one set per device) and a ring of sync events.  An event may
+// be re-recorded once every consumer has been enqueued behind it; the ring is far longer than the
+// number of fork / join points of a step, and hipStreamWaitEvent captures the record that was
+// current when it was called.
+struct AuxStreams {
+  hipStream_t s[SSAD_MAX_AUX_STREAMS] = {nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> ring;
+  size_t next = 0;
+  hipEvent_t event() {
+    if (ring.size() < 1024) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      ring.push_back(e);
+      return e;
+    }
+    hipEvent_t e = ring[next];
+    next = (next + 1) % ring.size();
+    return e;
+  }
+};
+
+AuxStreams* aux_streams() {
+  static std::map<int, AuxStreams*> per_device;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  auto it = per_device.find(dev);
+  if (it != per_device.end()) return it->second;
+  AuxStreams* a = new AuxStreams();
+  for (int k = 0; k < SSAD_MAX_AUX_STREAMS; ++k)
+    if (hipStreamCreateWithFlags(&a->s[k], hipStreamNonBlocking) != hipSuccess) return nullptr;
+  per_device[dev] = a;
+  return a;
+}
+
 int run_op(const ssad_op& o, ssad_stream_t s) {
   const void* const* p = o.p;
   const int32_t* i = o.i;
@@ -174,33 +208,79 @@ int ssad_timing_collect(ssad_timing* t, ssad_timing_class* out, int max_out) {
 int ssad_program_run(const ssad_op* ops, int n_ops, ssad_stream_t stream, ssad_timing* timing,
                      int* failed_index) {
   if (n_ops < 0 || (n_ops > 0 && !ops)) return SSAD_E_BADARG;
-  hipStream_t hs = (hipStream_t)stream;
-  // consecutive ops share an event: op k runs between event k and event k + 1 on the stream
-  hipEvent_t prev = nullptr;
-  size_t prev_idx = 0;
-  if (timing && n_ops > 0) {
-    prev = timing->get();
-    if (!prev) return SSAD_E_BADARG;
-    prev_idx = timing->used - 1;
-    const hipError_t e = hipEventRecord(prev, hs);
-    if (e != hipSuccess) return (int)e;
-  }
+  hipStream_t main_s = (hipStream_t)stream;
+  AuxStreams* aux = nullptr;              // created on first use, per device
+  bool dirty[SSAD_MAX_AUX_STREAMS + 1] = {false, false, false, false};
+  // per stream: the event that closed the previous op (consecutive ops of a stream share an event)
+  size_t prev_idx[SSAD_MAX_AUX_STREAMS + 1];
+  bool have_prev[SSAD_MAX_AUX_STREAMS + 1] = {false, false, false, false};
+  auto fail = [&](int k, int rc) {
+    if (failed_index) *failed_index = k;
+    return rc;
+  };
+  auto stream_of = [&](int k) -> hipStream_t { return k == 0 ? main_s : aux->s[k - 1]; };
+  auto join = [&](int k) -> int {
+    hipEvent_t e = aux->event();
+    if (!e) return SSAD_E_BADARG;
+    hipError_t err = hipEventRecord(e, aux->s[k - 1]);
+    if (err == hipSuccess) err = hipStreamWaitEvent(main_s, e, 0);
+    dirty[k] = false;
+    have_prev[0] = false;                  // the main stream's next op starts after the wait
+    return (int)err;
+  };
   for (int k = 0; k < n_ops; ++k) {
-    const int rc = run_op(ops[k], stream);
-    if (rc != 0) {
-      if (failed_index) *failed_index = k;
-      return rc;
+    const ssad_op& o = ops[k];
+    const int sid = (o.code == SSAD_OP_FORK || o.code == SSAD_OP_JOIN) ? o.i[0] : o.stream;
+    if (sid < 0 || sid > SSAD_MAX_AUX_STREAMS) return fail(k, SSAD_E_BADARG);
+    if (sid > 0 && !aux) {
+      aux = aux_streams();
+      if (!aux) return fail(k, SSAD_E_BADARG);
     }
+    if (o.code == SSAD_OP_FORK) {
+      if (sid == 0) return fail(k, SSAD_E_BADARG);
+      hipEvent_t e = aux->event();
+      if (!e) return fail(k, SSAD_E_BADARG);
+      hipError_t err = hipEventRecord(e, main_s);
+      if (err == hipSuccess) err = hipStreamWaitEvent(aux->s[sid - 1], e, 0);
+      if (err != hipSuccess) return fail(k, (int)err);
+      dirty[sid] = true;
+      have_prev[sid] = false;
+      continue;
+    }
+    if (o.code == SSAD_OP_JOIN) {
+      if (sid == 0) return fail(k, SSAD_E_BADARG);
+      if (dirty[sid]) {
+        const int rc = join(sid);
+        if (rc) return fail(k, rc);
+      }
+      continue;
+    }
+    hipStream_t hs = stream_of(sid);
+    if (sid > 0) dirty[sid] = true;
+    if (timing && !have_prev[sid]) {
+      hipEvent_t e0 = timing->get();
+      if (!e0) return fail(k, SSAD_E_BADARG);
+      const hipError_t e = hipEventRecord(e0, hs);
+      if (e != hipSuccess) return fail(k, (int)e);
+      prev_idx[sid] = timing->used - 1;
+      have_prev[sid] = true;
+    }
+    const int rc = run_op(o, (ssad_stream_t)hs);
+    if (rc != 0) return fail(k, rc);
     if (timing) {
       hipEvent_t e1 = timing->get();
-      if (!e1) return SSAD_E_BADARG;
+      if (!e1) return fail(k, SSAD_E_BADARG);
       const hipError_t e = hipEventRecord(e1, hs);
-      if (e != hipSuccess) return (int)e;
-      timing->recs.push_back({ops[k].klass, ops[k].work, prev_idx, timing->used - 1});
-      prev = e1;
-      prev_idx = timing->used - 1;
+      if (e != hipSuccess) return fail(k, (int)e);
+      timing->recs.push_back({o.klass, o.work, prev_idx[sid], timing->used - 1});
+      prev_idx[sid] = timing->used - 1;
     }
   }
+  for (int k = 1; k <= SSAD_MAX_AUX_STREAMS; ++k)
+    if (dirty[k]) {
+      const int rc = join(k);
+      if (rc) return fail(n_ops - 1, rc);
+    }
   return 0;
 }
 

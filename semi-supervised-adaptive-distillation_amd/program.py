@@ -23,6 +23,7 @@ AFFINE_CHANNEL, UPSAMPLE, UPSAMPLE_GRAD, STEM_POOL, RELU_GRAD_ROWSUM, RELU_GRAD,
     48, 49, 50, 51, 52, 53, 55
 GEMM_CONV, CONV1X1_WGRAD, TRANSPOSE_FILTER, SUBSAMPLE, SUBSAMPLE_GRAD, RELU, IM2COL_BATCHED = \
     54, 56, 57, 58, 59, 60, 61
+FORK, JOIN = 62, 63
 
 # timing classes: one per kernel family.  bound "mfma": work = direct-form FLOPs
 # (2*9*Cout*Cin per output pixel; the Winograd engine executes 1/2.25 of them);
@@ -74,7 +75,8 @@ PEAK = {"mfma": 157.3e12, "mfma16": 2.5e15, "hbm": 8.0e12}      # MI355X_MICROAR
 
 
 class Op(C.Structure):
-    _fields_ = [("code", C.c_int32), ("klass", C.c_int32), ("i", C.c_int32 * 8), ("f", C.c_float * 4),
+    _fields_ = [("code", C.c_int32), ("klass", C.c_int32), ("stream", C.c_int32), ("reserved", C.c_int32),
+                ("i", C.c_int32 * 8), ("f", C.c_float * 4),
                 ("l", C.c_int64 * 2), ("p", C.c_void_p * 8), ("work", C.c_double)]
 
 
@@ -144,13 +146,23 @@ class Program(object):
         self.keep = []          # host tables / tensors the op records point into
         self.marks = {}
         self.arr = None
+        self.default_stream = 0      # builders switch this around a block of ops meant for an aux stream
 
     def mark(self, name):
         self.marks[name] = len(self.ops)
 
-    def add(self, code, klass=0, i=(), f=(), l=(), p=(), work=0.0, keep=()):
+    def fork(self, k=1):
+        """Aux stream k waits for everything enqueued so far on the main stream."""
+        return self.add(FORK, 0, i=(k,))
+
+    def join(self, k=1):
+        """The main stream waits for everything enqueued so far on aux stream k."""
+        return self.add(JOIN, 0, i=(k,))
+
+    def add(self, code, klass=0, i=(), f=(), l=(), p=(), work=0.0, keep=(), stream=None):
         o = Op()
         o.code, o.klass, o.work = code, klass, float(work)
+        o.stream = self.default_stream if stream is None else int(stream)
         for k, v in enumerate(i):
             o.i[k] = int(v)
         for k, v in enumerate(f):

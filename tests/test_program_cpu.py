@@ -29,8 +29,8 @@ def test_program_header_symbols_are_exported():
                              "ssad_timing_destroy", "ssad_timing_reset"]
     raw = ctypes.CDLL(K.LIB_PATH)
     assert all(hasattr(raw, n) for n in names)
-    # the Python mirror of ssad_op has the C layout: 4+4 + 8*4 + 4*4 + 2*8 + 8*8 + 8
-    assert ctypes.sizeof(PR.Op) == 144 and PR.Op.p.offset == 72 and PR.Op.work.offset == 136
+    # the Python mirror of ssad_op has the C layout: 4*4 + 8*4 + 4*4 + 2*8 + 8*8 + 8
+    assert ctypes.sizeof(PR.Op) == 152 and PR.Op.p.offset == 80 and PR.Op.work.offset == 144
 
 
 def test_distillation_step_program_structure():
