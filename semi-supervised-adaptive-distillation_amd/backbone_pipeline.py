@@ -214,9 +214,11 @@ class NativeResNetFPN(object):
         arr[0] = K.ConvLevel(x.data_ptr(), 0, dy.data_ptr(), x.shape[0], x.shape[2], x.shape[3], 0, 0)
         nb = K.lib().ssad_conv3x3_wgrad_workspace_bytes(arr, 1, layer.cout, layer.cin)
         self._ws_need = max(self._ws_need, nb)
+        self._aux(P)
         idx = P.add(PR.CONV3X3_WGRAD, 49, i=(1, layer.cout, layer.cin, 0), l=(nb,),
                     p=(arr, layer.gw, layer.gb, None),
-                    work=2.0 * 9 * layer.cout * layer.cin * x.shape[0] * x.shape[2] * x.shape[3], keep=[x, dy])
+                    work=2.0 * 9 * layer.cout * layer.cin * x.shape[0] * x.shape[2] * x.shape[3], keep=[x, dy],
+                    stream=self._wstream)
         self._ws_ops.append((idx, 3))
 
     def _wgrad1(self, P, x, dy, layer):
@@ -224,20 +226,38 @@ class NativeResNetFPN(object):
         pix = x.shape[2] * x.shape[3]
         nb = K.lib().ssad_conv1x1_wgrad_workspace_bytes(N, Cc, pix, layer.cout)
         self._ws_need = max(self._ws_need, nb)
+        self._aux(P)
         idx = P.add(PR.CONV1X1_WGRAD, 52, i=(N, Cc, pix, layer.cout, 0), l=(nb,),
-                    p=(x, dy, layer.gw, None), work=2.0 * N * pix * Cc * layer.cout, keep=[x, dy])
+                    p=(x, dy, layer.gw, None), work=2.0 * N * pix * Cc * layer.cout, keep=[x, dy],
+                    stream=self._wstream)
         self._ws_ops.append((idx, 3))
 
     def _bias_grad(self, P, dz, layer, rowsum=None):
         """db[c] = sum over n, pixels of dz; from the [N][C] plane sums when a ReluGradient pass
         already produced them."""
+        self._aux(P)
         if rowsum is not None:
             P.add(PR.CHANNEL_SUM, 51, i=(rowsum.shape[0], rowsum.shape[1], 1, 0), p=(rowsum, layer.gb),
-                  work=4.0 * rowsum.numel())
+                  work=4.0 * rowsum.numel(), stream=self._wstream)
         else:
+            # plane sums with one workgroup per (image, channel) -- N x C workgroups instead of the C of
+            # ssad_channel_sum -- then the sum over the images of the tiny [N][C] table
             N, Cc = dz.shape[0], dz.shape[1]
-            P.add(PR.CHANNEL_SUM, 51, i=(N, Cc, dz.shape[2] * dz.shape[3], 0), p=(dz, layer.gb),
-                  work=4.0 * dz.numel())
+            rows = self._t(N, Cc)
+            P.add(PR.RELU_GRAD_ROWSUM, 51, i=(N, Cc, dz.shape[2] * dz.shape[3]), p=(None, dz, None, rows),
+                  work=4.0 * dz.numel(), stream=self._wstream, keep=[dz, rows])
+            P.add(PR.CHANNEL_SUM, 51, i=(N, Cc, 1, 0), p=(rows, layer.gb), work=4.0 * rows.numel(),
+                  stream=self._wstream)
+
+    def _aux(self, P):
+        """Filter / bias gradients do not feed the data-gradient chain: they run on an auxiliary
+        stream behind a FORK (everything they read has been enqueued on the main stream), so that
+        they fill the last partial round of workgroups of the chain's kernels and vice versa.  They
+        share one workspace, which is safe because they are serialised on that one stream; nothing
+        they read is modified by the main stream before the segment's JOIN (gradients that meet are
+        written to fresh buffers, not accumulated in place)."""
+        if self._wstream:
+            P.fork(self._wstream)
 
     def _ew(self, P, code, i=(), p=(), l=(), f=(), nbytes=0.0):
         P.add(code, 51, i=i, p=p, l=l, f=f, work=nbytes)
@@ -245,6 +265,8 @@ class NativeResNetFPN(object):
     # -- program construction ----------------------------------------------------------------------
     def _build(self):
         self._ws_need, self._ws_ops = 0, []
+        import os
+        self._wstream = 1 if os.environ.get("SSAD_OVERLAP_WGRAD", "1") == "1" else 0
         L = self._layers
         dev = self.device
         lib = K.lib()
@@ -463,9 +485,11 @@ class NativeResNetFPN(object):
                              nbytes=12.0 * tgt.numel())
                 dy = None
             else:
-                # identity shortcut: dx = dz + W1^T dz1, accumulated in place on dz
-                self._gemm(P, l1.w.view(cmid, cin), cin, dz1, dz, cmid, cin, acc=True)
-                dy = dz
+                # identity shortcut: dx = dz + W1^T dz1 (dz through the residual operand into a fresh
+                # buffer: the auxiliary stream may still be reading dz)
+                dx = self._like(dz)
+                self._gemm(P, l1.w.view(cmid, cin), cin, dz1, dx, cmid, cin, res=dz)
+                dy = dx
             if j == 0:
                 P.mark("bwd_res%d_done" % stage)
 

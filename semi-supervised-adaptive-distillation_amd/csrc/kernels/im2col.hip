@@ -240,6 +240,35 @@ int ssad_im2col(const float* x, int C, int H, int W, int kh, int kw, int dil_h, 
   return (int)hipGetLastError();
 }
 
+// Batched im2col, square kernel: blockIdx.z = (image, column-matrix row k = (c, ki, kj)) -- decoded
+// once per workgroup -- and every thread writes four consecutive output pixels of that row with one
+// 16-byte store (the per-image kernel above decodes six div / mod per 4-byte element: 0.66 TB/s on
+// the stem's 84 MB-per-image column matrix; this one streams at the store rate).
+__global__ __launch_bounds__(kT) void im2col_rows_kernel(const float* __restrict__ x, const Geo g, int rows,
+                                                         float* __restrict__ col) {
+  const int z = blockIdx.z;
+  const int n = z / rows, k = z - n * rows;
+  const int kj = k % g.kw, ki = (k / g.kw) % g.kh, c = k / (g.kw * g.kh);
+  const int ow4 = g.OW >> 2;
+  const int p4 = blockIdx.x * kT + threadIdx.x;
+  if (p4 >= g.OH * ow4) return;
+  const int oh = p4 / ow4, ox = (p4 - oh * ow4) * 4;
+  const int h = oh * g.sh - g.pt + ki * g.dh;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (h >= 0 && h < g.H) {
+    const float* row = x + (((long long)n * g.C + c) * g.H + h) * g.W;
+    const int w0 = ox * g.sw - g.pl + kj * g.dw;
+    float e[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int w = w0 + q * g.sw;
+      e[q] = (w >= 0 && w < g.W) ? row[w] : 0.0f;
+    }
+    v = make_float4(e[0], e[1], e[2], e[3]);
+  }
+  reinterpret_cast<float4*>(col + ((long long)z * g.OH + oh) * g.OW)[ox >> 2] = v;
+}
+
 // the same for a whole batch: col[n][C*kh*kw][OH*OW] (the X operand of ssad_conv1x1_gemm for a
 // k x k convolution: the ResNet stem's 7x7 / stride 2)
 int ssad_im2col_batched(const float* x, int N, int C, int H, int W, int kernel, int stride, int pad,
@@ -248,6 +277,14 @@ int ssad_im2col_batched(const float* x, int N, int C, int H, int W, int kernel, 
         ssad_conv_out_size(H, kernel, 1, pad, pad, stride), ssad_conv_out_size(W, kernel, 1, pad, pad, stride)};
   if (!x || !col || N < 0 || C < 1 || g.OH < 1 || g.OW < 1) return SSAD_E_BADARG;
   const long long per = (long long)C * kernel * kernel * g.OH * g.OW;
+  const int rows = C * kernel * kernel;
+  if (N == 0) return 0;
+  if ((g.OW & 3) == 0 && (((uintptr_t)col) & 15) == 0 && (long long)N * rows < 65536) {
+    const int p4 = g.OH * (g.OW >> 2);
+    hipLaunchKernelGGL(im2col_rows_kernel, dim3((p4 + kT - 1) / kT, 1, N * rows), dim3(kT), 0,
+                       (hipStream_t)stream, x, g, rows, col);
+    return (int)hipGetLastError();
+  }
   for (int n = 0; n < N; ++n)
     hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(per)), dim3(kT), 0, (hipStream_t)stream,
                        x + (long long)n * C * H * W, g, col + (long long)n * per);

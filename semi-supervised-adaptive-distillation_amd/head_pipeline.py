@@ -145,7 +145,9 @@ class DistillHeads(object):
         self.cls_logits, self.bbox_pred = lv(self.A * self.C), lv(4 * self.A)
         self.d_cls_logits = lv(self.A * self.C)
         self.d_bbox_pred = lv(4 * self.A)
-        self.dbuf = {"cls": [lv(D), lv(D)], "bbox": [lv(D), lv(D)]}   # ping-pong tower gradients
+        # one gradient set per tower depth (not ping-pong): the filter gradient of a layer runs on an
+        # auxiliary stream while the data-gradient chain continues, so its dY must stay intact
+        self.dbuf = {t: [lv(D) for _ in range(cfg.num_convs + 1)] for t in ("cls", "bbox")}
         self.d_fpn = {t: lv(D) for t in ("cls", "bbox")}
         if self.distill:
             # teacher scratch: two ping-pong feature sets per tower + probabilities
@@ -190,7 +192,7 @@ class DistillHeads(object):
         arr = self._conv_table(problems)
         px = sum(x.shape[0] * x.shape[2] * x.shape[3] for p in problems for x in p[0])
         wino = self._use_wino(Cout)
-        if not wino and klass in (2, 3, 4):
+        if not wino and klass in (2, 3, 4, 16):
             klass = 18
         idx = P.add(PR.CONV3X3, klass, i=(len(arr), Cout, Cin, flags, int(wino)), p=(arr, None, None),
                     work=2.0 * 9 * Cout * Cin * px,
@@ -203,10 +205,12 @@ class DistillHeads(object):
         nb = K.lib().ssad_conv3x3_wgrad_workspace_bytes(arr, len(arr), Cout, self.D)
         self._wgrad_ws_need = max(getattr(self, "_wgrad_ws_need", 0), nb)
         px = sum(x.shape[0] * x.shape[2] * x.shape[3] for x in xs)
+        if self._wstream:
+            P.fork(self._wstream)       # behind everything enqueued so far (the producer of dys)
         idx = P.add(PR.CONV3X3_WGRAD, klass if self._use_wino(Cout) else 19,
                     i=(len(arr), Cout, self.D, 0), l=(nb,),
                     p=(arr, self.grads[name + "_w"], self.grads[name + "_b"], None),
-                    work=2.0 * 9 * Cout * self.D * px, keep=list(xs) + list(dys))
+                    work=2.0 * 9 * Cout * self.D * px, keep=list(xs) + list(dys), stream=self._wstream)
         self._wgrad_ops.append(idx)
         return idx, arr
 
@@ -252,6 +256,9 @@ class DistillHeads(object):
                             + (pd.numel() if pd is not None else 0)))
 
     def _build_programs(self):
+        import os
+        # filter gradients on an auxiliary stream beside the data-gradient chain (program.py FORK / JOIN)
+        self._wstream = 1 if os.environ.get("SSAD_OVERLAP_WGRAD", "1") == "1" else 0
         self._wgrad_ops, self._wgrad_ws_need = [], 0
         self._in_slots = []          # (table, index, which): entries that read the bound inputs
         # filters (the teacher's are frozen: packed by a program of their own, run when they change)
@@ -428,8 +435,8 @@ class DistillHeads(object):
             x_in = self.act[t][nl - 1]
             Cout = self.params[name + "_b"].numel()
             self._emit_wgrad(P, x_in, dy[t], name, Cout, klass_w)
-            out = self.dbuf[t][nl & 1]
-            self._emit_conv(P, [(dy[t], out, x_in, self.packed[name][1], None)], D, Cout, K.CONV_MASK_AUX, 2)
+            out = self.dbuf[t][nl]
+            self._emit_conv(P, [(dy[t], out, x_in, self.packed[name][1], None)], D, Cout, K.CONV_MASK_AUX, 16)
             dy[t] = out
         for li in range(nl - 1, -1, -1):
             probs = []
@@ -440,10 +447,10 @@ class DistillHeads(object):
                 if li == 0:
                     for l in range(len(x_in)):
                         self._in_slots.append((arr, l, "student", l))
-                out = self.dbuf[t][li & 1] if li > 0 else self.d_fpn[t]
+                out = self.dbuf[t][li] if li > 0 else self.d_fpn[t]
                 probs.append((dy[t], out, x_in if li > 0 else None, self.packed[name][1], None))
                 dy[t] = out
-            self._emit_conv(P, probs, D, D, K.CONV_MASK_AUX if li > 0 else 0, 2)
+            self._emit_conv(P, probs, D, D, K.CONV_MASK_AUX if li > 0 else 0, 16)
             if li == nl // 2:
                 P.mark("backward_late_done")
         if "backward_late_done" not in P.marks:
@@ -643,7 +650,7 @@ class DistillHeadsF16(DistillHeads):
         self.cls_logits, self.bbox_pred = lv(self.A * self.C), lv(4 * self.A)
         self.d_cls_logits, self.d_bbox_pred = lv(self.A * self.C), lv(4 * self.A)
         self.dy_pred = {"cls": blk(self.A * self.C), "bbox": blk(4 * self.A)}
-        self.dbuf = {"cls": [blk(D), blk(D)], "bbox": [blk(D), blk(D)]}
+        self.dbuf = {t: [blk(D) for _ in range(cfg.num_convs + 1)] for t in ("cls", "bbox")}
         self.d_fpn = {t: lv(D) for t in ("cls", "bbox")}
         self.in_blk = {"student": blk(D)}
         if self.distill:
@@ -750,9 +757,11 @@ class DistillHeadsF16(DistillHeads):
         nb = K.lib().ssad_conv3x3_wgrad_f16_levels_workspace_bytes(arr, n, Cin, Cout)
         self._wgrad_ws_need = max(self._wgrad_ws_need, nb)
         px = sum(x.shape[0] * x.shape[2] * x.shape[3] for x in xbs)
+        if self._wstream:
+            P.fork(self._wstream)
         idx = P.add(PR.F16_WGRAD, 37, i=(n, Cin, Cout, 0), f=(1.0,), l=(nb,),
                     p=(arr, self.ls_state[1:2], self.grads[name + "_w"], self.grads[name + "_b"], None),
-                    work=2.0 * 9 * Cout * Cin * px, keep=list(xbs) + list(dybs))
+                    work=2.0 * 9 * Cout * Cin * px, keep=list(xbs) + list(dybs), stream=self._wstream)
         self._wgrad_ops.append(idx)
 
     def _finish_workspaces(self, P):
@@ -776,7 +785,7 @@ class DistillHeadsF16(DistillHeads):
             x_in = self.act[t][nl - 1]
             Cout = self.params[name + "_b"].numel()
             self._emit_wgrad16(P, x_in, dy[t], name, D, Cout)
-            out = self.dbuf[t][nl & 1]
+            out = self.dbuf[t][nl]
             self._emit_conv16(P, [(dy[t], out, x_in, self.packed[name][1], None)], Cout, D,
                               K.CONV_MASK_AUX, klass)
             dy[t] = out
@@ -786,7 +795,7 @@ class DistillHeadsF16(DistillHeads):
                 name = self._layers(t)[li]
                 x_in = self.act[t][li - 1] if li > 0 else self.in_blk["student"]
                 self._emit_wgrad16(P, x_in, dy[t], name, D, D)
-                out = self.dbuf[t][li & 1]
+                out = self.dbuf[t][li]
                 probs.append((dy[t], out, x_in if li > 0 else None, self.packed[name][1], None))
                 dy[t] = out
             self._emit_conv16(P, probs, D, D, K.CONV_MASK_AUX if li > 0 else 0, 34)

@@ -31,7 +31,9 @@ FORK, JOIN = 62, 63
 KLASS = {
     0: dict(name="other", bound=None),
     1: dict(name="filter pack (wino_pack_multi_kernel)", bound="hbm"),
-    2: dict(name="subnet conv3x3 fwd/dgrad, 256-wide output (wino_conv_z_kernel)", bound="mfma", wino=True),
+    2: dict(name="subnet tower conv3x3 forward, 256-wide output (wino_conv_z_kernel)", bound="mfma", wino=True),
+    16: dict(name="subnet conv3x3 data gradient, 256-wide output (wino_conv_z_kernel; runs beside the filter "
+                  "gradients of the auxiliary stream, so its launches share the chip)", bound="mfma", wino=True),
     3: dict(name="cls_pred conv3x3 fwd, 720-wide output (wino_conv_z_kernel)", bound="mfma", wino=True),
     4: dict(name="bbox_pred conv3x3 fwd, 36-wide output (wino_conv_z_kernel)", bound="mfma", wino=True),
     5: dict(name="subnet conv3x3 filter gradient, tower layers (wino_wgrad_kernel + reduce + bias grad)",
