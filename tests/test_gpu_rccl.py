@@ -101,6 +101,33 @@ def _worker(rank, world, port, outdir):
     # two fp32 addends (or one): the sum is order independent, so it must match bit for bit
     res["sum_exact"] = (world > 2) or torch.equal(reduced, sum(all_local[1:], all_local[0]))
     res["finite"] = bool(torch.isfinite(heads.params.flat).all())
+    # the native backbone's four gradient buckets (FPN, res5, res4, res3) through the same exchange
+    from ssad_amd.backbone_pipeline import NativeResNetFPN
+    hw = (128, 128)
+    bb = NativeResNetFPN("r50", 1, hw, dev, train=True, lr=0.01, process_group=dist.group.WORLD, world_size=world)
+    if rank != 0:
+        bb.params_flat.mul_(1.5)                       # must be overwritten by the broadcast
+    bb.broadcast_params()
+    img = torch.randn((1, 3) + hw, device=dev, generator=torch.Generator(device=dev).manual_seed(50 + rank))
+    bb.pack()
+    out = bb.forward(img)
+    d_out = [torch.randn(t.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(70 + rank))
+             for t in out]
+    solo = NativeResNetFPN("r50", 1, hw, dev, train=True, lr=0.01)          # no exchange: rank-local gradients
+    solo.params_flat.copy_(bb.params_flat); solo.frozen_flat.copy_(bb.frozen_flat)
+    solo.pack(); solo.forward(img); solo.backward(d_out); solo.dp.wait()
+    bb.backward(d_out)
+    bb.dp.wait()
+    torch.cuda.synchronize()
+    bl, br = gather(solo.grads_flat), gather(bb.grads_flat)
+    bwant = torch.stack([t.double() for t in bl]).sum(0)
+    res["bb_reduced_equal"] = all(torch.equal(br[0], t) for t in br)
+    res["bb_sum_err"] = (bb.grads_flat.double() - bwant).abs().max().item()
+    res["bb_sum_scale"] = bwant.abs().max().item()
+    bb.sgd_step()
+    torch.cuda.synchronize()
+    bp = gather(bb.params_flat)
+    res["bb_params_equal"] = all(torch.equal(bp[0], t) for t in bp)
     if rank == 0:
         np.savez(os.path.join(outdir, "res.npz"), **{k: np.asarray(v) for k, v in res.items()})
     dist.barrier()
@@ -119,6 +146,8 @@ def test_rccl_allreduce_buckets_and_update(world):
     assert bool(r["params_after_equal"]) and bool(r["params_changed"]) and bool(r["finite"])
     assert bool(r["local_differs"]) and bool(r["sum_exact"])
     assert float(r["sum_err"]) <= 1e-6 * float(r["sum_scale"])
+    assert bool(r["bb_reduced_equal"]) and bool(r["bb_params_equal"])
+    assert float(r["bb_sum_err"]) <= 1e-6 * float(r["bb_sum_scale"])
 
 
 def test_bench_refuses_more_ranks_than_gpus():
