@@ -239,6 +239,7 @@ def main():
 
     losses_txt = ("PowSum + SigmoidAdaptiveDistillLoss + SigmoidFocalLoss + SelectSmoothL1Loss"
                   if distill else "SigmoidFocalLoss + SelectSmoothL1Loss")
+    native = False
     if args.workload == "heads":
         s_fpn = [torch.randn((N, 256, h, w), device=dev, generator=gen) for h, w in shapes]
         t_fpn = [torch.randn((N, 256, h, w), device=dev, generator=gen) for h, w in shapes] if distill else s_fpn
@@ -249,11 +250,15 @@ def main():
               "FPN features; the whole step is one native program of this repo's HIP kernels" % (
                   "teacher fwd, " if distill else "", losses_txt))
     else:
-        native_ok = (not f16) and args.student in ("r50", "r101") and args.teacher in ("none", "r50", "r101")
+        native_ok = args.student in ("r50", "r101") and args.teacher in ("none", "r50", "r101", "x101-64x4d")
         if args.backbone == "native" and not native_ok:
-            sys.stderr.write("bench.py: --backbone native covers ResNet-50/101 in fp32\n")
+            sys.stderr.write("bench.py: --backbone native covers ResNet-50/101 students and ResNet-50/101 / "
+                             "ResNeXt-101-64x4d teachers\n")
             sys.exit(2)
-        if args.backbone == "native" or (args.backbone == "auto" and native_ok):
+        # with --precision f16 the native backbones still compute in fp32 (only the subnets have fp16
+        # kernels); "auto" then keeps the harness, whose backbones run under fp16 autocast
+        native = args.backbone == "native" or (args.backbone == "auto" and native_ok and not f16)
+        if native:
             from ssad_amd.backbone_pipeline import NativeDistillModel
             model = NativeDistillModel(heads, student_arch=args.student,
                                        teacher_arch=args.teacher if distill else None, N=N, image_hw=image_hw,
@@ -322,8 +327,10 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(host / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f16 storage / f32 accumulate (subnets: this repo's kernels; backbones: torch "
-                      "autocast on MIOpen / rocBLAS)" if f16 else "f32"),
+            "dtype": ("f32" if not f16 else
+                      "f16 storage / f32 accumulate (subnets: this repo's kernels; backbones: " + (
+                          "this repo's fp32 kernels)" if (args.workload == "full" and native) else
+                          "torch autocast on MIOpen / rocBLAS)")),
             "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": N, "image": "3x%dx%d" % image_hw,
                        "fpn_levels": [list(s) for s in shapes], "anchors": 9, "classes": 80,

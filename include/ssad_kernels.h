@@ -427,6 +427,17 @@ SSAD_API int ssad_subsample(const float* x, int N, int C, int H, int W, int stri
                             ssad_stream_t stream);
 SSAD_API int ssad_subsample_grad(const float* dy, int N, int C, int H, int W, int stride, int accumulate,
                                  float* dx, ssad_stream_t stream);
+/* Grouped 3x3 convolution, pad 1, stride 1 or 2, forward (ResNeXt's cardinality-64 layer:
+ * detectron/lib/modeling/ResNet.py:247-258; conv_op_impl.h:93-98,126-173), NCHW fp32:
+ * x [N][C][H][W], filter [C][C/group][3][3] packed once into MFMA operand order, bias [C] or NULL
+ * -> y [N][C][OH][OW], OH = (H-1)/stride + 1.  Channels per group 4, 8, 16 or 32
+ * (SSAD_E_BADARG / -1 otherwise: use the default engine). */
+SSAD_API long long ssad_grouped_conv3x3_filter_floats(int C, int group);
+SSAD_API int ssad_grouped_conv3x3_pack_filter(const float* w, int C, int group, float* packed,
+                                              ssad_stream_t stream);
+SSAD_API int ssad_grouped_conv3x3_forward(const float* x, const float* packed, const float* bias, int N, int C,
+                                          int H, int W, int group, int stride, int relu, float* y,
+                                          ssad_stream_t stream);
 /* MaxPool / MaxPoolGradient, NCHW (caffe2/operators/pool_op.cu): windows are clipped to
  * the image; every input equal to its window's maximum receives the gradient */
 SSAD_API int ssad_max_pool_forward(const float* x, int N, int C, int H, int W, int kh, int kw,

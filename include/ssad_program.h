@@ -139,7 +139,12 @@ enum ssad_opcode {
   SSAD_OP_FORK = 62,
   SSAD_OP_JOIN = 63,
   /* ssad_im2col_batched(p0 = x, i0..i3 = N, C, H, W, i4 = kernel, i5 = stride, i6 = pad, p1 = col) */
-  SSAD_OP_IM2COL_BATCHED = 61
+  SSAD_OP_IM2COL_BATCHED = 61,
+  /* ssad_grouped_conv3x3_forward(p0 = x, p1 = packed filter, p2 = bias, i0..i3 = N, C, H, W, i4 = group,
+   * i5 = stride, i6 = relu, p3 = y) */
+  SSAD_OP_GROUPED_CONV3X3 = 64,
+  /* ssad_grouped_conv3x3_pack_filter(p0 = w, i0 = C, i1 = group, p1 = packed) */
+  SSAD_OP_GROUPED_PACK = 65
 };
 
 typedef struct ssad_op {

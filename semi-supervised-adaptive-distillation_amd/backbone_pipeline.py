@@ -36,23 +36,34 @@ from . import kernels as K
 from . import program as PR
 from .data_parallel import BucketedAllReduce
 
-ARCHS = {"r50": (3, 4, 6, 3), "r101": (3, 4, 23, 3)}
+ARCHS = {"r50": (3, 4, 6, 3), "r101": (3, 4, 23, 3), "x101-64x4d": (3, 4, 23, 3)}
+# ResNeXt (ResNet.py:247-258): name -> (groups, width per group); the stride sits on the 3x3
+# (RESNETS.STRIDE_1X1 = False).  Forward only: it is the frozen teacher of BASELINE config 5.
+GROUPED = {"x101-64x4d": (64, 4)}
 
 
 class _Layer(object):
-    __slots__ = ("name", "k", "cin", "cout", "stride", "train", "w", "b", "gw", "gb", "wt", "pf", "pd")
+    __slots__ = ("name", "k", "cin", "cout", "stride", "train", "group", "w", "b", "gw", "gb", "wt", "pf", "pd")
 
-    def __init__(self, name, k, cin, cout, stride, train):
+    def __init__(self, name, k, cin, cout, stride, train, group=1):
         self.name, self.k, self.cin, self.cout, self.stride, self.train = name, k, cin, cout, stride, train
+        self.group = group
         self.w = self.b = self.gw = self.gb = self.wt = self.pf = self.pd = None
+
+    @property
+    def wcin(self):
+        """Input channels one filter sees ([cout][cin / group][k][k], conv_op_impl.h:43-47)."""
+        return self.cin // self.group
 
 
 class NativeResNetFPN(object):
     def __init__(self, arch="r50", N=2, image_hw=(640, 896), device="cuda", train=True, src=None,
                  fpn_dim=256, lr=1e-5, momentum=0.9, weight_decay=1e-4, process_group=None, world_size=1):
         if arch not in ARCHS:
-            raise K.KernelError("native backbone: architectures %s (ResNeXt's grouped 3x3 runs on the harness)"
-                                % sorted(ARCHS))
+            raise K.KernelError("native backbone: architectures %s" % sorted(ARCHS))
+        if arch in GROUPED and train:
+            raise K.KernelError("native backbone: %s is forward only (the frozen teacher); its grouped 3x3 has no "
+                                "gradient kernels" % arch)
         self.arch, self.N, self.hw, self.device, self.train = arch, N, tuple(image_hw), device, train
         self.D = fpn_dim
         self.momentum, self.weight_decay = momentum, weight_decay
@@ -73,20 +84,22 @@ class NativeResNetFPN(object):
     def _define_layers(self):
         L = self._layers
 
-        def add(name, k, cin, cout, stride=1, train=True):
-            L[name] = _Layer(name, k, cin, cout, stride, train and self.train)
+        def add(name, k, cin, cout, stride=1, train=True, group=1):
+            L[name] = _Layer(name, k, cin, cout, stride, train and self.train, group)
+        groups, width = GROUPED.get(self.arch, (1, 64))
         add("stem.0", 7, 3, 64, 2, train=False)
         cin = 64
         self.blocks = []                       # (stage, j, cin, cmid, cout, stride, has_proj, trainable)
         for si, nblk in enumerate(ARCHS[self.arch]):
             stage = si + 2
-            cmid, cout = 64 * 2 ** si, 256 * 2 ** si
+            cmid, cout = groups * width * 2 ** si, 256 * 2 ** si
             tr = stage > 2                     # FREEZE_AT = 2: the stem and res2 stay frozen
             for j in range(nblk):
                 stride = 2 if (j == 0 and si > 0) else 1
                 pre = "res%d.%d" % (stage, j)
-                add(pre + ".c1", 1, cin, cmid, stride, tr)
-                add(pre + ".c2", 3, cmid, cmid, 1, tr)
+                s1, s3 = (stride, 1) if groups == 1 else (1, stride)        # STRIDE_1X1
+                add(pre + ".c1", 1, cin, cmid, s1, tr)
+                add(pre + ".c2", 3, cmid, cmid, s3, tr, groups)
                 add(pre + ".c3", 1, cmid, cout, 1, tr)
                 proj = cin != cout or stride != 1
                 if proj:
@@ -130,13 +143,13 @@ class NativeResNetFPN(object):
         assert len(order) + len(frozen) == len(L) or not self.train
 
         def size(l):
-            return l.cout * l.cin * l.k * l.k + l.cout
+            return l.cout * l.wcin * l.k * l.k + l.cout
 
         self.frozen_flat = torch.empty(sum(size(l) for l in frozen), dtype=torch.float32, device=dev)
         off = 0
         for l in frozen:
-            nw = l.cout * l.cin * l.k * l.k
-            l.w = self.frozen_flat[off:off + nw].view(l.cout, l.cin, l.k, l.k)
+            nw = l.cout * l.wcin * l.k * l.k
+            l.w = self.frozen_flat[off:off + nw].view(l.cout, l.wcin, l.k, l.k)
             l.b = self.frozen_flat[off + nw:off + nw + l.cout]
             off += nw + l.cout
         n_train = sum(size(l) for l in order)
@@ -282,6 +295,9 @@ class NativeResNetFPN(object):
                 l.wt = self._t(l.cin, ldm)
                 tgt.add(PR.TRANSPOSE_FILTER, 54, i=(l.cout, l.cin, ldm), p=(l.w, l.wt),
                         work=8.0 * l.cout * l.cin)
+            elif l.k == 3 and l.group > 1:                       # ResNeXt: MFMA operand order, packed once
+                l.pf = self._t(lib.ssad_grouped_conv3x3_filter_floats(l.cout, l.group))
+                tgt.add(PR.GROUPED_PACK, 54, i=(l.cout, l.group), p=(l.w, l.pf), work=4.0 * (l.w.numel() + l.pf.numel()))
             elif l.k == 3:
                 l.pf = self._t(lib.ssad_conv_wino_filter_floats(l.cout, l.cin))
                 need_pd = l.train                  # every trainable 3x3 sends a gradient further down
@@ -352,9 +368,15 @@ class NativeResNetFPN(object):
             if stride != 1:
                 xs = self._t(N, cin, h, w)
                 self._ew(P, PR.SUBSAMPLE, i=(N, cin, x.shape[2], x.shape[3], stride), p=(x, xs), nbytes=8.0 * xs.numel())
-            y1, y2, y = self._t(N, cmid, h, w), self._t(N, cmid, h, w), self._t(N, cout, h, w)
-            self._gemm(P, l1.wt, l1.wt.shape[1], xs, y1, cin, cmid, bias=l1.b, relu=True)
-            self._conv3(P, [(y1, y2, None, l2.pf, l2.b)], cmid, cmid, K.CONV_RELU)
+            a = xs if l1.stride == stride else x              # ResNeXt strides on the 3x3: c1 sees the full map
+            y1 = self._t(N, cmid, a.shape[2], a.shape[3])
+            y2, y = self._t(N, cmid, h, w), self._t(N, cout, h, w)
+            self._gemm(P, l1.wt, l1.wt.shape[1], a, y1, cin, cmid, bias=l1.b, relu=True)
+            if l2.group > 1:
+                P.add(PR.GROUPED_CONV3X3, 56, i=(N, cmid, y1.shape[2], y1.shape[3], l2.group, l2.stride, 1),
+                      p=(y1, l2.pf, l2.b, y2), work=2.0 * 9 * cmid * l2.wcin * y2.shape[0] * h * w)
+            else:
+                self._conv3(P, [(y1, y2, None, l2.pf, l2.b)], cmid, cmid, K.CONV_RELU)
             sc = xs
             if proj:
                 lp = L[pre + ".proj"]

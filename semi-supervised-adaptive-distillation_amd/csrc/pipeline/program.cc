@@ -159,6 +159,11 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
       return ssad_relu((const float*)p[0], (float*)p[1], o.l[0], s);
     case SSAD_OP_IM2COL_BATCHED:
       return ssad_im2col_batched((const float*)p[0], i[0], i[1], i[2], i[3], i[4], i[5], i[6], (float*)p[1], s);
+    case SSAD_OP_GROUPED_CONV3X3:
+      return ssad_grouped_conv3x3_forward((const float*)p[0], (const float*)p[1], (const float*)p[2], i[0], i[1],
+                                          i[2], i[3], i[4], i[5], i[6], (float*)p[3], s);
+    case SSAD_OP_GROUPED_PACK:
+      return ssad_grouped_conv3x3_pack_filter((const float*)p[0], i[0], i[1], (float*)p[1], s);
     case SSAD_OP_CHANNEL_SUM:
       return ssad_channel_sum((const float*)p[0], i[0], i[1], i[2], (float*)p[1], i[3], s);
     default:

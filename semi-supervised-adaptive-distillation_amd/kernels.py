@@ -168,6 +168,10 @@ def lib():
     L.ssad_conv1x1_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]
     L.ssad_subsample.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_subsample_grad.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.ssad_grouped_conv3x3_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.ssad_grouped_conv3x3_filter_floats.argtypes = [i32, i32]
+    L.ssad_grouped_conv3x3_filter_floats.restype = C.c_longlong
+    L.ssad_grouped_conv3x3_pack_filter.argtypes = [vp, i32, i32, vp, vp]
     L.ssad_kernels_arch.restype = C.c_char_p
     L.ssad_kernels_abi_version.restype = i32
     _lib = L
@@ -862,3 +866,30 @@ def subsample_grad(dy, H, W, stride=2, accumulate_into=None):
     _check(lib().ssad_subsample_grad(_ptr(dy), N, Cc, H, W, stride, int(accumulate_into is not None), _ptr(dx),
                                      _stream()), "subsample_grad")
     return dx
+
+
+def grouped_conv3x3_pack_filter(w, group):
+    """[C][C/group][3][3] -> the grouped kernel's MFMA operand order."""
+    _f32c(w, "w")
+    Cc = w.shape[0]
+    n = lib().ssad_grouped_conv3x3_filter_floats(Cc, group)
+    if n < 0 or w.shape[1] * group != Cc:
+        raise KernelError("grouped_conv3x3: %d channels in %d groups (4, 8, 16 or 32 per group)" % (Cc, group))
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    _check(lib().ssad_grouped_conv3x3_pack_filter(_ptr(w), Cc, group, _ptr(out), _stream()), "grouped pack")
+    return out
+
+
+def grouped_conv3x3_forward(x, w, bias=None, group=64, stride=1, relu=False, out=None, packed=None):
+    """Grouped 3x3 / pad 1 convolution (ResNeXt): x [N,C,H,W], w [C, C/group, 3, 3] (or its pack)."""
+    _f32c(x, "x")
+    N, Cc, H, W = x.shape
+    if packed is None:
+        packed = grouped_conv3x3_pack_filter(w, group)
+    oh, ow = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = out if out is not None else torch.empty((N, Cc, oh, ow), dtype=torch.float32, device="cuda")
+    if bias is not None:
+        _f32c(bias, "bias")
+    _check(lib().ssad_grouped_conv3x3_forward(_ptr(x), _ptr(packed), _ptr(bias), N, Cc, H, W, group, stride,
+                                              int(relu), _ptr(y), _stream()), "grouped_conv3x3_forward")
+    return y

@@ -95,3 +95,23 @@ def test_native_backbone_frozen_teacher_matches_torch_r101_small():
         want = ref(images)
     for g, w in zip(got, want):
         assert rel(g, w) < 3e-5
+
+
+def test_native_resnext_teacher_matches_torch():
+    """ResNeXt-101-64x4d (BASELINE config 5's teacher): cardinality-64 grouped 3x3 layers with the
+    stride on the 3x3 (grouped_conv3x3.hip), forward only, against torch's float64 network."""
+    from ssad_amd.backbone_pipeline import NativeResNetFPN
+    from ssad_amd import kernels as K
+    ref = _torch_reference("x101-64x4d")
+    N, hw = 1, (128, 256)
+    nat = NativeResNetFPN("x101-64x4d", N, hw, "cuda", train=False, src=ref)
+    assert nat._layers["res2.0.c2"].group == 64 and nat._layers["res3.0.c2"].stride == 2
+    images = torch.randn((N, 3) + hw, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+    got = nat.forward(images)
+    with torch.no_grad():
+        want = ref.double()(images.double())
+    for g, w in zip(got, want):
+        assert tuple(g.shape) == tuple(w.shape)
+        assert rel(g, w) < 2e-5, rel(g, w)
+    with pytest.raises(K.KernelError):
+        NativeResNetFPN("x101-64x4d", N, hw, "cuda", train=True)

@@ -111,3 +111,52 @@ def test_gemm_conv_full_size_adjoints(K):
     n0 = 13
     ref = oracle.conv_forward(X[n0:n0 + 1].cpu().numpy(), Wt.cpu().numpy(), None, kernel=1, stride=1, pad=0)
     close(Y[n0:n0 + 1].cpu().numpy(), ref, CONV_RTOL, CONV_FLOOR, "full-size slice")
+
+
+def _grouped_oracle(X, Wt, b, group, stride):
+    """The groups are independent convolutions over contiguous channel blocks
+    (conv_op_impl.h:93-98,126-173): the oracle's dense conv per group."""
+    cg = X.shape[1] // group
+    outs = [oracle.conv_forward(np.ascontiguousarray(X[:, g * cg:(g + 1) * cg]),
+                                np.ascontiguousarray(Wt[g * cg:(g + 1) * cg]),
+                                None if b is None else b[g * cg:(g + 1) * cg], kernel=3, stride=stride, pad=1)
+            for g in range(group)]
+    return np.concatenate(outs, axis=1)
+
+
+@pytest.mark.parametrize("geom", [
+    (2, 4, 16, 19, 23, 1), (2, 4, 16, 19, 23, 2),       # cg = 4 (res2), ragged tiles
+    (1, 8, 8, 16, 32, 1), (2, 8, 4, 9, 17, 2),          # cg = 8 (res3)
+    (2, 16, 4, 12, 24, 1), (1, 16, 64, 8, 16, 2),       # cg = 16 (res4), 64 groups
+    (1, 32, 2, 10, 21, 1), (2, 32, 3, 16, 24, 2),       # cg = 32 (res5)
+], ids=lambda g: "N%d_cg%d_G%d_%dx%d_s%d" % g)
+def test_grouped_conv3x3_vs_oracle(K, geom):
+    N, cg, G, H, W, s = geom
+    C = cg * G
+    rng = np.random.default_rng(sum(geom))
+    X = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((C, cg, 3, 3)) * (1.0 / np.sqrt(9 * cg))).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    ref = _grouped_oracle(X, Wt, b, G, s)
+    got = K.grouped_conv3x3_forward(dev(X), dev(Wt), dev(b), group=G, stride=s)
+    assert tuple(got.shape) == ref.shape
+    close(got.cpu().numpy(), ref, CONV_RTOL, CONV_FLOOR, "Y")
+    got = K.grouped_conv3x3_forward(dev(X), dev(Wt), None, group=G, stride=s, relu=True)
+    close(got.cpu().numpy(), np.maximum(_grouped_oracle(X, Wt, None, G, s), 0), CONV_RTOL, CONV_FLOOR, "relu(Y)")
+
+
+def test_grouped_conv3x3_vs_reference_operator_golden(K, golden_dir):
+    """Every grouped case of tests/golden/conv_ref.npz (outputs of the reference's compiled ConvOp
+    with group > 1)."""
+    g = np.load(os.path.join(golden_dir, "conv_ref.npz"))
+    names = [k[:-5] for k in g.files if k.endswith("_dims") and int(g[k][9]) > 1]
+    assert len(names) >= 6
+    for name in names:
+        seed, N, Cin, M, H, W, k, s, p, grp = [int(v) for v in g[name + "_dims"]]
+        X, Wt, b, _ = mg.conv_ref_inputs(seed, N, Cin, M, H, W, k, s, p, grp)
+        Y = K.grouped_conv3x3_forward(dev(X), dev(Wt), dev(b), group=grp, stride=s).cpu().numpy()
+        close(Y.ravel()[g[name + "_Y_idx"]], g[name + "_Y"], CONV_RTOL, CONV_FLOOR, name + " Y")
+    with pytest.raises(K.KernelError):          # 12 channels per group: not a ResNeXt width
+        K.grouped_conv3x3_forward(torch.zeros(1, 24, 4, 4, device="cuda"), torch.zeros(24, 12, 3, 3, device="cuda"),
+                                  group=2)
+    assert K.lib().ssad_grouped_conv3x3_filter_floats(256, 64) == 64 * 9 * 64
