@@ -32,13 +32,20 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+using ssad_dev::uniform_rsrc;
 
 constexpr int kThreads = 256;
 constexpr int TS = 16;                 // output tile edge
 constexpr int HS = TS + 2;             // halo tile edge
 constexpr int CBC = 4;                 // 8-channel blocks per K chunk (32 channels)
 constexpr int SLOTS = CBC * HS * HS;   // 16-byte slots per stage (1296)
-constexpr int NLD = (SLOTS + kThreads - 1) / kThreads;   // staging loads per thread (6)
+constexpr int NDMA = (SLOTS + 63) / 64;   // wave-level LDS-DMA instructions per stage (21)
+constexpr int STAGE = NDMA * 64;           // stage pitch in slots (1344: the last instruction's tail)
+constexpr int NLD = (NDMA + 3) / 4;        // DMA instructions per wave (6; waves 1-3 issue 5)
+constexpr int AD = 6;                      // filter ring depth, K-steps
+constexpr unsigned kOob = 0x80000000u;     // buffer offset past any descriptor: loads 0
 constexpr int MT = 128;                // output channels per workgroup
 
 struct F16Conv {
@@ -64,62 +71,89 @@ struct F16Levels {
   const float* bias[SSAD_MAX_F16_LEVELS];
   int n_levels;
   int C, M, relu, sigmoid, out_nchw_f32;
+  int mblocks;                             // 128-wide output-channel blocks
 };
 
 __device__ __forceinline__ half8 as_half8(const uint4& v) {
   return __builtin_bit_cast(half8, v);
 }
 
-template <int DBG>   // ablation switches for tools/f16_probe.py: 1 no halo fetch, 2 no filter reload, 4 no LDS reads
+#ifdef F16_TIMELINE       // debug build only (tools/f16_timeline.py): s_memtime stamps of wave 0 per workgroup
+__device__ unsigned long long g_f16_dbg[4096][4];
+#define STAMP(k) \
+  if (threadIdx.x == 0 && blockIdx.x < 4096) g_f16_dbg[blockIdx.x][k] = __builtin_readcyclecounter()
+#else
+#define STAMP(k)
+#endif
+
+#ifndef F16_ABLATE        // debug builds (make EXTRA=-DF16_ABLATE=n): 1 no halo fetch, 2 no filter reload, 4 no LDS reads
+#define F16_ABLATE 0
+#endif
+constexpr int kOutBlocked = 0, kOutMasked = 1, kOutNchw = 2;
+
+template <int OUT>        // output form: blocked fp16, blocked fp16 under the ReluGradient mask, NCHW fp32
 __global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Levels q) {
-  __shared__ uint4 lds[2 * SLOTS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int DBG = F16_ABLATE;
+  __shared__ uint4 lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave index as a scalar: everything derived from it (channel block, LDS-DMA slots) is then
+  // wave-uniform for the compiler too -- otherwise each buffer access with such a scalar offset is
+  // wrapped in a readfirstlane waterfall loop
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wo = wave & 1, wp = wave >> 1;
   const int j = lane & 31, h = lane >> 5;
+  // Workgroup -> (tile, output-channel block).  Consecutive workgroup ids go round the 8 XCDs, so
+  // ids b, b + 8, b + 16 ... share an L2: the channel blocks of one tile are laid out along that
+  // sequence and fetch the tile's input from HBM once.
+  STAMP(0);
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int mb = seq % q.mblocks;
+  int t = (seq / q.mblocks) * 8 + xcd;
+  if (t >= q.tile0[q.n_levels]) return;
   int lv = 0;
   for (int l = 1; l < q.n_levels; ++l)
-    if ((int)blockIdx.x >= q.tile0[l]) lv = l;
+    if (t >= q.tile0[l]) lv = l;
   F16Conv p;
   p.x = q.x[lv]; p.w = q.w[lv]; p.bias = q.bias[lv]; p.aux = q.aux[lv]; p.y = q.y[lv];
   p.N = q.N[lv]; p.C = q.C; p.H = q.H[lv]; p.W = q.W[lv]; p.M = q.M;
   p.tiles_x = (p.W + TS - 1) / TS; p.tiles_y = (p.H + TS - 1) / TS;
   p.relu = q.relu; p.sigmoid = q.sigmoid; p.out_nchw_f32 = q.out_nchw_f32;
-  int t = blockIdx.x - q.tile0[lv];
+  t -= q.tile0[lv];
   const int tx = t % p.tiles_x; t /= p.tiles_x;
   const int ty = t % p.tiles_y;
   const int n = t / p.tiles_y;
   const int y0 = ty * TS, x0 = tx * TS;
-  const int ocb = blockIdx.y * MT;
+  const int ocb = mb * MT;
   const int CB = (p.C + 7) >> 3;          // channel blocks; a tail block is zero padded by the packers
   const long long plane = (long long)p.H * p.W;
+  const int plane16 = (int)plane * 16;
+  const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(p.x, (unsigned)((long long)p.N * CB * plane16));
+  const __amdgpu_buffer_rsrc_t wrs = uniform_rsrc(p.w, (unsigned)(9LL * CB * p.M * 16));
 
-  // ---- staging plan: slot s = tid + 256 i  ->  (block, row, col) of the halo tile
-  int goff[NLD];                           // 16-byte slots; the launcher checks the tensor fits 2^31
-  bool gok[NLD];
-  int gcb[NLD];
+  // ---- halo staging by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write.
+  // Stage slot s = (block, row, col) of the 18 x 18 x 4-block halo tile; wave-level instruction k
+  // writes slots [64 k, 64 k + 64); wave w issues k = w, w + 4, ...  Lanes outside the image (and
+  // past the last channel block) go to an out-of-range offset: the DMA writes zeros for them.
+  unsigned dvo[NLD];
+  int dcb[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    const int s = tid + kThreads * i;
+    const int s = 64 * (wave + 4 * i) + lane;
     const int cbl = s / (HS * HS), r = s % (HS * HS);
-    gcb[i] = cbl;
     const int gy = y0 - 1 + r / HS, gx = x0 - 1 + r % HS;
-    gok[i] = s < SLOTS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    goff[i] = (int)(((long long)n * CB + cbl) * plane + (long long)gy * p.W + gx);
+    const bool ok = s < SLOTS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    dcb[i] = cbl;
+    dvo[i] = ok ? (unsigned)((((long long)n * CB + cbl) * plane + (long long)gy * p.W + gx) * 16) : kOob;
   }
-  uint4 stage[NLD];
-  auto fetch = [&](int chunk) {
+  auto fetch = [&](int chunk, int buf) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      stage[i] = make_uint4(0u, 0u, 0u, 0u);
-      if (gok[i] && chunk * CBC + gcb[i] < CB)        // beyond the last block: K padding = 0
-        stage[i] = p.x[goff[i] + chunk * CBC * (int)plane];
-    }
-  };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int s = tid + kThreads * i;
-      if (s < SLOTS) lds[buf * SLOTS + s] = stage[i];
+      const int k = wave + 4 * i;
+      if (k < NDMA) {                                        // wave-uniform
+        const unsigned vo = (chunk * CBC + dcb[i] < CB) ? dvo[i] : kOob;     // K padding = 0
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr)(lds + buf * STAGE + 64 * k), 16, vo,
+                                                 chunk * CBC * plane16, 0, 0);
+      }
     }
   };
 
@@ -130,20 +164,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Level
   // a group (18 slots apart) collide on two 16-byte bank slots -- 2x the LDS cycles.
   const int brow = wp * 8 + (j >> 4), bcol = (j & 16) ? ((j - 2) & 15) : j;
   const int bbase = (h * HS + brow) * HS + bcol;           // + ((2 ks) * HS + 2 tt + dy) * HS + dx
-  // A (filter): row = output channel, clamped into range (rows beyond M are never stored)
-  int aoc[2];
+  // A (filter): Wp[tap][cb][m] x 16 B; lane = (row m, 8-channel half h).  Rows beyond M are
+  // clamped (never stored); a block beyond the last meets B = 0 (or reads zeros past the pack).
+  unsigned avo[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int oc = ocb + wo * 64 + i * 32 + j;
-    aoc[i] = oc < p.M ? oc : p.M - 1;
+    avo[i] = (unsigned)(h * p.M + (oc < p.M ? oc : p.M - 1)) * 16u;
   }
-  auto load_a = [&](int chunk, int q, half8 (&a)[2]) {     // q = ks * 9 + tap
-    const int ks = q / 9, tap = q % 9;
-    int cb = chunk * CBC + 2 * ks + h;                     // a block beyond the last meets B = 0
-    cb = cb < CB ? cb : CB - 1;
-    const long long row = ((long long)tap * CB + cb) * p.M;
+  auto load_a = [&](int chunk, int qq, half8 (&a)[2]) {     // qq = ks * 9 + tap
+    const int ks = qq / 9, tap = qq % 9;
+    const int soff = ((tap * CB + chunk * CBC + 2 * ks) * p.M) * 16;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a[i] = as_half8(p.w[row + aoc[i]]);
+    for (int i = 0; i < 2; ++i)
+      a[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrs, avo[i], soff, 0));
   };
 
   float16v acc[2][4];
@@ -155,98 +189,138 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Level
       for (int r = 0; r < 16; ++r) acc[i][tt][r] = 0.0f;
 
   const int nchunks = (CB + CBC - 1) / CBC;
-  // Filter ring, AD = 9 K-steps deep: vector-memory results return in order, so a filter load
-  // issued behind the halo fetch (an HBM-latency load) is only needed 9 steps (> 2000 MFMA
-  // cycles) later; a one-step prefetch stalls every chunk for the whole fetch latency.
-  constexpr int AD = 3;
+  // Filter ring, AD K-steps deep.  Vector-memory results return in order, so a filter load issued
+  // behind the halo DMA of the next chunk (HBM latency) cannot return before it: the AD steps
+  // loaded ahead of the DMA are what the MFMAs run on meanwhile.  Every phase of a step is fenced
+  // (sched_barrier) -- left alone, hipcc sinks each filter load to just above its first use and
+  // the ring degenerates to one step of cover.
   half8 ar[AD][2];
+  fetch(0, 0);
 #pragma unroll
-  for (int q = 0; q < AD; ++q) load_a(0, q, ar[q]);
-  fetch(0);
-  stash(0);
-  __syncthreads();
+  for (int qq = 0; qq < AD; ++qq) load_a(0, qq, ar[qq]);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * AD) : "memory");       // the DMA has landed
+  __builtin_amdgcn_s_barrier();
+  STAMP(1);
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
-    const uint4* tile = lds + (c & 1) * SLOTS;
+    const uint4* tile = lds + (c & 1) * STAGE;
     half8 b[2][4];
-    auto read_b = [&](int q, half8 (&bb)[4]) {
-      const int ks = q / 9, tap = q % 9, dy = tap / 3, dx = tap % 3;
+    auto read_b = [&](int qq, half8 (&bb)[4]) {
+      const int ks = qq / 9, tap = qq % 9, dy = tap / 3, dx = tap % 3;
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
         bb[tt] = as_half8(tile[bbase + ((2 * ks) * HS + 2 * tt + dy) * HS + dx]);
     };
     read_b(0, b[0]);
+    // the other buffer was last read in chunk c - 1, which every wave has left (barrier above)
+    if (more && !(DBG & 1)) fetch(c + 1, (c + 1) & 1);
 #pragma unroll
-    for (int q = 0; q < 18; ++q) {
-      if (q + 1 < 18 && !(DBG & 4)) read_b(q + 1, b[(q + 1) & 1]);
-      half8 a0 = ar[q % AD][0], a1 = ar[q % AD][1];
-      // refill this ring slot with the filter of step q + AD
-      if (!(DBG & 2)) {
-        if (q + AD < 18) load_a(c, q + AD, ar[q % AD]);
-        else if (more) load_a(c + 1, q + AD - 18, ar[q % AD]);
-      }
-      if (q == 0 && more && !(DBG & 1)) fetch(c + 1);      // behind the ring's loads of this step
+    for (int qq = 0; qq < 18; ++qq) {
+      if (qq + 1 < 18 && !(DBG & 4)) read_b(qq + 1, b[(qq + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
-        acc[0][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[q & 1][tt], acc[0][tt], 0, 0, 0);
-        acc[1][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[q & 1][tt], acc[1][tt], 0, 0, 0);
+        acc[0][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[qq % AD][0], b[qq & 1][tt], acc[0][tt], 0, 0, 0);
+        acc[1][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[qq % AD][1], b[qq & 1][tt], acc[1][tt], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      // refill this ring slot (its MFMAs have issued) with the filter of step qq + AD
+      if (!(DBG & 2)) {
+        if (qq + AD < 18) load_a(c, qq + AD, ar[qq % AD]);
+        else if (more) load_a(c + 1, qq + AD - 18, ar[qq % AD]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) stash((c + 1) & 1);
-    __syncthreads();
+    if (more) {
+      // all but the newest 2 AD loads (the ring of the next chunk's first steps) have returned,
+      // this wave's DMA among them; after the barrier everybody's has
+      if (DBG & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * AD) : "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }
 
-  // ---- epilogue: C/D row = (r & 3) + 8 (r >> 2) + 4 h, column = j.
-  // All bias values first: a load issued between stores would wait (in-order vmcnt) for
-  // every store before it -- one HBM write latency per store.
-  float bv[2][4][4];
+  STAMP(2);
+  // ---- epilogue: C/D row = (r & 3) + 8 (r >> 2) + 4 h, column = j.  Branch-free buffer accesses:
+  // a lane's pixel gives the vector offset (out-of-image lanes: an out-of-range offset, the store
+  // is dropped), the channel block is wave-uniform and goes into the scalar offset.  (The first
+  // version computed a 64-bit address with integer multiplies behind three run-time branches
+  // per store: the epilogue took 28 % of a workgroup's life, tools/f16_timeline.py.)
+  const int oc_w = ocb + wo * 64;                       // this wave's first output channel
+  unsigned pvo[4];                                      // per MFMA column tile: this lane's pixel
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const int gy = y0 + wp * 8 + 2 * tt + (j >> 4), gx = x0 + bcol;
+    const bool okp = gy < p.H && gx < p.W;
+    const long long pix = (long long)gy * p.W + gx;
+    if (OUT == kOutNchw) pvo[tt] = okp ? (unsigned)((((long long)n * p.M + 4 * h) * plane + pix) * 4) : kOob;
+    else pvo[tt] = okp ? (unsigned)((((long long)n * (p.M >> 3)) * plane + pix) * 16 + 8 * h) : kOob;
+  }
+  const unsigned ybytes = OUT == kOutNchw ? (unsigned)((long long)p.N * p.M * plane * 4)
+                                          : (unsigned)((long long)p.N * (p.M >> 3) * plane16);
+  const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(p.y, ybytes);
+  const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(p.bias ? (const void*)p.bias : (const void*)p.y,
+                                                  p.bias ? (unsigned)p.M * 4u : 0u);   // no bias: reads 0
+  // bias of the lane's 32 channels: 8 x 16 bytes (channels past M read 0; they are never stored)
+  float4 bq[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int oc = ocb + wo * 64 + i * 32 + 8 * g + 4 * h + e;
-        bv[i][g][e] = (p.bias && oc < p.M) ? p.bias[oc] : 0.0f;
-      }
+      bq[i][g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)h * 16u,
+                                                                                (oc_w + i * 32 + 8 * g) * 4, 0));
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int oc0 = ocb + wo * 64 + i * 32;
+    const int oc0 = oc_w + i * 32;
+    uint2 mk[4][4];
+    if (OUT == kOutMasked) {                            // relu_op.cu:44-53: dX = Y > 0 ? dY : 0
+      const __amdgpu_buffer_rsrc_t mrs = uniform_rsrc(p.aux, ybytes);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          mk[tt][g] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(
+                                                    mrs, pvo[tt], ((oc0 >> 3) + g) * plane16, 0));
+    }
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
-      const int gy = y0 + wp * 8 + 2 * tt + (j >> 4), gx = x0 + bcol;
-      if (gy >= p.H || gx >= p.W) continue;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int oc = oc0 + 8 * g + 4 * h;          // first of this lane's 4 channels
+        if (oc0 + 8 * g >= p.M) continue;               // wave-uniform
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[i][tt][4 * g + e] + bv[i][g][e];
-          if (p.relu) v[e] = fmaxf(v[e], 0.0f);
-          if (p.sigmoid) v[e] = 1.0f / (1.0f + __expf(-v[e]));     // sigmoid_op.cu:25-29
-        }
-        if (p.out_nchw_f32) {
-          float* yo = static_cast<float*>(p.y);
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][tt][4 * g + e] + bq[i][g][e];
+        if (p.relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (oc + e < p.M) yo[(((long long)n * p.M + oc + e) * p.H + gy) * p.W + gx] = v[e];
-        } else if (oc < p.M) {                        // M % 8 == 0 on this path
-          const long long slot = ((long long)n * (p.M >> 3) + (oc >> 3)) * plane + (long long)gy * p.W + gx;
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        }
+        if (p.sigmoid) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));     // sigmoid_op.cu:25-29
+        }
+        if (OUT == kOutNchw) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned vo = (oc0 + 8 * g + 4 * h + e < p.M) ? pvo[tt] : kOob;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), yrs, vo,
+                                                  (oc0 + 8 * g + e) * ((int)plane * 4), 0);
+          }
+        } else {
           half4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
-          if (p.aux) {                                // relu_op.cu:44-53: dX = Y > 0 ? dY : 0
-            const half4 m = *reinterpret_cast<const half4*>(p.aux + slot * 8 + 4 * h);
+          if (OUT == kOutMasked) {
+            const half4 m = __builtin_bit_cast(half4, mk[tt][g]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = m[e] > (_Float16)0.0f ? o[e] : (_Float16)0.0f;
           }
-          _Float16* yo = static_cast<_Float16*>(p.y);
-          *reinterpret_cast<half4*>(yo + slot * 8 + 4 * h) = o;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2v, o), yrs, pvo[tt],
+                                                ((oc0 >> 3) + g) * plane16, 0);
         }
       }
     }
   }
+  STAMP(3);
 }
 
 // NCHW fp32 -> blocked fp16 (round to nearest even), one thread per 16-byte slot
@@ -432,7 +506,8 @@ int ssad_conv3x3_forward_f16_levels(const ssad_f16_level* levels, int n_levels, 
   for (int l = 0; l < n_levels; ++l) {
     const ssad_f16_level& L = levels[l];
     if (!L.x || !L.y || L.N < 0 || L.H < 1 || L.W < 1 || masked != (L.aux != nullptr)) return SSAD_E_BADARG;
-    if ((long long)L.N * ((C + 7) / 8 + CBC) * L.H * L.W >= (1LL << 31)) return SSAD_E_BADARG;
+    // buffer addressing: byte offsets below 2^31 (2 GiB of blocked fp16 per level)
+    if ((long long)L.N * ((C + 7) / 8 + CBC) * L.H * L.W * 16 >= (1LL << 31)) return SSAD_E_BADARG;
     q.x[l] = static_cast<const uint4*>(L.x);
     q.y[l] = L.y;
     q.aux[l] = static_cast<const _Float16*>(L.aux);
@@ -451,15 +526,19 @@ int ssad_conv3x3_forward_f16_levels(const ssad_f16_level* levels, int n_levels, 
   q.relu = (flags & SSAD_CONV_RELU) != 0;
   q.sigmoid = (flags & SSAD_CONV_SIGMOID) != 0;
   q.out_nchw_f32 = nchw;
-  const dim3 grid((unsigned)tiles, (unsigned)((M + MT - 1) / MT));
-  static const int dbg = getenv("SSAD_F16_DBG") ? atoi(getenv("SSAD_F16_DBG")) : 0;
-  switch (dbg) {
-    case 1: hipLaunchKernelGGL(conv3x3_f16_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, q); break;
-    case 2: hipLaunchKernelGGL(conv3x3_f16_kernel<2>, grid, dim3(kThreads), 0, (hipStream_t)stream, q); break;
-    case 4: hipLaunchKernelGGL(conv3x3_f16_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, q); break;
-    case 7: hipLaunchKernelGGL(conv3x3_f16_kernel<7>, grid, dim3(kThreads), 0, (hipStream_t)stream, q); break;
-    default: hipLaunchKernelGGL(conv3x3_f16_kernel<0>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+  q.mblocks = (M + MT - 1) / MT;
+  if (9LL * ((C + 7) / 8) * M * 16 >= (1LL << 31)) return SSAD_E_BADARG;
+  const long long wgs = (tiles + 7) / 8 * 8 * q.mblocks;
+  if (wgs >= (1LL << 31)) return SSAD_E_BADARG;
+  const dim3 grid((unsigned)wgs);
+  // buffer-addressed output (and mask): byte offsets below 2^31 per level
+  for (int l = 0; l < n_levels; ++l) {
+    const long long px = (long long)levels[l].N * levels[l].H * levels[l].W;
+    if ((nchw ? px * M * 4 : px * (M >> 3) * 16) >= (1LL << 31)) return SSAD_E_BADARG;
   }
+  if (nchw) hipLaunchKernelGGL(conv3x3_f16_kernel<kOutNchw>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+  else if (masked) hipLaunchKernelGGL(conv3x3_f16_kernel<kOutMasked>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+  else hipLaunchKernelGGL(conv3x3_f16_kernel<kOutBlocked>, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
   return (int)hipGetLastError();
 }
 
@@ -851,3 +930,9 @@ int ssad_conv3x3_wgrad_f16(const void* x_blocked, const void* dy_blocked, int N,
 }
 
 }  // extern "C"
+
+#ifdef F16_TIMELINE
+extern "C" SSAD_API int ssad_f16_dbg_read(void* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_f16_dbg), sizeof(g_f16_dbg));
+}
+#endif
