@@ -510,8 +510,9 @@ SSAD_API int ssad_f16_pack_filter(const float* w, int M, int C, void* packed_fwd
                                   void* packed_dgrad, ssad_stream_t stream);
 #define SSAD_F16_OUT_NCHW_F32 16   /* prediction layers: write y as NCHW fp32 for the loss kernels */
 /* y = conv3x3(x_blocked, packed) (+ bias[M], fp32) (ReLU with SSAD_CONV_RELU, sigmoid with
- * SSAD_CONV_SIGMOID); y is blocked fp16 [N][M/8][H][W][8] (M % 8 == 0) or, with
- * SSAD_F16_OUT_NCHW_F32, float [N][M][H][W].  Data gradient: the same call with packed_dgrad,
+ * SSAD_CONV_SIGMOID, only together with SSAD_F16_OUT_NCHW_F32); y is blocked fp16
+ * [N][M/8][H][W][8] (M % 8 == 0) or, with SSAD_F16_OUT_NCHW_F32, float [N][M][H][W].  Each level's
+ * tensors are addressed through 32-bit buffer offsets: at most 2 GiB per tensor (SSAD_E_BADARG beyond).  Data gradient: the same call with packed_dgrad,
  * C and M exchanged, bias NULL, and with SSAD_CONV_MASK_AUX the fused ReluGradient
  * y = aux > 0 ? y : 0 (aux blocked fp16 like y, else NULL). */
 SSAD_API int ssad_conv3x3_forward_f16(const void* x_blocked, const void* packed, const float* bias,

@@ -33,6 +33,8 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 using ssad_dev::uniform_rsrc;
 
@@ -287,18 +289,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Level
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         if (oc0 + 8 * g >= p.M) continue;               // wave-uniform
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][tt][4 * g + e] + bq[i][g][e];
-        if (p.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-        }
-        if (p.sigmoid) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));     // sigmoid_op.cu:25-29
-        }
         if (OUT == kOutNchw) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][tt][4 * g + e] + bq[i][g][e];
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+          }
+          if (p.sigmoid) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));     // sigmoid_op.cu:25-29
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const unsigned vo = (oc0 + 8 * g + 4 * h + e < p.M) ? pvo[tt] : kOob;
@@ -306,9 +308,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f16_kernel(const F16Level
                                                   (oc0 + 8 * g + e) * ((int)plane * 4), 0);
           }
         } else {
-          half4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+          // packed arithmetic (v_pk_add_f32, v_cvt_pk_f16_f32, v_pk_max_f16): the epilogue is VALU
+          // time taken from the MFMAs of the wave sharing the SIMD.  ReLU after the rounding gives
+          // the same fp16 value as before it (rounding is monotonic and keeps the sign).
+          const float2v lo = float2v{acc[i][tt][4 * g], acc[i][tt][4 * g + 1]} + float2v{bq[i][g].x, bq[i][g].y};
+          const float2v hi = float2v{acc[i][tt][4 * g + 2], acc[i][tt][4 * g + 3]} + float2v{bq[i][g].z, bq[i][g].w};
+          half2v o01 = __builtin_convertvector(lo, half2v), o23 = __builtin_convertvector(hi, half2v);
+          if (p.relu) {
+            const half2v z = {(_Float16)0.0f, (_Float16)0.0f};
+            o01 = __builtin_elementwise_max(o01, z);
+            o23 = __builtin_elementwise_max(o23, z);
+          }
+          half4 o = {o01[0], o01[1], o23[0], o23[1]};
           if (OUT == kOutMasked) {
             const half4 m = __builtin_bit_cast(half4, mk[tt][g]);
 #pragma unroll
@@ -501,6 +512,7 @@ int ssad_conv3x3_forward_f16_levels(const ssad_f16_level* levels, int n_levels, 
   const int masked = (flags & SSAD_CONV_MASK_AUX) != 0;
   if (!nchw && (M & 7)) return SSAD_E_BADARG;                   // blocked output: whole 8-blocks
   if (masked && nchw) return SSAD_E_BADARG;
+  if ((flags & SSAD_CONV_SIGMOID) && !nchw) return SSAD_E_BADARG;     // probabilities leave as fp32
   F16Levels q;
   long long tiles = 0;
   for (int l = 0; l < n_levels; ++l) {
