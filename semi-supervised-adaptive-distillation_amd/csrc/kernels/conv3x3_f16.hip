@@ -614,13 +614,26 @@ struct F16Wgrad {           // all FPN levels sharing the filter: their stages f
 
 typedef short short4v __attribute__((ext_vector_type(4)));
 
-// 8 consecutive pixels of one channel: two transpose reads 4 pixels (8 slots) apart
-__device__ __forceinline__ half8 tr_pair(__attribute__((address_space(3))) short4v* p0, int off_slots) {
-  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0 + off_slots * 2);
-  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0 + (off_slots + 8) * 2);
+// 8 consecutive pixels of one channel: two transpose reads 4 pixels (8 slots) apart.
+// Inline assembly on purpose: behind an LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)` in front
+// of the first ds_read_b64_tr_b16 *intrinsic* (it cannot tell that the read and the DMA touch
+// different stages), i.e. every stage waited for the NEXT stage's DMA before its first MFMA -- the
+// double buffer hid nothing (MFMA busy 33 %).  The asm reads are invisible to that pass; their
+// completion is waited for by hand (tr_wait) before the MFMAs that consume them.
+__device__ __forceinline__ half8 tr_pair(unsigned lds_addr, int off_bytes) {
+  short4v lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(lds_addr), "i"(off_bytes));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(lds_addr), "i"(off_bytes + 128));
   typedef short short8v __attribute__((ext_vector_type(8)));
   const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(half8, v);
+}
+// all LDS reads issued so far have returned; the operands are tied to the statement so that no
+// MFMA consuming them can be scheduled above it
+__device__ __forceinline__ void tr_wait(half8 (&a)[2], half8 (&b)[2][3]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]),
+                 "+v"(b[1][1]), "+v"(b[1][2]));
 }
 
 __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wgrad p) {
@@ -707,25 +720,25 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
   for (int s = s0; s < s1; ++s) {
     const int buf = (s - s0) & 1;
     if (s + 1 < s1) fetch(s + 1, buf ^ 1);
-    auto* base = reinterpret_cast<__attribute__((address_space(3))) _Float16*>(
-        (__attribute__((address_space(3))) uint4*)lds + buf * W_STAGE);
-    auto* xa = reinterpret_cast<__attribute__((address_space(3))) short4v*>(base + xb_base);
-    auto* ya = reinterpret_cast<__attribute__((address_space(3))) short4v*>(base + ya_base);
+    const unsigned stage = (unsigned)(uintptr_t)((__attribute__((address_space(3))) uint4*)lds + buf * W_STAGE);
+    const unsigned xa = stage + xb_base * 2, ya = stage + ya_base * 2;        // byte addresses
     // operands of row r + 1 are fetched while the MFMAs of row r run (the transpose reads'
     // latency is otherwise exposed once per row: one wave per SIMD, nothing else to issue)
     half8 a[2][2], b[2][2][3];
     auto load_row = [&](int row, half8 (&aa)[2], half8 (&bb)[2][3]) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) aa[t] = tr_pair(ya, t * 2 * Y_PITCH + row * WPX * 2);
+      for (int t = 0; t < 2; ++t) aa[t] = tr_pair(ya, (t * 2 * Y_PITCH + row * WPX * 2) * 16);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) bb[u][kx] = tr_pair(xa, u * 2 * X_PITCH + (row * XPW + kx) * 2);
+        for (int kx = 0; kx < 3; ++kx) bb[u][kx] = tr_pair(xa, (u * 2 * X_PITCH + (row * XPW + kx) * 2) * 16);
     };
     load_row(0, a[0], b[0]);
 #pragma unroll
     for (int row = 0; row < WR; ++row) {
+      tr_wait(a[row & 1], b[row & 1]);
       if (row + 1 < WR) load_row(row + 1, a[(row + 1) & 1], b[(row + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);                     // the next row's reads go out first
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
