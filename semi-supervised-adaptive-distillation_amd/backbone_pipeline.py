@@ -466,6 +466,7 @@ class NativeResNetFPN(object):
         P.mark("bwd_fpn_done")
         grads_into = {5: dc5, 4: dc4, 3: dc3}
         dy = None
+        dy_is_dz = False          # dy already went through this block's ReluGradient (previous GEMM's epilogue)
         for (stage, j, cin, cmid, cout, stride, proj, tr) in reversed(self.blocks):
             if not tr:
                 break
@@ -478,12 +479,23 @@ class NativeResNetFPN(object):
                 # the stage's output feeds the lateral (already in grads_into) and, for res3 / res4,
                 # the next stage's first block, whose input gradient was accumulated onto it
                 dy = grads_into[stage]
+                dy_is_dz = False
             h, w = y.shape[2], y.shape[3]
-            # dz = ReluGradient(y, dy) and the plane sums for the bias gradient(s)
-            dz = self._like(y)
-            rows = self._t(N, cout)
-            self._ew(P, PR.RELU_GRAD_ROWSUM, i=(N, cout, h * w), p=(y, dy, dz, rows), nbytes=12.0 * y.numel())
-            self._bias_grad(P, dz, l3, rows)
+            if dy_is_dz:
+                # the block below (later in the forward order) produced dy with this block's
+                # ReluGradient mask already applied in its GEMM epilogue: no elementwise pass
+                dz = dy
+                rows = self._t(N, cout)                      # plane sums, on the auxiliary stream
+                self._aux(P)
+                P.add(PR.RELU_GRAD_ROWSUM, 51, i=(N, cout, h * w), p=(None, dz, None, rows),
+                      work=4.0 * dz.numel(), stream=self._wstream, keep=[dz, rows])
+                self._bias_grad(P, dz, l3, rows)
+            else:
+                # dz = ReluGradient(y, dy) and the plane sums for the bias gradient(s)
+                dz = self._like(y)
+                rows = self._t(N, cout)
+                self._ew(P, PR.RELU_GRAD_ROWSUM, i=(N, cout, h * w), p=(y, dy, dz, rows), nbytes=12.0 * y.numel())
+                self._bias_grad(P, dz, l3, rows)
             self._wgrad1(P, y2, dz, l3)
             dz2 = self._like(y2)
             self._gemm(P, l3.w.view(cout, cmid), cmid, dz, dz2, cout, cmid, mask=y2)
@@ -506,12 +518,15 @@ class NativeResNetFPN(object):
                     self._ew(P, PR.SUBSAMPLE_GRAD, i=(N, cin, x.shape[2], x.shape[3], stride, 1), p=(dxs, tgt),
                              nbytes=12.0 * tgt.numel())
                 dy = None
+                dy_is_dz = False
             else:
                 # identity shortcut: dx = dz + W1^T dz1 (dz through the residual operand into a fresh
                 # buffer: the auxiliary stream may still be reading dz)
+                # x is the previous block's output y: its ReluGradient mask goes into this epilogue
                 dx = self._like(dz)
-                self._gemm(P, l1.w.view(cmid, cin), cin, dz1, dx, cmid, cin, res=dz)
+                self._gemm(P, l1.w.view(cmid, cin), cin, dz1, dx, cmid, cin, res=dz, mask=x)
                 dy = dx
+                dy_is_dz = True
             if j == 0:
                 P.mark("bwd_res%d_done" % stage)
 
