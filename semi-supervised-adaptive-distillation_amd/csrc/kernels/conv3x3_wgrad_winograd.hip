@@ -46,6 +46,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
 
 constexpr int kBlock = 512;
 constexpr int GM = 64, GC = 64;          // output / input channels per workgroup
@@ -85,7 +86,7 @@ struct GArgs {
 };
 
 __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args) {
-  __shared__ float lds[2 * STAGE];
+  __shared__ float lds[3 * STAGE];       // three stages of raw units: the DMA runs two units ahead
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -127,94 +128,68 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
     }
   };
 
-  // ---- staging maps ----
-  // dY: 64 m x 4 rows x 16 px = 1024 float4; thread -> two of them (m, m+32)
-  const int d_m = tid >> 4, d_row = (tid >> 2) & 3, d_c4 = tid & 3;
-  const int d_lds = d_m * SY + d_row * UC + d_c4 * 4;
-  // X: thread -> channel tid>>3, columns (tid&7) + 8j (j<3, col<18), rows 0..5
-  const int x_c = tid >> 3, x_sub = tid & 7;
-  // LDS channel slot: bit pairs (0,1) <-> (2,3) of the channel swapped, so that the
-  // 4 channels x 8 columns of a store group land on 32 different banks (slot
-  // stride 4 -> 8 banks) while the 16 channels of an operand read stay distinct mod 16
-  const int x_lds = GM * SY + ((x_c & 0x30) | ((x_c & 3) << 2) | ((x_c >> 2) & 3)) * SX + x_sub;
-
-  float4 ry[2];
-  float rx[3][2][3];         // portion p: rows 2p, 2p+1; [row in pair][col iter]
-  __amdgpu_buffer_rsrc_t dyrs, xrs;
-  unsigned dy_off[2], x_off[3];
-  bool vec4 = true;
-  int cW = 0, cHW = 0;
-  bool have_next = false;
-
+  // ---- staging by LDS-DMA (buffer_load_dword ... lds), two units ahead ----
+  // One wave-level instruction writes 64 consecutive floats of LDS:
+  //   dY: the 4 x 16 patch of one channel (64 floats)       -> 64 instructions per unit,
+  //   X : floats [0, 64) and [64, 128) of one channel's 6 x 20 window (pitch 20, 18 columns
+  //       used; the tail lands in the channel's padding)     -> 128 instructions per unit,
+  // 24 per wave.  The per-lane offset (pixel of the lane's float, out-of-image lanes at an
+  // out-of-range offset = zero fill) is the same for every channel; the channel goes into the
+  // scalar offset.  No staging registers (the register version held 26 and stalled on its loads:
+  // cycle stamps 13.0 k per unit against 8.5 k without the loads -- HBM latency exceeds the 1-3
+  // k-steps between request and use; LDS-DMA into a THIRD stage gives two whole units).
+  // LDS channel slot of X: bit pairs (0,1) <-> (2,3) of the channel swapped, so that the 16
+  // channels of an operand read stay distinct mod 16 (see the header).
+  ssad_dev::rsrc_words dyrs, xrs;
+  unsigned dy_vo = kOOB, x_vo[2] = {kOOB, kOOB};
+  int cHW = 0, m_left = 0, c_left = 0;
   // describe the unit under the cursor (offsets relative to the image's channel block)
   auto setup_unit = [&]() {
     const GLevel& L = args.lv[l];
     const int H = L.H, W = L.W, HW = H * W;
-    cW = W; cHW = HW;
-    vec4 = !(W & 3);
+    cHW = HW;
     const int y0 = cuy * UR, x0 = cux * UC;
-    const int m_left = M - mb * GM, c_left = C - cb * GC;
-    dyrs = uniform_rsrc(L.dy + ((long long)cn * M + mb * GM) * HW,
-                        (unsigned)((m_left < GM ? m_left : GM) * HW * 4));
-    xrs = uniform_rsrc(L.x + ((long long)cn * C + cb * GC) * HW,
-                       (unsigned)((c_left < GC ? c_left : GC) * HW * 4));
+    m_left = M - mb * GM; c_left = C - cb * GC;
+    dyrs = ssad_dev::uniform_rsrc_words(L.dy + ((long long)cn * M + mb * GM) * HW,
+                                        (unsigned)((m_left < GM ? m_left : GM) * HW * 4));
+    xrs = ssad_dev::uniform_rsrc_words(L.x + ((long long)cn * C + cb * GC) * HW,
+                                       (unsigned)((c_left < GC ? c_left : GC) * HW * 4));
+    {
+      const int gy = y0 + (lane >> 4), gx = x0 + (lane & 15);
+      dy_vo = (gy < H && gx < W) ? (unsigned)((gy * W + gx) * 4) : kOOB;
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int gy = y0 + d_row, gx = x0 + d_c4 * 4;
-      const bool ok = gy < H && gx < W;
-      dy_off[k] = ok ? (unsigned)(((d_m + 32 * k) * HW + gy * W + gx) * 4) : kOOB;
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int col = x_sub + 8 * j;
-      const int gx = x0 - 1 + col;
-      const bool ok = col < UC + 2 && gx >= 0 && gx < W;
-      // row validity is added per row at load time
-      x_off[j] = ok ? (unsigned)((x_c * HW + (y0 - 1) * W + gx) * 4) : kOOB;
+      const int e = lane + 64 * k, row = e / XP, col = e % XP;
+      const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+      const bool ok = row < UR + 2 && col < UC + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      x_vo[k] = ok ? (unsigned)((gy * W + gx) * 4) : kOOB;
     }
   };
-  int ny0 = 0, nH = 0;
-  auto load_portion = [&](int p) {
-    if (!have_next) return;
-    if (p < 2) {
-      if (vec4) {
-        ry[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(dyrs, dy_off[p], 0, 0));
-      } else {
-        // W % 4 != 0: the four pixels straddle the row end individually
-        float t[4];
+  // quarter q of a unit's DMA (6 wave-level instructions): the loop issues one quarter per k-step so
+  // that the memory instructions interleave with the MFMAs instead of holding them up in one burst
+  auto issue_quarter = [&](float* st, int q) {
+    const unsigned base = (unsigned)(uintptr_t)(lds_ptr)st;           // LDS byte address of the stage
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bool ok = dy_off[p] != kOOB && (int)(cux * UC + d_c4 * 4 + e) < cW;
-          t[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-              dyrs, ok ? dy_off[p] + 4 * e : kOOB, 0, 0));
-        }
-        ry[p] = make_float4(t[0], t[1], t[2], t[3]);
-      }
+    for (int i = 2 * q; i < 2 * q + 2; ++i) {
+      const int m = wave * (GM / 8) + i;
+      ssad_dev::lds_dma<4>(dyrs, base + m * SY * 4, m < m_left ? dy_vo : kOOB, m * cHW * 4);
     }
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int row = 2 * p + rr;
-      const int gy = ny0 - 1 + row;
-      const bool rok = gy >= 0 && gy < nH;
+    for (int i = 2 * q; i < 2 * q + 2; ++i) {
+      const int c = wave * (GC / 8) + i;
+      const int slot = (c & 0x30) | ((c & 3) << 2) | ((c >> 2) & 3);
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-        rx[p][rr][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-            xrs, (rok && x_off[j] != kOOB) ? x_off[j] + (unsigned)(row * cW * 4) : kOOB, 0, 0));
+      for (int k = 0; k < 2; ++k)
+        ssad_dev::lds_dma<4>(xrs, base + (GM * SY + slot * SX + 64 * k) * 4, c < c_left ? x_vo[k] : kOOB,
+                             c * cHW * 4);
     }
   };
-  auto store_portion = [&](int p, float* st) {
-    if (!have_next) return;
-    if (p < 2) {   // channel stride 66 floats: 8-byte aligned only
-      float2* q = reinterpret_cast<float2*>(st + d_lds + p * 32 * SY);
-      q[0] = make_float2(ry[p].x, ry[p].y);
-      q[1] = make_float2(ry[p].z, ry[p].w);
-    }
+  auto issue_unit = [&](float* st) {
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (x_sub + 8 * j < UC + 2) st[x_lds + (2 * p + rr) * XP + 8 * j] = rx[p][rr][j];
+    for (int q = 0; q < 4; ++q) issue_quarter(st, q);
   };
+  constexpr int kDmaPerUnit = GM / 8 + 2 * (GC / 8);        // wave-level instructions per wave and unit (24)
 
   // ---- compute-side constants ----
   const int wm = wave & 1, wc = wave >> 1;
@@ -227,26 +202,34 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
 #pragma unroll
     for (int g = 0; g < 2; ++g) acc[x][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: first unit straight into stage 0 ----
-  have_next = u_begin < u_end;
-  if (have_next) {
+  // ---- prologue: units u_begin and u_begin + 1 into stages 0 and 1 ----
+  int lu = u_begin;                       // unit under the loader's cursor
+  for (int k = 0; k < 2 && lu < u_end; ++k, ++lu) {
     setup_unit();
-    ny0 = cuy * UR; nH = args.lv[l].H;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) { load_portion(p); store_portion(p, lds); }
+    issue_unit(lds + k * STAGE);
     advance();
   }
-  __syncthreads();
 
 #ifdef WGRAD_TIMELINE
   const bool dbg_on = blockIdx.x == 3 && blockIdx.y == 2 && tid == 0;
 #endif
+  int sidx = 0;                           // stage of unit u
   for (int u = u_begin; u < u_end; ++u) {
     WDBG(u - u_begin, 0);
-    const float* st = lds + ((u - u_begin) & 1) * STAGE;
-    float* nst = lds + (((u - u_begin) & 1) ^ 1) * STAGE;
-    have_next = u + 1 < u_end;
-    if (have_next) { setup_unit(); ny0 = cuy * UR; nH = args.lv[l].H; }
+    // this wave's DMA of unit u has landed (that of unit u + 1 may still fly) ...
+    if (u + 1 < u_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerUnit) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... and after the barrier everybody's has; every wave is also done with unit u - 1,
+    // whose stage the next DMA overwrites
+    __builtin_amdgcn_s_barrier();
+    const float* st = lds + sidx * STAGE;
+    float* nst = lds + (sidx == 0 ? 2 : sidx - 1) * STAGE;
+    const bool fetch = lu < u_end;
+    if (fetch) {
+      setup_unit();
+      advance();
+      ++lu;
+    }
     // raw operands of one k-step: B window d[4][4] as 8 float2, A patches 2 x 2 float2;
     // those of k-step ks+1 are requested before the MFMAs of k-step ks
     float2 rb[2][8], ra[2][4];
@@ -269,8 +252,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
     read_raw(0, rb[0], ra[0]);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      // next unit: portion ks is requested now; all three go to LDS after the last k-step
-      if (ks < 3) load_portion(ks);
+      if (fetch) issue_quarter(nst, ks);
       if (ks < 3) read_raw(ks + 1, rb[(ks + 1) & 1], ra[(ks + 1) & 1]);
       const float2 (&b8)[8] = rb[ks & 1];
       const float2 (&a4)[4] = ra[ks & 1];
@@ -316,12 +298,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
       }
     }
     WDBG(u - u_begin, 2);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) store_portion(p, nst);
-    WDBG(u - u_begin, 3);
-    if (have_next) advance();
-    __syncthreads();
-    WDBG(u - u_begin, 4);
+    if (++sidx == 3) sidx = 0;
   }
 
   // ---- partial dU slab: [sp][xi][Mp][Cp] ----

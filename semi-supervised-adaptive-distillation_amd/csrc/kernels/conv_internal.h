@@ -31,6 +31,39 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, un
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, n, 0x00020000);
 }
 
+// ---- LDS-DMA the compiler's waitcnt pass cannot see -------------------------------------------
+// Behind a `__builtin_amdgcn_raw_ptr_buffer_load_lds` in flight hipcc makes the NEXT LDS read of
+// the kernel wait for that DMA (it cannot prove that the read and the DMA touch different
+// stages): a multi-stage prefetch then stalls at every stage for the full latency of the fetch
+// it was supposed to hide (seen in the ISA as `s_waitcnt vmcnt(..)` in front of the first ds_read
+// after the issue).  Issued from inline assembly the DMA is invisible to that pass; the kernels
+// wait for it themselves (counted `s_waitcnt vmcnt(N)` + barrier) where a stage changes hands.
+// The compiler's own vmcnt bookkeeping for register loads stays safe: vector memory retires in
+// order, so an untracked operation can only make its waits longer, never shorter.
+typedef int rsrc_words __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ rsrc_words uniform_rsrc_words(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const unsigned n = __builtin_amdgcn_readfirstlane(bytes);
+  return rsrc_words{(int)lo, (int)(hi & 0xffffu), (int)n, 0x00020000};
+}
+
+// lane l: LDS[lds_byte_addr + BYTES * l ...] = buffer[voffset + soffset ...]  (zeros past the descriptor;
+// send a lane to offset 0x80000000 for zero fill).  lds_byte_addr and soffset must be wave-uniform.
+template <int BYTES>
+__device__ __forceinline__ void lds_dma(const rsrc_words& rsrc, unsigned lds_byte_addr, unsigned voffset,
+                                        int soffset) {
+  static_assert(BYTES == 4 || BYTES == 16, "LDS-DMA moves 4 or 16 bytes per lane");
+  if (BYTES == 4)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds_byte_addr), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory", "m0");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_byte_addr), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory", "m0");
+}
+
 }  // namespace ssad_dev
 
 #endif  // SSAD_CONV_INTERNAL_H_
