@@ -628,12 +628,18 @@ __device__ __forceinline__ half8 tr_pair(unsigned lds_addr, int off_bytes) {
   const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(half8, v);
 }
+// 4 consecutive pixels of one channel
+__device__ __forceinline__ short4v tr_quad(unsigned lds_addr, int off_bytes) {
+  short4v v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "i"(off_bytes));
+  return v;
+}
 // all LDS reads issued so far have returned; the operands are tied to the statement so that no
-// MFMA consuming them can be scheduled above it
-__device__ __forceinline__ void tr_wait(half8 (&a)[2], half8 (&b)[2][3]) {
+// instruction consuming them can be scheduled above it
+__device__ __forceinline__ void tr_wait(half8 (&a)[2], short4v (&x)[2][3]) {
   asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(a[0]), "+v"(a[1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]),
-                 "+v"(b[1][1]), "+v"(b[1][2]));
+               : "+v"(a[0]), "+v"(a[1]), "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[1][0]),
+                 "+v"(x[1][1]), "+v"(x[1][2]));
 }
 
 __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wgrad p) {
@@ -719,25 +725,46 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
   __syncthreads();
   for (int s = s0; s < s1; ++s) {
     const int buf = (s - s0) & 1;
-    if (s + 1 < s1) fetch(s + 1, buf ^ 1);
+    if (s + 1 < s1 && !(F16_ABLATE & 8)) fetch(s + 1, buf ^ 1);
     const unsigned stage = (unsigned)(uintptr_t)((__attribute__((address_space(3))) uint4*)lds + buf * W_STAGE);
     const unsigned xa = stage + xb_base * 2, ya = stage + ya_base * 2;        // byte addresses
     // operands of row r + 1 are fetched while the MFMAs of row r run (the transpose reads'
     // latency is otherwise exposed once per row: one wave per SIMD, nothing else to issue)
-    half8 a[2][2], b[2][2][3];
-    auto load_row = [&](int row, half8 (&aa)[2], half8 (&bb)[2][3]) {
+    // X operands of the three taps kx of a filter row are the same 8 pixels shifted by 0 / 1 / 2:
+    // a lane reads pixels 8h .. 8h + 11 of its channel ONCE (three transpose reads) and builds the
+    // shifted operands in registers -- kx = 2 is a register selection, kx = 1 four v_alignbit_b32 --
+    // instead of reading each shift from LDS (12 of the 16 read pairs per row; the kernel was
+    // bound by the LDS read rate: 64 KB per CU per 384 MFMA cycles).
+    half8 a[2][2];
+    short4v xr[2][2][3];                  // [buffer][u][lo, hi, next]
+    auto load_row = [&](int row, half8 (&aa)[2], short4v (&xx)[2][3]) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) aa[t] = tr_pair(ya, (t * 2 * Y_PITCH + row * WPX * 2) * 16);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) bb[u][kx] = tr_pair(xa, (u * 2 * X_PITCH + (row * XPW + kx) * 2) * 16);
+        for (int k = 0; k < 3; ++k) xx[u][k] = tr_quad(xa, (u * 2 * X_PITCH + row * XPW * 2) * 16 + k * 128);
     };
-    load_row(0, a[0], b[0]);
+    load_row(0, a[0], xr[0]);
 #pragma unroll
     for (int row = 0; row < WR; ++row) {
-      tr_wait(a[row & 1], b[row & 1]);
-      if (row + 1 < WR) load_row(row + 1, a[(row + 1) & 1], b[(row + 1) & 1]);
+      tr_wait(a[row & 1], xr[row & 1]);
+      half8 b[2][3];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x2 lo = __builtin_bit_cast(u32x2, xr[row & 1][u][0]), hi = __builtin_bit_cast(u32x2, xr[row & 1][u][1]),
+                    nx = __builtin_bit_cast(u32x2, xr[row & 1][u][2]);
+        // dwords d0..d4 = pixels (0,1) (2,3) (4,5) (6,7) (8,9) of this lane's 8-pixel half
+        b[u][0] = __builtin_bit_cast(half8, u32x4{lo.x, lo.y, hi.x, hi.y});
+        b[u][1] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(lo.y, lo.x, 16),
+                                                  __builtin_amdgcn_alignbit(hi.x, lo.y, 16),
+                                                  __builtin_amdgcn_alignbit(hi.y, hi.x, 16),
+                                                  __builtin_amdgcn_alignbit(nx.x, hi.y, 16)});
+        b[u][2] = __builtin_bit_cast(half8, u32x4{lo.y, hi.x, hi.y, nx.x});
+      }
+      if (row + 1 < WR && !(F16_ABLATE & 16)) load_row(row + 1, a[(row + 1) & 1], xr[(row + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);                     // the next row's reads go out first
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -745,8 +772,7 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
           for (int t = 0; t < 2; ++t)
-            acc[t][u][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[row & 1][t], b[row & 1][u][kx],
-                                                                   acc[t][u][kx], 0, 0, 0);
+            acc[t][u][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[row & 1][t], b[u][kx], acc[t][u][kx], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);                     // bound the operands in flight
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -772,8 +798,13 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
   }
 }
 
-// dW[m][c][tap] (+)= scale * sum_split part[split][tap][m][c]; the threads past 9 M C fold the
-// bias-gradient partials the same way: db[m] (+)= scale * sum_split dbpart[split][m]
+// dW[m][c][tap] (+)= scale * sum_split part[split][tap][m][c], splits summed in a fixed order.
+// Workgroup = one output channel m x 64 input channels: thread (tap, c) sums its element over the
+// splits (four independent chains; 256-byte runs along c), the [c][9] tile is transposed through
+// LDS and leaves as ONE contiguous 2304-byte run of dW -- with a thread per element writing
+// dW[(m C + c) 9 + tap] directly every wave store touched 36 cache lines (88 us per tower layer,
+// more than a third of the whole filter-gradient call).  Row m == M folds the bias partials:
+// db[m] (+)= scale * sum dbpart[k][m].
 constexpr int kDbSplits = 64;
 __global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_kernel(const float* __restrict__ part,
                                                                     int splits, int M, int C,
@@ -782,41 +813,50 @@ __global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_kernel(const float*
                                                                     float* __restrict__ dw,
                                                                     const float* __restrict__ dbpart,
                                                                     int dbparts, float* __restrict__ db) {
+  __shared__ float o[64 * 9];
   if (scale_dev) scale *= scale_dev[0];
-  // one thread per (tap, m, c) element -- 590 K threads for a tower layer; a thread per (m, c)
-  // with nine chains measured 3x slower: too few waves to cover the load latency -- four
-  // independent chains over the splits; then the threads past 9 M C fold the bias partials
-  const int i = blockIdx.x * kThreads + threadIdx.x;
-  const int total = 9 * M * C;
-  if (i < total) {
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int k = 0;
-    for (; k + 3 < splits; k += 4) {
-      s0 += part[(long long)k * total + i];
-      s1 += part[(long long)(k + 1) * total + i];
-      s2 += part[(long long)(k + 2) * total + i];
-      s3 += part[(long long)(k + 3) * total + i];
+  const int m = blockIdx.y, c0 = blockIdx.x * 64;
+  if (m == M) {                                            // the bias row
+    if (!db) return;
+    const int Mp = (M + 7) & ~7;
+    for (int mm = blockIdx.x * kThreads + threadIdx.x; mm < M; mm += gridDim.x * kThreads) {
+      float s = 0.0f;
+      for (int k = 0; k < dbparts; ++k) s += dbpart[k * Mp + mm];
+      s *= scale;
+      db[mm] = accumulate ? db[mm] + s : s;
     }
-    for (; k < splits; ++k) s0 += part[(long long)k * total + i];
-    const float s = ((s0 + s1) + (s2 + s3)) * scale;
-    const int c = i % C, m = (i / C) % M, tap = i / (C * M);
-    float* o = dw + ((long long)m * C + c) * 9 + tap;
-    *o = accumulate ? *o + s : s;
-  } else if (db && i < total + M) {
-    const int m = i - total, Mp = (M + 7) & ~7;
-    float s = 0.0f;
-    for (int k = 0; k < dbparts; ++k) s += dbpart[k * Mp + m];
-    s *= scale;
-    db[m] = accumulate ? db[m] + s : s;
+    return;
   }
+  const long long total = 9LL * M * C;
+  for (int e = threadIdx.x; e < 64 * 9; e += kThreads) {
+    const int tap = e >> 6, cl = e & 63, c = c0 + cl;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (c < C) {
+      const float* q = part + ((long long)tap * M + m) * C + c;
+      int k = 0;
+      for (; k + 3 < splits; k += 4) {
+        s0 += q[(long long)k * total];
+        s1 += q[(long long)(k + 1) * total];
+        s2 += q[(long long)(k + 2) * total];
+        s3 += q[(long long)(k + 3) * total];
+      }
+      for (; k < splits; ++k) s0 += q[(long long)k * total];
+    }
+    o[cl * 9 + tap] = ((s0 + s1) + (s2 + s3)) * scale;
+  }
+  __syncthreads();
+  const int nvalid = (C - c0 < 64 ? C - c0 : 64) * 9;
+  float* dst = dw + ((long long)m * C + c0) * 9;
+  for (int e = threadIdx.x; e < nvalid; e += kThreads) dst[e] = accumulate ? dst[e] + o[e] : o[e];
 }
 
-// dbpart[split][m] = sum of the blocked fp16 dY over the split's share of the N * H * W pixels
-// (grid: channel blocks x kDbSplits)
-__global__ __launch_bounds__(kThreads) void f16_bias_grad_kernel(const uint4* __restrict__ dy, int N,
-                                                                 int M, int plane,
-                                                                 float* __restrict__ dbpart) {
+// dbpart[level][split][m] = sum of the blocked fp16 dY over the split's share of the level's
+// N * H * W pixels (grid: channel blocks x kDbSplits x levels -- one launch for all levels)
+__global__ __launch_bounds__(kThreads) void f16_bias_grad_kernel(const F16Wgrad p, float* __restrict__ dbpart) {
   __shared__ float red[kThreads / 64][8];
+  const int lv = blockIdx.z;
+  const uint4* __restrict__ dy = p.dy[lv];
+  const int N = p.N[lv], M = p.M, plane = p.H[lv] * p.W[lv];
   const int MB = (M + 7) >> 3, mb = blockIdx.x;
   const long long total = (long long)N * plane;
   const long long per = (total + kDbSplits - 1) / kDbSplits;
@@ -838,7 +878,7 @@ __global__ __launch_bounds__(kThreads) void f16_bias_grad_kernel(const uint4* __
   if (threadIdx.x < 8) {
     float v = 0.0f;
     for (int w = 0; w < kThreads / 64; ++w) v += red[w][threadIdx.x];
-    dbpart[blockIdx.y * (MB * 8) + mb * 8 + threadIdx.x] = v;
+    dbpart[((size_t)lv * kDbSplits + blockIdx.y) * (MB * 8) + mb * 8 + threadIdx.x] = v;
   }
 }
 
@@ -928,13 +968,12 @@ int ssad_conv3x3_wgrad_f16_levels_dyn(const ssad_f16_wgrad_level* levels, int n_
                        p);
   }
   float* dbpart = p.part + (size_t)splits * 9 * (size_t)M * (size_t)C;
-  const size_t Mp = (size_t)((M + 7) & ~7);
-  if (db)
-    for (int l = 0; l < n_levels; ++l)
-      hipLaunchKernelGGL(f16_bias_grad_kernel, dim3((M + 7) / 8, kDbSplits), dim3(kThreads), 0, s, p.dy[l],
-                         p.N[l], M, p.H[l] * p.W[l], dbpart + (size_t)l * kDbSplits * Mp);
-  hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3((9 * M * C + M + kThreads - 1) / kThreads), dim3(kThreads),
-                     0, s, p.part, p.stages > 0 ? splits : 0, M, C, accumulate, scale, scale_dev, dw, dbpart,
+  if (db) {
+    p.n_levels = n_levels;
+    hipLaunchKernelGGL(f16_bias_grad_kernel, dim3((M + 7) / 8, kDbSplits, n_levels), dim3(kThreads), 0, s, p, dbpart);
+  }
+  hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3((C + 63) / 64, M + 1), dim3(kThreads), 0, s, p.part,
+                     p.stages > 0 ? splits : 0, M, C, accumulate, scale, scale_dev, dw, dbpart,
                      n_levels * kDbSplits, db);
   return (int)hipGetLastError();
 }
