@@ -636,16 +636,21 @@ __device__ __forceinline__ short4v tr_quad(unsigned lds_addr, int off_bytes) {
 }
 // all LDS reads issued so far have returned; the operands are tied to the statement so that no
 // instruction consuming them can be scheduled above it
-__device__ __forceinline__ void tr_wait(half8 (&a)[2], short4v (&x)[2][3]) {
+__device__ __forceinline__ void tr_wait(half8& a, short4v (&x)[2][3]) {
   asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(a[0]), "+v"(a[1]), "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[1][0]),
-                 "+v"(x[1][1]), "+v"(x[1][2]));
+               : "+v"(a), "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[1][2]));
 }
 
-__global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wgrad p) {
+// 8 waves: wave (wo, wc) owns 32 output x 64 input channels x 3 taps = 6 accumulator tiles.  With
+// 4 waves of twice that (one wave per SIMD, 192 accumulator registers) nothing covered the issue
+// time of the LDS-DMA instructions -- 18 per wave and stage at 100-185 cycles each beside 96 MFMAs
+// of 32: removing the DMA made the kernel 1.7x faster.  Two waves per SIMD do.
+constexpr int kWThreads = 512;
+__global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16Wgrad p) {
   extern __shared__ uint4 lds[];                           // 2 stages
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wo = wave & 1, wc = wave >> 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wo = wave & 3, wc = wave >> 2;
   const int ky = blockIdx.z;
   const int ocb = (blockIdx.x / p.cblocks) * W_OT, ccb = (blockIdx.x % p.cblocks) * (W_CT / 8);
   const int CB = (p.C + 7) >> 3, MB = (p.M + 7) >> 3;
@@ -656,25 +661,29 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
   constexpr unsigned kOob = 0x80000000u;
   // lane's place inside a 64-slot DMA piece: slot = 2 * pixel + (block & 1)
   const int lpix = lane >> 1, lodd = lane & 1;
-  auto fetch = [&](int s, int buf) {
+  // A stage's DMA: 5 X pieces + 4 dY pieces per wave.  fetch_setup computes the nine lane offsets
+  // (and the level's descriptors); fetch_piece issues ONE piece -- the loop issues a piece per row
+  // of MFMAs, so that the ~150-cycle issue of an LDS-DMA instruction on one wave runs under the
+  // MFMAs of the other wave of the SIMD instead of both waves issuing their nine at once.
+  constexpr int kPieces = X_PIECES / 8 + Y_PIECES / 8;     // 9
+  unsigned poff[kPieces];
+  __amdgpu_buffer_rsrc_t fxrs, fyrs;
+  auto fetch_setup = [&](int s) {
     int lv = 0;
     for (int l = 1; l < p.n_levels; ++l)
       if (s >= p.stage0[l]) lv = l;
     const int H = p.H[lv], W = p.W[lv], plane = H * W;
     const int seg_x = (W + WPX - 1) / WPX, seg_y = (H + WR - 1) / WR;
-    const __amdgpu_buffer_rsrc_t xrs =
-        ssad_dev::uniform_rsrc(p.x[lv], (unsigned)((long long)p.N[lv] * CB * plane * 16));
-    const __amdgpu_buffer_rsrc_t yrs =
-        ssad_dev::uniform_rsrc(p.dy[lv], (unsigned)((long long)p.N[lv] * MB * plane * 16));
+    fxrs = ssad_dev::uniform_rsrc(p.x[lv], (unsigned)((long long)p.N[lv] * CB * plane * 16));
+    fyrs = ssad_dev::uniform_rsrc(p.dy[lv], (unsigned)((long long)p.N[lv] * MB * plane * 16));
     int t = s - p.stage0[lv];
     const int sx = t % seg_x; t /= seg_x;
     const int sy = t % seg_y;
     const int n = t / seg_y;
     const int y0 = sy * WR, x0 = sx * WPX;
-    auto* dst = (__attribute__((address_space(3))) uint4*)lds + buf * W_STAGE;
 #pragma unroll
-    for (int i = 0; i < X_PIECES / 4; ++i) {
-      const int piece = i * 4 + wave;                       // pair = piece / 5, 32 pixels each
+    for (int i = 0; i < X_PIECES / 8; ++i) {
+      const int piece = i * 8 + wave;                       // pair = piece / 5, 32 pixels each
       const int pair = piece / (X_PAIR / 64), q = piece % (X_PAIR / 64);
       const int pix = q * 32 + lpix;                        // row * 20 + column
       const int gy = y0 + ky - 1 + pix / XPW, gx = x0 - 1 + pix % XPW;
@@ -682,22 +691,39 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
       unsigned off = kOob;
       if (cb < CB && gy >= 0 && gy < H && gx >= 0 && gx < W)
         off = (unsigned)(((n * CB + cb) * plane + gy * W + gx) * 16);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          xrs, (__attribute__((address_space(3))) void*)(dst + pair * X_PITCH + q * 64), 16, off, 0, 0, 0);
+      poff[i] = off;
     }
 #pragma unroll
-    for (int i = 0; i < Y_PIECES / 4; ++i) {
-      const int piece = i * 4 + wave;
+    for (int i = 0; i < Y_PIECES / 8; ++i) {
+      const int piece = i * 8 + wave;
       const int pair = piece / (Y_PAIR / 64), q = piece % (Y_PAIR / 64);
       const int pix = q * 32 + lpix;                        // row * 16 + column
       const int gy = y0 + pix / WPX, gx = x0 + pix % WPX;
       const int mb = (ocb >> 3) + pair * 2 + lodd;
       unsigned off = kOob;
       if (mb < MB && gy < H && gx < W) off = (unsigned)(((n * MB + mb) * plane + gy * W + gx) * 16);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          yrs, (__attribute__((address_space(3))) void*)(dst + Y_BASE + pair * Y_PITCH + q * 64), 16, off, 0, 0,
-          0);
+      poff[X_PIECES / 8 + i] = off;
     }
+  };
+  auto fetch_piece = [&](int k, int buf) {
+    auto* dst = (__attribute__((address_space(3))) uint4*)lds + buf * W_STAGE;
+    if (k < X_PIECES / 8) {
+      const int piece = k * 8 + wave;
+      const int pair = piece / (X_PAIR / 64), q = piece % (X_PAIR / 64);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          fxrs, (__attribute__((address_space(3))) void*)(dst + pair * X_PITCH + q * 64), 16, poff[k], 0, 0, 0);
+    } else {
+      const int piece = (k - X_PIECES / 8) * 8 + wave;
+      const int pair = piece / (Y_PAIR / 64), q = piece % (Y_PAIR / 64);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          fyrs, (__attribute__((address_space(3))) void*)(dst + Y_BASE + pair * Y_PITCH + q * 64), 16, poff[k], 0,
+          0, 0);
+    }
+  };
+  auto fetch = [&](int s, int buf) {
+    fetch_setup(s);
+#pragma unroll
+    for (int k = 0; k < kPieces; ++k) fetch_piece(k, buf);
   };
 
   // ---- transpose-read addressing (tools/tr16_probe.hip): lane l of a 16-lane group addresses
@@ -708,24 +734,23 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
   const int in_pair = (quad >> 1) * 8 + (quad & 1) * 4;    // halves: block of the pair, half slot
   // 32-channel MFMA tile = 2 pairs; group g & 1 takes the second
   const int xb_base = (((wc * 4 + (g & 1)) * X_PITCH + kpx * 2) * 8) + in_pair;          // + tile * 2 pairs
-  const int ya_base = ((Y_BASE + (wo * 4 + (g & 1)) * Y_PITCH + kpx * 2) * 8) + in_pair;
+  const int ya_base = ((Y_BASE + (wo * 2 + (g & 1)) * Y_PITCH + kpx * 2) * 8) + in_pair;
 
-  float16v acc[2][2][3];
+  float16v acc[2][3];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][u][kx][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc[u][kx][r] = 0.0f;
 
   if (s0 < s1) fetch(s0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int s = s0; s < s1; ++s) {
     const int buf = (s - s0) & 1;
-    if (s + 1 < s1 && !(F16_ABLATE & 8)) fetch(s + 1, buf ^ 1);
+    const bool more = s + 1 < s1 && !(F16_ABLATE & 8);
+    if (more) fetch_setup(s + 1);
     const unsigned stage = (unsigned)(uintptr_t)((__attribute__((address_space(3))) uint4*)lds + buf * W_STAGE);
     const unsigned xa = stage + xb_base * 2, ya = stage + ya_base * 2;        // byte addresses
     // operands of row r + 1 are fetched while the MFMAs of row r run (the transpose reads'
@@ -735,11 +760,10 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
     // shifted operands in registers -- kx = 2 is a register selection, kx = 1 four v_alignbit_b32 --
     // instead of reading each shift from LDS (12 of the 16 read pairs per row; the kernel was
     // bound by the LDS read rate: 64 KB per CU per 384 MFMA cycles).
-    half8 a[2][2];
+    half8 a[2];
     short4v xr[2][2][3];                  // [buffer][u][lo, hi, next]
-    auto load_row = [&](int row, half8 (&aa)[2], short4v (&xx)[2][3]) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) aa[t] = tr_pair(ya, (t * 2 * Y_PITCH + row * WPX * 2) * 16);
+    auto load_row = [&](int row, half8& aa, short4v (&xx)[2][3]) {
+      aa = tr_pair(ya, (row * WPX * 2) * 16);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -765,14 +789,16 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
         b[u][2] = __builtin_bit_cast(half8, u32x4{lo.y, hi.x, hi.y, nx.x});
       }
       if (row + 1 < WR && !(F16_ABLATE & 16)) load_row(row + 1, a[(row + 1) & 1], xr[(row + 1) & 1]);
+      if (more) {                                            // the next stage's DMA, a piece per row
+        fetch_piece(row, buf ^ 1);
+        if (row == 0) fetch_piece(WR, buf ^ 1);
+      }
       __builtin_amdgcn_sched_barrier(0);                     // the next row's reads go out first
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            acc[t][u][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[row & 1][t], b[u][kx], acc[t][u][kx], 0, 0, 0);
+          acc[u][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[row & 1], b[u][kx], acc[u][kx], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);                     // bound the operands in flight
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -786,15 +812,13 @@ __global__ __launch_bounds__(kThreads) void conv3x3_wgrad_f16_kernel(const F16Wg
     const int c = ccb * 8 + wc * 64 + u * 32 + (lane & 31);
     if (c >= p.C) continue;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = ocb + wo * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (m < p.M)
-            p.part[(((long long)blockIdx.y * 9 + ky * 3 + kx) * p.M + m) * p.C + c] = acc[t][u][kx][r];
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int m = ocb + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < p.M)
+          p.part[(((long long)blockIdx.y * 9 + ky * 3 + kx) * p.M + m) * p.C + c] = acc[u][kx][r];
+      }
   }
 }
 
@@ -964,7 +988,7 @@ int ssad_conv3x3_wgrad_f16_levels_dyn(const ssad_f16_wgrad_level* levels, int n_
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE * 16) == hipSuccess;
     }();
     if (!attr) return SSAD_E_BADARG;
-    hipLaunchKernelGGL(conv3x3_wgrad_f16_kernel, dim3(blocks, splits, 3), dim3(kThreads), 2 * W_STAGE * 16, s,
+    hipLaunchKernelGGL(conv3x3_wgrad_f16_kernel, dim3(blocks, splits, 3), dim3(kWThreads), 2 * W_STAGE * 16, s,
                        p);
   }
   float* dbpart = p.part + (size_t)splits * 9 * (size_t)M * (size_t)C;
