@@ -790,8 +790,8 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
       }
       if (row + 1 < WR && !(F16_ABLATE & 16)) load_row(row + 1, a[(row + 1) & 1], xr[(row + 1) & 1]);
       if (more) {                                            // the next stage's DMA, a piece per row
-        fetch_piece(row, buf ^ 1);
-        if (row == 0) fetch_piece(WR, buf ^ 1);
+        if (!(F16_ABLATE & 32) || row < X_PIECES / 8) fetch_piece(row, buf ^ 1);
+        if (row == 0 && !(F16_ABLATE & 32)) fetch_piece(WR, buf ^ 1);
       }
       __builtin_amdgcn_sched_barrier(0);                     // the next row's reads go out first
 #pragma unroll

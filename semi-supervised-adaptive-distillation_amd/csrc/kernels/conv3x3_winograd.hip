@@ -921,7 +921,7 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
 }
 
 #ifdef WINO_TIMELINE
-int ssad_dbg_read(void* host) {
+SSAD_API int ssad_dbg_read(void* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg), sizeof(g_dbg));
 }
 #endif

@@ -71,6 +71,23 @@ def test_f16_forward_vs_float64(K, N, C, M, H, W, relu, nchw):
     assert np.abs(got - want).max() <= tol * scale, np.abs(got - want).max() / scale
 
 
+def test_f16_sigmoid_epilogue_and_its_restriction(K):
+    """The teacher's probabilities leave the prediction layer as NCHW fp32 (sigmoid_op.cu:25-29 fused
+    into the epilogue); asking for the sigmoid with the blocked fp16 output is refused."""
+    rng = np.random.default_rng(77)
+    N, C, M, H, W = 1, 64, 72, 9, 11
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((M, C, 3, 3)) * (2.0 / (9 * C)) ** 0.5).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32) * 0.1
+    xb = K.f16_pack_activations(torch.from_numpy(x).cuda())
+    wf, _ = K.f16_pack_filter(torch.from_numpy(w).cuda(), True, False)
+    y = K.conv3x3_forward_f16(xb, wf, torch.from_numpy(b).cuda(), C, M, sigmoid=True, out_nchw_f32=True)
+    want = 1.0 / (1.0 + np.exp(-_conv64(_r16(x), _r16(w), b.astype(np.float64))))
+    assert np.abs(y.cpu().numpy() - want).max() <= 2e-5
+    with pytest.raises(K.KernelError):
+        K.conv3x3_forward_f16(xb, wf, torch.from_numpy(b).cuda(), C, M, sigmoid=True)
+
+
 def test_f16_data_gradient_is_the_adjoint(K):
     """<conv(x), dy> == <x, dgrad(dy)> with both sides evaluated from the fp16-rounded
     operands in float64 (the packed_dgrad filter is the flipped, transposed filter)."""
