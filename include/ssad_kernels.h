@@ -413,6 +413,14 @@ typedef struct ssad_gemm_conv {
   int lda, N, K, P, M, flags;
 } ssad_gemm_conv;
 SSAD_API int ssad_conv1x1_gemm(const ssad_gemm_conv* desc_host, ssad_stream_t stream);
+/* Convolution of any kernel / stride / pad (group 1) as an IMPLICIT GEMM, forward: the same kernel as
+ * ssad_conv1x1_gemm with the im2col view of the image gathered by the DMA itself -- no column buffer
+ * (caffe2/operators/conv_op_impl.h:126-173 materialises one per image; the 7x7/2 stem's is 1.35 GB at
+ * bs 16).  d->x = image [N][C][H][W], d->a = transposed filter [C*kernel*kernel][lda] (ssad_transpose_filter
+ * of w [M][C][k][k]), d->K = C*kernel*kernel, d->P = OH*OW (a multiple of 4), d->y = [N][M][OH][OW];
+ * bias / residual / mask / flags as in ssad_conv1x1_gemm. */
+SSAD_API int ssad_conv_implicit_gemm(const ssad_gemm_conv* d, int C, int H, int W, int kernel, int stride, int pad,
+                                     ssad_stream_t stream);
 /* wt[k][m] = w[m][k], rows padded with zeros to ldm >= M (ldm % 4 == 0) */
 SSAD_API int ssad_transpose_filter(const float* w, int M, int K, int ldm, float* wt, ssad_stream_t stream);
 /* dw[m][c] (+)= sum_{n,p} dy[n][m][p] x[n][c][p]  (conv_op_impl.h:451-500 for a 1x1 kernel);

@@ -144,7 +144,9 @@ enum ssad_opcode {
    * i5 = stride, i6 = relu, p3 = y) */
   SSAD_OP_GROUPED_CONV3X3 = 64,
   /* ssad_grouped_conv3x3_pack_filter(p0 = w, i0 = C, i1 = group, p1 = packed) */
-  SSAD_OP_GROUPED_PACK = 65
+  SSAD_OP_GROUPED_PACK = 65,
+  /* ssad_conv_implicit_gemm(p0 = ssad_gemm_conv*, i0..i5 = C, H, W, kernel, stride, pad) */
+  SSAD_OP_CONV_IMPLICIT = 66
 };
 
 typedef struct ssad_op {

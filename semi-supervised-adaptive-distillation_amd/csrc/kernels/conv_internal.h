@@ -56,12 +56,17 @@ template <int BYTES>
 __device__ __forceinline__ void lds_dma(const rsrc_words& rsrc, unsigned lds_byte_addr, unsigned voffset,
                                         int soffset) {
   static_assert(BYTES == 4 || BYTES == 16, "LDS-DMA moves 4 or 16 bytes per lane");
+  // M0 carries the LDS address of an LDS-DMA; it is a reserved register the compiler may be using
+  // itself, so the statement saves and restores it instead of declaring a clobber
+  unsigned saved_m0;
   if (BYTES == 4)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                 :: "s"(lds_byte_addr), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory", "m0");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(saved_m0) : "s"(lds_byte_addr), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
   else
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_byte_addr), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory", "m0");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(saved_m0) : "s"(lds_byte_addr), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
 }
 
 }  // namespace ssad_dev

@@ -56,6 +56,9 @@ struct GemmArgs {
   int lda, N, K, P, M, flags;
   int mtiles, ctiles;    // tiles along M and along the flattened columns
   long long Q;           // N * P
+  // implicit-GEMM convolution (gemm_conv_nn_kernel<BM, true>): x is the image [N][C][H][W], the
+  // columns are the output pixels (P = OH * OW), row k = (c, ky, kx) of the reduction is gathered
+  int C, H, W, OW, ksize, stride, pad;
 };
 
 // the b32 buffer builtins move 32-bit INTEGERS: floats go through a bit cast, not a conversion
@@ -74,7 +77,11 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-template <int BM>
+// IMPLICIT = true: the B operand is not a stored [K][P] matrix but the im2col view of an image,
+// gathered by the DMA itself (4 bytes per lane: a stride-2 window is not contiguous): the 7x7/2 stem
+// without its 1.35 GB column buffer (conv_op_impl.h:126-173 builds that buffer; same sums, same order
+// within a k-chunk).
+template <int BM, bool IMPLICIT = false>
 __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArgs g) {
   constexpr int TI = BM / 64;                  // 32-row MFMA tiles per wave along M (wave = BM/2 rows)
   constexpr int A_STAGE = BK * BM;             // floats
@@ -84,7 +91,8 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
   constexpr int A_ROWS_PER_INSTR = 64 / A_ROW_LANES;          // 2 (BM = 128) or 4 (BM = 64)
   constexpr int A_INSTR = BK / A_ROWS_PER_INSTR;              // wave-instructions per stage: 8 or 4
   constexpr int B_INSTR = BK / 2;                             // 8
-  constexpr int A_PER_WAVE = A_INSTR / 4, B_PER_WAVE = B_INSTR / 4;      // 2|1 and 2
+  constexpr int A_PER_WAVE = A_INSTR / 4;                     // 2 | 1
+  constexpr int B_PER_WAVE = IMPLICIT ? BK * (BN / 64) / 4 : B_INSTR / 4;      // 8 (64 columns each) | 2
   constexpr int LOADS = A_PER_WAVE + B_PER_WAVE;              // per wave per stage
   __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE];
 
@@ -98,7 +106,8 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
   const int K = g.K, P = g.P;
 
   const __amdgpu_buffer_rsrc_t ars = uniform_rsrc(g.a, (unsigned)((long long)K * g.lda * 4));
-  const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(g.x, (unsigned)((long long)g.N * K * P * 4));
+  const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(
+      g.x, IMPLICIT ? (unsigned)((long long)g.N * g.C * g.H * g.W * 4) : (unsigned)((long long)g.N * K * P * 4));
 
   // ---- per-lane DMA sources (fixed for the tile; the chunk moves them by a uniform offset) ----
   // A: wave-instruction `ia` (0..A_INSTR) covers rows ia * A_ROWS_PER_INSTR + lane / A_ROW_LANES
@@ -112,6 +121,20 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
     const int n = (int)(qb / P), p = (int)(qb - (long long)n * P);
     b_voff = (unsigned)((((long long)n * K + h) * P + p) * 4);
   }
+  // implicit mode: this lane's two columns (lane, lane + 64): top-left input pixel and its offset
+  int iy0[2] = {0, 0}, ix0[2] = {0, 0}, ioff[2] = {0, 0};
+  bool iok[2] = {false, false};
+  if (IMPLICIT) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const long long qc = q0 + hf * 64 + lane;
+      iok[hf] = qc < g.Q;
+      const int n = iok[hf] ? (int)(qc / P) : 0, pp = iok[hf] ? (int)(qc - (long long)n * P) : 0;
+      iy0[hf] = (pp / g.OW) * g.stride - g.pad;
+      ix0[hf] = (pp % g.OW) * g.stride - g.pad;
+      ioff[hf] = ((n * g.C * g.H + iy0[hf]) * g.W + ix0[hf]) * 4;       // may be negative at the border
+    }
+  }
   auto issue = [&](int chunk, int buf) {
     const int k0 = chunk * BK;
     float* base = lds + buf * STAGE;
@@ -122,12 +145,27 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
       const unsigned vo = (row + a_row < K) ? a_voff : kOob;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_ptr)(base + ia * 256), 16, vo, row * g.lda * 4, 0, 0);
     }
+    if (IMPLICIT) {
+      const int kk2 = g.ksize * g.ksize;
 #pragma unroll
-    for (int u = 0; u < B_PER_WAVE; ++u) {
-      const int ib = wave * B_PER_WAVE + u;
-      const int row = k0 + ib * 2;
-      const unsigned vo = (row + h < K) ? b_voff : kOob;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr)(base + A_STAGE + ib * 256), 16, vo, row * P * 4, 0, 0);
+      for (int u = 0; u < B_PER_WAVE; ++u) {
+        const int ib = wave * B_PER_WAVE + u;                        // (row in chunk, 64-column half)
+        const int rr = ib >> 1, hf = ib & 1;
+        const int row = k0 + rr;
+        const int c = row / kk2, r2 = row - c * kk2, ky = r2 / g.ksize, kx = r2 - ky * g.ksize;     // scalars
+        const bool ok = iok[hf] && row < K && (unsigned)(iy0[hf] + ky) < (unsigned)g.H &&
+                        (unsigned)(ix0[hf] + kx) < (unsigned)g.W;
+        const unsigned vo = ok ? (unsigned)(ioff[hf] + ((c * g.H + ky) * g.W + kx) * 4) : kOob;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr)(base + A_STAGE + rr * BN + hf * 64), 4, vo, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < B_PER_WAVE; ++u) {
+        const int ib = wave * B_PER_WAVE + u;
+        const int row = k0 + ib * 2;
+        const unsigned vo = (row + h < K) ? b_voff : kOob;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr)(base + A_STAGE + ib * 256), 16, vo, row * P * 4, 0, 0);
+      }
     }
   };
 
@@ -148,8 +186,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
   for (int c = 0; c < chunks; ++c) {
     // this wave's loads of chunk c have landed (those of chunk c + 1 may still fly) ...
     if (c + 1 < chunks) {
-      if constexpr (LOADS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -469,6 +506,7 @@ int ssad_conv1x1_gemm(const ssad_gemm_conv* d, ssad_stream_t stream) {
   g.lda = d->lda; g.N = d->N; g.K = d->K; g.P = d->P; g.M = d->M; g.flags = d->flags;
   g.Q = Q;
   g.ctiles = (int)((Q + BN - 1) / BN);
+  g.C = g.H = g.W = g.OW = g.ksize = g.stride = g.pad = 0;
   hipStream_t s = (hipStream_t)stream;
   // 64-row tiles for 64-wide outputs, and wherever 128-row tiles would leave the chip with
   // fewer than two workgroups per CU (res5 at bs 16 is 70 column tiles: 280 tiles of 128 rows
@@ -490,6 +528,38 @@ int ssad_conv1x1_gemm(const ssad_gemm_conv* d, ssad_stream_t stream) {
   } else {
     g.mtiles = (d->M + 127) / 128;
     hipLaunchKernelGGL(gemm_conv_nn_kernel<128>, dim3(g.mtiles * g.ctiles), dim3(kThreads), 0, s, g);
+  }
+  return (int)hipGetLastError();
+}
+
+int ssad_conv_implicit_gemm(const ssad_gemm_conv* d, int C, int H, int W, int kernel, int stride, int pad,
+                            ssad_stream_t stream) {
+  if (!d || !d->a || !d->x || !d->y || d->N < 0 || d->M < 1 || C < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
+  if (kernel < 1 || stride < 1 || pad < 0 || H + 2 * pad < kernel || W + 2 * pad < kernel) return SSAD_E_BADARG;
+  const int OH = (H + 2 * pad - kernel) / stride + 1, OW = (W + 2 * pad - kernel) / stride + 1;
+  const int K = C * kernel * kernel;
+  if (d->K != K || d->P != OH * OW) return SSAD_E_BADARG;
+  if (d->lda < d->M || (d->lda & 3) || (d->P & 3)) return SSAD_E_BADARG;        // the epilogue's 16-byte pieces
+  if ((uintptr_t)d->a & 15) return SSAD_E_BADARG;
+  if ((d->flags & SSAD_GEMM_ACCUMULATE) && (d->bias || d->residual)) return SSAD_E_BADARG;
+  const long long Q = (long long)d->N * d->P;
+  if (Q == 0) return 0;
+  if ((long long)d->N * C * H * W * 4 >= (1LL << 31) || (long long)d->N * d->M * d->P * 4 >= (1LL << 31) ||
+      (long long)K * d->lda * 4 >= (1LL << 31))
+    return SSAD_E_BADARG;
+  GemmArgs g;
+  g.a = d->a; g.x = d->x; g.y = d->y; g.bias = d->bias; g.res = d->residual; g.mask = d->mask;
+  g.lda = d->lda; g.N = d->N; g.K = K; g.P = d->P; g.M = d->M; g.flags = d->flags;
+  g.Q = Q;
+  g.ctiles = (int)((Q + BN - 1) / BN);
+  g.C = C; g.H = H; g.W = W; g.OW = OW; g.ksize = kernel; g.stride = stride; g.pad = pad;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->M <= 64) {
+    g.mtiles = (d->M + 63) / 64;
+    hipLaunchKernelGGL((gemm_conv_nn_kernel<64, true>), dim3(g.mtiles * g.ctiles), dim3(kThreads), 0, s, g);
+  } else {
+    g.mtiles = (d->M + 127) / 128;
+    hipLaunchKernelGGL((gemm_conv_nn_kernel<128, true>), dim3(g.mtiles * g.ctiles), dim3(kThreads), 0, s, g);
   }
   return (int)hipGetLastError();
 }

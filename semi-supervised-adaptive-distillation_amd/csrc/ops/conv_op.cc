@@ -152,6 +152,23 @@ static bool PointwiseGemmEligible(const ConvGeometry& g, int N, int C, int M, in
   return big < (1LL << 31) && (long long)C * ((M + 3) / 4 * 4) * 4 < (1LL << 31);
 }
 
+// A k x k layer (any stride / pad, one group, square kernel, no dilation) the implicit-GEMM kernel
+// takes: 4-pixel-multiple output maps, tensors below 2 GiB.  SSAD_CONV1X1_ENGINE=blas disables it too.
+static bool ImplicitGemmEligible(const ConvGeometry& g, int N, int C, int H, int W, int M, int P) {
+  static const bool off = [] {
+    const char* e = getenv("SSAD_CONV1X1_ENGINE");
+    const char* f = getenv("SSAD_CONV_IMPLICIT");
+    return (e && std::string(e) == "blas") || (f && std::string(f) == "0");
+  }();
+  if (off || g.group != 1 || g.kernel[0] != g.kernel[1] || g.dilation != vector<int>{1, 1}) return false;
+  if (g.stride[0] != g.stride[1] || g.stride[0] < 1) return false;
+  if (g.pads[0] != g.pads[1] || g.pads[0] != g.pads[2] || g.pads[0] != g.pads[3]) return false;
+  if ((P & 3) || N < 1) return false;
+  const long long K = (long long)C * g.kernel[0] * g.kernel[0];
+  return (long long)N * C * H * W * 4 < (1LL << 31) && (long long)N * M * P * 4 < (1LL << 31) &&
+         K * ((M + 3) / 4 * 4) * 4 < (1LL << 31);
+}
+
 // Default engine, forward (conv_op_impl.h:31-202): per image im2col -> col[C*kh*kw][OH*OW],
 // Y[n] = filter[M][C*kh*kw] . col, then the bias; a 1x1 / stride 1 / pad 0 layer skips the
 // im2col (its col buffer IS the image).
@@ -196,6 +213,21 @@ bool ConvOp<float, HIPContext>::RunDefaultEngine() {
                            InputSize() == 3 ? Input(BIAS).data<float>() : nullptr, nullptr, nullptr,
                            ldm, N, C, P, M, fuse_relu_ ? SSAD_GEMM_RELU : 0};
     CAFFE_ENFORCE_EQ(ssad_conv1x1_gemm(&d, s), 0, "pointwise Conv launch failed");
+    return true;
+  }
+  // k x k (7x7/2 stem, 3x3/2 of P6 / P7 and of the first bottleneck blocks under STRIDE_1X1 = False):
+  // the same GEMM kernel with the im2col view gathered by its DMA -- no column buffer, whole batch,
+  // bias (and a fused Relu) in the epilogue.
+  if (!pointwise && ImplicitGemmEligible(geom_, N, C, H, W, M, P)) {
+    const int ldm = (M + 3) / 4 * 4;
+    packed_filter_.Resize((TIndex)K * ldm);
+    float* wt = packed_filter_.mutable_data<float>();
+    CAFFE_ENFORCE_EQ(ssad_transpose_filter(filter.data<float>(), M, K, ldm, wt, s), 0);
+    const ssad_gemm_conv d{wt, X.data<float>(), Y->mutable_data<float>(),
+                           InputSize() == 3 ? Input(BIAS).data<float>() : nullptr, nullptr, nullptr,
+                           ldm, N, K, P, M, fuse_relu_ ? SSAD_GEMM_RELU : 0};
+    CAFFE_ENFORCE_EQ(ssad_conv_implicit_gemm(&d, C, H, W, kh, geom_.stride[0], geom_.pads[0], s), 0,
+                     "implicit-GEMM Conv launch failed");
     return true;
   }
   if (!pointwise) col_buffer_.Resize((TIndex)K * P);

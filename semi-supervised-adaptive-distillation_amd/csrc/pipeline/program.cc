@@ -162,6 +162,8 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
     case SSAD_OP_GROUPED_CONV3X3:
       return ssad_grouped_conv3x3_forward((const float*)p[0], (const float*)p[1], (const float*)p[2], i[0], i[1],
                                           i[2], i[3], i[4], i[5], i[6], (float*)p[3], s);
+    case SSAD_OP_CONV_IMPLICIT:
+      return ssad_conv_implicit_gemm((const ssad_gemm_conv*)p[0], i[0], i[1], i[2], i[3], i[4], i[5], s);
     case SSAD_OP_GROUPED_PACK:
       return ssad_grouped_conv3x3_pack_filter((const float*)p[0], i[0], i[1], (float*)p[1], s);
     case SSAD_OP_CHANNEL_SUM:

@@ -168,6 +168,7 @@ def lib():
     L.ssad_conv1x1_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]
     L.ssad_subsample.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_subsample_grad.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.ssad_conv_implicit_gemm.argtypes = [C.POINTER(GemmConv), i32, i32, i32, i32, i32, i32, vp]
     L.ssad_grouped_conv3x3_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_grouped_conv3x3_filter_floats.argtypes = [i32, i32]
     L.ssad_grouped_conv3x3_filter_floats.restype = C.c_longlong
@@ -892,4 +893,18 @@ def grouped_conv3x3_forward(x, w, bias=None, group=64, stride=1, relu=False, out
         _f32c(bias, "bias")
     _check(lib().ssad_grouped_conv3x3_forward(_ptr(x), _ptr(packed), _ptr(bias), N, Cc, H, W, group, stride,
                                               int(relu), _ptr(y), _stream()), "grouped_conv3x3_forward")
+    return y
+
+
+def conv_implicit_gemm(x, w, bias=None, stride=1, pad=0, relu=False, out=None):
+    """k x k convolution (group 1) as an implicit GEMM: x [N,C,H,W], w [M,C,k,k] -> [N,M,OH,OW]."""
+    _f32c(x, "x"); _f32c(w, "w")
+    N, Cc, H, W = x.shape
+    M, k = w.shape[0], w.shape[2]
+    oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    wt = transpose_filter(w.reshape(M, Cc * k * k, 1, 1))
+    y = out if out is not None else torch.empty((N, M, oh, ow), dtype=torch.float32, device="cuda")
+    d = gemm_conv_desc(wt, wt.shape[1], x, y, Cc * k * k, M, bias, None, None, relu, False)
+    d.P = oh * ow
+    _check(lib().ssad_conv_implicit_gemm(C.byref(d), Cc, H, W, k, stride, pad, _stream()), "conv_implicit_gemm")
     return y

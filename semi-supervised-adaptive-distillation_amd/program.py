@@ -24,7 +24,7 @@ AFFINE_CHANNEL, UPSAMPLE, UPSAMPLE_GRAD, STEM_POOL, RELU_GRAD_ROWSUM, RELU_GRAD,
 GEMM_CONV, CONV1X1_WGRAD, TRANSPOSE_FILTER, SUBSAMPLE, SUBSAMPLE_GRAD, RELU, IM2COL_BATCHED = \
     54, 56, 57, 58, 59, 60, 61
 FORK, JOIN = 62, 63
-GROUPED_CONV3X3, GROUPED_PACK = 64, 65
+GROUPED_CONV3X3, GROUPED_PACK, CONV_IMPLICIT = 64, 65, 66
 
 # timing classes: one per kernel family.  bound "mfma": work = direct-form FLOPs
 # (2*9*Cout*Cin per output pixel; the Winograd engine executes 1/2.25 of them);
@@ -69,7 +69,7 @@ KLASS = {
              bound="hbm"),
     52: dict(name="backbone pointwise conv filter gradient (gemm_conv_nt_kernel + reduce)", bound="mfma",
              wino=False),
-    53: dict(name="stem 7x7/2 conv (im2col + gemm_conv_nn_kernel)", bound="mfma", wino=False),
+    53: dict(name="stem 7x7/2 conv (implicit GEMM: gemm_conv_nn_kernel<64, true>)", bound="mfma", wino=False),
     54: dict(name="backbone filter packs (transpose / Winograd)", bound="hbm"),
     56: dict(name="grouped 3x3 conv, ResNeXt (grouped_conv3x3_kernel)", bound="mfma", wino=False),
     55: dict(name="backbone momentum SGD (sgd_flat_kernel)", bound="hbm"),

@@ -160,3 +160,46 @@ def test_grouped_conv3x3_vs_reference_operator_golden(K, golden_dir):
         K.grouped_conv3x3_forward(torch.zeros(1, 24, 4, 4, device="cuda"), torch.zeros(24, 12, 3, 3, device="cuda"),
                                   group=2)
     assert K.lib().ssad_grouped_conv3x3_filter_floats(256, 64) == 64 * 9 * 64
+
+
+@pytest.mark.parametrize("geom", [
+    (2, 3, 64, 32, 40, 7, 2, 3),        # the stem: 7x7 / 2, pad 3, three input channels
+    (2, 3, 64, 128, 192, 7, 2, 3),      # the stem at the body-graph test's image size
+    (1, 3, 16, 22, 32, 7, 2, 3),        # ragged borders on every side (11 x 16 outputs)
+    (2, 16, 24, 12, 16, 3, 2, 1),       # 3x3 / 2 (P6 / P7)
+    (1, 8, 136, 8, 12, 3, 1, 1),        # 3x3 / 1, two 128-row tiles
+    (2, 24, 40, 8, 12, 1, 1, 0),        # degenerates to the pointwise GEMM
+], ids=lambda g: "N%d_C%d_M%d_%dx%d_k%ds%dp%d" % g)
+def test_conv_implicit_gemm_vs_oracle(K, geom):
+    N, Cin, M, H, W, k, st, pad = geom
+    rng = np.random.default_rng(sum(geom))
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, k, k)) * (1.0 / np.sqrt(Cin * k * k))).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    ref = oracle.conv_forward(X, Wt, b, kernel=k, stride=st, pad=pad)
+    got = K.conv_implicit_gemm(dev(X), dev(Wt), dev(b), stride=st, pad=pad)
+    assert tuple(got.shape) == ref.shape
+    close(got.cpu().numpy(), ref, CONV_RTOL, CONV_FLOOR, "Y")
+    close(K.conv_implicit_gemm(dev(X), dev(Wt), None, stride=st, pad=pad, relu=True).cpu().numpy(),
+          np.maximum(oracle.conv_forward(X, Wt, None, kernel=k, stride=st, pad=pad), 0), CONV_RTOL, CONV_FLOOR,
+          "relu(Y)")
+
+
+def test_conv_implicit_gemm_vs_reference_operator_golden(K, golden_dir):
+    """The strided / 7x7 geometries of tests/golden/conv_ref.npz (outputs of the reference's compiled
+    ConvOp) whose output map is a multiple of 4 pixels."""
+    g = np.load(os.path.join(golden_dir, "conv_ref.npz"))
+    done = 0
+    for key in g.files:
+        if not key.endswith("_dims"):
+            continue
+        name = key[:-5]
+        seed, N, Cin, M, H, W, k, s, p, grp = [int(v) for v in g[key]]
+        oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        if grp != 1 or (oh * ow) % 4:
+            continue
+        X, Wt, b, _ = mg.conv_ref_inputs(seed, N, Cin, M, H, W, k, s, p, grp)
+        Y = K.conv_implicit_gemm(dev(X), dev(Wt), dev(b), stride=s, pad=p).cpu().numpy()
+        close(Y.ravel()[g[name + "_Y_idx"]], g[name + "_Y"], CONV_RTOL, CONV_FLOOR, name + " Y")
+        done += 1
+    assert done >= 7
