@@ -178,6 +178,10 @@ SSAD_API ssad_timing* ssad_timing_create(void);
 SSAD_API void ssad_timing_destroy(ssad_timing* t);
 /* forget the records taken so far (events are kept for reuse) */
 SSAD_API void ssad_timing_reset(ssad_timing* t);
+/* Bracket only the ops of the listed timing classes (n = 0: every op again).  Events between all
+ * ~500 ops of a step keep consecutive kernels from overlapping their tails (measured: 1 % of the
+ * step; more when collectives are in flight), so a throughput run times only what it reports. */
+SSAD_API int ssad_timing_select(ssad_timing* t, const int* klasses, int n);
 /* The caller must have synchronised the stream(s).  Writes up to max_out classes (ascending
  * klass) and returns how many there are, or a negative hipError_t. */
 SSAD_API int ssad_timing_collect(ssad_timing* t, ssad_timing_class* out, int max_out);

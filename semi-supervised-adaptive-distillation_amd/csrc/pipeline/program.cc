@@ -15,6 +15,13 @@ struct ssad_timing {
   size_t used = 0;
   struct Rec { int klass; double work; size_t e0, e1; };
   std::vector<Rec> recs;
+  std::vector<int> only;            // empty: every op is bracketed; else only ops of these classes
+  bool wants(int klass) const {
+    if (only.empty()) return true;
+    for (int k : only)
+      if (k == klass) return true;
+    return false;
+  }
   hipEvent_t get() {
     if (used == pool.size()) {
       hipEvent_t e = nullptr;
@@ -185,6 +192,12 @@ void ssad_timing_destroy(ssad_timing* t) {
   delete t;
 }
 
+int ssad_timing_select(ssad_timing* t, const int* klasses, int n) {
+  if (!t || n < 0 || (n > 0 && !klasses)) return SSAD_E_BADARG;
+  t->only.assign(klasses, klasses + n);
+  return 0;
+}
+
 void ssad_timing_reset(ssad_timing* t) {
   if (!t) return;
   t->used = 0;
@@ -264,7 +277,9 @@ int ssad_program_run(const ssad_op* ops, int n_ops, ssad_stream_t stream, ssad_t
     }
     hipStream_t hs = stream_of(sid);
     if (sid > 0) dirty[sid] = true;
-    if (timing && !have_prev[sid]) {
+    const bool timed = timing && timing->wants(o.klass);
+    if (timing && !timed) have_prev[sid] = false;      // the next timed op of this stream needs its own start
+    if (timed && !have_prev[sid]) {
       hipEvent_t e0 = timing->get();
       if (!e0) return fail(k, SSAD_E_BADARG);
       const hipError_t e = hipEventRecord(e0, hs);
@@ -274,7 +289,7 @@ int ssad_program_run(const ssad_op* ops, int n_ops, ssad_stream_t stream, ssad_t
     }
     const int rc = run_op(o, (ssad_stream_t)hs);
     if (rc != 0) return fail(k, rc);
-    if (timing) {
+    if (timed) {
       hipEvent_t e1 = timing->get();
       if (!e1) return fail(k, SSAD_E_BADARG);
       const hipError_t e = hipEventRecord(e1, hs);

@@ -99,6 +99,7 @@ def _lib():
         L.ssad_timing_destroy.argtypes = [C.c_void_p]
         L.ssad_timing_reset.argtypes = [C.c_void_p]
         L.ssad_timing_collect.argtypes = [C.c_void_p, C.POINTER(TimingClass), C.c_int]
+        L.ssad_timing_select.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
         L.ssad_program_run.argtypes = [C.POINTER(Op), C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         _bound = True
     return L
@@ -125,6 +126,14 @@ class Timing(object):
 
     def reset(self):
         _lib().ssad_timing_reset(self.handle)
+
+    def select(self, klasses=()):
+        """Time only the ops of these classes (empty: all)."""
+        arr = (C.c_int * max(len(klasses), 1))(*klasses)
+        rc = _lib().ssad_timing_select(self.handle, arr, len(klasses))
+        if rc != 0:
+            raise K.KernelError("ssad_timing_select failed with code %d" % rc)
+        return self
 
     def collect(self):
         """After a stream/device synchronise: {klass: dict(launches, ms, work)}."""

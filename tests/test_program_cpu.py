@@ -26,7 +26,7 @@ def test_program_header_symbols_are_exported():
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"SSAD_API\s+[^;(]*?\b(\w+)\s*\(", text)
     assert sorted(names) == ["ssad_program_run", "ssad_timing_collect", "ssad_timing_create",
-                             "ssad_timing_destroy", "ssad_timing_reset"]
+                             "ssad_timing_destroy", "ssad_timing_reset", "ssad_timing_select"]
     raw = ctypes.CDLL(K.LIB_PATH)
     assert all(hasattr(raw, n) for n in names)
     # the Python mirror of ssad_op has the C layout: 4*4 + 8*4 + 4*4 + 2*8 + 8*8 + 8
