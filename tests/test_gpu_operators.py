@@ -411,6 +411,41 @@ def test_head_graph_through_workspace_vs_oracle_and_fused():
             close_chain(heads.d_fpn[tower][i].cpu().numpy(), ref["d_fpn"][tower][i], "d_fpn")
 
 
+def test_executor_timing_classes_and_selection():
+    """ssad_program_run's event timing: every family of the step shows up with its launch count,
+    ssad_timing_select restricts the bracketing to the listed classes, and neither changes the
+    numbers the step produces."""
+    cfg, S, T, fs, ft, labs, tg, fg = small_problem(seed=35, N=1)
+    from ssad_amd.head_pipeline import DistillHeads
+    from ssad_amd import program as PR
+    dev = torch.device("cuda", 0)
+    t = lambda arrs: [torch.from_numpy(a).to(dev) for a in arrs]
+    args = (t(fs), t(ft), t(labs))
+    kw = dict(update=False, bbox_targets=[tuple(t(p)) for p in tg], fg_num=torch.from_numpy(fg).to(dev))
+    heads = DistillHeads(cfg, N=1, shapes=SHAPES, device=dev, student_init=S, teacher_init=T)
+    base = heads.step(*args, **kw).clone()
+    g0 = heads.grads.flat.clone()
+    everything = PR.Timing()
+    heads.timing = everything
+    heads.step(*args, **kw)
+    torch.cuda.synchronize()
+    allc = everything.collect()
+    assert {2, 8, 9, 16}.issubset(allc) and allc[9]["launches"] == 1 and allc[8]["launches"] == 1
+    assert all(c["ms"] > 0 for c in allc.values())
+    only = PR.Timing().select([9, 8])
+    heads.timing = only
+    losses = heads.step(*args, **kw)
+    torch.cuda.synchronize()
+    sel = only.collect()
+    assert sorted(sel) == [8, 9] and sel[9]["launches"] == 1 and sel[9]["work"] == allc[9]["work"]
+    assert torch.equal(losses, base) and torch.equal(heads.grads.flat, g0)
+    only.select([])                       # back to every class
+    only.reset()
+    heads.step(*args, **kw)
+    torch.cuda.synchronize()
+    assert sorted(only.collect()) == sorted(allc)
+
+
 def test_fused_sgd_step_matches_oracle():
     cfg, S, T, fs, ft, labs, tg, fg = small_problem(seed=33, N=1)
     from ssad_amd.head_pipeline import DistillHeads
