@@ -26,11 +26,11 @@ run() { # name, title, rocprof args..., -- cmd
 # is the period marker), so MIOpen's find-phase candidates of step 1 do not show
 SUMMARY_ARGS="--marker cls_losses_fused_kernel --last 5"
 run bench_full_trace "rocprofv3 --kernel-trace --stats: python bench.py --steps 5 --warmup 2 (default = full workload), the 5 timed steps" \
-    --kernel-trace --stats -d /tmp/prof_bench_full_trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline
+    --kernel-trace --stats -d /tmp/prof_bench_full_trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0
 run bench_heads_trace "rocprofv3 --kernel-trace --stats: python bench.py --workload heads --steps 5 --warmup 2, the 5 timed steps" \
-    --kernel-trace --stats -d /tmp/prof_bench_heads_trace -o t -- python bench.py --workload heads --steps 5 --warmup 2 --no-cpu-baseline
+    --kernel-trace --stats -d /tmp/prof_bench_heads_trace -o t -- python bench.py --workload heads --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0
 run bench_heads_f16_trace "rocprofv3 --kernel-trace --stats: python bench.py --workload heads --precision f16 --steps 5 --warmup 2 (fp16 storage subnets; not the headline precision), the 5 timed steps" \
-    --kernel-trace --stats -d /tmp/prof_bench_heads_f16_trace -o t -- python bench.py --workload heads --precision f16 --steps 5 --warmup 2 --no-cpu-baseline
+    --kernel-trace --stats -d /tmp/prof_bench_heads_f16_trace -o t -- python bench.py --workload heads --precision f16 --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0
 SUMMARY_ARGS=""
 run pmc_fetch "PMC pass 1 (FETCH_SIZE, KB): python tools/kbench.py" \
     --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_pmc_fetch -o t -- python tools/kbench.py
