@@ -143,7 +143,6 @@ struct WLevel {
   int block_start;
 };
 
-constexpr int kFlagYoungPrio = 1 << 16;   // launcher-internal flag bit (above the SSAD_CONV_* bits)
 
 struct WArgs {
   WLevel lv[SSAD_MAX_CONV_PROBLEMS];
@@ -432,7 +431,6 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   // static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves
   // per SIMD, item 4): waves 4-7 lose VALU arbitration to their older SIMD partners on every chunk;
   // one s_setprio for them, no per-segment flips
-  if ((args.flags & kFlagYoungPrio) && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   // ---- level tables and this workgroup's tile list ----
   if (tid < 32) {
@@ -877,8 +875,6 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
   WArgs a;
   a.n_levels = n_levels;
   a.M = Cout; a.K = Cin; a.chunks = cdiv(Cin, KC); a.flags = flags;
-  static const int young_prio = [] { const char* e = getenv("SSAD_WINO_PRIO"); return e ? atoi(e) : 0; }();
-  if (young_prio) a.flags |= kFlagYoungPrio;
   long long blocks = 0;
   for (int l = 0; l < n_levels; ++l) {
     WLevel& L = a.lv[l];
