@@ -10,14 +10,17 @@ PowSum + SigmoidAdaptiveDistillLoss forward/gradient + student backward
 HBM before the timed region.  Prints ONE JSON line on rank 0.
 
 Workloads
-  heads  the RetinaNet subnets + distillation losses only (this repo's HIP
-         kernels end to end), fed synthetic FPN features;
-  full   BASELINE config "R-50 student + R-101 teacher, bs=16/GPU, 600 px":
-         ResNet-FPN backbones run as a PyTorch harness (out of
-         scope as hand kernels) whose stride-1 3x3 convolutions call this
-         repo's Winograd / wgrad kernels (the rest is MIOpen / rocBLAS); subnets
-         + losses through the HIP kernels.  This is the configuration the
-         metric is quoted on.
+  heads  the RetinaNet subnets + distillation losses only, fed synthetic FPN features;
+  full   BASELINE config "R-50 student + R-101 teacher, bs=16/GPU, 600 px" (default): both
+         ResNet-FPN backbones, subnets, losses and both SGD updates as native programs of this
+         repo's HIP kernels (ssad_program_run), teacher on a second stream.  This is the
+         configuration the metric is quoted on.  --backbone harness selects round 1's PyTorch
+         harness for the backbones (MIOpen / rocBLAS), which `--precision f16` still uses by
+         default for its fp16-autocast backbones.
+
+Timing: `value` from the wall clock around K steps (barrier + synchronize on both sides, max
+over ranks).  Inside the timed region HIP events bracket only the kernel families the
+`roofline*` objects quote; `kernels[]` comes from --profile-steps instrumented steps after it.
 """
 import argparse
 import json
@@ -59,8 +62,9 @@ def parse():
     # subnet precision: f32 (the metric's precision, default) or fp16 storage / fp32 accumulation
     # (config 5; backbones stay fp32).  An f16 line is NOT the headline number.
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"])
-    # backbones: "native" = programs of this repo's kernels (ResNet-50/101, fp32);
-    # "harness" = the PyTorch harness (MIOpen / rocBLAS; needed for ResNeXt and the fp16 run)
+    # backbones: "native" = programs of this repo's kernels (ResNet-50/101 students, ResNet /
+    # ResNeXt-101-64x4d teachers, fp32); "harness" = the PyTorch harness (MIOpen / rocBLAS; what
+    # "auto" picks for --precision f16, whose backbones then run under fp16 autocast)
     ap.add_argument("--backbone", default="auto", choices=["auto", "native", "harness"])
     ap.add_argument("--profile-steps", type=int, default=3,
                     help="instrumented steps after the timed region (per-family kernel table)")
