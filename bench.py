@@ -30,11 +30,16 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The HIP runtime maps streams onto 4 hardware queues by default.  With RCCL's streams in
-# the process the harness' teacher stream and the main stream land on the SAME queue and
-# the two backbones serialise (measured: 113.4 ms/step against 110.8 with 8 queues).
-# Must be set before the runtime initialises, i.e. before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# The HIP runtime maps a process's streams round-robin onto GPU_MAX_HW_QUEUES hardware queues (default
+# 4).  Measured on one MI355X with the collectives forced onto a one-rank RCCL communicator
+# (SSAD_DP_FORCE=1): with 2, 4, 8 or 12 queues a step that issues collectives is 2.5-3 ms slower than
+# one that does not (full step 107.3 vs 104.7 ms at 8; fp16 subnets 13.5 vs 11.6 ms) -- two of the
+# streams involved (main / teacher / the executor's auxiliary streams / RCCL's) are created four apart
+# and then share a queue -- while with 3, 5, 6 or 7 queues the collectives cost nothing (104.4 vs 105.0
+# ms at 7; harness 105.7 vs 106.1).  Without collectives the count does not matter (>= 2).  A count
+# that is not a multiple of 4 therefore; must be set before the runtime initialises, i.e. before
+# torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "7")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
