@@ -683,7 +683,13 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
       }
       DBG(1, s, 2);
       if (++rbuf == NRAW) rbuf = 0;
-      __syncthreads();
+      // End of chunk: the LDS traffic of this wave (V writes, operand reads) and every vector-memory
+      // operation older than the AD filter operands still in flight for the NEXT chunk's first steps
+      // -- in particular this chunk's DMA -- must be done; the ring itself need not (__syncthreads()
+      // waits for vmcnt(0): the operand requested at the last step, an L2 round trip, was exposed at
+      // every chunk: 350-850 of ~10 k cycles in the cycle stamps).
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AD) : "memory");
+      __builtin_amdgcn_s_barrier();
       DBG(1, s, 3);
     }
     DBG(1, s - 1, 4);
