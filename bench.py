@@ -275,7 +275,7 @@ def main():
                                        teacher_arch=args.teacher if distill else None, N=N, image_hw=image_hw,
                                        device=dev, process_group=pg, world_size=world)
         else:
-            from ssad_amd.harness.full_model import FullDistillModel
+            from tools.harness.full_model import FullDistillModel
             model = FullDistillModel(heads, student_depth=args.student,
                                      teacher_depth=args.teacher if distill else None, device=dev,
                                      backbone_f16=f16, process_group=pg, world_size=world)
@@ -337,6 +337,8 @@ def main():
     loss_val = [float(v) for v in heads.losses.cpu()]
     assert all(np.isfinite(loss_val)), "non-finite distillation loss: %r" % (loss_val,)
     assert bool(torch.isfinite(heads.params.flat).all()), "non-finite subnet parameters after the run"
+    if args.workload == "full" and native:
+        assert bool(torch.isfinite(model.student.params_flat).all()), "non-finite backbone parameters after the run"
 
     if rank == 0:
         rows = kernel_report(timing_all.collect(), max(args.profile_steps, 1))      # all families

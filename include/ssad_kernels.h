@@ -221,6 +221,13 @@ SSAD_API int ssad_momentum_sgd_update(
 typedef struct ssad_sgd_segment {
   int64_t offset, n;
   int is_bias;
+  /* optional per-row gradient factor (device pointer, n / row_len floats; NULL = none):
+   * g' = row_scale[k / row_len] * g + wd * w.  A filter stored with a frozen AffineChannel
+   * scale s folded in (W' = s W, detectron/lib/modeling/ResNet.py:270-283 + affine_channel_op.cc:
+   * the scale is not a trained blob) follows the reference's update of W exactly when its
+   * gradient rows are multiplied by s^2. */
+  int row_len;
+  const float* row_scale;
 } ssad_sgd_segment;
 SSAD_API int ssad_momentum_sgd_flat(
     float* w, float* g, float* m, const float* lr, float momentum, float weight_decay,

@@ -4,7 +4,13 @@ through res3..res5 + FPN, and the SGD update, with no torch operator in the step
 Structure of the network: detectron/lib/modeling/ResNet.py:85-130,221-283 (bottleneck stages
 3-4-{6,23}-3, stride on the first 1x1 as with the MSRA weights, frozen BN = AffineChannel,
 folded into the convolution that precedes it: W' = s W, bias = b; stem + res2 frozen,
-TRAIN.FREEZE_CONV_BODY / FREEZE_AT = 2) and FPN.py:116-250 for RetinaNet (laterals on
+TRAIN.FREEZE_CONV_BODY / FREEZE_AT = 2).  The body's convolutions have no bias of their own
+(ResNet.py:270-283, no_bias=1) and AffineChannel's scale and bias are never trained
+(caffe2/modules/detectron/affine_channel_op.cc: the gradient operator produces dX only), so
+here the folded biases of res3..res5 are frozen values, not parameters, and the update of a
+folded filter multiplies its gradient rows by s^2 (ssad_sgd_segment.row_scale) -- W' = s W
+then follows the reference's update of W exactly: s (W - lr (s dW' + wd W)) = W' - lr (s^2 dW'
++ wd W').  Only the FPN's own convolutions (FPN.py:116-250) carry trained biases. and FPN.py:116-250 for RetinaNet (laterals on
 res3..res5, top-down nearest upsampling + Sum, 3x3 output convs, P6 = conv3x3/2 on res5,
 P7 = conv3x3/2 on relu(P6)).
 
@@ -43,12 +49,14 @@ GROUPED = {"x101-64x4d": (64, 4)}
 
 
 class _Layer(object):
-    __slots__ = ("name", "k", "cin", "cout", "stride", "train", "group", "w", "b", "gw", "gb", "wt", "pf", "pd")
+    __slots__ = ("name", "k", "cin", "cout", "stride", "train", "group", "affine", "w", "b", "gw", "gb", "wt",
+                 "pf", "pd", "s2")
 
-    def __init__(self, name, k, cin, cout, stride, train, group=1):
+    def __init__(self, name, k, cin, cout, stride, train, group=1, affine=False):
         self.name, self.k, self.cin, self.cout, self.stride, self.train = name, k, cin, cout, stride, train
         self.group = group
-        self.w = self.b = self.gw = self.gb = self.wt = self.pf = self.pd = None
+        self.affine = affine       # followed by a frozen AffineChannel (folded): the bias is not a parameter
+        self.w = self.b = self.gw = self.gb = self.wt = self.pf = self.pd = self.s2 = None
 
     @property
     def wcin(self):
@@ -58,7 +66,8 @@ class _Layer(object):
 
 class NativeResNetFPN(object):
     def __init__(self, arch="r50", N=2, image_hw=(640, 896), device="cuda", train=True, src=None,
-                 fpn_dim=256, lr=1e-5, momentum=0.9, weight_decay=1e-4, process_group=None, world_size=1):
+                 fpn_dim=256, lr=1e-5, momentum=0.9, weight_decay=1e-4, process_group=None, world_size=1,
+                 affine_scales=None, skip_flag=None, overlap_wgrad=None):
         if arch not in ARCHS:
             raise K.KernelError("native backbone: architectures %s" % sorted(ARCHS))
         if arch in GROUPED and train:
@@ -76,8 +85,12 @@ class NativeResNetFPN(object):
         self._layers = OrderedDict()
         self._bufs = []
         self._define_layers()
-        self._alloc_params(src)
+        self._alloc_params(src, affine_scales)
         self.lr = torch.full((1,), lr, dtype=torch.float32, device=device)
+        # device int (or None): when non-zero at execution time the update is dropped (a
+        # mixed-precision step whose gradients overflowed, head_pipeline.DistillHeadsF16)
+        self.skip_flag = skip_flag
+        self._overlap_wgrad = overlap_wgrad
         self._build()
 
     # -- network definition -------------------------------------------------------------
@@ -85,7 +98,8 @@ class NativeResNetFPN(object):
         L = self._layers
 
         def add(name, k, cin, cout, stride=1, train=True, group=1):
-            L[name] = _Layer(name, k, cin, cout, stride, train and self.train, group)
+            L[name] = _Layer(name, k, cin, cout, stride, train and self.train, group,
+                             affine=name.startswith(("stem", "res")))
         groups, width = GROUPED.get(self.arch, (1, 64))
         add("stem.0", 7, 3, 64, 2, train=False)
         cin = 64
@@ -128,32 +142,68 @@ class NativeResNetFPN(object):
                         groups["res%d" % stage].append(name)
         return groups
 
-    def _alloc_params(self, src):
+    # Folded AffineChannel scale of the random initialisation: the last layer of every bottleneck
+    # carries s = 0.25 (frozen-BN scales have no statistics with random weights; the damped residual
+    # branch keeps activations O(1) through 16 / 33 blocks, the job a trained model's BN does).
+    INIT_C3_SCALE = 0.25
+
+    def _default_init(self):
+        """Random weights of the network's shapes (there are no checkpoints on the box): He-normal
+        filters (fan in) with zero bias for the body, Xavier-uniform for the FPN's own layers
+        (FPN.py:116-250 uses XavierFill there).  Returns ({name.weight / name.bias: tensor},
+        {name: folded affine scale})."""
+        gen = torch.Generator().manual_seed(7)
+        sd, scales = {}, {}
+        for l in self._layers.values():
+            shape = (l.cout, l.wcin, l.k, l.k)
+            fan_in = l.wcin * l.k * l.k
+            if l.affine:
+                w = torch.randn(shape, generator=gen) * float(np.sqrt(2.0 / fan_in))
+                if l.name.endswith(".c3"):
+                    w *= self.INIT_C3_SCALE
+                    scales[l.name] = self.INIT_C3_SCALE
+            else:
+                bound = float(np.sqrt(6.0 / (fan_in + l.cout * l.k * l.k)))
+                w = (torch.rand(shape, generator=gen) * 2.0 - 1.0) * bound
+            sd[l.name + ".weight"] = w
+            sd[l.name + ".bias"] = torch.zeros(l.cout)
+        return sd, scales
+
+    def _alloc_params(self, src, affine_scales=None):
+        """src: None (random initialisation), a {name.weight / name.bias: tensor} dict or a module
+        whose state_dict() has those names (filters with the AffineChannel scale folded in);
+        affine_scales: {layer name: s (float or [cout] tensor)} of the folded scales (default 1)."""
         dev = self.device
         L = self._layers
+        scales = dict(affine_scales or {})
         if src is None:
-            from .harness.full_model import ResNetFPN
-            with torch.random.fork_rng():
-                torch.manual_seed(7)
-                src = ResNetFPN(self.arch, self.D)
-        sd = {k: v.detach() for k, v in src.state_dict().items()}
-        frozen = [l for l in L.values() if not l.train]
+            sd, init_scales = self._default_init()
+            for k, v in init_scales.items():
+                scales.setdefault(k, v)
+        else:
+            sd = src if isinstance(src, dict) else src.state_dict()
+            sd = {k: v.detach() for k, v in sd.items()}
         groups = self._bucket_order() if self.train else OrderedDict()
         order = [L[n] for g in groups.values() for n in g]
-        assert len(order) + len(frozen) == len(L) or not self.train
+        assert all(l.train for l in order) and (not self.train or len(order) == sum(l.train for l in L.values()))
 
-        def size(l):
-            return l.cout * l.wcin * l.k * l.k + l.cout
+        # frozen values: filters + biases of frozen layers, and the folded affine biases of the
+        # trainable body layers
+        def fsize(l):
+            return (0 if l.train else l.cout * l.wcin * l.k * l.k) + (l.cout if (not l.train or l.affine) else 0)
 
-        self.frozen_flat = torch.empty(sum(size(l) for l in frozen), dtype=torch.float32, device=dev)
-        off = 0
-        for l in frozen:
-            nw = l.cout * l.wcin * l.k * l.k
-            l.w = self.frozen_flat[off:off + nw].view(l.cout, l.wcin, l.k, l.k)
-            l.b = self.frozen_flat[off + nw:off + nw + l.cout]
-            off += nw + l.cout
-        n_train = sum(size(l) for l in order)
         f32 = dict(dtype=torch.float32, device=dev)
+        self.frozen_flat = torch.empty(sum(fsize(l) for l in L.values()), **f32)
+        off = 0
+        for l in L.values():
+            if not l.train:
+                nw = l.cout * l.wcin * l.k * l.k
+                l.w = self.frozen_flat[off:off + nw].view(l.cout, l.wcin, l.k, l.k)
+                off += nw
+            if not l.train or l.affine:
+                l.b = self.frozen_flat[off:off + l.cout]
+                off += l.cout
+        n_train = sum(l.cout * l.cin * l.k * l.k + (0 if l.affine else l.cout) for l in order)
         self.params_flat = torch.empty(n_train, **f32)
         self.grads_flat = torch.zeros(n_train, **f32)
         self.moms_flat = torch.zeros(n_train, **f32)
@@ -166,23 +216,29 @@ class NativeResNetFPN(object):
                 nw = l.cout * l.cin * l.k * l.k
                 l.w = self.params_flat[off:off + nw].view(l.cout, l.cin, l.k, l.k)
                 l.gw = self.grads_flat[off:off + nw].view(l.cout, l.cin, l.k, l.k)
-                self.segments.append((off, nw, 0))
+                sc = scales.get(n)
+                if sc is not None and l.affine:
+                    sc = torch.as_tensor(sc, dtype=torch.float32).reshape(-1).to(dev)
+                    l.s2 = (sc * sc).expand(l.cout).contiguous() if sc.numel() == 1 else (sc * sc).contiguous()
+                self.segments.append((off, nw, 0, l.cin * l.k * l.k, l.s2))
                 off += nw
-                l.b = self.params_flat[off:off + l.cout]
-                l.gb = self.grads_flat[off:off + l.cout]
-                self.segments.append((off, l.cout, 1))
-                off += l.cout
+                if not l.affine:
+                    l.b = self.params_flat[off:off + l.cout]
+                    l.gb = self.grads_flat[off:off + l.cout]
+                    self.segments.append((off, l.cout, 1, 0, None))
+                    off += l.cout
             self.bucket[gname] = self.grads_flat[start:off]
         for l in L.values():
-            l.w.copy_(sd[l.name + ".weight"].to(dev))
-            l.b.copy_(sd[l.name + ".bias"].to(dev))
+            l.w.copy_(sd[l.name + ".weight"].to(device=dev, dtype=torch.float32))
+            l.b.copy_(sd[l.name + ".bias"].to(device=dev, dtype=torch.float32))
 
-    def load_from(self, module):
-        """Copy the parameters of a harness ResNetFPN (same layer names)."""
-        sd = module.state_dict()
+    def load_from(self, src):
+        """Copy parameters from a {name.weight / name.bias: tensor} dict or a module with such a
+        state_dict() (filters with the AffineChannel scale folded in)."""
+        sd = src if isinstance(src, dict) else src.state_dict()
         for l in self._layers.values():
-            l.w.copy_(sd[l.name + ".weight"])
-            l.b.copy_(sd[l.name + ".bias"])
+            l.w.copy_(sd[l.name + ".weight"].detach().to(device=self.device, dtype=torch.float32))
+            l.b.copy_(sd[l.name + ".bias"].detach().to(device=self.device, dtype=torch.float32))
         self._packed_frozen = False
 
     # -- small emit helpers -------------------------------------------------------------------
@@ -279,7 +335,8 @@ class NativeResNetFPN(object):
     def _build(self):
         self._ws_need, self._ws_ops = 0, []
         import os
-        self._wstream = 1 if os.environ.get("SSAD_OVERLAP_WGRAD", "1") == "1" else 0
+        ov = self._overlap_wgrad
+        self._wstream = 1 if (os.environ.get("SSAD_OVERLAP_WGRAD", "1") == "1" if ov is None else ov) else 0
         L = self._layers
         dev = self.device
         lib = K.lib()
@@ -325,11 +382,13 @@ class NativeResNetFPN(object):
             self._emit_backward(P)
             P.mark("sgd")
             tab = (K.SgdSegment * len(self.segments))()
-            for i, (off, n, isb) in enumerate(self.segments):
-                tab[i] = K.SgdSegment(off, n, isb)
+            for i, (off, n, isb, row_len, s2) in enumerate(self.segments):
+                tab[i] = K.SgdSegment(off, n, isb, row_len if s2 is not None else 0,
+                                      s2.data_ptr() if s2 is not None else None)
             P.add(PR.SGD_FLAT, 55, i=(len(self.segments),), f=(self.momentum, self.weight_decay),
-                  p=(self.params_flat, self.grads_flat, self.moms_flat, self.lr, tab, None),
-                  work=4.0 * 6 * self.params_flat.numel())
+                  p=(self.params_flat, self.grads_flat, self.moms_flat, self.lr, tab, self.skip_flag),
+                  work=4.0 * 6 * self.params_flat.numel(),
+                  keep=[s2 for (_, _, _, _, s2) in self.segments if s2 is not None])
         P.mark("end")
         self.ws = torch.empty(max(self._ws_need, 16), dtype=torch.uint8, device=dev)
         for idx, slot in self._ws_ops:
@@ -487,17 +546,11 @@ class NativeResNetFPN(object):
                 # the block below (later in the forward order) produced dy with this block's
                 # ReluGradient mask already applied in its GEMM epilogue: no elementwise pass
                 dz = dy
-                rows = self._t(N, cout)                      # plane sums, on the auxiliary stream
-                self._aux(P)
-                P.add(PR.RELU_GRAD_ROWSUM, 51, i=(N, cout, h * w), p=(None, dz, None, rows),
-                      work=4.0 * dz.numel(), stream=self._wstream, keep=[dz, rows])
-                self._bias_grad(P, dz, l3, rows)
             else:
-                # dz = ReluGradient(y, dy) and the plane sums for the bias gradient(s)
+                # dz = ReluGradient(y, dy).  (No bias gradients in the body: the folded AffineChannel
+                # biases are frozen values, affine_channel_op.cc.)
                 dz = self._like(y)
-                rows = self._t(N, cout)
-                self._ew(P, PR.RELU_GRAD_ROWSUM, i=(N, cout, h * w), p=(y, dy, dz, rows), nbytes=12.0 * y.numel())
-                self._bias_grad(P, dz, l3, rows)
+                self._ew(P, PR.RELU_GRAD, p=(y, dy, dz), l=(y.numel(),), nbytes=12.0 * y.numel())
             self._wgrad1(P, y2, dz, l3)
             dz2 = self._like(y2)
             self._gemm(P, l3.w.view(cout, cmid), cmid, dz, dz2, cout, cmid, mask=y2)
@@ -505,11 +558,9 @@ class NativeResNetFPN(object):
             dz1 = self._like(y1)
             self._conv3(P, [(dz2, dz1, y1, l2.pd, None)], cmid, cmid, K.CONV_MASK_AUX)
             self._wgrad1(P, xs, dz1, l1)
-            self._bias_grad(P, dz1, l1)
             first_trainable = (stage == 3 and j == 0)
             if proj:
                 lp = L[pre + ".proj"]
-                self._bias_grad(P, dz, lp, rows)
                 self._wgrad1(P, xs, dz, lp)
                 if not first_trainable:
                     dxs = self._like(xs)
@@ -572,6 +623,23 @@ class NativeResNetFPN(object):
     def broadcast_params(self, src=0):
         self.dp.broadcast([self.params_flat, self.moms_flat], src=src)
 
+    SCALE_MOMENTUM = True             # cfg.SOLVER.SCALE_MOMENTUM (config.py:634)
+    SCALE_MOMENTUM_THRESHOLD = 1.1    # config.py:638
+
+    def update_lr(self, new_lr):
+        """UpdateWorkspaceLr + _CorrectMomentum (detector.py:594-648) for the backbone's flat
+        buffers: same rule as DistillHeads.update_lr."""
+        cur_lr = float(self.lr.item())
+        new_lr = float(np.float32(new_lr))
+        if cur_lr == new_lr or not self.train:
+            return new_lr
+        eps = 1e-10
+        ratio = max(new_lr / max(cur_lr, eps), cur_lr / max(new_lr, eps))
+        self.lr.fill_(new_lr)
+        if self.SCALE_MOMENTUM and cur_lr > 1e-7 and ratio > self.SCALE_MOMENTUM_THRESHOLD:
+            K.scale_(self.moms_flat, new_lr / cur_lr)
+        return new_lr
+
 
 class NativeDistillModel(object):
     """One iteration of the whole detector on one GPU with native backbones: teacher forward
@@ -580,17 +648,28 @@ class NativeDistillModel(object):
     of this repo's kernels, enqueued by ssad_program_run."""
 
     def __init__(self, heads, student_arch="r50", teacher_arch="r101", N=16, image_hw=(640, 896), device="cuda",
-                 process_group=None, world_size=1, lr=1e-5, momentum=0.9, weight_decay=1e-4, two_streams=True):
+                 process_group=None, world_size=1, lr=None, momentum=0.9, weight_decay=1e-4, two_streams=None,
+                 overlap_wgrad=None, student_src=None, teacher_src=None, student_scales=None):
+        """lr: None = the subnets' learning rate (one schedule for the whole detector,
+        optimizer.py:95-130).  two_streams / overlap_wgrad: None = environment
+        (SSAD_NATIVE_TWO_STREAMS / SSAD_OVERLAP_WGRAD, default on).  *_src: initial weights
+        (NativeResNetFPN._alloc_params), student_scales: the folded AffineChannel scales."""
+        import os
         self.heads = heads
         self.has_teacher = teacher_arch not in (None, "none")
         assert self.has_teacher == bool(getattr(heads, "distill", True))
-        self.student = NativeResNetFPN(student_arch, N, image_hw, device, train=True, lr=lr, momentum=momentum,
-                                       weight_decay=weight_decay, process_group=process_group,
-                                       world_size=world_size)
-        self.teacher = NativeResNetFPN(teacher_arch, N, image_hw, device, train=False) if self.has_teacher else None
+        lr = float(heads.lr.item()) if lr is None else lr
+        self.f16 = bool(getattr(heads, "F16", False))
+        self.student = NativeResNetFPN(student_arch, N, image_hw, device, train=True, src=student_src, lr=lr,
+                                       momentum=momentum, weight_decay=weight_decay, process_group=process_group,
+                                       world_size=world_size, affine_scales=student_scales,
+                                       skip_flag=heads.ls_counters if self.f16 else None,
+                                       overlap_wgrad=overlap_wgrad)
+        self.teacher = NativeResNetFPN(teacher_arch, N, image_hw, device, train=False,
+                                       src=teacher_src) if self.has_teacher else None
         self.student.broadcast_params()
-        import os
-        two_streams = two_streams and os.environ.get("SSAD_NATIVE_TWO_STREAMS", "1") == "1"
+        if two_streams is None:
+            two_streams = os.environ.get("SSAD_NATIVE_TWO_STREAMS", "1") == "1"
         self.side = torch.cuda.Stream() if (two_streams and self.has_teacher) else None
         # gradient w.r.t. an FPN level = cls-subnet part + bbox-subnet part
         Q = self.sum_prog = PR.Program()
@@ -599,7 +678,19 @@ class NativeDistillModel(object):
             ptrs = (C.c_void_p * 2)(a.data_ptr(), b.data_ptr())
             Q.add(PR.SUM_N, 51, i=(2,), l=(d.numel(),), p=(ptrs, d), work=12.0 * d.numel(), keep=[a, b, d])
         Q.build()
+        if self.f16:
+            # mixed precision: the backbone's reduced gradients join the subnets' finiteness check
+            # (an overflowing step must drop BOTH updates; the flag is cleared after both)
+            Q = self.check_prog = PR.Program()
+            n = self.student.grads_flat.numel()
+            Q.add(PR.CHECK_FINITE, 38, l=(n,), p=(self.student.grads_flat, heads.ls_counters), work=4.0 * n)
+            Q.build()
         self._timing = None
+
+    def update_lr(self, new_lr):
+        """One learning-rate schedule for subnets and backbone (detector.py:594-648)."""
+        self.heads.update_lr(new_lr)
+        return self.student.update_lr(new_lr)
 
     @property
     def timing(self):
@@ -617,7 +708,10 @@ class NativeDistillModel(object):
                 "bias / shortcut / ReLU; 3x3: Winograd engine; stem: im2col + GEMM + fused bias/ReLU/pool; "
                 "no torch operator in the step)")
 
-    def step(self, images, labels, bbox_targets, fg_num):
+    def step(self, images, labels, bbox_targets, fg_num, update=True):
+        """One iteration.  update=False stops after the gradient exchange (every parameter
+        gradient is then readable: the SGD launch overwrites the gradient buffers with the
+        applied update, as MomentumSGDUpdate does, momentum_sgd_op_gpu.cu:22-38)."""
         h, st, te = self.heads, self.student, self.teacher
         h.pack_student()
         st.pack()
@@ -640,6 +734,19 @@ class NativeDistillModel(object):
         h.backward()
         self.sum_prog.run(timing=self._timing)
         st.backward()
-        h.sgd_step()
-        st.sgd_step()
+        if not update:
+            h.wait_gradients()
+            st.dp.wait()
+            return h.losses
+        if self.f16:
+            h.wait_gradients()
+            st.dp.wait()
+            h.prog.run("sgd", "sgd_update", timing=self._timing)          # subnet gradients finite?
+            self.check_prog.run(timing=self._timing)                       # backbone gradients finite?
+            h.prog.run("sgd_update", "ls_update", timing=self._timing)    # both updates honour the flag
+            st.sgd_step()
+            h.prog.run("ls_update", "end", timing=self._timing)           # scale moves, flag cleared
+        else:
+            h.sgd_step()
+            st.sgd_step()
         return h.losses

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(kThreads) void sgd_flat_kernel(
     const long long i = sg.offset + k;
     const float wi = w[i];
     float gi = g[i];
+    if (sg.row_scale) gi *= sg.row_scale[k / sg.row_len];
     gi = sg.is_bias ? gi * 2.0f : gi + wd * wi;
     const float mi = lr * gi + mu * m[i];
     m[i] = mi;
@@ -364,9 +365,10 @@ int ssad_momentum_sgd_flat(float* w, float* g, float* m, const float* lr, float 
     for (int i = 0; i < cnt; ++i) {
       t.seg[i] = segments_host[base + i];
       if (t.seg[i].n < 0 || t.seg[i].offset < 0) return SSAD_E_BADARG;
+      if (t.seg[i].row_scale && t.seg[i].row_len <= 0) return SSAD_E_BADARG;
       nmax = t.seg[i].n > nmax ? t.seg[i].n : nmax;
     }
-    for (int i = cnt; i < SSAD_MAX_SGD_SEGMENTS; ++i) t.seg[i] = ssad_sgd_segment{0, 0, 0};
+    for (int i = cnt; i < SSAD_MAX_SGD_SEGMENTS; ++i) t.seg[i] = ssad_sgd_segment{0, 0, 0, 0, nullptr};
     if (nmax == 0) continue;
     int64_t bx = (nmax + kThreads - 1) / kThreads;
     if (bx > 512) bx = 512;

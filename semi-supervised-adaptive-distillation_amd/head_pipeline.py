@@ -95,7 +95,7 @@ class DistillHeads(object):
     def __init__(self, cfg=None, N=2, shapes=synth.LEVEL_SHAPES_600, device="cuda",
                  student_init=None, teacher_init=None, teacher_bbox_tower=True,
                  lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, world_size=1,
-                 distill=True):
+                 distill=True, overlap_wgrad=None):
         self.cfg = cfg or HeadConfig()
         self.N, self.shapes, self.device = N, list(shapes), device
         self.distill = bool(distill)
@@ -124,6 +124,7 @@ class DistillHeads(object):
         self.timing = None                 # program.Timing while bench.py measures
         self.t_packed = None
         self._teacher_packed = False
+        self._overlap_wgrad = overlap_wgrad      # None: environment (SSAD_OVERLAP_WGRAD, default on)
         self._alloc_buffers()
         self._build_programs()
 
@@ -258,7 +259,8 @@ class DistillHeads(object):
     def _build_programs(self):
         import os
         # filter gradients on an auxiliary stream beside the data-gradient chain (program.py FORK / JOIN)
-        self._wstream = 1 if os.environ.get("SSAD_OVERLAP_WGRAD", "1") == "1" else 0
+        ov = self._overlap_wgrad
+        self._wstream = 1 if (os.environ.get("SSAD_OVERLAP_WGRAD", "1") == "1" if ov is None else ov) else 0
         self._wgrad_ops, self._wgrad_ws_need = [], 0
         self._in_slots = []          # (table, index, which): entries that read the bound inputs
         # filters (the teacher's are frozen: packed by a program of their own, run when they change)
@@ -461,10 +463,13 @@ class DistillHeads(object):
         specs = self.params.specs
         tab = (K.SgdSegment * len(specs))()
         for k, (name, shape, is_bias, _) in enumerate(specs):
-            tab[k] = K.SgdSegment(self.params.offsets[name], int(np.prod(shape)), int(is_bias))
+            tab[k] = K.SgdSegment(self.params.offsets[name], int(np.prod(shape)), int(is_bias), 0, None)
+        if "sgd_update" not in P.marks:
+            P.mark("sgd_update")            # fp32: nothing precedes the update ("sgd" == "sgd_update")
         P.add(PR.SGD_FLAT, 11, i=(len(specs),), f=(self.momentum, self.weight_decay),
               p=(self.params.flat, self.grads.flat, self.moms.flat, self.lr, tab, None),
               work=4.0 * 6 * self.params.flat.numel())
+        P.mark("ls_update")                 # fp32: nothing follows the update
 
     # -- input binding ------------------------------------------------------------------------------
     def _bind(self, student_fpn=None, teacher_fpn=None, labels=None, bbox_targets=None, fg_num=None):
@@ -809,8 +814,13 @@ class DistillHeadsF16(DistillHeads):
             P.mark("backward_late_done")
 
     def _emit_sgd(self, P):
+        # "sgd": finiteness check of the reduced gradients | "sgd_update": the update, dropped on
+        # overflow | "ls_update": the scale moves and the flag is cleared.  A model that owns more
+        # gradients than the subnets' (backbone_pipeline.NativeDistillModel) runs its own checks on
+        # the same flag between "sgd" and "sgd_update" and its own updates before "ls_update".
         n = self.grads.flat.numel()
         P.add(PR.CHECK_FINITE, 38, l=(n,), p=(self.grads.flat, self.ls_counters), work=4.0 * n)
+        P.mark("sgd_update")
         idx = len(P.ops)
         DistillHeads._emit_sgd(self, P)
         P.set_ptr(idx, 5, self.ls_counters)            # the update is skipped on overflow

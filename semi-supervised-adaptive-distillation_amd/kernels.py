@@ -53,7 +53,8 @@ class PackEntry(C.Structure):
 
 
 class SgdSegment(C.Structure):
-    _fields_ = [("offset", C.c_int64), ("n", C.c_int64), ("is_bias", C.c_int)]
+    _fields_ = [("offset", C.c_int64), ("n", C.c_int64), ("is_bias", C.c_int), ("row_len", C.c_int),
+                ("row_scale", C.c_void_p)]
 
 
 class GemmConv(C.Structure):

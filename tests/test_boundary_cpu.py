@@ -282,10 +282,10 @@ def test_backbone_graph_matches_reference_capture(capture, cfg_kw):
 
 
 def test_tuned_gemm_picks_file_is_well_formed():
-    """harness/tunableop_gfx950.csv (the per-shape rocBLAS / hipBLASLt picks bench.py loads, never
+    """tools/harness/tunableop_gfx950.csv (the per-shape rocBLAS / hipBLASLt picks bench.py loads, never
     searches): validator lines for this stack first, then one pick per GEMM key."""
     import csv
-    path = os.path.join(os.path.dirname(ssad_amd.__file__), "harness", "tunableop_gfx950.csv")
+    path = os.path.join(ROOT, "tools", "harness", "tunableop_gfx950.csv")
     rows = list(csv.reader(open(path)))
     validators = {r[1]: r[2] for r in rows if r[0] == "Validator"}
     assert {"PT_VERSION", "ROCBLAS_VERSION", "HIPBLASLT_VERSION", "GCN_ARCH_NAME"} <= set(validators)

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def fm():
     import ssad_amd  # noqa: F401
-    from ssad_amd.harness import full_model
+    from tools.harness import full_model
     return full_model
 
 

@@ -36,7 +36,9 @@ def test_program_header_symbols_are_exported():
 def test_distillation_step_program_structure():
     h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu")
     m = h.prog.marks
-    assert list(m) == ["pack", "forward", "losses", "backward", "backward_late_done", "sgd", "end"]
+    assert list(m) == ["pack", "forward", "losses", "backward", "backward_late_done", "sgd", "sgd_update",
+                       "ls_update", "end"]
+    assert m["sgd"] == m["sgd_update"] and m["ls_update"] == m["end"]      # fp32: nothing around the update
     assert _codes(h, "pack", "forward") == [PR.WINO_PACK_FILTERS]        # 10 filters x {fwd, dgrad}: 1 launch
     # 4 tower depths (teacher+student x cls+bbox in one launch each), teacher cls_pred (sigmoid),
     # student cls_pred, bbox_pred (student + teacher)

@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ssad_amd  # noqa
-from ssad_amd.harness import full_model as fm
+from tools.harness import full_model as fm
 
 
 def main():

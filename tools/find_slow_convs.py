@@ -5,7 +5,7 @@ import sys, os, time
 import torch, torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ssad_amd
-from ssad_amd.harness.full_model import ResNetFPN
+from tools.harness.full_model import ResNetFPN
 
 def t(fn, n=3):
     fn(); torch.cuda.synchronize()

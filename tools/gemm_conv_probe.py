@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     a = ap.parse_args()
     if os.environ.get("SSAD_TUNED") == "1":
-        from ssad_amd.harness import full_model
+        from tools.harness import full_model
         full_model.setup_tunableop()
     N = a.batch
     tot = [0.0] * 6

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 
 def _K():
-    from .. import kernels
+    from ssad_amd import kernels
     return kernels
 
 
@@ -479,7 +479,7 @@ class FullDistillModel(object):
                 dist.broadcast(p.data, src=0, group=self.pg)
             # flat gradient buckets in backward-completion order (FPN, res5, res4, res3):
             # few, large all-reduces, each started by the hook of its last gradient
-            from ..data_parallel import BucketedAllReduce, GradBuckets
+            from ssad_amd.data_parallel import BucketedAllReduce, GradBuckets
             st = self.student
             fpn = list(st.lat.parameters()) + list(st.out.parameters()) + \
                 list(st.p6.parameters()) + list(st.p7.parameters())

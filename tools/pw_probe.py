@@ -6,7 +6,7 @@ import torch
 sys.path.insert(0, ".")
 import ssad_amd  # noqa
 from ssad_amd import kernels as K
-from ssad_amd.harness import full_model as fm
+from tools.harness import full_model as fm
 
 
 def timeit(fn, n=20):
