@@ -57,9 +57,10 @@ def test_native_backbone_forward_backward_vs_torch():
     assert max(fpn) < 2e-5, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     # Body, free-running activations: an activation within fp32 round-off of zero takes the other
     # side of a ReLU mask than in the float64 reference, and on these small maps (res5 is 8 x 12) one
-    # flipped element moves every gradient below it by ~sqrt(1 / elements) ~ 1e-3.  Bound 3e-3 per
-    # tensor here; the mask-safe variant below holds the same tensors to 1e-4.
-    assert errs[worst] < 3e-3, (worst, errs[worst])
+    # flipped element moves every gradient below it by ~sqrt(1 / elements) ~ 1e-3 (measured 6e-4 ..
+    # 4e-3 over seeds).  Sanity bound 1e-2 per tensor here; the mask-safe variant below holds the same
+    # tensors to 1e-4.
+    assert errs[worst] < 1e-2, (worst, errs[worst])
     # SGD: weights s^2 g + wd * w (s = the folded AffineChannel scale), biases 2 g (optimizer.py:115-130)
     p0, g0 = nat.params_flat.clone(), nat.grads_flat.clone()
     nat.sgd_step()
@@ -91,6 +92,7 @@ def test_native_backbone_default_initialisation_needs_no_harness():
     nat = NativeResNetFPN("r50", 1, (128, 128), "cuda", train=True)
     assert not any(m.startswith("tools.harness") for m in sys.modules)
     assert float(nat._layers["res3.0.c3"].s2[0]) == pytest.approx(nat.INIT_C3_SCALE ** 2)
+    nat.pack()
     got = nat.forward(torch.randn(1, 3, 128, 128, device="cuda"))
     assert all(torch.isfinite(t).all() for t in got)
     # activations stay O(1) through the 16 blocks
