@@ -113,7 +113,11 @@ SSAD_API int ssad_focal_loss_backward(
  * logits yields distill_losses[l], focal_losses[l] and levels[l].out = dX =
  * d(distill)/dx + d(focal)/dx with both loss gradients = 1.0 (what the
  * reference obtains from 2 forward ops, 2 gradient ops and an autograd Sum).
- * Requires focal gamma == 2 (RetinaNet). */
+ * Requires focal gamma == 2 (RetinaNet).
+ * ONE launch: each level's sums are finished by its last-arriving workgroup (arrival counters
+ * in the workspace).  WORKSPACE CONTRACT (also ssad_pow_sum): the buffer must be ZERO-FILLED
+ * once after it is allocated (hipMemset); every launch leaves the counters zero again, so the
+ * same buffer serves any number of launches on one stream.  Do not share it between streams. */
 SSAD_API size_t ssad_cls_losses_fused_workspace_bytes(int n_levels);
 SSAD_API int ssad_cls_losses_fused(
     const ssad_distill_level* levels_host, int n_levels, const float* normalizer,
@@ -161,7 +165,9 @@ SSAD_API int ssad_select_smooth_l1_levels(
 
 SSAD_API size_t ssad_pow_sum_workspace_bytes(int n_inputs);
 
-/* out[0] = sum_j sum_i powf(inputs[j][i], power); all inputs in one launch. */
+/* out[0] = sum_j sum_i powf(inputs[j][i], power); all inputs in one launch (the sum is finished by
+ * the last-arriving workgroup: the workspace must be zero-filled once after allocation, see
+ * ssad_cls_losses_fused). */
 SSAD_API int ssad_pow_sum(
     const float* const* inputs_host, const int64_t* sizes_host, int n_inputs,
     float power, float* out, void* workspace, size_t workspace_bytes,

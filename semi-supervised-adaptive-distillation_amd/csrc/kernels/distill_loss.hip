@@ -56,6 +56,7 @@ struct LevelArgs {
   int classes;       // C
   int cgroups;       // class groups per position block (work-item granularity)
   int cper;          // classes per group
+  int group_start;   // first arrival-group counter of this level (in-launch finalize)
 };
 
 struct LaunchArgs {
@@ -172,6 +173,58 @@ __device__ __forceinline__ double block_sum(double v) {
     for (int i = 0; i < kThreads / 64; ++i) t += wsum[i];
   }
   return t;
+}
+
+// ---- in-launch finalize ------------------------------------------------------
+// The last workgroup of a level to arrive sums that level's partials in index order (the
+// order the separate finalize launch used: results are bit-identical and independent of which
+// workgroup happens to be last) -- one launch instead of two per loss.  Cross-XCD visibility
+// (per-XCD L2s are not coherent): partials are published with 8-byte agent-scope atomic stores
+// (write-through), the store is waited for, then the arrival counter is bumped with an agent-scope
+// atomic; the reducer reads the partials with agent-scope atomic loads.  Arrival is two-level
+// (groups of kTicketGroup workgroups, then one counter per level) so that no single address sees
+// thousands of same-address atomics.  Counters live in the caller's workspace, must be ZERO before
+// the first launch (the workspace contract in ssad_kernels.h) and are left zero by every launch.
+constexpr int kTicketGroup = 32;
+constexpr int kTicketStride = 16;                         // ints: one 64-byte line per group counter
+constexpr int kTicketGroups = kMaxBlocks / kTicketGroup + SSAD_MAX_LEVELS;
+constexpr size_t kTicketBytes = sizeof(unsigned) * ((size_t)kTicketGroups * kTicketStride + 64);
+
+struct Tickets {
+  unsigned* group;      // [kTicketGroups][kTicketStride]
+  unsigned* level;      // [SSAD_MAX_LEVELS] (padded)
+};
+__host__ __device__ inline Tickets tickets_at(void* base) {
+  Tickets t;
+  t.group = (unsigned*)base;
+  t.level = t.group + (size_t)kTicketGroups * kTicketStride;
+  return t;
+}
+
+__device__ __forceinline__ void publish(double* slot, double v) {
+  __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double peek(const double* slot) {
+  return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Thread 0 only, after its publish() calls.  lb = workgroup index within the level, nb = the
+// level's workgroup count, g0 = index of the level's first group counter.  True for exactly one
+// workgroup of the level: the last to arrive.
+__device__ __forceinline__ bool arrive_last(const Tickets& t, int level, int lb, int nb, int g0) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the published partials have left
+  const int g = lb / kTicketGroup;
+  const int gsize = (nb - g * kTicketGroup) < kTicketGroup ? (nb - g * kTicketGroup) : kTicketGroup;
+  unsigned* gc = t.group + (size_t)(g0 + g) * kTicketStride;
+  if (__hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)gsize - 1u)
+    return false;
+  __hip_atomic_store(gc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int ngroups = (nb + kTicketGroup - 1) / kTicketGroup;
+  if (__hip_atomic_fetch_add(t.level + level, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+      (unsigned)ngroups - 1u)
+    return false;
+  __hip_atomic_store(t.level + level, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
 }
 
 __device__ __forceinline__ int find_level(const LaunchArgs& a, int bid) {
@@ -332,6 +385,137 @@ __device__ __forceinline__ float focal_grad_elem(float x, int t, int d, float ga
   return (-c1 * zp * term1 - c2 * zn * term2) * mult;      // mult = dloss * scale
 }
 
+// ---- packed (<2 x float>) element math of the hot configuration ------------------------------
+// gamma = 2, beta = 0, fast math, 16-byte aligned planes: see the note at cls_losses_fused_kernel.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct FusedK {              // wave-uniform constants of the packed path
+  float w_pos, w_neg;        // alpha / Np, (1 - alpha) / Np          (distillation)
+  float two_np;              // gamma * Np = 2 Np  (S = -Np * ce)
+  float alpha, c12a;         // alpha, 1 - 2 alpha
+  float neg_dmult;           // -(scale / Np)        (dloss = 1)
+  float zp, zn;              // alpha_f / Nf, (1 - alpha_f) / Nf      (focal)
+  float g1c, g2c;            // -zp * scale_f, zn * scale_f
+};
+
+struct PairOut { v2f store, a, b; };
+
+// One pair of logits of one class plane.  keepf = 1/0 per position (label != ignored_label),
+// notign = 1/0 (label != -1: the focal loss's own ignore value), tm1 = label - 1 (foreground class
+// index); d = class index of the plane.
+// WHAT: 0 = distillation loss only (r.a), 1 = distillation gradient only (r.store), 2 = everything.
+template <int WHAT>
+__device__ __forceinline__ PairOut fused_pair(v2f x, v2f q, v2f keepf, v2f notign, int tm1x, int tm1y,
+                                              int d, const FusedK& K) {
+  constexpr float kL2E = 1.4426950408889634f, kLN2 = 0.6931471805599453f;
+  constexpr float kNegLogFltMin = 87.33654475f;
+  v2f e, l2, inv, xpos;
+  e.x = __builtin_amdgcn_exp2f(fabsf(x.x) * -kL2E);
+  e.y = __builtin_amdgcn_exp2f(fabsf(x.y) * -kL2E);
+  const v2f onepe = e + 1.0f;
+  l2.x = __builtin_amdgcn_logf(onepe.x);  l2.y = __builtin_amdgcn_logf(onepe.y);
+  inv.x = __builtin_amdgcn_rcpf(onepe.x); inv.y = __builtin_amdgcn_rcpf(onepe.y);
+  const v2f sp = l2 * kLN2;                       // log(1 + e^-|x|)
+  xpos.x = fmaxf(x.x, 0.0f); xpos.y = fmaxf(x.y, 0.0f);
+  const v2f B = sp + xpos;                        // -log(1 - p)
+  v2f A = sp + (xpos - x);                        // -log p  (xpos - x = max(-x, 0) exactly)
+  A.x = fminf(A.x, kNegLogFltMin); A.y = fminf(A.y, kNegLogFltMin);   // log(max(FLT_MIN, p))
+  const v2f einv = e * inv;
+  v2f p;
+  p.x = x.x >= 0.0f ? inv.x : einv.x;
+  p.y = x.y >= 0.0f ? inv.y : einv.y;
+  const v2f omq = 1.0f - q;
+  const v2f qq = q * omq;                         // > 0 exactly when q is in (0, 1)
+  v2f mult;                                       // NaN for a teacher probability outside (0, 1):
+  mult.x = qq.x > 0.0f ? keepf.x : __builtin_nanf("");   // 0 * log 0 of .cu:58-59, also when the
+  mult.y = qq.y > 0.0f ? keepf.y : __builtin_nanf("");   // anchor is ignored
+  const v2f dl = B - x * q;
+  v2f edl;
+  edl.x = __builtin_amdgcn_exp2f(dl.x * -kL2E);
+  edl.y = __builtin_amdgcn_exp2f(dl.y * -kL2E);
+  const v2f at = 1.0f - edl;
+  const v2f pg = at * at;
+  const v2f ceN = (q * A) * K.w_pos + (omq * B) * K.w_neg;            // -ce / Np
+  PairOut r;
+  r.a = (pg * ceN) * mult;
+  const v2f diff = q - p;
+  const v2f t1 = ((diff * at) * edl) * (ceN * K.two_np);
+  const v2f t2 = pg * (diff * K.alpha - (omq * p) * K.c12a);
+  const v2f gd = (t1 + t2) * (mult * K.neg_dmult);
+  if constexpr (WHAT != 2) {
+    r.b = v2f{0.0f, 0.0f};
+    r.store = gd;
+    return r;
+  }
+  // SigmoidFocalLoss (sigmoid_focal_loss_op.cu:33-66, 74-105), gamma = 2
+  const v2f omp = 1.0f - p;
+  const v2f af = omp * omp, bf = p * p;
+  const v2f l1 = (af * A) * K.zp;
+  const v2f nz = notign * K.zn, ng = notign * K.g2c;
+  const v2f l2f = (bf * B) * nz;
+  const v2f g1 = (af * (omp + (p * A) * 2.0f)) * K.g1c;
+  const v2f g2 = (bf * ((B * omp) * 2.0f + p)) * ng;
+  const bool cx = tm1x == d, cy = tm1y == d;
+  r.b.x = cx ? l1.x : l2f.x;
+  r.b.y = cy ? l1.y : l2f.y;
+  v2f fg;
+  fg.x = cx ? g1.x : g2.x;
+  fg.y = cy ? g1.y : g2.y;
+  r.store = gd + fg;
+  return r;
+}
+
+// The packed traversal: work decomposition of traverse() for the 16-byte aligned case, pairs
+// of positions, four class planes in flight per thread.
+template <int WHAT>
+__device__ __forceinline__ Acc2 traverse_packed(const LevelArgs& L, int lb, const FusedK& K, int ignored) {
+  const int pl = 1 << L.pl_shift, cl = kThreads >> L.pl_shift;
+  const int pi = threadIdx.x & (pl - 1), ci = threadIdx.x >> L.pl_shift;
+  const int hw = L.hw;
+  v2f sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
+  for (int item = lb; item < L.items; item += L.blocks) {
+    const int sc = item / L.cgroups;
+    const int cg = item - sc * L.cgroups;
+    const int slab = sc / L.chunks;
+    const int chunk = sc - slab * L.chunks;
+    const int c_begin = cg * L.cper + ci;
+    const int c_end = (cg + 1) * L.cper < L.classes ? (cg + 1) * L.cper : L.classes;
+    const int pos = (chunk * pl + pi) * 4;
+    if (pos >= hw) continue;
+    const float* __restrict__ xs = L.x + (size_t)slab * L.slab + pos;
+    const float* __restrict__ qs = L.q + (size_t)slab * L.slab + pos;
+    float* __restrict__ ds = WHAT != 0 ? L.out + (size_t)slab * L.slab + pos : nullptr;
+    const int4 gv = *reinterpret_cast<const int4*>(L.g + (size_t)slab * hw + pos);
+    // everything that depends only on the label, once per 4 positions
+    const v2f k01 = {gv.x != ignored ? 1.0f : 0.0f, gv.y != ignored ? 1.0f : 0.0f};
+    const v2f k23 = {gv.z != ignored ? 1.0f : 0.0f, gv.w != ignored ? 1.0f : 0.0f};
+    const v2f n01 = {gv.x != -1 ? 1.0f : 0.0f, gv.y != -1 ? 1.0f : 0.0f};
+    const v2f n23 = {gv.z != -1 ? 1.0f : 0.0f, gv.w != -1 ? 1.0f : 0.0f};
+    const int t0 = gv.x - 1, t1 = gv.y - 1, t2 = gv.z - 1, t3 = gv.w - 1;
+    auto plane = [&](int c, const float4& xv, const float4& qv) {
+      const PairOut r0 = fused_pair<WHAT>(v2f{xv.x, xv.y}, v2f{qv.x, qv.y}, k01, n01, t0, t1, c, K);
+      const PairOut r1 = fused_pair<WHAT>(v2f{xv.z, xv.w}, v2f{qv.z, qv.w}, k23, n23, t2, t3, c, K);
+      if constexpr (WHAT != 1) sa += r0.a + r1.a;
+      if constexpr (WHAT == 2) sb += r0.b + r1.b;
+      if constexpr (WHAT != 0)
+        st4(ds + c * hw, make_float4(r0.store.x, r0.store.y, r1.store.x, r1.store.y));
+    };
+    int c = c_begin;
+    for (; c + 3 * cl < c_end; c += 4 * cl) {
+      float4 xv[4], qv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xv[u] = ld4(xs + (c + u * cl) * hw);
+        qv[u] = ld4(qs + (c + u * cl) * hw);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) plane(c + u * cl, xv[u], qv[u]);
+    }
+    for (; c < c_end; c += cl) plane(c, ld4(xs + c * hw), ld4(qs + c * hw));
+  }
+  return Acc2{sa.x + sa.y, sb.x + sb.y};
+}
+
 template <bool FAST, int GAMMA_MODE, bool BETA0>
 __global__ __launch_bounds__(kThreads) void distill_fwd_kernel(
     const LaunchArgs args, const float* __restrict__ normalizer,
@@ -343,9 +527,15 @@ __global__ __launch_bounds__(kThreads) void distill_fwd_kernel(
   const float w_neg = (1.0f - args.alpha) / np;
   const float gamma = args.gamma, beta = args.beta;
   const int ignored = args.ignored;
-  const Acc2 acc = traverse<0, true>(L, lb, [&](float x, float q, int t, int) {
-    return loss_elem<FAST, GAMMA_MODE, BETA0>(x, q, t != ignored, gamma, beta, w_pos, w_neg);
-  });
+  Acc2 acc;
+  if (FAST && GAMMA_MODE == 2 && BETA0 && L.vec4) {
+    const FusedK K{w_pos, w_neg, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    acc = traverse_packed<0>(L, lb, K, ignored);
+  } else {
+    acc = traverse<0, true>(L, lb, [&](float x, float q, int t, int) {
+      return loss_elem<FAST, GAMMA_MODE, BETA0>(x, q, t != ignored, gamma, beta, w_pos, w_neg);
+    });
+  }
   const double t = block_sum((double)acc.a);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
@@ -374,6 +564,12 @@ __global__ __launch_bounds__(kThreads) void distill_bwd_kernel(
   const float mult = dloss[(size_t)level * dloss_stride] * args.scale / np;
   const float gamma = args.gamma, alpha = args.alpha, beta = args.beta;
   const int ignored = args.ignored;
+  if (FAST && GAMMA_MODE == 2 && BETA0 && L.vec4) {
+    const FusedK K{alpha / np, (1.0f - alpha) / np, 2.0f * np, alpha, 1.0f - 2.0f * alpha, -mult,
+                   0.0f, 0.0f, 0.0f, 0.0f};
+    traverse_packed<1>(L, lb, K, ignored);
+    return;
+  }
   traverse<1, true>(L, lb, [&](float x, float q, int t, int) {
     return grad_elem<FAST, GAMMA_MODE, BETA0>(x, q, t != ignored, gamma, alpha, beta, mult);
   });
@@ -417,11 +613,23 @@ __global__ __launch_bounds__(kThreads) void focal_bwd_kernel(
 // distillation loss sum, focal loss sum and dX = d(distill)/dx + d(focal)/dx
 // (the reference runs two forward kernels, two gradient kernels, two Scale
 // passes and an autograd Sum over the same N x 720 x H x W tensor).
+//
+// Round 3: the pass was VALU-bound, not HBM-bound -- 78 vector instructions + 4 transcendentals
+// per logit (ISA count) = 0.32 ms of issue time for 137.5 M logits against 0.26 ms of streaming.
+// The hot path (gamma = 2 for both losses, beta = 0, fast math, 16-byte aligned planes) now works
+// on PAIRS of positions in <2 x float> so that adds / multiplies / fmas issue as v_pk_*_f32 (two
+// results per lane per instruction), shares every sub-expression of the four formulas
+// (S = -Np * ce; -log p and -log(1-p) kept positive; the correctly rounded division behind
+// __frcp_rn replaced by v_rcp_f32; raw v_exp_f32 / v_log_f32 without denormal range fix-ups: their
+// arguments are in [1, 2] resp. <= 0), hoists everything that depends only on the label out of
+// the class loop, and reduces both sums in the last-arriving workgroup (no finalize launch).
 template <bool FAST, int GAMMA_MODE, bool BETA0>
 __global__ __launch_bounds__(kThreads) void cls_losses_fused_kernel(
     const LaunchArgs args, const FocalScalars fs, const float* __restrict__ normalizer,
-    const float* __restrict__ fg_num, double* __restrict__ partials, int focal_offset) {
-  const LevelArgs& L = args.lv[find_level(args, blockIdx.x)];
+    const float* __restrict__ fg_num, double* __restrict__ partials, int focal_offset,
+    float* __restrict__ out_a, float* __restrict__ out_b) {
+  const int level = find_level(args, blockIdx.x);
+  const LevelArgs& L = args.lv[level];
   const int lb = blockIdx.x - L.block_start;
   const float np = fmaxf(normalizer[0], 1.0f);
   const float w_pos = args.alpha / np, w_neg = (1.0f - args.alpha) / np;
@@ -431,40 +639,47 @@ __global__ __launch_bounds__(kThreads) void cls_losses_fused_kernel(
   const float gamma = args.gamma, alpha = args.alpha, beta = args.beta, fgamma = fs.gamma;
   const float f_mult = fs.scale;
   const int ignored = args.ignored;
-  const Acc2 acc = traverse<2, true>(L, lb, [&](float x, float q, int t, int d) {
-    const bool keep = t != ignored;
-    Fused r;
-    r.a = loss_elem<FAST, GAMMA_MODE, BETA0>(x, q, keep, gamma, beta, w_pos, w_neg);
-    r.b = focal_loss_elem<FAST, 2>(x, t, d, fgamma, zp, zn);
-    r.store = grad_elem<FAST, GAMMA_MODE, BETA0>(x, q, keep, gamma, alpha, beta, d_mult) +
-              focal_grad_elem<FAST, 2>(x, t, d, fgamma, zp, zn, f_mult);
-    return r;
-  });
-  const double ta = block_sum((double)acc.a);
-  __syncthreads();
-  const double tb = block_sum((double)acc.b);
-  if (threadIdx.x == 0) {
-    partials[blockIdx.x] = ta;
-    partials[focal_offset + blockIdx.x] = tb;
+  Acc2 acc{0.0f, 0.0f};
+  if (FAST && GAMMA_MODE == 2 && BETA0 && L.vec4) {
+    const FusedK K{w_pos, w_neg, 2.0f * np, alpha, 1.0f - 2.0f * alpha, -d_mult, zp, zn, -zp * f_mult,
+                   zn * f_mult};
+    acc = traverse_packed<2>(L, lb, K, ignored);
+  } else {
+    acc = traverse<2, true>(L, lb, [&](float x, float q, int t, int d) {
+      const bool keep = t != ignored;
+      Fused r;
+      r.a = loss_elem<FAST, GAMMA_MODE, BETA0>(x, q, keep, gamma, beta, w_pos, w_neg);
+      r.b = focal_loss_elem<FAST, 2>(x, t, d, fgamma, zp, zn);
+      r.store = grad_elem<FAST, GAMMA_MODE, BETA0>(x, q, keep, gamma, alpha, beta, d_mult) +
+                focal_grad_elem<FAST, 2>(x, t, d, fgamma, zp, zn, f_mult);
+      return r;
+    });
   }
-}
-
-// finalize for the fused kernel: level l -> out_a[l], out_b[l]
-__global__ __launch_bounds__(kThreads) void fused_finalize_kernel(
-    const LaunchArgs args, const double* __restrict__ partials, int focal_offset,
-    float* __restrict__ out_a, float* __restrict__ out_b, float scale_a, float scale_b) {
-  const LevelArgs& L = args.lv[blockIdx.x];
+  double ta = block_sum((double)acc.a);
+  __syncthreads();
+  double tb = block_sum((double)acc.b);
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    publish(partials + blockIdx.x, ta);
+    publish(partials + focal_offset + blockIdx.x, tb);
+    s_last = arrive_last(tickets_at(partials + 2 * (size_t)focal_offset), level, lb, L.blocks,
+                         L.group_start) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // this level's last workgroup: fixed-order sum of the level's partials, then the float
+  // multiply by scale (math::Scale on one element, .cu:137-138)
   double va = 0.0, vb = 0.0;
   for (int i = threadIdx.x; i < L.blocks; i += kThreads) {
-    va += partials[L.block_start + i];
-    vb += partials[focal_offset + L.block_start + i];
+    va += peek(partials + L.block_start + i);
+    vb += peek(partials + focal_offset + L.block_start + i);
   }
-  const double ta = block_sum(va);
+  ta = block_sum(va);
   __syncthreads();
-  const double tb = block_sum(vb);
+  tb = block_sum(vb);
   if (threadIdx.x == 0) {
-    out_a[blockIdx.x] = (float)ta * scale_a;
-    out_b[blockIdx.x] = (float)tb * scale_b;
+    out_a[level] = (float)ta * args.scale;
+    out_b[level] = (float)tb * fs.scale;
   }
 }
 
@@ -571,7 +786,7 @@ __device__ __forceinline__ float pow_elem(float x, float p) {
 
 template <bool FAST>
 __global__ __launch_bounds__(kThreads) void pow_sum_kernel(
-    const PowArgs args, double* __restrict__ partials) {
+    const PowArgs args, double* __restrict__ partials, float* __restrict__ out, int accumulate) {
   int j = 0;
 #pragma unroll
   for (int i = 1; i < SSAD_MAX_POWSUM_INPUTS; ++i)
@@ -602,15 +817,18 @@ __global__ __launch_bounds__(kThreads) void pow_sum_kernel(
   for (long long i = n4 * 4 + (long long)lb * kThreads + threadIdx.x; i < n; i += (long long)nb * kThreads)
     acc += pow_elem<FAST>(x[i], p);
   dacc += (double)acc;
-  const double t = block_sum(dacc);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
-}
-
-__global__ __launch_bounds__(kThreads) void pow_sum_finalize_kernel(
-    const double* __restrict__ partials, int n, float* __restrict__ out, int accumulate) {
+  double t = block_sum(dacc);
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    publish(partials + blockIdx.x, t);
+    s_last = arrive_last(tickets_at(partials + kMaxBlocks), 0, blockIdx.x, gridDim.x, 0) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // last workgroup to arrive: the partials in index order (deterministic), one launch
   double v = 0.0;
-  for (int i = threadIdx.x; i < n; i += kThreads) v += partials[i];
-  const double t = block_sum(v);
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += kThreads) v += peek(partials + i);
+  t = block_sum(v);
   if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0f) + (float)t;
 }
 
@@ -689,6 +907,8 @@ int build_args(const ssad_distill_level* lv, int n_levels,
     if (b > L.items && L.items > 0) b = L.items;
     L.block_start = start;
     L.blocks = (int)b;
+    L.group_start = l == 0 ? 0 : a.lv[l - 1].group_start +
+                                  (a.lv[l - 1].blocks + kTicketGroup - 1) / kTicketGroup;
     start += (int)b;
   }
   *total_blocks = start;
@@ -819,7 +1039,7 @@ int ssad_focal_loss_backward(const ssad_distill_level* levels_host, int n_levels
 
 size_t ssad_cls_losses_fused_workspace_bytes(int n_levels) {
   (void)n_levels;
-  return 2 * sizeof(double) * kMaxBlocks;
+  return 2 * sizeof(double) * kMaxBlocks + kTicketBytes;
 }
 
 int ssad_cls_losses_fused(const ssad_distill_level* levels_host, int n_levels,
@@ -835,17 +1055,15 @@ int ssad_cls_losses_fused(const ssad_distill_level* levels_host, int n_levels,
   int blocks = 0;
   const int rc = build_args(levels_host, n_levels, distill_host, &a, &blocks, true);
   if (rc) return rc;
-  if (!workspace || workspace_bytes < 2 * sizeof(double) * kMaxBlocks) return SSAD_E_WORKSPACE;
+  if (!workspace || workspace_bytes < ssad_cls_losses_fused_workspace_bytes(n_levels)) return SSAD_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   double* partials = (double*)workspace;
   const FocalScalars fs{focal_host->gamma, focal_host->alpha, focal_host->scale};
   const bool fast = !accurate_math();
   const int gm = gamma_mode(a.gamma);
+  // one launch: the sums are finished by each level's last-arriving workgroup
   LAUNCH_BY_MODE(cls_losses_fused_kernel, fast, a.beta == 0.0f, gm, dim3(blocks), dim3(kThreads),
-                 0, s, a, fs, normalizer, fg_num, partials, kMaxBlocks);
-  hipLaunchKernelGGL(fused_finalize_kernel, dim3(n_levels), dim3(kThreads), 0, s, a,
-                     (const double*)partials, kMaxBlocks, distill_losses, focal_losses, a.scale,
-                     fs.scale);
+                 0, s, a, fs, normalizer, fg_num, partials, kMaxBlocks, distill_losses, focal_losses);
   return (int)hipGetLastError();
 }
 
@@ -932,7 +1150,7 @@ int ssad_select_smooth_l1_backward(const float* Y_hat, const float* Y, const flo
 
 size_t ssad_pow_sum_workspace_bytes(int n_inputs) {
   (void)n_inputs;
-  return sizeof(double) * kMaxBlocks;
+  return sizeof(double) * kMaxBlocks + kTicketBytes;
 }
 
 int ssad_pow_sum(
@@ -940,7 +1158,7 @@ int ssad_pow_sum(
     float power, float* out, void* workspace, size_t workspace_bytes,
     ssad_stream_t stream) {
   if (n_inputs < 1 || !out) return SSAD_E_BADARG;
-  if (!workspace || workspace_bytes < sizeof(double) * kMaxBlocks) return SSAD_E_WORKSPACE;
+  if (!workspace || workspace_bytes < ssad_pow_sum_workspace_bytes(n_inputs)) return SSAD_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   double* partials = (double*)workspace;
   const bool fast = !accurate_math();
@@ -972,10 +1190,11 @@ int ssad_pow_sum(
     for (int j = cnt; j < SSAD_MAX_POWSUM_INPUTS; ++j) {
       a.ptr[j] = nullptr; a.n[j] = 0; a.block_start[j] = start; a.blocks[j] = 0;
     }
-    if (fast) hipLaunchKernelGGL(pow_sum_kernel<true>, dim3(start), dim3(kThreads), 0, s, a, partials);
-    else hipLaunchKernelGGL(pow_sum_kernel<false>, dim3(start), dim3(kThreads), 0, s, a, partials);
-    hipLaunchKernelGGL(pow_sum_finalize_kernel, dim3(1), dim3(kThreads), 0, s,
-                       (const double*)partials, start, out, g0 > 0 ? 1 : 0);
+    const int accumulate = g0 > 0 ? 1 : 0;
+    if (fast) hipLaunchKernelGGL(pow_sum_kernel<true>, dim3(start), dim3(kThreads), 0, s, a, partials, out,
+                                 accumulate);
+    else hipLaunchKernelGGL(pow_sum_kernel<false>, dim3(start), dim3(kThreads), 0, s, a, partials, out,
+                            accumulate);
   }
   return (int)hipGetLastError();
 }

@@ -17,7 +17,12 @@ bool PowSumOp<float, HIPContext>::RunOnDevice() {
     sizes[i] = in.size();
   }
   const size_t ws_bytes = ssad_pow_sum_workspace_bytes(n);
-  _buff.Resize((TIndex)ws_bytes);
+  if ((size_t)_buff.size() != ws_bytes) {
+    // the launcher keeps its arrival counters in the scratch: zero once per allocation
+    _buff.Resize((TIndex)ws_bytes);
+    CAFFE_ENFORCE_EQ((int)hipMemsetAsync(_buff.mutable_data<uint8_t>(), 0, ws_bytes, context_.hip_stream()), 0,
+                     "PowSum scratch memset failed");
+  }
   const int rc = ssad_pow_sum(ptrs.data(), sizes.data(), n, power, res->mutable_data<float>(),
                               _buff.mutable_data<uint8_t>(), ws_bytes, context_.hip_stream());
   CAFFE_ENFORCE_EQ(rc, 0, "PowSum launch failed");

@@ -375,7 +375,7 @@ class DistillHeads(object):
             ptrs = (C.c_void_p * nlev)(*[t.data_ptr() for t in self.t_prob])
             sizes = (C.c_int64 * nlev)(*[t.numel() for t in self.t_prob])
             nb = L.ssad_pow_sum_workspace_bytes(nlev)
-            ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            ws = torch.zeros(nb, dtype=torch.uint8, device=self.device)     # arrival counters: zero once
             P.add(PR.POW_SUM, 8, i=(nlev,), f=(cfg.logits_power,), l=(nb,), p=(ptrs, sizes, self.normalizer, ws),
                   work=4.0 * n_logits, keep=list(self.t_prob))
         DP = K.DistillParams(**{k: v for k, v in self._distill_kw().items()})
@@ -385,7 +385,7 @@ class DistillHeads(object):
                 raise K.KernelError("the fused distillation + focal pass specialises focal gamma == 2")
             arr = self._cls_table(self.d_cls_logits)
             nb = L.ssad_cls_losses_fused_workspace_bytes(nlev)
-            ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            ws = torch.zeros(nb, dtype=torch.uint8, device=self.device)     # arrival counters: zero once
             P.add(PR.CLS_LOSSES_FUSED, 9, i=(nlev,), l=(nb,),
                   p=(arr, self.normalizer, self.fg_num, DP, FP, self.losses, self.focal_losses, ws),
                   work=12.0 * n_logits + 4.0 * n_labels)

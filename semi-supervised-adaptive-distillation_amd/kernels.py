@@ -208,7 +208,9 @@ def _workspace(nbytes, tag):
     key = (dev, torch.cuda.current_stream().cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device="cuda")
+        # zero-filled: PowSum / the fused classification losses keep their arrival counters here
+        # (ssad_kernels.h: zero once after allocation, every launch leaves them zero)
+        buf = torch.zeros(max(int(nbytes), 1), dtype=torch.uint8, device="cuda")
         _ws_cache[key] = buf
     return buf
 
