@@ -41,8 +41,8 @@ KLASS = {
             bound="mfma", wino=True),
     6: dict(name="cls_pred filter gradient (wino_wgrad_kernel + reduce + bias grad)", bound="mfma", wino=True),
     7: dict(name="bbox_pred filter gradient (wino_wgrad_kernel + reduce + bias grad)", bound="mfma", wino=True),
-    8: dict(name="PowSum (pow_sum_kernel + finalize)", bound="hbm"),
-    9: dict(name="fused classification losses fwd+bwd (cls_losses_fused_kernel + finalize)", bound="hbm"),
+    8: dict(name="PowSum (pow_sum_kernel, one launch: sum finished by the last-arriving workgroup)", bound="hbm"),
+    9: dict(name="fused classification losses fwd+bwd (cls_losses_fused_kernel, one launch)", bound="hbm"),
     10: dict(name="SelectSmoothL1Loss fwd+bwd (4 launches)", bound="hbm"),
     11: dict(name="momentum SGD, whole flat buffer (sgd_flat_kernel)", bound="hbm"),
     12: dict(name="SigmoidAdaptiveDistillLoss fwd (distill_fwd_kernel + finalize)", bound="hbm"),
