@@ -585,6 +585,60 @@ SSAD_API int ssad_conv3x3_wgrad_f16_levels_dyn(const ssad_f16_wgrad_level* level
                                                void* workspace, size_t workspace_bytes,
                                                ssad_stream_t stream);
 
+/* ---- the backbones in the same precision (BASELINE config 5; gemm_f16.hip, grouped_f16.hip) ---- */
+/* Pointwise (1x1) convolution on channel-blocked fp16 tensors, fp32 accumulation:
+ *   y[n][m][oy][ox] = act( sum_c W[m][c] x[n][c][stride oy][stride ox] + bias[m] + residual )
+ * x [N][ceil(C/8)][Hi][Wi][8], y [N][M/8][Ho][Wo][8] (M % 8 == 0); w = packed_fwd of
+ * ssad_pw_f16_pack_filter.  residual (or NULL): blocked fp16 like y -- or, with
+ * SSAD_PW_F16_RES_UPSAMPLE2, the [Ho/2][Wo/2] map whose 2x nearest upsampling is added (FPN's
+ * top-down Sum, FPN.py:283-306).  SSAD_CONV_RELU: ReLU.  mask (or NULL): blocked fp16 like y,
+ * y = mask > 0 ? y : 0 (ReluGradient of the layer below, for the data gradient -- the same call
+ * with packed_dgrad, C and M exchanged).  Hi / Wi = 0: Ho * stride, Wo * stride.
+ * Reference: CudnnConvOp<float16>, fp32 math (conv_op_cudnn.cc:631-636), algorithm
+ * conv_op_impl.h:126-173. */
+#define SSAD_PW_F16_RES_UPSAMPLE2 32
+typedef struct ssad_pw_f16 {
+  const void* x;
+  const void* w;
+  const float* bias;
+  const void* residual;
+  const void* mask;
+  void* y;
+  int N, C, M, Ho, Wo, Hi, Wi, stride, flags;
+} ssad_pw_f16;
+SSAD_API int ssad_conv1x1_f16(const ssad_pw_f16* desc_host, ssad_stream_t stream);
+/* w [M][C] fp32 -> packed_fwd [ceil(C/8)][M][8] and / or packed_dgrad [ceil(M/8)][C][8] fp16 */
+SSAD_API size_t ssad_pw_f16_filter_halves(int M, int C);
+SSAD_API int ssad_pw_f16_pack_filter(const float* w, int M, int C, void* packed_fwd, void* packed_dgrad,
+                                     ssad_stream_t stream);
+/* Filter (and optionally bias) gradient of a pointwise layer from blocked fp16 x and dy of one
+ * map size: dw [M][C], db [M] fp32, times scale (times scale_dev[0] if not NULL).  Deterministic. */
+SSAD_API size_t ssad_conv1x1_wgrad_f16_workspace_bytes(int N, int C, int H, int W, int M);
+SSAD_API int ssad_conv1x1_wgrad_f16(const void* x_blocked, const void* dy_blocked, int N, int C, int H, int W,
+                                    int M, int accumulate, float scale, const float* scale_dev, float* dw,
+                                    float* db, void* workspace, size_t workspace_bytes, ssad_stream_t stream);
+/* Elementwise passes on blocked fp16 tensors; N, C, H, W describe y.
+ *   0 subsample       y[y][x] = a[stride y][stride x]                     (a: H stride x W stride)
+ *   1 subsample grad  y[y][x] (+)= both multiples of stride ? a[y/stride][x/stride] : 0
+ *   2 upsample grad   y = sum of a's 2 x 2 blocks (a: 2H x 2W) (+ b)    upsample_nearest_op.cu:62-151
+ *   3 sum             y = a + b
+ *   4 relu            y = max(a, 0)
+ *   5 relu grad       y = a > 0 ? b : 0                                  relu_op.cu:44-53 */
+SSAD_API int ssad_f16_elementwise(int mode, const void* a, const void* b, void* y, int N, int C, int H, int W,
+                                  int stride, int accumulate, ssad_stream_t stream);
+/* bias + ReLU + 3x3 / stride 2 / pad 1 max pool of the stem's fp32 NCHW output z [N][C][H][W],
+ * written blocked fp16 [N][C/8][ceil(H/2)][ceil(W/2)][8] */
+SSAD_API int ssad_stem_pool_f16(const float* z, const float* bias, int N, int C, int H, int W, void* y_blocked,
+                                ssad_stream_t stream);
+/* ResNeXt's grouped 3x3 (stride 1, pad 1; ResNet.py:247-258) on blocked fp16, forward:
+ * w [C][C/group][3][3] -> packed (ssad_grouped_conv3x3_f16_filter_halves halves); C % 64 == 0,
+ * C / group in {4, 8, 16, 32}; y = relu?(conv + bias) */
+SSAD_API size_t ssad_grouped_conv3x3_f16_filter_halves(int C, int group);
+SSAD_API int ssad_grouped_conv3x3_f16_pack_filter(const float* w, int C, int group, void* packed,
+                                                  ssad_stream_t stream);
+SSAD_API int ssad_grouped_conv3x3_f16(const void* x_blocked, const void* packed, const float* bias, int N, int C,
+                                      int H, int W, int group, int relu, void* y_blocked, ssad_stream_t stream);
+
 /* ---------------------------------------------------------------------- */
 /* Introspection                                                           */
 /* ---------------------------------------------------------------------- */

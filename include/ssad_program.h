@@ -146,7 +146,23 @@ enum ssad_opcode {
   /* ssad_grouped_conv3x3_pack_filter(p0 = w, i0 = C, i1 = group, p1 = packed) */
   SSAD_OP_GROUPED_PACK = 65,
   /* ssad_conv_implicit_gemm(p0 = ssad_gemm_conv*, i0..i5 = C, H, W, kernel, stride, pad) */
-  SSAD_OP_CONV_IMPLICIT = 66
+  SSAD_OP_CONV_IMPLICIT = 66,
+  /* the backbones in fp16 storage (ssad_kernels.h: gemm_f16.hip, grouped_f16.hip) */
+  /* p0 = const ssad_pw_f16* (host) */
+  SSAD_OP_PW_F16 = 67,
+  /* i0 = M, i1 = C; p0 = w, p1 = packed_fwd, p2 = packed_dgrad */
+  SSAD_OP_PW_F16_PACK = 68,
+  /* i0..i5 = N, C, H, W, M, accumulate; f0 = scale; l0 = workspace bytes; p0 = x, p1 = dy, p2 = scale_dev,
+     p3 = dw, p4 = db, p5 = workspace */
+  SSAD_OP_PW_F16_WGRAD = 69,
+  /* i0 = mode, i1..i4 = N, C, H, W (of y), i5 = stride, i6 = accumulate; p0 = a, p1 = b, p2 = y */
+  SSAD_OP_F16_EW = 70,
+  /* i0..i3 = N, C, H, W (of z); p0 = z, p1 = bias, p2 = y */
+  SSAD_OP_STEM_POOL_F16 = 71,
+  /* i0..i5 = N, C, H, W, group, relu; p0 = x, p1 = packed, p2 = bias, p3 = y */
+  SSAD_OP_GROUPED_F16 = 72,
+  /* i0 = C, i1 = group; p0 = w, p1 = packed */
+  SSAD_OP_GROUPED_F16_PACK = 73
 };
 
 typedef struct ssad_op {

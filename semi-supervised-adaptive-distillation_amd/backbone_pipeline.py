@@ -660,23 +660,37 @@ class NativeDistillModel(object):
         assert self.has_teacher == bool(getattr(heads, "distill", True))
         lr = float(heads.lr.item()) if lr is None else lr
         self.f16 = bool(getattr(heads, "F16", False))
-        self.student = NativeResNetFPN(student_arch, N, image_hw, device, train=True, src=student_src, lr=lr,
-                                       momentum=momentum, weight_decay=weight_decay, process_group=process_group,
-                                       world_size=world_size, affine_scales=student_scales,
-                                       skip_flag=heads.ls_counters if self.f16 else None,
-                                       overlap_wgrad=overlap_wgrad)
-        self.teacher = NativeResNetFPN(teacher_arch, N, image_hw, device, train=False,
-                                       src=teacher_src) if self.has_teacher else None
+        # fp16 subnets that exchange blocked fp16 tensors with the backbone: the backbones run in the
+        # same precision (config 5: every convolution of the net, conv_op_cudnn.cc:631-636)
+        self.backbone_f16 = self.f16 and bool(getattr(heads, "blocked_io", False))
+        kw = dict(lr=lr, momentum=momentum, weight_decay=weight_decay, process_group=process_group,
+                  world_size=world_size, affine_scales=student_scales,
+                  skip_flag=heads.ls_counters if self.f16 else None, overlap_wgrad=overlap_wgrad)
+        if self.backbone_f16:
+            from .backbone_f16 import NativeResNetFPNF16
+            self.student = NativeResNetFPNF16(
+                student_arch, N, image_hw, device, train=True, src=student_src,
+                heads_io=dict(fpn_out=heads.in_blk["student"], inv_scale=heads.ls_state[1:2],
+                              d_fpn_in=(heads.dbuf["cls"][0], heads.dbuf["bbox"][0])), **kw)
+            self.teacher = NativeResNetFPNF16(
+                teacher_arch, N, image_hw, device, train=False, src=teacher_src,
+                heads_io=dict(fpn_out=heads.in_blk["teacher"])) if self.has_teacher else None
+        else:
+            self.student = NativeResNetFPN(student_arch, N, image_hw, device, train=True, src=student_src, **kw)
+            self.teacher = NativeResNetFPN(teacher_arch, N, image_hw, device, train=False,
+                                           src=teacher_src) if self.has_teacher else None
         self.student.broadcast_params()
         if two_streams is None:
             two_streams = os.environ.get("SSAD_NATIVE_TWO_STREAMS", "1") == "1"
         self.side = torch.cuda.Stream() if (two_streams and self.has_teacher) else None
-        # gradient w.r.t. an FPN level = cls-subnet part + bbox-subnet part
+        # gradient w.r.t. an FPN level = cls-subnet part + bbox-subnet part (the fp16 backbone's own
+        # program starts with that sum, on the blocked tensors)
         Q = self.sum_prog = PR.Program()
         self._ptrs = []
-        for a, b, d in zip(heads.d_fpn["cls"], heads.d_fpn["bbox"], self.student.d_fpn):
-            ptrs = (C.c_void_p * 2)(a.data_ptr(), b.data_ptr())
-            Q.add(PR.SUM_N, 51, i=(2,), l=(d.numel(),), p=(ptrs, d), work=12.0 * d.numel(), keep=[a, b, d])
+        if not self.backbone_f16:
+            for a, b, d in zip(heads.d_fpn["cls"], heads.d_fpn["bbox"], self.student.d_fpn):
+                ptrs = (C.c_void_p * 2)(a.data_ptr(), b.data_ptr())
+                Q.add(PR.SUM_N, 51, i=(2,), l=(d.numel(),), p=(ptrs, d), work=12.0 * d.numel(), keep=[a, b, d])
         Q.build()
         if self.f16:
             # mixed precision: the backbone's reduced gradients join the subnets' finiteness check
@@ -704,6 +718,11 @@ class NativeDistillModel(object):
             self.teacher.timing = t if self.side is None else None   # one timing object per stream
 
     def describe(self):
+        if self.backbone_f16:
+            return ("backbones = native programs of this repo's kernels in fp16 storage / fp32 accumulation "
+                    "(pointwise convs: pw_f16_kernel with fused bias / shortcut / ReLU / FPN upsample-add; 3x3: "
+                    "conv3x3_f16_kernel; ResNeXt grouped 3x3: grouped_f16_kernel; stem: fp32 implicit GEMM + fp16 "
+                    "pool; no torch operator in the step)")
         return ("backbones = native programs of this repo's kernels (pointwise convs: fp32-MFMA GEMM with fused "
                 "bias / shortcut / ReLU; 3x3: Winograd engine; stem: im2col + GEMM + fused bias/ReLU/pool; "
                 "no torch operator in the step)")
@@ -728,6 +747,8 @@ class NativeDistillModel(object):
         s_fpn = st.forward(images)
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+        if self.backbone_f16:
+            t_fpn = s_fpn = None              # already in the subnets' blocked input buffers
         h.forward_all(t_fpn, s_fpn)
         h.cls_losses(labels, fg_num)
         h.bbox_losses_fwd_bwd(bbox_targets, fg_num)

@@ -645,13 +645,18 @@ __device__ __forceinline__ void tr_wait(half8& a, short4v (&x)[2][3]) {
 // 4 waves of twice that (one wave per SIMD, 192 accumulator registers) nothing covered the issue
 // time of the LDS-DMA instructions -- 18 per wave and stage at 100-185 cycles each beside 96 MFMAs
 // of 32: removing the DMA made the kernel 1.7x faster.  Two waves per SIMD do.
+//
+// PW = true: the same machinery for a POINTWISE layer's filter gradient dW[m][c] = sum dY[m] X[c]
+// (the backbones' 1x1 convolutions, gemm_f16.hip): one filter row (ky = 1), of which only the
+// centre tap is multiplied and stored -- 2 of the 6 accumulator tiles, part[split][m][c].
 constexpr int kWThreads = 512;
+template <bool PW>
 __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16Wgrad p) {
   extern __shared__ uint4 lds[];                           // 2 stages
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wo = wave & 3, wc = wave >> 2;
-  const int ky = blockIdx.z;
+  const int ky = PW ? 1 : blockIdx.z;
   const int ocb = (blockIdx.x / p.cblocks) * W_OT, ccb = (blockIdx.x % p.cblocks) * (W_CT / 8);
   const int CB = (p.C + 7) >> 3, MB = (p.M + 7) >> 3;
   // this workgroup's share of the pixel stages
@@ -797,7 +802,7 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+        for (int kx = PW ? 1 : 0; kx < (PW ? 2 : 3); ++kx)
           acc[u][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[row & 1], b[u][kx], acc[u][kx], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);                     // bound the operands in flight
     }
@@ -812,12 +817,14 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
     const int c = ccb * 8 + wc * 64 + u * 32 + (lane & 31);
     if (c >= p.C) continue;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
+    for (int kx = PW ? 1 : 0; kx < (PW ? 2 : 3); ++kx)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = ocb + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < p.M)
-          p.part[(((long long)blockIdx.y * 9 + ky * 3 + kx) * p.M + m) * p.C + c] = acc[u][kx][r];
+        if (m < p.M) {
+          if (PW) p.part[((long long)blockIdx.y * p.M + m) * p.C + c] = acc[u][kx][r];
+          else p.part[(((long long)blockIdx.y * 9 + ky * 3 + kx) * p.M + m) * p.C + c] = acc[u][kx][r];
+        }
       }
   }
 }
@@ -874,6 +881,40 @@ __global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_kernel(const float*
   for (int e = threadIdx.x; e < nvalid; e += kThreads) dst[e] = accumulate ? dst[e] + o[e] : o[e];
 }
 
+// pointwise layers: dW[m][c] (+)= scale * sum_split part[split][m][c] (fixed order); row m == M
+// folds the bias partials as above.
+__global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_pw_kernel(const float* __restrict__ part, int splits,
+                                                                       int M, int C, int accumulate, float scale,
+                                                                       const float* __restrict__ scale_dev,
+                                                                       float* __restrict__ dw,
+                                                                       const float* __restrict__ dbpart, int dbparts,
+                                                                       float* __restrict__ db) {
+  if (scale_dev) scale *= scale_dev[0];
+  const long long total = (long long)M * C;
+  if (blockIdx.y == 1) {                                   // the bias row
+    if (!db) return;
+    const int Mp = (M + 7) & ~7;
+    for (int mm = blockIdx.x * kThreads + threadIdx.x; mm < M; mm += gridDim.x * kThreads) {
+      float s = 0.0f;
+      for (int k = 0; k < dbparts; ++k) s += dbpart[k * Mp + mm];
+      s *= scale;
+      db[mm] = accumulate ? db[mm] + s : s;
+    }
+    return;
+  }
+  for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long long)gridDim.x * kThreads) {
+    float s0 = 0.0f, s1 = 0.0f;
+    int k = 0;
+    for (; k + 1 < splits; k += 2) {
+      s0 += part[(long long)k * total + e];
+      s1 += part[(long long)(k + 1) * total + e];
+    }
+    if (k < splits) s0 += part[(long long)k * total + e];
+    const float v = (s0 + s1) * scale;
+    dw[e] = accumulate ? dw[e] + v : v;
+  }
+}
+
 // dbpart[level][split][m] = sum of the blocked fp16 dY over the split's share of the level's
 // N * H * W pixels (grid: channel blocks x kDbSplits x levels -- one launch for all levels)
 __global__ __launch_bounds__(kThreads) void f16_bias_grad_kernel(const F16Wgrad p, float* __restrict__ dbpart) {
@@ -907,7 +948,7 @@ __global__ __launch_bounds__(kThreads) void f16_bias_grad_kernel(const F16Wgrad 
 }
 
 namespace {
-int wgrad_splits(int blocks, int stages) {
+int wgrad_splits(int blocks, int stages, int rows = 3) {
   // one workgroup per CU at a time (148 KiB of LDS): whole rounds only -- 516 workgroups on 256
   // CUs take three rounds where 504 take two -- and ONE round measures best (tower layer, all
   // levels: 0.424 / 0.449 / 0.485 / 0.523 ms for 1 / 2 / 3 / 4 rounds: the per-workgroup prologue
@@ -920,7 +961,7 @@ int wgrad_splits(int blocks, int stages) {
     return n;
   }();
   static const int rounds = getenv("SSAD_F16_WGRAD_ROUNDS") ? atoi(getenv("SSAD_F16_WGRAD_ROUNDS")) : 1;
-  int s = (rounds * cus) / (3 * blocks);       // whole rounds; x 3 filter rows
+  int s = (rounds * cus) / (rows * blocks);    // whole rounds; x 3 filter rows (1 for a pointwise layer)
   if (s > stages) s = stages;
   return s < 1 ? 1 : s;
 }
@@ -937,26 +978,18 @@ int wgrad_stages(const ssad_f16_wgrad_level* levels, int n_levels) {
 }
 }  // namespace
 
-size_t ssad_conv3x3_wgrad_f16_levels_workspace_bytes(const ssad_f16_wgrad_level* levels, int n_levels, int C,
-                                                     int M) {
+namespace {
+size_t wgrad_ws_bytes(const ssad_f16_wgrad_level* levels, int n_levels, int C, int M, bool pw) {
   if (!levels || n_levels < 1) return 0;
   const int blocks = ((M + W_OT - 1) / W_OT) * ((C + W_CT - 1) / W_CT);
   const int stages = wgrad_stages(levels, n_levels);
-  return ((size_t)wgrad_splits(blocks, stages > 0 ? stages : 1) * 9 * (size_t)M * (size_t)C +
+  return ((size_t)wgrad_splits(blocks, stages > 0 ? stages : 1, pw ? 1 : 3) * (pw ? 1 : 9) * (size_t)M * (size_t)C +
           (size_t)n_levels * kDbSplits * (size_t)((M + 7) & ~7)) * sizeof(float);
 }
 
-int ssad_conv3x3_wgrad_f16_levels(const ssad_f16_wgrad_level* levels, int n_levels, int C, int M,
-                                  int accumulate, float scale, float* dw, float* db, void* workspace,
-                                  size_t workspace_bytes, ssad_stream_t stream) {
-  return ssad_conv3x3_wgrad_f16_levels_dyn(levels, n_levels, C, M, accumulate, scale, nullptr, dw, db,
-                                           workspace, workspace_bytes, stream);
-}
-
-int ssad_conv3x3_wgrad_f16_levels_dyn(const ssad_f16_wgrad_level* levels, int n_levels, int C, int M,
-                                      int accumulate, float scale, const float* scale_dev, float* dw,
-                                      float* db, void* workspace, size_t workspace_bytes,
-                                      ssad_stream_t stream) {
+int wgrad_launch(const ssad_f16_wgrad_level* levels, int n_levels, int C, int M, int accumulate, float scale,
+                 const float* scale_dev, float* dw, float* db, void* workspace, size_t workspace_bytes,
+                 ssad_stream_t stream, bool pw) {
   if (!levels || n_levels < 1 || n_levels > SSAD_MAX_F16_LEVELS || !dw || C < 1 || M < 1) return SSAD_E_BADARG;
   F16Wgrad p;
   long long stages = 0;
@@ -972,34 +1005,82 @@ int ssad_conv3x3_wgrad_f16_levels_dyn(const ssad_f16_wgrad_level* levels, int n_
     if (stages >= (1LL << 31)) return SSAD_E_BADARG;
   }
   for (int l = n_levels; l <= SSAD_MAX_F16_LEVELS; ++l) p.stage0[l] = (int)stages;
-  if (workspace_bytes < ssad_conv3x3_wgrad_f16_levels_workspace_bytes(levels, n_levels, C, M) || !workspace)
-    return SSAD_E_WORKSPACE;
+  if (workspace_bytes < wgrad_ws_bytes(levels, n_levels, C, M, pw) || !workspace) return SSAD_E_WORKSPACE;
   p.n_levels = n_levels;
   p.part = static_cast<float*>(workspace);
   p.C = C; p.M = M;
   p.stages = (int)stages;
   p.cblocks = (C + W_CT - 1) / W_CT;
   const int blocks = ((M + W_OT - 1) / W_OT) * p.cblocks;
-  const int splits = wgrad_splits(blocks, p.stages > 0 ? p.stages : 1);
+  const int splits = wgrad_splits(blocks, p.stages > 0 ? p.stages : 1, pw ? 1 : 3);
   hipStream_t s = (hipStream_t)stream;
   if (p.stages > 0) {
     static const bool attr = [] {
-      return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16_kernel),
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE * 16) == hipSuccess &&
+             hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE * 16) == hipSuccess;
     }();
     if (!attr) return SSAD_E_BADARG;
-    hipLaunchKernelGGL(conv3x3_wgrad_f16_kernel, dim3(blocks, splits, 3), dim3(kWThreads), 2 * W_STAGE * 16, s,
-                       p);
+    if (pw) hipLaunchKernelGGL(conv3x3_wgrad_f16_kernel<true>, dim3(blocks, splits, 1), dim3(kWThreads),
+                               2 * W_STAGE * 16, s, p);
+    else hipLaunchKernelGGL(conv3x3_wgrad_f16_kernel<false>, dim3(blocks, splits, 3), dim3(kWThreads),
+                            2 * W_STAGE * 16, s, p);
   }
-  float* dbpart = p.part + (size_t)splits * 9 * (size_t)M * (size_t)C;
+  float* dbpart = p.part + (size_t)splits * (pw ? 1 : 9) * (size_t)M * (size_t)C;
   if (db) {
     p.n_levels = n_levels;
     hipLaunchKernelGGL(f16_bias_grad_kernel, dim3((M + 7) / 8, kDbSplits, n_levels), dim3(kThreads), 0, s, p, dbpart);
   }
-  hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3((C + 63) / 64, M + 1), dim3(kThreads), 0, s, p.part,
-                     p.stages > 0 ? splits : 0, M, C, accumulate, scale, scale_dev, dw, dbpart,
-                     n_levels * kDbSplits, db);
+  if (pw) {
+    long long gx = ((long long)M * C + kThreads - 1) / kThreads;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(f16_wgrad_reduce_pw_kernel, dim3((unsigned)gx, 2), dim3(kThreads), 0, s, p.part,
+                       p.stages > 0 ? splits : 0, M, C, accumulate, scale, scale_dev, dw, dbpart,
+                       n_levels * kDbSplits, db);
+  } else {
+    hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3((C + 63) / 64, M + 1), dim3(kThreads), 0, s, p.part,
+                       p.stages > 0 ? splits : 0, M, C, accumulate, scale, scale_dev, dw, dbpart,
+                       n_levels * kDbSplits, db);
+  }
   return (int)hipGetLastError();
+}
+}  // namespace
+
+size_t ssad_conv3x3_wgrad_f16_levels_workspace_bytes(const ssad_f16_wgrad_level* levels, int n_levels, int C,
+                                                     int M) {
+  return wgrad_ws_bytes(levels, n_levels, C, M, false);
+}
+
+int ssad_conv3x3_wgrad_f16_levels(const ssad_f16_wgrad_level* levels, int n_levels, int C, int M,
+                                  int accumulate, float scale, float* dw, float* db, void* workspace,
+                                  size_t workspace_bytes, ssad_stream_t stream) {
+  return wgrad_launch(levels, n_levels, C, M, accumulate, scale, nullptr, dw, db, workspace, workspace_bytes,
+                      stream, false);
+}
+
+int ssad_conv3x3_wgrad_f16_levels_dyn(const ssad_f16_wgrad_level* levels, int n_levels, int C, int M,
+                                      int accumulate, float scale, const float* scale_dev, float* dw,
+                                      float* db, void* workspace, size_t workspace_bytes,
+                                      ssad_stream_t stream) {
+  return wgrad_launch(levels, n_levels, C, M, accumulate, scale, scale_dev, dw, db, workspace, workspace_bytes,
+                      stream, false);
+}
+
+/* pointwise layer: dW[M][C] and (optionally) db[M] from blocked fp16 X [N][C/8][H][W][8] and
+ * dY [N][M/8][H][W][8] */
+size_t ssad_conv1x1_wgrad_f16_workspace_bytes(int N, int C, int H, int W, int M) {
+  ssad_f16_wgrad_level L;
+  L.x = L.dy = nullptr; L.N = N; L.H = H; L.W = W;
+  return wgrad_ws_bytes(&L, 1, C, M, true);
+}
+
+int ssad_conv1x1_wgrad_f16(const void* x_blocked, const void* dy_blocked, int N, int C, int H, int W, int M,
+                           int accumulate, float scale, const float* scale_dev, float* dw, float* db,
+                           void* workspace, size_t workspace_bytes, ssad_stream_t stream) {
+  ssad_f16_wgrad_level L;
+  L.x = x_blocked; L.dy = dy_blocked; L.N = N; L.H = H; L.W = W;
+  return wgrad_launch(&L, 1, C, M, accumulate, scale, scale_dev, dw, db, workspace, workspace_bytes, stream, true);
 }
 
 size_t ssad_conv3x3_wgrad_f16_workspace_bytes(int N, int C, int H, int W, int M) {

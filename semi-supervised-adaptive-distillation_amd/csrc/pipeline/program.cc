@@ -175,6 +175,22 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
       return ssad_grouped_conv3x3_pack_filter((const float*)p[0], i[0], i[1], (float*)p[1], s);
     case SSAD_OP_CHANNEL_SUM:
       return ssad_channel_sum((const float*)p[0], i[0], i[1], i[2], (float*)p[1], i[3], s);
+    case SSAD_OP_PW_F16:
+      return ssad_conv1x1_f16((const ssad_pw_f16*)p[0], s);
+    case SSAD_OP_PW_F16_PACK:
+      return ssad_pw_f16_pack_filter((const float*)p[0], i[0], i[1], (void*)p[1], (void*)p[2], s);
+    case SSAD_OP_PW_F16_WGRAD:
+      return ssad_conv1x1_wgrad_f16(p[0], p[1], i[0], i[1], i[2], i[3], i[4], i[5], f[0], (const float*)p[2],
+                                    (float*)p[3], (float*)p[4], (void*)p[5], (size_t)o.l[0], s);
+    case SSAD_OP_F16_EW:
+      return ssad_f16_elementwise(i[0], p[0], p[1], (void*)p[2], i[1], i[2], i[3], i[4], i[5], i[6], s);
+    case SSAD_OP_STEM_POOL_F16:
+      return ssad_stem_pool_f16((const float*)p[0], (const float*)p[1], i[0], i[1], i[2], i[3], (void*)p[2], s);
+    case SSAD_OP_GROUPED_F16:
+      return ssad_grouped_conv3x3_f16(p[0], p[1], (const float*)p[2], i[0], i[1], i[2], i[3], i[4], i[5],
+                                      (void*)p[3], s);
+    case SSAD_OP_GROUPED_F16_PACK:
+      return ssad_grouped_conv3x3_f16_pack_filter((const float*)p[0], i[0], i[1], (void*)p[1], s);
     default:
       return SSAD_E_BADARG;
   }

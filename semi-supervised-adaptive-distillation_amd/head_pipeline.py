@@ -95,7 +95,7 @@ class DistillHeads(object):
     def __init__(self, cfg=None, N=2, shapes=synth.LEVEL_SHAPES_600, device="cuda",
                  student_init=None, teacher_init=None, teacher_bbox_tower=True,
                  lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, world_size=1,
-                 distill=True, overlap_wgrad=None):
+                 distill=True, overlap_wgrad=None, blocked_io=False):
         self.cfg = cfg or HeadConfig()
         self.N, self.shapes, self.device = N, list(shapes), device
         self.distill = bool(distill)
@@ -125,6 +125,10 @@ class DistillHeads(object):
         self.t_packed = None
         self._teacher_packed = False
         self._overlap_wgrad = overlap_wgrad      # None: environment (SSAD_OVERLAP_WGRAD, default on)
+        # fp16 pipeline only: the FPN levels arrive (and their gradients leave) channel-blocked fp16
+        # in this object's own buffers -- in_blk[...] is written by the backbone program, dbuf[t][0]
+        # read by it (backbone_f16.NativeResNetFPNF16): no NCHW fp32 round trip at the boundary
+        self.blocked_io = bool(blocked_io) and self.F16
         self._alloc_buffers()
         self._build_programs()
 
@@ -718,7 +722,7 @@ class DistillHeadsF16(DistillHeads):
         AC, A4 = self.A * self.C, 4 * self.A
         self._in_ops = []
         act_bytes = lambda x: 6.0 * x.numel()
-        for who in ("student", "teacher") if self.distill else ("student",):
+        for who in (("student", "teacher") if self.distill else ("student",)) if not self.blocked_io else ():
             src = self.fpn_in if who == "student" else self.t_fpn_in
             for l, (x, xb) in enumerate(zip(src, self.in_blk[who])):
                 idx = P.add(PR.F16_PACK_ACT, 32, i=(x.shape[0], x.shape[1], x.shape[2], x.shape[3]), f=(1.0,),
@@ -806,7 +810,7 @@ class DistillHeadsF16(DistillHeads):
             self._emit_conv16(P, probs, D, D, K.CONV_MASK_AUX if li > 0 else 0, 34)
             if li == nl // 2:
                 P.mark("backward_late_done")
-        for t in ("cls", "bbox"):
+        for t in ("cls", "bbox") if not self.blocked_io else ():
             for l in range(nlev):
                 xb, x = dy[t][l], self.d_fpn[t][l]
                 P.add(PR.F16_UNPACK_ACT, 32, i=tuple(x.shape), f=(1.0,), p=(xb, Sinv, x), work=6.0 * x.numel())

@@ -63,6 +63,14 @@ class GemmConv(C.Structure):
                 ("K", C.c_int), ("P", C.c_int), ("M", C.c_int), ("flags", C.c_int)]
 
 
+class PwF16(C.Structure):
+    """ssad_pw_f16 (include/ssad_kernels.h): one pointwise convolution on blocked fp16 tensors."""
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
+                ("mask", C.c_void_p), ("y", C.c_void_p), ("N", C.c_int), ("C", C.c_int), ("M", C.c_int),
+                ("Ho", C.c_int), ("Wo", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("stride", C.c_int),
+                ("flags", C.c_int)]
+
+
 class ConvLevel(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("aux", C.c_void_p),
                 ("N", C.c_int), ("H", C.c_int), ("W", C.c_int),
@@ -174,6 +182,19 @@ def lib():
     L.ssad_grouped_conv3x3_filter_floats.argtypes = [i32, i32]
     L.ssad_grouped_conv3x3_filter_floats.restype = C.c_longlong
     L.ssad_grouped_conv3x3_pack_filter.argtypes = [vp, i32, i32, vp, vp]
+    L.ssad_conv1x1_f16.argtypes = [C.POINTER(PwF16), vp]
+    L.ssad_pw_f16_filter_halves.restype = sz
+    L.ssad_pw_f16_filter_halves.argtypes = [i32, i32]
+    L.ssad_pw_f16_pack_filter.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.ssad_conv1x1_wgrad_f16_workspace_bytes.restype = sz
+    L.ssad_conv1x1_wgrad_f16_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    L.ssad_conv1x1_wgrad_f16.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp]
+    L.ssad_f16_elementwise.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.ssad_stem_pool_f16.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    L.ssad_grouped_conv3x3_f16_filter_halves.restype = sz
+    L.ssad_grouped_conv3x3_f16_filter_halves.argtypes = [i32, i32]
+    L.ssad_grouped_conv3x3_f16_pack_filter.argtypes = [vp, i32, i32, vp, vp]
+    L.ssad_grouped_conv3x3_f16.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_kernels_arch.restype = C.c_char_p
     L.ssad_kernels_abi_version.restype = i32
     _lib = L
@@ -660,6 +681,9 @@ def conv3x3_wgrad(xs, dys, Cout, *, want_db=True, accumulate=False, dW=None, db=
 # ---- fp16 storage / fp32 accumulation (config 5's precision) ---------------------------
 
 F16_OUT_NCHW_F32 = 16
+PW_F16_RES_UPSAMPLE2 = 32
+# ssad_f16_elementwise modes
+EW_SUBSAMPLE, EW_SUBSAMPLE_GRAD, EW_UPSAMPLE_GRAD, EW_SUM2, EW_RELU, EW_RELU_GRAD = 0, 1, 2, 3, 4, 5
 
 
 def f16_pack_activations(x, scale=1.0, out=None):

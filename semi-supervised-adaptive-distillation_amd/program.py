@@ -25,6 +25,7 @@ GEMM_CONV, CONV1X1_WGRAD, TRANSPOSE_FILTER, SUBSAMPLE, SUBSAMPLE_GRAD, RELU, IM2
     54, 56, 57, 58, 59, 60, 61
 FORK, JOIN = 62, 63
 GROUPED_CONV3X3, GROUPED_PACK, CONV_IMPLICIT = 64, 65, 66
+PW_F16, PW_F16_PACK, PW_F16_WGRAD, F16_EW, STEM_POOL_F16, GROUPED_F16, GROUPED_F16_PACK = 67, 68, 69, 70, 71, 72, 73
 
 # timing classes: one per kernel family.  bound "mfma": work = direct-form FLOPs
 # (2*9*Cout*Cin per output pixel; the Winograd engine executes 1/2.25 of them);
@@ -73,6 +74,16 @@ KLASS = {
     54: dict(name="backbone filter packs (transpose / Winograd)", bound="hbm"),
     56: dict(name="grouped 3x3 conv, ResNeXt (grouped_conv3x3_kernel)", bound="mfma", wino=False),
     55: dict(name="backbone momentum SGD (sgd_flat_kernel)", bound="hbm"),
+    # backbones in fp16 storage / fp32 accumulation (BASELINE config 5)
+    57: dict(name="fp16 backbone pointwise conv fwd / data gradient (pw_f16_kernel)", bound="mfma16"),
+    58: dict(name="fp16 backbone conv3x3 fwd / data gradient (conv3x3_f16_kernel)", bound="mfma16"),
+    59: dict(name="fp16 backbone conv3x3 filter gradient (conv3x3_wgrad_f16_kernel<false> + reduce)", bound="mfma16"),
+    60: dict(name="fp16 backbone pointwise filter gradient (conv3x3_wgrad_f16_kernel<true> + reduce)",
+             bound="mfma16"),
+    61: dict(name="fp16 grouped 3x3 conv, ResNeXt (grouped_f16_kernel)", bound="mfma16"),
+    62: dict(name="fp16 backbone elementwise: subsample / scatter, ReluGradient, upsample gradient, sums, stem pool",
+             bound="hbm"),
+    63: dict(name="fp16 backbone filter packs", bound="hbm"),
 }
 
 PEAK = {"mfma": 157.3e12, "mfma16": 2.5e15, "hbm": 8.0e12}      # MI355X_MICROARCH.md chip table
