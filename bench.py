@@ -64,12 +64,12 @@ def parse():
     # --student r50 --batch-per-gpu 2), no teacher network, no distillation loss
     ap.add_argument("--teacher", default="r101", choices=["none", "r50", "r101", "x101-64x4d"])
     ap.add_argument("--px", type=int, default=600, choices=[600, 500])
-    # subnet precision: f32 (the metric's precision, default) or fp16 storage / fp32 accumulation
-    # (config 5; backbones stay fp32).  An f16 line is NOT the headline number.
+    # precision: f32 (the metric's precision, default) or fp16 storage / fp32 accumulation in every
+    # convolution of the net (config 5).  An f16 line is NOT the headline number.
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"])
-    # backbones: "native" = programs of this repo's kernels (ResNet-50/101 students, ResNet /
-    # ResNeXt-101-64x4d teachers, fp32); "harness" = the PyTorch harness (MIOpen / rocBLAS; what
-    # "auto" picks for --precision f16, whose backbones then run under fp16 autocast)
+    # backbones: "native" (= "auto") = programs of this repo's kernels in the run's precision (ResNet-50/101
+    # students, ResNet / ResNeXt-101-64x4d teachers); "harness" = round 1's PyTorch backbones under
+    # tools/harness (MIOpen / rocBLAS), for A/B runs only
     ap.add_argument("--backbone", default="auto", choices=["auto", "native", "harness"])
     ap.add_argument("--profile-steps", type=int, default=3,
                     help="instrumented steps after the timed region (per-family kernel table)")
@@ -220,10 +220,19 @@ def main():
     rng = np.random.default_rng(1234 + rank)
     f16 = args.precision == "f16"
     distill = args.teacher != "none"
+    native_ok = args.student in ("r50", "r101") and args.teacher in ("none", "r50", "r101", "x101-64x4d")
+    if args.backbone == "native" and not native_ok:
+        sys.stderr.write("bench.py: --backbone native covers ResNet-50/101 students and ResNet-50/101 / "
+                         "ResNeXt-101-64x4d teachers\n")
+        sys.exit(2)
+    # every precision runs on native programs of this repo's kernels by default ("harness" = round
+    # 1's PyTorch backbones, kept under tools/ for A/B runs)
+    native = args.workload == "full" and (args.backbone == "native" or (args.backbone == "auto" and native_ok))
+    hkw = dict(blocked_io=True) if (f16 and native and os.environ.get("SSAD_F16_BACKBONE", "1") == "1") else {}
     heads = (DistillHeadsF16 if f16 else DistillHeads)(cfg, N=N, shapes=shapes, device=dev,
                          student_init=synth.head_params(np.random.default_rng(1)),
                          teacher_init=synth.head_params(np.random.default_rng(2)) if distill else None,
-                         process_group=pg, world_size=world, lr=1e-4, distill=distill)
+                         process_group=pg, world_size=world, lr=1e-4, distill=distill, **hkw)
     heads.broadcast_params()
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     labels = [torch.from_numpy(synth.distill_inputs(rng, N, 9, 80, h, w)[2]).to(dev)
@@ -250,7 +259,6 @@ def main():
 
     losses_txt = ("PowSum + SigmoidAdaptiveDistillLoss + SigmoidFocalLoss + SelectSmoothL1Loss"
                   if distill else "SigmoidFocalLoss + SelectSmoothL1Loss")
-    native = False
     if args.workload == "heads":
         s_fpn = [torch.randn((N, 256, h, w), device=dev, generator=gen) for h, w in shapes]
         t_fpn = [torch.randn((N, 256, h, w), device=dev, generator=gen) for h, w in shapes] if distill else s_fpn
@@ -261,14 +269,6 @@ def main():
               "FPN features; the whole step is one native program of this repo's HIP kernels" % (
                   "teacher fwd, " if distill else "", losses_txt))
     else:
-        native_ok = args.student in ("r50", "r101") and args.teacher in ("none", "r50", "r101", "x101-64x4d")
-        if args.backbone == "native" and not native_ok:
-            sys.stderr.write("bench.py: --backbone native covers ResNet-50/101 students and ResNet-50/101 / "
-                             "ResNeXt-101-64x4d teachers\n")
-            sys.exit(2)
-        # with --precision f16 the native backbones still compute in fp32 (only the subnets have fp16
-        # kernels); "auto" then keeps the harness, whose backbones run under fp16 autocast
-        native = args.backbone == "native" or (args.backbone == "auto" and native_ok and not f16)
         if native:
             from ssad_amd.backbone_pipeline import NativeDistillModel
             model = NativeDistillModel(heads, student_arch=args.student,
@@ -356,9 +356,11 @@ def main():
             "host_enqueue_ms_per_step": round(host / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if not f16 else
-                      "f16 storage / f32 accumulate (subnets: this repo's kernels; backbones: " + (
-                          "this repo's fp32 kernels)" if (args.workload == "full" and native) else
-                          "torch autocast on MIOpen / rocBLAS)")),
+                      "f16 storage / f32 accumulate (subnets: this repo's kernels" + (
+                          ")" if args.workload != "full" else
+                          "; backbones: this repo's fp16 kernels)" if (native and hkw) else
+                          "; backbones: this repo's fp32 kernels)" if native else
+                          "; backbones: torch autocast on MIOpen / rocBLAS)")),
             "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": N, "image": "3x%dx%d" % image_hw,
                        "fpn_levels": [list(s) for s in shapes], "anchors": 9, "classes": 80,
@@ -392,8 +394,9 @@ def main():
                                 traffic=None)
         if not args.no_cpu_baseline and world == 1 and distill:     # rank 0 at N=1 only
             cb = cpu_baseline(args, cfg)
-            # the same scope on the GPU: the subnets + losses + SGD step alone (outside the timed region)
-            sf = [torch.randn((N, 256, h, w), device=dev, generator=gen) for h, w in shapes]
+            # the same scope on the GPU: the subnets + losses + SGD step alone (outside the timed region;
+            # with blocked fp16 I/O the subnets' inputs are whatever the backbones left in their buffers)
+            sf = [torch.randn((N, 256, h, w), device=dev, generator=gen) for h, w in shapes] if not hkw else None
             for _ in range(2):
                 heads.step(sf, sf, labels, bbox_targets=bbox_targets, fg_num=fg_num)
             torch.cuda.synchronize()

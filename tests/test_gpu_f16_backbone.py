@@ -141,14 +141,15 @@ def test_pointwise_f16_filter_gradient(N, Cc, M, H, W):
     dw = torch.empty((M, Cc), device=DEV)
     db = torch.empty((M,), device=DEV)
     inv = torch.tensor([0.5], device=DEV)
-    rc = L.ssad_conv1x1_wgrad_f16(_blk(x).data_ptr(), _blk(dy).data_ptr(), N, Cc, H, W, M, 0, 2.0, inv.data_ptr(),
+    xb, dyb = _blk(x), _blk(dy)              # (kept alive: the launcher only sees addresses)
+    rc = L.ssad_conv1x1_wgrad_f16(xb.data_ptr(), dyb.data_ptr(), N, Cc, H, W, M, 0, 2.0, inv.data_ptr(),
                                   dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, _stream())
     assert rc == 0, rc
     want = torch.einsum("nmhw,nchw->mc", _h(dy), _h(x))          # scale 2.0 * 0.5 = 1
     _close(dw, want, "dW", tol=2e-5)                             # fp32 results: accumulation order only
     _close(db, _h(dy).sum(dim=(0, 2, 3)), "db", tol=2e-5)
     dw2 = torch.empty_like(dw)
-    L.ssad_conv1x1_wgrad_f16(_blk(x).data_ptr(), _blk(dy).data_ptr(), N, Cc, H, W, M, 0, 2.0, inv.data_ptr(),
+    L.ssad_conv1x1_wgrad_f16(xb.data_ptr(), dyb.data_ptr(), N, Cc, H, W, M, 0, 2.0, inv.data_ptr(),
                              dw2.data_ptr(), None, ws.data_ptr(), nb, _stream())
     assert torch.equal(dw, dw2)                                  # deterministic
 
@@ -211,3 +212,133 @@ def test_f16_elementwise_passes_and_stem_pool():
     assert L.ssad_stem_pool_f16(zz.data_ptr(), bias.data_ptr(), N, 64, 14, 22, y.data_ptr(), _stream()) == 0
     want = F.max_pool2d(F.relu(zz + bias.view(1, -1, 1, 1)), 3, 2, 1)
     assert torch.equal(_unblk(y, 64), want.half().float())
+
+
+# ---------------------------------------------------------------------------
+# the networks built from these kernels
+# ---------------------------------------------------------------------------
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-300))
+
+
+def test_f16_backbone_forward_backward_vs_float64_reference():
+    """NativeResNetFPNF16 (R-50-FPN, train) against tests/torch_ref.py in float64 on the same
+    weights, ReLU masks made flip-proof: FPN levels to ~1e-2 of their scale (fp16 activations
+    through 50 layers), every trained gradient norm-wise (fp16 activations AND gradients)."""
+    from ssad_amd.backbone_f16 import NativeResNetFPNF16
+    from torch_ref import RefResNetFPN
+    N, hw = 2, (256, 384)
+    g = _gen(7)
+    images = torch.randn((N, 3) + hw, device=DEV, generator=g)
+    ref = RefResNetFPN("r50", seed=11).calibrate(images, margin=0.05)
+    nat = NativeResNetFPNF16("r50", N, hw, DEV, train=True, src=ref.state_dict(), lr=0.01, affine_scales=ref.scales)
+    nat.pack()
+    nat.forward(images)
+    got = nat.fpn_f32()
+    want = ref(images)
+    errs_f = [_rel(a, b.detach()) for a, b in zip(got, want)]
+    assert max(errs_f) < 1e-2, errs_f
+    d_fpn = [torch.randn(t.shape, device=DEV, generator=g) for t in want]
+    torch.autograd.backward(want, [d.double() for d in d_fpn])
+    S = 64.0                                            # a loss scale: the program divides it out again
+    nat.inv_scale.fill_(1.0 / S)
+    nat.backward(d_fpn, scale=S)
+    torch.cuda.synchronize()
+    errs = {}
+    for name, p in ref.p.items():
+        if not p.requires_grad:
+            continue
+        lname, kind = name.rsplit(".", 1)
+        layer = nat._layers[lname]
+        errs[name] = _rel(layer.gw if kind == "weight" else layer.gb, p.grad)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print("fp16 backbone: FPN level errors", errs_f, "worst gradients", worst)
+    assert worst[0][1] < 3e-2, worst
+    # the update runs on the fp32 master copies
+    p0 = nat.params_flat.clone()
+    nat.sgd_step()
+    assert torch.isfinite(nat.params_flat).all() and not torch.equal(p0, nat.params_flat)
+
+
+def test_f16_resnext_teacher_forward_vs_float64_reference():
+    from ssad_amd.backbone_f16 import NativeResNetFPNF16
+    from torch_ref import RefResNetFPN
+    N, hw = 1, (128, 256)
+    images = torch.randn((N, 3) + hw, device=DEV, generator=_gen(9))
+    ref = RefResNetFPN("x101-64x4d", seed=13)
+    nat = NativeResNetFPNF16("x101-64x4d", N, hw, DEV, train=False, src=ref.state_dict())
+    assert nat._layers["res2.0.c2"].group == 64 and nat._layers["res3.0.c2"].stride == 2
+    nat.forward(images)
+    with torch.no_grad():
+        want = ref(images)
+    errs = [_rel(a, b) for a, b in zip(nat.fpn_f32(), want)]
+    print("fp16 X-101 teacher: FPN level errors", errs)
+    assert max(errs) < 1.5e-2, errs
+
+
+def test_config5_step_on_native_fp16_kernels_matches_fp32_native_step():
+    """BASELINE config 5's step -- R-101-FPN student + ResNeXt-101-64x4d teacher, every
+    convolution with fp16 storage / fp32 accumulation on this repo's kernels -- against the fp32
+    native step on the same weights and inputs (small image, bs 2): losses, every parameter
+    gradient (norm-wise per tensor), and the dynamic loss scale dropping BOTH updates when a
+    backbone gradient overflows."""
+    from ssad_amd import synth
+    from ssad_amd.head_pipeline import DistillHeads, DistillHeadsF16
+    from ssad_amd.backbone_pipeline import NativeDistillModel
+    from ssad_amd.modeling.retinanet_heads import HeadConfig
+    from torch_ref import RefResNetFPN
+    N, hw = 2, (256, 384)
+    shapes = [(32, 48), (16, 24), (8, 12), (4, 6), (2, 3)]
+    rng = np.random.default_rng(21)
+    images = torch.randn((N, 3) + hw, device=DEV, generator=_gen(21))
+    ref_s = RefResNetFPN("r101", seed=31).calibrate(images, margin=0.05)
+    ref_t = RefResNetFPN("x101-64x4d", seed=32)
+    cfg = HeadConfig(num_gpus=1)
+    S, T = synth.head_params(rng), synth.head_params(rng)
+    labs = [synth.distill_inputs(rng, N, 9, 80, h, w)[2] for h, w in shapes]
+    tg = [synth.bbox_targets(rng, l) for l in labs]
+    fg = np.array([max(1, sum(t[0].shape[0] for t in tg))], np.float32)
+    to = lambda a: torch.from_numpy(a).to(DEV)
+    labels, targets, fg_num = [to(a) for a in labs], [(to(y), to(l)) for y, l in tg], to(fg)
+    kw = dict(N=N, shapes=shapes, device=DEV, student_init=S, teacher_init=T, lr=1e-4)
+    mk = dict(student_src=ref_s.state_dict(), teacher_src=ref_t.state_dict(), student_scales=ref_s.scales)
+
+    h32 = DistillHeads(cfg, **kw)
+    m32 = NativeDistillModel(h32, "r101", "x101-64x4d", N, hw, DEV, **mk)
+    m32.step(images, labels, targets, fg_num, update=False)
+    h16 = DistillHeadsF16(cfg, blocked_io=True, **kw)
+    m16 = NativeDistillModel(h16, "r101", "x101-64x4d", N, hw, DEV, **mk)
+    assert m16.backbone_f16 and type(m16.student).__name__ == "NativeResNetFPNF16"
+    m16.step(images, labels, targets, fg_num, update=False)
+    torch.cuda.synchronize()
+    for name in ("losses", "focal_losses", "bbox_losses"):
+        a, b = getattr(h16, name).double().cpu(), getattr(h32, name).double().cpu()
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max()), (name, a, b)
+    errs = {}
+    for name in S:
+        errs[name] = _rel(h16.grads[name], h32.grads[name])
+    for lname, l16 in m16.student._layers.items():
+        if l16.train:
+            errs[lname] = _rel(l16.gw, m32.student._layers[lname].gw)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    print("config 5 step, fp16 vs fp32 native: worst gradient differences", worst)
+    assert worst[0][1] < 6e-2, worst
+    # one real step: both updates applied, everything finite
+    p_h, p_b = h16.params.flat.clone(), m16.student.params_flat.clone()
+    m16.step(images, labels, targets, fg_num)
+    torch.cuda.synchronize()
+    assert torch.isfinite(h16.params.flat).all() and torch.isfinite(m16.student.params_flat).all()
+    assert not torch.equal(p_h, h16.params.flat) and not torch.equal(p_b, m16.student.params_flat)
+    # an overflowing step: scale so large that fp16 gradients become Inf -> BOTH updates are
+    # dropped, the scale is halved, momentum untouched
+    p_h, p_b = h16.params.flat.clone(), m16.student.params_flat.clone()
+    mo_h, mo_b = h16.moms.flat.clone(), m16.student.moms_flat.clone()
+    h16.ls_state.copy_(torch.tensor([1.0e9, 1.0e-9], device=DEV))
+    m16.step(images, labels, targets, fg_num)
+    torch.cuda.synchronize()
+    assert torch.equal(p_h, h16.params.flat) and torch.equal(p_b, m16.student.params_flat)
+    assert torch.equal(mo_h, h16.moms.flat) and torch.equal(mo_b, m16.student.moms_flat)
+    assert float(h16.ls_state[0]) == pytest.approx(min(0.5e9, DistillHeadsF16.LOSS_SCALE_MAX))
+    assert int(h16.ls_counters[0]) == 0
