@@ -295,7 +295,12 @@ def test_config5_step_on_native_fp16_kernels_matches_fp32_native_step():
     ref_s = RefResNetFPN("r101", seed=31).calibrate(images, margin=0.05)
     ref_t = RefResNetFPN("x101-64x4d", seed=32)
     cfg = HeadConfig(num_gpus=1)
-    S, T = synth.head_params(rng), synth.head_params(rng)
+    # flip-proof ReLU masks in the towers too (fp16 and fp32 activations differ by ~1e-3: a
+    # pre-activation that close to zero would take different sides in the two runs)
+    from test_gpu_operators import make_mask_safe
+    with torch.no_grad():
+        fs = [f.float().cpu().numpy() for f in ref_s(images)]
+    S, T = make_mask_safe(cfg, synth.head_params(rng), fs), synth.head_params(rng)
     labs = [synth.distill_inputs(rng, N, 9, 80, h, w)[2] for h, w in shapes]
     tg = [synth.bbox_targets(rng, l) for l in labs]
     fg = np.array([max(1, sum(t[0].shape[0] for t in tg))], np.float32)
@@ -324,7 +329,7 @@ def test_config5_step_on_native_fp16_kernels_matches_fp32_native_step():
             errs[lname] = _rel(l16.gw, m32.student._layers[lname].gw)
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
     print("config 5 step, fp16 vs fp32 native: worst gradient differences", worst)
-    assert worst[0][1] < 6e-2, worst
+    assert worst[0][1] < 2e-2, worst
     # one real step: both updates applied, everything finite
     p_h, p_b = h16.params.flat.clone(), m16.student.params_flat.clone()
     m16.step(images, labels, targets, fg_num)
