@@ -109,27 +109,20 @@ def kernel_report(classes, steps):
     return out
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of one kernel from the committed PMC passes (profiles/README.md:
-    FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc runs; FETCH x2 where the
-    calibration pass says so)."""
+def pmc_traffic(klass):
+    """HBM bytes per launch of one timing class from the committed counter passes over THIS
+    command's launches (profiles/rNN_pmc_classes.json: tools/profile_round3.sh runs separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --workload heads` and
+    tools/pmc_by_class.py attributes the dispatches to classes; read side x 2, the gfx950
+    correction calibrated in profiles/r02_pmc_fetch_calib.md).  -> (bytes or None, note)"""
     try:
         import glob
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
-        pm = json.load(open(files[-1]))
-        ks = [v for k, v in pm["kernels"].items() if k.startswith(kernel_prefix)]
-        if not ks:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_classes.json")))
+        e = json.load(open(files[-1]))["classes"].get(str(klass))
+        if not e or "hbm_bytes" not in e:
             return None, None
-        f = pm.get("fetch_calibration", {}).get(kernel_prefix)
-        fetch = [v.get("FETCH_SIZE_KB_raw", 0) * 1024 * (f if f else 1.0) for v in ks]
-        write = [v.get("WRITE_SIZE_KB", 0) * 1024 for v in ks]
-        note = ("FETCH_SIZE (x%.2f: calibrated on a known byte count in this kernel's access pattern, "
-                "profiles/README.md) + WRITE_SIZE per dispatch, separate rocprofv3 --pmc passes, file %s"
-                % (f, os.path.basename(files[-1]))) if f else (
-                "FETCH_SIZE + WRITE_SIZE per dispatch from separate rocprofv3 --pmc passes (%s); FETCH "
-                "uncalibrated for this kernel (true read side between 1x and 2x)" % os.path.basename(files[-1]))
-        total = int(sum(fetch) / len(fetch) + sum(write) / len(write))
-        return (total, note) if total > 0 else (None, None)
+        return int(e["hbm_bytes"]), ("2 x FETCH_SIZE + WRITE_SIZE per dispatch of this class, separate rocprofv3 "
+                                     "--pmc passes over bench.py --workload heads (%s)" % os.path.basename(files[-1]))
     except Exception:
         return None, None
 
@@ -345,8 +338,12 @@ def main():
         by = {r["class"]: r for r in kernel_report(timing.collect(), args.steps)}     # the timed region
         dom_k = 34 if f16 else (2 if 2 in by else 18)
         dom = by.get(dom_k)
-        prefix = "conv3x3_f16_kernel" if f16 else ("wino_conv_z_kernel" if dom_k == 2 else "conv3x3_kernel<8, 1")
-        traffic, traffic_note = pmc_traffic(prefix)
+        traffic, traffic_note = pmc_traffic(dom_k) if not f16 else (None, None)
+        # algorithmic HBM bytes of one launch of the dominant class: the four towers' inputs + outputs of
+        # all levels + the packed filters, each once (fp32)
+        px = N * sum(h * w for h, w in shapes)
+        ntow = (4 if distill else 2) if dom_k == 2 else 1
+        dom_alg_bytes = ntow * (2 * 256 * px * 4 + 16 * 256 * 256 * 4) if dom_k == 2 else None
         heads_ms = sum(r["ms_per_step"] for r in rows if r["class"] < 48)
         backbone_ms = sum(r["ms_per_step"] for r in rows if r["class"] >= 48)
         out = {
@@ -371,6 +368,9 @@ def main():
             # the dominant kernel: frac = EXECUTED MFMA flops / dense peak (a hardware fraction)
             "roofline": dict(kernel=dom["kernel"], bound="mfma", achieved=dom["achieved"], peak=dom["peak"],
                              unit="TFLOP/s", frac=dom["frac"], traffic=traffic, traffic_note=traffic_note,
+                             algorithmic_bytes=dom_alg_bytes,
+                             traffic_over_algorithmic=(round(traffic / dom_alg_bytes, 2)
+                                                       if (traffic and dom_alg_bytes) else None),
                              direct_equiv_tflops=dom["direct_equiv_tflops"],
                              achieved_note=("executed MFMA FLOP/s: algorithmic direct-form flops (2*9*Cout*Cin "
                                             "per output pixel, SURVEY 8d) / 2.25 for the Winograd F(2x2,3x3) "
@@ -388,10 +388,12 @@ def main():
         for key, k in (("roofline_loss", 9 if distill else 15), ("roofline_pow_sum", 8)):
             r = by.get(k)
             if r:
+                tr, tnote = pmc_traffic(k) if not f16 else (None, None)
                 out[key] = dict(kernel=r["kernel"], bound="hbm", achieved=r["achieved"], peak=r["peak"],
                                 unit="GB/s", frac=r["frac"], launches_per_step=r["launches_per_step"],
                                 avg_launch_ms=r["avg_launch_ms"], bytes_per_launch=r["bytes_per_launch"],
-                                traffic=None)
+                                traffic=tr, traffic_note=tnote,
+                                traffic_over_algorithmic=(round(tr / r["bytes_per_launch"], 3) if tr else None))
         if not args.no_cpu_baseline and world == 1 and distill:     # rank 0 at N=1 only
             cb = cpu_baseline(args, cfg)
             # the same scope on the GPU: the subnets + losses + SGD step alone (outside the timed region;

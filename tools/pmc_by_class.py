@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Hardware counters of the launches bench.py actually times, keyed by timing class.
+
+    python tools/pmc_by_class.py --out profiles/r03_pmc_classes.json --md profiles/r03_pmc_classes.md \
+        fetch=/tmp/prof_pmc_fetch/x.db write=/tmp/prof_pmc_write/x.db mfma=/tmp/prof_pmc_mfma/x.db
+
+Each .db is a rocprofv3 `--kernel-trace --pmc ...` capture of
+`python bench.py --workload heads --steps K ...` (separate passes per counter group, as
+MI355X_MICROARCH.md prescribes).  One kernel serves several timing classes (wino_conv_z_kernel:
+tower forward = class 2, cls_pred = 3, bbox_pred = 4, data gradients = 16), so dispatches are
+attributed by ORDER: the step's program (built here on the CPU with batch 1 -- the launch sequence
+does not depend on the batch) gives, per kernel name, the sequence of classes of one step; a step
+ends with its sgd_flat_kernel dispatch; launches of one kernel name are issued on one stream, so
+their dispatch ids are in program order.
+"""
+import json
+import os
+import re
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"[<(].*", "", name)
+    return name
+
+
+def class_sequences(f16=False):
+    """{kernel name: [class of its 1st, 2nd, ... launch within one step]} for the subnets step."""
+    import ssad_amd  # noqa: F401
+    from ssad_amd import program as PR, synth
+    from ssad_amd.head_pipeline import DistillHeads, DistillHeadsF16
+    from ssad_amd.modeling.retinanet_heads import HeadConfig
+    h = (DistillHeadsF16 if f16 else DistillHeads)(HeadConfig(num_gpus=1), N=1, shapes=synth.LEVEL_SHAPES_600,
+                                                   device="cpu")
+    names = {PR.CONV3X3: "wino_conv_z_kernel", PR.CONV3X3_WGRAD: "wino_wgrad_kernel", PR.POW_SUM: "pow_sum_kernel",
+             PR.CLS_LOSSES_FUSED: "cls_losses_fused_kernel", PR.SGD_FLAT: "sgd_flat_kernel",
+             PR.F16_CONV3X3: "conv3x3_f16_kernel", PR.F16_WGRAD: "conv3x3_wgrad_f16_kernel"}
+    seq = {}
+    for op in h.prog.ops:
+        n = names.get(op.code)
+        if n is None or (op.code == PR.CONV3X3 and not op.i[4]):
+            continue
+        seq.setdefault(n, []).append(op.klass)
+    return seq
+
+
+def read_db(path):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    rows = cur.execute("select dispatch_id, kernel_name, counter_name, value from counters_collection").fetchall()
+    disp = {}
+    for did, kn, cn, v in rows:
+        d = disp.setdefault(did, {"name": short(kn), "c": {}})
+        d["c"][cn] = d["c"].get(cn, 0.0) + v          # summed over XCDs / SEs
+    return [dict(id=k, **v) for k, v in sorted(disp.items())]
+
+
+def attribute(dispatches, seq):
+    """-> {klass: {"kernel", "dispatches", counter: per-dispatch average}}; steps = segments that end
+    with sgd_flat_kernel and contain exactly the expected number of launches of every kernel."""
+    steps, cur = [], []
+    for d in dispatches:
+        cur.append(d)
+        if d["name"] == "sgd_flat_kernel":
+            steps.append(cur)
+            cur = []
+    acc, used = {}, 0
+    for st in steps:
+        per = {}
+        for d in st:
+            if d["name"] in seq:
+                per.setdefault(d["name"], []).append(d)
+        if any(len(per.get(n, [])) != len(s) for n, s in seq.items()):
+            continue                                   # warm-up step with extra (teacher pack) or partial capture
+        used += 1
+        for n, s in seq.items():
+            for d, k in zip(per[n], s):
+                a = acc.setdefault(k, {"kernel": n, "dispatches": 0, "sum": {}})
+                a["dispatches"] += 1
+                for cn, v in d["c"].items():
+                    a["sum"][cn] = a["sum"].get(cn, 0.0) + v
+    out = {}
+    for k, a in acc.items():
+        e = {"kernel": a["kernel"], "dispatches": a["dispatches"]}
+        for cn, v in a["sum"].items():
+            e[cn] = v / a["dispatches"]
+        out[k] = e
+    return out, used, len(steps)
+
+
+def main():
+    args = sys.argv[1:]
+    out_path = md_path = None
+    f16 = False
+    passes = {}
+    i = 0
+    while i < len(args):
+        if args[i] == "--out":
+            out_path = args[i + 1]; i += 2
+        elif args[i] == "--md":
+            md_path = args[i + 1]; i += 2
+        elif args[i] == "--f16":
+            f16 = True; i += 1
+        else:
+            k, v = args[i].split("=", 1)
+            passes[k] = v; i += 1
+    seq = class_sequences(f16)
+    merged, notes = {}, []
+    for pname, path in passes.items():
+        got, used, total = attribute(read_db(path), seq)
+        notes.append("%s: %d of %d captured steps matched the program's launch sequence" % (pname, used, total))
+        for k, e in got.items():
+            m = merged.setdefault(k, {"kernel": e["kernel"]})
+            m["dispatches_" + pname] = e["dispatches"]
+            for cn, v in e.items():
+                if cn not in ("kernel", "dispatches"):
+                    m[cn] = v
+    for k, e in merged.items():
+        if "FETCH_SIZE" in e or "WRITE_SIZE" in e:
+            # KB per dispatch; gfx950 reports half of the bytes fetched for every access pattern this
+            # repo uses (profiles/r02_pmc_fetch_calib.md, MI355X_MICROARCH.md HBM section): x 2
+            e["hbm_read_bytes"] = 2.0 * 1024.0 * e.get("FETCH_SIZE", 0.0)
+            e["hbm_write_bytes"] = 1024.0 * e.get("WRITE_SIZE", 0.0)
+            e["hbm_bytes"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
+        if e.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in e:
+            # GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs on the chip
+            e["MfmaUtil_pct"] = round(100.0 * e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 2)
+        if e.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_ANY" in e:
+            e["wait_inst_any_pct"] = round(100.0 * e["SQ_WAIT_INST_ANY"] / e["SQ_WAVE_CYCLES"], 1)
+    doc = {"workload": "python bench.py --workload heads%s (bs 16, 600 px), per-dispatch averages by timing class "
+                       "(ssad_amd/program.py: KLASS)" % (" --precision f16" if f16 else ""),
+           "attribution": notes, "classes": {str(k): merged[k] for k in sorted(merged)}}
+    if out_path:
+        json.dump(doc, open(out_path, "w"), indent=1, sort_keys=True)
+    lines = ["# Counters of the timed launches, by timing class", "", doc["workload"], ""] + ["* " + n for n in notes]
+    cols = ["hbm_read_bytes", "hbm_write_bytes", "MfmaUtil_pct", "wait_inst_any_pct", "SQ_LDS_BANK_CONFLICT"]
+    lines += ["", "| class | kernel | " + " | ".join(cols) + " |", "|---|---|" + "---|" * len(cols)]
+    for k in sorted(merged):
+        e = merged[k]
+        lines.append("| %d | %s | %s |" % (k, e["kernel"], " | ".join(
+            ("%.4g" % e[c]) if c in e else "" for c in cols)))
+    text = "\n".join(lines) + "\n"
+    if md_path:
+        open(md_path, "w").write(text)
+    print(text)
+
+
+if __name__ == "__main__":
+    main()

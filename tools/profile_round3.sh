@@ -1,0 +1,48 @@
+#!/bin/bash
+# Round-3 rocprofv3 evidence on the GPU box.  Kernel traces of the three bench configurations and
+# SEPARATE counter passes (MI355X_MICROARCH.md: one --pmc group per run, with --kernel-trace only)
+# over the launches bench.py itself times (`--workload heads`, bs 16), attributed to timing classes by
+# tools/pmc_by_class.py.  Only summaries land in gpurun_out/; copy them to profiles/ afterwards.
+#   tools/profile_round3.sh r03 [traces|pmc|all]
+set -u
+TAG=${1:-r03}
+WHAT=${2:-all}
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/profiles_$TAG
+mkdir -p $O
+cd $R
+trace() { # name, marker, title, bench args...
+  local name=$1; shift; local marker=$1; shift; local title=$1; shift
+  rm -rf /tmp/prof_$name
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o t -- python bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0 > $O/$name.log 2>&1
+  local db=$(ls /tmp/prof_$name/*.db 2>/dev/null | head -1)
+  if [ -n "$db" ]; then
+    python tools/rocpd_summary.py $db $O/$name.md --json $O/$name.json --title "$title" --marker $marker --last 5 --busy > /dev/null
+  fi
+  tail -2 $O/$name.log | cut -c1-400 > $O/$name.tail; rm -f $O/$name.log
+}
+pmc() { # name, counters..., -- bench args
+  local name=$1; shift
+  local ctr=()
+  while [ "$1" != "--" ]; do ctr+=("$1"); shift; done
+  shift
+  rm -rf /tmp/prof_$name
+  rocprofv3 --kernel-trace --pmc "${ctr[@]}" -d /tmp/prof_$name -o t -- python bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 > $O/$name.log 2>&1
+  tail -2 $O/$name.log | cut -c1-400 > $O/$name.tail; rm -f $O/$name.log
+}
+if [ "$WHAT" = "traces" ] || [ "$WHAT" = "all" ]; then
+  trace bench_full_trace cls_losses_fused_kernel "rocprofv3 --kernel-trace --stats: python bench.py --steps 5 --warmup 2 (default: config 3, fp32, native), the 5 timed steps"
+  trace bench_heads_trace cls_losses_fused_kernel "rocprofv3 --kernel-trace --stats: python bench.py --workload heads --steps 5 --warmup 2, the 5 timed steps" --workload heads
+  trace bench_cfg5_f16_trace cls_losses_fused_kernel "rocprofv3 --kernel-trace --stats: python bench.py --student r101 --teacher x101-64x4d --px 500 --precision f16 --steps 5 --warmup 2 (BASELINE config 5 on native fp16 kernels), the 5 timed steps" --student r101 --teacher x101-64x4d --px 500 --precision f16
+fi
+if [ "$WHAT" = "pmc" ] || [ "$WHAT" = "all" ]; then
+  pmc pmc_fetch FETCH_SIZE -- --workload heads
+  pmc pmc_write WRITE_SIZE -- --workload heads
+  pmc pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT -- --workload heads
+  pmc pmc_wait SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAVES -- --workload heads
+  python tools/pmc_by_class.py --out $O/pmc_classes.json --md $O/pmc_classes.md \
+      fetch=$(ls /tmp/prof_pmc_fetch/*.db | head -1) write=$(ls /tmp/prof_pmc_write/*.db | head -1) \
+      mfma=$(ls /tmp/prof_pmc_mfma/*.db | head -1) wait=$(ls /tmp/prof_pmc_wait/*.db | head -1) > /dev/null 2> $O/pmc_classes.err
+fi
+ls -la $O
