@@ -14,9 +14,10 @@ Workloads
   full   BASELINE config "R-50 student + R-101 teacher, bs=16/GPU, 600 px" (default): both
          ResNet-FPN backbones, subnets, losses and both SGD updates as native programs of this
          repo's HIP kernels (ssad_program_run), teacher on a second stream.  This is the
-         configuration the metric is quoted on.  --backbone harness selects round 1's PyTorch
-         harness for the backbones (MIOpen / rocBLAS), which `--precision f16` still uses by
-         default for its fp16-autocast backbones.
+         configuration the metric is quoted on.  `--precision f16` runs every convolution of the
+         net with fp16 storage / fp32 accumulation on this repo's kernels (config 5's precision).
+         --backbone harness selects round 1's PyTorch backbones (tools/harness: MIOpen / rocBLAS)
+         for A/B runs.
 
 Timing: `value` from the wall clock around K steps (barrier + synchronize on both sides, max
 over ranks).  Inside the timed region HIP events bracket only the kernel families the

@@ -639,6 +639,14 @@ SSAD_API int ssad_grouped_conv3x3_f16_pack_filter(const float* w, int C, int gro
 SSAD_API int ssad_grouped_conv3x3_f16(const void* x_blocked, const void* packed, const float* bias, int N, int C,
                                       int H, int W, int group, int relu, void* y_blocked, ssad_stream_t stream);
 
+/* Plain fp32 GEMM on the matrix cores (exact fp32 v_mfma_f32_32x32x2_f32): row-major
+ * C[M x N] = alpha op(A) op(B) + beta C for `batch` problems `stride_*` elements apart -- math::Gemm /
+ * math::GemmStridedBatched (caffe2/utils/math_gpu.cu:33-80) of the default convolution engine's im2col
+ * route (conv_op_impl.h:126-173, :451-560).  Any sizes / leading dimensions; beta == 0 does not read C. */
+SSAD_API int ssad_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, int lda,
+                           long long stride_a, const float* B, int ldb, long long stride_b, float beta, float* C,
+                           int ldc, long long stride_c, int batch, ssad_stream_t stream);
+
 /* ---------------------------------------------------------------------- */
 /* Introspection                                                           */
 /* ---------------------------------------------------------------------- */

@@ -1,6 +1,5 @@
-// blas.h -- plain fp32 GEMM for the default convolution engine, through rocBLAS.
-// rocBLAS is opened lazily (dlopen on first use), so a process that only runs the
-// matrix-core 3x3 engine and the loss kernels never loads it.
+// blas.h -- plain fp32 GEMM for the default convolution engine's im2col route, on this repo's
+// own matrix-core kernel (kernels/gemm_general.hip); no vendor BLAS.
 #ifndef C2HIP_BLAS_H_
 #define C2HIP_BLAS_H_
 

@@ -2,7 +2,8 @@
 // (im2col + GEMM, caffe2/operators/conv_op_impl.h:31-202 and :358-577) that
 // serves every geometry the matrix-core 3x3 engine does not (the backbone's
 // 1x1, strided and 7x7 convolutions), plus MaxPool and the per-channel sum of
-// the bias gradient.  The GEMMs themselves go to rocBLAS (csrc/c2/blas.cc).
+// the bias gradient.  The GEMMs themselves: kernels/gemm_general.hip
+// (through csrc/c2/blas.cc, the math::Gemm front end).
 //
 //   Im2col / Col2im NCHW    caffe2/utils/math_gpu.cu im2col_gpu_kernel_nchw /
 //                           col2im_gpu_kernel_nchw

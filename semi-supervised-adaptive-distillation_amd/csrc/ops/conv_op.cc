@@ -140,7 +140,7 @@ bool ConvOp<float, HIPContext>::RunOnDevice() {
 
 // A pointwise layer the GEMM kernels take: 1x1, no padding, no dilation, equal strides, one group,
 // 16-byte pixel rows, 16-byte aligned channel rows (C % 4), tensors below 2 GiB.
-// hip_algo = "blas" keeps the rocBLAS route.
+// SSAD_CONV1X1_ENGINE=blas keeps the im2col + general-GEMM route (kernels/gemm_general.hip).
 static bool PointwiseGemmEligible(const ConvGeometry& g, int N, int C, int M, int P) {
   static const bool off = [] { const char* e = getenv("SSAD_CONV1X1_ENGINE"); return e && std::string(e) == "blas"; }();
   if (off) return false;
@@ -195,7 +195,7 @@ bool ConvOp<float, HIPContext>::RunDefaultEngine() {
                          geom_.pads == vector<int>{0, 0, 0, 0};
   // Pointwise layers (the bottleneck 1x1s, projection shortcuts, FPN laterals; stride 1 or the
   // stride-2 first blocks): this repo's fp32-MFMA GEMM over the whole batch with the bias (and a
-  // fused Relu) in its epilogue (kernels/gemm_conv.hip) instead of N rocBLAS calls + a bias pass.
+  // fused Relu) in its epilogue (kernels/gemm_conv.hip) instead of N per-image GEMM calls + a bias pass.
   // A strided pointwise convolution is the pointwise convolution of the subsampled map.
   if (PointwiseGemmEligible(geom_, N, C, M, P)) {
     const int st = geom_.stride[0];

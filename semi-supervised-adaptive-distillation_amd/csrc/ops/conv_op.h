@@ -14,8 +14,8 @@
 // the matrix-core kernels of this repo; every other 2-D NCHW geometry (the
 // backbone's 1x1, strided and 7x7 layers, and `group` > 1 -- ResNeXt's grouped 3x3 --
 // as one strided-batched GEMM per image) runs on the DEFAULT engine of
-// conv_op_impl.h:31-202 / :358-577 -- im2col + GEMM per image, with the GEMMs on
-// rocBLAS.  NHWC and non-2-D convolutions raise UnsupportedOperatorFeature at
+// conv_op_impl.h:31-202 / :358-577 -- im2col + GEMM per image, with the GEMMs on this
+// repo's general fp32-MFMA kernel (kernels/gemm_general.hip; no vendor BLAS).  NHWC and non-2-D convolutions raise UnsupportedOperatorFeature at
 // construction (caffe2/core/operator.h:765-782).  The operator packs its filter on
 // every RunOnDevice (the filter blob may have been updated in between, as under
 // training); the fused step (head_pipeline) packs once per parameter update instead.

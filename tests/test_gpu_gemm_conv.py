@@ -203,3 +203,40 @@ def test_conv_implicit_gemm_vs_reference_operator_golden(K, golden_dir):
         close(Y.ravel()[g[name + "_Y_idx"]], g[name + "_Y"], CONV_RTOL, CONV_FLOOR, name + " Y")
         done += 1
     assert done >= 7
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_general_gemm_matches_float64(K, ta, tb):
+    """ssad_gemm_f32 (kernels/gemm_general.hip): math::Gemm / GemmStridedBatched of the default
+    convolution engine's im2col route -- every transposition, sizes that are multiples of nothing,
+    padded leading dimensions, alpha / beta, a batch; beta = 0 must ignore what C held (NaN)."""
+    import ctypes as C
+    L = K.lib()
+    L.ssad_gemm_f32.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int,
+                                C.c_longlong, C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p, C.c_int,
+                                C.c_longlong, C.c_int, C.c_void_p]
+    g = torch.Generator(device="cuda").manual_seed(17)
+    M, N, Kk, batch = 75, 131, 147, 3
+    lda = (M if ta else Kk) + 5
+    ldb = (Kk if tb else N) + 3
+    ldc = N + 2
+    A = torch.randn((batch, Kk if ta else M, lda), device="cuda", generator=g)
+    B = torch.randn((batch, N if tb else Kk, ldb), device="cuda", generator=g)
+    Cm = torch.full((batch, M, ldc), float("nan"), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    rc = L.ssad_gemm_f32(ta, tb, M, N, Kk, 1.5, A.data_ptr(), lda, A.stride(0), B.data_ptr(), ldb, B.stride(0), 0.0,
+                         Cm.data_ptr(), ldc, Cm.stride(0), batch, st)
+    assert rc == 0
+    opA = (A[:, :, :M].transpose(1, 2) if ta else A[:, :, :Kk]).double()
+    opB = (B[:, :, :Kk].transpose(1, 2) if tb else B[:, :, :N]).double()
+    want = 1.5 * torch.bmm(opA, opB)
+    got = Cm[:, :, :N].double()
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert torch.isnan(Cm[:, :, N:]).all()                      # the padding of C was not touched
+    # beta = 1 accumulates
+    rc = L.ssad_gemm_f32(ta, tb, M, N, Kk, -0.5, A.data_ptr(), lda, A.stride(0), B.data_ptr(), ldb, B.stride(0), 1.0,
+                         Cm.data_ptr(), ldc, Cm.stride(0), batch, st)
+    assert rc == 0
+    got = Cm[:, :, :N].double()
+    assert float((got - want * (1.0 / 1.5)).abs().max()) <= 2e-5 * float(want.abs().max())
