@@ -413,6 +413,11 @@ constexpr int ZNT = 256;                  // tiles per workgroup in the LDS list
 constexpr int AD = 8;                     // filter operand ring depth (steps)
 static_assert(ZRAW <= ZRAWP && STEPS == 16 && AD == 8, "variant Z is written for KC = 16");
 
+// NT: cache policy of the streamed traffic.  bit 0: the raw-patch DMA is non-temporal, bit 1: the
+// output stores are.  Round-3 counters (profiles/r03_pmc_classes.md) showed 9.7x the algorithmic
+// read bytes leaving L2 on the tower launches: the 2 MB filter block of a phase shares a 4 MB L2
+// with ~15 MB of patches and outputs streaming through it and is evicted again and again.
+template <int NT>
 __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args) {
   __shared__ float raw[NRAW * ZRAWP];
   __shared__ float vbuf[2 * VBUF];
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
 #pragma unroll
     for (int j = 0; j < ZL; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(dst + j * 512),
-                                               4, vo[j], soff, 0, 0);
+                                               4, vo[j], soff, 0, (NT & 1) ? 2 : 0);
     if (++ld_ch == chunks) { ld_ch = 0; ++ld_tile; }
     if (++ld_buf == NRAW) ld_buf = 0;
   };
@@ -779,7 +784,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
                   }
                   __builtin_amdgcn_raw_buffer_store_b64(
                       __builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, make_float2(o0, o1)),
-                      yrsrc, vo[g][a], (2 * h + rr) * HW * 4, 0);
+                      yrsrc, vo[g][a], (2 * h + rr) * HW * 4, (NT & 2) ? 2 : 0);
                 }
               }
             }
@@ -913,7 +918,11 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
     if (total >= (1LL << 31)) return SSAD_E_BADARG;
     long long grid = total < cus2 ? total : cus2;
     if (grid * ZNT < total) grid = (total + ZNT - 1) / ZNT;
-    hipLaunchKernelGGL(wino_conv_z_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    static const int nt = [] { const char* e = getenv("SSAD_WINO_NT"); return e ? atoi(e) & 3 : 0; }();
+    if (nt == 3) hipLaunchKernelGGL(wino_conv_z_kernel<3>, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    else if (nt == 2) hipLaunchKernelGGL(wino_conv_z_kernel<2>, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    else if (nt == 1) hipLaunchKernelGGL(wino_conv_z_kernel<1>, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(wino_conv_z_kernel<0>, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
   }
   // SSAD_WINO_VARIANT=0: the non-persistent kernel

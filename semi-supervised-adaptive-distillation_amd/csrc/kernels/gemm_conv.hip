@@ -539,7 +539,9 @@ int ssad_conv_implicit_gemm(const ssad_gemm_conv* d, int C, int H, int W, int ke
   const int OH = (H + 2 * pad - kernel) / stride + 1, OW = (W + 2 * pad - kernel) / stride + 1;
   const int K = C * kernel * kernel;
   if (d->K != K || d->P != OH * OW) return SSAD_E_BADARG;
-  if (d->lda < d->M || (d->lda & 3) || (d->P & 3)) return SSAD_E_BADARG;        // the epilogue's 16-byte pieces
+  // (no constraint on P: the im2col view is gathered 4 bytes per lane and the epilogue stores
+  // element-wise -- odd output maps such as P7's 5 x 7 run here too)
+  if (d->lda < d->M || (d->lda & 3)) return SSAD_E_BADARG;                       // 16-byte filter pieces
   if ((uintptr_t)d->a & 15) return SSAD_E_BADARG;
   if ((d->flags & SSAD_GEMM_ACCUMULATE) && (d->bias || d->residual)) return SSAD_E_BADARG;
   const long long Q = (long long)d->N * d->P;

@@ -153,7 +153,7 @@ static bool PointwiseGemmEligible(const ConvGeometry& g, int N, int C, int M, in
 }
 
 // A k x k layer (any stride / pad, one group, square kernel, no dilation) the implicit-GEMM kernel
-// takes: 4-pixel-multiple output maps, tensors below 2 GiB.  SSAD_CONV1X1_ENGINE=blas disables it too.
+// takes: any output map size, tensors below 2 GiB.  SSAD_CONV1X1_ENGINE=blas disables it too.
 static bool ImplicitGemmEligible(const ConvGeometry& g, int N, int C, int H, int W, int M, int P) {
   static const bool off = [] {
     const char* e = getenv("SSAD_CONV1X1_ENGINE");
@@ -163,7 +163,7 @@ static bool ImplicitGemmEligible(const ConvGeometry& g, int N, int C, int H, int
   if (off || g.group != 1 || g.kernel[0] != g.kernel[1] || g.dilation != vector<int>{1, 1}) return false;
   if (g.stride[0] != g.stride[1] || g.stride[0] < 1) return false;
   if (g.pads[0] != g.pads[1] || g.pads[0] != g.pads[2] || g.pads[0] != g.pads[3]) return false;
-  if ((P & 3) || N < 1) return false;
+  if (N < 1) return false;
   const long long K = (long long)C * g.kernel[0] * g.kernel[0];
   return (long long)N * C * H * W * 4 < (1LL << 31) && (long long)N * M * P * 4 < (1LL << 31) &&
          K * ((M + 3) / 4 * 4) * 4 < (1LL << 31);

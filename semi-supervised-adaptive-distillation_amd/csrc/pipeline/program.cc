@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "ssad_program.h"
@@ -55,15 +56,28 @@ struct AuxStreams {
   }
 };
 
-AuxStreams* aux_streams() {
+// One set per device, created on first use.  The map is shared by every thread that runs a
+// program (one per stream in the step), hence the lock; a set whose streams could not all be
+// created is destroyed again, not leaked or half-registered.
+AuxStreams* aux_streams(hipError_t* why) {
   static std::map<int, AuxStreams*> per_device;
+  static std::mutex lock;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  hipError_t err = hipGetDevice(&dev);
+  if (err != hipSuccess) { *why = err; return nullptr; }
+  std::lock_guard<std::mutex> guard(lock);
   auto it = per_device.find(dev);
   if (it != per_device.end()) return it->second;
   AuxStreams* a = new AuxStreams();
-  for (int k = 0; k < SSAD_MAX_AUX_STREAMS; ++k)
-    if (hipStreamCreateWithFlags(&a->s[k], hipStreamNonBlocking) != hipSuccess) return nullptr;
+  for (int k = 0; k < SSAD_MAX_AUX_STREAMS; ++k) {
+    err = hipStreamCreateWithFlags(&a->s[k], hipStreamNonBlocking);
+    if (err != hipSuccess) {
+      for (int j = 0; j < k; ++j) (void)hipStreamDestroy(a->s[j]);
+      delete a;
+      *why = err;
+      return nullptr;
+    }
+  }
   per_device[dev] = a;
   return a;
 }
@@ -250,32 +264,38 @@ int ssad_program_run(const ssad_op* ops, int n_ops, ssad_stream_t stream, ssad_t
   // per stream: the event that closed the previous op (consecutive ops of a stream share an event)
   size_t prev_idx[SSAD_MAX_AUX_STREAMS + 1];
   bool have_prev[SSAD_MAX_AUX_STREAMS + 1] = {false, false, false, false};
-  auto fail = [&](int k, int rc) {
-    if (failed_index) *failed_index = k;
-    return rc;
-  };
   auto stream_of = [&](int k) -> hipStream_t { return k == 0 ? main_s : aux->s[k - 1]; };
   auto join = [&](int k) -> int {
     hipEvent_t e = aux->event();
-    if (!e) return SSAD_E_BADARG;
+    if (!e) return (int)hipErrorOutOfMemory;
     hipError_t err = hipEventRecord(e, aux->s[k - 1]);
     if (err == hipSuccess) err = hipStreamWaitEvent(main_s, e, 0);
     dirty[k] = false;
     have_prev[0] = false;                  // the main stream's next op starts after the wait
     return (int)err;
   };
+  // Error path: whatever was already enqueued on an auxiliary stream is joined first, so that work
+  // the caller enqueues on the main stream afterwards cannot race with it; the first error wins.
+  auto fail = [&](int k, int rc) {
+    if (failed_index) *failed_index = k;
+    if (aux)
+      for (int j = 1; j <= SSAD_MAX_AUX_STREAMS; ++j)
+        if (dirty[j]) (void)join(j);
+    return rc;
+  };
   for (int k = 0; k < n_ops; ++k) {
     const ssad_op& o = ops[k];
     const int sid = (o.code == SSAD_OP_FORK || o.code == SSAD_OP_JOIN) ? o.i[0] : o.stream;
     if (sid < 0 || sid > SSAD_MAX_AUX_STREAMS) return fail(k, SSAD_E_BADARG);
     if (sid > 0 && !aux) {
-      aux = aux_streams();
-      if (!aux) return fail(k, SSAD_E_BADARG);
+      hipError_t why = hipSuccess;
+      aux = aux_streams(&why);
+      if (!aux) return fail(k, why != hipSuccess ? (int)why : SSAD_E_BADARG);
     }
     if (o.code == SSAD_OP_FORK) {
       if (sid == 0) return fail(k, SSAD_E_BADARG);
       hipEvent_t e = aux->event();
-      if (!e) return fail(k, SSAD_E_BADARG);
+      if (!e) return fail(k, (int)hipErrorOutOfMemory);
       hipError_t err = hipEventRecord(e, main_s);
       if (err == hipSuccess) err = hipStreamWaitEvent(aux->s[sid - 1], e, 0);
       if (err != hipSuccess) return fail(k, (int)err);
@@ -297,7 +317,7 @@ int ssad_program_run(const ssad_op* ops, int n_ops, ssad_stream_t stream, ssad_t
     if (timing && !timed) have_prev[sid] = false;      // the next timed op of this stream needs its own start
     if (timed && !have_prev[sid]) {
       hipEvent_t e0 = timing->get();
-      if (!e0) return fail(k, SSAD_E_BADARG);
+      if (!e0) return fail(k, (int)hipErrorOutOfMemory);
       const hipError_t e = hipEventRecord(e0, hs);
       if (e != hipSuccess) return fail(k, (int)e);
       prev_idx[sid] = timing->used - 1;
@@ -307,7 +327,7 @@ int ssad_program_run(const ssad_op* ops, int n_ops, ssad_stream_t stream, ssad_t
     if (rc != 0) return fail(k, rc);
     if (timed) {
       hipEvent_t e1 = timing->get();
-      if (!e1) return fail(k, SSAD_E_BADARG);
+      if (!e1) return fail(k, (int)hipErrorOutOfMemory);
       const hipError_t e = hipEventRecord(e1, hs);
       if (e != hipSuccess) return fail(k, (int)e);
       timing->recs.push_back({o.klass, o.work, prev_idx[sid], timing->used - 1});
