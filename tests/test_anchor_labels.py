@@ -190,3 +190,61 @@ def test_device_detect_matches_oracle(case):
     assert np.array_equal(got[:, 4], ref[:, 4])                # scores, in order
     assert np.array_equal(got[:, 5], ref[:, 5])                # classes
     np.testing.assert_allclose(got[:, :4], ref[:, :4], rtol=2e-5, atol=2e-3)
+
+
+# ---------------------------------------------------------------------------
+# pinned by the reference's own Python: tests/golden/anchor_labels_ref.npz was written by
+# detectron/lib/roi_data/retinanet.py:97-306 (+ data_utils.py, generate_anchors.py, the compiled
+# cython_bbox.pyx) and utils/boxes.py run in the build container (tests/golden/make_anchor_labels.py)
+# ---------------------------------------------------------------------------
+
+def _ref_fixture():
+    return np.load(os.path.join(HERE, "golden", "anchor_labels_ref.npz"))
+
+
+def test_oracle_labelling_reproduces_the_reference_blobs_exactly():
+    z = _ref_fixture()
+    H, W = [int(v) for v in z["image_hw"]]
+    boxes, classes = [], []
+    for i, s in enumerate(z["scales"]):
+        boxes.append(z["gt_boxes_%d" % i] * float(s))           # retinanet.py:122: float32 boxes x python float
+        classes.append(z["gt_classes_%d" % i])
+        assert boxes[-1].dtype == np.float32
+    out = OA.retinanet_blobs(boxes, classes, H, W)
+    assert np.array_equal(np.float32(out["fg_num"]), z["blob_retnet_fg_num"][0])
+    assert np.array_equal(np.float32(out["bg_num"]), z["blob_retnet_bg_num"][0])
+    n_fg = 0
+    for lvl in range(3, 8):
+        lab = z["blob_retnet_cls_labels_fpn%d" % lvl]
+        assert lab.dtype == np.int32 and np.array_equal(out["labels_fpn%d" % lvl], lab), lvl
+        locs = z["blob_retnet_roi_fg_bbox_locs_fpn%d" % lvl]
+        assert np.array_equal(out["locs_fpn%d" % lvl], locs), lvl
+        tg = z["blob_retnet_roi_bbox_targets_fpn%d" % lvl]
+        assert tg.dtype == np.float32 and np.array_equal(out["targets_fpn%d" % lvl], tg), lvl
+        n_fg += locs.shape[0]
+        assert locs.shape[0] > 0                                   # every level carries foreground anchors
+    # the anchors themselves: first anchor of each (level, octave, aspect) field, and the field sizes
+    cells = OA.cell_anchors()
+    assert np.array_equal(cells.reshape(-1, 4), z["cell_anchors"])
+    assert [OA.field_size(2.0 ** (3 + k // 9)) for k in range(45)] == [int(v) for v in z["field_sizes"]]
+
+
+def test_oracle_box_decoding_reproduces_the_reference():
+    """bbox_transform (with the BBOX_XFORM_CLIP clamp) and clip_tiled_boxes of utils/boxes.py:193-260."""
+    from oracle import detect as OD
+    z = _ref_fixture()
+    got = OD.bbox_transform(z["decode_anchors"], z["decode_deltas"])
+    # The fixture was computed under numpy 2, whose promotion rules differ from the numpy 1.x the
+    # reference was written for: `np.minimum(dw, cfg.BBOX_XFORM_CLIP)` (boxes.py:176-177) meets a
+    # float64 SCALAR (np.log's result) and the width / height expressions run in float64 there before
+    # they are stored into the float32 result; under the old value-based casting they stay float32,
+    # which is what the oracle (and detect.hip) follow.  Hence 1-ulp differences: compared at 1e-6
+    # relative, not bit for bit.
+    assert str(z["decode_boxes_dtype_was"]) == "float32"
+    assert np.allclose(got, z["decode_boxes"], rtol=1e-6, atol=1e-4)
+    clipped = OD.clip_tiled_boxes(got.copy(), (600, 899))
+    assert np.allclose(clipped, z["decode_clipped"], rtol=1e-6, atol=1e-4)
+    assert clipped.min() >= 0 and clipped[:, 0::2].max() <= 898 and clipped[:, 1::2].max() <= 599
+    big = z["decode_deltas"][:, 2] >= 6.0                         # the BBOX_XFORM_CLIP clamp was exercised
+    assert big.any() and np.allclose((got[big, 2] - got[big, 0] + 1) /
+                                     (z["decode_anchors"][big, 2] - z["decode_anchors"][big, 0] + 1), 62.5, rtol=1e-5)
