@@ -99,3 +99,72 @@ def test_running_without_a_device_fails_loudly():
     h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu")
     with pytest.raises(K.KernelError):
         h.prog.run("pack", "forward", stream=0)
+
+
+# ---------------------------------------------------------------------------
+# backbone programs (built over CPU tensors: structure only)
+# ---------------------------------------------------------------------------
+
+def _count(prog, lo, hi):
+    from collections import Counter
+    return Counter(o.code for o in prog.ops[prog.marks[lo]:prog.marks[hi]])
+
+
+def test_fp32_backbone_program_trains_no_body_bias_and_scales_folded_filters():
+    """detectron/lib/modeling/ResNet.py:270-283 + affine_channel_op.cc: the body's convolutions have
+    no bias and the frozen AffineChannel is never trained -- only FPN layers own bias parameters, and
+    a filter with a folded scale s carries the s^2 row factor into the SGD table."""
+    from ssad_amd.backbone_pipeline import NativeResNetFPN
+    bb = NativeResNetFPN("r50", 1, (128, 128), "cpu", train=True)
+    L = bb._layers
+    assert all(l.gb is None for l in L.values() if l.train and l.affine)
+    assert all(l.gb is not None for n, l in L.items() if n.startswith(("lat", "out", "p6", "p7")))
+    assert not L["stem.0"].train and not L["res2.0.c1"].train and L["res3.0.c1"].train
+    scaled = [s for s in bb.segments if s[4] is not None]
+    assert len(scaled) == 4 + 6 + 3                       # the c3 layers of res3..res5
+    assert all(float(s[4][0]) == 0.0625 and s[4].numel() * s[3] == s[1] for s in scaled)     # s^2, one per row
+    n_bias = sum(1 for s in bb.segments if s[2])
+    assert n_bias == 3 + 3 + 2                             # lat x3, out x3, p6, p7
+    bw = _count(bb.prog, "backward", "sgd")
+    assert bw[PR.RELU_GRAD_ROWSUM] == 3                    # bias gradients of the three laterals only
+    assert bw[PR.CONV1X1_WGRAD] == 2 * 13 + 3 + 3           # c1 + c3 of 13 blocks, 3 projections, 3 laterals
+    assert _count(bb.prog, "sgd", "end") == {PR.SGD_FLAT: 1}
+    # four gradient buckets in the order the backward pass completes them
+    assert list(bb.bucket) == ["fpn", "res5", "res4", "res3"]
+    assert sum(b.numel() for b in bb.bucket.values()) == bb.grads_flat.numel()
+
+
+def test_fp16_backbone_program_uses_only_fp16_convolutions_after_the_stem():
+    """BASELINE config 5: every convolution of the net with fp16 storage (conv_op_cudnn.cc:631-636);
+    the 7x7 stem on the fp32 image is the one fp32-MFMA launch."""
+    from ssad_amd.backbone_f16 import NativeResNetFPNF16
+    from ssad_amd import synth
+    hw, shapes = (128, 128), [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    heads = DistillHeadsF16(HeadConfig(num_gpus=1), N=1, shapes=shapes, device="cpu", blocked_io=True)
+    assert heads.blocked_io
+    codes = [o.code for o in heads.prog.ops]
+    assert PR.F16_PACK_ACT in codes                        # (the prediction gradients are still packed)
+    fwd = heads.prog.ops[heads.prog.marks["forward"]:heads.prog.marks["losses"]]
+    assert all(o.code != PR.F16_PACK_ACT for o in fwd)     # no fp32 -> fp16 conversion of the FPN levels
+    assert all(o.code != PR.F16_UNPACK_ACT for o in heads.prog.ops)
+    st = NativeResNetFPNF16("r50", 1, hw, "cpu", train=True,
+                            heads_io=dict(fpn_out=heads.in_blk["student"], inv_scale=heads.ls_state[1:2],
+                                          d_fpn_in=(heads.dbuf["cls"][0], heads.dbuf["bbox"][0])),
+                            skip_flag=heads.ls_counters)
+    fw = _count(st.prog, "forward", "backward")
+    assert fw[PR.CONV_IMPLICIT] == 1 and fw[PR.GEMM_CONV] == 0 and fw[PR.CONV3X3] == 0
+    assert fw[PR.PW_F16] == 16 * 2 + 4 + 3 and fw[PR.F16_CONV3X3] == 16 + 1 + 2
+    assert [t.data_ptr() for t in st.fpn] == [t.data_ptr() for t in heads.in_blk["student"]]
+    bw = _count(st.prog, "backward", "sgd")
+    assert bw[PR.GEMM_CONV] == bw[PR.CONV3X3] == bw[PR.CONV3X3_WGRAD] == bw[PR.CONV1X1_WGRAD] == 0
+    assert bw[PR.PW_F16_WGRAD] == 2 * 13 + 3 + 3 and bw[PR.F16_WGRAD] == 13 + 3 + 2
+    # every filter gradient is unscaled by the subnets' 1 / loss-scale, read on the device
+    inv = heads.ls_state.data_ptr() + 4
+    assert {o.p[2] for o in st.prog.ops if o.code == PR.PW_F16_WGRAD} == {inv}
+    assert {o.p[1] for o in st.prog.ops if o.code == PR.F16_WGRAD} == {inv}
+    sgd = [o for o in st.prog.ops if o.code == PR.SGD_FLAT]
+    assert len(sgd) == 1 and sgd[0].p[5] == heads.ls_counters.data_ptr()     # dropped on overflow with the subnets'
+    # the frozen ResNeXt teacher: grouped 3x3 layers, no backward, nothing to train
+    te = NativeResNetFPNF16("x101-64x4d", 1, hw, "cpu", train=False, heads_io=dict(fpn_out=heads.in_blk["teacher"]))
+    cw = _count(te.prog, "forward", "backward")
+    assert cw[PR.GROUPED_F16] == 33 and te.params_flat.numel() == 0 and "sgd" not in te.prog.marks
