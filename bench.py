@@ -324,6 +324,16 @@ def main():
     heads.timing = None
     if args.workload == "full":
         model.timing = None
+    # What enqueueing a step costs the launching thread by itself: with an EMPTY queue (the time spent
+    # inside step() during the timed region above also contains the waits on a full HIP queue -- the
+    # GPU is the bottleneck -- and says nothing about the host)
+    pure = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        step()
+        pure.append(time.perf_counter() - th)
+    torch.cuda.synchronize()
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -351,7 +361,11 @@ def main():
             "metric": METRIC, "value": round(world * N * args.steps / dt, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "host_enqueue_ms_per_step": round(host / args.steps * 1e3, 3), "higher_is_better": True,
+            "host_enqueue_ms_per_step": round(min(pure) * 1e3, 3),
+            "host_enqueue_note": ("launching thread's time to enqueue one whole step into an empty queue; "
+                                  "host_in_step_ms_per_step = time inside step() during the timed region, "
+                                  "which includes blocking on the full HIP queue of a GPU-bound step"),
+            "host_in_step_ms_per_step": round(host / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if not f16 else
                       "f16 storage / f32 accumulate (subnets: this repo's kernels" + (
