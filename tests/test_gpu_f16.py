@@ -404,3 +404,32 @@ def test_f16_dynamic_loss_scale_drops_overflowing_steps(K):
     h.ls_counters[1] = h.LOSS_SCALE_GROWTH_INTERVAL - 1
     h.step(t(fs), t(ft), t(labs), fg_num=torch.tensor([50.0], device=dev), **args)
     assert h.loss_scale == 16384.0 and int(h.ls_counters[1]) == 0
+
+
+def test_f16_pipeline_against_the_cpu_oracle(K):
+    """The fp16-storage subnet iteration against oracle/head_step.py itself (the CPU restatement of
+    the reference graph, fp32), not against another HIP pipeline: flip-proof tower masks
+    (tests/test_gpu_operators.py:make_mask_safe -- an fp16-rounded pre-activation may not change
+    sides), losses within 1e-3, every parameter gradient within 1 % norm-wise (4 % for the first
+    tower layers' filters, whose sums cancel: see test_f16_pipeline_tracks_the_fp32_pipeline)."""
+    from ssad_amd.head_pipeline import DistillHeadsF16
+    from oracle import head_step
+    from test_gpu_operators import mask_safe_problem
+    cfg, S, T, fs, ft, labs, tg, fg = mask_safe_problem(seed=43, N=2)
+    ref = head_step.head_step(S, T, fs, ft, labs, scale=cfg.loss_scale * cfg.temperature ** 2,
+                              loss_scale=cfg.loss_scale, bbox_targets=tg, fg_num=fg)
+    dev = torch.device("cuda", 0)
+    t = lambda arrs: [torch.from_numpy(a).to(dev) for a in arrs]
+    shapes = [tuple(f.shape[2:]) for f in fs]
+    h = DistillHeadsF16(cfg, N=fs[0].shape[0], shapes=shapes, device=dev, student_init=S, teacher_init=T)
+    h.step(t(fs), t(ft), t(labs), update=False, bbox_targets=[tuple(t(p)) for p in tg],
+           fg_num=torch.from_numpy(fg).to(dev))
+    torch.cuda.synchronize()
+    for got, want in ((h.losses, ref["losses"]), (h.focal_losses, ref["focal_losses"]), (h.bbox_losses, ref["bbox_losses"])):
+        got = got.cpu().numpy().astype(np.float64)
+        assert np.all(np.abs(got - want) <= 1e-3 * np.abs(want) + 1e-9), (got, want)
+    rel = lambda a, b: np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30)
+    errs = {k: rel(h.grads[k].cpu().numpy(), g.astype(np.float64)) for k, g in ref["grads"].items()}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    for k, e in errs.items():
+        assert e < (4e-2 if "conv_n0" in k and k.endswith("_w") else 1e-2), worst
