@@ -67,6 +67,8 @@ struct PwF16 {
   int Hi, Wi, stride;    // input map; output (y, x) reads input (stride y, stride x)
   int relu, res_up;
   int mblocks;           // ceil(M / 128)
+  int stages;            // LDS ring depth (2 .. Geo::S): min(chunks + 1, Geo::S) -- a short K takes less LDS,
+                         // so more workgroups are resident to cover the fetch latency
   long long total;       // N * Ho * Wo
 };
 
@@ -155,19 +157,21 @@ __global__ __launch_bounds__(kThreads, 2) void pw_f16_kernel(const PwF16 p) {
       for (int r = 0; r < 16; ++r) acc[i][tt][r] = 0.0f;
 
   const int nchunks = (CB + CBC - 1) / CBC;
-  constexpr int D = G::S - 1;                              // chunks in flight
-#pragma unroll
+  const int S = p.stages, D = S - 1;                       // ring depth, chunks in flight (wave-uniform)
   for (int c = 0; c < D; ++c)
     if (c < nchunks) fetch(c, c);
+  int slot = 0;                                            // c % S
   for (int c = 0; c < nchunks; ++c) {
     // chunk c has landed when at most the operations of the chunks issued after it are outstanding
     // (vector memory retires in order).  Near the end fewer chunks are behind it: wait for all.
-    if (c + D - 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * G::OPS) : "memory");
+    if (c + D - 1 < nchunks && D == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::OPS) : "memory");
+    else if (c + D - 1 < nchunks && D == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::OPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // the stage of chunk c - 1 is free (every wave is past the barrier): refill it
-    if (c + D < nchunks) fetch(c + D, (c + D) % G::S);
-    const uint4* st = lds + (c % G::S) * G::STAGE;
+    if (c + D < nchunks) fetch(c + D, slot == 0 ? S - 1 : slot - 1);      // (c + D) % S = (c - 1) % S
+    const uint4* st = lds + slot * G::STAGE;
+    slot = slot + 1 == S ? 0 : slot + 1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       half8 a[2], b[G::NT];
@@ -397,12 +401,14 @@ int cu_count() {
 }
 
 template <int PT>
-int launch_pw(const PwF16& p, hipStream_t s) {
+int launch_pw(PwF16 p, hipStream_t s) {
   using G = Geo<PT>;
   const long long tiles = (p.total + PT - 1) / PT;
   const long long wgs = (tiles + 7) / 8 * 8 * p.mblocks;
   if (wgs >= (1LL << 31)) return SSAD_E_BADARG;
-  const size_t lds_bytes = (size_t)G::S * G::STAGE * 16;
+  const int nchunks = (((p.C + 7) >> 3) + CBC - 1) / CBC;
+  p.stages = nchunks + 1 < G::S ? (nchunks + 1 < 2 ? 2 : nchunks + 1) : G::S;
+  const size_t lds_bytes = (size_t)p.stages * G::STAGE * 16;
   static const bool attr = [] {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(pw_f16_kernel<PT, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)G::S * G::STAGE * 16)) ==
@@ -464,8 +470,9 @@ int ssad_conv1x1_f16(const ssad_pw_f16* d, ssad_stream_t stream) {
     return SSAD_E_BADARG;
   // 256-pixel tiles unless they leave the chip under-filled (two workgroups per CU are resident)
   static const int cus = cu_count();
+  static const int force = [] { const char* e = getenv("SSAD_PW_F16_PT"); return e ? atoi(e) : 0; }();   // tuning
   const long long wg256 = ((p.total + 255) / 256) * p.mblocks;
-  if (wg256 >= 2LL * cus) return launch_pw<256>(p, (hipStream_t)stream);
+  if (force == 256 || (force != 128 && wg256 >= 2LL * cus)) return launch_pw<256>(p, (hipStream_t)stream);
   return launch_pw<128>(p, (hipStream_t)stream);
 }
 
