@@ -105,7 +105,7 @@ class NativeResNetFPNF16(NativeResNetFPN):
                     p=(arr, self.inv_scale, layer.gw, layer.gb, None),
                     work=2.0 * 9 * layer.cout * layer.cin * x.shape[0] * x.shape[2] * x.shape[3], keep=[x, dy],
                     stream=self._wstream)
-        self._ws_ops.append((idx, 4))
+        self._ws_ops.append((idx, 4, self._wstream))
 
     def _wg1(self, P, x, dy, layer):
         N, H, W = x.shape[0], x.shape[2], x.shape[3]
@@ -115,14 +115,20 @@ class NativeResNetFPNF16(NativeResNetFPN):
         idx = P.add(PR.PW_F16_WGRAD, KL_W1, i=(N, layer.cin, H, W, layer.cout, 0), f=(1.0,), l=(nb,),
                     p=(x, dy, self.inv_scale, layer.gw, layer.gb, None),
                     work=2.0 * N * H * W * layer.cin * layer.cout, keep=[x, dy], stream=self._wstream)
-        self._ws_ops.append((idx, 5))
+        self._ws_ops.append((idx, 5, self._wstream))
 
     # -- program construction --------------------------------------------------------------------
     def _build(self):
         import os
         self._ws_need, self._ws_ops = 0, []
         ov = self._overlap_wgrad
-        self._wstream = 1 if (os.environ.get("SSAD_OVERLAP_WGRAD", "1") == "1" if ov is None else ov) else 0
+        on = os.environ.get("SSAD_OVERLAP_WGRAD", "1") == "1" if ov is None else ov
+        # filter / bias gradients go round-robin over this many auxiliary streams (each with its own
+        # workspace): the small reduce launch that ends one filter gradient then runs beside the next
+        # one's main kernel instead of in front of it
+        nws = max(1, min(3, int(os.environ.get("SSAD_WGRAD_STREAMS", "2"))))
+        self._wstreams = list(range(1, nws + 1)) if on else [0]
+        self._wstream, self._wnext = self._wstreams[0], 0
         L, dev, lib = self._layers, self.device, K.lib()
         inv = self._io.get("inv_scale")
         self.inv_scale = inv if inv is not None else torch.ones(1, dtype=torch.float32, device=dev)
@@ -170,9 +176,10 @@ class NativeResNetFPNF16(NativeResNetFPN):
                   work=4.0 * 6 * self.params_flat.numel(),
                   keep=[s2 for (_, _, _, _, s2) in self.segments if s2 is not None])
         P.mark("end")
-        self.ws = torch.empty(max(self._ws_need, 16), dtype=torch.uint8, device=dev)
-        for idx, slot in self._ws_ops:
-            P.set_ptr(idx, slot, self.ws)
+        self.wss = {k: torch.empty(max(self._ws_need, 16), dtype=torch.uint8, device=dev) for k in self._wstreams}
+        self.ws = self.wss[self._wstreams[0]]
+        for idx, slot, k in self._ws_ops:
+            P.set_ptr(idx, slot, self.wss[k])
         P.build()
 
     # -- forward -----------------------------------------------------------------------------------

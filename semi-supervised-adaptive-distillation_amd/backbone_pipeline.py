@@ -257,7 +257,8 @@ class NativeResNetFPN(object):
         reads before it writes shows up as NaN in the results)."""
         for t in self._bufs:
             t.fill_(value)
-        self.ws.view(torch.float32)[: self.ws.numel() // 4].fill_(value)
+        for w in self.wss.values():
+            w.view(torch.float32)[: w.numel() // 4].fill_(value)
         self._packed_frozen = False
 
     def _gemm(self, P, a, lda, x, y, Kc, M, bias=None, res=None, mask=None, relu=False, acc=False, klass=50):
@@ -288,7 +289,7 @@ class NativeResNetFPN(object):
                     p=(arr, layer.gw, layer.gb, None),
                     work=2.0 * 9 * layer.cout * layer.cin * x.shape[0] * x.shape[2] * x.shape[3], keep=[x, dy],
                     stream=self._wstream)
-        self._ws_ops.append((idx, 3))
+        self._ws_ops.append((idx, 3, self._wstream))
 
     def _wgrad1(self, P, x, dy, layer):
         N, Cc = x.shape[0], x.shape[1]
@@ -299,7 +300,7 @@ class NativeResNetFPN(object):
         idx = P.add(PR.CONV1X1_WGRAD, 52, i=(N, Cc, pix, layer.cout, 0), l=(nb,),
                     p=(x, dy, layer.gw, None), work=2.0 * N * pix * Cc * layer.cout, keep=[x, dy],
                     stream=self._wstream)
-        self._ws_ops.append((idx, 3))
+        self._ws_ops.append((idx, 3, self._wstream))
 
     def _bias_grad(self, P, dz, layer, rowsum=None):
         """db[c] = sum over n, pixels of dz; from the [N][C] plane sums when a ReluGradient pass
@@ -325,6 +326,8 @@ class NativeResNetFPN(object):
         share one workspace, which is safe because they are serialised on that one stream; nothing
         they read is modified by the main stream before the segment's JOIN (gradients that meet are
         written to fresh buffers, not accumulated in place)."""
+        self._wstream = self._wstreams[self._wnext % len(self._wstreams)]
+        self._wnext += 1
         if self._wstream:
             P.fork(self._wstream)
 
@@ -336,7 +339,13 @@ class NativeResNetFPN(object):
         self._ws_need, self._ws_ops = 0, []
         import os
         ov = self._overlap_wgrad
-        self._wstream = 1 if (os.environ.get("SSAD_OVERLAP_WGRAD", "1") == "1" if ov is None else ov) else 0
+        on = os.environ.get("SSAD_OVERLAP_WGRAD", "1") == "1" if ov is None else ov
+        # filter / bias gradients go round-robin over this many auxiliary streams (each with its own
+        # workspace): the small reduce launch that ends one filter gradient then runs beside the next
+        # one's main kernel instead of in front of it
+        nws = max(1, min(3, int(os.environ.get("SSAD_WGRAD_STREAMS", "2"))))
+        self._wstreams = list(range(1, nws + 1)) if on else [0]
+        self._wstream, self._wnext = self._wstreams[0], 0
         L = self._layers
         dev = self.device
         lib = K.lib()
@@ -390,9 +399,10 @@ class NativeResNetFPN(object):
                   work=4.0 * 6 * self.params_flat.numel(),
                   keep=[s2 for (_, _, _, _, s2) in self.segments if s2 is not None])
         P.mark("end")
-        self.ws = torch.empty(max(self._ws_need, 16), dtype=torch.uint8, device=dev)
-        for idx, slot in self._ws_ops:
-            P.set_ptr(idx, slot, self.ws)
+        self.wss = {k: torch.empty(max(self._ws_need, 16), dtype=torch.uint8, device=dev) for k in self._wstreams}
+        self.ws = self.wss[self._wstreams[0]]
+        for idx, slot, k in self._ws_ops:
+            P.set_ptr(idx, slot, self.wss[k])
         P.build()
 
     # -- forward ----------------------------------------------------------------------------------------

@@ -142,7 +142,7 @@ def test_native_distill_model_step_matches_composed_reference_and_is_race_free()
     cfg, images, ref_s, ref_t, S, T, labs, tg, fg = _problem()
     labels, targets, fg_num = _inputs(labs, tg, fg)
     model = _model(cfg, ref_s, ref_t, S, T, overlap=True)
-    assert model.side is not None and model.student._wstream == 1 and model.heads._wstream == 1
+    assert model.side is not None and model.student._wstreams == [1, 2] and model.heads._wstream == 1
     assert any(s2 is not None for (_, _, _, _, s2) in model.student.segments)      # the folded c3 scales
     h, st = model.heads, model.student
 
@@ -195,7 +195,7 @@ def test_overlapped_and_serial_execution_agree_bit_for_bit():
     labels, targets, fg_num = _inputs(labs, tg, fg)
     a = _model(cfg, ref_s, ref_t, S, T, overlap=True)
     b = _model(cfg, ref_s, ref_t, S, T, overlap=False)
-    assert a.side is not None and b.side is None and b.student._wstream == 0 and b.heads._wstream == 0
+    assert a.side is not None and b.side is None and b.student._wstreams == [0] and b.heads._wstream == 0
     for it in range(3):
         for m in (a, b):
             if it == 0:
