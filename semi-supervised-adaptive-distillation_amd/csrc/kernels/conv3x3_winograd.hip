@@ -149,6 +149,7 @@ struct WArgs {
   int n_levels;
   int M, K, chunks, flags;
   int patches, mblocks;   // persistent variant: tiles = patches x mblocks
+  int xcd_group;          // consecutive tiles per XCD inside a round of the grid (1 = round robin)
 };
 
 __global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) {
@@ -431,7 +432,23 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int total = args.patches * args.mblocks;
-  const int my_n = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  // Which tiles a workgroup walks: round i of the grid covers tiles [i G, (i + 1) G); inside a round
+  // the workgroups of ONE XCD (ids b, b + 8, ...: they share an L2) take runs of `xg` CONTIGUOUS
+  // tiles, i.e. patches that are neighbours in x (and, for long runs, in y).  A patch row is 18
+  // floats = 72 bytes at a 64-byte stride: it straddles two 128-byte lines that its x neighbours use
+  // too, and 2 of its 10 rows belong to the patch above.  With neighbours on different XCDs (round 2:
+  // xg = 1, tile = id + i G) every XCD fetched its own copy of those lines -- the counters showed
+  // 60 M line fills per tower launch where the input is 6 M lines (profiles/r03_tcc_classes.md).
+  const int G = (int)gridDim.x;
+  int slot = (int)blockIdx.x;
+  {
+    const int xg = args.xcd_group;
+    if (xg > 1 && (G & 7) == 0 && ((G >> 3) % xg) == 0) {
+      const int r = slot >> 3, x = slot & 7;
+      slot = (r / xg) * (8 * xg) + x * xg + (r % xg);
+    }
+  }
+  const int my_n = total > slot ? (total - slot + G - 1) / G : 0;
   const int S = my_n * chunks;     // flattened (tile, chunk) sequence length
   // static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves
   // per SIMD, item 4): waves 4-7 lose VALU arbitration to their older SIMD partners on every chunk;
@@ -451,7 +468,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   }
   __syncthreads();
   for (int i = tid; i < my_n; i += kBlock) {
-    const int t = (int)blockIdx.x + i * (int)gridDim.x;
+    const int t = slot + i * G;
     const int mb = t / args.patches;
     int pid = t - mb * args.patches;
     int l = -1;
@@ -918,10 +935,12 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
     if (total >= (1LL << 31)) return SSAD_E_BADARG;
     long long grid = total < cus2 ? total : cus2;
     if (grid * ZNT < total) grid = (total + ZNT - 1) / ZNT;
-    static const int nt = [] { const char* e = getenv("SSAD_WINO_NT"); return e ? atoi(e) & 3 : 0; }();
-    if (nt == 3) hipLaunchKernelGGL(wino_conv_z_kernel<3>, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
-    else if (nt == 2) hipLaunchKernelGGL(wino_conv_z_kernel<2>, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
-    else if (nt == 1) hipLaunchKernelGGL(wino_conv_z_kernel<1>, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    // SSAD_WINO_NT=2: non-temporal output stores (tuning; measured +-0).  SSAD_WINO_XCD_GROUP: tiles per
+    // XCD run (1 = round 2's round-robin order)
+    static const int nt = [] { const char* e = getenv("SSAD_WINO_NT"); return e ? atoi(e) & 2 : 0; }();
+    static const int xg = [] { const char* e = getenv("SSAD_WINO_XCD_GROUP"); return e ? atoi(e) : 8; }();
+    a.xcd_group = xg;
+    if (nt == 2) hipLaunchKernelGGL(wino_conv_z_kernel<2>, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(wino_conv_z_kernel<0>, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
   }
