@@ -133,13 +133,21 @@ def main():
             e["MfmaUtil_pct"] = round(100.0 * e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 2)
         if e.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_ANY" in e:
             e["wait_inst_any_pct"] = round(100.0 * e["SQ_WAIT_INST_ANY"] / e["SQ_WAVE_CYCLES"], 1)
+        if "TCC_HIT_sum" in e and "TCC_MISS_sum" in e:
+            e["l2_hit_pct"] = round(100.0 * e["TCC_HIT_sum"] / max(e["TCC_HIT_sum"] + e["TCC_MISS_sum"], 1.0), 1)
+        if "TCC_EA0_RDREQ_sum" in e:
+            # every fabric read request of these kernels is a 128-byte line fill (TCC_EA0_RDREQ_32B = 0;
+            # PowSum: 4.30 M requests for 550 MB)
+            e["l2_fill_bytes"] = 128.0 * e["TCC_EA0_RDREQ_sum"]
     doc = {"workload": "python bench.py --workload heads%s (bs 16, 600 px), per-dispatch averages by timing class "
                        "(ssad_amd/program.py: KLASS)" % (" --precision f16" if f16 else ""),
            "attribution": notes, "classes": {str(k): merged[k] for k in sorted(merged)}}
     if out_path:
         json.dump(doc, open(out_path, "w"), indent=1, sort_keys=True)
     lines = ["# Counters of the timed launches, by timing class", "", doc["workload"], ""] + ["* " + n for n in notes]
-    cols = ["hbm_read_bytes", "hbm_write_bytes", "MfmaUtil_pct", "wait_inst_any_pct", "SQ_LDS_BANK_CONFLICT"]
+    cols = ["hbm_read_bytes", "hbm_write_bytes", "MfmaUtil_pct", "wait_inst_any_pct", "SQ_LDS_BANK_CONFLICT",
+            "l2_hit_pct", "l2_fill_bytes"]
+    cols = [c for c in cols if any(c in e for e in merged.values())]
     lines += ["", "| class | kernel | " + " | ".join(cols) + " |", "|---|---|" + "---|" * len(cols)]
     for k in sorted(merged):
         e = merged[k]

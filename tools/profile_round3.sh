@@ -41,8 +41,15 @@ if [ "$WHAT" = "pmc" ] || [ "$WHAT" = "all" ]; then
   pmc pmc_write WRITE_SIZE -- --workload heads
   pmc pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT -- --workload heads
   pmc pmc_wait SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAVES -- --workload heads
+  pmc pmc_tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -- --workload heads
   python tools/pmc_by_class.py --out $O/pmc_classes.json --md $O/pmc_classes.md \
       fetch=$(ls /tmp/prof_pmc_fetch/*.db | head -1) write=$(ls /tmp/prof_pmc_write/*.db | head -1) \
-      mfma=$(ls /tmp/prof_pmc_mfma/*.db | head -1) wait=$(ls /tmp/prof_pmc_wait/*.db | head -1) > /dev/null 2> $O/pmc_classes.err
+      mfma=$(ls /tmp/prof_pmc_mfma/*.db | head -1) wait=$(ls /tmp/prof_pmc_wait/*.db | head -1) \
+      tcc=$(ls /tmp/prof_pmc_tcc/*.db | head -1) > /dev/null 2> $O/pmc_classes.err
+  # the same passes with round 2's round-robin work order (A/B of the XCD-aware order)
+  SSAD_WINO_XCD_GROUP=1 SSAD_WGRAD_XCD_GROUP=1 pmc pmc_fetch_rr FETCH_SIZE -- --workload heads
+  SSAD_WINO_XCD_GROUP=1 SSAD_WGRAD_XCD_GROUP=1 pmc pmc_tcc_rr TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -- --workload heads
+  python tools/pmc_by_class.py --out $O/pmc_classes_roundrobin.json --md $O/pmc_classes_roundrobin.md \
+      fetch=$(ls /tmp/prof_pmc_fetch_rr/*.db | head -1) tcc=$(ls /tmp/prof_pmc_tcc_rr/*.db | head -1) > /dev/null 2>> $O/pmc_classes.err
 fi
 ls -la $O
