@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "conv_internal.h"
 #include "ssad_kernels.h"
 
 namespace {
@@ -286,13 +287,7 @@ int ssad_conv1x1_bias_act2(const float* x, int C1, const float* x2, int C2, cons
     a.ptiles = (P + PT - 1) / PT;
     const long long tiles = (long long)N * a.ptiles;
     if (tiles >= (1LL << 31)) return SSAD_E_BADARG;
-    static const int cus = [] {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
-        n = 256;
-      return n;
-    }();
+    const int cus = ssad_cu_count();
     const int mblocks = M / TM;
     const int per_cu = C == 64 ? 2 : 1;
     long long g = ((long long)per_cu * cus + mblocks - 1) / mblocks;

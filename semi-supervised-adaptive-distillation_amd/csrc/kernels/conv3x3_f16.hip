@@ -971,13 +971,7 @@ int wgrad_splits(int blocks, int stages, int rows = 3) {
   // CUs take three rounds where 504 take two -- and ONE round measures best (tower layer, all
   // levels: 0.424 / 0.449 / 0.485 / 0.523 ms for 1 / 2 / 3 / 4 rounds: the per-workgroup prologue
   // and the 2.4 MB of partial sums per split are not hidden at this occupancy)
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
-      n = 256;
-    return n;
-  }();
+  const int cus = ssad_cu_count();
   static const int rounds = getenv("SSAD_F16_WGRAD_ROUNDS") ? atoi(getenv("SSAD_F16_WGRAD_ROUNDS")) : 1;
   int s = (rounds * cus) / (rows * blocks);    // whole rounds; x 3 filter rows (1 for a pointwise layer)
   if (s > stages) s = stages;

@@ -399,13 +399,7 @@ int plan(const ssad_conv_level* lv, int n_levels, int Cout, int Cin, GArgs* a) {
   a->total_units = (int)units;
   // splits: minimise rounds(S) x units-per-split(S) on the chip's CUs (all
   // workgroups cost the same), at least 8 units per split, smallest S on ties
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    return n;
-  }();
+  const int cus = ssad_cu_count();
   const int oblocks = a->mblocks * a->cblocks;
   int s = 1;
   long long best = -1;

@@ -924,13 +924,7 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
   a.patches = (int)blocks; a.mblocks = cdiv(Cout, BM);
   static const int variant = [] { const char* e = getenv("SSAD_WINO_VARIANT"); return e ? atoi(e) : 2; }();
   if (variant == 2) {   // any Cin: channels past Cin read as zero (buffer range check, zero-padded filter)
-    static const int cus2 = [] {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-        n = 256;
-      return n;
-    }();
+    const int cus2 = ssad_cu_count();
     const long long total = blocks * a.mblocks;
     if (total >= (1LL << 31)) return SSAD_E_BADARG;
     long long grid = total < cus2 ? total : cus2;

@@ -16,6 +16,19 @@ int ssad_wino_wgrad_launch(const ssad_conv_level* lv, int n_levels, float* dW, i
                            int accumulate, void* workspace, size_t workspace_bytes,
                            hipStream_t stream);
 
+// Compute units of the CURRENT device (cached per device: a process may drive several GPUs, and
+// workspace sizing and launch must agree on the same device's count).
+inline int ssad_cu_count() {
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cache[dev] > 0) return cache[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+  cache[dev] = n;
+  return n;
+}
+
 namespace ssad_dev {
 
 // Buffer descriptor from values the compiler must treat as wave-uniform: every

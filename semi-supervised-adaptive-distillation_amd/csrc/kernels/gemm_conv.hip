@@ -472,13 +472,7 @@ __global__ __launch_bounds__(kThreads) void subsample_grad_kernel(const float* _
 }
 
 int pick_splits(int tiles, int chunks) {
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    return n;
-  }();
+  const int cus = ssad_cu_count();
   // about three workgroups per CU, at least 8 chunks (128 columns) each
   int s = (3 * cus + tiles - 1) / tiles;
   const int cap = chunks / 8 > 0 ? chunks / 8 : 1;
@@ -511,13 +505,7 @@ int ssad_conv1x1_gemm(const ssad_gemm_conv* d, ssad_stream_t stream) {
   // 64-row tiles for 64-wide outputs, and wherever 128-row tiles would leave the chip with
   // fewer than two workgroups per CU (res5 at bs 16 is 70 column tiles: 280 tiles of 128 rows
   // put two workgroups on 24 CUs and one on the rest, i.e. the launch takes twice its share)
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    return n;
-  }();
+  const int cus = ssad_cu_count();
   static const int force_bm = [] { const char* e = getenv("SSAD_GEMM_BM"); return e ? atoi(e) : 0; }();
   // (measured: the 64-row tile runs within a few % of the 128-row one on large problems and
   // quantises better on mid-sized ones, so it is the default below ~6 tiles of 128 rows per CU)

@@ -392,14 +392,6 @@ inline unsigned grid_for(long long n) {
   return (unsigned)(b < 1 ? 1 : (b > 65535 * 8 ? 65535 * 8 : b));
 }
 
-int cu_count() {
-  int dev = 0, n = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
-    n = 256;
-  return n;
-}
-
 template <int PT>
 int launch_pw(PwF16 p, hipStream_t s) {
   using G = Geo<PT>;
@@ -469,7 +461,7 @@ int ssad_conv1x1_f16(const ssad_pw_f16* d, ssad_stream_t stream) {
       (long long)d->N * (d->M >> 3) * d->Ho * d->Wo * 16 >= (1LL << 31) || (long long)(CB + CBC) * d->M * 16 >= (1LL << 31))
     return SSAD_E_BADARG;
   // 256-pixel tiles unless they leave the chip under-filled (two workgroups per CU are resident)
-  static const int cus = cu_count();
+  const int cus = ssad_cu_count();
   static const int force = [] { const char* e = getenv("SSAD_PW_F16_PT"); return e ? atoi(e) : 0; }();   // tuning
   const long long wg256 = ((p.total + 255) / 256) * p.mblocks;
   if (force == 256 || (force != 128 && wg256 >= 2LL * cus)) return launch_pw<256>(p, (hipStream_t)stream);
