@@ -62,6 +62,14 @@ bool IsSubnetGeometry(const ConvGeometry& g) {
          g.pads == vector<int>{1, 1, 1, 1};
 }
 
+// A pointwise layer the fp16 GEMM kernel takes (gemm_f16.hip): 1x1, no padding, no dilation, one
+// group, equal strides 1 or 2 -- the bottleneck 1x1s, projection shortcuts and FPN laterals.
+bool IsPointwiseF16Geometry(const ConvGeometry& g) {
+  return g.order == "NCHW" && g.group == 1 && g.kernel == vector<int>{1, 1} &&
+         g.dilation == vector<int>{1, 1} && g.pads == vector<int>{0, 0, 0, 0} &&
+         g.stride[0] == g.stride[1] && (g.stride[0] == 1 || g.stride[0] == 2);
+}
+
 bool IsDefaultEngineGeometry(const ConvGeometry& g) {
   return g.order == "NCHW" && g.group >= 1 && g.kernel.size() == 2;
 }
@@ -86,6 +94,10 @@ template <>
 bool ConvGradientOp<float, HIPContext>::RunDefaultEngine();
 template <>
 bool ConvOp<float, HIPContext>::RunFloat16();
+template <>
+bool ConvOp<float, HIPContext>::RunFloat16Pointwise();
+template <>
+bool ConvGradientOp<float, HIPContext>::RunFloat16Pointwise();
 template <>
 bool ConvGradientOp<float, HIPContext>::RunFloat16();
 
@@ -418,8 +430,10 @@ bool ConvOp<float, HIPContext>::RunFloat16() {
   auto& X = Input(INPUT);
   auto& filter = Input(FILTER);
   auto* Y = Output(0);
+  if (IsPointwiseF16Geometry(geom_)) return RunFloat16Pointwise();
   CAFFE_ENFORCE(IsSubnetGeometry(geom_),
-                "float16 Conv: the HIP engine implements kernel 3, stride 1, pad 1, group 1, NCHW");
+                "float16 Conv: the HIP engines implement kernel 3 / stride 1 / pad 1 and kernel 1 / stride 1|2 / "
+                "pad 0 (group 1, NCHW)");
   CAFFE_ENFORCE(filter.IsType<float16>(), "float16 Conv: the filter must be float16 too");
   CAFFE_ENFORCE_EQ(X.ndim(), 4);
   CAFFE_ENFORCE_EQ(filter.ndim(), 4);
@@ -474,8 +488,10 @@ bool ConvGradientOp<float, HIPContext>::RunFloat16() {
   auto& filter = Input(FILTER);
   auto& dY = Input(OUTPUT_GRAD);
   auto* dfilter = Output(FILTER_GRAD);
+  if (IsPointwiseF16Geometry(geom_)) return RunFloat16Pointwise();
   CAFFE_ENFORCE(IsSubnetGeometry(geom_),
-                "float16 ConvGradient: the HIP engine implements kernel 3, stride 1, pad 1, group 1, NCHW");
+                "float16 ConvGradient: the HIP engines implement kernel 3 / stride 1 / pad 1 and kernel 1 / "
+                "stride 1|2 / pad 0 (group 1, NCHW)");
   CAFFE_ENFORCE(filter.IsType<float16>() && dY.IsType<float16>(),
                 "float16 ConvGradient: filter and output gradient must be float16 too");
   CAFFE_ENFORCE(!relu_grad_on_input_, "relu_grad_on_input is an extension of the fp32 3x3 engine");
@@ -537,6 +553,134 @@ bool ConvGradientOp<float, HIPContext>::RunFloat16() {
                        "float16 ConvGradient (data) launch failed");
       CAFFE_ENFORCE_EQ(ssad_cast_f32_to_f16(out.data<float>(), dx, X.size(), s), 0);
     }
+  }
+  return true;
+}
+
+// float16 blobs, pointwise layer (the backbones' 1x1 convolutions under CudnnConvOp<float16>,
+// conv_op_cudnn.cc:631-636): NCHW fp16 -> channel-blocked -> pw_f16_kernel -> NCHW fp16.
+template <>
+bool ConvOp<float, HIPContext>::RunFloat16Pointwise() {
+  auto& X = Input(INPUT);
+  auto& filter = Input(FILTER);
+  auto* Y = Output(0);
+  CAFFE_ENFORCE(filter.IsType<float16>(), "float16 Conv: the filter must be float16 too");
+  CAFFE_ENFORCE_EQ(X.ndim(), 4);
+  CAFFE_ENFORCE_EQ(filter.ndim(), 4);
+  const int N = X.dim32(0), C = X.dim32(1), H = X.dim32(2), W = X.dim32(3);
+  const int M = filter.dim32(0), st = geom_.stride[0];
+  CAFFE_ENFORCE(C == filter.dim32(1) && filter.dim32(2) == 1 && filter.dim32(3) == 1);
+  CAFFE_ENFORCE(M % 8 == 0, "float16 pointwise Conv: the output width must be a multiple of 8 channels");
+  const int OH = (H - 1) / st + 1, OW = (W - 1) / st + 1;
+  hipStream_t s = context_.hip_stream();
+  auto& wf32 = f16_scratch_[0];
+  wf32.Resize((TIndex)filter.size());
+  CAFFE_ENFORCE_EQ(ssad_cast_f16_to_f32(filter.raw_data(), wf32.mutable_data<float>(), filter.size(), s), 0);
+  packed_filter_.Resize((TIndex)((ssad_pw_f16_filter_halves(M, C) + 1) / 2));
+  float* packed = packed_filter_.mutable_data<float>();
+  CAFFE_ENFORCE_EQ(ssad_pw_f16_pack_filter(wf32.data<float>(), M, C, packed, nullptr, s), 0);
+  const float* bias = nullptr;
+  if (InputSize() == 3) {
+    auto& b = Input(BIAS);
+    CAFFE_ENFORCE(b.IsType<float16>() && b.ndim() == 1 && b.dim32(0) == M);
+    auto& b32 = f16_scratch_[1];
+    b32.Resize(M);
+    CAFFE_ENFORCE_EQ(ssad_cast_f16_to_f32(b.raw_data(), b32.mutable_data<float>(), M, s), 0);
+    bias = b32.data<float>();
+  }
+  auto& xb = f16_scratch_[2];
+  auto& yb = f16_scratch_[3];
+  xb.Resize((TIndex)((BlockedHalves(N, C, H, W) + 1) / 2));
+  yb.Resize((TIndex)((BlockedHalves(N, M, OH, OW) + 1) / 2));
+  CAFFE_ENFORCE_EQ(ssad_f16_block_activations(X.raw_data(), N, C, H, W, xb.mutable_data<float>(), s), 0);
+  const ssad_pw_f16 d{xb.data<float>(), packed, bias, nullptr, nullptr, yb.mutable_data<float>(),
+                      N, C, M, OH, OW, H, W, st, fuse_relu_ ? SSAD_CONV_RELU : 0};
+  CAFFE_ENFORCE_EQ(ssad_conv1x1_f16(&d, s), 0, "float16 pointwise Conv launch failed");
+  Y->Resize(N, M, OH, OW);
+  CAFFE_ENFORCE_EQ(ssad_f16_unblock_activations(yb.data<float>(), N, M, OH, OW,
+                                                Y->raw_mutable_data(TypeMeta::Make<float16>()), s), 0);
+  return true;
+}
+
+// float16 blobs, pointwise layer, gradient (conv_op_impl.h:451-560 for a 1x1 kernel): dfilter / dbias
+// summed in fp32 and stored as fp16, dX = W^T dY; a stride-2 layer is the stride-1 layer on the
+// subsampled input, its dX scattered back to the even positions.
+template <>
+bool ConvGradientOp<float, HIPContext>::RunFloat16Pointwise() {
+  auto& X = Input(INPUT);
+  auto& filter = Input(FILTER);
+  auto& dY = Input(OUTPUT_GRAD);
+  auto* dfilter = Output(FILTER_GRAD);
+  CAFFE_ENFORCE(filter.IsType<float16>() && dY.IsType<float16>(),
+                "float16 ConvGradient: filter and output gradient must be float16 too");
+  CAFFE_ENFORCE(!relu_grad_on_input_, "relu_grad_on_input is an extension of the fp32 3x3 engine");
+  const int N = X.dim32(0), C = X.dim32(1), H = X.dim32(2), W = X.dim32(3);
+  const int M = filter.dim32(0), st = geom_.stride[0];
+  CAFFE_ENFORCE(C == filter.dim32(1) && filter.dim32(2) == 1 && filter.dim32(3) == 1);
+  const int OH = (H - 1) / st + 1, OW = (W - 1) / st + 1;
+  CAFFE_ENFORCE(dY.ndim() == 4 && dY.dim32(0) == N && dY.dim32(1) == M && dY.dim32(2) == OH && dY.dim32(3) == OW,
+                "output gradient shape does not match the convolution output");
+  hipStream_t s = context_.hip_stream();
+  auto& xb = f16_scratch_[0];
+  auto& dyb = f16_scratch_[1];
+  xb.Resize((TIndex)((BlockedHalves(N, C, H, W) + 1) / 2));
+  dyb.Resize((TIndex)((BlockedHalves(N, M, OH, OW) + 1) / 2));
+  CAFFE_ENFORCE_EQ(ssad_f16_block_activations(X.raw_data(), N, C, H, W, xb.mutable_data<float>(), s), 0);
+  CAFFE_ENFORCE_EQ(ssad_f16_block_activations(dY.raw_data(), N, M, OH, OW, dyb.mutable_data<float>(), s), 0);
+  const float* xs = xb.data<float>();
+  CAFFE_ENFORCE(st == 1 || (H % st == 0 && W % st == 0),
+                "float16 pointwise ConvGradient: a strided layer needs an input map that is a multiple of the stride");
+  if (st > 1) {                                 // the strided layer's view of its input
+    auto& sub = f16_scratch_[6];
+    sub.Resize((TIndex)((BlockedHalves(N, C, OH, OW) + 1) / 2));
+    CAFFE_ENFORCE_EQ(ssad_f16_elementwise(0, xb.data<float>(), nullptr, sub.mutable_data<float>(), N, C, OH, OW, st,
+                                          0, s), 0);
+    xs = sub.data<float>();
+  }
+  auto& dw32 = f16_scratch_[2];
+  auto& db32 = f16_scratch_[3];
+  dw32.Resize((TIndex)filter.size());
+  db32.Resize(M);
+  const size_t wsb = ssad_conv1x1_wgrad_f16_workspace_bytes(N, C, OH, OW, M);
+  workspace_.Resize((TIndex)wsb);
+  CAFFE_ENFORCE_EQ(ssad_conv1x1_wgrad_f16(xs, dyb.data<float>(), N, C, OH, OW, M, 0, 1.0f, nullptr,
+                                          dw32.mutable_data<float>(), no_bias_ ? nullptr : db32.mutable_data<float>(),
+                                          workspace_.mutable_data<uint8_t>(), wsb, s),
+                   0, "float16 pointwise ConvGradient (filter) launch failed");
+  dfilter->ResizeLike(filter);
+  CAFFE_ENFORCE_EQ(ssad_cast_f32_to_f16(dw32.data<float>(), dfilter->raw_mutable_data(TypeMeta::Make<float16>()),
+                                        filter.size(), s), 0);
+  if (!no_bias_) {
+    auto* dbias = Output(BIAS_OR_INPUT_GRAD);
+    dbias->Resize(M);
+    CAFFE_ENFORCE_EQ(ssad_cast_f32_to_f16(db32.data<float>(), dbias->raw_mutable_data(TypeMeta::Make<float16>()),
+                                          M, s), 0);
+  }
+  if (OutputSize() == 3 || (no_bias_ && OutputSize() == 2)) {
+    CAFFE_ENFORCE(C % 8 == 0, "float16 pointwise ConvGradient: the input width must be a multiple of 8 channels");
+    auto* dX = Output(no_bias_ ? BIAS_OR_INPUT_GRAD : INPUT_GRAD);
+    dX->ResizeLike(X);
+    auto& wf32 = f16_scratch_[4];
+    wf32.Resize((TIndex)filter.size());
+    CAFFE_ENFORCE_EQ(ssad_cast_f16_to_f32(filter.raw_data(), wf32.mutable_data<float>(), filter.size(), s), 0);
+    packed_filter_.Resize((TIndex)((ssad_pw_f16_filter_halves(M, C) + 1) / 2));
+    float* packed = packed_filter_.mutable_data<float>();
+    CAFFE_ENFORCE_EQ(ssad_pw_f16_pack_filter(wf32.data<float>(), M, C, nullptr, packed, s), 0);
+    auto& dxs = f16_scratch_[5];
+    dxs.Resize((TIndex)((BlockedHalves(N, C, OH, OW) + 1) / 2));
+    const ssad_pw_f16 d{dyb.data<float>(), packed, nullptr, nullptr, nullptr, dxs.mutable_data<float>(),
+                        N, M, C, OH, OW, OH, OW, 1, 0};
+    CAFFE_ENFORCE_EQ(ssad_conv1x1_f16(&d, s), 0, "float16 pointwise ConvGradient (data) launch failed");
+    const float* full = dxs.data<float>();
+    if (st > 1) {
+      auto& up = f16_scratch_[7];
+      up.Resize((TIndex)((BlockedHalves(N, C, H, W) + 1) / 2));
+      CAFFE_ENFORCE_EQ(ssad_f16_elementwise(1, dxs.data<float>(), nullptr, up.mutable_data<float>(), N, C, H, W, st,
+                                            0, s), 0);
+      full = up.data<float>();
+    }
+    CAFFE_ENFORCE_EQ(ssad_f16_unblock_activations(full, N, C, H, W, dX->raw_mutable_data(TypeMeta::Make<float16>()),
+                                                  s), 0);
   }
   return true;
 }

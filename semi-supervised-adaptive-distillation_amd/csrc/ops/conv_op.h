@@ -74,6 +74,7 @@ class ConvOp final : public Operator<Context> {
   Tensor<Context> packed_filter_;
   Tensor<Context> col_buffer_;
   Tensor<Context> f16_scratch_[4];
+  bool RunFloat16Pointwise();
 };
 
 template <typename T, class Context>
@@ -104,7 +105,8 @@ class ConvGradientOp final : public Operator<Context> {
   Tensor<Context> packed_filter_;
   Tensor<Context> workspace_;
   Tensor<Context> col_buffer_;
-  Tensor<Context> f16_scratch_[6];
+  Tensor<Context> f16_scratch_[8];
+  bool RunFloat16Pointwise();
 };
 
 }  // namespace caffe2

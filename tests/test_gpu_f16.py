@@ -433,3 +433,40 @@ def test_f16_pipeline_against_the_cpu_oracle(K):
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
     for k, e in errs.items():
         assert e < (4e-2 if "conv_n0" in k and k.endswith("_w") else 1e-2), worst
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_float16_pointwise_conv_through_the_operators(stride):
+    """The backbones' 1x1 convolutions on TensorProto::FLOAT16 blobs through `Conv` / `ConvGradient`
+    (CudnnConvOp<float16>, conv_op_cudnn.cc:631-636; ResNet.py:221-283 bottleneck 1x1s with the
+    stride on the first one): fp16 in / out, fp32 sums, against float64 on the same fp16 values."""
+    from ssad_amd.caffe2_hip import caffe2_pb2, core, workspace
+    rng = np.random.default_rng(900 + stride)
+    N, C, M, H, W = 2, 72, 136, 10, 14
+    X = rng.standard_normal((N, C, H, W)).astype(np.float16)
+    Wt = (rng.standard_normal((M, C, 1, 1)) * 0.1).astype(np.float16)
+    b = rng.standard_normal(M).astype(np.float16)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dY = rng.standard_normal((N, M, OH, OW)).astype(np.float16)
+    gpu = core.DeviceOption(caffe2_pb2.HIP, 0)
+    for name, arr in (("pX", X), ("pw", Wt), ("pb", b), ("pY_grad", dY)):
+        workspace.FeedBlob(name, arr, gpu)
+    with core.DeviceScope(gpu):
+        conv = core.CreateOperator("Conv", ["pX", "pw", "pb"], ["pY"], kernel=1, pad=0, stride=stride,
+                                   order="NCHW", engine="CUDNN")
+    workspace.RunOperatorOnce(conv)
+    Y = workspace.FetchBlob("pY")
+    assert Y.dtype == np.float16 and Y.shape == (N, M, OH, OW)
+    x64, w64, dy64 = X.astype(np.float64), Wt.astype(np.float64).reshape(M, C), dY.astype(np.float64)
+    xs = x64[:, :, ::stride, ::stride]
+    want = np.einsum("mc,nchw->nmhw", w64, xs) + b.astype(np.float64).reshape(1, -1, 1, 1)
+    assert np.abs(Y.astype(np.float64) - want).max() <= 1e-3 * np.abs(want).max()
+    g, _ = core.GradientRegistry.GetGradientForOp(conv, ["pY_grad"])
+    workspace.RunOperatorsOnce(g)
+    dW, db, dX = (workspace.FetchBlob(n) for n in ("pw_grad", "pb_grad", "pX_grad"))
+    assert dW.dtype == db.dtype == dX.dtype == np.float16 and dW.shape == (M, C, 1, 1) and dX.shape == X.shape
+    want_dx = np.zeros_like(x64)
+    want_dx[:, :, ::stride, ::stride] = np.einsum("mc,nmhw->nchw", w64, dy64)
+    for got, ref in ((dW.reshape(M, C), np.einsum("nmhw,nchw->mc", dy64, xs)), (db, dy64.sum((0, 2, 3))),
+                     (dX, want_dx)):
+        assert np.abs(got.astype(np.float64) - ref).max() <= 1e-3 * np.abs(ref).max()
