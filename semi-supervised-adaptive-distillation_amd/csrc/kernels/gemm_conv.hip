@@ -309,6 +309,8 @@ struct WgradArgs {
   int mtiles, ctiles;
   int chunks;         // total 16-column chunks = N * P / 16
   int per_split;      // chunks per split
+  int splits;         // splits that own >= 1 chunk
+  int xcd_group;      // consecutive (split, tile) work items per XCD run (1 = round robin)
 };
 
 __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nt_kernel(const WgradArgs g) {
@@ -318,11 +320,22 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nt_kernel(const WgradAr
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
   const int j = lane & 31, h = lane >> 5;
-  const int tile = blockIdx.x;
+  // work item v = (split, tile), split-major; an XCD (workgroups b, b + 8, ...) takes runs of xcd_group
+  // consecutive items: the tiles of one split read the same column range of X and dY
+  int v = (int)blockIdx.x;
+  {
+    const int G = (int)gridDim.x, xg = g.xcd_group;
+    if (xg > 1 && (G & 7) == 0 && ((G >> 3) % xg) == 0) {
+      const int r = v >> 3, x = v & 7;
+      v = (r / xg) * (8 * xg) + x * xg + (r % xg);
+    }
+  }
+  const int ntiles = g.mtiles * g.ctiles;
+  const int split = v / ntiles, tile = v - split * ntiles;
   const int mt = tile % g.mtiles, ct = tile / g.mtiles;
   const int m0 = mt * 128, c0 = ct * 128;
   const int P = g.P;
-  const int ch0 = blockIdx.y * g.per_split;
+  const int ch0 = split * g.per_split;
   const int ch1 = min(ch0 + g.per_split, g.chunks);
   const int nch = ch1 - ch0;
 
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nt_kernel(const WgradAr
     if (++buf == NSTAGE) buf = 0;
   }
 
-  float* slab = g.part + (long long)blockIdx.y * g.M * g.C;
+  float* slab = g.part + (long long)split * g.M * g.C;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -583,7 +596,14 @@ int ssad_conv1x1_wgrad(const float* x, const float* dy, int N, int C, int P, int
   g.per_split = (g.chunks + splits - 1) / splits;
   const int used = (g.chunks + g.per_split - 1) / g.per_split;        // splits that own >= 1 chunk
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gemm_conv_nt_kernel, dim3(g.mtiles * g.ctiles, used), dim3(kThreads), 0, s, g);
+  g.splits = used;
+  {
+    // tuning: SSAD_GEMM_WGRAD_XCD_GROUP = run length (0 / unset: round robin; -1: one operand-sharing set,
+    // i.e. the mtiles tiles of one X block; -2: a whole split)
+    static const int want = [] { const char* e = getenv("SSAD_GEMM_WGRAD_XCD_GROUP"); return e ? atoi(e) : 0; }();
+    g.xcd_group = want == -1 ? g.mtiles : (want == -2 ? g.mtiles * g.ctiles : (want > 0 ? want : 1));
+  }
+  hipLaunchKernelGGL(gemm_conv_nt_kernel, dim3(g.mtiles * g.ctiles * used), dim3(kThreads), 0, s, g);
   const long long n = (long long)M * C;
   hipLaunchKernelGGL(gemm_conv_wgrad_reduce_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)),
                      dim3(kThreads), 0, s, (const float*)g.part, used, n, accumulate, dw);

@@ -52,4 +52,14 @@ if [ "$WHAT" = "pmc" ] || [ "$WHAT" = "all" ]; then
   python tools/pmc_by_class.py --out $O/pmc_classes_roundrobin.json --md $O/pmc_classes_roundrobin.md \
       fetch=$(ls /tmp/prof_pmc_fetch_rr/*.db | head -1) tcc=$(ls /tmp/prof_pmc_tcc_rr/*.db | head -1) > /dev/null 2>> $O/pmc_classes.err
 fi
+if [ "$WHAT" = "pmc16" ] || [ "$WHAT" = "all" ]; then
+  # the fp16-storage subnets (bench.py --workload heads --precision f16), same attribution
+  pmc pmc16_mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT -- --workload heads --precision f16
+  pmc pmc16_fetch FETCH_SIZE -- --workload heads --precision f16
+  pmc pmc16_write WRITE_SIZE -- --workload heads --precision f16
+  pmc pmc16_tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -- --workload heads --precision f16
+  python tools/pmc_by_class.py --f16 --out $O/pmc_classes_f16.json --md $O/pmc_classes_f16.md \
+      mfma=$(ls /tmp/prof_pmc16_mfma/*.db | head -1) fetch=$(ls /tmp/prof_pmc16_fetch/*.db | head -1) \
+      write=$(ls /tmp/prof_pmc16_write/*.db | head -1) tcc=$(ls /tmp/prof_pmc16_tcc/*.db | head -1) > /dev/null 2>> $O/pmc_classes.err
+fi
 ls -la $O
