@@ -324,3 +324,44 @@ def test_kernel_entry_points_refuse_bad_arguments_without_a_device(lib):
     assert raw.ssad_affine_channel(p, None, None, None, p, 1, 0, 16, 1, None) == -1
     raw.ssad_conv_out_size.argtypes = [i32] * 6
     assert raw.ssad_conv_out_size(7, 3, 1, 1, 1, 2) == 4 and raw.ssad_conv_out_size(2, 7, 1, 0, 0, 1) == -1
+    # round 3: the backbones' fp16 entry points
+    from ssad_amd import kernels as K
+    raw.ssad_conv1x1_f16.argtypes = [ctypes.POINTER(K.PwF16), vp]
+    d = K.PwF16()
+    d.x = d.w = d.y = p.value
+    d.N, d.C, d.M, d.Ho, d.Wo, d.Hi, d.Wi, d.stride, d.flags = 1, 32, 36, 4, 4, 4, 4, 1, 0
+    assert raw.ssad_conv1x1_f16(ctypes.byref(d), None) == -1            # whole 8-channel output blocks only
+    d.M, d.stride = 32, 3
+    assert raw.ssad_conv1x1_f16(ctypes.byref(d), None) == -1            # stride 1 or 2
+    d.stride, d.Hi = 2, 6
+    assert raw.ssad_conv1x1_f16(ctypes.byref(d), None) == -1            # (Ho - 1) * stride must lie inside the input
+    d.stride, d.Hi, d.flags = 1, 4, K.PW_F16_RES_UPSAMPLE2
+    assert raw.ssad_conv1x1_f16(ctypes.byref(d), None) == -1            # the upsampled residual needs a residual
+    d.flags, d.N = 0, 0
+    assert raw.ssad_conv1x1_f16(ctypes.byref(d), None) == 0             # an empty batch is a no-op
+    raw.ssad_conv1x1_wgrad_f16_workspace_bytes.restype = sz
+    raw.ssad_conv1x1_wgrad_f16_workspace_bytes.argtypes = [i32] * 5
+    raw.ssad_conv1x1_wgrad_f16.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp]
+    need = raw.ssad_conv1x1_wgrad_f16_workspace_bytes(2, 256, 10, 14, 64)
+    assert need >= 256 * 64 * 4
+    assert raw.ssad_conv1x1_wgrad_f16(p, p, 2, 256, 10, 14, 64, 0, 1.0, None, p, None, p, need - 1, None) == -2
+    assert raw.ssad_conv1x1_wgrad_f16(p, p, 2, 256, 10, 14, 64, 0, 1.0, None, None, None, p, need, None) == -1
+    raw.ssad_grouped_conv3x3_f16.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    assert raw.ssad_grouped_conv3x3_f16(p, p, None, 1, 256, 8, 8, 3, 1, p, None) == -1       # 256 % 3
+    assert raw.ssad_grouped_conv3x3_f16(p, p, None, 1, 256, 8, 8, 2, 1, p, None) == -1       # 128-wide groups
+    assert raw.ssad_grouped_conv3x3_f16(p, p, None, 1, 96, 8, 8, 24, 1, p, None) == -1       # C % 64
+    raw.ssad_grouped_conv3x3_f16_filter_halves.restype = sz
+    raw.ssad_grouped_conv3x3_f16_filter_halves.argtypes = [i32, i32]
+    assert raw.ssad_grouped_conv3x3_f16_filter_halves(256, 64) == 16 * 5 * 64 * 8
+    assert raw.ssad_grouped_conv3x3_f16_filter_halves(2048, 64) == 128 * 9 * 64 * 8
+    raw.ssad_f16_elementwise.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    assert raw.ssad_f16_elementwise(9, p, None, p, 1, 8, 2, 2, 1, 0, None) == -1             # unknown mode
+    assert raw.ssad_f16_elementwise(3, p, None, p, 1, 8, 2, 2, 1, 0, None) == -1             # a sum needs b
+    assert raw.ssad_f16_elementwise(0, p, None, p, 1, 8, 2, 2, 0, 0, None) == -1             # stride >= 1
+    raw.ssad_gemm_f32.argtypes = [i32, i32, i32, i32, i32, f32, vp, i32, ctypes.c_longlong, vp, i32, ctypes.c_longlong,
+                                  f32, vp, i32, ctypes.c_longlong, i32, vp]
+    assert raw.ssad_gemm_f32(0, 0, 4, 4, 4, 1.0, p, 0, 0, p, 4, 0, 0.0, p, 4, 0, 1, None) == -1   # lda < 1
+    assert raw.ssad_gemm_f32(0, 0, 0, 4, 4, 1.0, None, 4, 0, None, 4, 0, 0.0, None, 4, 0, 1, None) == 0   # empty
+    raw.ssad_momentum_sgd_flat.argtypes = [vp, vp, vp, vp, f32, f32, ctypes.POINTER(K.SgdSegment), i32, vp, vp]
+    seg = (K.SgdSegment * 1)(K.SgdSegment(0, 8, 0, 0, p.value))
+    assert raw.ssad_momentum_sgd_flat(p, p, p, p, 0.9, 1e-4, seg, 1, None, None) == -1      # row_scale without row_len
