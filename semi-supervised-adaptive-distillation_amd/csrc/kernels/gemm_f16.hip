@@ -216,6 +216,18 @@ __global__ __launch_bounds__(kThreads, 2) void pw_f16_kernel(const PwF16 p) {
                                                   p.res ? (unsigned)((long long)p.N * MB * plane_r16) : 0u);
   const __amdgpu_buffer_rsrc_t mrs = uniform_rsrc(MASKED ? (const void*)p.mask : (const void*)p.y,
                                                   MASKED ? ybytes : 0u);
+  // A lane holds channels 4h .. 4h + 3 of each 8-channel block g for its pixel: half a 16-byte slot.
+  // Blocks are handled in PAIRS (g_e, g_o): v_permlane32_swap exchanges the halves between lanes j
+  // and j + 32, after which lane h = 0 holds the whole slot of g_e and lane h = 1 the whole slot of
+  // g_o -- one 16-byte store (and one 16-byte residual / mask load, redistributed the same way) per
+  // lane and pair instead of two 8-byte ones.
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  auto swap2 = [](unsigned a, unsigned b, unsigned& ra, unsigned& rb) {
+    // rows of 32 lanes: ra = {a.row0, b.row0}, rb = {a.row1, b.row1}
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    ra = r.x; rb = r.y;
+  };
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int oc0 = oc_w + i * 32;
@@ -228,31 +240,60 @@ __global__ __launch_bounds__(kThreads, 2) void pw_f16_kernel(const PwF16 p) {
 #pragma unroll
     for (int tt = 0; tt < G::NT; ++tt) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (oc0 + 8 * g >= p.M) continue;                  // wave-uniform
-        float2v lo = float2v{acc[i][tt][4 * g], acc[i][tt][4 * g + 1]} + float2v{bq[g].x, bq[g].y};
-        float2v hi = float2v{acc[i][tt][4 * g + 2], acc[i][tt][4 * g + 3]} + float2v{bq[g].z, bq[g].w};
+      for (int gp = 0; gp < 2; ++gp) {
+        if (oc0 + 16 * gp >= p.M) continue;                // wave-uniform
+        const bool mine = oc0 + 8 * (2 * gp + h) < p.M;    // this lane's own slot (block 2 gp + h) exists
+        const unsigned pbase = pvo[tt] == kOob ? kOob : pvo[tt] - 8u * h;      // slot address of the pixel
+        const unsigned vo = (mine && pbase != kOob) ? pbase + (unsigned)h * (unsigned)(plane_o * 16) : kOob;
+        const int so = ((oc0 >> 3) + 2 * gp) * plane_o * 16;
+        unsigned re[2] = {0, 0}, ro[2] = {0, 0};           // residual halves for (g_e, 4h..), (g_o, 4h..)
         if (p.res) {                                       // wave-uniform
-          const half4 rv = __builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(
-                                                         rrs, rvo[tt], ((oc0 >> 3) + g) * plane_r16, 0));
-          lo += float2v{(float)rv[0], (float)rv[1]};
-          hi += float2v{(float)rv[2], (float)rv[3]};
+          const unsigned rbase = rvo[tt] == kOob ? kOob : rvo[tt] - 8u * h;
+          const unsigned rv = (mine && rbase != kOob) ? rbase + (unsigned)h * (unsigned)plane_r16 : kOob;
+          const u32x4 L = __builtin_amdgcn_raw_buffer_load_b128(rrs, rv, ((oc0 >> 3) + 2 * gp) * plane_r16, 0);
+          swap2(L.x, L.z, re[0], ro[0]);
+          swap2(L.y, L.w, re[1], ro[1]);
         }
-        half2v o01 = __builtin_convertvector(lo, half2v), o23 = __builtin_convertvector(hi, half2v);
-        if (p.relu) {
-          const half2v z = {(_Float16)0.0f, (_Float16)0.0f};
-          o01 = __builtin_elementwise_max(o01, z);
-          o23 = __builtin_elementwise_max(o23, z);
+        unsigned me[2] = {0, 0}, mo[2] = {0, 0};
+        if (MASKED) {
+          const u32x4 L = __builtin_amdgcn_raw_buffer_load_b128(mrs, vo, so, 0);
+          swap2(L.x, L.z, me[0], mo[0]);
+          swap2(L.y, L.w, me[1], mo[1]);
         }
-        half4 o = {o01[0], o01[1], o23[0], o23[1]};
-        if (MASKED) {                                      // relu_op.cu:44-53: dX = Y > 0 ? dY : 0
-          const half4 m = __builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(
-                                                        mrs, pvo[tt], ((oc0 >> 3) + g) * plane_o * 16, 0));
+        unsigned out[2][2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = m[e] > (_Float16)0.0f ? o[e] : (_Float16)0.0f;
+        for (int eo = 0; eo < 2; ++eo) {
+          const int g = 2 * gp + eo;
+          float2v lo = float2v{acc[i][tt][4 * g], acc[i][tt][4 * g + 1]} + float2v{bq[g].x, bq[g].y};
+          float2v hi = float2v{acc[i][tt][4 * g + 2], acc[i][tt][4 * g + 3]} + float2v{bq[g].z, bq[g].w};
+          if (p.res) {
+            const half4 rv = __builtin_bit_cast(half4, u32x2{eo ? ro[0] : re[0], eo ? ro[1] : re[1]});
+            lo += float2v{(float)rv[0], (float)rv[1]};
+            hi += float2v{(float)rv[2], (float)rv[3]};
+          }
+          half2v o01 = __builtin_convertvector(lo, half2v), o23 = __builtin_convertvector(hi, half2v);
+          if (p.relu) {
+            const half2v z = {(_Float16)0.0f, (_Float16)0.0f};
+            o01 = __builtin_elementwise_max(o01, z);
+            o23 = __builtin_elementwise_max(o23, z);
+          }
+          half4 o = {o01[0], o01[1], o23[0], o23[1]};
+          if (MASKED) {                                    // relu_op.cu:44-53: dX = Y > 0 ? dY : 0
+            const half4 m = __builtin_bit_cast(half4, u32x2{eo ? mo[0] : me[0], eo ? mo[1] : me[1]});
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = m[e] > (_Float16)0.0f ? o[e] : (_Float16)0.0f;
+          }
+          const u32x2 od = __builtin_bit_cast(u32x2, o);
+          out[eo][0] = od.x; out[eo][1] = od.y;
         }
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2v, o), yrs, pvo[tt],
-                                              ((oc0 >> 3) + g) * plane_o * 16, 0);
+        u32x4 slot;
+        {
+          unsigned a0, b0, a1, b1;
+          swap2(out[0][0], out[1][0], a0, b0);
+          swap2(out[0][1], out[1][1], a1, b1);
+          slot = u32x4{a0, a1, b0, b1};
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(slot, yrs, vo, so, 0);
       }
     }
   }
