@@ -158,3 +158,50 @@ def test_two_rank_hook_driven_gradient_buckets():
         assert np.allclose(r[0][k][:n], want, rtol=1e-6, atol=1e-7)
         assert np.all(r[0][k][n:] == 0) and np.any(want != 0)
     assert not np.array_equal(r[0]["flat0"], r[0]["flat1"])
+
+
+# ---------------------------------------------------------------------------
+# the backbone's four gradient buckets (backbone_pipeline.NativeResNetFPN) under gloo, world 2
+# ---------------------------------------------------------------------------
+
+def _backbone_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssad_amd.backbone_pipeline import NativeResNetFPN
+    torch.manual_seed(1234 + rank)                    # only the broadcast may make the ranks agree
+    bb = NativeResNetFPN("r50", 1, (128, 128), "cpu", train=True, lr=0.01, process_group=dist.group.WORLD,
+                         world_size=world)
+    if rank == 1:
+        bb.params_flat.add_(1.0)                      # diverge on purpose
+        bb.moms_flat.fill_(3.0)
+    bb.broadcast_params()
+    gr = torch.Generator().manual_seed(70 + rank)
+    bb.grads_flat.copy_(torch.randn(bb.grads_flat.shape, generator=gr))
+    local = bb.grads_flat.clone()
+    # as NativeResNetFPN.backward() does: one asynchronous all-reduce per stage bucket, in the order the
+    # backward pass completes them, then the wait in front of the SGD launch
+    names = list(bb.bucket)
+    for n in names:
+        bb.dp.issue(bb.bucket[n])
+    bb.dp.wait()
+    np.savez(os.path.join(outdir, "bb%d.npz" % rank), params=bb.params_flat.numpy(), moms=bb.moms_flat.numpy(),
+             local=local.numpy(), reduced=bb.grads_flat.numpy(),
+             sizes=np.array([bb.bucket[n].numel() for n in names]), names=np.array(names))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_backbone_buckets_cover_every_gradient_exactly_once():
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_backbone_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        r = [np.load(os.path.join(d, "bb%d.npz" % i)) for i in range(world)]
+    assert list(r[0]["names"]) == ["fpn", "res5", "res4", "res3"]
+    assert int(r[0]["sizes"].sum()) == r[0]["local"].size           # the buckets tile the flat buffer
+    assert np.array_equal(r[0]["params"], r[1]["params"]) and np.array_equal(r[0]["moms"], r[1]["moms"])
+    assert float(np.abs(r[1]["moms"]).max()) == 0.0                 # rank 0's state won the broadcast
+    total = r[0]["local"] + r[1]["local"]
+    assert not np.array_equal(r[0]["local"], r[1]["local"])
+    for k in range(world):
+        assert np.array_equal(r[k]["reduced"], total)               # every element reduced once, bit for bit
