@@ -57,6 +57,11 @@ constexpr int SX = 130;                  // X LDS channel stride (6 * 20 + 10)
 constexpr int STAGE = GM * SY + GC * SX; // floats per stage
 constexpr unsigned kOOB = 0x80000000u;
 
+// WGRAD_ABLATE (debug builds only, results are wrong): 1 = no staging DMA inside the loop, 2 = raw values
+// instead of B^T d B / A d A^T, 4 = no per-unit barrier, 8 = no operand reads inside the loop
+#ifndef WGRAD_ABLATE
+#define WGRAD_ABLATE 0
+#endif
 #ifdef WGRAD_TIMELINE   // tools/wgrad_timeline.py
 __device__ unsigned long long g_wdbg[64][8];
 #define WDBG(it, k) if (dbg_on && (it) < 64) g_wdbg[it][k] = __builtin_readcyclecounter()
@@ -234,9 +239,11 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
     // this wave's DMA of unit u has landed (that of unit u + 1 may still fly) ...
     if (u + 1 < u_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaPerUnit) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WDBG(u - u_begin, 5);
     // ... and after the barrier everybody's has; every wave is also done with unit u - 1,
     // whose stage the next DMA overwrites
-    __builtin_amdgcn_s_barrier();
+    if (!(WGRAD_ABLATE & 4)) __builtin_amdgcn_s_barrier();
+    WDBG(u - u_begin, 6);
     const float* st = lds + sidx * STAGE;
     float* nst = lds + (sidx == 0 ? 2 : sidx - 1) * STAGE;
     const bool fetch = lu < u_end;
@@ -267,8 +274,8 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
     read_raw(0, rb[0], ra[0]);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (fetch) issue_quarter(nst, ks);
-      if (ks < 3) read_raw(ks + 1, rb[(ks + 1) & 1], ra[(ks + 1) & 1]);
+      if (fetch && !(WGRAD_ABLATE & 1)) issue_quarter(nst, ks);
+      if (ks < 3 && !(WGRAD_ABLATE & 8)) read_raw(ks + 1, rb[(ks + 1) & 1], ra[(ks + 1) & 1]);
       const float2 (&b8)[8] = rb[ks & 1];
       const float2 (&a4)[4] = ra[ks & 1];
       // ---- B operand: raw 4x4 window -> V = B^T d B (16 values) ----
@@ -280,6 +287,10 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
           d[r][0] = b8[2 * r].x; d[r][1] = b8[2 * r].y; d[r][2] = b8[2 * r + 1].x; d[r][3] = b8[2 * r + 1].y;
         }
         float t[4][4];
+        if (WGRAD_ABLATE & 2) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = d[i >> 2][i & 3];
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           t[0][j] = d[0][j] - d[2][j];
@@ -294,6 +305,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
           v[i * 4 + 2] = t[i][2] - t[i][1];
           v[i * 4 + 3] = t[i][1] - t[i][3];
         }
+        }
       }
       // ---- A operand per 16-channel group: raw 2x2 -> A d A^T without the signs of
       //      A's last row (re-applied by the reduce kernel) ----
@@ -304,7 +316,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
         const float q[4] = {r0.y, r0.y + r1.y, r0.y - r1.y, r1.y};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float dm[4] = {p[i], p[i] + q[i], p[i] - q[i], q[i]};
+          const float dm[4] = {p[i], (WGRAD_ABLATE & 2) ? q[i] : p[i] + q[i], (WGRAD_ABLATE & 2) ? p[i] : p[i] - q[i], q[i]};
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i * 4 + j][mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(dm[j], v[i * 4 + j],

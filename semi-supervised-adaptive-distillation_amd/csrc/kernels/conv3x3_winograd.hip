@@ -367,12 +367,24 @@ __global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) 
 constexpr int NRAW = 3;
 constexpr unsigned kOOBOff = 0x80000000u;
 
+// WINO_ABLATE (debug builds only, results are wrong): 1 = no raw-patch DMA in the loop, 2 = no input transform,
+// 4 = filter operand ring not refilled, 8 = B operands not re-read, 16 = no epilogue, 32 = no per-chunk barrier
+#ifndef WINO_ABLATE
+#define WINO_ABLATE 0
+#endif
+#ifndef WINO_DMA_SPREAD
+#define WINO_DMA_SPREAD 1
+#endif
 #ifdef WINO_TIMELINE
 __device__ unsigned long long g_dbg[2][64][8];
+__device__ unsigned long long g_wv[8][64][2];     // per wave of the stamped workgroup: steps done, barrier passed
 #define DBG(role, it, k) \
   if (dbg_on && (it) < 64) g_dbg[role][it][k] = __builtin_readcyclecounter()
+#define DBGW(it, k) \
+  if (blockIdx.x == 3 && lane == 0 && (it) < 64) g_wv[wave][it][k] = __builtin_readcyclecounter()
 #else
 #define DBG(role, it, k)
+#define DBGW(it, k)
 #endif
 
 struct WTile {
@@ -497,16 +509,28 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   // The per-tile byte offsets live in LDS (zvoff), not in VGPRs: a spilled
   // offset would be reloaded from scratch with a vmcnt(0) wait in the middle
   // of the filter-operand ring.
-  __amdgpu_buffer_rsrc_t xrsrc;
+  ssad_dev::rsrc_words xrs = ssad_dev::uniform_rsrc_words(args.lv[0].x, 0);
   int chunk_bytes = 0;
   int ld_tile = 0, ld_ch = 0, ld_buf = 0;      // load cursor over (tile, chunk), its raw buffer
   unsigned* myvoff = zvoff + wave * (ZL * 64) + lane;
-  auto dma_next = [&]() {
-    if (ld_ch == 0) {
+  const unsigned raw_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)raw;
+  // real = false: the same ZL instructions with every lane out of range (zeros into the buffer nobody
+  // reads any more): a wave's vector-memory queue then has the SAME shape in every chunk, which is
+  // what the counted waits of the filter ring below rely on
+  // One chunk's DMA = dma_begin (cursor bookkeeping, once per tile the lane offsets), ZL x dma_issue, dma_end.
+  // The main loop spreads the ZL instructions over steps 0..ZL-1 (WINO_DMA_SPREAD, default): issued as one burst
+  // at step 0 by all 8 waves at once they held each wave for ~750 cycles (cycle stamps around the block), which
+  // an isolated burst does not cost (tools/coissue_probe.hip) -- the texture addresser of the CU is shared.
+  bool dma_real = true;
+  int dma_soff = 0;
+  unsigned dma_dst = 0;
+  auto dma_begin = [&](bool real) {
+    dma_real = real;
+    if (real && ld_ch == 0) {
       const WTile Tt = get_tile(ld_tile);
       const WLevel& L = args.lv[Tt.l];
       const int H = L.H, W = L.W, HW = H * W;
-      xrsrc = uniform_rsrc(L.x + (long long)Tt.n * K * HW, K * HW * 4);
+      xrs = ssad_dev::uniform_rsrc_words(L.x + (long long)Tt.n * K * HW, (unsigned)(K * HW * 4));
       chunk_bytes = KC * HW * 4;
 #pragma unroll 1
       for (int j = 0; j < ZL; ++j) {
@@ -521,17 +545,31 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
         myvoff[j * 64] = ok ? (unsigned)(((2 * p + hi) * HW + gy * W + gx) * 4) : kOOBOff;
       }
     }
-    const int soff = ld_ch * chunk_bytes;
-    float* dst = raw + ld_buf * ZRAWP + wave * 64;
+    dma_soff = __builtin_amdgcn_readfirstlane(real ? ld_ch * chunk_bytes : 0);
+    dma_dst = __builtin_amdgcn_readfirstlane(raw_lds + (unsigned)(ld_buf * ZRAWP + wave * 64) * 4u);
+  };
+  // real = false: the same instruction with every lane out of range (zeros into the buffer nobody reads any
+  // more): a wave's vector-memory queue then has the SAME shape in every chunk, which is what the counted
+  // waits of the filter ring below rely on
+  auto dma_offset = [&](int j) { return dma_real ? myvoff[j * 64] : kOOBOff; };
+  // inline assembly, not __builtin_amdgcn_raw_ptr_buffer_load_lds: behind the builtin hipcc makes the next LDS
+  // read of the kernel (the transform's raw-patch read, one step later) wait for the DMA itself
+  // (`s_waitcnt vmcnt(1)` in the round-2 ISA); see conv_internal.h
+  auto dma_issue = [&](int j, unsigned vo) { ssad_dev::lds_dma<4>(xrs, dma_dst + j * 2048, vo, dma_soff); };
+  auto dma_end = [&]() {
+    if (dma_real) {
+      if (++ld_ch == chunks) { ld_ch = 0; ++ld_tile; }
+      if (++ld_buf == NRAW) ld_buf = 0;
+    }
+  };
+  auto dma_next = [&](bool real) {
+    dma_begin(real);
     unsigned vo[ZL];
 #pragma unroll
-    for (int j = 0; j < ZL; ++j) vo[j] = myvoff[j * 64];
+    for (int j = 0; j < ZL; ++j) vo[j] = dma_offset(j);
 #pragma unroll
-    for (int j = 0; j < ZL; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(dst + j * 512),
-                                               4, vo[j], soff, 0, (NT & 1) ? 2 : 0);
-    if (++ld_ch == chunks) { ld_ch = 0; ++ld_tile; }
-    if (++ld_buf == NRAW) ld_buf = 0;
+    for (int j = 0; j < ZL; ++j) dma_issue(j, vo[j]);
+    dma_end();
   };
 
   // ---- transform: work item = (tile, channel, row a); wave w owns row a = w & 3 for
@@ -583,8 +621,15 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
     if (mt >= mtiles) mt = 0;
     return __builtin_amdgcn_readfirstlane(mt * chunks * STEPS * 1024);
   };
-  auto a_load = [&](__amdgpu_buffer_rsrc_t rs, int soff) {
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, a_voff, soff, 0));
+  // The filter ring is loaded and awaited by hand.  Vector memory retires in order and hipcc does not
+  // count the DMA above, so its own wait in front of a ring slot (vmcnt(7): "the 7 younger ring loads
+  // may still fly") made every step that followed a DMA issue wait for one more of the 7 HBM fetches
+  // queued BEHIND the slot it needed.  The queue of a wave is, per chunk: R(8) D0 R(9) D1 ... R(14) D6 R(15) ... R(23),
+  // R(j) = operand of step j requested at step j - 8, Dj = one wave-load of the raw-patch DMA, issued at the end
+  // of step j (burst variant: all seven behind R(8)).  Step j needs R(j): 7 ring loads are younger, plus the
+  // D issued since R(j) was: j of them for j < 8, 15 - j after (burst: 7 for j = 1..8).
+  auto a_load = [&](f32x4& dst, const ssad_dev::rsrc_words& rs, int soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(a_voff), "s"(rs), "s"(soff));
   };
   auto load_bias = [&](const WTile& Tt) {
     const WLevel& L = args.lv[Tt.l];
@@ -599,15 +644,15 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
 
   // ---- prologue: chunks 0..2 by DMA, chunk 0 transformed, filter ring primed ----
   WTile T = get_tile(0);
-  __amdgpu_buffer_rsrc_t arsrc = uniform_rsrc(args.lv[T.l].packed, stream_bytes);
+  ssad_dev::rsrc_words arsrc = ssad_dev::uniform_rsrc_words(args.lv[T.l].packed, (unsigned)stream_bytes);
   int abase = stream_off(T);
-  float4 ar[AD];
+  f32x4 ar[AD];
 #pragma unroll
-  for (int k = 0; k < AD; ++k) ar[k] = a_load(arsrc, abase + k * 1024);
+  for (int k = 0; k < AD; ++k) a_load(ar[k], arsrc, abase + k * 1024);
   f32x4 bv = load_bias(T);
-  dma_next();
-  if (S > 1) dma_next();
-  if (S > 2) dma_next();
+  dma_next(true);
+  if (S > 1) dma_next(true);
+  if (S > 2) dma_next(true);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   transform(raw, vbuf);
@@ -616,7 +661,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   int s = 0;
   int rbuf = 1;                      // raw buffer holding chunk s+1
   WTile Tn = T;
-  __amdgpu_buffer_rsrc_t nrsrc = arsrc;
+  ssad_dev::rsrc_words nrsrc = arsrc;
   int nbase = abase;
   const int look = chunks > 1 ? 1 : 0;
   for (int i = 0; i < my_n; ++i) {
@@ -637,15 +682,15 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
       //    holds / has requested the filter operands of the next 8 steps, so
       //    these HBM loads sit behind them in the in-order vmcnt queue;
       //  * once per tile, the next tile's filter stream position.
-      auto side_dma = [&]() { if (s + 3 < S) dma_next(); };
+      auto side_dma = [&]() { if (!(WINO_ABLATE & 1)) dma_next(s + 3 < S); };
       auto side_look = [&]() {
         if (ch == look && i + 1 < my_n) {
           Tn = get_tile(i + 1);
-          nrsrc = uniform_rsrc(args.lv[Tn.l].packed, stream_bytes);
+          nrsrc = ssad_dev::uniform_rsrc_words(args.lv[Tn.l].packed, (unsigned)stream_bytes);
           nbase = stream_off(Tn);
         }
       };
-      const bool xf = s + 1 < S;
+      const bool xf = s + 1 < S && !(WINO_ABLATE & 2);
       const float* xsrc = raw + rbuf * ZRAWP;
       float* xdst = vbuf + ((s + 1) & 1) * VBUF;
       DBG(1, s, 1);
@@ -665,12 +710,29 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
           bc[xr][0] = b2.x; bc[xr][1] = b2.y;
         }
         float2 xd[4];
+        unsigned dma_vo = kOOBOff;
 #pragma unroll
         for (int step = 0; step < STEPS; ++step) {       // step = ks*4 + xq
           const int xq = step & 3;
           const int nks = (step + 1) >> 2, nxq = (step + 1) & 3;
-          const float4 a0 = ar[step & (AD - 1)];
-          const float av[4] = {a0.x, a0.y, a0.z, a0.w};
+          // this step's operand has landed (see a_load)
+          {
+            const int younger = (WINO_ABLATE & 1) ? 0
+                : WINO_DMA_SPREAD ? (step < AD ? (step < ZL ? step : ZL) : (STEPS - 1 - step < ZL ? STEPS - 1 - step : ZL))
+                                  : (step >= 1 && step <= AD ? ZL : 0);
+            switch (younger) {      // `step` is a compile-time constant after unrolling: one case survives
+              case 0: asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[step & (AD - 1)]) : "n"(AD - 1)); break;
+              case 1: asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[step & (AD - 1)]) : "n"(AD)); break;
+              case 2: asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[step & (AD - 1)]) : "n"(AD + 1)); break;
+              case 3: asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[step & (AD - 1)]) : "n"(AD + 2)); break;
+              case 4: asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[step & (AD - 1)]) : "n"(AD + 3)); break;
+              case 5: asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[step & (AD - 1)]) : "n"(AD + 4)); break;
+              case 6: asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[step & (AD - 1)]) : "n"(AD + 5)); break;
+              default: asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[step & (AD - 1)]) : "n"(AD + 6)); break;
+            }
+          }
+          const f32x4 a0 = ar[step & (AD - 1)];
+          const float av[4] = {a0[0], a0[1], a0[2], a0[3]};
 #pragma unroll
           for (int xr = 0; xr < 4; ++xr) {
             const int xi = xq * 4 + xr;
@@ -678,22 +740,28 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
             for (int g = 0; g < 2; ++g)
               acc[xi][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[xr], bc[xr][g], acc[xi][g], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (step < STEPS - 1) {
+            if (step < STEPS - 1 && !(WINO_ABLATE & 8)) {
               const float2 b2 = *reinterpret_cast<const float2*>(vb + ((nxq * 4 + xr) * KC + nks * 4) * VP);
               bc[xr][0] = b2.x; bc[xr][1] = b2.y;
             }
             __builtin_amdgcn_sched_barrier(0);
           }
           // refill the ring slot just consumed with the operand of step + 8
-          {
+          if (!(WINO_ABLATE & 4)) {
             const bool tl = last && step + AD >= STEPS;
-            ar[step & (AD - 1)] = a_load(tl ? nrsrc : arsrc,
-                                         (tl ? nbase - chunks * STEPS * 1024 : abase) +
-                                             (ch * STEPS + step + AD) * 1024);
+            a_load(ar[step & (AD - 1)], tl ? nrsrc : arsrc,
+                   (tl ? nbase - chunks * STEPS * 1024 : abase) + (ch * STEPS + step + AD) * 1024);
           }
           if (xf && (step & 3) == 1) xf_load(xsrc, step >> 2, xd);
           if (xf && (step & 3) == 3) xf_store(xdst, step >> 2, xd);
-          if (step == 0) side_dma();
+          if (WINO_DMA_SPREAD && !(WINO_ABLATE & 1)) {
+            if (step == 0) { DBG(1, s, 6); dma_begin(s + 3 < S); dma_vo = dma_offset(0); DBG(1, s, 7); }
+            if (step < ZL) dma_issue(step, dma_vo);
+            if (step + 1 < ZL) dma_vo = dma_offset(step + 1);
+            if (step == ZL - 1) dma_end();
+          } else if (step == 0) {
+            side_dma();
+          }
           if (step == 6) side_look();
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -704,20 +772,23 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       DBG(1, s, 2);
+      DBGW(s, 0);
       if (++rbuf == NRAW) rbuf = 0;
-      // End of chunk: the LDS traffic of this wave (V writes, operand reads) and every vector-memory
-      // operation older than the AD filter operands still in flight for the NEXT chunk's first steps
-      // -- in particular this chunk's DMA -- must be done; the ring itself need not (__syncthreads()
-      // waits for vmcnt(0): the operand requested at the last step, an L2 round trip, was exposed at
-      // every chunk: 350-850 of ~10 k cycles in the cycle stamps).
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AD) : "memory");
-      __builtin_amdgcn_s_barrier();
+      // End of chunk s: the LDS traffic of this wave (V writes, operand reads) must be done, and the DMA
+      // of chunk s - 1 (the raw patch the NEXT chunk's steps transform) must have landed.  The DMA of chunk
+      // s itself feeds the transform two chunks from now and may still fly: with three raw buffers nothing
+      // overwrites it before.  Younger than the last DMA instruction of chunk s - 1 are the ring loads of the
+      // steps after it (STEPS - ZL; burst variant: 15) and this chunk's STEPS + ZL instructions.  (Round 2 waited for vmcnt(AD): every DMA
+      // had to land within its own chunk, ~3.7 k cycles after the request.)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((WINO_ABLATE & 128) ? AD : WINO_DMA_SPREAD ? (STEPS - ZL) + STEPS + ZL : 2 * (STEPS - 1) + 1 + ZL) : "memory");
+      if (!(WINO_ABLATE & 32)) __builtin_amdgcn_s_barrier();
       DBG(1, s, 3);
+      DBGW(s, 1);
     }
     DBG(1, s - 1, 4);
     // next tile's bias flies during the epilogue
     if (i + 1 < my_n) bv = load_bias(Tn);
-    if (active) {
+    if (active && !(WINO_ABLATE & 16)) {
       const WLevel& L = args.lv[T.l];
       const int H = L.H, W = L.W, HW = H * W;
       const int flags = args.flags;
@@ -843,7 +914,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
     // a wave that sat out this tile's MFMAs re-primes its ring for the next tile
     if (!active && i + 1 < my_n) {
 #pragma unroll
-      for (int k = 0; k < AD; ++k) ar[k] = a_load(nrsrc, nbase + k * 1024);
+      for (int k = 0; k < AD; ++k) a_load(ar[k], nrsrc, nbase + k * 1024);
     }
     T = Tn;
     arsrc = nrsrc;
@@ -947,6 +1018,9 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
 #ifdef WINO_TIMELINE
 SSAD_API int ssad_dbg_read(void* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg), sizeof(g_dbg));
+}
+SSAD_API int ssad_dbg_read_waves(void* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wv), sizeof(g_wv));
 }
 #endif
 

@@ -29,3 +29,18 @@ for s in range(40):
     r = [int(v) - t0 for v in buf[s, :5]]
     print(s, r, "setup=%d steps=%d store=%d barrier=%d total=%d" %
           (r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[4] - r[0]))
+for s in range(5, 9):
+    r = [int(buf[s, k]) - int(buf[s, 0]) for k in (0, 5, 6, 1, 2)]
+    print("FINE unit %d: vmcnt wait %d, barrier %d, setup_unit %d, steps %d; to next top %d" %
+          (s, r[1], r[2] - r[1], r[3] - r[2], r[4] - r[3], int(buf[s + 1, 0]) - int(buf[s, 2])))
+tot = [int(buf[s + 1, 0]) - int(buf[s, 0]) for s in range(4, 40)]
+print("SUMMARY cycles/unit median %d min %d max %d" % (int(np.median(tot)), min(tot), max(tot)))
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
+for _ in range(10):
+    K.conv3x3_wgrad(Xs, dYs, M, want_db=False)
+ev1.record()
+torch.cuda.synchronize()
+ms = ev0.elapsed_time(ev1) / 10
+fl = 2.0 * M * Cin * 9 * N * sum(h * w for h, w in shapes) / 2.25
+print("SUMMARY wgrad all levels %.3f ms  %.1f TF/s executed" % (ms, fl / ms / 1e9))

@@ -33,3 +33,22 @@ for s in range(40):
     r = [int(v) - t0 if v else 0 for v in buf[1, s, :6]]
     print(s, r, "setup=%d steps=%d wait=%d" % (r[1] - r[0], r[2] - r[1], r[3] - r[2]),
           ("epilogue=%d" % (r[5] - r[4])) if r[5] else "")
+wv = np.zeros((8, 64, 2), dtype=np.uint64)
+if hasattr(K.lib(), "ssad_dbg_read_waves") and K.lib().ssad_dbg_read_waves(wv.ctypes.data_as(C.c_void_p)) == 0:
+    for s in range(20, 28):
+        rel = int(wv[:, s - 1, 1].max())      # release of the previous chunk's barrier
+        print("WAVES chunk %d: steps done at +%s, released +%d" %
+              (s, [int(wv[w, s, 0]) - rel for w in range(8)], int(wv[0, s, 1]) - rel))
+for s in range(3, 22):
+    print("DMA block of chunk %d: %d cycles (tile decode every 16th)" % (s, int(buf[1, s, 7]) - int(buf[1, s, 6])))
+tot = [int(buf[1, s + 1, 0]) - int(buf[1, s, 0]) for s in range(2, 14)]
+print("SUMMARY cycles/chunk median %d min %d max %d (chunks 2-13 of the first tile)" % (int(np.median(tot)), min(tot), max(tot)))
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
+for _ in range(10):
+    K.conv3x3_forward(Xs, wf, b, M, relu=True, out=Ys, wino=True)
+ev1.record()
+torch.cuda.synchronize()
+ms = ev0.elapsed_time(ev1) / 10
+fl = 2.0 * M * Cin * 9 * N * sum(h * w for h, w in shapes) / 2.25
+print("SUMMARY forward all levels %.3f ms  %.1f TF/s executed = %.3f of 157.3" % (ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3))
