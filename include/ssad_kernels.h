@@ -305,6 +305,10 @@ SSAD_API int ssad_conv_wino_pack_filter(
 SSAD_API int ssad_conv3x3_forward_wino(
     const ssad_conv_level* levels_host, int n_levels, const float* packed,
     const float* bias, int Cout, int Cin, int flags, ssad_stream_t stream);
+/* Kernel launches one ssad_conv3x3_forward_wino call makes for these level shapes: 1, or 2 when some maps
+ * are staged as 8 x 16-pixel patches and others as pairs of 8 x 8 sub-patches (host-side query, no device
+ * work; profiling tools attribute hardware counters to calls by launch order). */
+SSAD_API int ssad_conv3x3_forward_wino_launches(const ssad_conv_level* levels_host, int n_levels);
 /* ssad_conv_wino_pack_filter for a whole table of filters in one launch (the training step
  * repacks every filter after each update: 20 student filters x {forward, data gradient}). */
 #define SSAD_MAX_PACK_ENTRIES 32   /* per launch; longer tables are chunked */

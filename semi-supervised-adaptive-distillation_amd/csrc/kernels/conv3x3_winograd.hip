@@ -141,6 +141,9 @@ struct WLevel {
   int N, H, W;
   int tiles_x, tiles_y;
   int block_start;
+  // persistent variant: 8 x 8-pixel sub-patches, two per work item
+  int sub_x, sub_y;       // sub-patches per row / column of one image
+  int pair_start;         // first work item of this level
 };
 
 
@@ -387,9 +390,14 @@ __device__ unsigned long long g_wv[8][64][2];     // per wave of the stamped wor
 #define DBGW(it, k)
 #endif
 
+// One work item of the persistent kernel: two 8 x 8-pixel sub-patches of one level (4 x 4 tiles each = the two
+// tile groups of the MFMAs), each with its own image and origin; y0 = kNoSub marks an absent partner.
 struct WTile {
-  int l, n, y0, x0, mb;
+  int l, mb;
+  int n[2], y0[2], x0[2];
 };
+constexpr int SP = 8;                     // sub-patch edge (output pixels)
+constexpr int kNoSub = 1 << 24;
 
 // ---------------------------------------------------------------------------
 // Variant Z: persistent, 8 symmetric waves, LDS-DMA staging, everything
@@ -412,9 +420,11 @@ struct WTile {
 //   every step  : 8 MFMAs, B operands single-buffered (ds_read_b64 reissued
 //                 into the registers an MFMA pair just consumed);
 //   one barrier.
-// The raw patch lives in LDS as channel pairs with row pitch 40
-// (addr = (c>>1)*400 + r*40 + (c&1)*20 + q): the transform's ds_read_b64 of a
-// half-wave (4 x 8 tiles of one channel) then covers all 64 banks once.
+// The raw data lives in LDS as channel pairs with row pitch 40
+// (addr = (c>>1)*400 + r*40 + (c&1)*20 + q): q < 10 is the 10 x 10 window of the work item's first 8 x 8
+// sub-patch, q >= 10 that of the second (round 2 staged ONE 8 x 16 patch, 18 of the 20 columns: on a
+// 40 x 56 map 12.5 % of the MFMAs then ran outside the image, 6 % over the five levels of a 600 px
+// batch; 8 x 8 sub-patches tile 40 x 56 exactly, pairs may span images).
 // Tiles of a workgroup are decoded once, in parallel, into an LDS list.
 // ---------------------------------------------------------------------------
 constexpr int ZP = 40;                    // raw row pitch (two channels side by side)
@@ -430,12 +440,15 @@ static_assert(ZRAW <= ZRAWP && STEPS == 16 && AD == 8, "variant Z is written for
 // output stores are.  Round-3 counters (profiles/r03_pmc_classes.md) showed 9.7x the algorithmic
 // read bytes leaving L2 on the tower launches: the 2 MB filter block of a phase shares a 4 MB L2
 // with ~15 MB of patches and outputs streaming through it and is evicted again and again.
-template <int NT>
+// PAIRS: the work item is two 8 x 8 sub-patches (true) or one 8 x 16 patch (false: the round-2 geometry; on
+// maps that 8 x 16 patches tile exactly it is ~4 % faster -- 18 instead of 2 x 10 staged columns -- so the
+// launcher takes it whenever the sub-patches would not save at least 2 % of the computed pixels).
+template <int NT, bool PAIRS>
 __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args) {
   __shared__ float raw[NRAW * ZRAWP];
   __shared__ float vbuf[2 * VBUF];
   __shared__ int lv_start[32], lv_tx[32], lv_per[32];
-  __shared__ int trec[ZNT * 5];
+  __shared__ int trec[ZNT * 8];
   __shared__ unsigned zvoff[8 * ZL * 64];   // per wave, per wave-load, per lane
 
   const int K = args.K, M = args.M;
@@ -466,15 +479,15 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   // per SIMD, item 4): waves 4-7 lose VALU arbitration to their older SIMD partners on every chunk;
   // one s_setprio for them, no per-segment flips
 
-  // ---- level tables and this workgroup's tile list ----
+  // ---- level tables and this workgroup's work items ----
   if (tid < 32) {
     int v = 0x7fffffff, tx = 1, per = 1;
 #pragma unroll
     for (int i = 0; i < SSAD_MAX_CONV_PROBLEMS; ++i)
       if (tid == i && i < args.n_levels) {
-        v = args.lv[i].block_start;
-        tx = args.lv[i].tiles_x;
-        per = args.lv[i].tiles_x * args.lv[i].tiles_y;
+        v = PAIRS ? args.lv[i].pair_start : args.lv[i].block_start;
+        tx = PAIRS ? args.lv[i].sub_x : args.lv[i].tiles_x;
+        per = PAIRS ? args.lv[i].sub_x * args.lv[i].sub_y : args.lv[i].tiles_x * args.lv[i].tiles_y;
       }
     lv_start[tid] = v; lv_tx[tid] = tx; lv_per[tid] = per;
   }
@@ -487,21 +500,31 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
     for (int k = 0; k < args.n_levels; ++k) l += pid >= lv_start[k];
     pid -= lv_start[l];
     const int per = lv_per[l], tx = lv_tx[l];
-    const int n = pid / per;
-    pid -= n * per;
-    const int ty0 = pid / tx, tx0 = pid - ty0 * tx;
-    int* r = trec + i * 5;
-    r[0] = l; r[1] = n; r[2] = ty0 * PR; r[3] = tx0 * PC; r[4] = mb;
+    int* r = trec + i * 8;
+    r[0] = l; r[1] = mb;
+    for (int h = 0; h < 2; ++h) {
+      int sid = PAIRS ? 2 * pid + h : pid;
+      const int n = sid / per;
+      sid -= n * per;
+      const int sy = sid / tx, sx = sid - sy * tx;
+      const bool there = n < args.lv[l].N;
+      r[2 + 3 * h] = there ? n : 0;
+      r[3 + 3 * h] = there ? sy * SP : kNoSub;
+      r[4 + 3 * h] = PAIRS ? sx * SP : sx * PC + h * SP;     // (one patch = its left and right half)
+    }
   }
   __syncthreads();
   auto get_tile = [&](int i) {
-    const int* r = trec + i * 5;
+    const int* r = trec + i * 8;
     WTile o;
     o.l = __builtin_amdgcn_readfirstlane(r[0]);
-    o.n = __builtin_amdgcn_readfirstlane(r[1]);
-    o.y0 = __builtin_amdgcn_readfirstlane(r[2]);
-    o.x0 = __builtin_amdgcn_readfirstlane(r[3]);
-    o.mb = __builtin_amdgcn_readfirstlane(r[4]);
+    o.mb = __builtin_amdgcn_readfirstlane(r[1]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      o.n[h] = __builtin_amdgcn_readfirstlane(r[2 + 3 * h]);
+      o.y0[h] = __builtin_amdgcn_readfirstlane(r[3 + 3 * h]);
+      o.x0[h] = __builtin_amdgcn_readfirstlane(r[4 + 3 * h]);
+    }
     return o;
   };
 
@@ -530,7 +553,8 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
       const WTile Tt = get_tile(ld_tile);
       const WLevel& L = args.lv[Tt.l];
       const int H = L.H, W = L.W, HW = H * W;
-      xrs = ssad_dev::uniform_rsrc_words(L.x + (long long)Tt.n * K * HW, (unsigned)(K * HW * 4));
+      // descriptor over the level's whole batch: the two sub-patches may sit in different images
+      xrs = ssad_dev::uniform_rsrc_words(L.x, (unsigned)((long long)L.N * K * HW * 4));
       chunk_bytes = KC * HW * 4;
 #pragma unroll 1
       for (int j = 0; j < ZL; ++j) {
@@ -538,11 +562,12 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
         const int p = e / ZCP, rem = e - p * ZCP;
         const int r = rem / ZP, cq = rem - r * ZP;
         const int hi = cq >= ZP / 2 ? 1 : 0;
-        const int q = cq - hi * (ZP / 2);
-        const int gy = Tt.y0 - 1 + r, gx = Tt.x0 - 1 + q;
-        const bool ok = (e < ZRAW) & (q < PC + 2) & ((unsigned)gy < (unsigned)H) &
-                        ((unsigned)gx < (unsigned)W);
-        myvoff[j * 64] = ok ? (unsigned)(((2 * p + hi) * HW + gy * W + gx) * 4) : kOOBOff;
+        const int q = cq - hi * (ZP / 2);                 // 0..19: sub-patch q / 10, column q % 10
+        const int sb = PAIRS && q >= SP + 2 ? 1 : 0;
+        const int gy = (sb ? Tt.y0[1] : Tt.y0[0]) - 1 + r, gx = (sb ? Tt.x0[1] : Tt.x0[0]) - 1 + q - sb * (SP + 2);
+        const int n = sb ? Tt.n[1] : Tt.n[0];
+        const bool ok = (e < ZRAW) & (PAIRS || q < PC + 2) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+        myvoff[j * 64] = ok ? (unsigned)(((n * K + 2 * p + hi) * HW + gy * W + gx) * 4) : kOOBOff;
       }
     }
     dma_soff = __builtin_amdgcn_readfirstlane(real ? ld_ch * chunk_bytes : 0);
@@ -580,7 +605,11 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   const int t_rb = t_row == 0 ? 2 : t_row == 1 ? 2 : t_row == 2 ? 1 : 3;
   const float t_sg = t_row == 1 ? 1.0f : -1.0f;
   const int t_tile = lane & 31, t_c = (wave >> 2) * 2 + (lane >> 5);   // channel within a round of 4
-  const int t_src = (t_c >> 1) * ZCP + (t_c & 1) * (ZP / 2) + (2 * (t_tile >> 3)) * ZP + 2 * (t_tile & 7);
+  // tile t of the work item: PAIRS: sub-patch t >> 4, row (t & 15) >> 2, column t & 3 of its 4 x 4 tiles;
+  // else row t >> 3, column t & 7 of the patch's 4 x 8
+  const int t_src = (t_c >> 1) * ZCP + (t_c & 1) * (ZP / 2) +
+      (PAIRS ? (2 * ((t_tile & 15) >> 2)) * ZP + 2 * (t_tile & 3) + (t_tile >> 4) * (SP + 2)
+             : (2 * (t_tile >> 3)) * ZP + 2 * (t_tile & 7));
   const int t_dst = (t_row * 4 * KC + t_c) * VP + (t_tile & 15) * 2 + (t_tile >> 4);
   const int t_oa = t_src + t_ra * ZP, t_ob = t_src + t_rb * ZP;
   auto xf_load = [&](const float* rb0, int rnd, float2 (&d)[4]) {
@@ -817,20 +846,21 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
       if (fast && !sigm) {
         // straight-line path: buffer stores, per-lane offset per tile group,
         // (row, channel) displacement in the scalar offset
-        const int img_bytes = M * HW * 4;
-        const __amdgpu_buffer_rsrc_t yrsrc = uniform_rsrc(L.y + (long long)T.n * M * HW, img_bytes);
-        const __amdgpu_buffer_rsrc_t krsrc =
-            uniform_rsrc(masked ? L.aux + (long long)T.n * M * HW : L.y, img_bytes);
+        // (descriptors over the level's whole batch: tile group g = sub-patch g has its own image)
+        const int lvl_bytes = L.N * M * HW * 4;
+        const __amdgpu_buffer_rsrc_t yrsrc = uniform_rsrc(L.y, lvl_bytes);
+        const __amdgpu_buffer_rsrc_t krsrc = uniform_rsrc(masked ? L.aux : L.y, lvl_bytes);
         const float lo = relu ? 0.0f : -__builtin_inff();
         unsigned vo[2][2];             // [tile group][row a]
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           const int tile = g * 16 + jn;
-          const int py = T.y0 + 2 * (tile >> 3), px = T.x0 + 2 * (tile & 7);
+          const int py = PAIRS ? T.y0[g] + 2 * (jn >> 2) : T.y0[0] + 2 * (tile >> 3);
+          const int px = PAIRS ? T.x0[g] + 2 * (jn & 3) : T.x0[0] + 2 * (tile & 7);
 #pragma unroll
           for (int a = 0; a < 2; ++a)
             vo[g][a] = ((py + a < H) & (px < W))
-                ? (unsigned)(((mt * 16 + kq * 4) * HW + (py + a) * W + px) * 4) : kOOBOff;
+                ? (unsigned)(((T.n[g] * M + mt * 16 + kq * 4) * HW + (py + a) * W + px) * 4) : kOOBOff;
         }
         // channels r, r+1 of an accumulator quad are adjacent registers: the
         // whole A^T M A runs as v_pk_add_f32 on (r, r+1) pairs; the final max
@@ -879,12 +909,13 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
         };
         if (masked) emit(std::true_type{}); else emit(std::false_type{});
       } else {
-        float* yout = L.y + (long long)T.n * M * HW;
-        const float* aux = masked ? L.aux + (long long)T.n * M * HW : nullptr;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
+          float* yout = L.y + (long long)T.n[g] * M * HW;
+          const float* aux = masked ? L.aux + (long long)T.n[g] * M * HW : nullptr;
           const int tile = g * 16 + jn;
-          const int py = T.y0 + 2 * (tile >> 3), px = T.x0 + 2 * (tile & 7);
+          const int py = PAIRS ? T.y0[g] + 2 * (jn >> 2) : T.y0[0] + 2 * (tile >> 3);
+          const int px = PAIRS ? T.x0[g] + 2 * (jn & 3) : T.x0[0] + 2 * (tile & 7);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = mt * 16 + kq * 4 + r;
@@ -966,53 +997,100 @@ int ssad_conv_wino_pack_filters(const ssad_pack_entry* entries_host, int n_entri
   return (int)hipGetLastError();
 }
 
+// Geometry of the persistent kernel per level: 8 x 16 patches where they tile the map exactly or the 8 x 8
+// sub-patches would not save pixels (a patch stages 18 columns where two sub-patches stage 20: ~4 % faster per
+// computed pixel), sub-patch pairs elsewhere.  SSAD_WINO_PAIRS=0 / 1 forces one geometry for every level.
+static bool level_wants_pairs(int N, int H, int W) {
+  static const int geom = [] { const char* e = getenv("SSAD_WINO_PAIRS"); return (e && *e) ? atoi(e) : -1; }();
+  if (geom >= 0) return geom != 0;
+  const long long by_patch = (long long)cdiv(W, PC) * cdiv(H, PR) * 128;
+  const long long by_sub = (long long)cdiv(W, SP) * cdiv(H, SP) * 64;
+  (void)N;
+  return by_sub * 100 <= by_patch * 96;
+}
+
+// number of kernel launches one call makes (1, or 2 when both geometries occur); tools/pmc_by_class.py
+// attributes counters to timing classes by launch order
+int ssad_conv3x3_forward_wino_launches(const ssad_conv_level* lv, int n_levels) {
+  if (!lv || n_levels < 1) return 0;
+  static const int variant = [] { const char* e = getenv("SSAD_WINO_VARIANT"); return e ? atoi(e) : 2; }();
+  if (variant != 2) return 1;
+  int with_pairs = 0, with_patches = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    if ((long long)lv[l].N * lv[l].H * lv[l].W == 0) continue;
+    if (level_wants_pairs(lv[l].N, lv[l].H, lv[l].W)) ++with_pairs; else ++with_patches;
+  }
+  return (with_pairs > 0) + (with_patches > 0);
+}
+
 int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const float* packed,
                               const float* bias, int Cout, int Cin, int flags,
                               ssad_stream_t stream) {
   if (n_levels < 1 || n_levels > SSAD_MAX_CONV_PROBLEMS || Cout <= 0 || Cin <= 0)
     return SSAD_E_BADARG;
-  WArgs a;
-  a.n_levels = n_levels;
-  a.M = Cout; a.K = Cin; a.chunks = cdiv(Cin, KC); a.flags = flags;
-  long long blocks = 0;
   for (int l = 0; l < n_levels; ++l) {
-    WLevel& L = a.lv[l];
-    L.x = lv[l].x; L.y = lv[l].y; L.aux = lv[l].aux;
-    L.packed = lv[l].packed ? lv[l].packed : packed;
-    L.bias = lv[l].packed ? lv[l].bias : bias;
-    if (!L.packed) return SSAD_E_BADARG;
-    L.N = lv[l].N; L.H = lv[l].H; L.W = lv[l].W;
-    if (L.N < 0 || L.H < 0 || L.W < 0) return SSAD_E_BADARG;
-    if ((long long)L.H * L.W * (Cin > Cout ? Cin : Cout) >= (1LL << 29)) return SSAD_E_BADARG;
-    if ((flags & SSAD_CONV_MASK_AUX) && !L.aux) return SSAD_E_BADARG;
-    L.tiles_x = cdiv(L.W, PC); L.tiles_y = cdiv(L.H, PR);
-    L.block_start = (int)blocks;
-    blocks += (long long)L.N * L.tiles_x * L.tiles_y;
-    if (blocks >= (1LL << 31)) return SSAD_E_BADARG;
+    if (!(lv[l].packed ? lv[l].packed : packed)) return SSAD_E_BADARG;
+    if (lv[l].N < 0 || lv[l].H < 0 || lv[l].W < 0) return SSAD_E_BADARG;
+    if ((long long)lv[l].N * lv[l].H * lv[l].W * (Cin > Cout ? Cin : Cout) >= (1LL << 29)) return SSAD_E_BADARG;
+    if ((flags & SSAD_CONV_MASK_AUX) && !lv[l].aux) return SSAD_E_BADARG;
   }
-  for (int l = n_levels; l < SSAD_MAX_CONV_PROBLEMS; ++l) a.lv[l] = WLevel{};
-  if (blocks == 0) return 0;
-  a.patches = (int)blocks; a.mblocks = cdiv(Cout, BM);
   static const int variant = [] { const char* e = getenv("SSAD_WINO_VARIANT"); return e ? atoi(e) : 2; }();
-  if (variant == 2) {   // any Cin: channels past Cin read as zero (buffer range check, zero-padded filter)
-    const int cus2 = ssad_cu_count();
-    const long long total = blocks * a.mblocks;
-    if (total >= (1LL << 31)) return SSAD_E_BADARG;
-    long long grid = total < cus2 ? total : cus2;
-    if (grid * ZNT < total) grid = (total + ZNT - 1) / ZNT;
-    // SSAD_WINO_NT=2: non-temporal output stores (tuning; measured +-0).  SSAD_WINO_XCD_GROUP: tiles per
-    // XCD run (1 = round 2's round-robin order)
-    static const int nt = [] { const char* e = getenv("SSAD_WINO_NT"); return e ? atoi(e) & 2 : 0; }();
-    static const int xg = [] { const char* e = getenv("SSAD_WINO_XCD_GROUP"); return e ? atoi(e) : 8; }();
-    a.xcd_group = xg;
-    if (nt == 2) hipLaunchKernelGGL(wino_conv_z_kernel<2>, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(wino_conv_z_kernel<0>, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
+  // pass 0: the levels staged as 8 x 16 patches; pass 1: those staged as sub-patch pairs (persistent kernel
+  // only; SSAD_WINO_VARIANT=0, the non-persistent kernel, takes every level in pass 0)
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool use_pairs = pass == 1;
+    WArgs a;
+    a.M = Cout; a.K = Cin; a.chunks = cdiv(Cin, KC); a.flags = flags;
+    a.mblocks = cdiv(Cout, BM);
+    int nl = 0;
+    long long blocks = 0, pairs = 0;
+    for (int l = 0; l < n_levels; ++l) {
+      if ((long long)lv[l].N * lv[l].H * lv[l].W == 0) continue;
+      if (variant == 2 ? level_wants_pairs(lv[l].N, lv[l].H, lv[l].W) != use_pairs : use_pairs) continue;
+      WLevel& L = a.lv[nl++];
+      L.x = lv[l].x; L.y = lv[l].y; L.aux = lv[l].aux;
+      L.packed = lv[l].packed ? lv[l].packed : packed;
+      L.bias = lv[l].packed ? lv[l].bias : bias;
+      L.N = lv[l].N; L.H = lv[l].H; L.W = lv[l].W;
+      L.tiles_x = cdiv(L.W, PC); L.tiles_y = cdiv(L.H, PR);
+      L.block_start = (int)blocks;
+      blocks += (long long)L.N * L.tiles_x * L.tiles_y;
+      L.sub_x = cdiv(L.W, SP); L.sub_y = cdiv(L.H, SP);
+      L.pair_start = (int)pairs;
+      pairs += ((long long)L.N * L.sub_x * L.sub_y + 1) / 2;
+      if (blocks >= (1LL << 31)) return SSAD_E_BADARG;
+    }
+    if (nl == 0) continue;
+    a.n_levels = nl;
+    for (int l = nl; l < SSAD_MAX_CONV_PROBLEMS; ++l) a.lv[l] = WLevel{};
+    if (variant == 2) {   // any Cin: channels past Cin read as zero (buffer range check, zero-padded filter)
+      const int cus2 = ssad_cu_count();
+      a.patches = (int)(use_pairs ? pairs : blocks);
+      const long long total = (long long)a.patches * a.mblocks;
+      if (total >= (1LL << 31)) return SSAD_E_BADARG;
+      long long grid = total < cus2 ? total : cus2;
+      if (grid * ZNT < total) grid = (total + ZNT - 1) / ZNT;
+      // SSAD_WINO_NT=2: non-temporal output stores (tuning; measured +-0).  SSAD_WINO_XCD_GROUP: tiles per
+      // XCD run (1 = round 2's round-robin order)
+      static const int nt = [] { const char* e = getenv("SSAD_WINO_NT"); return e ? atoi(e) & 2 : 0; }();
+      static const int xg = [] { const char* e = getenv("SSAD_WINO_XCD_GROUP"); return e ? atoi(e) : 8; }();
+      a.xcd_group = xg;
+      const dim3 g3((unsigned)grid), b3(kBlock);
+      if (nt == 2 && use_pairs) hipLaunchKernelGGL((wino_conv_z_kernel<2, true>), g3, b3, 0, (hipStream_t)stream, a);
+      else if (nt == 2) hipLaunchKernelGGL((wino_conv_z_kernel<2, false>), g3, b3, 0, (hipStream_t)stream, a);
+      else if (use_pairs) hipLaunchKernelGGL((wino_conv_z_kernel<0, true>), g3, b3, 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((wino_conv_z_kernel<0, false>), g3, b3, 0, (hipStream_t)stream, a);
+    } else {
+      // SSAD_WINO_VARIANT=0: the non-persistent kernel
+      a.patches = (int)blocks;
+      a.xcd_group = 1;
+      hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)blocks, cdiv(Cout, BM)), dim3(kBlock), 0,
+                         (hipStream_t)stream, a);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
   }
-  // SSAD_WINO_VARIANT=0: the non-persistent kernel
-  hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)blocks, cdiv(Cout, BM)), dim3(kBlock), 0,
-                     (hipStream_t)stream, a);
-  return (int)hipGetLastError();
+  return 0;
 }
 
 #ifdef WINO_TIMELINE

@@ -41,12 +41,20 @@ def class_sequences(f16=False):
     names = {PR.CONV3X3: "wino_conv_z_kernel", PR.CONV3X3_WGRAD: "wino_wgrad_kernel", PR.POW_SUM: "pow_sum_kernel",
              PR.CLS_LOSSES_FUSED: "cls_losses_fused_kernel", PR.SGD_FLAT: "sgd_flat_kernel",
              PR.F16_CONV3X3: "conv3x3_f16_kernel", PR.F16_WGRAD: "conv3x3_wgrad_f16_kernel"}
+    from ssad_amd import kernels as K
     seq = {}
     for op in h.prog.ops:
         n = names.get(op.code)
         if n is None or (op.code == PR.CONV3X3 and not op.i[4]):
             continue
-        seq.setdefault(n, []).append(op.klass)
+        launches = 1
+        if op.code == PR.CONV3X3:
+            # one call = one launch per staging geometry present among its levels (8 x 16 patches / sub-patch
+            # pairs, conv3x3_winograd.hip); the levels of the batch-1 program have the bench's map sizes
+            import ctypes as C
+            launches = K.lib().ssad_conv3x3_forward_wino_launches(C.cast(op.p[0], C.POINTER(K.ConvLevel)), op.i[0])
+        for k in range(launches):
+            seq.setdefault(n, []).append((op.klass, k == 0))
     return seq
 
 
@@ -80,9 +88,9 @@ def attribute(dispatches, seq):
             continue                                   # warm-up step with extra (teacher pack) or partial capture
         used += 1
         for n, s in seq.items():
-            for d, k in zip(per[n], s):
+            for d, (k, first) in zip(per[n], s):
                 a = acc.setdefault(k, {"kernel": n, "dispatches": 0, "sum": {}})
-                a["dispatches"] += 1
+                a["dispatches"] += int(first)          # per CALL: a call's launches are summed
                 for cn, v in d["c"].items():
                     a["sum"][cn] = a["sum"].get(cn, 0.0) + v
     out = {}
