@@ -190,19 +190,24 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
   // that the memory instructions interleave with the MFMAs instead of holding them up in one burst
   auto issue_quarter = [&](float* st, int q) {
     const unsigned base = (unsigned)(uintptr_t)(lds_ptr)st;           // LDS byte address of the stage
+    // Channels past the tensor's last (only in its last block: Cout 720 = 11.25 blocks) re-read the last
+    // valid channel instead of being masked per lane: the scalar offset is not range-checked, a per-lane select
+    // is a VALU instruction (v_cndmask: 8 cycles of the SIMD that the fp32 MFMAs do not get,
+    // tools/coissue_probe.hip), and rows / columns of dU beyond (M, C) are never read by the reduce kernel.
 #pragma unroll
     for (int i = 2 * q; i < 2 * q + 2; ++i) {
       const int m = wave * (GM / 8) + i;
-      ssad_dev::lds_dma<4>(dyrs, base + m * SY * 4, m < m_left ? dy_vo : kOOB, m * cHW * 4);
+      const int mm = m < m_left ? m : m_left - 1;
+      ssad_dev::lds_dma<4>(dyrs, base + m * SY * 4, dy_vo, mm * cHW * 4);
     }
 #pragma unroll
     for (int i = 2 * q; i < 2 * q + 2; ++i) {
       const int c = wave * (GC / 8) + i;
+      const int cc = c < c_left ? c : c_left - 1;
       const int slot = (c & 0x30) | ((c & 3) << 2) | ((c >> 2) & 3);
 #pragma unroll
       for (int k = 0; k < 2; ++k)
-        ssad_dev::lds_dma<4>(xrs, base + (GM * SY + slot * SX + 64 * k) * 4, c < c_left ? x_vo[k] : kOOB,
-                             c * cHW * 4);
+        ssad_dev::lds_dma<4>(xrs, base + (GM * SY + slot * SX + 64 * k) * 4, x_vo[k], cc * cHW * 4);
     }
   };
   auto issue_unit = [&](float* st) {

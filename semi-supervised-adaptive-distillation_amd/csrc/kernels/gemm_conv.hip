@@ -138,11 +138,15 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
   auto issue = [&](int chunk, int buf) {
     const int k0 = chunk * BK;
     float* base = lds + buf * STAGE;
+    // (rows past K are masked per lane only in the chunk that contains K: a per-lane select is a VALU
+    // instruction, and VALU cycles are cycles the fp32 MFMAs of the SIMD do not get -- tools/coissue_probe.hip)
+    const bool tail = k0 + BK > K;
 #pragma unroll
     for (int u = 0; u < A_PER_WAVE; ++u) {
       const int ia = wave * A_PER_WAVE + u;
       const int row = k0 + ia * A_ROWS_PER_INSTR;                  // first row of this instruction
-      const unsigned vo = (row + a_row < K) ? a_voff : kOob;
+      unsigned vo = a_voff;
+      if (tail) vo = (row + a_row < K) ? a_voff : kOob;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_ptr)(base + ia * 256), 16, vo, row * g.lda * 4, 0, 0);
     }
     if (IMPLICIT) {
@@ -163,7 +167,8 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
       for (int u = 0; u < B_PER_WAVE; ++u) {
         const int ib = wave * B_PER_WAVE + u;
         const int row = k0 + ib * 2;
-        const unsigned vo = (row + h < K) ? b_voff : kOob;
+        unsigned vo = b_voff;
+        if (tail) vo = (row + h < K) ? b_voff : kOob;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr)(base + A_STAGE + ib * 256), 16, vo, row * P * 4, 0, 0);
       }
     }
@@ -194,22 +199,28 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
     // whose buffer the next DMA overwrites
     __builtin_amdgcn_s_barrier();
     if (c + 2 < chunks) issue(c + 2, buf == 0 ? 2 : buf - 1);
-    const float* s = lds + buf * STAGE;
+    // Operand reads: ONE base register per operand (lane part + stage), every (k, tile) displacement an
+    // immediate offset of a ds_read_b32.  Read through volatile pointers: hipcc otherwise pairs the two tiles
+    // of a step into ds_read2_b32, whose 8-bit offsets do not reach the next k row (512 B), and pays for it
+    // with two v_add_u32 per step -- VALU issue that the MFMAs of the SIMD wait for.
+    typedef const volatile __attribute__((address_space(3))) float* lds_cvf;
+    const lds_cvf sa = (lds_cvf)(lds + buf * STAGE + a_rd + h * BM);
+    const lds_cvf sb = (lds_cvf)(lds + buf * STAGE + b_rd + h * BN);
     // operands of step ks + 1 are requested before the MFMAs of step ks are issued
     float av[2][TI], bv[2][2];
 #pragma unroll
-    for (int i = 0; i < TI; ++i) av[0][i] = s[a_rd + h * BM + i * 32];
+    for (int i = 0; i < TI; ++i) av[0][i] = sa[i * 32];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) bv[0][t] = s[b_rd + h * BN + t * 32];
+    for (int t = 0; t < 2; ++t) bv[0][t] = sb[t * 32];
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
       const int cur = ks & 1, nxt = cur ^ 1;
       if (ks + 1 < BK / 2) {
-        const int k = 2 * (ks + 1) + h;
+        const int k = 2 * (ks + 1);
 #pragma unroll
-        for (int i = 0; i < TI; ++i) av[nxt][i] = s[a_rd + k * BM + i * 32];
+        for (int i = 0; i < TI; ++i) av[nxt][i] = sa[k * BM + i * 32];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) bv[nxt][t] = s[b_rd + k * BN + t * 32];
+        for (int t = 0; t < 2; ++t) bv[nxt][t] = sb[k * BN + t * 32];
       }
       __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of this step's MFMAs
 #pragma unroll
