@@ -709,7 +709,9 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
       const int piece = i * 8 + wave;                       // pair = piece / 5, 32 pixels each
       const int pair = piece / (X_PAIR / 64), q = piece % (X_PAIR / 64);
       const int pix = q * 32 + lpix;                        // row * 20 + column
-      const int gy = y0 + ky - 1 + pix / XPW, gx = x0 - 1 + pix % XPW;
+      // PW: no halo -- the X tile starts AT x0, so that the one tap of a pointwise layer is the unshifted
+      // operand (kx = 0: registers as they come from the transpose reads, no v_alignbit / v_mov in the loop)
+      const int gy = y0 + ky - 1 + pix / XPW, gx = x0 - (PW ? 0 : 1) + pix % XPW;
       const int cb = ccb + pair * 2 + lodd;
       unsigned off = kOob;
       if (cb < CB && gy >= 0 && gy < H && gx >= 0 && gx < W)
@@ -790,7 +792,8 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) xx[u][k] = tr_quad(xa, (u * 2 * X_PITCH + row * XPW * 2) * 16 + k * 128);
+        for (int k = 0; k < (PW ? 2 : 3); ++k)
+          xx[u][k] = tr_quad(xa, (u * 2 * X_PITCH + row * XPW * 2) * 16 + k * 128);
     };
     load_row(0, a[0], xr[0]);
 #pragma unroll
@@ -820,7 +823,7 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int kx = PW ? 1 : 0; kx < (PW ? 2 : 3); ++kx)
+        for (int kx = 0; kx < (PW ? 1 : 3); ++kx)
           acc[u][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[row & 1], b[u][kx], acc[u][kx], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);                     // bound the operands in flight
     }
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
     const int c = ccb * 8 + wc * 64 + u * 32 + (lane & 31);
     if (c >= p.C) continue;
 #pragma unroll
-    for (int kx = PW ? 1 : 0; kx < (PW ? 2 : 3); ++kx)
+    for (int kx = 0; kx < (PW ? 1 : 3); ++kx)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = ocb + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
