@@ -639,12 +639,13 @@ __device__ __forceinline__ short4v tr_quad(unsigned lds_addr, int off_bytes) {
 }
 // all LDS reads issued so far have returned; the operands are tied to the statement so that no
 // instruction consuming them can be scheduled above it
-__device__ __forceinline__ void tr_wait(half8& a, short4v (&x)[2][3]) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(a), "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[1][2]));
+__device__ __forceinline__ void tr_wait(half8 (&a)[2], short4v (&x)[3]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
 }
 
-// 8 waves: wave (wo, wc) owns 32 output x 64 input channels x 3 taps = 6 accumulator tiles.  With
+// 8 waves: wave (wo, wc) owns 64 output x 32 input channels x 3 taps = 6 accumulator tiles (round 2: 32 x 64 --
+// the tap shifts are built in registers from the X operand, 4 v_perm + 4 v_mov per X tile and row, and VALU
+// issue is time the MFMAs of the SIMD do not get (tools/coissue_probe.hip): one X tile per wave halves it).  With
 // 4 waves of twice that (one wave per SIMD, 192 accumulator registers) nothing covered the issue
 // time of the LDS-DMA instructions -- 18 per wave and stage at 100-185 cycles each beside 96 MFMAs
 // of 32: removing the DMA made the kernel 1.7x faster.  Two waves per SIMD do.
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
   extern __shared__ uint4 lds[];                           // 2 stages
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wo = wave & 3, wc = wave >> 2;
+  const int wo = wave & 1, wc = wave >> 1;
   // Work item v = (split, filter row, block pair), split-major.  The items of one split read the SAME
   // pixel stages (X by every output block and filter row, dY by every input block); workgroups b,
   // b + 8, ... share an XCD and its L2, so each XCD takes runs of `xcd_group` consecutive items
@@ -758,8 +759,8 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
   const int kpx = 8 * (g >> 1) + pj;                       // pixel within the 16-pixel K-step
   const int in_pair = (quad >> 1) * 8 + (quad & 1) * 4;    // halves: block of the pair, half slot
   // 32-channel MFMA tile = 2 pairs; group g & 1 takes the second
-  const int xb_base = (((wc * 4 + (g & 1)) * X_PITCH + kpx * 2) * 8) + in_pair;          // + tile * 2 pairs
-  const int ya_base = ((Y_BASE + (wo * 2 + (g & 1)) * Y_PITCH + kpx * 2) * 8) + in_pair;
+  const int xb_base = (((wc * 2 + (g & 1)) * X_PITCH + kpx * 2) * 8) + in_pair;
+  const int ya_base = ((Y_BASE + (wo * 4 + (g & 1)) * Y_PITCH + kpx * 2) * 8) + in_pair;   // + tile * 2 pairs
 
   float16v acc[2][3];
 #pragma unroll
@@ -785,34 +786,31 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
     // shifted operands in registers -- kx = 2 is a register selection, kx = 1 four v_alignbit_b32 --
     // instead of reading each shift from LDS (12 of the 16 read pairs per row; the kernel was
     // bound by the LDS read rate: 64 KB per CU per 384 MFMA cycles).
-    half8 a[2];
-    short4v xr[2][2][3];                  // [buffer][u][lo, hi, next]
-    auto load_row = [&](int row, half8& aa, short4v (&xx)[2][3]) {
-      aa = tr_pair(ya, (row * WPX * 2) * 16);
+    half8 a[2][2];                        // [buffer][output tile u]
+    short4v xr[2][3];                     // [buffer][lo, hi, next]
+    auto load_row = [&](int row, half8 (&aa)[2], short4v (&xx)[3]) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u) aa[u] = tr_pair(ya, (u * 2 * Y_PITCH + row * WPX * 2) * 16);
 #pragma unroll
-        for (int k = 0; k < (PW ? 2 : 3); ++k)
-          xx[u][k] = tr_quad(xa, (u * 2 * X_PITCH + row * XPW * 2) * 16 + k * 128);
+      for (int k = 0; k < (PW ? 2 : 3); ++k) xx[k] = tr_quad(xa, (row * XPW * 2) * 16 + k * 128);
     };
     load_row(0, a[0], xr[0]);
 #pragma unroll
     for (int row = 0; row < WR; ++row) {
       tr_wait(a[row & 1], xr[row & 1]);
-      half8 b[2][3];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      half8 b[3];
+      {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const u32x2 lo = __builtin_bit_cast(u32x2, xr[row & 1][u][0]), hi = __builtin_bit_cast(u32x2, xr[row & 1][u][1]),
-                    nx = __builtin_bit_cast(u32x2, xr[row & 1][u][2]);
+        const u32x2 lo = __builtin_bit_cast(u32x2, xr[row & 1][0]), hi = __builtin_bit_cast(u32x2, xr[row & 1][1]),
+                    nx = __builtin_bit_cast(u32x2, xr[row & 1][2]);
         // dwords d0..d4 = pixels (0,1) (2,3) (4,5) (6,7) (8,9) of this lane's 8-pixel half
-        b[u][0] = __builtin_bit_cast(half8, u32x4{lo.x, lo.y, hi.x, hi.y});
-        b[u][1] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(lo.y, lo.x, 16),
-                                                  __builtin_amdgcn_alignbit(hi.x, lo.y, 16),
-                                                  __builtin_amdgcn_alignbit(hi.y, hi.x, 16),
-                                                  __builtin_amdgcn_alignbit(nx.x, hi.y, 16)});
-        b[u][2] = __builtin_bit_cast(half8, u32x4{lo.y, hi.x, hi.y, nx.x});
+        b[0] = __builtin_bit_cast(half8, u32x4{lo.x, lo.y, hi.x, hi.y});
+        b[1] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(lo.y, lo.x, 16),
+                                               __builtin_amdgcn_alignbit(hi.x, lo.y, 16),
+                                               __builtin_amdgcn_alignbit(hi.y, hi.x, 16),
+                                               __builtin_amdgcn_alignbit(nx.x, hi.y, 16)});
+        b[2] = __builtin_bit_cast(half8, u32x4{lo.y, hi.x, hi.y, nx.x});
       }
       if (row + 1 < WR && !(F16_ABLATE & 16)) load_row(row + 1, a[(row + 1) & 1], xr[(row + 1) & 1]);
       if (more) {                                            // the next stage's DMA, a piece per row
@@ -824,7 +822,7 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int kx = 0; kx < (PW ? 1 : 3); ++kx)
-          acc[u][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[row & 1], b[u][kx], acc[u][kx], 0, 0, 0);
+          acc[u][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[row & 1][u], b[kx], acc[u][kx], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);                     // bound the operands in flight
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -833,15 +831,15 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
 
   // ---- partial sums: part[split][tap][m][c], c contiguous across lanes
   const int h = lane >> 5;
+  const int c = ccb * 8 + wc * 32 + (lane & 31);
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int c = ccb * 8 + wc * 64 + u * 32 + (lane & 31);
     if (c >= p.C) continue;
 #pragma unroll
     for (int kx = 0; kx < (PW ? 1 : 3); ++kx)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = ocb + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int m = ocb + wo * 64 + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m < p.M) {
           if (PW) p.part[((long long)split * p.M + m) * p.C + c] = acc[u][kx][r];
           else p.part[(((long long)split * 9 + ky * 3 + kx) * p.M + m) * p.C + c] = acc[u][kx][r];
