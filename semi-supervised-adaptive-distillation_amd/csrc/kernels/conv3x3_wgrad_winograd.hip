@@ -415,13 +415,16 @@ int plan(const ssad_conv_level* lv, int n_levels, int Cout, int Cin, GArgs* a) {
   }
   a->total_units = (int)units;
   // splits: minimise rounds(S) x units-per-split(S) on the chip's CUs (all
-  // workgroups cost the same), at least 8 units per split, smallest S on ties
+  // workgroups cost the same), at least 8 units per split, smallest S on ties.  Up to one split per CU:
+  // a 64 x 64-channel layer (res2 of the backbones) is ONE block pair -- with the round-2 cap of 32 splits its
+  // filter gradient ran on 32 of the 256 CUs.  (Workspace: splits x 16 x Mp x Cp floats, 64 MB at most.)
   const int cus = ssad_cu_count();
   const int oblocks = a->mblocks * a->cblocks;
   int s = 1;
   long long best = -1;
-  for (int t = 1; t <= 32; ++t) {
+  for (int t = 1; t <= cus; ++t) {
     if (t > 1 && units / t < 8) break;
+    if (t > 32 && (long long)t * 16 * a->mblocks * GM * a->cblocks * GC * 4 > (64LL << 20)) break;
     const long long cost = (long long)cdiv(oblocks * t, cus) * cdiv((int)(units ? units : 1), t);
     if (best < 0 || cost < best) { best = cost; s = t; }
   }

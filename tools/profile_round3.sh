@@ -46,7 +46,9 @@ if [ "$WHAT" = "pmc" ] || [ "$WHAT" = "all" ]; then
       fetch=$(ls /tmp/prof_pmc_fetch/*.db | head -1) write=$(ls /tmp/prof_pmc_write/*.db | head -1) \
       mfma=$(ls /tmp/prof_pmc_mfma/*.db | head -1) wait=$(ls /tmp/prof_pmc_wait/*.db | head -1) \
       tcc=$(ls /tmp/prof_pmc_tcc/*.db | head -1) > /dev/null 2> $O/pmc_classes.err
-  # the same passes with round 2's round-robin work order (A/B of the XCD-aware order)
+fi
+if [ "$WHAT" = "pmc_rr" ]; then
+  # fetch / L2 passes with round 2's round-robin work order (A/B of the XCD-aware order; not part of "all")
   SSAD_WINO_XCD_GROUP=1 SSAD_WGRAD_XCD_GROUP=1 pmc pmc_fetch_rr FETCH_SIZE -- --workload heads
   SSAD_WINO_XCD_GROUP=1 SSAD_WGRAD_XCD_GROUP=1 pmc pmc_tcc_rr TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -- --workload heads
   python tools/pmc_by_class.py --out $O/pmc_classes_roundrobin.json --md $O/pmc_classes_roundrobin.md \
