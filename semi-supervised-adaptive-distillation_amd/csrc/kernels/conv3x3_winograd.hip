@@ -436,15 +436,15 @@ constexpr int ZNT = 256;                  // tiles per workgroup in the LDS list
 constexpr int AD = 8;                     // filter operand ring depth (steps)
 static_assert(ZRAW <= ZRAWP && STEPS == 16 && AD == 8, "variant Z is written for KC = 16");
 
-// NT: cache policy of the streamed traffic.  bit 0: the raw-patch DMA is non-temporal, bit 1: the
-// output stores are.  Round-3 counters (profiles/r03_pmc_classes.md) showed 9.7x the algorithmic
-// read bytes leaving L2 on the tower launches: the 2 MB filter block of a phase shares a 4 MB L2
-// with ~15 MB of patches and outputs streaming through it and is evicted again and again.
 // PAIRS: the work item is two 8 x 8 sub-patches (true) or one 8 x 16 patch (false: the round-2 geometry; on
 // maps that 8 x 16 patches tile exactly it is ~4 % faster -- 18 instead of 2 x 10 staged columns -- so the
 // launcher takes it whenever the sub-patches would not save at least 2 % of the computed pixels).
-template <int NT, bool PAIRS>
+// NHALF (Cout <= 64: res2 of the backbones, bbox_pred): a 128-channel block would leave waves 4-7 (and their
+// half of every SIMD's MFMA issue) idle; instead waves w and w + 4 share output channels 16 (w & 3) .. and
+// split the work item's two tile groups between them (8 accumulator quads per wave instead of 16).
+template <bool PAIRS, bool NHALF>
 __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args) {
+  constexpr int NG = NHALF ? 1 : 2;        // tile groups per wave
   __shared__ float raw[NRAW * ZRAWP];
   __shared__ float vbuf[2 * VBUF];
   __shared__ int lv_start[32], lv_tx[32], lv_per[32];
@@ -456,6 +456,8 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = NHALF ? (wave & 3) : wave;          // this wave's 16-channel slice of the block
+  const int g0 = NHALF ? (wave >> 2) : 0;            // its first tile group
   const int total = args.patches * args.mblocks;
   // Which tiles a workgroup walks: round i of the grid covers tiles [i G, (i + 1) G); inside a round
   // the workgroups of ONE XCD (ids b, b + 8, ...: they share an L2) take runs of `xg` CONTIGUOUS
@@ -641,12 +643,12 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   const bool dbg_on = blockIdx.x == 3 && tid == 0;
 #endif
   const int kq = lane >> 4, jn = lane & 15;
-  const float* bbase = vbuf + kq * VP + jn * 2;
+  const float* bbase = vbuf + kq * VP + jn * 2 + g0;
   const int mtiles = cdiv(M, 16);
   const int stream_bytes = (mtiles * chunks * STEPS * 256 + 1024) * 4;
   const unsigned a_voff = lane * 16;
   auto stream_off = [&](const WTile& Tt) {
-    int mt = Tt.mb * (BM / 16) + wave;
+    int mt = Tt.mb * (BM / 16) + wv;
     if (mt >= mtiles) mt = 0;
     return __builtin_amdgcn_readfirstlane(mt * chunks * STEPS * 1024);
   };
@@ -666,7 +668,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
     if (L.bias) {
       const __amdgpu_buffer_rsrc_t brsrc = uniform_rsrc(L.bias, M * 4);
       b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-          brsrc, (unsigned)(((Tt.mb * (BM / 16) + wave) * 16 + kq * 4) * 4), 0, 0));
+          brsrc, (unsigned)(((Tt.mb * (BM / 16) + wv) * 16 + kq * 4) * 4), 0, 0));
     }
     return b;
   };
@@ -694,14 +696,14 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   int nbase = abase;
   const int look = chunks > 1 ? 1 : 0;
   for (int i = 0; i < my_n; ++i) {
-    const int mt = T.mb * (BM / 16) + wave;
+    const int mt = T.mb * (BM / 16) + wv;
     const bool active = mt < mtiles;
-    f32x4 acc[16][2];
+    f32x4 acc[16][NG];
     // bias folded into the accumulators: b * u u^T, u = (1,0,0,-1), A^T u = (1,1)
 #pragma unroll
     for (int x = 0; x < 16; ++x)
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
+      for (int g = 0; g < NG; ++g)
         acc[x][g] = (x == 0 || x == 15) ? bv : (x == 3 || x == 12) ? -bv : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int ch = 0; ch < chunks; ++ch, ++s) {
       DBG(1, s, 0);
@@ -732,12 +734,17 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
         // B operands are single-buffered: right after the two MFMAs of an xr
         // pair issue, the same registers take the next step's pair (a 2-step
         // ring was measured: no gain).
-        float bc[4][2];
+        float bc[4][NG];
+        auto b_read = [&](float (&b)[NG], const float* src) {
+          if (NHALF) {
+            b[0] = src[0];
+          } else {
+            const float2 b2 = *reinterpret_cast<const float2*>(src);
+            b[0] = b2.x; b[NG - 1] = b2.y;
+          }
+        };
 #pragma unroll
-        for (int xr = 0; xr < 4; ++xr) {
-          const float2 b2 = *reinterpret_cast<const float2*>(vb + (xr * KC) * VP);
-          bc[xr][0] = b2.x; bc[xr][1] = b2.y;
-        }
+        for (int xr = 0; xr < 4; ++xr) b_read(bc[xr], vb + (xr * KC) * VP);
         float2 xd[4];
         unsigned dma_vo = kOOBOff;
 #pragma unroll
@@ -766,13 +773,10 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
           for (int xr = 0; xr < 4; ++xr) {
             const int xi = xq * 4 + xr;
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+            for (int g = 0; g < NG; ++g)
               acc[xi][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[xr], bc[xr][g], acc[xi][g], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (step < STEPS - 1 && !(WINO_ABLATE & 8)) {
-              const float2 b2 = *reinterpret_cast<const float2*>(vb + ((nxq * 4 + xr) * KC + nks * 4) * VP);
-              bc[xr][0] = b2.x; bc[xr][1] = b2.y;
-            }
+            if (step < STEPS - 1 && !(WINO_ABLATE & 8)) b_read(bc[xr], vb + ((nxq * 4 + xr) * KC + nks * 4) * VP);
             __builtin_amdgcn_sched_barrier(0);
           }
           // refill the ring slot just consumed with the operand of step + 8
@@ -851,23 +855,25 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
         const __amdgpu_buffer_rsrc_t yrsrc = uniform_rsrc(L.y, lvl_bytes);
         const __amdgpu_buffer_rsrc_t krsrc = uniform_rsrc(masked ? L.aux : L.y, lvl_bytes);
         const float lo = relu ? 0.0f : -__builtin_inff();
-        unsigned vo[2][2];             // [tile group][row a]
+        unsigned vo[NG][2];            // [local tile group][row a]
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int gi = 0; gi < NG; ++gi) {
+          const int g = g0 + gi;
           const int tile = g * 16 + jn;
-          const int py = PAIRS ? T.y0[g] + 2 * (jn >> 2) : T.y0[0] + 2 * (tile >> 3);
-          const int px = PAIRS ? T.x0[g] + 2 * (jn & 3) : T.x0[0] + 2 * (tile & 7);
+          const int sy0 = g ? T.y0[1] : T.y0[0], sx0 = g ? T.x0[1] : T.x0[0], sn = g ? T.n[1] : T.n[0];
+          const int py = PAIRS ? sy0 + 2 * (jn >> 2) : T.y0[0] + 2 * (tile >> 3);
+          const int px = PAIRS ? sx0 + 2 * (jn & 3) : T.x0[0] + 2 * (tile & 7);
 #pragma unroll
           for (int a = 0; a < 2; ++a)
-            vo[g][a] = ((py + a < H) & (px < W))
-                ? (unsigned)(((T.n[g] * M + mt * 16 + kq * 4) * HW + (py + a) * W + px) * 4) : kOOBOff;
+            vo[gi][a] = ((py + a < H) & (px < W))
+                ? (unsigned)(((sn * M + mt * 16 + kq * 4) * HW + (py + a) * W + px) * 4) : kOOBOff;
         }
         // channels r, r+1 of an accumulator quad are adjacent registers: the
         // whole A^T M A runs as v_pk_add_f32 on (r, r+1) pairs; the final max
         // (ReLU clamp or -inf) doubles as the repack into (x, x+1) store pairs.
         auto emit = [&](auto has_mask) {
 #pragma unroll
-          for (int g = 0; g < 2; ++g)
+          for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               f32x2 kk[2][2];
@@ -902,7 +908,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
                   }
                   __builtin_amdgcn_raw_buffer_store_b64(
                       __builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, make_float2(o0, o1)),
-                      yrsrc, vo[g][a], (2 * h + rr) * HW * 4, (NT & 2) ? 2 : 0);
+                      yrsrc, vo[g][a], (2 * h + rr) * HW * 4, 0);
                 }
               }
             }
@@ -910,17 +916,19 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
         if (masked) emit(std::true_type{}); else emit(std::false_type{});
       } else {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          float* yout = L.y + (long long)T.n[g] * M * HW;
-          const float* aux = masked ? L.aux + (long long)T.n[g] * M * HW : nullptr;
+        for (int gi = 0; gi < NG; ++gi) {
+          const int g = g0 + gi;
+          const int sy0 = g ? T.y0[1] : T.y0[0], sx0 = g ? T.x0[1] : T.x0[0], sn = g ? T.n[1] : T.n[0];
+          float* yout = L.y + (long long)sn * M * HW;
+          const float* aux = masked ? L.aux + (long long)sn * M * HW : nullptr;
           const int tile = g * 16 + jn;
-          const int py = PAIRS ? T.y0[g] + 2 * (jn >> 2) : T.y0[0] + 2 * (tile >> 3);
-          const int px = PAIRS ? T.x0[g] + 2 * (jn & 3) : T.x0[0] + 2 * (tile & 7);
+          const int py = PAIRS ? sy0 + 2 * (jn >> 2) : T.y0[0] + 2 * (tile >> 3);
+          const int px = PAIRS ? sx0 + 2 * (jn & 3) : T.x0[0] + 2 * (tile & 7);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = mt * 16 + kq * 4 + r;
             float v[2][2];
-            out_tile(g, r, v);
+            out_tile(gi, r, v);
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
               const int yy = py + a;
@@ -1070,16 +1078,17 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
       if (total >= (1LL << 31)) return SSAD_E_BADARG;
       long long grid = total < cus2 ? total : cus2;
       if (grid * ZNT < total) grid = (total + ZNT - 1) / ZNT;
-      // SSAD_WINO_NT=2: non-temporal output stores (tuning; measured +-0).  SSAD_WINO_XCD_GROUP: tiles per
-      // XCD run (1 = round 2's round-robin order)
-      static const int nt = [] { const char* e = getenv("SSAD_WINO_NT"); return e ? atoi(e) & 2 : 0; }();
+      // SSAD_WINO_XCD_GROUP: tiles per XCD run (1 = round 2's round-robin order).  (Non-temporal output stores,
+      // SSAD_WINO_NT in earlier rounds, measured +-0 and are gone.)
       static const int xg = [] { const char* e = getenv("SSAD_WINO_XCD_GROUP"); return e ? atoi(e) : 8; }();
+      static const int nhalf = [] { const char* e = getenv("SSAD_WINO_NHALF"); return (e && *e) ? atoi(e) : 1; }();
       a.xcd_group = xg;
       const dim3 g3((unsigned)grid), b3(kBlock);
-      if (nt == 2 && use_pairs) hipLaunchKernelGGL((wino_conv_z_kernel<2, true>), g3, b3, 0, (hipStream_t)stream, a);
-      else if (nt == 2) hipLaunchKernelGGL((wino_conv_z_kernel<2, false>), g3, b3, 0, (hipStream_t)stream, a);
-      else if (use_pairs) hipLaunchKernelGGL((wino_conv_z_kernel<0, true>), g3, b3, 0, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL((wino_conv_z_kernel<0, false>), g3, b3, 0, (hipStream_t)stream, a);
+      const bool half = nhalf && Cout <= 64;
+      if (use_pairs && half) hipLaunchKernelGGL((wino_conv_z_kernel<true, true>), g3, b3, 0, (hipStream_t)stream, a);
+      else if (use_pairs) hipLaunchKernelGGL((wino_conv_z_kernel<true, false>), g3, b3, 0, (hipStream_t)stream, a);
+      else if (half) hipLaunchKernelGGL((wino_conv_z_kernel<false, true>), g3, b3, 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((wino_conv_z_kernel<false, false>), g3, b3, 0, (hipStream_t)stream, a);
     } else {
       // SSAD_WINO_VARIANT=0: the non-persistent kernel
       a.patches = (int)blocks;

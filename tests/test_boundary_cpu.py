@@ -365,3 +365,26 @@ def test_kernel_entry_points_refuse_bad_arguments_without_a_device(lib):
     raw.ssad_momentum_sgd_flat.argtypes = [vp, vp, vp, vp, f32, f32, ctypes.POINTER(K.SgdSegment), i32, vp, vp]
     seg = (K.SgdSegment * 1)(K.SgdSegment(0, 8, 0, 0, p.value))
     assert raw.ssad_momentum_sgd_flat(p, p, p, p, 0.9, 1e-4, seg, 1, None, None) == -1      # row_scale without row_len
+
+
+def test_winograd_launch_count_query_follows_the_level_shapes():
+    """ssad_conv3x3_forward_wino_launches (host-side, no device work): one launch per staging geometry present.
+    8 x 16 patches tile 80 x 112 exactly; 8 x 8 sub-patches save 12.5 % of the pixels on 40 x 56."""
+    import ctypes as C
+    from ssad_amd import kernels as K
+    if os.environ.get("SSAD_WINO_PAIRS") or os.environ.get("SSAD_WINO_VARIANT"):
+        pytest.skip("geometry forced through the environment")
+    L = K.lib()
+
+    def launches(shapes):
+        arr = (K.ConvLevel * len(shapes))()
+        for i, (n, h, w) in enumerate(shapes):
+            arr[i].N, arr[i].H, arr[i].W = n, h, w
+        return L.ssad_conv3x3_forward_wino_launches(arr, len(shapes))
+
+    assert launches([(16, 80, 112)]) == 1
+    assert launches([(16, 40, 56)]) == 1
+    assert launches([(16, 80, 112), (16, 40, 56)]) == 2
+    assert launches([(16, 80, 112), (16, 40, 56), (16, 20, 28), (16, 10, 14), (16, 5, 7)]) == 2
+    assert launches([(0, 80, 112), (16, 40, 56)]) == 1          # an empty level launches nothing
+    assert L.ssad_conv3x3_forward_wino_launches(None, 0) == 0

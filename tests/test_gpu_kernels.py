@@ -449,6 +449,23 @@ def test_fused_cls_losses_equal_separate_ops(K):
 # Winograd F(2x2,3x3) engine: same contract, same tolerance as the direct kernel
 # ---------------------------------------------------------------------------
 
+@pytest.mark.parametrize("pairs", ["0", "1"])
+def test_winograd_both_staging_geometries_forced(pairs):
+    """The persistent kernel stages a work item as one 8 x 16 patch or as two 8 x 8 sub-patches (which may sit in
+    different images; an odd count leaves an absent partner), chosen per level by the launcher.  The library reads
+    SSAD_WINO_PAIRS once per process, so each forced geometry runs the Winograd parity tests in a child process."""
+    import subprocess
+    import sys
+    if os.environ.get("SSAD_WINO_PAIRS_CHILD"):
+        pytest.skip("child run")
+    env = dict(os.environ, SSAD_WINO_PAIRS=pairs, SSAD_WINO_PAIRS_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "winograd_vs_oracle or winograd_multilevel_matches or winograd_persistent_short or "
+                        "winograd_multiproblem"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 @pytest.mark.parametrize("shape", [
     (1, 8, 128, 8, 16), (2, 16, 40, 9, 17), (2, 36, 256, 5, 7), (1, 256, 256, 10, 14),
     (1, 24, 130, 17, 33), (3, 8, 65, 2, 31), (1, 720, 256, 5, 7), (2, 256, 720, 3, 4)],
