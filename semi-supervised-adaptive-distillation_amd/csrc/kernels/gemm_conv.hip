@@ -356,19 +356,29 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nt_kernel(const WgradAr
   // a wave-instruction covers 16 rows x 64 B: lane -> row (lane >> 2), slot (lane & 3), which
   // holds source piece slot ^ ((row >> 2) & 3)
   const int d_row = lane >> 2, d_slot = lane & 3;
+  // The lane's part of a source offset (its row of the tile, its 16-byte piece) is fixed for the whole kernel;
+  // what moves with the chunk -- image n, first column p -- is wave-uniform and goes into the instruction's SCALAR
+  // offset.  (Round 2 rebuilt the full 64-bit per-lane offset for every DMA: ~40 VALU instructions per chunk
+  // beside 32 MFMAs, and VALU issue is time the fp32 MFMAs of the SIMD do not get, tools/coissue_probe.hip.)
+  unsigned vy0[2], vx0[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = (wave * 2 + u) * 16 + d_row;
+    const int piece = d_slot ^ ((row >> 2) & 3);
+    vy0[u] = (m0 + row < g.M) ? (unsigned)((((long long)(m0 + row)) * P + piece * 4) * 4) : kOob;
+    vx0[u] = (c0 + row < g.C) ? (unsigned)((((long long)(c0 + row)) * P + piece * 4) * 4) : kOob;
+  }
   auto issue = [&](int chunk, int buf) {
     const long long q = (long long)(ch0 + chunk) * BK;            // first column of the chunk
     const int n = (int)(q / P), p = (int)(q - (long long)n * P);  // 16 | P: a chunk stays in one image
+    const int sy = __builtin_amdgcn_readfirstlane((int)((((long long)n * g.M) * P + p) * 4));
+    const int sx = __builtin_amdgcn_readfirstlane((int)((((long long)n * g.C) * P + p) * 4));
     float* base = lds + buf * STAGE;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int inst = wave * 2 + u;                               // 8 instructions per operand
-      const int row = inst * 16 + d_row;
-      const int piece = d_slot ^ ((row >> 2) & 3);
-      const unsigned vy = (m0 + row < g.M) ? (unsigned)((((long long)n * g.M + m0 + row) * P + p + piece * 4) * 4) : kOob;
-      const unsigned vx = (c0 + row < g.C) ? (unsigned)((((long long)n * g.C + c0 + row) * P + p + piece * 4) * 4) : kOob;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrs, (lds_ptr)(base + inst * 256), 16, vy, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr)(base + TSTAGE + inst * 256), 16, vx, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrs, (lds_ptr)(base + inst * 256), 16, vy0[u], sy, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr)(base + TSTAGE + inst * 256), 16, vx0[u], sx, 0, 0);
     }
   };
 
