@@ -16,6 +16,10 @@ int ssad_wino_wgrad_launch(const ssad_conv_level* lv, int n_levels, float* dW, i
                            int accumulate, void* workspace, size_t workspace_bytes,
                            hipStream_t stream);
 
+// The ResNet stem (7x7 / stride 2 / pad 3, 3 -> 64 channels) from an LDS-staged raw patch (stem.hip); taken by
+// ssad_conv_implicit_gemm for exactly that geometry when no epilogue term is asked for.
+int ssad_stem7x7s2_launch(const float* x, const float* wt, int lda, int N, int H, int W, float* y, hipStream_t stream);
+
 // Compute units of the CURRENT device (cached per device: a process may drive several GPUs, and
 // workspace sizing and launch must agree on the same device's count).
 inline int ssad_cu_count() {

@@ -166,6 +166,8 @@ def test_grouped_conv3x3_vs_reference_operator_golden(K, golden_dir):
     (2, 3, 64, 32, 40, 7, 2, 3),        # the stem: 7x7 / 2, pad 3, three input channels
     (2, 3, 64, 128, 192, 7, 2, 3),      # the stem at the body-graph test's image size
     (1, 3, 16, 22, 32, 7, 2, 3),        # ragged borders on every side (11 x 16 outputs)
+    (1, 3, 64, 22, 32, 7, 2, 3),        # the same map through the stem kernel (one partial 8 x 32 tile)
+    (3, 3, 64, 75, 141, 7, 2, 3),       # odd image, 38 x 71 outputs: partial tiles right and below, 3 images
     (2, 16, 24, 12, 16, 3, 2, 1),       # 3x3 / 2 (P6 / P7)
     (1, 8, 136, 8, 12, 3, 1, 1),        # 3x3 / 1, two 128-row tiles
     (2, 24, 40, 8, 12, 1, 1, 0),        # degenerates to the pointwise GEMM
@@ -183,6 +185,12 @@ def test_conv_implicit_gemm_vs_oracle(K, geom):
     close(K.conv_implicit_gemm(dev(X), dev(Wt), None, stride=st, pad=pad, relu=True).cpu().numpy(),
           np.maximum(oracle.conv_forward(X, Wt, None, kernel=k, stride=st, pad=pad), 0), CONV_RTOL, CONV_FLOOR,
           "relu(Y)")
+    # no epilogue term at all: for the stem geometry (3 -> 64 channels, 7x7 / 2, pad 3) this is the dedicated kernel
+    # of stem.hip (raw patch staged in LDS), which the backbones call; any other geometry stays on the general path
+    plain = K.conv_implicit_gemm(dev(X), dev(Wt), None, stride=st, pad=pad)
+    close(plain.cpu().numpy(), oracle.conv_forward(X, Wt, None, kernel=k, stride=st, pad=pad), CONV_RTOL, CONV_FLOOR,
+          "Y without bias")
+    assert torch.equal(plain, K.conv_implicit_gemm(dev(X), dev(Wt), None, stride=st, pad=pad)), "run-to-run bits"
 
 
 def test_conv_implicit_gemm_vs_reference_operator_golden(K, golden_dir):
