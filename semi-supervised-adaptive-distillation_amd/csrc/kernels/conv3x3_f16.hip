@@ -690,7 +690,15 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
   // of MFMAs, so that the ~150-cycle issue of an LDS-DMA instruction on one wave runs under the
   // MFMAs of the other wave of the SIMD instead of both waves issuing their nine at once.
   constexpr int kPieces = X_PIECES / 8 + Y_PIECES / 8;     // 9
-  unsigned poff[kPieces];
+  // Offsets of a stage's nine pieces.  A stage whose X window and dY tile lie inside the image ("interior": most of
+  // them) differs from any other interior stage of its level only by a wave-uniform displacement -- image, first
+  // row, first column -- which rides in the DMA's SCALAR offset; the lane parts (which pixel of the tile, which
+  // channel block) are computed once per level (lconst).  Only border stages build per-lane offsets with their
+  // image-edge masks.  (Round 2 did that for every stage: ~225 VALU instructions per wave and stage beside 48 MFMAs
+  // -- removing the next stage's fetch made the kernel 1.36x faster, and it was this arithmetic, not the DMA:
+  // issuing the nine instructions earlier or later moved nothing.)
+  unsigned poff[kPieces], lconst[kPieces];
+  int cur_lv = -1, soffx = 0, soffy = 0;
   __amdgpu_buffer_rsrc_t fxrs, fyrs;
   auto fetch_setup = [&](int s) {
     int lv = 0;
@@ -698,21 +706,52 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
       if (s >= p.stage0[l]) lv = l;
     const int H = p.H[lv], W = p.W[lv], plane = H * W;
     const int seg_x = (W + WPX - 1) / WPX, seg_y = (H + WR - 1) / WR;
-    fxrs = ssad_dev::uniform_rsrc(p.x[lv], (unsigned)((long long)p.N[lv] * CB * plane * 16));
-    fyrs = ssad_dev::uniform_rsrc(p.dy[lv], (unsigned)((long long)p.N[lv] * MB * plane * 16));
+    if (lv != cur_lv) {
+      cur_lv = lv;
+      fxrs = ssad_dev::uniform_rsrc(p.x[lv], (unsigned)((long long)p.N[lv] * CB * plane * 16));
+      fyrs = ssad_dev::uniform_rsrc(p.dy[lv], (unsigned)((long long)p.N[lv] * MB * plane * 16));
+#pragma unroll
+      for (int i = 0; i < X_PIECES / 8; ++i) {
+        const int piece = i * 8 + wave;
+        const int pair = piece / (X_PAIR / 64), q = piece % (X_PAIR / 64);
+        const int pix = q * 32 + lpix;
+        const int cb = ccb + pair * 2 + lodd;
+        lconst[i] = cb < CB ? (unsigned)((cb * plane + (pix / XPW) * W + pix % XPW) * 16) : kOob;
+      }
+#pragma unroll
+      for (int i = 0; i < Y_PIECES / 8; ++i) {
+        const int piece = i * 8 + wave;
+        const int pair = piece / (Y_PAIR / 64), q = piece % (Y_PAIR / 64);
+        const int pix = q * 32 + lpix;
+        const int mb = (ocb >> 3) + pair * 2 + lodd;
+        lconst[X_PIECES / 8 + i] = mb < MB ? (unsigned)((mb * plane + (pix / WPX) * W + pix % WPX) * 16) : kOob;
+      }
+    }
     int t = s - p.stage0[lv];
     const int sx = t % seg_x; t /= seg_x;
     const int sy = t % seg_y;
     const int n = t / seg_y;
     const int y0 = sy * WR, x0 = sx * WPX;
+    // PW: no halo -- the X tile starts AT x0, so that the one tap of a pointwise layer is the unshifted
+    // operand (kx = 0: registers as they come from the transpose reads, no v_alignbit / v_mov in the loop)
+    const int gy0 = y0 + ky - 1, gx0 = x0 - (PW ? 0 : 1);
+    // the X window's used columns: 18 (16 + halo) of the 20 fetched; the other two may hold anything
+    const bool interior = gy0 >= 0 && gy0 + WR <= H && gx0 >= 0 && gx0 + (PW ? WPX : WPX + 2) <= W &&
+                          y0 + WR <= H && x0 + WPX <= W;
+    if (interior) {
+      soffx = __builtin_amdgcn_readfirstlane((n * CB * plane + gy0 * W + gx0) * 16);
+      soffy = __builtin_amdgcn_readfirstlane((n * MB * plane + y0 * W + x0) * 16);
+#pragma unroll
+      for (int k = 0; k < kPieces; ++k) poff[k] = lconst[k];
+      return;
+    }
+    soffx = soffy = 0;
 #pragma unroll
     for (int i = 0; i < X_PIECES / 8; ++i) {
       const int piece = i * 8 + wave;                       // pair = piece / 5, 32 pixels each
       const int pair = piece / (X_PAIR / 64), q = piece % (X_PAIR / 64);
       const int pix = q * 32 + lpix;                        // row * 20 + column
-      // PW: no halo -- the X tile starts AT x0, so that the one tap of a pointwise layer is the unshifted
-      // operand (kx = 0: registers as they come from the transpose reads, no v_alignbit / v_mov in the loop)
-      const int gy = y0 + ky - 1 + pix / XPW, gx = x0 - (PW ? 0 : 1) + pix % XPW;
+      const int gy = gy0 + pix / XPW, gx = gx0 + pix % XPW;
       const int cb = ccb + pair * 2 + lodd;
       unsigned off = kOob;
       if (cb < CB && gy >= 0 && gy < H && gx >= 0 && gx < W)
@@ -737,12 +776,12 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
       const int piece = k * 8 + wave;
       const int pair = piece / (X_PAIR / 64), q = piece % (X_PAIR / 64);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          fxrs, (__attribute__((address_space(3))) void*)(dst + pair * X_PITCH + q * 64), 16, poff[k], 0, 0, 0);
+          fxrs, (__attribute__((address_space(3))) void*)(dst + pair * X_PITCH + q * 64), 16, poff[k], soffx, 0, 0);
     } else {
       const int piece = (k - X_PIECES / 8) * 8 + wave;
       const int pair = piece / (Y_PAIR / 64), q = piece % (Y_PAIR / 64);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          fyrs, (__attribute__((address_space(3))) void*)(dst + Y_BASE + pair * Y_PITCH + q * 64), 16, poff[k], 0,
+          fyrs, (__attribute__((address_space(3))) void*)(dst + Y_BASE + pair * Y_PITCH + q * 64), 16, poff[k], soffy,
           0, 0);
     }
   };
