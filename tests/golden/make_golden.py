@@ -204,7 +204,9 @@ CONV_REF_GEOMS = [("k1s1", 2, 24, 40, 9, 13, 1, 1, 0, 1), ("k1s2", 2, 32, 16, 10
                   ("k3g64c4", 1, 256, 256, 9, 20, 3, 1, 1, 64), ("k3g4c16s2", 2, 64, 64, 11, 18, 3, 2, 1, 4),
                   ("k3g2c32", 1, 64, 64, 10, 17, 3, 1, 1, 2), ("k3g2c32s2", 1, 64, 64, 16, 9, 3, 2, 1, 2),
                   # strided k x k with 4-pixel-multiple output maps (what the implicit GEMM takes)
-                  ("k7s2p176", 1, 3, 16, 22, 32, 7, 2, 3, 1), ("k3s2p80", 2, 16, 24, 16, 20, 3, 2, 1, 1)]
+                  ("k7s2p176", 1, 3, 16, 22, 32, 7, 2, 3, 1), ("k3s2p80", 2, 16, 24, 16, 20, 3, 2, 1, 1),
+                  # the stem itself (3 -> 64 channels): two images, 22 x 36 outputs = partial 8 x 32 tiles of stem.hip
+                  ("k7s2m64", 2, 3, 64, 44, 72, 7, 2, 3, 1)]
 
 
 def conv_ref_inputs(seed, N, Cin, M, H, W, kernel=3, stride=1, pad=1, group=1):
