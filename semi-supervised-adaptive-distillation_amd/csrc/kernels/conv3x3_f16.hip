@@ -887,6 +887,236 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// All NINE taps in one workgroup (round 3, end): the kernel above moves 74 KB from L2 to LDS per 12.6 MFLOP
+// (170 flop per byte) and that operand stream, not latency, bounds it.  Here a workgroup owns
+// 128 output x 64 input channels x 9 taps: a stage is 8 rows x 16 pixels of dY and the 10 x 20 X window around
+// it (58 KB per 18.9 MFLOP = 325 flop per byte); wave (wo, wc) = 32 x 32 channels x 9 taps = 9 accumulator tiles.
+// A lane keeps the three X rows a dY row meets, each in its three column shifts (9 operands, 36 registers), as a
+// rolling window: per dY row ONE new X row is read (three transpose reads) and shifted (4 v_perm + 4 v_mov), one
+// dY operand is read, nine MFMAs are issued.  Partial sums: part[split][tap][M][C] as above, same reduce kernel.
+// ---------------------------------------------------------------------------------------------------
+constexpr int N9_OT = 128, N9_CT = 64;
+constexpr int X9_ROWS = WR + 2;
+constexpr int X9_USED = X9_ROWS * XPW;                        // 200 pixels
+constexpr int X9_PAIR = (X9_USED * 2 + 63) / 64 * 64;         // 448 slots = 7 DMA pieces per block pair
+constexpr int X9_PITCH = X9_PAIR + 8;
+constexpr int X9_PAIRS = N9_CT / 16, Y9_PAIRS = N9_OT / 16;   // 4, 8
+constexpr int Y9_BASE = X9_PAIRS * X9_PITCH;
+constexpr int W9_STAGE = Y9_BASE + Y9_PAIRS * Y_PITCH;        // 3936 slots = 61.5 KiB
+constexpr int X9_PIECES = X9_PAIRS * (X9_PAIR / 64);          // 28
+constexpr int Y9_PIECES = Y9_PAIRS * (Y_PAIR / 64);           // 32
+constexpr int P9 = 8;                                         // pieces per wave and stage (60 of 64 used)
+static_assert(X9_PIECES + Y9_PIECES <= 8 * P9 && P9 == WR, "one DMA piece per wave and row");
+
+__device__ __forceinline__ void tr_wait9(half8& a, short4v (&x)[3]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+}
+__device__ __forceinline__ void tr_wait9x(short4v (&x)[3], short4v (&y)[3]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]));
+}
+
+__global__ __launch_bounds__(kWThreads) void wgrad9_f16_kernel(const F16Wgrad p) {
+  extern __shared__ uint4 lds[];                           // 2 stages
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wo = wave & 3, wc = wave >> 2;
+  int v = (int)blockIdx.x;
+  {
+    const int G = (int)gridDim.x, xg = p.xcd_group;
+    if (xg > 1 && (G & 7) == 0 && ((G >> 3) % xg) == 0) {
+      const int r = v >> 3, x = v & 7;
+      v = (r / xg) * (8 * xg) + x * xg + (r % xg);
+    }
+  }
+  const int split = v / p.blocks, bp = v - split * p.blocks;
+  const int ocb = (bp / p.cblocks) * N9_OT, ccb = (bp % p.cblocks) * (N9_CT / 8);
+  const int CB = (p.C + 7) >> 3, MB = (p.M + 7) >> 3;
+  const int per = (p.stages + p.splits - 1) / p.splits;
+  const int s0 = split * per, s1 = min(s0 + per, p.stages);
+
+  constexpr unsigned kOob = 0x80000000u;
+  const int lpix = lane >> 1, lodd = lane & 1;
+  // piece k of this wave: index k * 8 + wave into [28 X pieces | 32 dY pieces | 4 unused]
+  unsigned poff[P9], lconst[P9];
+  int cur_lv = -1, soffx = 0, soffy = 0;
+  __amdgpu_buffer_rsrc_t fxrs, fyrs;
+  auto lane_const = [&](int k, int plane, int W) -> unsigned {
+    const int pc = k * 8 + wave;
+    if (pc < X9_PIECES) {
+      const int pair = pc / (X9_PAIR / 64), q = pc % (X9_PAIR / 64);
+      const int pix = q * 32 + lpix;
+      const int cb = ccb + pair * 2 + lodd;
+      return (cb < CB && pix < X9_USED) ? (unsigned)((cb * plane + (pix / XPW) * W + pix % XPW) * 16) : kOob;
+    }
+    if (pc < X9_PIECES + Y9_PIECES) {
+      const int py = pc - X9_PIECES;
+      const int pair = py / (Y_PAIR / 64), q = py % (Y_PAIR / 64);
+      const int pix = q * 32 + lpix;
+      const int mb = (ocb >> 3) + pair * 2 + lodd;
+      return mb < MB ? (unsigned)((mb * plane + (pix / WPX) * W + pix % WPX) * 16) : kOob;
+    }
+    return kOob;
+  };
+  auto fetch_setup = [&](int s) {
+    int lv = 0;
+    for (int l = 1; l < p.n_levels; ++l)
+      if (s >= p.stage0[l]) lv = l;
+    const int H = p.H[lv], W = p.W[lv], plane = H * W;
+    const int seg_x = (W + WPX - 1) / WPX, seg_y = (H + WR - 1) / WR;
+    if (lv != cur_lv) {
+      cur_lv = lv;
+      fxrs = ssad_dev::uniform_rsrc(p.x[lv], (unsigned)((long long)p.N[lv] * CB * plane * 16));
+      fyrs = ssad_dev::uniform_rsrc(p.dy[lv], (unsigned)((long long)p.N[lv] * MB * plane * 16));
+#pragma unroll
+      for (int k = 0; k < P9; ++k) lconst[k] = lane_const(k, plane, W);
+    }
+    int t = s - p.stage0[lv];
+    const int sx = t % seg_x; t /= seg_x;
+    const int sy = t % seg_y;
+    const int n = t / seg_y;
+    const int y0 = sy * WR, x0 = sx * WPX;
+    const int gy0 = y0 - 1, gx0 = x0 - 1;
+    const bool interior = gy0 >= 0 && gy0 + X9_ROWS <= H && gx0 >= 0 && gx0 + WPX + 2 <= W && y0 + WR <= H &&
+                          x0 + WPX <= W;
+    if (interior) {
+      soffx = __builtin_amdgcn_readfirstlane((n * CB * plane + gy0 * W + gx0) * 16);
+      soffy = __builtin_amdgcn_readfirstlane((n * MB * plane + y0 * W + x0) * 16);
+#pragma unroll
+      for (int k = 0; k < P9; ++k) poff[k] = lconst[k];
+      return;
+    }
+    soffx = soffy = 0;
+#pragma unroll
+    for (int k = 0; k < P9; ++k) {
+      const int pc = k * 8 + wave;
+      unsigned off = kOob;
+      if (pc < X9_PIECES) {
+        const int pair = pc / (X9_PAIR / 64), q = pc % (X9_PAIR / 64);
+        const int pix = q * 32 + lpix;
+        const int gy = gy0 + pix / XPW, gx = gx0 + pix % XPW;
+        const int cb = ccb + pair * 2 + lodd;
+        if (cb < CB && pix < X9_USED && gy >= 0 && gy < H && gx >= 0 && gx < W)
+          off = (unsigned)(((n * CB + cb) * plane + gy * W + gx) * 16);
+      } else if (pc < X9_PIECES + Y9_PIECES) {
+        const int py = pc - X9_PIECES;
+        const int pair = py / (Y_PAIR / 64), q = py % (Y_PAIR / 64);
+        const int pix = q * 32 + lpix;
+        const int gy = y0 + pix / WPX, gx = x0 + pix % WPX;
+        const int mb = (ocb >> 3) + pair * 2 + lodd;
+        if (mb < MB && gy < H && gx < W) off = (unsigned)(((n * MB + mb) * plane + gy * W + gx) * 16);
+      }
+      poff[k] = off;
+    }
+  };
+  auto fetch_piece = [&](int k, int buf) {
+    auto* dst = (__attribute__((address_space(3))) uint4*)lds + buf * W9_STAGE;
+    const int pc = k * 8 + wave;
+    if (pc < X9_PIECES) {
+      const int pair = pc / (X9_PAIR / 64), q = pc % (X9_PAIR / 64);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          fxrs, (__attribute__((address_space(3))) void*)(dst + pair * X9_PITCH + q * 64), 16, poff[k], soffx, 0, 0);
+    } else if (pc < X9_PIECES + Y9_PIECES) {
+      const int py = pc - X9_PIECES;
+      const int pair = py / (Y_PAIR / 64), q = py % (Y_PAIR / 64);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          fyrs, (__attribute__((address_space(3))) void*)(dst + Y9_BASE + pair * Y_PITCH + q * 64), 16, poff[k], soffy,
+          0, 0);
+    }
+  };
+
+  // transpose-read addressing as in the kernel above
+  const int g = lane >> 4, i16 = lane & 15;
+  const int quad = i16 & 3, pj = i16 >> 2;
+  const int kpx = 8 * (g >> 1) + pj;
+  const int in_pair = (quad >> 1) * 8 + (quad & 1) * 4;
+  const int xb_base = (((wc * 2 + (g & 1)) * X9_PITCH + kpx * 2) * 8) + in_pair;
+  const int ya_base = ((Y9_BASE + (wo * 2 + (g & 1)) * Y_PITCH + kpx * 2) * 8) + in_pair;
+
+  float16v acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  if (s0 < s1) {
+    fetch_setup(s0);
+#pragma unroll
+    for (int k = 0; k < P9; ++k) fetch_piece(k, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int s = s0; s < s1; ++s) {
+    const int buf = (s - s0) & 1;
+    const bool more = s + 1 < s1;
+    if (more) fetch_setup(s + 1);
+    const unsigned stage = (unsigned)(uintptr_t)((__attribute__((address_space(3))) uint4*)lds + buf * W9_STAGE);
+    const unsigned xa = stage + xb_base * 2, ya = stage + ya_base * 2;        // byte addresses
+    // a window row's three column shifts from its 12 pixels (lo, hi, next): dwords = pixel pairs
+    auto shifts = [&](const short4v (&xx)[3], half8 (&b)[3]) {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x2 lo = __builtin_bit_cast(u32x2, xx[0]), hi = __builtin_bit_cast(u32x2, xx[1]),
+                  nx = __builtin_bit_cast(u32x2, xx[2]);
+      b[0] = __builtin_bit_cast(half8, u32x4{lo.x, lo.y, hi.x, hi.y});
+      b[1] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(lo.y, lo.x, 16),
+                                             __builtin_amdgcn_alignbit(hi.x, lo.y, 16),
+                                             __builtin_amdgcn_alignbit(hi.y, hi.x, 16),
+                                             __builtin_amdgcn_alignbit(nx.x, hi.y, 16)});
+      b[2] = __builtin_bit_cast(half8, u32x4{lo.y, hi.x, hi.y, nx.x});
+    };
+    auto read_x = [&](int xrow, short4v (&xx)[3]) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) xx[k] = tr_quad(xa, (xrow * XPW * 2) * 16 + k * 128);
+    };
+    half8 bw[3][3];                       // window row (X row index % 3) x column shift
+    half8 a[2];
+    short4v xr[2][3];
+    {
+      short4v x0r[3], x1r[3];
+      read_x(0, x0r);
+      read_x(1, x1r);
+      tr_wait9x(x0r, x1r);
+      shifts(x0r, bw[0]);
+      shifts(x1r, bw[1]);
+    }
+    a[0] = tr_pair(ya, 0);
+    read_x(2, xr[0]);
+#pragma unroll
+    for (int row = 0; row < WR; ++row) {
+      tr_wait9(a[row & 1], xr[row & 1]);
+      shifts(xr[row & 1], bw[(row + 2) % 3]);
+      if (row + 1 < WR) {
+        a[(row + 1) & 1] = tr_pair(ya, ((row + 1) * WPX * 2) * 16);
+        read_x(row + 3, xr[(row + 1) & 1]);
+      }
+      if (more) fetch_piece(row, buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[row & 1], bw[(row + ky) % 3][kx],
+                                                                    acc[ky * 3 + kx], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  const int h = lane >> 5;
+  const int c = ccb * 8 + wc * 32 + (lane & 31);
+  if (c < p.C) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = ocb + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < p.M) p.part[(((long long)split * 9 + t) * p.M + m) * p.C + c] = acc[t][r];
+      }
+  }
+}
+
 // dW[m][c][tap] (+)= scale * sum_split part[split][tap][m][c], splits summed in a fixed order.
 // Workgroup = one output channel m x 64 input channels: thread (tap, c) sums its element over the
 // splits (four independent chains; 256-byte runs along c), the [c][9] tile is transposed through
@@ -895,6 +1125,36 @@ __global__ __launch_bounds__(kWThreads) void conv3x3_wgrad_f16_kernel(const F16W
 // more than a third of the whole filter-gradient call).  Row m == M folds the bias partials:
 // db[m] (+)= scale * sum dbpart[k][m].
 constexpr int kDbSplits = 64;
+// db[m] (+)= scale * sum_k dbpart[k][m] in a fixed order.  64 outputs per pass of a workgroup, the k range dealt to
+// 4 thread groups x 4 independent chains: one thread summing its output's n_levels x 64 partials alone was a chain
+// of 320 dependent loads -- 80 us, the whole duration of the reduce launch (the filter rows take 20).
+__device__ __forceinline__ void bias_row_reduce(const float* __restrict__ dbpart, int dbparts, int M, float scale,
+                                                int accumulate, float* __restrict__ db, float* red) {
+  const int Mp = (M + 7) & ~7;
+  const int ml = threadIdx.x & 63, j = threadIdx.x >> 6;           // kThreads = 256: j = 0..3
+  for (int m0 = blockIdx.x * 64; m0 < M; m0 += gridDim.x * 64) {
+    const int mm = m0 + ml;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (mm < M) {
+      int k = j;
+      for (; k + 12 < dbparts; k += 16) {
+        s0 += dbpart[k * Mp + mm];
+        s1 += dbpart[(k + 4) * Mp + mm];
+        s2 += dbpart[(k + 8) * Mp + mm];
+        s3 += dbpart[(k + 12) * Mp + mm];
+      }
+      for (; k < dbparts; k += 4) s0 += dbpart[k * Mp + mm];
+    }
+    red[j * 64 + ml] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (j == 0 && mm < M) {
+      const float s = ((red[ml] + red[64 + ml]) + (red[128 + ml] + red[192 + ml])) * scale;
+      db[mm] = accumulate ? db[mm] + s : s;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_kernel(const float* __restrict__ part,
                                                                     int splits, int M, int C,
                                                                     int accumulate, float scale,
@@ -907,13 +1167,7 @@ __global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_kernel(const float*
   const int m = blockIdx.y, c0 = blockIdx.x * 64;
   if (m == M) {                                            // the bias row
     if (!db) return;
-    const int Mp = (M + 7) & ~7;
-    for (int mm = blockIdx.x * kThreads + threadIdx.x; mm < M; mm += gridDim.x * kThreads) {
-      float s = 0.0f;
-      for (int k = 0; k < dbparts; ++k) s += dbpart[k * Mp + mm];
-      s *= scale;
-      db[mm] = accumulate ? db[mm] + s : s;
-    }
+    bias_row_reduce(dbpart, dbparts, M, scale, accumulate, db, o);
     return;
   }
   const long long total = 9LL * M * C;
@@ -951,13 +1205,8 @@ __global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_pw_kernel(const flo
   const long long total = (long long)M * C;
   if (blockIdx.y == 1) {                                   // the bias row
     if (!db) return;
-    const int Mp = (M + 7) & ~7;
-    for (int mm = blockIdx.x * kThreads + threadIdx.x; mm < M; mm += gridDim.x * kThreads) {
-      float s = 0.0f;
-      for (int k = 0; k < dbparts; ++k) s += dbpart[k * Mp + mm];
-      s *= scale;
-      db[mm] = accumulate ? db[mm] + s : s;
-    }
+    __shared__ float red[kThreads];
+    bias_row_reduce(dbpart, dbparts, M, scale, accumulate, db, red);
     return;
   }
   for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long long)gridDim.x * kThreads) {
@@ -1006,6 +1255,15 @@ __global__ __launch_bounds__(kThreads) void f16_bias_grad_kernel(const F16Wgrad 
 }
 
 namespace {
+bool use_wgrad9() {
+  static const bool on = [] { const char* e = getenv("SSAD_F16_WGRAD9"); return !(e && e[0] == '0'); }();
+  return on;
+}
+int wgrad_blocks(int C, int M, bool pw) {
+  if (!pw && use_wgrad9()) return ((M + N9_OT - 1) / N9_OT) * ((C + N9_CT - 1) / N9_CT);
+  return ((M + W_OT - 1) / W_OT) * ((C + W_CT - 1) / W_CT);
+}
+int wgrad_rows(bool pw) { return (pw || use_wgrad9()) ? 1 : 3; }
 int wgrad_splits(int blocks, int stages, int rows = 3) {
   // one workgroup per CU at a time (148 KiB of LDS): whole rounds only -- 516 workgroups on 256
   // CUs take three rounds where 504 take two -- and ONE round measures best (tower layer, all
@@ -1033,9 +1291,9 @@ int wgrad_stages(const ssad_f16_wgrad_level* levels, int n_levels) {
 namespace {
 size_t wgrad_ws_bytes(const ssad_f16_wgrad_level* levels, int n_levels, int C, int M, bool pw) {
   if (!levels || n_levels < 1) return 0;
-  const int blocks = ((M + W_OT - 1) / W_OT) * ((C + W_CT - 1) / W_CT);
+  const int blocks = wgrad_blocks(C, M, pw);
   const int stages = wgrad_stages(levels, n_levels);
-  return ((size_t)wgrad_splits(blocks, stages > 0 ? stages : 1, pw ? 1 : 3) * (pw ? 1 : 9) * (size_t)M * (size_t)C +
+  return ((size_t)wgrad_splits(blocks, stages > 0 ? stages : 1, wgrad_rows(pw)) * (pw ? 1 : 9) * (size_t)M * (size_t)C +
           (size_t)n_levels * kDbSplits * (size_t)((M + 7) & ~7)) * sizeof(float);
 }
 
@@ -1062,23 +1320,26 @@ int wgrad_launch(const ssad_f16_wgrad_level* levels, int n_levels, int C, int M,
   p.part = static_cast<float*>(workspace);
   p.C = C; p.M = M;
   p.stages = (int)stages;
-  p.cblocks = (C + W_CT - 1) / W_CT;
-  const int blocks = ((M + W_OT - 1) / W_OT) * p.cblocks;
-  const int splits = wgrad_splits(blocks, p.stages > 0 ? p.stages : 1, pw ? 1 : 3);
+  const bool nine = !pw && use_wgrad9();
+  p.cblocks = nine ? (C + N9_CT - 1) / N9_CT : (C + W_CT - 1) / W_CT;
+  const int blocks = wgrad_blocks(C, M, pw);
+  const int splits = wgrad_splits(blocks, p.stages > 0 ? p.stages : 1, wgrad_rows(pw));
   hipStream_t s = (hipStream_t)stream;
   if (p.stages > 0) {
     static const bool attr = [] {
       return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16_kernel<false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE * 16) == hipSuccess &&
              hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16_kernel<true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE * 16) == hipSuccess;
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE * 16) == hipSuccess &&
+             hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad9_f16_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W9_STAGE * 16) == hipSuccess;
     }();
     if (!attr) return SSAD_E_BADARG;
     p.blocks = blocks; p.splits = splits;
     {
       // runs of one whole split per XCD when that divides evenly, else the largest common run length
       static const int force = [] { const char* e = getenv("SSAD_F16_WGRAD_XCD_GROUP"); return e ? atoi(e) : 0; }();
-      const int per_split = blocks * (pw ? 1 : 3), total = per_split * splits;
+      const int per_split = blocks * wgrad_rows(pw), total = per_split * splits;
       int g = 1;
       if ((total & 7) == 0) {
         int x = total >> 3, y = per_split;
@@ -1086,7 +1347,8 @@ int wgrad_launch(const ssad_f16_wgrad_level* levels, int n_levels, int C, int M,
         g = x;
       }
       p.xcd_group = force > 0 ? force : g;
-      if (pw) hipLaunchKernelGGL(conv3x3_wgrad_f16_kernel<true>, dim3(total), dim3(kWThreads), 2 * W_STAGE * 16, s, p);
+      if (nine) hipLaunchKernelGGL(wgrad9_f16_kernel, dim3(total), dim3(kWThreads), 2 * W9_STAGE * 16, s, p);
+      else if (pw) hipLaunchKernelGGL(conv3x3_wgrad_f16_kernel<true>, dim3(total), dim3(kWThreads), 2 * W_STAGE * 16, s, p);
       else hipLaunchKernelGGL(conv3x3_wgrad_f16_kernel<false>, dim3(total), dim3(kWThreads), 2 * W_STAGE * 16, s, p);
     }
   }
