@@ -446,14 +446,16 @@ __global__ __launch_bounds__(kThreads) void gemm_conv_wgrad_reduce_kernel(const 
                                                                           float* __restrict__ dw) {
   const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
-  float s0 = 0.0f, s1 = 0.0f;
+  // eight independent chains (fixed order): with two, a thread's `splits` loads (up to 3 x CUs / tiles) went out
+  // two at a time and the launch was a chain of load latencies (59 us average in the step)
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int k = 0;
-  for (; k + 1 < splits; k += 2) {
-    s0 += part[(long long)k * n + i];
-    s1 += part[(long long)(k + 1) * n + i];
+  for (; k + 7 < splits; k += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += part[(long long)(k + u) * n + i];
   }
-  if (k < splits) s0 += part[(long long)k * n + i];
-  const float s = s0 + s1;
+  for (; k < splits; ++k) a[k & 7] += part[(long long)k * n + i];
+  const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   dw[i] = accumulate ? dw[i] + s : s;
 }
 
