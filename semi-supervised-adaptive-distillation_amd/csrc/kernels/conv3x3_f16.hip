@@ -1210,14 +1210,14 @@ __global__ __launch_bounds__(kThreads) void f16_wgrad_reduce_pw_kernel(const flo
     return;
   }
   for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long long)gridDim.x * kThreads) {
-    float s0 = 0.0f, s1 = 0.0f;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // eight independent chains, fixed order
     int k = 0;
-    for (; k + 1 < splits; k += 2) {
-      s0 += part[(long long)k * total + e];
-      s1 += part[(long long)(k + 1) * total + e];
+    for (; k + 7 < splits; k += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += part[(long long)(k + u) * total + e];
     }
-    if (k < splits) s0 += part[(long long)k * total + e];
-    const float v = (s0 + s1) * scale;
+    for (; k < splits; ++k) a[k & 7] += part[(long long)k * total + e];
+    const float v = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) * scale;
     dw[e] = accumulate ? dw[e] + v : v;
   }
 }
