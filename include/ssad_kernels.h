@@ -438,6 +438,33 @@ SSAD_API int ssad_conv1x1_gemm(const ssad_gemm_conv* desc_host, ssad_stream_t st
  * bias / residual / mask / flags as in ssad_conv1x1_gemm. */
 SSAD_API int ssad_conv_implicit_gemm(const ssad_gemm_conv* d, int C, int H, int W, int kernel, int stride, int pad,
                                      ssad_stream_t stream);
+/* The same with split-K through the caller's workspace: a k x k layer on a small map is a handful of tiles with a
+ * very long reduction (FPN's P6, 3x3 / stride 2, 2048 -> 256 on 10 x 14 x 16 images: 36 tiles, K = 18 432).  The
+ * reduction is cut into `splits` ranges of whole 16-row chunks, one workgroup per (tile, range); partial tiles go
+ * to workspace[split][N][M][P] and a second launch adds them in split order (deterministic) and applies bias /
+ * residual / ReLU / mask / accumulate.  workspace == NULL or a plan of one split = ssad_conv_implicit_gemm.
+ * (detectron/lib/modeling/FPN.py:193-224 builds P6 / P7 with stride 2; conv_op_impl.h:126-173.) */
+SSAD_API size_t ssad_conv_implicit_gemm_workspace_bytes(int N, int M, int C, int H, int W, int kernel, int stride,
+                                                        int pad);
+SSAD_API int ssad_conv_implicit_gemm_ws(const ssad_gemm_conv* d, int C, int H, int W, int kernel, int stride, int pad,
+                                        void* workspace, size_t workspace_bytes, ssad_stream_t stream);
+/* Gradients of a k x k / strided convolution (group 1) at the layer's own size (conv_op_impl.h:358-577: im2col,
+ * dW += dY col^T, dcol = W^T dY, col2im -- there per image, here with the batch flattened into the GEMM's column
+ * index so that P6 / P7's 140 / 35 pixels per image fill tiles): conv_strided.hip.
+ *   wgrad: dw[M][C][k][k] (+)= sum_{n,oy,ox} dy[n][m][oy][ox] x[n][c][oy*s+ky-pad][ox*s+kx-pad]
+ *   dgrad: dx[N][C][H][W] (+)= mask > 0 ? sum_{m,ky,kx} w[m][c][ky][kx] dy[n][m][(iy+pad-ky)/s][(ix+pad-kx)/s] : 0
+ *          (mask: optional [N][C][H][W], the ReluGradient of the layer below; w in its natural layout, C*k*k % 4 == 0)
+ * Every buffer involved must stay below 2 GiB (the column buffer is C*k*k x N*OH*OW floats). */
+SSAD_API size_t ssad_conv_kxk_wgrad_workspace_bytes(int N, int C, int H, int W, int M, int kernel, int stride,
+                                                    int pad);
+SSAD_API int ssad_conv_kxk_wgrad(const float* x, const float* dy, int N, int C, int H, int W, int M, int kernel,
+                                 int stride, int pad, float* dw, int accumulate, void* workspace,
+                                 size_t workspace_bytes, ssad_stream_t stream);
+SSAD_API size_t ssad_conv_kxk_dgrad_workspace_bytes(int N, int C, int H, int W, int M, int kernel, int stride,
+                                                    int pad);
+SSAD_API int ssad_conv_kxk_dgrad(const float* w, const float* dy, int N, int C, int H, int W, int M, int kernel,
+                                 int stride, int pad, float* dx, const float* mask, int accumulate, void* workspace,
+                                 size_t workspace_bytes, ssad_stream_t stream);
 /* wt[k][m] = w[m][k], rows padded with zeros to ldm >= M (ldm % 4 == 0) */
 SSAD_API int ssad_transpose_filter(const float* w, int M, int K, int ldm, float* wt, ssad_stream_t stream);
 /* dw[m][c] (+)= sum_{n,p} dy[n][m][p] x[n][c][p]  (conv_op_impl.h:451-500 for a 1x1 kernel);

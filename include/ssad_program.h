@@ -162,7 +162,17 @@ enum ssad_opcode {
   /* i0..i5 = N, C, H, W, group, relu; p0 = x, p1 = packed, p2 = bias, p3 = y */
   SSAD_OP_GROUPED_F16 = 72,
   /* i0 = C, i1 = group; p0 = w, p1 = packed */
-  SSAD_OP_GROUPED_F16_PACK = 73
+  SSAD_OP_GROUPED_F16_PACK = 73,
+  /* k x k / strided convolutions at their own size (FPN's P6 / P7: 3x3, stride 2), ssad_kernels.h */
+  /* ssad_conv_implicit_gemm_ws(p0 = ssad_gemm_conv*, i0..i5 = C, H, W, kernel, stride, pad, p1 = workspace,
+   * l0 = workspace bytes): forward with split-K */
+  SSAD_OP_CONV_IMPLICIT_WS = 74,
+  /* ssad_conv_kxk_wgrad(p0 = x, p1 = dy, i0..i3 = N, C, H, W, i4 = M, i5 = kernel, i6 = stride, i7 = pad, p2 = dw,
+   * l1 = accumulate, p3 = workspace, l0 = workspace bytes) */
+  SSAD_OP_CONV_KXK_WGRAD = 75,
+  /* ssad_conv_kxk_dgrad(p0 = w, p1 = dy, i0..i7 as above, p2 = dx, p4 = mask or NULL, l1 = accumulate,
+   * p3 = workspace, l0 = workspace bytes) */
+  SSAD_OP_CONV_KXK_DGRAD = 76
 };
 
 typedef struct ssad_op {

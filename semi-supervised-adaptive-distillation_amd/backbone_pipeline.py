@@ -319,6 +319,39 @@ class NativeResNetFPN(object):
             P.add(PR.CHANNEL_SUM, 51, i=(N, Cc, 1, 0), p=(rows, layer.gb), work=4.0 * rows.numel(),
                   stream=self._wstream)
 
+    def _conv_s2(self, P, x, y, layer):
+        """y = conv3x3 / stride 2 / pad 1 (x) + bias at the layer's own size (FPN.py:193-224)."""
+        N, Cc, H, W = x.shape
+        oh, ow = y.shape[2], y.shape[3]
+        d = K.gemm_conv_desc(layer.wt, layer.cout, x, y, Cc * 9, layer.cout, bias=layer.b)
+        d.P = oh * ow
+        nb = K.lib().ssad_conv_implicit_gemm_workspace_bytes(N, layer.cout, Cc, H, W, 3, 2, 1)
+        ws = self._t(max(nb // 4, 4))
+        P.add(PR.CONV_IMPLICIT_WS, 64, i=(Cc, H, W, 3, 2, 1), p=(d, ws), l=(nb,),
+              work=2.0 * 9 * Cc * layer.cout * N * oh * ow, keep=[layer.wt, x, y, layer.b])
+
+    def _wgrad_s2(self, P, x, dy, layer):
+        N, Cc, H, W = x.shape
+        nb = K.lib().ssad_conv_kxk_wgrad_workspace_bytes(N, Cc, H, W, layer.cout, 3, 2, 1)
+        assert nb > 0
+        self._ws_need = max(self._ws_need, nb)
+        self._aux(P)
+        idx = P.add(PR.CONV_KXK_WGRAD, 65, i=(N, Cc, H, W, layer.cout, 3, 2, 1), l=(nb, 0),
+                    p=(x, dy, layer.gw, None), keep=[x, dy],
+                    work=2.0 * 9 * Cc * layer.cout * N * dy.shape[2] * dy.shape[3], stream=self._wstream)
+        self._ws_ops.append((idx, 3, self._wstream))
+        self._bias_grad(P, dy, layer)
+
+    def _dgrad_s2(self, P, layer, dy, dx, mask=None):
+        N, Cc, H, W = dx.shape
+        nb = K.lib().ssad_conv_kxk_dgrad_workspace_bytes(N, Cc, H, W, layer.cout, 3, 2, 1)
+        assert nb > 0
+        if self._dgrad_ws is None or self._dgrad_ws.numel() * 4 < nb:
+            self._dgrad_ws = self._t(nb // 4)          # main stream only: the two layers run one after the other
+        P.add(PR.CONV_KXK_DGRAD, 64, i=(N, Cc, H, W, layer.cout, 3, 2, 1), l=(nb, 0),
+              p=(layer.w, dy, dx, self._dgrad_ws, mask), keep=[dy, dx],
+              work=2.0 * 9 * Cc * layer.cout * N * dy.shape[2] * dy.shape[3])
+
     def _aux(self, P):
         """Filter / bias gradients do not feed the data-gradient chain: they run on an auxiliary
         stream behind a FORK (everything they read has been enqueued on the main stream), so that
@@ -346,6 +379,11 @@ class NativeResNetFPN(object):
         nws = max(1, min(3, int(os.environ.get("SSAD_WGRAD_STREAMS", "2"))))
         self._wstreams = list(range(1, nws + 1)) if on else [0]
         self._wstream, self._wnext = self._wstreams[0], 0
+        # FPN's stride-2 3x3 layers (P6, P7) at their own size: implicit GEMM with split-K forward, flattened-batch
+        # GEMMs for the gradients (conv_strided.hip).  SSAD_STRIDED_3X3=winograd: rounds 1-2's stride-1 Winograd
+        # layer + subsampling (4x the direct-form flops), kept for A/B runs.
+        self._strided_own = os.environ.get("SSAD_STRIDED_3X3", "own") != "winograd"
+        self._dgrad_ws = None
         L = self._layers
         dev = self.device
         lib = K.lib()
@@ -364,6 +402,12 @@ class NativeResNetFPN(object):
             elif l.k == 3 and l.group > 1:                       # ResNeXt: MFMA operand order, packed once
                 l.pf = self._t(lib.ssad_grouped_conv3x3_filter_floats(l.cout, l.group))
                 tgt.add(PR.GROUPED_PACK, 54, i=(l.cout, l.group), p=(l.w, l.pf), work=4.0 * (l.w.numel() + l.pf.numel()))
+            elif l.k == 3 and l.stride == 2 and self._strided_own:
+                # P6 / P7 at their own size: the implicit GEMM's [Cin * 9][Cout] operand (the data and filter
+                # gradients read the filter in its natural layout)
+                l.wt = self._t(l.cin * 9, l.cout)
+                tgt.add(PR.TRANSPOSE_FILTER, 54, i=(l.cout, l.cin * 9, l.cout), p=(l.w, l.wt),
+                        work=8.0 * l.w.numel())
             elif l.k == 3:
                 l.pf = self._t(lib.ssad_conv_wino_filter_floats(l.cout, l.cin))
                 need_pd = l.train                  # every trainable 3x3 sends a gradient further down
@@ -473,18 +517,28 @@ class NativeResNetFPN(object):
         p5, p4, p3 = (self._like(t) for t in (t5, t4, t3))
         self._conv3(P, [(t, p, None, L[name].pf, L[name].b)                # three filters, one launch
                         for t, p, name in ((t5, p5, "out.0"), (t4, p4, "out.1"), (t3, p3, "out.2"))], D, D, 0)
-        # P6 / P7: stride-1 convolution, then the even positions
         l6, l7 = L["p6"], L["p7"]
-        p6f = self._t(N, D, c5.shape[2], c5.shape[3])
-        self._conv3(P, [(c5, p6f, None, l6.pf, l6.b)], D, l6.cin, 0)
-        p6 = self._t(N, D, c5.shape[2] // 2, c5.shape[3] // 2)
-        self._ew(P, PR.SUBSAMPLE, i=(N, D, c5.shape[2], c5.shape[3], 2), p=(p6f, p6), nbytes=8.0 * p6.numel())
-        r6 = self._like(p6)
-        self._ew(P, PR.RELU, p=(p6, r6), l=(p6.numel(),), nbytes=8.0 * p6.numel())
-        p7f = self._like(p6)
-        self._conv3(P, [(r6, p7f, None, l7.pf, l7.b)], D, D, 0)
-        p7 = self._t(N, D, (p6.shape[2] + 1) // 2, (p6.shape[3] + 1) // 2)
-        self._ew(P, PR.SUBSAMPLE, i=(N, D, p6.shape[2], p6.shape[3], 2), p=(p7f, p7), nbytes=8.0 * p7.numel())
+        if self._strided_own:
+            # P6 / P7 (3x3, stride 2) at their own size
+            p6 = self._t(N, D, (c5.shape[2] - 1) // 2 + 1, (c5.shape[3] - 1) // 2 + 1)
+            self._conv_s2(P, c5, p6, l6)
+            r6 = self._like(p6)
+            self._ew(P, PR.RELU, p=(p6, r6), l=(p6.numel(),), nbytes=8.0 * p6.numel())
+            p7 = self._t(N, D, (p6.shape[2] - 1) // 2 + 1, (p6.shape[3] - 1) // 2 + 1)
+            self._conv_s2(P, r6, p7, l7)
+            p6f = p7f = None
+        else:
+            # SSAD_STRIDED_3X3=winograd: stride-1 convolution, then the even positions
+            p6f = self._t(N, D, c5.shape[2], c5.shape[3])
+            self._conv3(P, [(c5, p6f, None, l6.pf, l6.b)], D, l6.cin, 0)
+            p6 = self._t(N, D, c5.shape[2] // 2, c5.shape[3] // 2)
+            self._ew(P, PR.SUBSAMPLE, i=(N, D, c5.shape[2], c5.shape[3], 2), p=(p6f, p6), nbytes=8.0 * p6.numel())
+            r6 = self._like(p6)
+            self._ew(P, PR.RELU, p=(p6, r6), l=(p6.numel(),), nbytes=8.0 * p6.numel())
+            p7f = self._like(p6)
+            self._conv3(P, [(r6, p7f, None, l7.pf, l7.b)], D, D, 0)
+            p7 = self._t(N, D, (p6.shape[2] + 1) // 2, (p6.shape[3] + 1) // 2)
+            self._ew(P, PR.SUBSAMPLE, i=(N, D, p6.shape[2], p6.shape[3], 2), p=(p7f, p7), nbytes=8.0 * p7.numel())
         self.fpn = [p3, p4, p5, p6, p7]                   # finest first (synth.LEVEL_SHAPES_*)
         self._fpn_saved = dict(t3=t3, t4=t4, t5=t5, r6=r6, p6f=p6f, p7f=p7f)
 
@@ -498,20 +552,31 @@ class NativeResNetFPN(object):
         self.d_fpn = [self._like(p) for p in self.fpn]
         d3, d4, d5, d6, d7 = self.d_fpn
         l6, l7 = L["p6"], L["p7"]
-        # P7 = sub(conv(relu(p6)))
-        d7f = self._like(S["p7f"])
-        self._ew(P, PR.SUBSAMPLE_GRAD, i=(N, D, d7f.shape[2], d7f.shape[3], 2, 0), p=(d7, d7f), nbytes=4.0 * d7f.numel())
-        self._wgrad3(P, r6, d7f, l7)
-        dr6 = self._like(r6)
-        self._conv3(P, [(d7f, dr6, r6, l7.pd, None)], D, D, K.CONV_MASK_AUX)          # masked by p6 > 0
-        ptrs = (C.c_void_p * 2)(d6.data_ptr(), dr6.data_ptr())
-        P.add(PR.SUM_N, 51, i=(2,), l=(d6.numel(),), p=(ptrs, d6), work=12.0 * d6.numel(), keep=[d6, dr6])
-        # P6 = sub(conv(c5))
-        d6f = self._like(S["p6f"])
-        self._ew(P, PR.SUBSAMPLE_GRAD, i=(N, D, d6f.shape[2], d6f.shape[3], 2, 0), p=(d6, d6f), nbytes=4.0 * d6f.numel())
-        self._wgrad3(P, c5, d6f, l6)
         dc5 = self._like(c5)
-        self._conv3(P, [(d6f, dc5, None, l6.pd, None)], l6.cin, D, 0)
+        if self._strided_own:
+            # P7 = conv_s2(relu(p6)): filter gradient, then the data gradient masked by p6 > 0, added to P6's own
+            self._wgrad_s2(P, r6, d7, l7)
+            dr6 = self._like(r6)
+            self._dgrad_s2(P, l7, d7, dr6, mask=r6)
+            ptrs = (C.c_void_p * 2)(d6.data_ptr(), dr6.data_ptr())
+            P.add(PR.SUM_N, 51, i=(2,), l=(d6.numel(),), p=(ptrs, d6), work=12.0 * d6.numel(), keep=[d6, dr6])
+            # P6 = conv_s2(c5)
+            self._wgrad_s2(P, c5, d6, l6)
+            self._dgrad_s2(P, l6, d6, dc5)
+        else:
+            # P7 = sub(conv(relu(p6)))
+            d7f = self._like(S["p7f"])
+            self._ew(P, PR.SUBSAMPLE_GRAD, i=(N, D, d7f.shape[2], d7f.shape[3], 2, 0), p=(d7, d7f), nbytes=4.0 * d7f.numel())
+            self._wgrad3(P, r6, d7f, l7)
+            dr6 = self._like(r6)
+            self._conv3(P, [(d7f, dr6, r6, l7.pd, None)], D, D, K.CONV_MASK_AUX)          # masked by p6 > 0
+            ptrs = (C.c_void_p * 2)(d6.data_ptr(), dr6.data_ptr())
+            P.add(PR.SUM_N, 51, i=(2,), l=(d6.numel(),), p=(ptrs, d6), work=12.0 * d6.numel(), keep=[d6, dr6])
+            # P6 = sub(conv(c5))
+            d6f = self._like(S["p6f"])
+            self._ew(P, PR.SUBSAMPLE_GRAD, i=(N, D, d6f.shape[2], d6f.shape[3], 2, 0), p=(d6, d6f), nbytes=4.0 * d6f.numel())
+            self._wgrad3(P, c5, d6f, l6)
+            self._conv3(P, [(d6f, dc5, None, l6.pd, None)], l6.cin, D, 0)
         # output convs: filter gradients and the three data gradients in one launch
         dt5, dt4, dt3 = self._like(t5), self._like(t4), self._like(t3)
         for t, d, name in ((t5, d5, "out.0"), (t4, d4, "out.1"), (t3, d3, "out.2")):

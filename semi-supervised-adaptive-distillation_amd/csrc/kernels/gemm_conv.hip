@@ -59,6 +59,11 @@ struct GemmArgs {
   // implicit-GEMM convolution (gemm_conv_nn_kernel<BM, true>): x is the image [N][C][H][W], the
   // columns are the output pixels (P = OH * OW), row k = (c, ky, kx) of the reduction is gathered
   int C, H, W, OW, ksize, stride, pad;
+  // split-K (a k x k layer on a small map is a few tiles with a very long reduction: P6 is 36 tiles of K = 18 432):
+  // workgroup b owns tile b % tiles and the chunks [split * per_split, ...) with split = b / tiles; with splits > 1
+  // it writes its raw partial tile to part[split][N][M][P] and splitk_reduce_kernel applies the epilogue terms
+  int splits, per_split;
+  float* part;
 };
 
 // the b32 buffer builtins move 32-bit INTEGERS: floats go through a bit cast, not a conversion
@@ -99,7 +104,9 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
   const int j = lane & 31, h = lane >> 5;
-  const int tile = xcd_remap(blockIdx.x, g.mtiles * g.ctiles);
+  const int ntiles = g.mtiles * g.ctiles;
+  const int split = g.splits > 1 ? (int)blockIdx.x / ntiles : 0;
+  const int tile = xcd_remap((int)blockIdx.x - split * ntiles, ntiles);
   const int mt = tile % g.mtiles, ct = tile / g.mtiles;
   const int m0 = mt * BM;
   const long long q0 = (long long)ct * BN;
@@ -121,19 +128,39 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
     const int n = (int)(qb / P), p = (int)(qb - (long long)n * P);
     b_voff = (unsigned)((((long long)n * K + h) * P + p) * 4);
   }
-  // implicit mode: this lane's two columns (lane, lane + 64): top-left input pixel and its offset
-  int iy0[2] = {0, 0}, ix0[2] = {0, 0}, ioff[2] = {0, 0};
-  bool iok[2] = {false, false};
+  // implicit mode: this lane's two columns (lane, lane + 64): offset of the window's top-left input pixel and the
+  // taps that stay inside the image as bit masks (bit ky of ymask, bit kx of xmask; both 0 for a column past Q)
+  int ioff[2] = {0, 0};
+  unsigned ymask[2] = {0, 0}, xmask[2] = {0, 0};
+  // ... and this wave's four reduction rows of the NEXT chunk to fetch, as (c, ky, kx): wave-uniform, advanced by
+  // BK rows per chunk with carries instead of two divisions per row and chunk (the divisions were ~500 scalar
+  // instructions per chunk in front of the MFMAs: P6's forward pass ran at 56 TF/s)
+  int s_c[4] = {0, 0, 0, 0}, s_ky[4] = {0, 0, 0, 0}, s_kx[4] = {0, 0, 0, 0};
+  int d_c = 0, d_ky = 0, d_kx = 0;
   if (IMPLICIT) {
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const long long qc = q0 + hf * 64 + lane;
-      iok[hf] = qc < g.Q;
-      const int n = iok[hf] ? (int)(qc / P) : 0, pp = iok[hf] ? (int)(qc - (long long)n * P) : 0;
-      iy0[hf] = (pp / g.OW) * g.stride - g.pad;
-      ix0[hf] = (pp % g.OW) * g.stride - g.pad;
-      ioff[hf] = ((n * g.C * g.H + iy0[hf]) * g.W + ix0[hf]) * 4;       // may be negative at the border
+      const bool ok = qc < g.Q;
+      const int n = ok ? (int)(qc / P) : 0, pp = ok ? (int)(qc - (long long)n * P) : 0;
+      const int iy0 = (pp / g.OW) * g.stride - g.pad, ix0 = (pp % g.OW) * g.stride - g.pad;
+      ioff[hf] = ((n * g.C * g.H + iy0) * g.W + ix0) * 4;       // may be negative at the border
+      if (ok)
+        for (int t = 0; t < g.ksize; ++t) {
+          ymask[hf] |= (unsigned)((unsigned)(iy0 + t) < (unsigned)g.H) << t;
+          xmask[hf] |= (unsigned)((unsigned)(ix0 + t) < (unsigned)g.W) << t;
+        }
     }
+    const int kk2 = g.ksize * g.ksize;
+    const int row0 = (g.splits > 1 ? split * g.per_split : 0) * BK + wave * 4;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int row = row0 + v, c = row / kk2, r2 = row - c * kk2;
+      s_c[v] = c; s_ky[v] = r2 / g.ksize; s_kx[v] = r2 - s_ky[v] * g.ksize;
+    }
+    d_c = BK / kk2;
+    const int d_r = BK - d_c * kk2;
+    d_ky = d_r / g.ksize; d_kx = d_r - d_ky * g.ksize;
   }
   auto issue = [&](int chunk, int buf) {
     const int k0 = chunk * BK;
@@ -150,17 +177,24 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_ptr)(base + ia * 256), 16, vo, row * g.lda * 4, 0, 0);
     }
     if (IMPLICIT) {
-      const int kk2 = g.ksize * g.ksize;
+      // (issue() is called for consecutive chunks, so the (c, ky, kx) state above is always this chunk's)
 #pragma unroll
       for (int u = 0; u < B_PER_WAVE; ++u) {
         const int ib = wave * B_PER_WAVE + u;                        // (row in chunk, 64-column half)
-        const int rr = ib >> 1, hf = ib & 1;
-        const int row = k0 + rr;
-        const int c = row / kk2, r2 = row - c * kk2, ky = r2 / g.ksize, kx = r2 - ky * g.ksize;     // scalars
-        const bool ok = iok[hf] && row < K && (unsigned)(iy0[hf] + ky) < (unsigned)g.H &&
-                        (unsigned)(ix0[hf] + kx) < (unsigned)g.W;
-        const unsigned vo = ok ? (unsigned)(ioff[hf] + ((c * g.H + ky) * g.W + kx) * 4) : kOob;
+        const int rr = ib >> 1, hf = ib & 1, v = u >> 1;
+        const int soff = ((s_c[v] * g.H + s_ky[v]) * g.W + s_kx[v]) * 4;                  // scalar
+        const unsigned in = (ymask[hf] >> s_ky[v]) & (xmask[hf] >> s_kx[v]) & 1u;
+        unsigned vo = in ? (unsigned)(ioff[hf] + soff) : kOob;
+        if (tail) vo = (k0 + rr < K) ? vo : kOob;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr)(base + A_STAGE + rr * BN + hf * 64), 4, vo, 0, 0, 0);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {                                   // + BK rows, with carries
+        s_kx[v] += d_kx;
+        if (s_kx[v] >= g.ksize) { s_kx[v] -= g.ksize; ++s_ky[v]; }
+        s_ky[v] += d_ky;
+        if (s_ky[v] >= g.ksize) { s_ky[v] -= g.ksize; ++s_c[v]; }
+        s_c[v] += d_c;
       }
     } else {
 #pragma unroll
@@ -182,13 +216,17 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.0f;
 
-  const int chunks = (K + BK - 1) / BK;
-  issue(0, 0);
-  if (chunks > 1) issue(1, 1);
+  int chunk0 = 0, chunks = (K + BK - 1) / BK;
+  if (g.splits > 1) {
+    chunk0 = split * g.per_split;
+    chunks = chunks < chunk0 + g.per_split ? chunks : chunk0 + g.per_split;
+  }
+  issue(chunk0, 0);
+  if (chunk0 + 1 < chunks) issue(chunk0 + 1, 1);
   const int a_rd = wm * (BM / 2) + j;          // + k * BM (+ 32 for the second row tile)
   const int b_rd = A_STAGE + wn * 64 + j;      // + k * BN (+ 32)
   int buf = 0;
-  for (int c = 0; c < chunks; ++c) {
+  for (int c = chunk0; c < chunks; ++c) {
     // this wave's loads of chunk c have landed (those of chunk c + 1 may still fly) ...
     if (c + 1 < chunks) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
@@ -234,11 +272,16 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
   }
 
   // ---- epilogue: bias, residual, ReLU, ReluGradient mask, accumulate -- in registers ----------
-  const bool relu = g.flags & SSAD_GEMM_RELU, accum = g.flags & SSAD_GEMM_ACCUMULATE;
+  const bool partial = g.splits > 1;          // raw partial sums: the reduce kernel owns every epilogue term
+  const bool relu = !partial && (g.flags & SSAD_GEMM_RELU), accum = !partial && (g.flags & SSAD_GEMM_ACCUMULATE);
+  const float* const gbias = partial ? nullptr : g.bias;
+  const float* const gres = partial ? nullptr : g.res;
+  const float* const gmask = partial ? nullptr : g.mask;
   const long long ybytes = (long long)g.N * g.M * P * 4;
-  const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(g.y, (unsigned)ybytes);
-  const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(g.res ? g.res : g.y, (unsigned)ybytes);
-  const __amdgpu_buffer_rsrc_t krs = uniform_rsrc(g.mask ? g.mask : g.y, (unsigned)ybytes);
+  float* const yout = partial ? g.part + (long long)split * ((long long)g.N * g.M * P) : g.y;
+  const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(yout, (unsigned)ybytes);
+  const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(gres ? gres : yout, (unsigned)ybytes);
+  const __amdgpu_buffer_rsrc_t krs = uniform_rsrc(gmask ? gmask : yout, (unsigned)ybytes);
   // Every optional term is applied to a whole 32 x 32 tile (16 values per lane) under ONE
   // wave-uniform branch, so its 16 loads are issued back to back and waited for once (a
   // per-element "load or not" makes hipcc branch and drain vmcnt per element).
@@ -247,11 +290,11 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
     float bvv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) bvv[r] = 0.0f;
-    if (g.bias) {
+    if (gbias) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        bvv[r] = g.bias[m < g.M ? m : g.M - 1];
+        bvv[r] = gbias[m < g.M ? m : g.M - 1];
       }
     }
 #pragma unroll
@@ -271,7 +314,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
       f32x16 v = acc[i][t];
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] += bvv[r];
-      if (g.res) {
+      if (gres) {
         float tmp[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) tmp[r] = ldf(rrs, off[r]);
@@ -282,7 +325,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_conv_nn_kernel(const GemmArg
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
       }
-      if (g.mask) {
+      if (gmask) {
         float tmp[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) tmp[r] = ldf(krs, off[r]);
@@ -507,6 +550,25 @@ __global__ __launch_bounds__(kThreads) void subsample_grad_kernel(const float* _
   }
 }
 
+// split-K epilogue of the implicit GEMM: y = epilogue(sum_s part[s]) in split order (deterministic); the terms of
+// gemm_conv_nn_kernel's epilogue in the same order (bias, residual, ReLU, mask, accumulate)
+__global__ __launch_bounds__(kThreads) void splitk_reduce_kernel(const float* __restrict__ part, int splits, long long n,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ res,
+                                                                 const float* __restrict__ mask, int flags, int M, int P,
+                                                                 float* __restrict__ y) {
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+    float v = 0.0f;
+    for (int s = 0; s < splits; ++s) v += part[(long long)s * n + i];
+    if (bias) v += bias[(int)((i / P) % M)];
+    if (res) v += res[i];
+    if (flags & SSAD_GEMM_RELU) v = fmaxf(v, 0.0f);
+    if (mask) v = mask[i] > 0.0f ? v : 0.0f;
+    if (flags & SSAD_GEMM_ACCUMULATE) v += y[i];
+    y[i] = v;
+  }
+}
+
 int pick_splits(int tiles, int chunks) {
   const int cus = ssad_cu_count();
   // about three workgroups per CU, at least 8 chunks (128 columns) each
@@ -537,6 +599,7 @@ int ssad_conv1x1_gemm(const ssad_gemm_conv* d, ssad_stream_t stream) {
   g.Q = Q;
   g.ctiles = (int)((Q + BN - 1) / BN);
   g.C = g.H = g.W = g.OW = g.ksize = g.stride = g.pad = 0;
+  g.splits = 1; g.per_split = 0; g.part = nullptr;
   hipStream_t s = (hipStream_t)stream;
   // 64-row tiles for 64-wide outputs, and wherever 128-row tiles would leave the chip with
   // fewer than two workgroups per CU (res5 at bs 16 is 70 column tiles: 280 tiles of 128 rows
@@ -556,10 +619,38 @@ int ssad_conv1x1_gemm(const ssad_gemm_conv* d, ssad_stream_t stream) {
   return (int)hipGetLastError();
 }
 
-int ssad_conv_implicit_gemm(const ssad_gemm_conv* d, int C, int H, int W, int kernel, int stride, int pad,
-                            ssad_stream_t stream) {
+// split-K plan of the implicit GEMM: (splits, chunks per split).  A launch wants about four workgroups per CU (the
+// 4-byte gather is latency-bound: P6 forward 0.333 ms with two per CU, 0.306 with four); a split is worth its slab
+// traffic only with >= 16 chunks (256 reduction rows) of its own.
+static void implicit_split_plan(int M, long long Q, int K, int* splits, int* per_split) {
+  const int mt = M <= 64 ? (M + 63) / 64 : (M + 127) / 128;
+  const long long tiles = (long long)mt * ((Q + BN - 1) / BN);
+  const int chunks = (K + BK - 1) / BK;
+  static const int force = [] { const char* e = getenv("SSAD_IMPLICIT_SPLITS"); return e ? atoi(e) : 0; }();
+  long long s = (4LL * ssad_cu_count() + tiles - 1) / tiles;
+  if (s > chunks / 16) s = chunks / 16;
+  if (force > 0) s = force;
+  if (s > chunks) s = chunks;
+  if (s < 1) s = 1;
+  const int per = (int)((chunks + s - 1) / s);
+  *per_split = per;
+  *splits = (chunks + per - 1) / per;           // every split owns >= 1 chunk
+}
+
+size_t ssad_conv_implicit_gemm_workspace_bytes(int N, int M, int C, int H, int W, int kernel, int stride, int pad) {
+  if (N < 1 || M < 1 || C < 1 || kernel < 1 || stride < 1 || pad < 0 || H + 2 * pad < kernel || W + 2 * pad < kernel)
+    return 0;
+  const int OH = (H + 2 * pad - kernel) / stride + 1, OW = (W + 2 * pad - kernel) / stride + 1;
+  int splits, per;
+  implicit_split_plan(M, (long long)N * OH * OW, C * kernel * kernel, &splits, &per);
+  return splits > 1 ? (size_t)splits * N * M * OH * OW * sizeof(float) : 0;
+}
+
+int ssad_conv_implicit_gemm_ws(const ssad_gemm_conv* d, int C, int H, int W, int kernel, int stride, int pad,
+                               void* workspace, size_t workspace_bytes, ssad_stream_t stream) {
   if (!d || !d->a || !d->x || !d->y || d->N < 0 || d->M < 1 || C < 1 || H < 1 || W < 1) return SSAD_E_BADARG;
   if (kernel < 1 || stride < 1 || pad < 0 || H + 2 * pad < kernel || W + 2 * pad < kernel) return SSAD_E_BADARG;
+  if (kernel > 32) return SSAD_E_BADARG;                  // the taps inside the image are one 32-bit mask per axis
   const int OH = (H + 2 * pad - kernel) / stride + 1, OW = (W + 2 * pad - kernel) / stride + 1;
   const int K = C * kernel * kernel;
   if (d->K != K || d->P != OH * OW) return SSAD_E_BADARG;
@@ -587,15 +678,37 @@ int ssad_conv_implicit_gemm(const ssad_gemm_conv* d, int C, int H, int W, int ke
   g.Q = Q;
   g.ctiles = (int)((Q + BN - 1) / BN);
   g.C = C; g.H = H; g.W = W; g.OW = OW; g.ksize = kernel; g.stride = stride; g.pad = pad;
+  g.splits = 1; g.per_split = 0; g.part = nullptr;
+  if (workspace) {
+    // no workspace = no split (the stem and the operator surface's forward pass: ssad_conv_implicit_gemm)
+    implicit_split_plan(d->M, Q, K, &g.splits, &g.per_split);
+    if (g.splits > 1) {
+      if (workspace_bytes < (size_t)g.splits * d->N * d->M * d->P * sizeof(float)) return SSAD_E_WORKSPACE;
+      if ((uintptr_t)workspace & 15) return SSAD_E_BADARG;
+      g.part = (float*)workspace;
+    }
+  }
   hipStream_t s = (hipStream_t)stream;
   if (d->M <= 64) {
     g.mtiles = (d->M + 63) / 64;
-    hipLaunchKernelGGL((gemm_conv_nn_kernel<64, true>), dim3(g.mtiles * g.ctiles), dim3(kThreads), 0, s, g);
+    hipLaunchKernelGGL((gemm_conv_nn_kernel<64, true>), dim3(g.mtiles * g.ctiles * g.splits), dim3(kThreads), 0, s, g);
   } else {
     g.mtiles = (d->M + 127) / 128;
-    hipLaunchKernelGGL((gemm_conv_nn_kernel<128, true>), dim3(g.mtiles * g.ctiles), dim3(kThreads), 0, s, g);
+    hipLaunchKernelGGL((gemm_conv_nn_kernel<128, true>), dim3(g.mtiles * g.ctiles * g.splits), dim3(kThreads), 0, s, g);
+  }
+  if (g.splits > 1) {
+    const long long n = (long long)d->N * d->M * d->P;
+    long long b = (n + kThreads - 1) / kThreads;
+    if (b > 4096) b = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)b), dim3(kThreads), 0, s, (const float*)g.part, g.splits,
+                       n, d->bias, d->residual, d->mask, d->flags, d->M, d->P, d->y);
   }
   return (int)hipGetLastError();
+}
+
+int ssad_conv_implicit_gemm(const ssad_gemm_conv* d, int C, int H, int W, int kernel, int stride, int pad,
+                            ssad_stream_t stream) {
+  return ssad_conv_implicit_gemm_ws(d, C, H, W, kernel, stride, pad, nullptr, 0, stream);
 }
 
 int ssad_transpose_filter(const float* w, int M, int K, int ldm, float* wt, ssad_stream_t stream) {

@@ -179,6 +179,15 @@ def lib():
     L.ssad_subsample.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_subsample_grad.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_conv_implicit_gemm.argtypes = [C.POINTER(GemmConv), i32, i32, i32, i32, i32, i32, vp]
+    L.ssad_conv_implicit_gemm_workspace_bytes.restype = sz
+    L.ssad_conv_implicit_gemm_workspace_bytes.argtypes = [i32] * 8
+    L.ssad_conv_implicit_gemm_ws.argtypes = [C.POINTER(GemmConv), i32, i32, i32, i32, i32, i32, vp, sz, vp]
+    L.ssad_conv_kxk_wgrad_workspace_bytes.restype = sz
+    L.ssad_conv_kxk_wgrad_workspace_bytes.argtypes = [i32] * 8
+    L.ssad_conv_kxk_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp]
+    L.ssad_conv_kxk_dgrad_workspace_bytes.restype = sz
+    L.ssad_conv_kxk_dgrad_workspace_bytes.argtypes = [i32] * 8
+    L.ssad_conv_kxk_dgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, sz, vp]
     L.ssad_grouped_conv3x3_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_grouped_conv3x3_filter_floats.argtypes = [i32, i32]
     L.ssad_grouped_conv3x3_filter_floats.restype = C.c_longlong
@@ -924,7 +933,7 @@ def grouped_conv3x3_forward(x, w, bias=None, group=64, stride=1, relu=False, out
     return y
 
 
-def conv_implicit_gemm(x, w, bias=None, stride=1, pad=0, relu=False, out=None):
+def conv_implicit_gemm(x, w, bias=None, stride=1, pad=0, relu=False, out=None, split_k=False):
     """k x k convolution (group 1) as an implicit GEMM: x [N,C,H,W], w [M,C,k,k] -> [N,M,OH,OW]."""
     _f32c(x, "x"); _f32c(w, "w")
     N, Cc, H, W = x.shape
@@ -934,5 +943,39 @@ def conv_implicit_gemm(x, w, bias=None, stride=1, pad=0, relu=False, out=None):
     y = out if out is not None else torch.empty((N, M, oh, ow), dtype=torch.float32, device="cuda")
     d = gemm_conv_desc(wt, wt.shape[1], x, y, Cc * k * k, M, bias, None, None, relu, False)
     d.P = oh * ow
+    if split_k:
+        nb = lib().ssad_conv_implicit_gemm_workspace_bytes(N, M, Cc, H, W, k, stride, pad)
+        ws = _workspace(nb, "implicit_splitk")
+        _check(lib().ssad_conv_implicit_gemm_ws(C.byref(d), Cc, H, W, k, stride, pad, _ptr(ws), nb, _stream()),
+               "conv_implicit_gemm_ws")
+        return y
     _check(lib().ssad_conv_implicit_gemm(C.byref(d), Cc, H, W, k, stride, pad, _stream()), "conv_implicit_gemm")
     return y
+
+
+def conv_kxk_wgrad(x, dy, k, stride, pad, out=None, accumulate=False):
+    """dW [M][C][k][k] of a k x k / strided convolution (conv_strided.hip): x [N,C,H,W], dy [N,M,OH,OW]."""
+    _f32c(x, "x"); _f32c(dy, "dy")
+    N, Cc, H, W = x.shape
+    M = dy.shape[1]
+    dw = out if out is not None else torch.empty((M, Cc, k, k), dtype=torch.float32, device="cuda")
+    nb = lib().ssad_conv_kxk_wgrad_workspace_bytes(N, Cc, H, W, M, k, stride, pad)
+    ws = _workspace(nb, "kxk_wgrad")
+    _check(lib().ssad_conv_kxk_wgrad(_ptr(x), _ptr(dy), N, Cc, H, W, M, k, stride, pad, _ptr(dw), int(accumulate),
+                                     _ptr(ws), nb, _stream()), "conv_kxk_wgrad")
+    return dw
+
+
+def conv_kxk_dgrad(w, dy, H, W, stride, pad, mask=None, out=None, accumulate=False):
+    """dX [N][C][H][W] of a k x k / strided convolution: w [M,C,k,k], dy [N,M,OH,OW]; mask: ReluGradient of the
+    layer below (dX = 0 where mask <= 0)."""
+    _f32c(w, "w"); _f32c(dy, "dy")
+    M, Cc, k = w.shape[0], w.shape[1], w.shape[2]
+    N = dy.shape[0]
+    dx = out if out is not None else torch.empty((N, Cc, H, W), dtype=torch.float32, device="cuda")
+    nb = lib().ssad_conv_kxk_dgrad_workspace_bytes(N, Cc, H, W, M, k, stride, pad)
+    ws = _workspace(nb, "kxk_dgrad")
+    _check(lib().ssad_conv_kxk_dgrad(_ptr(w), _ptr(dy), N, Cc, H, W, M, k, stride, pad, _ptr(dx),
+                                     _ptr(mask) if mask is not None else None, int(accumulate), _ptr(ws), nb,
+                                     _stream()), "conv_kxk_dgrad")
+    return dx

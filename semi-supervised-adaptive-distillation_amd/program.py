@@ -26,6 +26,7 @@ GEMM_CONV, CONV1X1_WGRAD, TRANSPOSE_FILTER, SUBSAMPLE, SUBSAMPLE_GRAD, RELU, IM2
 FORK, JOIN = 62, 63
 GROUPED_CONV3X3, GROUPED_PACK, CONV_IMPLICIT = 64, 65, 66
 PW_F16, PW_F16_PACK, PW_F16_WGRAD, F16_EW, STEM_POOL_F16, GROUPED_F16, GROUPED_F16_PACK = 67, 68, 69, 70, 71, 72, 73
+CONV_IMPLICIT_WS, CONV_KXK_WGRAD, CONV_KXK_DGRAD = 74, 75, 76
 
 # timing classes: one per kernel family.  bound "mfma": work = direct-form FLOPs
 # (2*9*Cout*Cin per output pixel; the Winograd engine executes 1/2.25 of them);
@@ -74,6 +75,10 @@ KLASS = {
     54: dict(name="backbone filter packs (transpose / Winograd)", bound="hbm"),
     56: dict(name="grouped 3x3 conv, ResNeXt (grouped_conv3x3_kernel)", bound="mfma", wino=False),
     55: dict(name="backbone momentum SGD (sgd_flat_kernel)", bound="hbm"),
+    64: dict(name="P6 / P7 3x3 stride-2 conv fwd / data gradient at their own size (implicit GEMM with split-K; "
+                  "flattened-batch GEMM + col2im)", bound="mfma", wino=False),
+    65: dict(name="P6 / P7 3x3 stride-2 filter gradient (im2col + gemm_conv_nt_kernel + reduce)", bound="mfma",
+             wino=False),
     # backbones in fp16 storage / fp32 accumulation (BASELINE config 5)
     57: dict(name="fp16 backbone pointwise conv fwd / data gradient (pw_f16_kernel)", bound="mfma16"),
     58: dict(name="fp16 backbone conv3x3 fwd / data gradient (conv3x3_f16_kernel)", bound="mfma16"),

@@ -126,7 +126,14 @@ def test_fp32_backbone_program_trains_no_body_bias_and_scales_folded_filters():
     n_bias = sum(1 for s in bb.segments if s[2])
     assert n_bias == 3 + 3 + 2                             # lat x3, out x3, p6, p7
     bw = _count(bb.prog, "backward", "sgd")
-    assert bw[PR.RELU_GRAD_ROWSUM] == 3                    # bias gradients of the three laterals only
+    # bias gradients of the three laterals and of P6 / P7 (the other 3x3 layers get theirs from the Winograd
+    # filter-gradient launch); no body layer has one
+    assert bw[PR.RELU_GRAD_ROWSUM] == 3 + 2
+    # P6 / P7 (3x3, stride 2: FPN.py:193-224) run at their own size: no stride-1 layer + subsampling
+    assert bw[PR.CONV_KXK_WGRAD] == 2 and bw[PR.CONV_KXK_DGRAD] == 2
+    assert bw[PR.SUBSAMPLE_GRAD] == 2                      # res4.0 / res5.0's strided pointwise layers only
+    fw = _count(bb.prog, "forward", "backward")
+    assert fw[PR.CONV_IMPLICIT_WS] == 2 and fw[PR.SUBSAMPLE] == 3          # res3.0 / res4.0 / res5.0
     assert bw[PR.CONV1X1_WGRAD] == 2 * 13 + 3 + 3           # c1 + c3 of 13 blocks, 3 projections, 3 laterals
     assert _count(bb.prog, "sgd", "end") == {PR.SGD_FLAT: 1}
     # four gradient buckets in the order the backward pass completes them
