@@ -324,6 +324,40 @@ bool ConvGradientOp<float, HIPContext>::RunDefaultEngine() {
     }
     return true;
   }
+  {
+    // k x k / strided layers of group 1 (FPN's P6 / P7, the stem): the whole batch at once -- im2col with the batch
+    // flattened into the GEMM's column index, filter gradient on the nt GEMM kernel (deterministic split
+    // reduction), data gradient = nn GEMM + gather-form col2im (kernels/conv_strided.hip).  The per-image loop
+    // below (conv_op_impl.h:451-560 as written) stays for grouped / dilated / rectangular / asymmetric geometries;
+    // SSAD_CONVGRAD_ENGINE=im2col forces it.
+    static const bool batched = [] { const char* e = getenv("SSAD_CONVGRAD_ENGINE"); return !(e && e[0] == 'i'); }();
+    const bool square = kh == kw && geom_.stride[0] == geom_.stride[1] && geom_.dilation == vector<int>{1, 1} &&
+                        geom_.pads[0] == geom_.pads[1] && geom_.pads[0] == geom_.pads[2] &&
+                        geom_.pads[0] == geom_.pads[3];
+    const size_t wsw = batched && G == 1 && square && !pointwise
+                           ? ssad_conv_kxk_wgrad_workspace_bytes(N, C, H, W, M, kh, geom_.stride[0], geom_.pads[0])
+                           : 0;
+    const bool dx_ok = !dX || (K % 4 == 0 && ((uintptr_t)filter.data<float>() & 15) == 0);
+    if (wsw > 0 && dx_ok) {
+      const size_t wsd = dX ? ssad_conv_kxk_dgrad_workspace_bytes(N, C, H, W, M, kh, geom_.stride[0], geom_.pads[0]) : 0;
+      workspace_.Resize((TIndex)(wsw > wsd ? wsw : wsd));
+      CAFFE_ENFORCE_EQ(ssad_conv_kxk_wgrad(X.data<float>(), dY.data<float>(), N, C, H, W, M, kh, geom_.stride[0],
+                                           geom_.pads[0], dfilter->mutable_data<float>(), 0,
+                                           workspace_.mutable_data<uint8_t>(), wsw, s), 0,
+                       "ConvGradient (filter, batched im2col) launch failed");
+      if (dX)
+        CAFFE_ENFORCE_EQ(ssad_conv_kxk_dgrad(filter.data<float>(), dY.data<float>(), N, C, H, W, M, kh,
+                                             geom_.stride[0], geom_.pads[0], dX->mutable_data<float>(), nullptr, 0,
+                                             workspace_.mutable_data<uint8_t>(), wsd, s), 0,
+                         "ConvGradient (input, batched col2im) launch failed");
+      if (!no_bias_) {
+        auto* dbias = Output(BIAS_OR_INPUT_GRAD);
+        dbias->Resize(M);
+        CAFFE_ENFORCE_EQ(ssad_channel_sum(dY.data<float>(), N, M, P, dbias->mutable_data<float>(), 0, s), 0);
+      }
+      return true;
+    }
+  }
   if (!pointwise) col_buffer_.Resize((TIndex)K * P);
   for (int n = 0; n < N; ++n) {
     const float* xn = X.data<float>() + (size_t)n * C * H * W;
