@@ -22,9 +22,9 @@ Kernels:
   * every 3x3 / stride 1 convolution: the Winograd engine of the subnets (forward, data
     gradient with the fused ReluGradient mask, filter + bias gradient);
   * the stride-2 pointwise layers run on ssad_subsample's output (shared by c1 and the
-    projection); P6 / P7 (3x3 / stride 2) = the stride-1 convolution followed by subsampling --
-    the outputs at even positions are exactly the strided convolution's -- which costs 4x the
-    flops of two small layers and needs no further kernel;
+    projection); P6 / P7 (3x3 / stride 2) run at their own size: implicit GEMM with split-K forward,
+    flattened-batch GEMMs + gather-form col2im for the gradients (csrc/kernels/conv_strided.hip;
+    SSAD_STRIDED_3X3=winograd: the stride-1 Winograd layer + subsampling of rounds 1-2, 4x the flops);
   * the 7x7 / stride 2 stem: batched im2col + the same GEMM, then bias + ReLU + 3x3/2 max pool
     in one pass (ssad_max_pool3x3s2_bias_relu).
 
