@@ -181,3 +181,22 @@ def test_strided_argument_validation(K):
     assert L.ssad_conv_kxk_dgrad(p(dw), p(dy), 1, 8, 6, 6, 4, 3, 2, 1, p(x), None, 0, p(wsd), nd - 1, None) == -2
     # Cin * k * k must be a multiple of 4 (the filter is a GEMM operand with 16-byte rows)
     assert L.ssad_conv_kxk_dgrad(p(dw), p(dy), 1, 3, 6, 6, 4, 3, 2, 1, p(x), None, 0, p(wsd), nd, None) == -1
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 8, 12), (1, 3, 7, 16), (3, 4, 9, 10), (2, 2, 6, 4), (1, 1, 1, 4)],
+                         ids=lambda s: "N%d_C%d_%dx%d" % s)
+def test_subsample_stride2_fast_path_and_general_path(K, shape):
+    """ssad_subsample / ssad_subsample_grad: widths that are multiples of 4 take the 16-byte kernels, the others the
+    general one; both are exact copies (bit equality with the slice / the zero-stuffed scatter)."""
+    N, Cc, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn((N, Cc, H, W), device="cuda", generator=g)
+    y = K.subsample(x, 2)
+    assert torch.equal(y, x[:, :, ::2, ::2])
+    dy = torch.randn_like(y)
+    ref = torch.zeros_like(x)
+    ref[:, :, ::2, ::2] = dy
+    assert torch.equal(K.subsample_grad(dy, H, W, 2), ref)
+    base = torch.randn_like(x)
+    want = base + ref
+    assert torch.equal(K.subsample_grad(dy, H, W, 2, accumulate_into=base.clone()), want)
