@@ -307,6 +307,39 @@ __global__ __launch_bounds__(kThreads) void upsample_nearest_grad_kernel(
   }
 }
 
+// scale 2, even W (FPN's top-down path at every level of a 600 / 500 px image): a thread writes 16 bytes of an output
+// row -- (x0, x0, x1, x1) (+ 16 bytes of the addend) from one 8-byte load; a 64-lane group walks a row, four rows per
+// workgroup, the row index is decomposed once per thread.  The gradient: 8 bytes of dx from two 16-byte loads.
+__global__ __launch_bounds__(kThreads) void upsample2_kernel(const float* __restrict__ x, const float* __restrict__ addend,
+                                                             float* __restrict__ y, unsigned rows, int H, int W) {
+  const unsigned r = blockIdx.x * 4 + (threadIdx.x >> 6);          // output row: plane * 2H + oy
+  if (r >= rows) return;
+  const unsigned pl = r / (unsigned)(2 * H), oy = r - pl * (unsigned)(2 * H);
+  const float2* src = reinterpret_cast<const float2*>(x + ((size_t)pl * H + (oy >> 1)) * W);
+  const float4* add = addend ? reinterpret_cast<const float4*>(addend + (size_t)r * 2 * W) : nullptr;
+  float4* dst = reinterpret_cast<float4*>(y + (size_t)r * 2 * W);
+  for (int j = threadIdx.x & 63; j < (W >> 1); j += 64) {
+    const float2 v = src[j];
+    float4 o = make_float4(v.x, v.x, v.y, v.y);
+    if (add) { const float4 a = add[j]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+    dst[j] = o;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void upsample2_grad_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                  unsigned rows, int H, int W) {
+  const unsigned r = blockIdx.x * 4 + (threadIdx.x >> 6);          // input row: plane * H + i
+  if (r >= rows) return;
+  const float4* s0 = reinterpret_cast<const float4*>(dy + (size_t)r * 4 * W);      // output rows 2r, 2r + 1
+  const float4* s1 = s0 + (W >> 1);
+  float2* dst = reinterpret_cast<float2*>(dx + (size_t)r * W);
+  for (int j = threadIdx.x & 63; j < (W >> 1); j += 64) {
+    const float4 a = s0[j], b = s1[j];
+    // the reference kernel's order: (a, b) = (0,0), (0,1), (1,0), (1,1)
+    dst[j] = make_float2(((a.x + a.y) + b.x) + b.y, ((a.z + a.w) + b.z) + b.w);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -455,6 +488,12 @@ int ssad_upsample_nearest(const float* x, const float* addend, float* y, int N, 
   if (!x || !y || N < 0 || C < 0 || H < 0 || W < 0 || scale < 1) return SSAD_E_BADARG;
   const long long planes = (long long)N * C, total = planes * H * W * scale * scale;
   if (total == 0) return 0;
+  if (scale == 2 && !(W & 1) && planes * 2 * H < (1LL << 31) && aligned16(x, y, addend ? addend : y)) {
+    const long long orows = planes * 2 * H;
+    hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((orows + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, x,
+                       addend, y, (unsigned)orows, H, W);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(upsample_nearest_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
                      (hipStream_t)stream, x, addend, y, planes, H, W, scale);
   return (int)hipGetLastError();
@@ -465,6 +504,12 @@ int ssad_upsample_nearest_grad(const float* dy, float* dx, int N, int C, int H, 
   if (!dy || !dx || N < 0 || C < 0 || H < 0 || W < 0 || scale < 1) return SSAD_E_BADARG;
   const long long planes = (long long)N * C, total = planes * H * W;
   if (total == 0) return 0;
+  if (scale == 2 && !(W & 1) && planes * H < (1LL << 31) && aligned16(dy, dx, dx)) {
+    const long long irows = planes * H;
+    hipLaunchKernelGGL(upsample2_grad_kernel, dim3((unsigned)((irows + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream,
+                       dy, dx, (unsigned)irows, H, W);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(upsample_nearest_grad_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
                      (hipStream_t)stream, dy, dx, planes, H, W, scale);
   return (int)hipGetLastError();

@@ -200,3 +200,24 @@ def test_subsample_stride2_fast_path_and_general_path(K, shape):
     base = torch.randn_like(x)
     want = base + ref
     assert torch.equal(K.subsample_grad(dy, H, W, 2, accumulate_into=base.clone()), want)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 8, 12), (1, 3, 7, 6), (3, 4, 5, 7), (1, 2, 1, 2)],
+                         ids=lambda s: "N%d_C%d_%dx%d" % s)
+def test_upsample_nearest_fast_path_and_general_path(K, shape):
+    """ssad_upsample_nearest (+ lateral Sum, also in place) / its gradient (upsample_nearest_op.cu:62-151): even
+    widths take the 16-byte kernels, odd ones the general kernel; same values, same summation order."""
+    N, Cc, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn((N, Cc, H, W), device="cuda", generator=g)
+    up = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    assert torch.equal(K.upsample_nearest(x, 2), up)
+    add = torch.randn_like(up)
+    assert torch.equal(K.upsample_nearest(x, 2, addend=add), up + add)
+    inplace = add.clone()
+    K.upsample_nearest(x, 2, addend=inplace, out=inplace)
+    assert torch.equal(inplace, up + add)
+    dy = torch.randn_like(up)
+    d = dy.view(N, Cc, H, 2, W, 2)
+    want = ((d[:, :, :, 0, :, 0] + d[:, :, :, 0, :, 1]) + d[:, :, :, 1, :, 0]) + d[:, :, :, 1, :, 1]
+    assert torch.equal(K.upsample_nearest_grad(dy, 2), want)
