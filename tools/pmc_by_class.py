@@ -27,7 +27,9 @@ def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"[<(].*", "", name)
-    return name
+    # the fp16 3x3 filter gradient is one of two kernels (all nine taps per workgroup since the end of round 3,
+    # SSAD_F16_WGRAD9=0: one filter row per workgroup); same op, same class, same stream
+    return {"wgrad9_f16_kernel": "conv3x3_wgrad_f16_kernel"}.get(name, name)
 
 
 def class_sequences(f16=False):
