@@ -467,6 +467,17 @@ SSAD_API int ssad_conv_kxk_dgrad(const float* w, const float* dy, int N, int C, 
                                  size_t workspace_bytes, ssad_stream_t stream);
 /* wt[k][m] = w[m][k], rows padded with zeros to ldm >= M (ldm % 4 == 0) */
 SSAD_API int ssad_transpose_filter(const float* w, int M, int K, int ldm, float* wt, ssad_stream_t stream);
+/* ssad_transpose_filter for a whole table of filters in ONE launch (the training step re-transposes every trainable
+ * pointwise filter after each update: 34 launches of 5 us for the R-50 student, a serial chain that waits for a
+ * free CU slot 34 times when another stream's persistent kernels hold the chip). */
+#define SSAD_MAX_TRANSPOSE_ENTRIES 64   /* per launch; longer tables are chunked */
+typedef struct ssad_transpose_entry {
+  const float* w;          /* [M][K] */
+  float* wt;               /* [K][ldm] */
+  int M, K, ldm;
+  int reserved;
+} ssad_transpose_entry;
+SSAD_API int ssad_transpose_filters(const ssad_transpose_entry* entries_host, int n_entries, ssad_stream_t stream);
 /* dw[m][c] (+)= sum_{n,p} dy[n][m][p] x[n][c][p]  (conv_op_impl.h:451-500 for a 1x1 kernel);
  * deterministic split reduction through the caller's workspace.  P % 16 == 0. */
 SSAD_API size_t ssad_conv1x1_wgrad_workspace_bytes(int N, int C, int P, int M);

@@ -172,7 +172,9 @@ enum ssad_opcode {
   SSAD_OP_CONV_KXK_WGRAD = 75,
   /* ssad_conv_kxk_dgrad(p0 = w, p1 = dy, i0..i7 as above, p2 = dx, p4 = mask or NULL, l1 = accumulate,
    * p3 = workspace, l0 = workspace bytes) */
-  SSAD_OP_CONV_KXK_DGRAD = 76
+  SSAD_OP_CONV_KXK_DGRAD = 76,
+  /* ssad_transpose_filters(p0 = const ssad_transpose_entry* (host), i0 = n_entries) */
+  SSAD_OP_TRANSPOSE_FILTERS = 77
 };
 
 typedef struct ssad_op {

@@ -391,14 +391,15 @@ class NativeResNetFPN(object):
         prep, P = PR.Program(), PR.Program()
         self.prep, self.prog = prep, P
         wino_frozen, wino_train = [], []
+        tr_frozen, tr_train = [], []          # (w, wt, M, K, ldm): every transposed filter of a program in one launch
         P.mark("pack")
         for l in L.values():
             tgt = P if l.train else prep
+            trs = tr_train if l.train else tr_frozen
             if l.k == 1:
                 ldm = (l.cout + 3) // 4 * 4
                 l.wt = self._t(l.cin, ldm)
-                tgt.add(PR.TRANSPOSE_FILTER, 54, i=(l.cout, l.cin, ldm), p=(l.w, l.wt),
-                        work=8.0 * l.cout * l.cin)
+                trs.append((l.w, l.wt, l.cout, l.cin, ldm))
             elif l.k == 3 and l.group > 1:                       # ResNeXt: MFMA operand order, packed once
                 l.pf = self._t(lib.ssad_grouped_conv3x3_filter_floats(l.cout, l.group))
                 tgt.add(PR.GROUPED_PACK, 54, i=(l.cout, l.group), p=(l.w, l.pf), work=4.0 * (l.w.numel() + l.pf.numel()))
@@ -406,8 +407,7 @@ class NativeResNetFPN(object):
                 # P6 / P7 at their own size: the implicit GEMM's [Cin * 9][Cout] operand (the data and filter
                 # gradients read the filter in its natural layout)
                 l.wt = self._t(l.cin * 9, l.cout)
-                tgt.add(PR.TRANSPOSE_FILTER, 54, i=(l.cout, l.cin * 9, l.cout), p=(l.w, l.wt),
-                        work=8.0 * l.w.numel())
+                trs.append((l.w, l.wt, l.cout, l.cin * 9, l.cout))
             elif l.k == 3:
                 l.pf = self._t(lib.ssad_conv_wino_filter_floats(l.cout, l.cin))
                 need_pd = l.train                  # every trainable 3x3 sends a gradient further down
@@ -415,8 +415,17 @@ class NativeResNetFPN(object):
                 (wino_train if l.train else wino_frozen).append(l)
             else:                                                    # stem: [147][64]
                 l.wt = self._t(l.cin * l.k * l.k, l.cout)
-                tgt.add(PR.TRANSPOSE_FILTER, 54, i=(l.cout, l.cin * l.k * l.k, l.cout), p=(l.w, l.wt),
-                        work=8.0 * l.w.numel())
+                trs.append((l.w, l.wt, l.cout, l.cin * l.k * l.k, l.cout))
+        # one launch per program for all transposes (ssad_transpose_filters): as 34 launches of ~5 us they were a
+        # serial chain at the start of every step, each waiting for a CU slot behind the other stream's persistent
+        # kernels (tools/step_timeline.py: the main stream sat idle for ~7 ms there)
+        for tgt, trs in ((prep, tr_frozen), (P, tr_train)):
+            if trs:
+                tab = (K.TransposeEntry * len(trs))()
+                for i, (w, wt, M, Kc, ldm) in enumerate(trs):
+                    tab[i] = K.TransposeEntry(w.data_ptr(), wt.data_ptr(), M, Kc, ldm, 0)
+                tgt.add(PR.TRANSPOSE_FILTERS, 54, i=(len(trs),), p=(tab,),
+                        work=8.0 * sum(M * Kc for (_, _, M, Kc, _) in trs), keep=[t for e in trs for t in e[:2]])
         for tgt, ls in ((prep, wino_frozen), (P, wino_train)):
             if ls:
                 tab = (K.PackEntry * len(ls))()

@@ -519,6 +519,29 @@ __global__ __launch_bounds__(kThreads) void transpose_filter_kernel(const float*
   }
 }
 
+// every entry of a table in one launch: blockIdx.y = entry, blockIdx.x = 32 x 32 tile of that entry (workgroups past
+// an entry's last tile leave at once)
+struct TransposeTable {
+  ssad_transpose_entry e[SSAD_MAX_TRANSPOSE_ENTRIES];
+};
+__global__ __launch_bounds__(kThreads) void transpose_filter_multi_kernel(const TransposeTable t) {
+  const ssad_transpose_entry e = t.e[blockIdx.y];
+  const int kt = (e.K + 31) / 32, mt = (e.ldm + 31) / 32;
+  if ((int)blockIdx.x >= kt * mt) return;
+  __shared__ float tile[32][33];
+  const int k0 = ((int)blockIdx.x % kt) * 32, m0 = ((int)blockIdx.x / kt) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int m = m0 + r, k = k0 + tx;
+    tile[r][tx] = (m < e.M && k < e.K) ? e.w[(long long)m * e.K + k] : 0.0f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, m = m0 + tx;
+    if (k < e.K && m < e.ldm) e.wt[(long long)k * e.ldm + m] = tile[tx][r];
+  }
+}
+
 // y[n][c][oy][ox] = x[n][c][oy * s][ox * s] (the input of a strided pointwise convolution) and
 // its gradient (dx zero except at the sampled positions)
 __global__ __launch_bounds__(kThreads) void subsample_kernel(const float* __restrict__ x, long long planes,
@@ -751,6 +774,29 @@ int ssad_transpose_filter(const float* w, int M, int K, int ldm, float* wt, ssad
   if (!w || !wt || M < 1 || K < 1 || ldm < M) return SSAD_E_BADARG;
   hipLaunchKernelGGL(transpose_filter_kernel, dim3((K + 31) / 32, (ldm + 31) / 32), dim3(kThreads), 0,
                      (hipStream_t)stream, w, M, K, ldm, wt);
+  return (int)hipGetLastError();
+}
+
+int ssad_transpose_filters(const ssad_transpose_entry* entries, int n_entries, ssad_stream_t stream) {
+  if (n_entries < 0 || (n_entries > 0 && !entries)) return SSAD_E_BADARG;
+  for (int i = 0; i < n_entries; ++i)
+    if (!entries[i].w || !entries[i].wt || entries[i].M < 1 || entries[i].K < 1 || entries[i].ldm < entries[i].M)
+      return SSAD_E_BADARG;
+  for (int base = 0; base < n_entries; base += SSAD_MAX_TRANSPOSE_ENTRIES) {
+    const int cnt = n_entries - base < SSAD_MAX_TRANSPOSE_ENTRIES ? n_entries - base : SSAD_MAX_TRANSPOSE_ENTRIES;
+    TransposeTable t;
+    long long most = 0;
+    for (int i = 0; i < SSAD_MAX_TRANSPOSE_ENTRIES; ++i) {
+      t.e[i] = i < cnt ? entries[base + i] : ssad_transpose_entry{nullptr, nullptr, 0, 0, 0, 0};
+      if (i < cnt) {
+        const long long tiles = (long long)((t.e[i].K + 31) / 32) * ((t.e[i].ldm + 31) / 32);
+        if (tiles > most) most = tiles;
+      }
+    }
+    if (most >= (1LL << 31)) return SSAD_E_BADARG;
+    hipLaunchKernelGGL(transpose_filter_multi_kernel, dim3((unsigned)most, (unsigned)cnt), dim3(kThreads), 0,
+                       (hipStream_t)stream, t);
+  }
   return (int)hipGetLastError();
 }
 

@@ -39,3 +39,32 @@ def T(fn):
     torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0; torch.cuda.synchronize(); return round(dt * 1e3, 2)
 print("pack", T(lambda: (h.pack_student(), st.pack())), "teacher fwd", T(lambda: te.forward(images)), "student fwd", T(lambda: st.forward(images)),
       "heads fwd", T(lambda: h.forward_all(te.fpn, st.fpn)))
+# steady state (queue full, no synchronize between steps): where does the launching thread spend its time, and
+# when, relative to the start of step(), does it reach each phase -- a phase the host reaches late is a phase the
+# GPU cannot have started early
+import collections
+acc = collections.OrderedDict(); at = collections.OrderedDict()
+def wrap(obj, name, label):
+    f = getattr(obj, name)
+    def g(*a, **k):
+        t0 = time.perf_counter(); r = f(*a, **k); t1 = time.perf_counter()
+        acc[label] = acc.get(label, 0.0) + (t1 - t0); at[label] = at.get(label, 0.0) + (t0 - step_t0[0])
+        return r
+    setattr(obj, name, g)
+step_t0 = [0.0]
+wrap(te, "forward", "teacher.forward"); wrap(h, "pack_student", "heads.pack"); wrap(st, "pack", "student.pack")
+wrap(st, "forward", "student.forward"); wrap(h, "forward_all", "heads.forward"); wrap(h, "bbox_losses_fwd_bwd", "losses")
+wrap(h, "backward", "heads.backward"); wrap(st, "backward", "student.backward"); wrap(h, "sgd_step", "heads.sgd")
+wrap(st, "sgd_step", "student.sgd")
+for _ in range(3): model.step(images, labels, tg, fgn)
+acc.clear(); at.clear()
+K_ = 20
+t_all = time.perf_counter()
+for _ in range(K_):
+    step_t0[0] = time.perf_counter(); model.step(images, labels, tg, fgn)
+host_total = time.perf_counter() - t_all
+torch.cuda.synchronize()
+wall = time.perf_counter() - t_all
+print("steady state: %.2f ms/step wall, host inside step() %.2f ms/step" % (wall / K_ * 1e3, host_total / K_ * 1e3))
+for k in acc:
+    print("  %-18s reached at %7.2f ms, takes %7.2f ms" % (k, at[k] / K_ * 1e3, acc[k] / K_ * 1e3))
