@@ -377,6 +377,15 @@ def main():
             "config": {"workload": wl, "batch_per_gpu": N, "image": "3x%dx%d" % image_hw,
                        "fpn_levels": [list(s) for s in shapes], "anchors": 9, "classes": 80,
                        "parallelism": "dp%d" % world,
+                       "schedule": ("one process, HIP streams: student on the main stream, filter gradients on "
+                                    "auxiliary streams, frozen teacher on a side stream" + (
+                                        "; the teacher's forward pass of a step is ordered after the previous "
+                                        "step's last reader of its outputs (not after the previous update), so it "
+                                        "may run beside the previous step's backward pass -- every timed step "
+                                        "still enqueues and executes its own teacher forward inside the timed "
+                                        "region" if getattr(model, "_teacher_ahead", False) and
+                                        getattr(model, "side", None) is not None else "")
+                                    ) if args.workload == "full" and native else None,
                        "distill_loss": loss_val,
                        "focal_loss": [float(v) for v in heads.focal_losses.cpu()],
                        "bbox_loss": [float(v) for v in heads.bbox_losses.cpu()]},

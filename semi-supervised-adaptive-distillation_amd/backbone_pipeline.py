@@ -766,9 +766,23 @@ class NativeDistillModel(object):
         self.student.broadcast_params()
         if two_streams is None:
             two_streams = os.environ.get("SSAD_NATIVE_TWO_STREAMS", "1") == "1"
-        self.side = torch.cuda.Stream() if (two_streams and self.has_teacher) else None
+        prio = int(os.environ.get("SSAD_SIDE_PRIORITY", "0"))
+        self.side = torch.cuda.Stream(priority=prio) if (two_streams and self.has_teacher) else None
         # SSAD_TEACHER_FIRST=0: the teacher's forward pass is enqueued behind the student's filter packs (rounds 2-3)
         self._teacher_first = os.environ.get("SSAD_TEACHER_FIRST", "1") == "1"
+        # The frozen teacher's forward pass depends on the images only -- not on the student's update.  Ordered after
+        # the previous step's last READER of the teacher's output buffers (the subnets' forward launches) instead of
+        # after everything the previous step enqueued, it may start while the previous step's backward pass is still
+        # running whenever the launching thread is ahead of the GPU (it is: ~5 steps in steady state).  Taken only
+        # when `images` cannot have a pending writer on the current stream (step(): `images_event`, or the same
+        # unmodified tensor as the step before); otherwise the teacher waits for the current stream as before.
+        # SSAD_TEACHER_AHEAD=0: the teacher waits for the whole previous step (rounds 2-3).
+        # Measured (same-call A/B, 20 steps): config 3 (fp32) 95.7 -> 93.4 ms/step; config 5 (fp16 backbones, small
+        # HBM-bound launches) 26.07 -> 26.8 ms -- there the teacher beside the backward pass costs more than it
+        # fills, so the fp16 backbones keep the old order by default.
+        self._teacher_ahead = os.environ.get("SSAD_TEACHER_AHEAD", "0" if self.backbone_f16 else "1") == "1"
+        self._t_fpn_read = None               # event: the subnets have consumed the teacher's FPN levels
+        self._images_key = None
         # gradient w.r.t. an FPN level = cls-subnet part + bbox-subnet part (the fp16 backbone's own
         # program starts with that sum, on the blocked tensors)
         Q = self.sum_prog = PR.Program()
@@ -813,7 +827,7 @@ class NativeDistillModel(object):
                 "bias / shortcut / ReLU; 3x3: Winograd engine; stem: im2col + GEMM + fused bias/ReLU/pool; "
                 "no torch operator in the step)")
 
-    def step(self, images, labels, bbox_targets, fg_num, update=True):
+    def step(self, images, labels, bbox_targets, fg_num, update=True, images_event=None):
         """One iteration.  update=False stops after the gradient exchange (every parameter
         gradient is then readable: the SGD launch overwrites the gradient buffers with the
         applied update, as MomentumSGDUpdate does, momentum_sgd_op_gpu.cu:22-38)."""
@@ -825,7 +839,18 @@ class NativeDistillModel(object):
         early = self._teacher_first and te is not None and self.side is not None
         if early:
             cur = torch.cuda.current_stream()
-            self.side.wait_stream(cur)            # the previous step's readers of the teacher's FPN buffers
+            # Running ahead is only safe when nothing enqueued on the current stream can still be WRITING `images`:
+            # the caller says so with `images_event` (recorded by the input pipeline after its copy), or the tensor
+            # is the very one (same storage, same version counter) the previous step already read.
+            key = (images.data_ptr(), images._version)
+            known = images_event is not None or key == self._images_key
+            self._images_key = key
+            if self._teacher_ahead and self._t_fpn_read is not None and known:
+                self.side.wait_event(self._t_fpn_read)      # the previous step's readers of the teacher's FPN buffers
+                if images_event is not None:
+                    self.side.wait_event(images_event)
+            else:
+                self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
                 t_fpn = te.forward(images)
         h.pack_student()
@@ -845,6 +870,12 @@ class NativeDistillModel(object):
         h.forward_all(t_fpn, s_fpn)
         h.cls_losses(labels, fg_num)
         h.bbox_losses_fwd_bwd(bbox_targets, fg_num)
+        if self.side is not None and self._teacher_ahead:
+            # the teacher's FPN levels have been read (forward_all); recorded behind the loss launches, which are
+            # HBM-bound and short (0.45 ms): the next step's teacher starts beside the backward pass, not beside them
+            if self._t_fpn_read is None:
+                self._t_fpn_read = torch.cuda.Event()
+            self._t_fpn_read.record(torch.cuda.current_stream())
         h.backward()
         self.sum_prog.run(timing=self._timing)
         st.backward()

@@ -234,3 +234,45 @@ def test_update_lr_reaches_the_backbone():
     assert torch.allclose(m.heads.moms.flat, torch.full_like(m.heads.moms.flat, 0.1))
     m.update_lr(LR * 0.1 * 1.05)          # below the threshold: no momentum correction
     assert torch.allclose(m.student.moms_flat, torch.full_like(m.student.moms_flat, 0.1))
+
+
+def test_teacher_running_ahead_of_the_previous_step_changes_no_bit():
+    """The frozen teacher's forward pass is ordered after the previous step's last reader of its output buffers,
+    not after the previous step's update (NativeDistillModel.step): with the launching thread ahead of the GPU --
+    six iterations enqueued back to back, no synchronisation in between -- it overlaps the previous step's
+    backward pass.  Same bits as the model whose teacher waits for the whole previous step; also with a fresh
+    image tensor every step (falls back to the full wait) and with the input pipeline's event."""
+    cfg, images, ref_s, ref_t, S, T, labs, tg, fg = _problem(seed=6)
+    labels, targets, fg_num = _inputs(labs, tg, fg)
+    a = _model(cfg, ref_s, ref_t, S, T, overlap=True)
+    b = _model(cfg, ref_s, ref_t, S, T, overlap=True)
+    c = _model(cfg, ref_s, ref_t, S, T, overlap=True)
+    d = _model(cfg, ref_s, ref_t, S, T, overlap=True)
+    a._teacher_ahead, b._teacher_ahead, c._teacher_ahead, d._teacher_ahead = True, False, True, True
+    copy_stream = torch.cuda.Stream()
+    for m in (a, b, c, d):
+        m.student.poison()
+        m.teacher.poison()
+        torch.cuda.synchronize()
+        for it in range(6):
+            if m is c:
+                m.step(images.clone(), labels, targets, fg_num)          # a tensor the model has not seen
+            elif m is d:
+                with torch.cuda.stream(copy_stream):                      # the input pipeline: copy + event
+                    fresh = images.clone()
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                torch.cuda.current_stream().wait_event(ev)               # the student reads it on this stream
+                m.step(fresh, labels, targets, fg_num, images_event=ev)
+            else:
+                m.step(images, labels, targets, fg_num)
+        torch.cuda.synchronize()
+    assert a._t_fpn_read is not None and a._images_key is not None
+    for m, what in ((a, "ahead"), (c, "fresh tensor"), (d, "images_event")):
+        assert torch.isfinite(m.heads.losses).all()
+        assert torch.equal(m.heads.losses, b.heads.losses), what
+        assert torch.equal(m.heads.params.flat, b.heads.params.flat), what
+        assert torch.equal(m.student.params_flat, b.student.params_flat), what
+        assert torch.equal(m.student.moms_flat, b.student.moms_flat), what
+        for l in range(len(SHAPES)):
+            assert torch.equal(m.teacher.fpn[l], b.teacher.fpn[l]), (what, l)
