@@ -286,6 +286,15 @@ def main():
               args.px, image_hw[0], image_hw[1]) + model.describe() +
               "; subnets, %s and subnet SGD = one native program of this repo's HIP kernels" % losses_txt)
 
+    # The step's critical path is the stream step() is called on (student forward, subnets, data gradients); the
+    # teacher, the filter gradients and the collectives run on other streams and fill the chip beside it.
+    # The step therefore runs on a high-priority stream (HIP has two levels: 0 and -1): config 3 94.3 -> 93.3 ms,
+    # config 5 26.7 -> 26.5 ms in same-call A/B (tools/dbg/main_prio_ab.sh); SSAD_MAIN_PRIORITY=0: the default stream.
+    _prio = int(os.environ.get("SSAD_MAIN_PRIORITY", "-1"))
+    if _prio:
+        _main = torch.cuda.Stream(priority=_prio)
+        _main.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(_main)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -377,8 +386,9 @@ def main():
             "config": {"workload": wl, "batch_per_gpu": N, "image": "3x%dx%d" % image_hw,
                        "fpn_levels": [list(s) for s in shapes], "anchors": 9, "classes": 80,
                        "parallelism": "dp%d" % world,
-                       "schedule": ("one process, HIP streams: student on the main stream, filter gradients on "
-                                    "auxiliary streams, frozen teacher on a side stream" + (
+                       "schedule": ("one process, HIP streams: student on the main stream%s, filter gradients on "
+                                    "auxiliary streams, frozen teacher on a side stream" % (
+                                        " (high priority)" if _prio < 0 else "") + (
                                         "; the teacher's forward pass of a step is ordered after the previous "
                                         "step's last reader of its outputs (not after the previous update), so it "
                                         "may run beside the previous step's backward pass -- every timed step "

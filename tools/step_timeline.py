@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Coarse timeline of ONE step of a rocprofv3 rocpd capture: per hardware queue, the busy share of every time bin
 (which stream runs alone when -- e.g. the teacher's forward pass after the student's has finished).
-usage: step_timeline.py x.db [bin_ms] [marker]      (a step = the span between the last two `marker` kernels)"""
+usage: step_timeline.py x.db [bin_ms] [marker] [back]
+(a step = the span between two consecutive `marker` kernels; `back` = how many steps before the last one -- bench.py
+ends with three synchronised steps for its host-enqueue figure, so the steady state is e.g. back = 6)"""
 import sqlite3
 import sys
 from collections import defaultdict
@@ -14,7 +16,8 @@ cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
 qcol = "queue_id" if "queue_id" in cols else "stream_id"
 rows = cur.execute("select name, start, end, %s from kernels" % qcol).fetchall()
 marks = sorted(r[1] for r in rows if marker in r[0])
-lo, hi = marks[-2], marks[-1]
+back = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+lo, hi = marks[-2 - back], marks[-1 - back]
 rows = [r for r in rows if r[2] > lo and r[1] < hi]
 nb = int((hi - lo) / 1e6 / bin_ms) + 1
 busy = defaultdict(lambda: [0.0] * nb)
@@ -32,10 +35,19 @@ for q in sorted(busy, key=lambda q: -sum(busy[q])):
 tot = [sum(busy[q][b] for q in busy) for b in range(nb)]
 print("sum           | %s" % " ".join("%3d" % round(100 * v / bin_ms) for v in tot))
 # per bin: the kernel names with the most time (what phase is this)
+import re
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    return re.sub(r"[<(].*", "", n)[:28]
+
+
 top = defaultdict(lambda: defaultdict(float))
 for name, s, e, q in rows:
     b = int((max(s, lo) - lo) / 1e6 / bin_ms)
-    top[b][name.split("(")[0].split("<")[0][-28:]] += (e - s) / 1e6
+    top[b][short(name)] += (e - s) / 1e6
 for b in range(nb):
     t = sorted(top[b].items(), key=lambda kv: -kv[1])[:2]
     print("bin %2d: %s" % (b, ", ".join("%s %.1f" % kv for kv in t)))
