@@ -51,3 +51,14 @@ for name, s, e, q in rows:
 for b in range(nb):
     t = sorted(top[b].items(), key=lambda kv: -kv[1])[:2]
     print("bin %2d: %s" % (b, ", ".join("%s %.1f" % kv for kv in t)))
+
+# the busiest queue's kernels by total time in this step (the critical path's make-up)
+main_q = max(busy, key=lambda q: sum(busy[q]))
+acc = defaultdict(lambda: [0.0, 0])
+for name, s, e, q in rows:
+    if q == main_q:
+        acc[short(name)][0] += (min(e, hi) - max(s, lo)) / 1e6
+        acc[short(name)][1] += 1
+print("queue %s by kernel:" % main_q)
+for k, (ms, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:24]:
+    print("  %-30s %4d launches %7.2f ms" % (k, n, ms))
