@@ -779,6 +779,7 @@ int ssad_transpose_filter(const float* w, int M, int K, int ldm, float* wt, ssad
 
 int ssad_transpose_filters(const ssad_transpose_entry* entries, int n_entries, ssad_stream_t stream) {
   if (n_entries < 0 || (n_entries > 0 && !entries)) return SSAD_E_BADARG;
+  if (n_entries == 0) return 0;
   for (int i = 0; i < n_entries; ++i)
     if (!entries[i].w || !entries[i].wt || entries[i].M < 1 || entries[i].K < 1 || entries[i].ldm < entries[i].M)
       return SSAD_E_BADARG;

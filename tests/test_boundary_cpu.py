@@ -388,3 +388,44 @@ def test_winograd_launch_count_query_follows_the_level_shapes():
     assert launches([(16, 80, 112), (16, 40, 56), (16, 20, 28), (16, 10, 14), (16, 5, 7)]) == 2
     assert launches([(0, 80, 112), (16, 40, 56)]) == 1          # an empty level launches nothing
     assert L.ssad_conv3x3_forward_wino_launches(None, 0) == 0
+
+
+def test_strided_conv_entry_points_refuse_bad_arguments_without_a_device(lib):
+    """Round 3's k x k / strided convolution entry points (FPN's P6 / P7 at their own size; conv_strided.hip,
+    gemm_conv.hip) and the one-launch filter transposes: workspace sizing is host arithmetic, every argument error
+    is found before the first HIP call."""
+    raw = ctypes.CDLL(_capi.LIB_PATH)
+    vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.cast(buf, vp)
+    for fn in ("ssad_conv_kxk_wgrad_workspace_bytes", "ssad_conv_kxk_dgrad_workspace_bytes",
+               "ssad_conv_implicit_gemm_workspace_bytes"):
+        getattr(raw, fn).restype = sz
+        getattr(raw, fn).argtypes = [i32] * 8
+    # P6 at the bench's size: N 16, C 2048, 20 x 28, M 256, 3x3 / 2 / 1 -> col buffer [18432][2240] + dyT + GEMM slabs
+    need = raw.ssad_conv_kxk_wgrad_workspace_bytes(16, 2048, 20, 28, 256, 3, 2, 1)
+    assert need >= 18432 * 2240 * 4 + 256 * 2240 * 4
+    assert raw.ssad_conv_kxk_dgrad_workspace_bytes(16, 2048, 20, 28, 256, 3, 2, 1) >= 18432 * 2240 * 4
+    # a column buffer of 2 GiB or more, a stride of 0, a kernel larger than the padded map: no plan
+    assert raw.ssad_conv_kxk_wgrad_workspace_bytes(64, 2048, 40, 56, 256, 3, 1, 1) == 0
+    assert raw.ssad_conv_kxk_wgrad_workspace_bytes(1, 8, 6, 6, 4, 3, 0, 1) == 0
+    assert raw.ssad_conv_kxk_dgrad_workspace_bytes(1, 8, 2, 2, 4, 7, 1, 1) == 0
+    # forward split-K plan: (N, M, C, H, W, kernel, stride, pad); a pointwise-sized reduction needs no slabs
+    assert raw.ssad_conv_implicit_gemm_workspace_bytes(16, 256, 2048, 20, 28, 3, 2, 1) >= 2 * 16 * 256 * 140 * 4
+    assert raw.ssad_conv_implicit_gemm_workspace_bytes(16, 64, 3, 640, 896, 7, 2, 3) == 0
+    raw.ssad_conv_kxk_wgrad.argtypes = [vp, vp] + [i32] * 8 + [vp, i32, vp, sz, vp]
+    raw.ssad_conv_kxk_dgrad.argtypes = [vp, vp] + [i32] * 8 + [vp, vp, i32, vp, sz, vp]
+    assert raw.ssad_conv_kxk_wgrad(None, p, 1, 8, 6, 6, 4, 3, 2, 1, p, 0, p, 1 << 20, None) == -1
+    assert raw.ssad_conv_kxk_wgrad(p, p, 1, 8, 6, 6, 4, 3, 2, 1, p, 0, None, 1 << 20, None) == -2
+    assert raw.ssad_conv_kxk_wgrad(p, p, 1, 8, 6, 6, 4, 3, 2, 1, p, 0, p, 16, None) == -2
+    assert raw.ssad_conv_kxk_dgrad(p, p, 1, 3, 6, 6, 4, 3, 2, 1, p, None, 0, p, 1 << 20, None) == -1   # C*k*k % 4
+    assert raw.ssad_conv_kxk_dgrad(p, None, 1, 8, 6, 6, 4, 3, 2, 1, p, None, 0, p, 1 << 20, None) == -1
+
+    class TransposeEntry(ctypes.Structure):
+        _fields_ = [("w", vp), ("wt", vp), ("M", i32), ("K", i32), ("ldm", i32), ("reserved", i32)]
+    raw.ssad_transpose_filters.argtypes = [ctypes.POINTER(TransposeEntry), i32, vp]
+    tab = (TransposeEntry * 2)(TransposeEntry(ctypes.addressof(buf), ctypes.addressof(buf), 4, 4, 4, 0),
+                               TransposeEntry(ctypes.addressof(buf), ctypes.addressof(buf), 8, 4, 4, 0))   # ldm < M
+    assert raw.ssad_transpose_filters(tab, 2, None) == -1
+    assert raw.ssad_transpose_filters(None, 1, None) == -1
+    assert raw.ssad_transpose_filters(None, 0, None) == 0
