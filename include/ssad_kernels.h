@@ -115,11 +115,20 @@ SSAD_API int ssad_focal_loss_backward(
  * reference obtains from 2 forward ops, 2 gradient ops and an autograd Sum).
  * Requires focal gamma == 2 (RetinaNet).
  * ONE launch: each level's sums are finished by its last-arriving workgroup (arrival counters
- * in the workspace).  WORKSPACE CONTRACT (also ssad_pow_sum): the buffer must be ZERO-FILLED
- * once after it is allocated (hipMemset); every launch leaves the counters zero again, so the
- * same buffer serves any number of launches on one stream.  Do not share it between streams. */
+ * in the workspace, which the launcher zeroes with a hipMemsetAsync of a few KB on `stream` before
+ * the launch -- the caller's buffer needs no preparation, and a buffer whose counters an aborted
+ * launch left non-zero heals).  Do not share a workspace between streams.
+ * ssad_cls_losses_fused_prezeroed (also ssad_pow_sum_prezeroed): the same without the memset, for a
+ * caller that zero-filled the buffer once after allocating it and only ever passes it to these two
+ * entry points on one stream (every completed launch leaves the counters zero again); this is what
+ * ssad_program_run uses for the workspaces it is given. */
 SSAD_API size_t ssad_cls_losses_fused_workspace_bytes(int n_levels);
 SSAD_API int ssad_cls_losses_fused(
+    const ssad_distill_level* levels_host, int n_levels, const float* normalizer,
+    const float* fg_num, const ssad_distill_params* distill_host,
+    const ssad_focal_params* focal_host, float* distill_losses, float* focal_losses,
+    void* workspace, size_t workspace_bytes, ssad_stream_t stream);
+SSAD_API int ssad_cls_losses_fused_prezeroed(
     const ssad_distill_level* levels_host, int n_levels, const float* normalizer,
     const float* fg_num, const ssad_distill_params* distill_host,
     const ssad_focal_params* focal_host, float* distill_losses, float* focal_losses,
@@ -166,9 +175,13 @@ SSAD_API int ssad_select_smooth_l1_levels(
 SSAD_API size_t ssad_pow_sum_workspace_bytes(int n_inputs);
 
 /* out[0] = sum_j sum_i powf(inputs[j][i], power); all inputs in one launch (the sum is finished by
- * the last-arriving workgroup: the workspace must be zero-filled once after allocation, see
- * ssad_cls_losses_fused). */
+ * the last-arriving workgroup; arrival counters as for ssad_cls_losses_fused: zeroed by the
+ * launcher, or by the caller for the _prezeroed form). */
 SSAD_API int ssad_pow_sum(
+    const float* const* inputs_host, const int64_t* sizes_host, int n_inputs,
+    float power, float* out, void* workspace, size_t workspace_bytes,
+    ssad_stream_t stream);
+SSAD_API int ssad_pow_sum_prezeroed(
     const float* const* inputs_host, const int64_t* sizes_host, int n_inputs,
     float power, float* out, void* workspace, size_t workspace_bytes,
     ssad_stream_t stream);
@@ -668,6 +681,11 @@ SSAD_API int ssad_conv1x1_wgrad_f16(const void* x_blocked, const void* dy_blocke
  *   5 relu grad       y = a > 0 ? b : 0                                  relu_op.cu:44-53 */
 SSAD_API int ssad_f16_elementwise(int mode, const void* a, const void* b, void* y, int N, int C, int H, int W,
                                   int stride, int accumulate, ssad_stream_t stream);
+/* The strided pointwise layer's view of its input at any map size (odd maps too: the output is
+ * [(Hi - 1) / stride + 1][(Wi - 1) / stride + 1], conv_pool_op_base.h:45-194 with kernel 1, pad 0):
+ * y[y][x] = a[stride y][stride x] on blocked fp16. */
+SSAD_API int ssad_f16_subsample(const void* a_blocked, int N, int C, int Hi, int Wi, int stride, void* y_blocked,
+                                ssad_stream_t stream);
 /* bias + ReLU + 3x3 / stride 2 / pad 1 max pool of the stem's fp32 NCHW output z [N][C][H][W],
  * written blocked fp16 [N][C/8][ceil(H/2)][ceil(W/2)][8] */
 SSAD_API int ssad_stem_pool_f16(const float* z, const float* bias, int N, int C, int H, int W, void* y_blocked,
@@ -693,6 +711,11 @@ SSAD_API int ssad_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float 
 /* Introspection                                                           */
 /* ---------------------------------------------------------------------- */
 SSAD_API const char* ssad_kernels_arch(void);   /* "gfx950" */
+/* ABI version of this header.  History: 2 -> 3 (round 4): ssad_sgd_segment grew row_len / row_scale
+ * (24 -> 32 bytes); ssad_pow_sum / ssad_cls_losses_fused need the larger workspace their
+ * *_workspace_bytes report and zero their own arrival counters; *_prezeroed entry points added.
+ * A binding built against version 2 must refuse to run against this library. */
+#define SSAD_KERNELS_ABI_VERSION 3
 SSAD_API int ssad_kernels_abi_version(void);
 
 #ifdef __cplusplus

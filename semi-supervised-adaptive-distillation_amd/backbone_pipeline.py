@@ -782,7 +782,7 @@ class NativeDistillModel(object):
         # fills, so the fp16 backbones keep the old order by default.
         self._teacher_ahead = os.environ.get("SSAD_TEACHER_AHEAD", "0" if self.backbone_f16 else "1") == "1"
         self._t_fpn_read = None               # event: the subnets have consumed the teacher's FPN levels
-        self._images_key = None
+        self._images_ref, self._images_version = None, -1
         # gradient w.r.t. an FPN level = cls-subnet part + bbox-subnet part (the fp16 backbone's own
         # program starts with that sum, on the blocked tensors)
         Q = self.sum_prog = PR.Program()
@@ -841,10 +841,15 @@ class NativeDistillModel(object):
             cur = torch.cuda.current_stream()
             # Running ahead is only safe when nothing enqueued on the current stream can still be WRITING `images`:
             # the caller says so with `images_event` (recorded by the input pipeline after its copy), or the tensor
-            # is the very one (same storage, same version counter) the previous step already read.
-            key = (images.data_ptr(), images._version)
-            known = images_event is not None or key == self._images_key
-            self._images_key = key
+            # is the very OBJECT the previous step already read, unmodified since (same version counter).  The
+            # model keeps a reference to that tensor: a fresh batch tensor can then never be mistaken for it (its
+            # storage cannot be handed out again by the caching allocator while the reference lives, and a fresh
+            # tensor's version counter starts at 0 just like the old one's -- address + version alone would match
+            # a new batch whose host-to-device copy is still queued on the current stream, which the side stream
+            # does not wait for).  Anything else -- new tensor, view, in-place update -- takes the full wait.
+            known = images_event is not None or (images is self._images_ref and
+                                                 images._version == self._images_version)
+            self._images_ref, self._images_version = images, images._version
             if self._teacher_ahead and self._t_fpn_read is not None and known:
                 self.side.wait_event(self._t_fpn_read)      # the previous step's readers of the teacher's FPN buffers
                 if images_event is not None:

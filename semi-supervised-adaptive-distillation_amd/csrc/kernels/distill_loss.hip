@@ -185,6 +185,9 @@ __device__ __forceinline__ double block_sum(double v) {
 // (groups of kTicketGroup workgroups, then one counter per level) so that no single address sees
 // thousands of same-address atomics.  Counters live in the caller's workspace, must be ZERO before
 // the first launch (the workspace contract in ssad_kernels.h) and are left zero by every launch.
+#ifndef SSAD_TICKET_FENCES
+#define SSAD_TICKET_FENCES 1     // 0: round 3's relaxed atomics + s_waitcnt (A/B builds only)
+#endif
 constexpr int kTicketGroup = 32;
 constexpr int kTicketStride = 16;                         // ints: one 64-byte line per group counter
 constexpr int kTicketGroups = kMaxBlocks / kTicketGroup + SSAD_MAX_LEVELS;
@@ -212,19 +215,36 @@ __device__ __forceinline__ double peek(const double* slot) {
 // level's workgroup count, g0 = index of the level's first group counter.  True for exactly one
 // workgroup of the level: the last to arrive.
 __device__ __forceinline__ bool arrive_last(const Tickets& t, int level, int lb, int nb, int g0) {
+#if SSAD_TICKET_FENCES
+  // release: the partials published above are visible at agent scope before the arrival is; the
+  // workgroup that sees the last arrival acquires every earlier arrival's release (the chain of
+  // read-modify-writes on one counter is a release sequence)
+  constexpr int kArrive = __ATOMIC_ACQ_REL;
+#else
+  // gfx9: stores are counted in vmcnt, and the partials are agent-scope write-through atomic stores
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the published partials have left
+  constexpr int kArrive = __ATOMIC_RELAXED;
+#endif
   const int g = lb / kTicketGroup;
   const int gsize = (nb - g * kTicketGroup) < kTicketGroup ? (nb - g * kTicketGroup) : kTicketGroup;
   unsigned* gc = t.group + (size_t)(g0 + g) * kTicketStride;
-  if (__hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)gsize - 1u)
+  if (__hip_atomic_fetch_add(gc, 1u, kArrive, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)gsize - 1u)
     return false;
   __hip_atomic_store(gc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int ngroups = (nb + kTicketGroup - 1) / kTicketGroup;
-  if (__hip_atomic_fetch_add(t.level + level, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+  if (__hip_atomic_fetch_add(t.level + level, 1u, kArrive, __HIP_MEMORY_SCOPE_AGENT) !=
       (unsigned)ngroups - 1u)
     return false;
   __hip_atomic_store(t.level + level, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return true;
+}
+
+// Every thread of the reducing workgroup, after the __syncthreads() that broadcast arrive_last():
+// the peeks below must not be satisfied by anything fetched before the last arrival was seen.
+__device__ __forceinline__ void reducer_acquire() {
+#if SSAD_TICKET_FENCES
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
 }
 
 __device__ __forceinline__ int find_level(const LaunchArgs& a, int bid) {
@@ -667,6 +687,7 @@ __global__ __launch_bounds__(kThreads) void cls_losses_fused_kernel(
   }
   __syncthreads();
   if (!s_last) return;
+  reducer_acquire();
   // this level's last workgroup: fixed-order sum of the level's partials, then the float
   // multiply by scale (math::Scale on one element, .cu:137-138)
   double va = 0.0, vb = 0.0;
@@ -825,6 +846,7 @@ __global__ __launch_bounds__(kThreads) void pow_sum_kernel(
   }
   __syncthreads();
   if (!s_last) return;
+  reducer_acquire();
   // last workgroup to arrive: the partials in index order (deterministic), one launch
   double v = 0.0;
   for (int i = threadIdx.x; i < (int)gridDim.x; i += kThreads) v += peek(partials + i);
@@ -1042,12 +1064,12 @@ size_t ssad_cls_losses_fused_workspace_bytes(int n_levels) {
   return 2 * sizeof(double) * kMaxBlocks + kTicketBytes;
 }
 
-int ssad_cls_losses_fused(const ssad_distill_level* levels_host, int n_levels,
-                          const float* normalizer, const float* fg_num,
-                          const ssad_distill_params* distill_host,
-                          const ssad_focal_params* focal_host, float* distill_losses,
-                          float* focal_losses, void* workspace, size_t workspace_bytes,
-                          ssad_stream_t stream) {
+static int cls_losses_fused_impl(const ssad_distill_level* levels_host, int n_levels,
+                                 const float* normalizer, const float* fg_num,
+                                 const ssad_distill_params* distill_host,
+                                 const ssad_focal_params* focal_host, float* distill_losses,
+                                 float* focal_losses, void* workspace, size_t workspace_bytes,
+                                 ssad_stream_t stream, bool zero_tickets) {
   if (!focal_host || !distill_host || focal_host->gamma != 2.0f ||
       focal_host->num_classes != distill_host->num_classes)
     return SSAD_E_BADARG;     // the fused kernel specialises the focal gamma = 2 of RetinaNet
@@ -1058,6 +1080,11 @@ int ssad_cls_losses_fused(const ssad_distill_level* levels_host, int n_levels,
   if (!workspace || workspace_bytes < ssad_cls_losses_fused_workspace_bytes(n_levels)) return SSAD_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   double* partials = (double*)workspace;
+  // arrival counters: zeroed here unless the caller vouches for them (a few KB; also heals a buffer
+  // whose counters an aborted launch left non-zero)
+  if (zero_tickets &&
+      hipMemsetAsync(partials + 2 * (size_t)kMaxBlocks, 0, kTicketBytes, s) != hipSuccess)
+    return (int)hipGetLastError();
   const FocalScalars fs{focal_host->gamma, focal_host->alpha, focal_host->scale};
   const bool fast = !accurate_math();
   const int gm = gamma_mode(a.gamma);
@@ -1065,6 +1092,26 @@ int ssad_cls_losses_fused(const ssad_distill_level* levels_host, int n_levels,
   LAUNCH_BY_MODE(cls_losses_fused_kernel, fast, a.beta == 0.0f, gm, dim3(blocks), dim3(kThreads),
                  0, s, a, fs, normalizer, fg_num, partials, kMaxBlocks, distill_losses, focal_losses);
   return (int)hipGetLastError();
+}
+
+int ssad_cls_losses_fused(const ssad_distill_level* levels_host, int n_levels,
+                          const float* normalizer, const float* fg_num,
+                          const ssad_distill_params* distill_host,
+                          const ssad_focal_params* focal_host, float* distill_losses,
+                          float* focal_losses, void* workspace, size_t workspace_bytes,
+                          ssad_stream_t stream) {
+  return cls_losses_fused_impl(levels_host, n_levels, normalizer, fg_num, distill_host, focal_host,
+                               distill_losses, focal_losses, workspace, workspace_bytes, stream, true);
+}
+
+int ssad_cls_losses_fused_prezeroed(const ssad_distill_level* levels_host, int n_levels,
+                                    const float* normalizer, const float* fg_num,
+                                    const ssad_distill_params* distill_host,
+                                    const ssad_focal_params* focal_host, float* distill_losses,
+                                    float* focal_losses, void* workspace, size_t workspace_bytes,
+                                    ssad_stream_t stream) {
+  return cls_losses_fused_impl(levels_host, n_levels, normalizer, fg_num, distill_host, focal_host,
+                               distill_losses, focal_losses, workspace, workspace_bytes, stream, false);
 }
 
 size_t ssad_select_smooth_l1_workspace_bytes(int n_levels) {
@@ -1153,14 +1200,16 @@ size_t ssad_pow_sum_workspace_bytes(int n_inputs) {
   return sizeof(double) * kMaxBlocks + kTicketBytes;
 }
 
-int ssad_pow_sum(
+static int pow_sum_impl(
     const float* const* inputs_host, const int64_t* sizes_host, int n_inputs,
     float power, float* out, void* workspace, size_t workspace_bytes,
-    ssad_stream_t stream) {
+    ssad_stream_t stream, bool zero_tickets) {
   if (n_inputs < 1 || !out) return SSAD_E_BADARG;
   if (!workspace || workspace_bytes < ssad_pow_sum_workspace_bytes(n_inputs)) return SSAD_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   double* partials = (double*)workspace;
+  if (zero_tickets && hipMemsetAsync(partials + kMaxBlocks, 0, kTicketBytes, s) != hipSuccess)
+    return (int)hipGetLastError();
   const bool fast = !accurate_math();
   // groups of SSAD_MAX_POWSUM_INPUTS inputs per launch; later groups add on
   for (int g0 = 0; g0 < n_inputs; g0 += SSAD_MAX_POWSUM_INPUTS) {
@@ -1197,6 +1246,20 @@ int ssad_pow_sum(
                             accumulate);
   }
   return (int)hipGetLastError();
+}
+
+int ssad_pow_sum(
+    const float* const* inputs_host, const int64_t* sizes_host, int n_inputs,
+    float power, float* out, void* workspace, size_t workspace_bytes,
+    ssad_stream_t stream) {
+  return pow_sum_impl(inputs_host, sizes_host, n_inputs, power, out, workspace, workspace_bytes, stream, true);
+}
+
+int ssad_pow_sum_prezeroed(
+    const float* const* inputs_host, const int64_t* sizes_host, int n_inputs,
+    float power, float* out, void* workspace, size_t workspace_bytes,
+    ssad_stream_t stream) {
+  return pow_sum_impl(inputs_host, sizes_host, n_inputs, power, out, workspace, workspace_bytes, stream, false);
 }
 
 }  // extern "C"

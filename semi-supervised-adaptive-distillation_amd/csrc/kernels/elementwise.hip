@@ -453,7 +453,7 @@ int ssad_fill(float* y, float value, int64_t n, ssad_stream_t stream) {
 }
 
 const char* ssad_kernels_arch(void) { return "gfx950"; }
-int ssad_kernels_abi_version(void) { return 2; }
+int ssad_kernels_abi_version(void) { return 3; }
 
 int ssad_affine_channel(const float* x, const float* scale, const float* bias,
                         const float* residual, float* y, int N, int C, int HW, int relu,

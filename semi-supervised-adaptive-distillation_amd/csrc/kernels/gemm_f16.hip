@@ -330,6 +330,7 @@ struct EwF16 {
   uint4* y;
   int N, CB, H, W;       // geometry of y
   int mode, stride, accumulate;
+  int Ha, Wa;            // EW_SUBSAMPLE: a's own map (H stride x W stride, or an odd map one short of it)
 };
 enum { EW_SUBSAMPLE = 0, EW_SUBSAMPLE_GRAD = 1, EW_UPSAMPLE_GRAD = 2, EW_SUM2 = 3, EW_RELU = 4, EW_RELU_GRAD = 5 };
 
@@ -352,8 +353,7 @@ __global__ __launch_bounds__(kThreads) void ew_f16_kernel(const EwF16 p) {
     uint4 v;
     switch (p.mode) {
       case EW_SUBSAMPLE: {          // y[.., y, x] = a[.., s y, s x]   (a is H s x W s: a strided 1x1 conv's view)
-        const int Wa = p.W * p.stride;
-        v = p.a[(ncb * p.H * p.stride + (long long)y * p.stride) * Wa + (long long)x * p.stride];
+        v = p.a[(ncb * p.Ha + (long long)y * p.stride) * p.Wa + (long long)x * p.stride];
         break;
       }
       case EW_SUBSAMPLE_GRAD: {     // y[.., y, x] (+)= (y, x both multiples of s) ? a[.., y / s, x / s] : 0
@@ -521,7 +521,23 @@ int ssad_f16_elementwise(int mode, const void* a, const void* b, void* y, int N,
   p.y = static_cast<uint4*>(y);
   p.N = N; p.CB = (C + 7) >> 3; p.H = H; p.W = W;
   p.mode = mode; p.stride = stride; p.accumulate = accumulate;
+  p.Ha = H * stride; p.Wa = W * stride;
   hipLaunchKernelGGL(ew_f16_kernel, dim3(grid_for((long long)N * p.CB * H * W)), dim3(kThreads), 0,
+                     (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}
+
+int ssad_f16_subsample(const void* a, int N, int C, int Hi, int Wi, int stride, void* y, ssad_stream_t stream) {
+  if (!a || !y || N < 0 || C < 1 || Hi < 1 || Wi < 1 || stride < 1) return SSAD_E_BADARG;
+  if (N == 0) return 0;
+  EwF16 p;
+  p.a = static_cast<const uint4*>(a);
+  p.b = nullptr;
+  p.y = static_cast<uint4*>(y);
+  p.N = N; p.CB = (C + 7) >> 3; p.H = (Hi - 1) / stride + 1; p.W = (Wi - 1) / stride + 1;
+  p.mode = EW_SUBSAMPLE; p.stride = stride; p.accumulate = 0;
+  p.Ha = Hi; p.Wa = Wi;
+  hipLaunchKernelGGL(ew_f16_kernel, dim3(grid_for((long long)N * p.CB * p.H * p.W)), dim3(kThreads), 0,
                      (hipStream_t)stream, p);
   return (int)hipGetLastError();
 }

@@ -334,22 +334,51 @@ bool ConvGradientOp<float, HIPContext>::RunDefaultEngine() {
     const bool square = kh == kw && geom_.stride[0] == geom_.stride[1] && geom_.dilation == vector<int>{1, 1} &&
                         geom_.pads[0] == geom_.pads[1] && geom_.pads[0] == geom_.pads[2] &&
                         geom_.pads[0] == geom_.pads[3];
-    const size_t wsw = batched && G == 1 && square && !pointwise
-                           ? ssad_conv_kxk_wgrad_workspace_bytes(N, C, H, W, M, kh, geom_.stride[0], geom_.pads[0])
-                           : 0;
     const bool dx_ok = !dX || (K % 4 == 0 && ((uintptr_t)filter.data<float>() & 15) == 0);
-    if (wsw > 0 && dx_ok) {
-      const size_t wsd = dX ? ssad_conv_kxk_dgrad_workspace_bytes(N, C, H, W, M, kh, geom_.stride[0], geom_.pads[0]) : 0;
-      workspace_.Resize((TIndex)(wsw > wsd ? wsw : wsd));
-      CAFFE_ENFORCE_EQ(ssad_conv_kxk_wgrad(X.data<float>(), dY.data<float>(), N, C, H, W, M, kh, geom_.stride[0],
-                                           geom_.pads[0], dfilter->mutable_data<float>(), 0,
-                                           workspace_.mutable_data<uint8_t>(), wsw, s), 0,
-                       "ConvGradient (filter, batched im2col) launch failed");
-      if (dX)
-        CAFFE_ENFORCE_EQ(ssad_conv_kxk_dgrad(filter.data<float>(), dY.data<float>(), N, C, H, W, M, kh,
-                                             geom_.stride[0], geom_.pads[0], dX->mutable_data<float>(), nullptr, 0,
-                                             workspace_.mutable_data<uint8_t>(), wsd, s), 0,
-                         "ConvGradient (input, batched col2im) launch failed");
+    // The column buffer of a whole batch can be large (7x7 stem, 16 images of 600x1000: 1.4 GB + 0.6 GB of
+    // transposed dY, against 88 MB per image in the loop below): the batch is processed in image groups whose
+    // workspace stays under a budget (SSAD_CONVGRAD_WS_BYTES, default 256 MiB); the filter gradient accumulates
+    // over the groups in order (deterministic).  A layer whose single image exceeds the budget takes the loop.
+    const size_t budget = [] {
+      const char* e = getenv("SSAD_CONVGRAD_WS_BYTES");
+      const long long b = e ? atoll(e) : 0;
+      return b > 0 ? (size_t)b : (size_t)256 << 20;
+    }();
+    auto need = [&](int n) -> size_t {
+      const size_t a = ssad_conv_kxk_wgrad_workspace_bytes(n, C, H, W, M, kh, geom_.stride[0], geom_.pads[0]);
+      if (a == 0) return 0;
+      const size_t b = dX ? ssad_conv_kxk_dgrad_workspace_bytes(n, C, H, W, M, kh, geom_.stride[0], geom_.pads[0]) : 0;
+      return a > b ? a : b;
+    };
+    int grp = 0;
+    if (batched && G == 1 && square && !pointwise && dx_ok && need(1) > 0 && need(1) <= budget) {
+      grp = 1;
+      while (grp < N) {                      // the largest group under the budget (need() is monotone in n)
+        const int nxt = grp * 2 < N ? grp * 2 : N;
+        const size_t nb = need(nxt);
+        if (nb == 0 || nb > budget) break;
+        grp = nxt;
+      }
+    }
+    if (grp > 0) {
+      workspace_.Resize((TIndex)need(grp));
+      for (int n0 = 0; n0 < N; n0 += grp) {
+        const int n = (N - n0 < grp) ? N - n0 : grp;
+        const float* xg = X.data<float>() + (size_t)n0 * C * H * W;
+        const float* dyg = dY.data<float>() + (size_t)n0 * M * P;
+        const size_t wsw = ssad_conv_kxk_wgrad_workspace_bytes(n, C, H, W, M, kh, geom_.stride[0], geom_.pads[0]);
+        CAFFE_ENFORCE_EQ(ssad_conv_kxk_wgrad(xg, dyg, n, C, H, W, M, kh, geom_.stride[0], geom_.pads[0],
+                                             dfilter->mutable_data<float>(), n0 > 0 ? 1 : 0,
+                                             workspace_.mutable_data<uint8_t>(), wsw, s), 0,
+                         "ConvGradient (filter, batched im2col) launch failed");
+        if (dX) {
+          const size_t wsd = ssad_conv_kxk_dgrad_workspace_bytes(n, C, H, W, M, kh, geom_.stride[0], geom_.pads[0]);
+          CAFFE_ENFORCE_EQ(ssad_conv_kxk_dgrad(filter.data<float>(), dyg, n, C, H, W, M, kh, geom_.stride[0],
+                                               geom_.pads[0], dX->mutable_data<float>() + (size_t)n0 * C * H * W,
+                                               nullptr, 0, workspace_.mutable_data<uint8_t>(), wsd, s), 0,
+                           "ConvGradient (input, batched col2im) launch failed");
+        }
+      }
       if (!no_bias_) {
         auto* dbias = Output(BIAS_OR_INPUT_GRAD);
         dbias->Resize(M);
@@ -662,13 +691,10 @@ bool ConvGradientOp<float, HIPContext>::RunFloat16Pointwise() {
   CAFFE_ENFORCE_EQ(ssad_f16_block_activations(X.raw_data(), N, C, H, W, xb.mutable_data<float>(), s), 0);
   CAFFE_ENFORCE_EQ(ssad_f16_block_activations(dY.raw_data(), N, M, OH, OW, dyb.mutable_data<float>(), s), 0);
   const float* xs = xb.data<float>();
-  CAFFE_ENFORCE(st == 1 || (H % st == 0 && W % st == 0),
-                "float16 pointwise ConvGradient: a strided layer needs an input map that is a multiple of the stride");
-  if (st > 1) {                                 // the strided layer's view of its input
+  if (st > 1) {                                 // the strided layer's view of its input (odd maps included)
     auto& sub = f16_scratch_[6];
     sub.Resize((TIndex)((BlockedHalves(N, C, OH, OW) + 1) / 2));
-    CAFFE_ENFORCE_EQ(ssad_f16_elementwise(0, xb.data<float>(), nullptr, sub.mutable_data<float>(), N, C, OH, OW, st,
-                                          0, s), 0);
+    CAFFE_ENFORCE_EQ(ssad_f16_subsample(xb.data<float>(), N, C, H, W, st, sub.mutable_data<float>(), s), 0);
     xs = sub.data<float>();
   }
   auto& dw32 = f16_scratch_[2];

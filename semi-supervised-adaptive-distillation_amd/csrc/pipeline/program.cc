@@ -98,10 +98,10 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
       return ssad_conv3x3_wgrad((const ssad_conv_level*)p[0], i[0], (float*)p[1], (float*)p[2], i[1], i[2],
                                 i[3], (void*)p[3], (size_t)o.l[0], s);
     case SSAD_OP_POW_SUM:
-      return ssad_pow_sum((const float* const*)p[0], (const int64_t*)p[1], i[0], f[0], (float*)p[2],
+      return ssad_pow_sum_prezeroed((const float* const*)p[0], (const int64_t*)p[1], i[0], f[0], (float*)p[2],
                           (void*)p[3], (size_t)o.l[0], s);
     case SSAD_OP_CLS_LOSSES_FUSED:
-      return ssad_cls_losses_fused((const ssad_distill_level*)p[0], i[0], (const float*)p[1],
+      return ssad_cls_losses_fused_prezeroed((const ssad_distill_level*)p[0], i[0], (const float*)p[1],
                                    (const float*)p[2], (const ssad_distill_params*)p[3],
                                    (const ssad_focal_params*)p[4], (float*)p[5], (float*)p[6],
                                    (void*)p[7], (size_t)o.l[0], s);

@@ -121,6 +121,7 @@ def lib():
     L.ssad_cls_losses_fused.argtypes = [
         C.POINTER(DistillLevel), i32, vp, vp, C.POINTER(DistillParams), C.POINTER(FocalParams),
         vp, vp, vp, sz, vp]
+    L.ssad_cls_losses_fused_prezeroed.argtypes = L.ssad_cls_losses_fused.argtypes
     L.ssad_select_smooth_l1_workspace_bytes.restype = sz
     L.ssad_select_smooth_l1_workspace_bytes.argtypes = [i32]
     L.ssad_select_smooth_l1_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32,
@@ -133,6 +134,7 @@ def lib():
     L.ssad_pow_sum_workspace_bytes.restype = sz
     L.ssad_pow_sum_workspace_bytes.argtypes = [i32]
     L.ssad_pow_sum.argtypes = [C.POINTER(vp), C.POINTER(i64), i32, f32, vp, vp, sz, vp]
+    L.ssad_pow_sum_prezeroed.argtypes = L.ssad_pow_sum.argtypes
     L.ssad_relu.argtypes = [vp, vp, i64, vp]
     L.ssad_relu_grad.argtypes = [vp, vp, vp, i64, vp]
     L.ssad_sigmoid.argtypes = [vp, vp, i64, vp]
@@ -206,6 +208,7 @@ def lib():
     L.ssad_conv1x1_wgrad_f16_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     L.ssad_conv1x1_wgrad_f16.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, sz, vp]
     L.ssad_f16_elementwise.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.ssad_f16_subsample.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_stem_pool_f16.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     L.ssad_grouped_conv3x3_f16_filter_halves.restype = sz
     L.ssad_grouped_conv3x3_f16_filter_halves.argtypes = [i32, i32]
@@ -213,6 +216,9 @@ def lib():
     L.ssad_grouped_conv3x3_f16.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_kernels_arch.restype = C.c_char_p
     L.ssad_kernels_abi_version.restype = i32
+    if L.ssad_kernels_abi_version() != ABI_VERSION:
+        raise KernelError("%s has kernel ABI %d, this binding is written against %d (include/ssad_kernels.h): "
+                          "rebuild csrc/" % (LIB_PATH, L.ssad_kernels_abi_version(), ABI_VERSION))
     _lib = L
     return L
 
@@ -239,14 +245,16 @@ def _f32c(t, name):
 _ws_cache = {}
 
 
+ABI_VERSION = 3        # SSAD_KERNELS_ABI_VERSION of include/ssad_kernels.h
+
+
 def _workspace(nbytes, tag):
     dev = torch.cuda.current_device()
     # one buffer per (device, stream, use): launches on different streams may overlap
     key = (dev, torch.cuda.current_stream().cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        # zero-filled: PowSum / the fused classification losses keep their arrival counters here
-        # (ssad_kernels.h: zero once after allocation, every launch leaves them zero)
+        # (zero-filled for tidiness only: the launchers that keep arrival counters here zero them)
         buf = torch.zeros(max(int(nbytes), 1), dtype=torch.uint8, device="cuda")
         _ws_cache[key] = buf
     return buf

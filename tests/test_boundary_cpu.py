@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib):
     raw = ctypes.CDLL(_capi.LIB_PATH)
     missing = [n for n in names if not hasattr(raw, n)]
     assert not missing, "declared in include/ but not exported: %s" % missing
-    assert raw.ssad_kernels_abi_version() == 2
+    assert raw.ssad_kernels_abi_version() == 3
     raw.ssad_kernels_arch.restype = ctypes.c_char_p
     assert raw.ssad_kernels_arch() == b"gfx950"
 

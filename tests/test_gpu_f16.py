@@ -435,14 +435,16 @@ def test_f16_pipeline_against_the_cpu_oracle(K):
         assert e < (4e-2 if "conv_n0" in k and k.endswith("_w") else 1e-2), worst
 
 
-@pytest.mark.parametrize("stride", [1, 2])
-def test_float16_pointwise_conv_through_the_operators(stride):
+@pytest.mark.parametrize("stride,H,W", [(1, 10, 14), (2, 10, 14), (2, 9, 13)],
+                         ids=["s1", "s2", "s2_odd_map"])
+def test_float16_pointwise_conv_through_the_operators(stride, H, W):
     """The backbones' 1x1 convolutions on TensorProto::FLOAT16 blobs through `Conv` / `ConvGradient`
     (CudnnConvOp<float16>, conv_op_cudnn.cc:631-636; ResNet.py:221-283 bottleneck 1x1s with the
-    stride on the first one): fp16 in / out, fp32 sums, against float64 on the same fp16 values."""
+    stride on the first one): fp16 in / out, fp32 sums, against float64 on the same fp16 values.
+    A strided layer on an odd map (a 75 x 125 res4 input) runs forward AND backward."""
     from ssad_amd.caffe2_hip import caffe2_pb2, core, workspace
     rng = np.random.default_rng(900 + stride)
-    N, C, M, H, W = 2, 72, 136, 10, 14
+    N, C, M = 2, 72, 136
     X = rng.standard_normal((N, C, H, W)).astype(np.float16)
     Wt = (rng.standard_normal((M, C, 1, 1)) * 0.1).astype(np.float16)
     b = rng.standard_normal(M).astype(np.float16)

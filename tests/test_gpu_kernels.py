@@ -200,6 +200,53 @@ def test_distill_full_size_properties(K):
     assert abs(sum(parts) - float(l1[0])) <= 1e-5 * abs(float(l1[0]))
 
 
+def test_ticket_launchers_heal_a_dirty_workspace(K):
+    """ssad_pow_sum / ssad_cls_losses_fused finish their sums in the last-arriving workgroup through
+    arrival counters in the caller's workspace; the launchers zero the counters themselves (ABI 3),
+    so a workspace full of garbage -- never zeroed, or left dirty by an aborted launch -- gives the
+    same bits as a clean one.  The *_prezeroed forms rely on the caller's zero fill and leave the
+    counters zero for the next launch."""
+    import ctypes as C
+    L = K.lib()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xs = [torch.rand(n, device="cuda", generator=g) for n in (100000, 4097, 33)]
+    want = K.pow_sum(xs, 1.8).clone()
+    n = len(xs)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in xs])
+    sizes = (C.c_int64 * n)(*[t.numel() for t in xs])
+    nb = L.ssad_pow_sum_workspace_bytes(n)
+    st = torch.cuda.current_stream().cuda_stream
+    dirty = torch.full((nb,), 0xA5, dtype=torch.uint8, device="cuda")
+    out = torch.full((), float("nan"), device="cuda")
+    for _ in range(2):
+        assert L.ssad_pow_sum(ptrs, sizes, n, 1.8, out.data_ptr(), dirty.data_ptr(), nb, st) == 0
+        assert torch.equal(out, want)
+        out.fill_(float("nan"))
+    clean = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    for _ in range(3):          # every launch leaves the counters zero
+        assert L.ssad_pow_sum_prezeroed(ptrs, sizes, n, 1.8, out.data_ptr(), clean.data_ptr(), nb, st) == 0
+        assert torch.equal(out, want)
+        out.fill_(float("nan"))
+    # the fused classification losses: two levels
+    levels = []
+    for (h, w) in ((12, 20), (6, 10)):
+        x = torch.randn((2, 720, h, w), device="cuda", generator=g) * 2 - 4
+        q = torch.sigmoid(torch.randn((2, 720, h, w), device="cuda", generator=g) * 2 - 4).clamp(1e-6, 1 - 1e-6)
+        t = torch.randint(-1, 81, (2, 9, h, w), device="cuda", generator=g, dtype=torch.int32)
+        levels.append((x, q, t))
+    norm, fg = torch.tensor([37.5], device="cuda"), torch.tensor([11.0], device="cuda")
+    dkw = dict(gamma=2.0, alpha=0.5, beta=0.0, num_classes=80, scale=0.5)
+    fkw = dict(gamma=2.0, alpha=0.25, num_classes=80, scale=1.0)
+    dl0, fl0, dx0 = K.cls_losses_fused(levels, norm, fg, dkw, fkw)
+    dl0, fl0, dx0 = dl0.clone(), fl0.clone(), [d.clone() for d in dx0]
+    nb = L.ssad_cls_losses_fused_workspace_bytes(2)
+    K._ws_cache[(torch.cuda.current_device(), st, "clsfused")] = torch.full((nb,), 0x5A, dtype=torch.uint8,
+                                                                              device="cuda")
+    dl1, fl1, dx1 = K.cls_losses_fused(levels, norm, fg, dkw, fkw)
+    assert torch.equal(dl0, dl1) and torch.equal(fl0, fl1)
+    assert all(torch.equal(a, b) for a, b in zip(dx0, dx1))
+
+
 # ---------------------------------------------------------------------------
 # PowSum
 # ---------------------------------------------------------------------------

@@ -267,7 +267,7 @@ def test_teacher_running_ahead_of_the_previous_step_changes_no_bit():
             else:
                 m.step(images, labels, targets, fg_num)
         torch.cuda.synchronize()
-    assert a._t_fpn_read is not None and a._images_key is not None
+    assert a._t_fpn_read is not None and a._images_ref is images
     for m, what in ((a, "ahead"), (c, "fresh tensor"), (d, "images_event")):
         assert torch.isfinite(m.heads.losses).all()
         assert torch.equal(m.heads.losses, b.heads.losses), what
@@ -276,3 +276,39 @@ def test_teacher_running_ahead_of_the_previous_step_changes_no_bit():
         assert torch.equal(m.student.moms_flat, b.student.moms_flat), what
         for l in range(len(SHAPES)):
             assert torch.equal(m.teacher.fpn[l], b.teacher.fpn[l]), (what, l)
+
+
+def test_fresh_batch_tensor_every_step_is_never_read_before_its_producer():
+    """A training loop hands step() a NEW tensor every iteration, produced by work queued on the
+    current stream (host-to-device copy, preprocessing).  The caching allocator gives the new batch
+    the address of the one just freed and its version counter starts at 0 again: the teacher must not
+    take that for "the tensor the previous step already read" and run ahead of the producer on its
+    side stream (it would compute this step's distillation targets on the previous batch).  Six
+    iterations enqueued back to back with a different batch each, against the model whose teacher
+    waits for everything: same bits."""
+    cfg, images, ref_s, ref_t, S, T, labs, tg, fg = _problem(seed=7)
+    labels, targets, fg_num = _inputs(labs, tg, fg)
+    a = _model(cfg, ref_s, ref_t, S, T, overlap=True)
+    b = _model(cfg, ref_s, ref_t, S, T, overlap=True)
+    a._teacher_ahead, b._teacher_ahead = True, False
+    seen = {}
+    for m in (a, b):
+        m.student.poison()
+        m.teacher.poison()
+        torch.cuda.synchronize()
+        ptrs = []
+        for it in range(6):
+            batch = images * (1.0 + 0.25 * it)            # produced on the current stream, right now
+            ptrs.append(batch.data_ptr())
+            m.step(batch, labels, targets, fg_num)
+            del batch
+        torch.cuda.synchronize()
+        seen[m] = ptrs
+    # the situation the test is about did occur: a later batch reused an earlier batch's address
+    assert len(set(seen[a])) < len(seen[a])
+    assert torch.isfinite(a.heads.losses).all()
+    assert torch.equal(a.heads.losses, b.heads.losses)
+    assert torch.equal(a.heads.params.flat, b.heads.params.flat)
+    assert torch.equal(a.student.params_flat, b.student.params_flat)
+    for l in range(len(SHAPES)):
+        assert torch.equal(a.teacher.fpn[l], b.teacher.fpn[l]), l

@@ -720,3 +720,43 @@ def test_default_engine_vs_reference_operator_golden(golden_dir, case):
         got = workspace.FetchBlob(blob).ravel()[g["%s_%s_idx" % (name, key)]]
         close(got, g["%s_%s" % (name, key)], CONV_RTOL, CONV_FLOOR, "%s %s" % (name, key))
     close(workspace.FetchBlob("b_grad"), g[name + "_db"], CONV_RTOL, CONV_FLOOR, name + " db")
+
+
+@pytest.mark.parametrize("budget", ["groups_of_one", "per_image_loop"])
+def test_conv_gradient_batched_engine_respects_its_workspace_budget(golden_dir, budget, monkeypatch):
+    """ConvGradient's batched im2col route holds the column buffer of every image it processes at once
+    (1.4 GB for the 7x7 stem at 16 x 600x1000): it works in image groups under SSAD_CONVGRAD_WS_BYTES
+    (default 256 MiB), accumulating the filter gradient over the groups, and leaves layers whose single
+    image does not fit to the per-image loop (conv_op_impl.h:451-560).  Same answers either way: the
+    reference operator's stored outputs for its 3x3 / stride 2 and stem geometries."""
+    import ctypes as C
+    import make_golden as mg
+    from ssad_amd import kernels as K
+    g = np.load(__import__("os").path.join(golden_dir, "conv_ref.npz"))
+    L = K.lib()
+    ran = 0
+    for case in mg_ref_geoms():
+        name = case[0]
+        seed, N, Cin, M, H, W, k, s, p, grp = [int(v) for v in g[name + "_dims"]]
+        if k == 1 or grp != 1 or N < 2:
+            continue
+        one = max(L.ssad_conv_kxk_wgrad_workspace_bytes(1, Cin, H, W, M, k, s, p),
+                  L.ssad_conv_kxk_dgrad_workspace_bytes(1, Cin, H, W, M, k, s, p))
+        two = max(L.ssad_conv_kxk_wgrad_workspace_bytes(2, Cin, H, W, M, k, s, p),
+                  L.ssad_conv_kxk_dgrad_workspace_bytes(2, Cin, H, W, M, k, s, p))
+        assert 0 < one < two
+        monkeypatch.setenv("SSAD_CONVGRAD_WS_BYTES", str(one if budget == "groups_of_one" else one - 1))
+        X, Wt, b, dY = mg.conv_ref_inputs(seed, N, Cin, M, H, W, k, s, p, grp)
+        feed("X", X); feed("w", Wt); feed("b", b); feed("Y_grad", dY)
+        with core.DeviceScope(GPU):
+            conv = core.CreateOperator("Conv", ["X", "w", "b"], ["Y"], kernel=k, pad=p, stride=s, order="NCHW",
+                                       engine="CUDNN")
+        workspace.RunOperatorOnce(conv)
+        gops, _ = core.GradientRegistry.GetGradientForOp(conv, ["Y_grad"])
+        workspace.RunOperatorsOnce(gops)
+        for key, blob in (("dW", "w_grad"), ("dX", "X_grad")):
+            got = workspace.FetchBlob(blob).ravel()[g["%s_%s_idx" % (name, key)]]
+            close(got, g["%s_%s" % (name, key)], CONV_RTOL, CONV_FLOOR, "%s %s (%s)" % (name, key, budget))
+        close(workspace.FetchBlob("b_grad"), g[name + "_db"], CONV_RTOL, CONV_FLOOR, name + " db")
+        ran += 1
+    assert ran >= 2, ran
