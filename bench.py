@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=3,
                     help="instrumented steps after the timed region (per-family kernel table)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the short config 5 (fp16) and config 2 (student only) legs after the headline run")
     ap.add_argument("--cpu-sample", default="auto")
     return ap.parse_args()
 
@@ -128,10 +130,56 @@ def pmc_traffic(klass):
         return None, None
 
 
+def cpu_reference_conv(budget_s=25.0):
+    """The reference's OWN CPU operators for the convolutions of the subnets step:
+    oracle/_ref/libref_conv.so = ConvOp / ConvGradientOp<float, CPUContext> (conv_op_impl.h:31-202,
+    358-577: per-image im2col + Eigen GEMM, one thread as the reference builds them) compiled from
+    /root/reference by oracle/build_ref_conv.sh.  One image; every convolution a step runs on it (student
+    towers + predictors forward and gradient, teacher forward) on the FPN levels from the coarsest
+    upwards for as long as the budget lasts.  None when the library was not built."""
+    from oracle import oracle
+    from ssad_amd import synth
+    if oracle.load_ref_conv() is None:
+        return None
+    rng = np.random.default_rng(7)
+    used, t_total, fl_total, px_used = [], 0.0, 0.0, 0
+    last = None
+    for li in range(len(synth.LEVEL_SHAPES_600) - 1, -1, -1):
+        h, w = synth.LEVEL_SHAPES_600[li]
+        if last is not None and t_total + 4.5 * last > budget_s:
+            break
+        t_level = 0.0
+        x = rng.standard_normal((1, 256, h, w)).astype(np.float32)
+        for M, n_fwd, n_bwd in ((256, 16, 8), (720, 2, 1), (36, 2, 1)):     # towers (student + teacher), cls_pred, bbox_pred
+            Wt = (rng.standard_normal((M, 256, 3, 3)) * 0.01).astype(np.float32)
+            b = np.zeros(M, np.float32)
+            t0 = time.perf_counter()
+            for _ in range(n_fwd):
+                y = oracle.ref_conv_forward(x, Wt, b)
+            for _ in range(n_bwd):
+                oracle.ref_conv_backward(x, Wt, y)
+            t_level += time.perf_counter() - t0
+            fl_total += 2.0 * 9 * 256 * M * h * w * (n_fwd + 2 * n_bwd)
+        t_total += t_level
+        last = t_level
+        px_used += h * w
+        used.append("P%d" % (li + 3))
+    frac = px_used / float(sum(h * w for h, w in synth.LEVEL_SHAPES_600))
+    return {"value": round(frac / t_total, 5), "unit": "images/s", "cores": 1, "kind": "reference",
+            "gflops": round(fl_total / t_total / 1e9, 2),
+            "sample": "1 image, the convolutions of the subnets step only (no losses, no backbone): student towers + "
+                      "predictors forward and gradient, teacher forward, FPN levels %s (%.1f%% of the pixels, scaled by "
+                      "pixel share), the reference's compiled ConvOp / ConvGradientOp<float, CPUContext> "
+                      "(oracle/_ref/libref_conv.so, Eigen GEMM, 1 thread), %.1f s" % (
+                          "+".join(reversed(used)), 100 * frac, t_total)}
+
+
 def cpu_baseline(args, cfg):
     """The oracle's restatement of the same step (subnets + losses; the
     reference has no CPU operators for the losses)
-    timed on the host cores of this box, on a bounded sample: ONE image."""
+    timed on the host cores of this box, on a bounded sample: ONE image.  Beside it
+    (`reference_conv`) the reference's own compiled CPU convolution operators on the
+    convolutions of that step."""
     from oracle import oracle, head_step
     from ssad_amd import synth
     cores = min(os.cpu_count() or 1, 64)   # beyond ~64 threads the 256-row GEMMs stop scaling
@@ -149,12 +197,155 @@ def cpu_baseline(args, cfg):
     head_step.head_step(S, T, f, f, labs, scale=1.0, bbox_targets=tg, fg_num=fg)
     dt = time.time() - t0
     frac = sum(h * w for h, w in shapes) / float(sum(h * w for h, w in synth.LEVEL_SHAPES_600))
-    return {
+    out = {
         "value": round(frac / dt, 5), "unit": "images/s", "cores": oracle.num_threads(),
         "kind": "port",
         "sample": "1 image, subnets+losses only (no backbone), FPN levels %s of 5 (%.1f%% of "
                   "the pixels, scaled by pixel share), OpenMP im2col+GEMM oracle, %.1f s" % (
                       "P3-P7" if len(shapes) == 5 else "P4-P7", 100 * frac, dt)}
+    try:
+        out["reference_conv"] = cpu_reference_conv()
+    except Exception as e:          # the checker library is optional on the box
+        out["reference_conv"] = {"error": repr(e)}
+    return out
+
+
+def make_workload(args, dev, world, pg, rank):
+    """Everything one configuration needs: subnets (+ backbones for --workload full), synthetic
+    labels / box targets / images resident in HBM, and step() = one training iteration.
+    -> dict(step, heads, model, wl, N, shapes, image_hw, f16, distill, native, hkw, labels, bbox_targets,
+    fg_num, gen)"""
+    from ssad_amd import synth
+    from ssad_amd.head_pipeline import DistillHeads, DistillHeadsF16
+    from ssad_amd.modeling.retinanet_heads import HeadConfig
+    N = args.batch_per_gpu
+    shapes = synth.LEVEL_SHAPES_600 if args.px == 600 else synth.LEVEL_SHAPES_500
+    image_hw = (640, 896) if args.px == 600 else (512, 768)
+    cfg = HeadConfig(num_gpus=world)
+    rng = np.random.default_rng(1234 + rank)
+    f16 = args.precision == "f16"
+    distill = args.teacher != "none"
+    native_ok = args.student in ("r50", "r101") and args.teacher in ("none", "r50", "r101", "x101-64x4d")
+    if args.backbone == "native" and not native_ok:
+        sys.stderr.write("bench.py: --backbone native covers ResNet-50/101 students and ResNet-50/101 / "
+                         "ResNeXt-101-64x4d teachers\n")
+        sys.exit(2)
+    # every precision runs on native programs of this repo's kernels by default ("harness" = round
+    # 1's PyTorch backbones, kept under tools/ for A/B runs)
+    native = args.workload == "full" and (args.backbone == "native" or (args.backbone == "auto" and native_ok))
+    hkw = dict(blocked_io=True) if (f16 and native and os.environ.get("SSAD_F16_BACKBONE", "1") == "1") else {}
+    heads = (DistillHeadsF16 if f16 else DistillHeads)(cfg, N=N, shapes=shapes, device=dev,
+                         student_init=synth.head_params(np.random.default_rng(1)),
+                         teacher_init=synth.head_params(np.random.default_rng(2)) if distill else None,
+                         process_group=pg, world_size=world, lr=1e-4, distill=distill, **hkw)
+    heads.broadcast_params()
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    labels = [torch.from_numpy(synth.distill_inputs(rng, N, 9, 80, h, w)[2]).to(dev)
+              for h, w in shapes] if N <= 4 else None
+    if labels is None:
+        labels = []
+        for h, w in shapes:
+            u = torch.rand((N, 9, h, w), device=dev, generator=gen)
+            lab = torch.zeros((N, 9, h, w), dtype=torch.int32, device=dev)
+            lab[u < 0.05] = -1
+            fg = (u >= 0.05) & (u < 0.07)
+            lab[fg] = torch.randint(1, 81, (int(fg.sum()),), device=dev, generator=gen,
+                                    dtype=torch.int32)
+            labels.append(lab)
+    # box-regression targets for every foreground anchor (SelectSmoothL1Loss inputs)
+    bbox_targets, n_fg = [], 0
+    for lab in labels:
+        idx = torch.nonzero(lab > 0)
+        Lc = torch.stack([idx[:, 0], 4 * idx[:, 1], idx[:, 2], idx[:, 3]], dim=1).float().contiguous()
+        Y = (torch.randn((Lc.shape[0], 4), device=dev, generator=gen) * 0.5).contiguous()
+        bbox_targets.append((Y, Lc))
+        n_fg += Lc.shape[0]
+    fg_num = torch.tensor([float(max(n_fg, 1))], device=dev)
+
+    losses_txt = ("PowSum + SigmoidAdaptiveDistillLoss + SigmoidFocalLoss + SelectSmoothL1Loss"
+                  if distill else "SigmoidFocalLoss + SelectSmoothL1Loss")
+    model = None
+    if args.workload == "heads":
+        s_fpn = [torch.randn((N, 256, h, w), device=dev, generator=gen) for h, w in shapes]
+        t_fpn = [torch.randn((N, 256, h, w), device=dev, generator=gen) for h, w in shapes] if distill else s_fpn
+
+        def step():
+            heads.step(s_fpn, t_fpn, labels, bbox_targets=bbox_targets, fg_num=fg_num)
+        wl = ("heads-only: RetinaNet cls+bbox subnets (%sstudent fwd+bwd) + %s fwd/bwd + SGD on synthetic "
+              "FPN features; the whole step is one native program of this repo's HIP kernels" % (
+                  "teacher fwd, " if distill else "", losses_txt))
+    else:
+        if native:
+            from ssad_amd.backbone_pipeline import NativeDistillModel
+            model = NativeDistillModel(heads, student_arch=args.student,
+                                       teacher_arch=args.teacher if distill else None, N=N, image_hw=image_hw,
+                                       device=dev, process_group=pg, world_size=world)
+        else:
+            from tools.harness.full_model import FullDistillModel
+            model = FullDistillModel(heads, student_depth=args.student,
+                                     teacher_depth=args.teacher if distill else None, device=dev,
+                                     backbone_f16=f16, process_group=pg, world_size=world)
+        images = torch.randn((N, 3) + image_hw, device=dev, generator=gen)
+
+        def step():
+            model.step(images, labels, bbox_targets, fg_num)
+
+        def pretty(a):
+            return a.upper().replace("R", "R-", 1) if a[0] == "r" else a.upper().replace("X", "X-", 1)
+        wl = ("%s-FPN student%s, %d px (3x%dx%d): " % (
+              pretty(args.student), (" + %s-FPN teacher adaptive distillation" % pretty(args.teacher))
+              if distill else " only (plain RetinaNet training, BASELINE config 2)",
+              args.px, image_hw[0], image_hw[1]) + model.describe() +
+              "; subnets, %s and subnet SGD = one native program of this repo's HIP kernels" % losses_txt)
+
+    return dict(step=step, heads=heads, model=model, wl=wl, N=N, shapes=shapes, image_hw=image_hw, f16=f16,
+                distill=distill, native=native, hkw=hkw, labels=labels, bbox_targets=bbox_targets, fg_num=fg_num,
+                gen=gen, cfg=cfg)
+
+
+def also_leg(dev, dom_klass, steps=5, warmup=2, **cfgkw):
+    """A short run of ANOTHER BASELINE configuration on this GPU, after (and outside) the headline's
+    timed region: built from scratch (make_workload), `warmup` untimed + `steps` timed iterations
+    bracketed by synchronize(), the dominant convolution class bracketed by HIP events inside
+    them.  Same step, same kernels, same schedule as a `bench.py` run with these flags."""
+    import gc
+    from ssad_amd import program as PR
+    a = argparse.Namespace(workload="full", backbone="auto", **cfgkw)
+    W = make_workload(a, dev, 1, None, 0)
+    try:
+        for _ in range(warmup):
+            W["step"]()
+        torch.cuda.synchronize()
+        timing = PR.Timing().select([dom_klass])
+        W["heads"].timing = timing
+        W["model"].timing = timing
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            W["step"]()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        W["heads"].timing = None
+        W["model"].timing = None
+        h = W["heads"]
+        losses = [float(v) for v in (h.losses if W["distill"] else h.focal_losses).cpu()]
+        ok = all(np.isfinite(losses)) and bool(torch.isfinite(h.params.flat).all()) and \
+            bool(torch.isfinite(W["model"].student.params_flat).all())
+        dom = {r["class"]: r for r in kernel_report(timing.collect(), steps)}.get(dom_klass)
+        out = {"workload": W["wl"], "batch_per_gpu": W["N"], "image": "3x%dx%d" % W["image_hw"],
+               "dtype": "f16 storage / f32 accumulate" if W["f16"] else "f32", "steps": steps, "warmup": warmup,
+               "ms_per_step": round(dt / steps * 1e3, 3), "images_per_s": round(W["N"] * steps / dt, 2),
+               "finite": ok, ("distill_loss" if W["distill"] else "focal_loss"): losses,
+               "roofline": dict(kernel=dom["kernel"], bound="mfma", achieved=dom["achieved"], peak=dom["peak"],
+                                unit="TFLOP/s", frac=dom["frac"], launches_per_step=dom["launches_per_step"],
+                                avg_launch_ms=dom["avg_launch_ms"], flops_per_launch=dom["flops_per_launch"],
+                                direct_equiv_tflops=dom["direct_equiv_tflops"]) if dom else None}
+        if W["f16"]:
+            out["loss_scale"] = float(h.ls_state[0])
+        return out
+    finally:
+        W.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
 
 
 def launch_ranks(args):
@@ -202,90 +393,14 @@ def main():
         pg = dist.group.WORLD
 
     import ssad_amd  # noqa: F401
-    from ssad_amd import kernels as K, synth, program as PR
-    from ssad_amd.head_pipeline import DistillHeads, DistillHeadsF16
-    from ssad_amd.modeling.retinanet_heads import HeadConfig
+    from ssad_amd import kernels as K, program as PR
     K.lib()   # fail loudly if the HIP extension is missing
 
-    N = args.batch_per_gpu
-    shapes = synth.LEVEL_SHAPES_600 if args.px == 600 else synth.LEVEL_SHAPES_500
-    image_hw = (640, 896) if args.px == 600 else (512, 768)
-    cfg = HeadConfig(num_gpus=world)
-    rng = np.random.default_rng(1234 + rank)
-    f16 = args.precision == "f16"
-    distill = args.teacher != "none"
-    native_ok = args.student in ("r50", "r101") and args.teacher in ("none", "r50", "r101", "x101-64x4d")
-    if args.backbone == "native" and not native_ok:
-        sys.stderr.write("bench.py: --backbone native covers ResNet-50/101 students and ResNet-50/101 / "
-                         "ResNeXt-101-64x4d teachers\n")
-        sys.exit(2)
-    # every precision runs on native programs of this repo's kernels by default ("harness" = round
-    # 1's PyTorch backbones, kept under tools/ for A/B runs)
-    native = args.workload == "full" and (args.backbone == "native" or (args.backbone == "auto" and native_ok))
-    hkw = dict(blocked_io=True) if (f16 and native and os.environ.get("SSAD_F16_BACKBONE", "1") == "1") else {}
-    heads = (DistillHeadsF16 if f16 else DistillHeads)(cfg, N=N, shapes=shapes, device=dev,
-                         student_init=synth.head_params(np.random.default_rng(1)),
-                         teacher_init=synth.head_params(np.random.default_rng(2)) if distill else None,
-                         process_group=pg, world_size=world, lr=1e-4, distill=distill, **hkw)
-    heads.broadcast_params()
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    labels = [torch.from_numpy(synth.distill_inputs(rng, N, 9, 80, h, w)[2]).to(dev)
-              for h, w in shapes] if N <= 4 else None
-    if labels is None:
-        labels = []
-        for h, w in shapes:
-            u = torch.rand((N, 9, h, w), device=dev, generator=gen)
-            lab = torch.zeros((N, 9, h, w), dtype=torch.int32, device=dev)
-            lab[u < 0.05] = -1
-            fg = (u >= 0.05) & (u < 0.07)
-            lab[fg] = torch.randint(1, 81, (int(fg.sum()),), device=dev, generator=gen,
-                                    dtype=torch.int32)
-            labels.append(lab)
-    # box-regression targets for every foreground anchor (SelectSmoothL1Loss inputs)
-    bbox_targets, n_fg = [], 0
-    for lab in labels:
-        idx = torch.nonzero(lab > 0)
-        Lc = torch.stack([idx[:, 0], 4 * idx[:, 1], idx[:, 2], idx[:, 3]], dim=1).float().contiguous()
-        Y = (torch.randn((Lc.shape[0], 4), device=dev, generator=gen) * 0.5).contiguous()
-        bbox_targets.append((Y, Lc))
-        n_fg += Lc.shape[0]
-    fg_num = torch.tensor([float(max(n_fg, 1))], device=dev)
-
-    losses_txt = ("PowSum + SigmoidAdaptiveDistillLoss + SigmoidFocalLoss + SelectSmoothL1Loss"
-                  if distill else "SigmoidFocalLoss + SelectSmoothL1Loss")
-    if args.workload == "heads":
-        s_fpn = [torch.randn((N, 256, h, w), device=dev, generator=gen) for h, w in shapes]
-        t_fpn = [torch.randn((N, 256, h, w), device=dev, generator=gen) for h, w in shapes] if distill else s_fpn
-
-        def step():
-            heads.step(s_fpn, t_fpn, labels, bbox_targets=bbox_targets, fg_num=fg_num)
-        wl = ("heads-only: RetinaNet cls+bbox subnets (%sstudent fwd+bwd) + %s fwd/bwd + SGD on synthetic "
-              "FPN features; the whole step is one native program of this repo's HIP kernels" % (
-                  "teacher fwd, " if distill else "", losses_txt))
-    else:
-        if native:
-            from ssad_amd.backbone_pipeline import NativeDistillModel
-            model = NativeDistillModel(heads, student_arch=args.student,
-                                       teacher_arch=args.teacher if distill else None, N=N, image_hw=image_hw,
-                                       device=dev, process_group=pg, world_size=world)
-        else:
-            from tools.harness.full_model import FullDistillModel
-            model = FullDistillModel(heads, student_depth=args.student,
-                                     teacher_depth=args.teacher if distill else None, device=dev,
-                                     backbone_f16=f16, process_group=pg, world_size=world)
-        images = torch.randn((N, 3) + image_hw, device=dev, generator=gen)
-
-        def step():
-            model.step(images, labels, bbox_targets, fg_num)
-
-        def pretty(a):
-            return a.upper().replace("R", "R-", 1) if a[0] == "r" else a.upper().replace("X", "X-", 1)
-        wl = ("%s-FPN student%s, %d px (3x%dx%d): " % (
-              pretty(args.student), (" + %s-FPN teacher adaptive distillation" % pretty(args.teacher))
-              if distill else " only (plain RetinaNet training, BASELINE config 2)",
-              args.px, image_hw[0], image_hw[1]) + model.describe() +
-              "; subnets, %s and subnet SGD = one native program of this repo's HIP kernels" % losses_txt)
-
+    W = make_workload(args, dev, world, pg, rank)
+    step, heads, model, wl = W["step"], W["heads"], W["model"], W["wl"]
+    N, shapes, image_hw, f16, distill, native, hkw = (W[k] for k in ("N", "shapes", "image_hw", "f16", "distill",
+                                                                     "native", "hkw"))
+    labels, bbox_targets, fg_num, gen, cfg = W["labels"], W["bbox_targets"], W["fg_num"], W["gen"], W["cfg"]
     # The step's critical path is the stream step() is called on (student forward, subnets, data gradients); the
     # teacher, the filter gradients and the collectives run on other streams and fill the chip beside it.
     # The step therefore runs on a high-priority stream (HIP has two levels: 0 and -1): config 3 94.3 -> 93.3 ms,
@@ -444,6 +559,30 @@ def main():
             cb["scope_note"] = ("value and gpu_same_scope_images_per_s both cover subnets + losses (no backbone); "
                                 "the headline `value` covers the whole step")
             out["cpu_baseline"] = cb
+        # BASELINE's other single-GPU workloads, each a short run of its own AFTER the headline's timed region
+        # (the headline `value` above is untouched by them): config 5 = R-101 student + ResNeXt-101-64x4d
+        # teacher, 500 px, every convolution fp16 storage / fp32 accumulation; config 2 = R-50 student only,
+        # bs 2, 600 px.  Only from the default headline run on one GPU.
+        default_cfg3 = (args.workload == "full" and native and not f16 and distill and args.student == "r50" and
+                        args.teacher == "r101" and args.px == 600 and N == 16)
+        if world == 1 and pg is None and default_cfg3 and not args.no_also:
+            del step, heads, model, W
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            also = {}
+            for key, kl, kw in (("cfg5_f16", 34, dict(student="r101", teacher="x101-64x4d", px=500, precision="f16",
+                                                      batch_per_gpu=16)),
+                                ("cfg2", 2, dict(student="r50", teacher="none", px=600, precision="f32",
+                                                 batch_per_gpu=2))):
+                try:
+                    also[key] = also_leg(dev, kl, **kw)
+                except Exception as e:      # never lose the headline line to a side leg
+                    also[key] = {"error": repr(e)}
+            out["also"] = also
+            out["also_note"] = ("other BASELINE configs on the same GPU, each built from scratch and run for a few "
+                                "steps AFTER the timed region of the headline; `value` / `ms_per_step` above are "
+                                "config 3 only")
         # the ONE result line, last on rank 0's stdout (with NCCL_DEBUG=VERSION in the environment
         # RCCL prints its version banner to stdout when the communicator is created, i.e. earlier)
         sys.stdout.flush()

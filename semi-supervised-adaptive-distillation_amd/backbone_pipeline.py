@@ -176,6 +176,10 @@ class NativeResNetFPN(object):
         dev = self.device
         L = self._layers
         scales = dict(affine_scales or {})
+        # weights from outside (a checkpoint, utils/net.py): every trainable folded filter gets a scale slot, so
+        # that load_from() can install other AffineChannel scales later without rebuilding the program.  The
+        # random initialisation keeps slots only where its scale is not 1 (bench.py's path, unchanged).
+        all_slots = src is not None or affine_scales is not None
         if src is None:
             sd, init_scales = self._default_init()
             for k, v in init_scales.items():
@@ -183,6 +187,9 @@ class NativeResNetFPN(object):
         else:
             sd = src if isinstance(src, dict) else src.state_dict()
             sd = {k: v.detach() for k, v in sd.items()}
+        # the folded scales as given (utils/net.py writes them back as <conv>_bn_s when saving)
+        self.affine_scale_values = {k: torch.as_tensor(v, dtype=torch.float32).reshape(-1).cpu().clone()
+                                    for k, v in scales.items() if k in L and L[k].affine}
         groups = self._bucket_order() if self.train else OrderedDict()
         order = [L[n] for g in groups.values() for n in g]
         assert all(l.train for l in order) and (not self.train or len(order) == sum(l.train for l in L.values()))
@@ -217,6 +224,8 @@ class NativeResNetFPN(object):
                 l.w = self.params_flat[off:off + nw].view(l.cout, l.cin, l.k, l.k)
                 l.gw = self.grads_flat[off:off + nw].view(l.cout, l.cin, l.k, l.k)
                 sc = scales.get(n)
+                if sc is None and all_slots and l.affine:
+                    sc = 1.0
                 if sc is not None and l.affine:
                     sc = torch.as_tensor(sc, dtype=torch.float32).reshape(-1).to(dev)
                     l.s2 = (sc * sc).expand(l.cout).contiguous() if sc.numel() == 1 else (sc * sc).contiguous()
@@ -232,13 +241,35 @@ class NativeResNetFPN(object):
             l.w.copy_(sd[l.name + ".weight"].to(device=dev, dtype=torch.float32))
             l.b.copy_(sd[l.name + ".bias"].to(device=dev, dtype=torch.float32))
 
-    def load_from(self, src):
+    def load_from(self, src, affine_scales=None):
         """Copy parameters from a {name.weight / name.bias: tensor} dict or a module with such a
-        state_dict() (filters with the AffineChannel scale folded in)."""
+        state_dict() (filters with the AffineChannel scale folded in).  affine_scales: {layer: s} of
+        the folded scales when they differ from the ones the network was built with -- the update of
+        a trainable folded filter multiplies its gradient rows by s^2 (see the module docstring), so
+        the network needs a scale slot for that layer (built with src= / affine_scales=)."""
         sd = src if isinstance(src, dict) else src.state_dict()
         for l in self._layers.values():
             l.w.copy_(sd[l.name + ".weight"].detach().to(device=self.device, dtype=torch.float32))
             l.b.copy_(sd[l.name + ".bias"].detach().to(device=self.device, dtype=torch.float32))
+        if affine_scales is not None:
+            for name, sc in affine_scales.items():
+                l = self._layers.get(name)
+                if l is None or not l.affine:
+                    raise K.KernelError("load_from: %r is not a layer followed by an AffineChannel" % (name,))
+                sc = torch.as_tensor(sc, dtype=torch.float32).reshape(-1)
+                if sc.numel() == 1:
+                    sc = sc.expand(l.cout)
+                if sc.numel() != l.cout:
+                    raise K.KernelError("load_from: %d scales for the %d channels of %s" % (sc.numel(), l.cout, name))
+                self.affine_scale_values[name] = sc.cpu().clone()
+                if not l.train:
+                    continue
+                if l.s2 is None:
+                    if bool((sc == 1).all()):
+                        continue
+                    raise K.KernelError("load_from: %s has no scale slot (the network was built from the random "
+                                        "initialisation); build it with src= / affine_scales=" % name)
+                l.s2.copy_((sc * sc).to(self.device))
         self._packed_frozen = False
 
     # -- small emit helpers -------------------------------------------------------------------

@@ -64,6 +64,7 @@ struct LaunchArgs {
   int n_levels;
   float gamma, alpha, beta, scale;
   int ignored;
+  int fences;          // ticket memory ordering (arrive_last)
 };
 
 // ---- math helpers ---------------------------------------------------------
@@ -185,9 +186,6 @@ __device__ __forceinline__ double block_sum(double v) {
 // (groups of kTicketGroup workgroups, then one counter per level) so that no single address sees
 // thousands of same-address atomics.  Counters live in the caller's workspace, must be ZERO before
 // the first launch (the workspace contract in ssad_kernels.h) and are left zero by every launch.
-#ifndef SSAD_TICKET_FENCES
-#define SSAD_TICKET_FENCES 1     // 0: round 3's relaxed atomics + s_waitcnt (A/B builds only)
-#endif
 constexpr int kTicketGroup = 32;
 constexpr int kTicketStride = 16;                         // ints: one 64-byte line per group counter
 constexpr int kTicketGroups = kMaxBlocks / kTicketGroup + SSAD_MAX_LEVELS;
@@ -214,37 +212,41 @@ __device__ __forceinline__ double peek(const double* slot) {
 // Thread 0 only, after its publish() calls.  lb = workgroup index within the level, nb = the
 // level's workgroup count, g0 = index of the level's first group counter.  True for exactly one
 // workgroup of the level: the last to arrive.
-__device__ __forceinline__ bool arrive_last(const Tickets& t, int level, int lb, int nb, int g0) {
-#if SSAD_TICKET_FENCES
-  // release: the partials published above are visible at agent scope before the arrival is; the
-  // workgroup that sees the last arrival acquires every earlier arrival's release (the chain of
-  // read-modify-writes on one counter is a release sequence)
-  constexpr int kArrive = __ATOMIC_ACQ_REL;
-#else
-  // gfx9: stores are counted in vmcnt, and the partials are agent-scope write-through atomic stores
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the published partials have left
-  constexpr int kArrive = __ATOMIC_RELAXED;
-#endif
+// Memory ordering, `fences`:
+//   0  relaxed agent-scope atomics + s_waitcnt vmcnt(0): the partials are agent-scope atomic (write-through) stores
+//      and gfx9 counts stores in vmcnt, so they have left the CU before the arrival is visible; the reducer reads
+//      them with agent-scope atomic loads behind a control dependence + barrier.  Correct on gfx950 by the ISA's
+//      counter semantics, not by the C++ memory model.
+//   1  the arrival is a RELEASE read-modify-write (the chain of RMWs on one counter is a release sequence) and the
+//      reducing workgroup issues an ACQUIRE fence before its peeks: what the memory model asks for.
+//   2  every arrival ACQ_REL.
+// Measured on MI355X, config 3's fused classification-loss launch (2.2 G logits, 2048 workgroups): mode 0 = 0.308 ms,
+// mode 1 = 0.798 ms, mode 2 = 0.828 ms (PowSum 0.105 / 0.195 / 0.203): the agent-scope RELEASE alone -- an L2
+// write-back (buffer_wbl2) per arrival under the other workgroups' streaming traffic -- costs 2.6x, so the default
+// stays 0 (ticket_fences()); modes 1 / 2 are kept selectable (SSAD_TICKET_FENCES) and tested for equal bits.
+__device__ __forceinline__ unsigned ticket_add(unsigned* p, int fences) {
+  if (fences == 2) return __hip_atomic_fetch_add(p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (fences == 1) return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool arrive_last(const Tickets& t, int level, int lb, int nb, int g0, int fences) {
+  if (fences == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the published partials have left
   const int g = lb / kTicketGroup;
   const int gsize = (nb - g * kTicketGroup) < kTicketGroup ? (nb - g * kTicketGroup) : kTicketGroup;
   unsigned* gc = t.group + (size_t)(g0 + g) * kTicketStride;
-  if (__hip_atomic_fetch_add(gc, 1u, kArrive, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)gsize - 1u)
-    return false;
+  if (ticket_add(gc, fences) != (unsigned)gsize - 1u) return false;
   __hip_atomic_store(gc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int ngroups = (nb + kTicketGroup - 1) / kTicketGroup;
-  if (__hip_atomic_fetch_add(t.level + level, 1u, kArrive, __HIP_MEMORY_SCOPE_AGENT) !=
-      (unsigned)ngroups - 1u)
-    return false;
+  if (ticket_add(t.level + level, fences) != (unsigned)ngroups - 1u) return false;
   __hip_atomic_store(t.level + level, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return true;
 }
 
 // Every thread of the reducing workgroup, after the __syncthreads() that broadcast arrive_last():
 // the peeks below must not be satisfied by anything fetched before the last arrival was seen.
-__device__ __forceinline__ void reducer_acquire() {
-#if SSAD_TICKET_FENCES
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
+__device__ __forceinline__ void reducer_acquire(int fences) {
+  if (fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 __device__ __forceinline__ int find_level(const LaunchArgs& a, int bid) {
@@ -683,11 +685,11 @@ __global__ __launch_bounds__(kThreads) void cls_losses_fused_kernel(
     publish(partials + blockIdx.x, ta);
     publish(partials + focal_offset + blockIdx.x, tb);
     s_last = arrive_last(tickets_at(partials + 2 * (size_t)focal_offset), level, lb, L.blocks,
-                         L.group_start) ? 1 : 0;
+                         L.group_start, args.fences) ? 1 : 0;
   }
   __syncthreads();
   if (!s_last) return;
-  reducer_acquire();
+  reducer_acquire(args.fences);
   // this level's last workgroup: fixed-order sum of the level's partials, then the float
   // multiply by scale (math::Scale on one element, .cu:137-138)
   double va = 0.0, vb = 0.0;
@@ -793,6 +795,7 @@ struct PowArgs {
   int blocks[SSAD_MAX_POWSUM_INPUTS];
   int n_inputs;
   float power;
+  int fences;
 };
 
 // x^p.  Positive normal x (teacher probabilities) take the exp2/log2 path;
@@ -842,11 +845,11 @@ __global__ __launch_bounds__(kThreads) void pow_sum_kernel(
   __shared__ int s_last;
   if (threadIdx.x == 0) {
     publish(partials + blockIdx.x, t);
-    s_last = arrive_last(tickets_at(partials + kMaxBlocks), 0, blockIdx.x, gridDim.x, 0) ? 1 : 0;
+    s_last = arrive_last(tickets_at(partials + kMaxBlocks), 0, blockIdx.x, gridDim.x, 0, args.fences) ? 1 : 0;
   }
   __syncthreads();
   if (!s_last) return;
-  reducer_acquire();
+  reducer_acquire(args.fences);
   // last workgroup to arrive: the partials in index order (deterministic), one launch
   double v = 0.0;
   for (int i = threadIdx.x; i < (int)gridDim.x; i += kThreads) v += peek(partials + i);
@@ -857,6 +860,15 @@ __global__ __launch_bounds__(kThreads) void pow_sum_kernel(
 // ---- host side ---------------------------------------------------------------
 
 int gamma_mode(float g) { return g == 2.0f ? 2 : (g == 1.0f ? 1 : 0); }
+
+// SSAD_TICKET_FENCES: memory ordering of the in-launch finalize (see arrive_last).  Default 0: same-call A/B on
+// MI355X (tools/dbg/r4_fence_ab.sh, bench.py --workload heads, two rounds): fused classification losses
+// 0.308 / 0.798 / 0.828 ms for modes 0 / 1 / 2, PowSum 0.105 / 0.195 / 0.203 ms -- already the release half
+// (buffer_wbl2 at every one of 2048 arrivals) costs 2.6x on an HBM-bound streaming kernel.
+int ticket_fences() {
+  static const int v = [] { const char* e = getenv("SSAD_TICKET_FENCES"); return e ? atoi(e) : 0; }();
+  return v < 0 ? 0 : (v > 2 ? 2 : v);
+}
 
 bool accurate_math() {
   static const bool v = [] {
@@ -875,6 +887,7 @@ int build_args(const ssad_distill_level* lv, int n_levels,
   a.n_levels = n_levels;
   a.gamma = P->gamma; a.alpha = P->alpha; a.beta = P->beta; a.scale = P->scale;
   a.ignored = P->ignored_label;
+  a.fences = ticket_fences();
   long long total_items = 0;
   for (int l = 0; l < n_levels; ++l) {
     const ssad_distill_level& s = lv[l];
@@ -1217,6 +1230,7 @@ static int pow_sum_impl(
     const int cnt = (n_inputs - g0 < SSAD_MAX_POWSUM_INPUTS) ? n_inputs - g0 : SSAD_MAX_POWSUM_INPUTS;
     a.n_inputs = cnt;
     a.power = power;
+    a.fences = ticket_fences();
     long long total = 0;
     for (int j = 0; j < cnt; ++j) {
       if (sizes_host[g0 + j] < 0) return SSAD_E_BADARG;

@@ -72,7 +72,9 @@ def test_native_backbone_forward_backward_vs_torch():
             g = (g.view(-1, row_len) * s2.view(-1, 1)).reshape(-1)
             scaled += 1
         want[off:off + n] = p0[off:off + n] - 0.01 * (2.0 * g if is_bias else g + 1e-4 * p0[off:off + n])
-    assert scaled == sum(1 for l in nat._layers.values() if l.train and l.name.endswith(".c3"))
+    # a network built from given weights has a scale slot for every trainable folded filter (ones where
+    # the source gave no scale), so that a checkpoint's AffineChannel scales can be installed later
+    assert scaled == sum(1 for l in nat._layers.values() if l.train and l.affine)
     assert float(nat._layers["res3.0.c3"].s2[0]) == pytest.approx(0.0625)
     assert torch.allclose(nat.params_flat, want, rtol=1e-5, atol=1e-8)
 

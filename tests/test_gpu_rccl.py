@@ -128,6 +128,51 @@ def _worker(rank, world, port, outdir):
     torch.cuda.synchronize()
     bp = gather(bb.params_flat)
     res["bb_params_equal"] = all(torch.equal(bp[0], t) for t in bp)
+    # the object bench.py measures -- NativeDistillModel: both backbones, subnets, losses, both updates -- under
+    # bench.py's schedule (step on a high-priority stream, teacher on a side stream running ahead, filter gradients
+    # on the auxiliary streams) WITH the collectives in flight: three iterations enqueued back to back.  One rank:
+    # same bits as the model that issues no collective at all (an all-reduce over one rank is the identity, so any
+    # difference is an ordering bug between RCCL's stream and the step's).  More ranks: rank-local images,
+    # identical parameters everywhere afterwards.
+    from ssad_amd.backbone_pipeline import NativeDistillModel
+    mhw, mshapes, mN = (128, 256), [(16, 32), (8, 16), (4, 8), (2, 4), (1, 2)], 2
+    mrng = np.random.default_rng(900 + rank)
+    mlabs = [torch.from_numpy(synth.distill_inputs(mrng, mN, 9, 80, h, w)[2]).to(dev) for h, w in mshapes]
+    mtg = [synth.bbox_targets(mrng, l.cpu().numpy()) for l in mlabs]
+    mfg = torch.tensor([float(max(1, sum(t[0].shape[0] for t in mtg)))], device=dev)
+    mtg = [(torch.from_numpy(y).to(dev), torch.from_numpy(l).to(dev)) for y, l in mtg]
+    mimg = torch.randn((mN, 3) + mhw, device=dev, generator=torch.Generator(device=dev).manual_seed(300 + rank))
+    S0, T0 = synth.head_params(np.random.default_rng(1)), synth.head_params(np.random.default_rng(2))
+
+    def run_model(pg_):
+        hd = DistillHeads(cfg, N=mN, shapes=mshapes, device=dev, student_init=S0, teacher_init=T0, lr=1e-3,
+                          process_group=pg_, world_size=world)
+        hd.broadcast_params()
+        m = NativeDistillModel(hd, "r50", "r50", mN, mhw, dev, process_group=pg_, world_size=world, lr=1e-3)
+        assert m.side is not None and m._teacher_ahead
+        main = torch.cuda.Stream(priority=-1)
+        main.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(main):
+            for _ in range(3):
+                m.step(mimg, mlabs, mtg, mfg)
+        torch.cuda.synchronize()
+        return m
+    dpm = run_model(dist.group.WORLD)
+    assert dpm.student.dp.active and dpm.heads.dp.active
+    res["model_finite"] = bool(torch.isfinite(dpm.student.params_flat).all() and
+                               torch.isfinite(dpm.heads.params.flat).all() and torch.isfinite(dpm.heads.losses).all())
+    mp_b, mp_h = gather(dpm.student.params_flat), gather(dpm.heads.params.flat)
+    res["model_params_equal"] = all(torch.equal(mp_b[0], t) for t in mp_b) and all(torch.equal(mp_h[0], t) for t in mp_h)
+    if world == 1:
+        solo_m = run_model(None)
+        assert not solo_m.student.dp.active
+        res["model_matches_no_collective_run"] = bool(
+            torch.equal(solo_m.student.params_flat, dpm.student.params_flat) and
+            torch.equal(solo_m.student.moms_flat, dpm.student.moms_flat) and
+            torch.equal(solo_m.heads.params.flat, dpm.heads.params.flat) and
+            torch.equal(solo_m.heads.losses, dpm.heads.losses))
+    else:
+        res["model_matches_no_collective_run"] = True
     if rank == 0:
         np.savez(os.path.join(outdir, "res.npz"), **{k: np.asarray(v) for k, v in res.items()})
     dist.barrier()
@@ -148,6 +193,7 @@ def test_rccl_allreduce_buckets_and_update(world):
     assert float(r["sum_err"]) <= 1e-6 * float(r["sum_scale"])
     assert bool(r["bb_reduced_equal"]) and bool(r["bb_params_equal"])
     assert float(r["bb_sum_err"]) <= 1e-6 * float(r["bb_sum_scale"])
+    assert bool(r["model_finite"]) and bool(r["model_params_equal"]) and bool(r["model_matches_no_collective_run"])
 
 
 def test_bench_refuses_more_ranks_than_gpus():

@@ -141,3 +141,107 @@ def test_update_lr_rescales_update_history_and_checkpoint_round_trip(tmp_path):
     assert torch.equal(other.teacher.flat, heads.teacher.flat)
     assert torch.equal(other.params.flat, heads.params.flat)
     assert torch.equal(other.moms.flat, heads.moms.flat)
+
+
+# ---------------------------------------------------------------------------
+# backbones: the reference's blob layout <-> NativeResNetFPN's folded layout
+# ---------------------------------------------------------------------------
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GRAPHS = {"r50": "backbone_graph_r50_fpn.json", "x101-64x4d": "backbone_graph_x101_64x4d_fpn.json"}
+
+
+def reference_backbone_blobs(arch, rng, prefix="", momentum=True):
+    """A synthetic weights-file body for `arch` in the REFERENCE's layout: every parameter blob the
+    imported reference builder creates (names and shapes from tests/golden/backbone_graph_*.json,
+    captured by tests/golden/make_backbone_graph.py), random values; AffineChannel scales of both
+    signs away from zero; `_momentum` for what the reference trains (filters of res3.., FPN)."""
+    import json
+    g = json.load(open(os.path.join(GOLDEN, GRAPHS[arch])))
+    blobs = OrderedDict()
+    for prm in g["params"]:
+        name, shape = prm["name"], tuple(prm["shape"])
+        if name.endswith("_bn_s"):
+            v = rng.uniform(0.5, 1.5, shape) * rng.choice([-1.0, 1.0], shape, p=[0.1, 0.9])
+        elif name.endswith("_bn_b") or name.endswith("_b"):
+            v = rng.standard_normal(shape) * 0.05
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            v = rng.standard_normal(shape) * np.sqrt(2.0 / fan_in) * (0.25 if "branch2c" in name else 1.0)
+        blobs[prefix + name] = v.astype(np.float32)
+        trainable = name.startswith("fpn_") or (name.endswith("_w") and name[:4] in ("res3", "res4", "res5"))
+        if momentum and trainable:
+            blobs[prefix + name + "_momentum"] = (rng.standard_normal(shape) * 1e-3).astype(np.float32)
+    return blobs, g
+
+
+@pytest.mark.parametrize("arch", ["r50", "x101-64x4d"])
+def test_backbone_blob_names_and_shapes_are_the_reference_builders(arch):
+    """utils/net.backbone_blob_names against the parameter list of the imported reference builder
+    (ResNet.py:85-130,221-283 + FPN.py:116-250 run under a recording model): same blobs, and the
+    native network's filter shapes are the blobs' shapes."""
+    import json
+    from ssad_amd.backbone_pipeline import NativeResNetFPN
+    g = json.load(open(os.path.join(GOLDEN, GRAPHS[arch])))
+    shapes = {p["name"]: tuple(p["shape"]) for p in g["params"]}
+    names = net.backbone_blob_names(arch)
+    mine = [n for t in names.values() for n in t if n is not None]
+    assert len(mine) == len(set(mine)) and set(mine) == set(shapes)
+    nat = NativeResNetFPN.__new__(NativeResNetFPN)
+    nat.arch, nat.train, nat.D = arch, arch != "x101-64x4d", 256
+    nat._layers = OrderedDict()
+    nat._define_layers()
+    assert set(nat._layers) == set(names) and len(names) == len(nat._layers)
+    for lname, (wn, sn, bn) in names.items():
+        l = nat._layers[lname]
+        assert shapes[wn] == (l.cout, l.wcin, l.k, l.k), (lname, wn)
+        assert shapes[bn] == (l.cout,) and (sn is None or shapes[sn] == (l.cout,))
+        assert (sn is not None) == l.affine
+    # R-101 has no capture of its own: same rule, 23 blocks in res4
+    r101 = net.backbone_blob_names("r101")
+    assert r101["lat.1"][0] == "fpn_inner_res4_22_sum_lateral_w" and r101["out.1"][2] == "fpn_res4_22_sum_b"
+    assert "res4.22.c3" in r101 and "res4.23.c1" not in r101 and r101["res4.0.proj"][0] == "res4_0_branch1_w"
+
+
+def test_backbone_fold_and_unfold_round_trip_cpu():
+    """Reference layout -> folded native parameters (W' = s W, m' = s m) -> reference layout: every
+    blob comes back (filters and update history to fp32 rounding of the fold / un-fold, the
+    AffineChannel blobs exactly), only the reference's trainable blobs carry `_momentum`, and the
+    trainable folded filters' SGD row scales are s^2."""
+    from ssad_amd.backbone_pipeline import NativeResNetFPN
+    rng = np.random.default_rng(3)
+    blobs, _ = reference_backbone_blobs("r50", rng)
+    state, scales, moms, missing = net.backbone_from_blobs(blobs, "r50")
+    assert not missing and len(scales) == 53                      # one AffineChannel per body convolution
+    w, sc = blobs["res4_1_branch2b_w"], blobs["res4_1_branch2b_bn_s"]
+    assert np.array_equal(state["res4.1.c2.weight"].numpy(), w * sc.reshape(-1, 1, 1, 1))
+    assert np.array_equal(state["res4.1.c2.bias"].numpy(), blobs["res4_1_branch2b_bn_b"])
+    assert np.array_equal(moms["res4.1.c2.weight"].numpy(),
+                          blobs["res4_1_branch2b_w_momentum"] * sc.reshape(-1, 1, 1, 1))
+    assert np.array_equal(state["lat.0.weight"].numpy(), blobs["fpn_inner_res5_2_sum_w"])   # no fold for the FPN
+    with pytest.raises(KeyError):
+        bad = dict(blobs)
+        del bad["res2_0_branch1_bn_s"]
+        net.backbone_from_blobs(bad, "r50")
+    nat = NativeResNetFPN("r50", 1, (128, 128), "cpu", train=True, src=state, affine_scales=scales)
+    net.load_backbone(nat, blobs)
+    l = nat._layers["res4.1.c2"]
+    assert l.s2 is not None and np.allclose(l.s2.numpy(), sc * sc, rtol=1e-6)
+    assert nat._layers["res2.0.c1"].s2 is None                       # frozen: no update, no slot
+    out = net.backbone_to_blobs(nat)
+    assert set(out) == set(blobs)
+    for k, v in blobs.items():
+        if k.endswith("_bn_s") or k.endswith("_bn_b") or k.endswith("_b") or k.startswith("fpn_"):
+            assert np.array_equal(out[k], v), k
+        else:
+            assert np.allclose(out[k], v, rtol=3e-7, atol=1e-12), k
+    # another set of scales into the same network (a second checkpoint): slots exist for every trainable layer
+    blobs2, _ = reference_backbone_blobs("r50", np.random.default_rng(4))
+    net.load_backbone(nat, blobs2)
+    assert np.allclose(l.s2.numpy(), blobs2["res4_1_branch2b_bn_s"] ** 2, rtol=1e-6)
+    assert np.array_equal(net.backbone_to_blobs(nat)["res3_0_branch1_bn_s"], blobs2["res3_0_branch1_bn_s"])
+    # a network built from the random initialisation has slots only where its own scale is not 1
+    rnd = NativeResNetFPN("r50", 1, (128, 128), "cpu", train=True)
+    from ssad_amd.kernels import KernelError
+    with pytest.raises(KernelError):
+        net.load_backbone(rnd, blobs)

@@ -1,0 +1,75 @@
+"""Which tensors differ between the overlapped and the serial config-3 step at full size, after 1..3
+iterations, for each overlap feature switched on alone (round 4: tests/test_gpu_full_size.py found
+bbox_losses differing in the last bits)."""
+import os
+import sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ssad_amd  # noqa
+from ssad_amd import synth
+import test_gpu_full_size as T
+
+N, hw, shapes = 16, (640, 896), synth.LEVEL_SHAPES_600
+batch = T._inputs(N, shapes, hw, seed=1234)
+
+
+def build(two_streams, overlap_wgrad, ahead):
+    from ssad_amd.head_pipeline import DistillHeads
+    from ssad_amd.backbone_pipeline import NativeDistillModel
+    from ssad_amd.modeling.retinanet_heads import HeadConfig
+    cfg = HeadConfig(num_gpus=1)
+    kw = dict(N=N, shapes=shapes, device="cuda", student_init=synth.head_params(np.random.default_rng(1)),
+              teacher_init=synth.head_params(np.random.default_rng(2)), lr=1e-4, overlap_wgrad=overlap_wgrad)
+    heads = DistillHeads(cfg, **kw)
+    m = NativeDistillModel(heads, "r50", "r101", N, hw, "cuda", two_streams=two_streams, overlap_wgrad=overlap_wgrad)
+    m._teacher_ahead = ahead
+    return m
+
+
+def diff(a, b, tag):
+    bad = []
+    for name in ("losses", "focal_losses", "bbox_losses"):
+        x, y = getattr(a.heads, name), getattr(b.heads, name)
+        if not torch.equal(x, y):
+            bad.append((name, float((x - y).abs().max())))
+    for name, shape, _, _ in a.heads.params.specs:
+        for what, fa, fb in (("param", a.heads.params, b.heads.params), ("update", a.heads.grads, b.heads.grads)):
+            x, y = fa[name], fb[name]
+            if not torch.equal(x, y):
+                bad.append(("%s %s" % (what, name), float((x - y).abs().max()), int((x != y).sum()), x.numel()))
+    for lname, la in a.student._layers.items():
+        lb = b.student._layers[lname]
+        if la.train and not torch.equal(la.w, lb.w):
+            bad.append(("backbone " + lname, float((la.w - lb.w).abs().max()), int((la.w != lb.w).sum()), la.w.numel()))
+    for l in range(5):
+        if not torch.equal(a.student.d_fpn[l], b.student.d_fpn[l]):
+            bad.append(("d_fpn %d" % l, float((a.student.d_fpn[l] - b.student.d_fpn[l]).abs().max())))
+        if not torch.equal(a.teacher.fpn[l], b.teacher.fpn[l]):
+            bad.append(("teacher fpn %d" % l,))
+        if not torch.equal(a.student.fpn[l], b.student.fpn[l]):
+            bad.append(("student fpn %d" % l,))
+    print(tag, "->", "SAME" if not bad else bad[:12], flush=True)
+
+
+ref = {}
+for steps in (1, 2, 3):
+    b = build(False, False, False)
+    T._run(b, batch, steps, high_priority=False)
+    ref[steps] = b
+configs = [("all on, high prio", True, True, True, True), ("all on, normal prio", True, True, True, False),
+           ("two_streams only", True, False, False, False), ("wgrad overlap only", False, True, False, False),
+           ("two_streams + ahead", True, False, True, False)]
+for tag, ts, ow, ah, hp in configs:
+    for steps in (1, 2, 3):
+        a = build(ts, ow, ah)
+        T._run(a, batch, steps, high_priority=hp)
+        diff(a, ref[steps], "%s, %d step(s)" % (tag, steps))
+        del a
+        torch.cuda.empty_cache()
+# serial twice: is the serial program itself reproducible at this size?
+b2 = build(False, False, False)
+T._run(b2, batch, 3, high_priority=False)
+diff(b2, ref[3], "serial vs serial, 3 steps")
