@@ -659,8 +659,29 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   // R(j) = operand of step j requested at step j - 8, Dj = one wave-load of the raw-patch DMA, issued at the end
   // of step j (burst variant: all seven behind R(8)).  Step j needs R(j): 7 ring loads are younger, plus the
   // D issued since R(j) was: j of them for j < 8, 15 - j after (burst: 7 for j = 1..8).
-  auto a_load = [&](f32x4& dst, const ssad_dev::rsrc_words& rs, int soff) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(a_voff), "s"(rs), "s"(soff));
+  //
+  // IN-FLIGHT RING REGISTERS AND THE COMPILER (round 4).  An a_load's destination is "defined" for hipcc the moment
+  // the statement is issued, long before the data lands; any copy the register allocator makes of it before the
+  // counted wait (`"+v"` on the ring slot) copies a register the load has not written yet.  Inside the chunk loop the
+  // slots stay in their registers (checked on the built library by tests/test_isa_lint.py).  Across the TILE loop
+  // they did not: rounds 1-3 prefetched the next tile's first 8 operands during the last chunk and re-primed the
+  // ring of a wave that had sat a tile out in an `if` at the tile's end; the merge of the two definitions made
+  // hipcc copy all 32 ring registers aside before the epilogue and back after it, and a prefetch that landed in
+  // between (late: HBM contention from another stream) was overwritten by the stale copy -- one wave's 16 channels
+  // of one tile wrong, seen only at full size with two streams (tests/test_gpu_full_size.py; 89 of 400 launches of
+  // res2's 64 -> 64 layer under load in tools/dbg/r4_wino_stress.py, where NG = 1 halves the time a load has).
+  // Now nothing real is in flight when control leaves the chunk loop: the last chunk's steps 8..15 issue their ring
+  // loads with every lane out of range (zeros, no memory traffic: the queue keeps the shape the counted waits
+  // assume), ALL waves load the next tile's first operands in straight-line code before the epilogue, and a
+  // vmcnt(0) tied to the eight slots follows the epilogue (the loads had the epilogue to land).
+  auto a_load_at = [&](f32x4& dst, unsigned voff, const ssad_dev::rsrc_words& rs, int soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff));
+  };
+  auto a_load = [&](f32x4& dst, const ssad_dev::rsrc_words& rs, int soff) { a_load_at(dst, a_voff, rs, soff); };
+  auto ring_landed = [&](f32x4 (&r)[AD]) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                 :: "memory");
   };
   auto load_bias = [&](const WTile& Tt) {
     const WLevel& L = args.lv[Tt.l];
@@ -684,7 +705,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   dma_next(true);
   if (S > 1) dma_next(true);
   if (S > 2) dma_next(true);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ring_landed(ar);
   __syncthreads();
   transform(raw, vbuf);
   __syncthreads();
@@ -725,10 +746,11 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
       const float* xsrc = raw + rbuf * ZRAWP;
       float* xdst = vbuf + ((s + 1) & 1) * VBUF;
       DBG(1, s, 1);
-      // operands 8 steps ahead: past the tile's last chunk they come from the
-      // next tile (nrsrc / nbase are set by side_look at step 6 of chunk `look`,
-      // before the first such load at step 8 even when look is the last chunk)
+      // operands 8 steps ahead: steps 8..15 request those of the NEXT chunk's steps 0..7 -- of this tile only; in
+      // the tile's last chunk the same instructions go out with every lane out of range, and the next tile's first
+      // operands are requested after the chunk loop (nrsrc / nbase: side_look, chunk `look`)
       const bool last = ch == chunks - 1;
+      const unsigned tail_voff = last ? kOOBOff : a_voff;
       if (active) {
         const float* vb = bbase + (s & 1) * VBUF;
         // B operands are single-buffered: right after the two MFMAs of an xr
@@ -781,9 +803,9 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
           }
           // refill the ring slot just consumed with the operand of step + 8
           if (!(WINO_ABLATE & 4)) {
-            const bool tl = last && step + AD >= STEPS;
-            a_load(ar[step & (AD - 1)], tl ? nrsrc : arsrc,
-                   (tl ? nbase - chunks * STEPS * 1024 : abase) + (ch * STEPS + step + AD) * 1024);
+            // past the tile's last operand: the same instruction with every lane out of range (see a_load)
+            a_load_at(ar[step & (AD - 1)], step + AD >= STEPS ? tail_voff : a_voff, arsrc,
+                      abase + (ch * STEPS + step + AD) * 1024);
           }
           if (xf && (step & 3) == 1) xf_load(xsrc, step >> 2, xd);
           if (xf && (step & 3) == 3) xf_store(xdst, step >> 2, xd);
@@ -819,7 +841,10 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
       DBGW(s, 1);
     }
     DBG(1, s - 1, 4);
-    // next tile's bias flies during the epilogue
+    // The next tile's first operands and bias fly during the epilogue -- every wave, active or not, and also after
+    // the last tile (Tn = T then: a harmless re-read), so that the ring has ONE definition at this point (see a_load)
+#pragma unroll
+    for (int k = 0; k < AD; ++k) a_load(ar[k], nrsrc, nbase + k * 1024);
     if (i + 1 < my_n) bv = load_bias(Tn);
     if (active && !(WINO_ABLATE & 16)) {
       const WLevel& L = args.lv[T.l];
@@ -950,11 +975,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
       }
     }
     DBG(1, s - 1, 5);
-    // a wave that sat out this tile's MFMAs re-primes its ring for the next tile
-    if (!active && i + 1 < my_n) {
-#pragma unroll
-      for (int k = 0; k < AD; ++k) a_load(ar[k], nrsrc, nbase + k * 1024);
-    }
+    ring_landed(ar);
     T = Tn;
     arsrc = nrsrc;
     abase = nbase;

@@ -1,0 +1,53 @@
+"""Compiled-code check for a hazard no functional test catches reliably (tools/isa_lint.py).
+
+Kernels that issue loads from inline assembly and wait for them with hand-counted `s_waitcnt`
+(wino_conv_z_kernel's filter-operand ring, the fp16 filter gradient's transpose reads) rely on the
+compiler never touching a destination register between the load and its wait.  Round 4's full-size
+race test found hipcc copying the whole ring aside and back around the epilogue; a prefetch landing in
+between was overwritten by the stale copy -- wrong results only when HBM was contended by another stream.
+The lint reads hipcc's own assembly for the kernel sources and reports any such access; this test
+compiles the two sources (device side only, no GPU needed) and requires a clean report."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "semi-supervised-adaptive-distillation_amd", "csrc")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.mark.parametrize("src,expect", [("conv3x3_winograd.hip", "wino_conv_z_kernel"),
+                                        ("conv3x3_f16.hip", "conv3x3_wgrad_f16_kernel")])
+def test_no_access_to_in_flight_asm_load_destinations(tmp_path, src, expect):
+    import isa_lint
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = str(tmp_path / (src + ".s"))
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + CSRC, "-fvisibility=hidden", "--cuda-device-only", "-S", "-o", out,
+                           os.path.join(CSRC, "kernels", src)], stderr=subprocess.DEVNULL)
+    seen, findings = 0, []
+    for name, lines in isa_lint.kernels(open(out).read()):
+        ring, bad = isa_lint.lint(lines)
+        if ring and expect in name:
+            seen += 1
+        findings += [(name, no, code) for no, code in bad]
+    assert seen >= 2, "the lint found no asm-issued loads in %s: has the kernel changed shape?" % src
+    assert not findings, findings[:10]
+
+
+def test_lint_recognises_the_round3_shadow_copy():
+    """The pattern it exists for, in miniature: an asm load, a compiler copy of its destination, the wait."""
+    import isa_lint
+    text = "\n".join([
+        "_Zk:", "\t;;#ASMSTART", "\tbuffer_load_dwordx4 v[2:5], v150, s[12:15], s44 offen", "\t;;#ASMEND",
+        "\tv_mov_b64_e32 v[34:35], v[2:3]",
+        "\t;;#ASMSTART", "\ts_waitcnt vmcnt(7)", "\t;;#ASMEND",
+        "\tv_mfma_f32_16x16x4_f32 v[82:85], v2, v111, v[82:85]",
+        "\tv_cndmask_b32_e64 v2, 0, 1, s[56:57]", "\tv_cmp_ne_u32_e64 s[6:7], 1, v2",
+        "\t.set _Zk.uses_flat_scratch, 0"])
+    (name, lines), = list(isa_lint.kernels(text))
+    ring, bad = isa_lint.lint(lines)
+    assert ring == {2, 3, 4, 5}
+    assert [code for _, code in bad] == ["v_mov_b64_e32 v[34:35], v[2:3]"]     # the MFMA and the later temp use are fine

@@ -54,22 +54,23 @@ def diff(a, b, tag):
     print(tag, "->", "SAME" if not bad else bad[:12], flush=True)
 
 
-ref = {}
-for steps in (1, 2, 3):
-    b = build(False, False, False)
-    T._run(b, batch, steps, high_priority=False)
-    ref[steps] = b
-configs = [("all on, high prio", True, True, True, True), ("all on, normal prio", True, True, True, False),
-           ("two_streams only", True, False, False, False), ("wgrad overlap only", False, True, False, False),
-           ("two_streams + ahead", True, False, True, False)]
-for tag, ts, ow, ah, hp in configs:
+if __name__ == "__main__":
+    ref = {}
     for steps in (1, 2, 3):
-        a = build(ts, ow, ah)
-        T._run(a, batch, steps, high_priority=hp)
-        diff(a, ref[steps], "%s, %d step(s)" % (tag, steps))
-        del a
-        torch.cuda.empty_cache()
-# serial twice: is the serial program itself reproducible at this size?
-b2 = build(False, False, False)
-T._run(b2, batch, 3, high_priority=False)
-diff(b2, ref[3], "serial vs serial, 3 steps")
+        b = build(False, False, False)
+        T._run(b, batch, steps, high_priority=False)
+        ref[steps] = b
+    configs = [("all on, high prio", True, True, True, True), ("all on, normal prio", True, True, True, False),
+               ("two_streams only", True, False, False, False), ("wgrad overlap only", False, True, False, False),
+               ("two_streams + ahead", True, False, True, False)]
+    for tag, ts, ow, ah, hp in configs:
+        for steps in (1, 2, 3):
+            a = build(ts, ow, ah)
+            T._run(a, batch, steps, high_priority=hp)
+            diff(a, ref[steps], "%s, %d step(s)" % (tag, steps))
+            del a
+            torch.cuda.empty_cache()
+    # serial twice: is the serial program itself reproducible at this size?
+    b2 = build(False, False, False)
+    T._run(b2, batch, 3, high_priority=False)
+    diff(b2, ref[3], "serial vs serial, 3 steps")
