@@ -320,7 +320,7 @@ def test_config5_step_on_native_fp16_kernels_matches_fp32_native_step():
     for name in ("losses", "focal_losses", "bbox_losses"):
         a, b = getattr(h16, name).double().cpu(), getattr(h32, name).double().cpu()
         assert torch.isfinite(a).all()
-        assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max()), (name, a, b)
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()), (name, a, b)
     errs = {}
     for name in S:
         errs[name] = _rel(h16.grads[name], h32.grads[name])
@@ -329,7 +329,7 @@ def test_config5_step_on_native_fp16_kernels_matches_fp32_native_step():
             errs[lname] = _rel(l16.gw, m32.student._layers[lname].gw)
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
     print("config 5 step, fp16 vs fp32 native: worst gradient differences", worst)
-    assert worst[0][1] < 2e-2, worst
+    assert worst[0][1] < 5e-3, worst          # measured 1.6e-3 (fp16 activations and gradients)
     # one real step: both updates applied, everything finite
     p_h, p_b = h16.params.flat.clone(), m16.student.params_flat.clone()
     m16.step(images, labels, targets, fg_num)
@@ -347,3 +347,50 @@ def test_config5_step_on_native_fp16_kernels_matches_fp32_native_step():
     assert torch.equal(mo_h, h16.moms.flat) and torch.equal(mo_b, m16.student.moms_flat)
     assert float(h16.ls_state[0]) == pytest.approx(min(0.5e9, DistillHeadsF16.LOSS_SCALE_MAX))
     assert int(h16.ls_counters[0]) == 0
+
+
+def test_config5_fp16_step_against_the_oracle_composition():
+    """The fp16 step against the SAME reference the fp32 headline object is held to
+    (tests/test_gpu_native_model.py): float64 torch backbones -> oracle/head_step.py (the CPU
+    restatement of the subnets and all four losses) -> autograd through the float64 student.
+    SURVEY section 7's bar for the fp16 route: activations ~1e-2, losses within 1e-3."""
+    from ssad_amd import synth
+    from ssad_amd.head_pipeline import DistillHeadsF16
+    from ssad_amd.backbone_pipeline import NativeDistillModel
+    from ssad_amd.modeling.retinanet_heads import HeadConfig
+    from torch_ref import RefResNetFPN
+    from test_gpu_operators import make_mask_safe
+    import test_gpu_native_model as NM
+    N, hw = NM.N, NM.HW
+    shapes = NM.SHAPES
+    rng = np.random.default_rng(41)
+    images = torch.randn((N, 3) + hw, device=DEV, generator=_gen(41))
+    ref_s = RefResNetFPN("r101", seed=51).calibrate(images, margin=0.05)
+    ref_t = RefResNetFPN("x101-64x4d", seed=52)
+    cfg = HeadConfig(num_gpus=1)
+    with torch.no_grad():
+        fs = [f.float().cpu().numpy() for f in ref_s(images)]
+    S, T = make_mask_safe(cfg, synth.head_params(rng), fs), synth.head_params(rng)
+    labs = [synth.distill_inputs(rng, N, 9, 80, h, w)[2] for h, w in shapes]
+    tg = [synth.bbox_targets(rng, l) for l in labs]
+    fg = np.array([max(1, sum(t[0].shape[0] for t in tg))], np.float32)
+    ref = NM._reference(cfg, images, ref_s, ref_t, S, T, labs, tg, fg)
+    labels, targets, fg_num = NM._inputs(labs, tg, fg)
+    h16 = DistillHeadsF16(cfg, blocked_io=True, N=N, shapes=shapes, device=DEV, student_init=S, teacher_init=T, lr=1e-4)
+    m16 = NativeDistillModel(h16, "r101", "x101-64x4d", N, hw, DEV, student_src=ref_s.state_dict(),
+                             teacher_src=ref_t.state_dict(), student_scales=ref_s.scales)
+    m16.step(images, labels, targets, fg_num, update=False)
+    torch.cuda.synchronize()
+    rel = {}
+    for name, want in (("losses", ref["losses"]), ("focal_losses", ref["focal_losses"]), ("bbox_losses", ref["bbox_losses"])):
+        got = getattr(h16, name).double().cpu().numpy()
+        assert np.isfinite(got).all()
+        rel[name] = float(np.abs(got - want).max() / np.abs(want).max())
+    gerr = {k: _rel(h16.grads[k], torch.from_numpy(np.asarray(g, np.float64)).to(DEV)) for k, g in ref["grads"].items()}
+    for lname, l16 in m16.student._layers.items():
+        if l16.train:
+            gerr[lname] = _rel(l16.gw, ref["backbone_grads"][lname + ".weight"])
+    worst = sorted(gerr.items(), key=lambda kv: -kv[1])[:5]
+    print("config 5 fp16 step vs oracle composition: loss errors", rel, "worst gradients", worst)
+    assert max(rel.values()) <= 1e-3, rel          # measured 8e-6
+    assert worst[0][1] < 5e-3, worst               # measured 1.9e-3
