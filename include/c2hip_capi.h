@@ -108,6 +108,21 @@ C2HIP_CAPI int c2hip_get_gradient_defs(const void* def_bytes, size_t n,
 C2HIP_CAPI int c2hip_set_stream(int device_id, void* hip_stream, int enabled);
 C2HIP_CAPI int c2hip_device_synchronize(int device_id);
 
+/* --- the data-parallel communicator of this process -------------------------
+ * The reference's DP net carries its exchange as operators: model.net.NCCLAllreduce(gradients, gradients)
+ * per parameter (detectron/lib/modeling/optimizer.py:72-92; caffe2/contrib/nccl/cuda_nccl_op_gpu.cc:25-118),
+ * with one process owning every GPU (ncclCommInitAll, cuda_nccl_gpu.cc:141-175).  Here a replica is a
+ * process: rank 0 creates an id (c2hip_comm_unique_id, 128 bytes = ncclUniqueId), the launcher hands it to
+ * every rank, each calls c2hip_comm_init (ncclCommInitRank on RCCL over xGMI, loaded with dlopen), and from
+ * then on the registered `NCCLAllreduce` / `NCCLBroadcast` operators -- one blob per rank, in place allowed --
+ * run over that communicator on the operator's stream.  Without a communicator they are the reference's
+ * single-GPU no-ops.  Errors: c2hip_comm_last_error(). */
+C2HIP_CAPI const char* c2hip_comm_last_error(void);
+C2HIP_CAPI int c2hip_comm_unique_id(void* id_out, size_t nbytes);
+C2HIP_CAPI int c2hip_comm_init(const void* id, size_t nbytes, int world, int rank, int device_id);
+C2HIP_CAPI int c2hip_comm_world(void);          /* 0 = no communicator */
+C2HIP_CAPI int c2hip_comm_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -681,6 +681,18 @@ SSAD_API int ssad_conv1x1_wgrad_f16(const void* x_blocked, const void* dy_blocke
  *   5 relu grad       y = a > 0 ? b : 0                                  relu_op.cu:44-53 */
 SSAD_API int ssad_f16_elementwise(int mode, const void* a, const void* b, void* y, int N, int C, int H, int W,
                                   int stride, int accumulate, ssad_stream_t stream);
+/* Every fp16 filter of a network packed in ONE launch (the step repacks each trained filter after its
+ * update: config 5's R-101 student has 66 pointwise and 45 3x3 layers, i.e. 111 launches of 5-13 us that
+ * ran as a serial chain at the head of every step).  taps = 1: the pointwise layout of
+ * ssad_pw_f16_pack_filter; taps = 9: the 3x3 layout of ssad_f16_pack_filter.  wf / wd may each be NULL. */
+#define SSAD_MAX_F16_PACK_ENTRIES 64   /* per launch; longer tables are chunked */
+typedef struct ssad_f16_pack_entry {
+  const float* w;          /* [M][C] or [M][C][3][3] fp32 */
+  void* wf;                /* forward pack (or NULL) */
+  void* wd;                /* data-gradient pack (or NULL) */
+  int M, C, taps, reserved;
+} ssad_f16_pack_entry;
+SSAD_API int ssad_f16_pack_filters(const ssad_f16_pack_entry* entries_host, int n_entries, ssad_stream_t stream);
 /* The strided pointwise layer's view of its input at any map size (odd maps too: the output is
  * [(Hi - 1) / stride + 1][(Wi - 1) / stride + 1], conv_pool_op_base.h:45-194 with kernel 1, pad 0):
  * y[y][x] = a[stride y][stride x] on blocked fp16. */

@@ -174,7 +174,9 @@ enum ssad_opcode {
    * p3 = workspace, l0 = workspace bytes) */
   SSAD_OP_CONV_KXK_DGRAD = 76,
   /* ssad_transpose_filters(p0 = const ssad_transpose_entry* (host), i0 = n_entries) */
-  SSAD_OP_TRANSPOSE_FILTERS = 77
+  SSAD_OP_TRANSPOSE_FILTERS = 77,
+  /* p0 = const ssad_f16_pack_entry* (host table, kept alive by the caller), i0 = entries */
+  SSAD_OP_F16_PACK_FILTERS = 78
 };
 
 typedef struct ssad_op {

@@ -136,29 +136,37 @@ class NativeResNetFPNF16(NativeResNetFPN):
         self.prep, self.prog = prep, P
         P.mark("pack")
         h16 = dict(dtype=torch.float16, device=dev)
+        # every fp16 filter of a program in ONE launch (ssad_f16_pack_filters): as 111 launches of 5-13 us (R-101
+        # student) they were a serial chain at the head of every step
+        packs = {True: [], False: []}              # trainable (every step) / frozen (once): (w, wf, wd, M, C, taps)
         for l in L.values():
             tgt = P if l.train else prep
-            if l.k == 1:
-                n = lib.ssad_pw_f16_filter_halves(l.cout, l.cin)
+            if l.k == 1 or (l.k == 3 and l.group == 1):
+                n = (lib.ssad_pw_f16_filter_halves if l.k == 1 else lib.ssad_f16_filter_halves)(l.cout, l.cin)
                 l.pf = torch.empty(n, **h16)
                 l.pd = torch.empty(n, **h16) if l.train else None
-                tgt.add(PR.PW_F16_PACK, KL_PACK, i=(l.cout, l.cin), p=(l.w, l.pf, l.pd),
-                        work=4.0 * l.w.numel() + 2.0 * n * (2 if l.train else 1))
-            elif l.k == 3 and l.group > 1:
+                packs[bool(l.train)].append((l.w, l.pf, l.pd, l.cout, l.cin, 1 if l.k == 1 else 9))
+            elif l.k == 3:
                 n = lib.ssad_grouped_conv3x3_f16_filter_halves(l.cout, l.group)
                 l.pf = torch.empty(n, **h16)
                 tgt.add(PR.GROUPED_F16_PACK, KL_PACK, i=(l.cout, l.group), p=(l.w, l.pf),
                         work=4.0 * l.w.numel() + 2.0 * n)
-            elif l.k == 3:
-                n = lib.ssad_f16_filter_halves(l.cout, l.cin)
-                l.pf = torch.empty(n, **h16)
-                l.pd = torch.empty(n, **h16) if l.train else None
-                tgt.add(PR.F16_PACK_FILTER, KL_PACK, i=(l.cout, l.cin), p=(l.w, l.pf, l.pd),
-                        work=4.0 * l.w.numel() + 2.0 * n * (2 if l.train else 1))
             else:                                                    # stem: fp32 [147][64] (Cin = 3)
                 l.wt = self._t(l.cin * l.k * l.k, l.cout)
                 tgt.add(PR.TRANSPOSE_FILTER, 54, i=(l.cout, l.cin * l.k * l.k, l.cout), p=(l.w, l.wt),
                         work=8.0 * l.w.numel())
+        for train, tgt in ((True, P), (False, prep)):
+            ents = packs[train]
+            if not ents:
+                continue
+            tab = (K.F16PackEntry * len(ents))()
+            for i, (w, wf, wd, M, Cc, taps) in enumerate(ents):
+                tab[i] = K.F16PackEntry(w.data_ptr(), wf.data_ptr(), wd.data_ptr() if wd is not None else None,
+                                        M, Cc, taps, 0)
+            tgt.add(PR.F16_PACK_FILTERS, KL_PACK, i=(len(ents),), p=(tab,),
+                    work=sum(4.0 * w.numel() + 2.0 * (wf.numel() + (wd.numel() if wd is not None else 0))
+                             for (w, wf, wd, M, Cc, taps) in ents),
+                    keep=[t for e in ents for t in e[:3] if t is not None])
         prep.build()
         self._packed_frozen = False
         P.mark("forward")

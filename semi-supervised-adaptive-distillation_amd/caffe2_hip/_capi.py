@@ -47,6 +47,9 @@ def load(path=None):
                                           cp, sz]
     L.c2hip_set_stream.argtypes = [i32, vp, i32]
     L.c2hip_device_synchronize.argtypes = [i32]
+    L.c2hip_comm_last_error.restype = C.c_char_p
+    L.c2hip_comm_unique_id.argtypes = [vp, sz]
+    L.c2hip_comm_init.argtypes = [vp, sz, i32, i32, i32]
     _lib = L
     return L
 

@@ -143,3 +143,35 @@ def RunNetOnce(net):
 
 def SetStream(gpu_id, hip_stream, enabled=True):
     _capi.check(_capi.load().c2hip_set_stream(gpu_id, C.c_void_p(hip_stream), int(enabled)))
+
+
+# ---------------------------------------------------------------------------
+# The data-parallel communicator of this process (include/c2hip_capi.h): what makes the registered
+# NCCLAllreduce / NCCLBroadcast operators (optimizer.py:72-92) exchange over RCCL.  One process = one
+# GPU: rank 0 calls CommUniqueId() and ships the 128 bytes to every rank (torch.distributed's store, a
+# file, MPI: the launcher's business); every rank then calls CommInit.
+# ---------------------------------------------------------------------------
+
+def _comm_check(rc):
+    if rc != 0:
+        raise _capi.C2Error(_capi.load().c2hip_comm_last_error().decode("utf-8", "replace"))
+
+
+def CommUniqueId():
+    import ctypes as C
+    buf = C.create_string_buffer(128)
+    _comm_check(_capi.load().c2hip_comm_unique_id(buf, 128))
+    return buf.raw
+
+
+def CommInit(unique_id, world, rank, gpu_id=0):
+    assert len(unique_id) == 128
+    _comm_check(_capi.load().c2hip_comm_init(unique_id, 128, int(world), int(rank), int(gpu_id)))
+
+
+def CommWorld():
+    return int(_capi.load().c2hip_comm_world())
+
+
+def CommDestroy():
+    _comm_check(_capi.load().c2hip_comm_destroy())

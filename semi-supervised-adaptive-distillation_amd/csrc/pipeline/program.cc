@@ -207,6 +207,8 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
       return ssad_grouped_conv3x3_f16_pack_filter((const float*)p[0], i[0], i[1], (void*)p[1], s);
     case SSAD_OP_TRANSPOSE_FILTERS:
       return ssad_transpose_filters((const ssad_transpose_entry*)p[0], i[0], s);
+    case SSAD_OP_F16_PACK_FILTERS:
+      return ssad_f16_pack_filters((const ssad_f16_pack_entry*)p[0], i[0], s);
     case SSAD_OP_CONV_IMPLICIT_WS:
       return ssad_conv_implicit_gemm_ws((const ssad_gemm_conv*)p[0], i[0], i[1], i[2], i[3], i[4], i[5], (void*)p[1],
                                         (size_t)o.l[0], s);

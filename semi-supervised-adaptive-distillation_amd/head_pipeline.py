@@ -690,9 +690,16 @@ class DistillHeadsF16(DistillHeads):
         return packed, ops, []
 
     def _emit_pack(self, P, entries, direct):
-        for w, M, Cc, wf, wd in entries:
-            P.add(PR.F16_PACK_FILTER, 33, i=(M, Cc), p=(w, wf, wd),
-                  work=4.0 * w.numel() + 2.0 * (wf.numel() + (wd.numel() if wd is not None else 0)))
+        """All of a network's filters in one launch (ssad_f16_pack_filters)."""
+        if not entries:
+            return
+        tab = (K.F16PackEntry * len(entries))()
+        for i, (w, M, Cc, wf, wd) in enumerate(entries):
+            tab[i] = K.F16PackEntry(w.data_ptr(), wf.data_ptr(), wd.data_ptr() if wd is not None else None, M, Cc, 9, 0)
+        P.add(PR.F16_PACK_FILTERS, 33, i=(len(entries),), p=(tab,),
+              work=sum(4.0 * w.numel() + 2.0 * (wf.numel() + (wd.numel() if wd is not None else 0))
+                       for w, M, Cc, wf, wd in entries),
+              keep=[t for e in entries for t in (e[0], e[3], e[4]) if t is not None])
 
     def _f16_table(self, problems):
         """problems: [(xs, outs, masks or None, packed or None, bias or None)] -> ssad_f16_level[]"""

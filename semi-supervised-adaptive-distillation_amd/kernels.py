@@ -57,6 +57,11 @@ class TransposeEntry(C.Structure):
                 ("reserved", C.c_int)]
 
 
+class F16PackEntry(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("wf", C.c_void_p), ("wd", C.c_void_p), ("M", C.c_int), ("C", C.c_int),
+                ("taps", C.c_int), ("reserved", C.c_int)]
+
+
 class SgdSegment(C.Structure):
     _fields_ = [("offset", C.c_int64), ("n", C.c_int64), ("is_bias", C.c_int), ("row_len", C.c_int),
                 ("row_scale", C.c_void_p)]
@@ -187,6 +192,7 @@ def lib():
     L.ssad_subsample_grad.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_conv_implicit_gemm.argtypes = [C.POINTER(GemmConv), i32, i32, i32, i32, i32, i32, vp]
     L.ssad_transpose_filters.argtypes = [C.POINTER(TransposeEntry), i32, vp]
+    L.ssad_f16_pack_filters.argtypes = [C.POINTER(F16PackEntry), i32, vp]
     L.ssad_conv_implicit_gemm_workspace_bytes.restype = sz
     L.ssad_conv_implicit_gemm_workspace_bytes.argtypes = [i32] * 8
     L.ssad_conv_implicit_gemm_ws.argtypes = [C.POINTER(GemmConv), i32, i32, i32, i32, i32, i32, vp, sz, vp]

@@ -26,7 +26,7 @@ GEMM_CONV, CONV1X1_WGRAD, TRANSPOSE_FILTER, SUBSAMPLE, SUBSAMPLE_GRAD, RELU, IM2
 FORK, JOIN = 62, 63
 GROUPED_CONV3X3, GROUPED_PACK, CONV_IMPLICIT = 64, 65, 66
 PW_F16, PW_F16_PACK, PW_F16_WGRAD, F16_EW, STEM_POOL_F16, GROUPED_F16, GROUPED_F16_PACK = 67, 68, 69, 70, 71, 72, 73
-CONV_IMPLICIT_WS, CONV_KXK_WGRAD, CONV_KXK_DGRAD, TRANSPOSE_FILTERS = 74, 75, 76, 77
+CONV_IMPLICIT_WS, CONV_KXK_WGRAD, CONV_KXK_DGRAD, TRANSPOSE_FILTERS, F16_PACK_FILTERS = 74, 75, 76, 77, 78
 
 # timing classes: one per kernel family.  bound "mfma": work = direct-form FLOPs
 # (2*9*Cout*Cin per output pixel; the Winograd engine executes 1/2.25 of them);

@@ -49,7 +49,8 @@ def test_registered_operators(lib):
     for op in ("SigmoidAdaptiveDistillLoss", "SigmoidAdaptiveDistillLossGradient", "PowSum",
                "Conv", "ConvGradient", "Relu", "ReluGradient", "Sigmoid", "Sum", "Scale",
                "WeightedSum", "ConstantFill", "MomentumSGDUpdate", "SigmoidFocalLoss",
-               "SigmoidFocalLossGradient", "SelectSmoothL1Loss", "SelectSmoothL1LossGradient"):
+               "SigmoidFocalLossGradient", "SelectSmoothL1Loss", "SelectSmoothL1LossGradient",
+               "NCCLAllreduce", "NCCLBroadcast"):      # optimizer.py:72-92: the DP net's exchange is an operator
         assert core.IsOperator(op), op
     assert not core.IsOperator("NoSuchOp")
     mi, ma, mo, mx = (ctypes.c_int() for _ in range(4))
@@ -59,6 +60,10 @@ def test_registered_operators(lib):
     assert (mi.value, ma.value) == (5, 5)
     assert lib.c2hip_has_schema(b"PowSum", mi, ma, mo, mx)
     assert mi.value == 1 and ma.value >= 1000 and mo.value == 1
+    # no communicator in this process: the collectives are the reference's single-GPU no-ops
+    from ssad_amd.caffe2_hip import workspace
+    assert workspace.CommWorld() == 0
+    workspace.CommDestroy()                  # idempotent
 
 
 def test_proto_wire_roundtrip_python_and_cpp(lib):

@@ -472,3 +472,38 @@ def test_float16_pointwise_conv_through_the_operators(stride, H, W):
     for got, ref in ((dW.reshape(M, C), np.einsum("nmhw,nchw->mc", dy64, xs)), (db, dy64.sum((0, 2, 3))),
                      (dX, want_dx)):
         assert np.abs(got.astype(np.float64) - ref).max() <= 1e-3 * np.abs(ref).max()
+
+
+def test_f16_filter_packs_in_one_launch_equal_the_single_packs(K):
+    """ssad_f16_pack_filters (every filter of a network in one launch) against ssad_pw_f16_pack_filter /
+    ssad_f16_pack_filter entry by entry: same bits, for pointwise and 3x3 filters, channel counts with
+    8-block tails, forward-only and gradient-only entries, more entries than one launch's table."""
+    import ctypes as C
+    L = K.lib()
+    g = torch.Generator(device="cuda").manual_seed(77)
+    st = torch.cuda.current_stream().cuda_stream
+    shapes = [(64, 256, 1), (256, 64, 1), (136, 72, 1), (36, 256, 9), (256, 256, 9), (72, 40, 9), (2048, 512, 1)]
+    shapes = shapes + [(8 * (i % 5 + 1), 16 * (i % 3 + 1), 1 if i % 2 else 9) for i in range(70)]    # > 64 entries
+    ws, want, got, tab = [], [], [], (K.F16PackEntry * len(shapes))()
+    for i, (M, Cc, taps) in enumerate(shapes):
+        w = torch.randn((M, Cc, 3, 3) if taps == 9 else (M, Cc), device="cuda", generator=g)
+        n = (L.ssad_f16_filter_halves if taps == 9 else L.ssad_pw_f16_filter_halves)(M, Cc)
+        need_f, need_d = i % 3 != 1, i % 3 != 2
+        a = [torch.zeros(n, dtype=torch.float16, device="cuda") if need else None for need in (need_f, need_d)]
+        b = [torch.zeros(n, dtype=torch.float16, device="cuda") if need else None for need in (need_f, need_d)]
+        fn = L.ssad_f16_pack_filter if taps == 9 else L.ssad_pw_f16_pack_filter
+        p = lambda t: t.data_ptr() if t is not None else None
+        assert fn(w.data_ptr(), M, Cc, p(a[0]), p(a[1]), st) == 0
+        tab[i] = K.F16PackEntry(w.data_ptr(), p(b[0]), p(b[1]), M, Cc, taps, 0)
+        ws.append(w); want.append(a); got.append(b)
+    assert L.ssad_f16_pack_filters(tab, len(shapes), st) == 0
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(want, got)):
+        for x, y in zip(a, b):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert torch.equal(x, y), shapes[i]
+    bad = (K.F16PackEntry * 1)(K.F16PackEntry(ws[0].data_ptr(), None, None, 64, 256, 1, 0))
+    assert L.ssad_f16_pack_filters(bad, 1, st) == -1              # nothing to write
+    bad[0] = K.F16PackEntry(ws[0].data_ptr(), got[0][0].data_ptr(), None, 64, 256, 3, 0)
+    assert L.ssad_f16_pack_filters(bad, 1, st) == -1              # taps must be 1 or 9

@@ -173,6 +173,36 @@ def _worker(rank, world, port, outdir):
             torch.equal(solo_m.heads.losses, dpm.heads.losses))
     else:
         res["model_matches_no_collective_run"] = True
+    # the exchange as OPERATORS of the C-ABI surface (optimizer.py:72-92 `model.net.NCCLAllreduce(grads, grads)`,
+    # cuda_nccl_op_gpu.cc:68-88): rank 0 creates the id, every rank joins, each rank's net lists its own blob
+    from ssad_amd.caffe2_hip import caffe2_pb2, core, workspace as c2ws, dyndep
+    dyndep.InitOpsLibrary()
+    c2ws.ResetWorkspace()
+    ids = [c2ws.CommUniqueId() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    assert c2ws.CommWorld() == 0
+    gpu_opt = core.DeviceOption(caffe2_pb2.HIP, rank)
+    mine = (np.arange(1000, dtype=np.float32) * 0.25 + 10.0 * rank).reshape(10, 100)
+    c2ws.FeedBlob("g", mine, gpu_opt)
+    with core.DeviceScope(gpu_opt):
+        ar = core.CreateOperator("NCCLAllreduce", ["g"], ["g"])
+        bc = core.CreateOperator("NCCLBroadcast", ["w"], ["w"], root=0)
+    c2ws.RunOperatorOnce(ar)                                   # no communicator yet: the single-GPU no-op
+    res["op_noop_without_comm"] = bool(np.array_equal(c2ws.FetchBlob("g"), mine))
+    c2ws.CommInit(ids[0], world, rank, gpu_id=rank)
+    res["op_comm_world"] = c2ws.CommWorld()
+    c2ws.RunOperatorOnce(ar)
+    want_g = sum((np.arange(1000, dtype=np.float32) * 0.25 + 10.0 * r).reshape(10, 100) for r in range(world))
+    res["op_allreduce_ok"] = bool(np.array_equal(c2ws.FetchBlob("g"), want_g.astype(np.float32)))
+    c2ws.FeedBlob("w", np.full((7,), float(rank + 3), np.float32), gpu_opt)
+    c2ws.RunOperatorOnce(bc)
+    res["op_broadcast_ok"] = bool(np.array_equal(c2ws.FetchBlob("w"), np.full((7,), 3.0, np.float32)))
+    c2ws.FeedBlob("h", (np.ones(64) * (rank + 1)).astype(np.float16), gpu_opt)
+    with core.DeviceScope(gpu_opt):
+        c2ws.RunOperatorOnce(core.CreateOperator("NCCLAllreduce", ["h"], ["h2"]))
+    res["op_allreduce_f16_ok"] = bool(np.array_equal(c2ws.FetchBlob("h2"),
+                                                     np.full(64, world * (world + 1) / 2, np.float16)))
+    c2ws.CommDestroy()
     if rank == 0:
         np.savez(os.path.join(outdir, "res.npz"), **{k: np.asarray(v) for k, v in res.items()})
     dist.barrier()
@@ -194,6 +224,8 @@ def test_rccl_allreduce_buckets_and_update(world):
     assert bool(r["bb_reduced_equal"]) and bool(r["bb_params_equal"])
     assert float(r["bb_sum_err"]) <= 1e-6 * float(r["bb_sum_scale"])
     assert bool(r["model_finite"]) and bool(r["model_params_equal"]) and bool(r["model_matches_no_collective_run"])
+    assert bool(r["op_noop_without_comm"]) and int(r["op_comm_world"]) == world
+    assert bool(r["op_allreduce_ok"]) and bool(r["op_broadcast_ok"]) and bool(r["op_allreduce_f16_ok"])
 
 
 def test_bench_refuses_more_ranks_than_gpus():
