@@ -126,7 +126,7 @@ class NativeResNetFPNF16(NativeResNetFPN):
         # filter / bias gradients go round-robin over this many auxiliary streams (each with its own
         # workspace): the small reduce launch that ends one filter gradient then runs beside the next
         # one's main kernel instead of in front of it
-        nws = max(1, min(3, int(os.environ.get("SSAD_WGRAD_STREAMS", "2"))))
+        nws = 2      # 1 was indistinguishable, 3 worse
         self._wstreams = list(range(1, nws + 1)) if on else [0]
         self._wstream, self._wnext = self._wstreams[0], 0
         L, dev, lib = self._layers, self.device, K.lib()

@@ -407,7 +407,7 @@ class NativeResNetFPN(object):
         # filter / bias gradients go round-robin over this many auxiliary streams (each with its own
         # workspace): the small reduce launch that ends one filter gradient then runs beside the next
         # one's main kernel instead of in front of it
-        nws = max(1, min(3, int(os.environ.get("SSAD_WGRAD_STREAMS", "2"))))
+        nws = 2      # 1 was indistinguishable, 3 worse
         self._wstreams = list(range(1, nws + 1)) if on else [0]
         self._wstream, self._wnext = self._wstreams[0], 0
         # FPN's stride-2 3x3 layers (P6, P7) at their own size: implicit GEMM with split-K forward, flattened-batch
@@ -797,10 +797,9 @@ class NativeDistillModel(object):
         self.student.broadcast_params()
         if two_streams is None:
             two_streams = os.environ.get("SSAD_NATIVE_TWO_STREAMS", "1") == "1"
-        prio = int(os.environ.get("SSAD_SIDE_PRIORITY", "0"))
-        self.side = torch.cuda.Stream(priority=prio) if (two_streams and self.has_teacher) else None
-        # SSAD_TEACHER_FIRST=0: the teacher's forward pass is enqueued behind the student's filter packs (rounds 2-3)
-        self._teacher_first = os.environ.get("SSAD_TEACHER_FIRST", "1") == "1"
+        self.side = torch.cuda.Stream() if (two_streams and self.has_teacher) else None      # normal priority: high measured worse
+        # the teacher's forward pass is enqueued BEFORE the student's filter packs (attribute kept for A/B in tests)
+        self._teacher_first = True
         # The frozen teacher's forward pass depends on the images only -- not on the student's update.  Ordered after
         # the previous step's last READER of the teacher's output buffers (the subnets' forward launches) instead of
         # after everything the previous step enqueued, it may start while the previous step's backward pass is still

@@ -1333,7 +1333,7 @@ int wgrad_splits(int blocks, int stages, int rows = 3) {
   // levels: 0.424 / 0.449 / 0.485 / 0.523 ms for 1 / 2 / 3 / 4 rounds: the per-workgroup prologue
   // and the 2.4 MB of partial sums per split are not hidden at this occupancy)
   const int cus = ssad_cu_count();
-  static const int rounds = getenv("SSAD_F16_WGRAD_ROUNDS") ? atoi(getenv("SSAD_F16_WGRAD_ROUNDS")) : 1;
+  constexpr int rounds = 1;
   int s = (rounds * cus) / (rows * blocks);    // whole rounds; x 3 filter rows (1 for a pointwise layer)
   if (s > stages) s = stages;
   return s < 1 ? 1 : s;
@@ -1401,7 +1401,6 @@ int wgrad_launch(const ssad_f16_wgrad_level* levels, int n_levels, int C, int M,
     p.blocks = blocks; p.splits = splits;
     {
       // runs of one whole split per XCD when that divides evenly, else the largest common run length
-      static const int force = [] { const char* e = getenv("SSAD_F16_WGRAD_XCD_GROUP"); return e ? atoi(e) : 0; }();
       const int per_split = blocks * wgrad_rows(pw), total = per_split * splits;
       int g = 1;
       if ((total & 7) == 0) {
@@ -1409,7 +1408,7 @@ int wgrad_launch(const ssad_f16_wgrad_level* levels, int n_levels, int C, int M,
         while (y) { const int t = x % y; x = y; y = t; }
         g = x;
       }
-      p.xcd_group = force > 0 ? force : g;
+      p.xcd_group = g;
       if (nine) hipLaunchKernelGGL(wgrad9_f16_kernel, dim3(total), dim3(kWThreads), 2 * W9_STAGE * 16, s, p);
       else if (pw) hipLaunchKernelGGL(conv3x3_wgrad_f16_kernel<true>, dim3(total), dim3(kWThreads), 2 * W_STAGE * 16, s, p);
       else hipLaunchKernelGGL(conv3x3_wgrad_f16_kernel<false>, dim3(total), dim3(kWThreads), 2 * W_STAGE * 16, s, p);

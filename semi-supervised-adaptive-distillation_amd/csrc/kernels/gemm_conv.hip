@@ -664,11 +664,10 @@ int ssad_conv1x1_gemm(const ssad_gemm_conv* d, ssad_stream_t stream) {
   // fewer than two workgroups per CU (res5 at bs 16 is 70 column tiles: 280 tiles of 128 rows
   // put two workgroups on 24 CUs and one on the rest, i.e. the launch takes twice its share)
   const int cus = ssad_cu_count();
-  static const int force_bm = [] { const char* e = getenv("SSAD_GEMM_BM"); return e ? atoi(e) : 0; }();
   // (measured: the 64-row tile runs within a few % of the 128-row one on large problems and
   // quantises better on mid-sized ones, so it is the default below ~6 tiles of 128 rows per CU)
   const bool small = (long long)((d->M + 127) / 128) * g.ctiles < 6LL * cus;
-  if (force_bm == 64 || (force_bm != 128 && (d->M <= 64 || small))) {
+  if (d->M <= 64 || small) {
     g.mtiles = (d->M + 63) / 64;
     hipLaunchKernelGGL(gemm_conv_nn_kernel<64>, dim3(g.mtiles * g.ctiles), dim3(kThreads), 0, s, g);
   } else {
@@ -824,12 +823,7 @@ int ssad_conv1x1_wgrad(const float* x, const float* dy, int N, int C, int P, int
   const int used = (g.chunks + g.per_split - 1) / g.per_split;        // splits that own >= 1 chunk
   hipStream_t s = (hipStream_t)stream;
   g.splits = used;
-  {
-    // tuning: SSAD_GEMM_WGRAD_XCD_GROUP = run length (0 / unset: round robin; -1: one operand-sharing set,
-    // i.e. the mtiles tiles of one X block; -2: a whole split)
-    static const int want = [] { const char* e = getenv("SSAD_GEMM_WGRAD_XCD_GROUP"); return e ? atoi(e) : 0; }();
-    g.xcd_group = want == -1 ? g.mtiles : (want == -2 ? g.mtiles * g.ctiles : (want > 0 ? want : 1));
-  }
+  g.xcd_group = 1;      // round robin: runs of operand-sharing tiles per XCD measured worse
   hipLaunchKernelGGL(gemm_conv_nt_kernel, dim3(g.mtiles * g.ctiles * used), dim3(kThreads), 0, s, g);
   const long long n = (long long)M * C;
   hipLaunchKernelGGL(gemm_conv_wgrad_reduce_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)),

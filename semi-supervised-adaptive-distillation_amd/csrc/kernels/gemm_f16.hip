@@ -503,9 +503,8 @@ int ssad_conv1x1_f16(const ssad_pw_f16* d, ssad_stream_t stream) {
     return SSAD_E_BADARG;
   // 256-pixel tiles unless they leave the chip under-filled (two workgroups per CU are resident)
   const int cus = ssad_cu_count();
-  static const int force = [] { const char* e = getenv("SSAD_PW_F16_PT"); return e ? atoi(e) : 0; }();   // tuning
   const long long wg256 = ((p.total + 255) / 256) * p.mblocks;
-  if (force == 256 || (force != 128 && wg256 >= 2LL * cus)) return launch_pw<256>(p, (hipStream_t)stream);
+  if (wg256 >= 2LL * cus) return launch_pw<256>(p, (hipStream_t)stream);
   return launch_pw<128>(p, (hipStream_t)stream);
 }
 

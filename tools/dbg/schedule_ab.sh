@@ -2,9 +2,6 @@ run() { echo -n "$1: "; env $1 python bench.py --no-cpu-baseline --profile-steps
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['ms_per_step'])"; }
 run X=1
-run SSAD_WGRAD_STREAMS=1
-run SSAD_WGRAD_STREAMS=3
 run GPU_MAX_HW_QUEUES=8
 run GPU_MAX_HW_QUEUES=5
-run SSAD_TEACHER_FIRST=0
 run X=2
