@@ -114,7 +114,7 @@ def kernel_report(classes, steps):
 
 def pmc_traffic(klass):
     """HBM bytes per launch of one timing class from the committed counter passes over THIS
-    command's launches (profiles/rNN_pmc_classes.json: tools/profile_round3.sh runs separate
+    command's launches (profiles/rNN_pmc_classes.json: tools/profile_round.sh runs separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --workload heads` and
     tools/pmc_by_class.py attributes the dispatches to classes; read side x 2, the gfx950
     correction calibrated in profiles/r02_pmc_fetch_calib.md).  -> (bytes or None, note)"""
