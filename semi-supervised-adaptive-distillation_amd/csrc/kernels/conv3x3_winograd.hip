@@ -612,7 +612,15 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   const int t_src = (t_c >> 1) * ZCP + (t_c & 1) * (ZP / 2) +
       (PAIRS ? (2 * ((t_tile & 15) >> 2)) * ZP + 2 * (t_tile & 3) + (t_tile >> 4) * (SP + 2)
              : (2 * (t_tile >> 3)) * ZP + 2 * (t_tile & 7));
-  const int t_dst = (t_row * 4 * KC + t_c) * VP + (t_tile & 15) * 2 + (t_tile >> 4);
+  // V row = 32 tiles of one (position, channel).  128-channel blocks: slot (t & 15) * 2 + (t >> 4), i.e. the two tile
+  // groups interleaved -- a wave's ds_read_b64 takes both.  NHALF: a wave reads ONE group with ds_read_b32, and
+  // stride-2 floats would touch only every other bank (2-way conflicts: 4.2e7 conflict cycles per bbox_pred launch in
+  // profiles/r03_pmc_classes.md against 1.9e7 for a tower launch of 30x the work); there the groups are contiguous
+  // halves of the row, swapped in channel rows 2, 3 of every k group so that the four rows of an MFMA step (kq = 0..3,
+  // pitch 32 floats) cover all 64 banks.  (Round 4; the launch times did not move -- bbox_pred 0.555 ms before and
+  // after: a 36-wide layer is bound by the per-patch side jobs, transform and DMA, not by LDS reads.)
+  const int t_dst = (t_row * 4 * KC + t_c) * VP +
+      (NHALF ? ((((t_tile >> 4) ^ (t_c >> 1)) & 1) * 16 + (t_tile & 15)) : ((t_tile & 15) * 2 + (t_tile >> 4)));
   const int t_oa = t_src + t_ra * ZP, t_ob = t_src + t_rb * ZP;
   auto xf_load = [&](const float* rb0, int rnd, float2 (&d)[4]) {
     d[0] = *reinterpret_cast<const float2*>(rb0 + t_oa + rnd * 2 * ZCP);
@@ -643,7 +651,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   const bool dbg_on = blockIdx.x == 3 && tid == 0;
 #endif
   const int kq = lane >> 4, jn = lane & 15;
-  const float* bbase = vbuf + kq * VP + jn * 2 + g0;
+  const float* bbase = vbuf + kq * VP + (NHALF ? (((g0 ^ (kq >> 1)) & 1) * 16 + jn) : jn * 2);
   const int mtiles = cdiv(M, 16);
   const int stream_bytes = (mtiles * chunks * STEPS * 256 + 1024) * 4;
   const unsigned a_voff = lane * 16;
