@@ -40,7 +40,10 @@ def main():
               ("x101 res5 2048->2048", 2048, 2048, 16, 24, True),
               ("lat res3 512->256 +up", 512, 256, 64, 96, False)]
     tot = 0.0
+    only = sys.argv[1] if len(sys.argv) > 1 else ""          # substring filter on the shape's name
     for name, Cc, M, H, W, res in shapes:
+        if only not in name:
+            continue
         x = torch.randn((N, Cc // 8, H, W, 8), device="cuda").half()
         y = torch.empty((N, M // 8, H, W, 8), device="cuda", dtype=torch.float16)
         r = torch.randn((N, M // 8, H, W, 8), device="cuda").half() if res else None
