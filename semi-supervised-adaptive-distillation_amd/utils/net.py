@@ -328,5 +328,7 @@ def initialize_from_blobs(model, src):
     for k in list(model.heads.preserved):
         if k in owned:
             del model.heads.preserved[k]          # the backbones own these now
+    # rank 0's loaded state is what every replica starts from (net.py:185-208 broadcast_parameters)
+    model.heads.broadcast_params()
     model.student.broadcast_params()
     return loaded, missing
