@@ -585,6 +585,14 @@ def main():
                                 "config 3 only")
         # the ONE result line, last on rank 0's stdout (with NCCL_DEBUG=VERSION in the environment
         # RCCL prints its version banner to stdout when the communicator is created, i.e. earlier)
+        # ... into C stdio's buffer, which is flushed at process exit, i.e. AFTER anything Python prints: measured on
+        # the box with a forced one-rank communicator, the five banner lines followed the JSON line in the file.
+        # Flush the C streams first so that the result line is the last line of stdout.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if pg is not None:
