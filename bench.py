@@ -468,6 +468,16 @@ def main():
     if args.workload == "full" and native:
         assert bool(torch.isfinite(model.student.params_flat).all()), "non-finite backbone parameters after the run"
 
+    # Every rank empties its C stdio buffer NOW (RCCL's version banner sits there until process exit otherwise and
+    # would land after rank 0's result line in the launcher's merged stdout), then all meet, then rank 0 prints.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if pg is not None:
+        torch.distributed.barrier()
     if rank == 0:
         rows = kernel_report(timing_all.collect(), max(args.profile_steps, 1))      # all families
         by = {r["class"]: r for r in kernel_report(timing.collect(), args.steps)}     # the timed region
