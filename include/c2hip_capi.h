@@ -85,6 +85,34 @@ C2HIP_CAPI c2hip_operator* c2hip_create_operator(c2hip_workspace* ws, const void
 C2HIP_CAPI int c2hip_run_operator(c2hip_operator* op, int sync);
 C2HIP_CAPI void c2hip_destroy_operator(c2hip_operator* op);
 
+/* --- nets (caffe2/python/workspace.py CreateNet / RunNet / RunNetOnce -> pybind_state.cc
+ *     "create_net" / "run_net" / "run_net_once" -> caffe2/core/workspace.cc:180-260; the training loop is
+ *     one workspace.RunNet(model.net.Proto().name) per iteration, detectron/tools/train_net.py:165-189) ---
+ * netdef_bytes: protobuf-serialized NetDef (caffe2.proto:176-215).  The net is instantiated ONCE: its
+ * operator list is lowered for the MI355X kernels (Conv + Relu fusion, one multi-level launch per shared
+ * filter, the shared-filter gradient Sum absorbed: csrc/c2/net.h, csrc/ops/net_lowering.cc; NetDef arg
+ * hip_lowering = 0 keeps the list as written) and its operators are created; a run enqueues them in order
+ * and synchronises once (NetDef arg hip_sync_every_op = 1: after every operator, as the reference's
+ * executors do).  Results are those of running the operators one by one. */
+C2HIP_CAPI int c2hip_create_net(c2hip_workspace* ws, const void* netdef_bytes, size_t n, int overwrite);
+C2HIP_CAPI int c2hip_run_net(c2hip_workspace* ws, const char* name, int num_iter);
+C2HIP_CAPI int c2hip_run_net_once(c2hip_workspace* ws, const void* netdef_bytes, size_t n);
+C2HIP_CAPI int c2hip_delete_net(c2hip_workspace* ws, const char* name);
+/* '\n'-separated net names; returns the byte count needed */
+C2HIP_CAPI size_t c2hip_nets(c2hip_workspace* ws, char* buf, size_t buflen);
+/* The operator list a created net actually runs, as [u32 length][OperatorDef bytes]...; *n_ops receives
+ * the count.  Returns the byte count needed (0 + error if the net does not exist). */
+C2HIP_CAPI size_t c2hip_net_lowered_ops(c2hip_workspace* ws, const char* name, void* buf, size_t buflen,
+                                        int* n_ops);
+/* The lowering alone, without a workspace or a device (host logic; filters are assumed fp32): writes the
+ * lowered operator list as above and a one-line report into report_buf. */
+C2HIP_CAPI size_t c2hip_lower_net(const void* netdef_bytes, size_t n, void* buf, size_t buflen, int* n_ops,
+                                  char* report_buf, size_t report_buflen);
+/* Process-wide event counters for tests and benchmarks: "filter_packs" (3x3 filter packs issued by the
+ * operators' pack cache), "conv_launch_calls" (3x3 launcher calls made by Conv / ConvGradient / the group
+ * operators).  -1 for an unknown name. */
+C2HIP_CAPI long long c2hip_counter(const char* name);
+
 /* --- registry / schema / gradients (core.RefreshRegisteredOperators,
  *     core.GetGradientForOp -> pybind get_gradient_defs) ------------------- */
 /* '\n'-separated registered keys for a device type; returns bytes needed */

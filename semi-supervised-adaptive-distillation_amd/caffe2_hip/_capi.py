@@ -39,6 +39,18 @@ def load(path=None):
     L.c2hip_create_operator.argtypes = [vp, cp, sz]
     L.c2hip_run_operator.argtypes = [vp, i32]
     L.c2hip_destroy_operator.argtypes = [vp]
+    L.c2hip_create_net.argtypes = [vp, cp, sz, i32]
+    L.c2hip_run_net.argtypes = [vp, cp, i32]
+    L.c2hip_run_net_once.argtypes = [vp, cp, sz]
+    L.c2hip_delete_net.argtypes = [vp, cp]
+    L.c2hip_nets.restype = sz
+    L.c2hip_nets.argtypes = [vp, cp, sz]
+    L.c2hip_net_lowered_ops.restype = sz
+    L.c2hip_net_lowered_ops.argtypes = [vp, cp, vp, sz, C.POINTER(i32)]
+    L.c2hip_lower_net.restype = sz
+    L.c2hip_lower_net.argtypes = [cp, sz, vp, sz, C.POINTER(i32), cp, sz]
+    L.c2hip_counter.restype = C.c_longlong
+    L.c2hip_counter.argtypes = [cp]
     L.c2hip_registered_operators.restype = sz
     L.c2hip_registered_operators.argtypes = [i32, cp, sz]
     L.c2hip_has_schema.argtypes = [cp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),

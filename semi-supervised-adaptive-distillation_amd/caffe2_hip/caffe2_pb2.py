@@ -1,5 +1,5 @@
-"""OperatorDef / Argument / DeviceOption with the protobuf wire format of
-caffe2/proto/caffe2.proto:97-172, hand-coded (no protoc in this image).
+"""OperatorDef / Argument / DeviceOption / NetDef with the protobuf wire format of
+caffe2/proto/caffe2.proto:97-215, hand-coded (no protoc in this image).
 SerializeToString() / ParseFromString() interoperate with the C++ codec in
 csrc/c2/proto.cc and with real caffe2_pb2 messages."""
 import struct
@@ -235,3 +235,56 @@ class OperatorDef(object):
         if self.name:
             d["name"] = self.name
         return d
+
+
+class NetDef(object):
+    """caffe2.proto:176-215."""
+
+    def __init__(self, name=""):
+        self.name = name
+        self.op = []
+        self.type = ""
+        self.num_workers = 0
+        self.device_option = None
+        self.arg = []
+        self.external_input = []
+        self.external_output = []
+
+    def SerializeToString(self):
+        out = _ld(1, _b(self.name)) if self.name else b""
+        out += b"".join(_ld(2, o.SerializeToString()) for o in self.op)
+        if self.type:
+            out += _ld(3, _b(self.type))
+        if self.num_workers:
+            out += _key(4, 0) + _varint(int(self.num_workers))
+        if self.device_option is not None:
+            out += _ld(5, self.device_option.SerializeToString())
+        out += b"".join(_ld(6, a.SerializeToString()) for a in self.arg)
+        out += b"".join(_ld(7, _b(s)) for s in self.external_input)
+        out += b"".join(_ld(8, _b(s)) for s in self.external_output)
+        return out
+
+    def ParseFromString(self, data):
+        r = _Reader(data)
+        while not r.done():
+            k = r.varint()
+            f, w = k >> 3, k & 7
+            if w == 2 and f == 1:
+                self.name = r.bytes_().decode()
+            elif w == 2 and f == 2:
+                self.op.append(OperatorDef().ParseFromString(r.bytes_()))
+            elif w == 2 and f == 3:
+                self.type = r.bytes_().decode()
+            elif w == 0 and f == 4:
+                self.num_workers = r.varint()
+            elif w == 2 and f == 5:
+                self.device_option = DeviceOption().ParseFromString(r.bytes_())
+            elif w == 2 and f == 6:
+                self.arg.append(Argument().ParseFromString(r.bytes_()))
+            elif w == 2 and f == 7:
+                self.external_input.append(r.bytes_().decode())
+            elif w == 2 and f == 8:
+                self.external_output.append(r.bytes_().decode())
+            else:
+                r.skip(w)
+        return self

@@ -153,18 +153,12 @@ class GradientRegistry(object):
         return ops, g_input[:len(op.input)]
 
 
-class _NetProto(object):
-    def __init__(self, name):
-        self.name = name
-        self.op = []
-        self.external_input = []
-
-
 class Net(object):
-    """caffe2.python.core.Net: `net.<OpType>(inputs, outputs, **args)`."""
+    """caffe2.python.core.Net: `net.<OpType>(inputs, outputs, **args)`; Proto() is the NetDef
+    that workspace.CreateNet serializes (caffe2.proto:176-215)."""
 
     def __init__(self, name):
-        self._net = _NetProto(name)
+        self._net = caffe2_pb2.NetDef(name)
 
     def Name(self):
         return self._net.name

@@ -13,7 +13,6 @@ _DT = {np.dtype(np.float32): 1, np.dtype(np.int32): 2, np.dtype(np.int64): 10,
 _NP = {v: k for k, v in _DT.items()}
 
 _ws = None
-_nets = {}
 
 
 def _handle():
@@ -25,10 +24,8 @@ def _handle():
 
 def ResetWorkspace():
     global _ws
-    for ops in _nets.values():
-        for h in ops:
-            _capi.load().c2hip_destroy_operator(h)
-    _nets.clear()
+    _sync_twins.clear()
+    _protos.clear()
     if _ws is not None:
         _capi.load().c2hip_workspace_destroy(_ws)
     _ws = None
@@ -104,41 +101,117 @@ def RunOperatorsOnce(ops):
     return True
 
 
+def _net_proto(net):
+    return net.Proto() if hasattr(net, "Proto") else net
+
+
 def CreateNet(net, overwrite=False):
-    proto = net.Proto() if hasattr(net, "Proto") else net
-    if proto.name in _nets:
-        if not overwrite:
-            raise _capi.C2Error("net %s already exists" % proto.name)
-        for h in _nets.pop(proto.name):
-            _capi.load().c2hip_destroy_operator(h)
-    handles = []
-    for op in proto.op:
-        ser = op.SerializeToString()
-        h = _capi.load().c2hip_create_operator(_handle(), ser, len(ser))
-        if not h:
-            raise _capi.C2Error(_capi.load().c2hip_last_error().decode("utf-8", "replace"))
-        handles.append(h)
-    _nets[proto.name] = handles
+    """workspace.CreateNet: the serialized NetDef goes to the library, which lowers the operator
+    list (Conv + Relu fusion, one multi-level launch per shared filter: csrc/ops/net_lowering.cc)
+    and instantiates the operators once."""
+    proto = _net_proto(net)
+    ser = proto.SerializeToString()
+    _capi.check(_capi.load().c2hip_create_net(_handle(), ser, len(ser), int(bool(overwrite))))
+    _protos[proto.name] = proto
+    _sync_twins.pop(proto.name, None)
     return True
 
 
 def RunNet(name, num_iter=1, sync_every_op=False):
-    """Runs the ops of a created net in order.  sync_every_op=True is the
-    reference's behaviour (caffe2/core/operator.h:378 syncs the stream after
-    every operator); the default enqueues the whole net and syncs once."""
+    """workspace.RunNet (the training loop's one call per iteration, tools/train_net.py:173): the
+    created net enqueues its operators in order and synchronises once per run.
+    sync_every_op=True runs the net's operators one by one with a synchronisation after each --
+    the reference executors' behaviour (caffe2/core/operator.h:378) -- through a twin of the net
+    created with the NetDef argument hip_sync_every_op."""
     name = name.Proto().name if hasattr(name, "Proto") else str(name)
-    L = _capi.load()
-    for _ in range(num_iter):
-        for h in _nets[name]:
-            _capi.check(L.c2hip_run_operator(h, 1 if sync_every_op else 0))
-        if not sync_every_op:
-            _capi.check(L.c2hip_device_synchronize(0))
+    if sync_every_op:
+        if name not in _sync_twins:
+            if name not in _protos:
+                raise _capi.C2Error("Network %s does not exist yet." % name)
+            CreateSyncTwin(_protos[name])
+        name = _sync_twins[name]
+    _capi.check(_capi.load().c2hip_run_net(_handle(), name.encode(), int(num_iter)))
     return True
 
 
+_sync_twins = {}
+_protos = {}
+
+
+def CreateSyncTwin(net, lowering=False):
+    """A second instantiation of `net` whose Run synchronises after every operator (and, by default,
+    runs the operator list as written, without the lowering): the reference's execution model, for
+    A/B checks against the lowered single-sync net."""
+    proto = _net_proto(net)
+    twin = caffe2_pb2.NetDef(proto.name + "__sync_every_op")
+    twin.op = proto.op
+    twin.type, twin.device_option = proto.type, proto.device_option
+    twin.external_input, twin.external_output = proto.external_input, proto.external_output
+    twin.arg = list(proto.arg) + [core.MakeArgument("hip_sync_every_op", 1),
+                                  core.MakeArgument("hip_lowering", int(bool(lowering)))]
+    ser = twin.SerializeToString()
+    _capi.check(_capi.load().c2hip_create_net(_handle(), ser, len(ser), 1))
+    _sync_twins[proto.name] = twin.name
+    return twin.name
+
+
 def RunNetOnce(net):
-    CreateNet(net, overwrite=True)
-    return RunNet(net)
+    ser = _net_proto(net).SerializeToString()
+    _capi.check(_capi.load().c2hip_run_net_once(_handle(), ser, len(ser)))
+    return True
+
+
+def DeleteNet(name):
+    name = name.Proto().name if hasattr(name, "Proto") else str(name)
+    _capi.check(_capi.load().c2hip_delete_net(_handle(), name.encode()))
+    _sync_twins.pop(name, None)
+    _protos.pop(name, None)
+    return True
+
+
+def Nets():
+    L = _capi.load()
+    n = L.c2hip_nets(_handle(), None, 0)
+    buf = C.create_string_buffer(n)
+    L.c2hip_nets(_handle(), buf, n)
+    return [s for s in buf.value.decode().split("\n") if s]
+
+
+def _unpack_defs(raw, count):
+    import struct
+    pos, ops = 0, []
+    for _ in range(count):
+        (ln,) = struct.unpack_from("<I", raw, pos)
+        ops.append(caffe2_pb2.OperatorDef().ParseFromString(raw[pos + 4:pos + 4 + ln]))
+        pos += 4 + ln
+    return ops
+
+
+def LoweredOps(name):
+    """The operator list a created net actually runs (after the lowering)."""
+    name = name.Proto().name if hasattr(name, "Proto") else str(name)
+    L, n_ops = _capi.load(), C.c_int(0)
+    need = L.c2hip_net_lowered_ops(_handle(), name.encode(), None, 0, C.byref(n_ops))
+    if need == 0 and n_ops.value == 0:
+        _capi.check(1 if L.c2hip_last_error() else 0)
+    buf = C.create_string_buffer(max(need, 1))
+    L.c2hip_net_lowered_ops(_handle(), name.encode(), buf, need, C.byref(n_ops))
+    return _unpack_defs(buf.raw[:need], n_ops.value)
+
+
+def LowerNet(net):
+    """The lowering alone (no workspace, no device): -> (operator list, one-line report)."""
+    ser = _net_proto(net).SerializeToString()
+    L, n_ops = _capi.load(), C.c_int(0)
+    rep = C.create_string_buffer(1024)
+    need = L.c2hip_lower_net(ser, len(ser), None, 0, C.byref(n_ops), rep, 1024)
+    buf = C.create_string_buffer(max(need, 1))
+    L.c2hip_lower_net(ser, len(ser), buf, need, C.byref(n_ops), rep, 1024)
+    return _unpack_defs(buf.raw[:need], n_ops.value), rep.value.decode()
+
+
+def Counter(name):
+    return int(_capi.load().c2hip_counter(name.encode()))
 
 
 def SetStream(gpu_id, hip_stream, enabled=True):

@@ -1,0 +1,136 @@
+// net.cc -- the net object of Workspace::CreateNet / RunNet for HIPContext (see net.h).
+#include "c2/net.h"
+
+#include <cstdlib>
+
+namespace caffe2 {
+
+namespace {
+
+const Argument* FindArg(const NetDef& def, const char* name) {
+  for (const Argument& a : def.arg)
+    if (a.name == name) return &a;
+  return nullptr;
+}
+
+bool EnvFlag(const char* name, bool dflt) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  return !(e[0] == '0' || e[0] == 'n' || e[0] == 'N' || e[0] == 'f' || e[0] == 'F');
+}
+
+int BlobDtype(const Workspace* ws, const string& name) {
+  const Blob* b = ws->GetBlob(name);
+  if (!b) return 0;
+  if (b->IsType<TensorHIP>()) return (int)b->Get<TensorHIP>().meta().id;
+  if (b->IsType<TensorCPU>()) return (int)b->Get<TensorCPU>().meta().id;
+  return 0;
+}
+
+}  // namespace
+
+string LoweringReport::ToString() const {
+  return MakeString("ops ", ops_in, " -> ", ops_out, "; Relu fused ", relu_fused, ", ReluGradient fused ",
+                    relu_grad_fused, "; ConvGroup ", conv_groups, " (", conv_group_members,
+                    " Conv); ConvGradientGroup ", conv_grad_groups, " (", conv_grad_group_members,
+                    " ConvGradient); Sum absorbed ", sums_absorbed, "; loss groups ", loss_groups, " (",
+                    loss_group_members, " ops)", fell_back ? "; FELL BACK to the list as written" : "");
+}
+
+NetBase::NetBase(const NetDef& def, Workspace* ws) : name_(def.name) {
+  const Argument* sync = FindArg(def, "hip_sync_every_op");
+  sync_every_op_ = EnvFlag("C2HIP_NET_SYNC_EVERY_OP", sync && sync->has_i && sync->i != 0);
+  const Argument* low = FindArg(def, "hip_lowering");
+  const bool lowering = EnvFlag("C2HIP_NET_LOWERING", !(low && low->has_i && low->i == 0));
+
+  // the net's device option is the default of operators that carry none (net_simple.cc:41-50)
+  NetDef scoped = def;
+  if (def.has_device_option)
+    for (OperatorDef& op : scoped.op)
+      if (!op.has_device_option) {
+        op.device_option = def.device_option;
+        op.has_device_option = true;
+      }
+  if (lowering) {
+    LoweringOptions opt;
+    opt.fuse_relu = EnvFlag("C2HIP_NET_FUSE_RELU", true);
+    opt.group_convs = EnvFlag("C2HIP_NET_GROUP_CONVS", true);
+    opt.group_losses = EnvFlag("C2HIP_NET_GROUP_LOSSES", true);
+    opt.blob_dtype = [ws](const string& n) { return BlobDtype(ws, n); };
+    for (const string& s : def.external_output) opt.keep.insert(s);
+    if (const Argument* k = FindArg(def, "hip_keep_blobs"))
+      for (const string& s : k->strings) opt.keep.insert(s);
+    lowered_ = LowerNet(scoped, opt, &report_);
+  } else {
+    lowered_ = scoped.op;
+    report_.ops_in = report_.ops_out = (int)lowered_.size();
+  }
+  operators_.reserve(lowered_.size());
+  for (const OperatorDef& op : lowered_) operators_.push_back(CreateOperator(op, ws));
+}
+
+bool NetBase::Run() {
+  OperatorBase* last = nullptr;
+  for (auto& op : operators_) {
+    const bool ok = sync_every_op_ ? op->Run() : op->RunAsync();
+    if (!ok) return false;
+    if (op->OnDeviceStream()) last = op.get();
+  }
+  // one synchronisation per run: every operator of a process enqueues on the one device stream
+  // (context.cc: per-(gpu, stream id) pool stream, or the caller's via c2hip_set_stream)
+  if (!sync_every_op_ && last) return last->Finish();
+  return true;
+}
+
+std::unique_ptr<NetBase> CreateNet(const NetDef& def, Workspace* ws) {
+  // caffe2/core/net.cc:35-60 looks `type` up in the net registry; every executor type the
+  // reference's configs name ("simple", "dag": detectron/lib/core/config.py MODEL.EXECUTION_TYPE)
+  // maps to the in-order single-stream executor here.
+  CAFFE_ENFORCE(def.type.empty() || def.type == "simple" || def.type == "dag" ||
+                    def.type == "async_dag" || def.type == "async_simple",
+                "net type '", def.type, "' is not available for HIPContext");
+  return std::unique_ptr<NetBase>(new NetBase(def, ws));
+}
+
+// ---- Workspace's net functions (caffe2/core/workspace.cc:180-260) ----------------------------
+Workspace::Workspace() {}
+Workspace::~Workspace() {
+  net_map_.clear();   // operators hold raw Blob*: destroy them before the blobs
+  blobs_.clear();
+}
+
+NetBase* Workspace::CreateNet(const NetDef& def, bool overwrite) {
+  CAFFE_ENFORCE(!def.name.empty(), "NetDef should have a name");
+  auto it = net_map_.find(def.name);
+  if (it != net_map_.end()) {
+    CAFFE_ENFORCE(overwrite, "A net with name ", def.name,
+                  " already exists; pass overwrite = true to replace it");
+    // workspace.cc:196-201: delete first, so that the old net's operators release their buffers
+    net_map_.erase(it);
+  }
+  std::unique_ptr<NetBase> net = caffe2::CreateNet(def, this);
+  NetBase* raw = net.get();
+  net_map_[def.name] = std::move(net);
+  return raw;
+}
+
+NetBase* Workspace::GetNet(const string& name) {
+  auto it = net_map_.find(name);
+  return it == net_map_.end() ? nullptr : it->second.get();
+}
+
+void Workspace::DeleteNet(const string& name) { net_map_.erase(name); }
+
+bool Workspace::RunNet(const string& name) {
+  NetBase* net = GetNet(name);
+  CAFFE_ENFORCE(net != nullptr, "Network ", name, " does not exist yet.");
+  return net->Run();
+}
+
+vector<string> Workspace::Nets() const {
+  vector<string> names;
+  for (const auto& kv : net_map_) names.push_back(kv.first);
+  return names;
+}
+
+}  // namespace caffe2

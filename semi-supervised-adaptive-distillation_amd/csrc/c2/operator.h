@@ -59,6 +59,10 @@ class C2HIP_API OperatorBase {
   // RunAsync = enqueue only.
   virtual bool Run(int /*stream_id*/ = 0) { CAFFE_NOT_IMPLEMENTED; }
   virtual bool RunAsync(int stream_id = 0) { return Run(stream_id); }
+  // what a net needs to synchronise once per run instead of once per operator: does the operator
+  // enqueue on a device stream, and wait for + check that stream
+  virtual bool OnDeviceStream() const { return false; }
+  virtual bool Finish() { return true; }
 
  protected:
   OperatorDef def_;
@@ -90,6 +94,8 @@ class Operator : public OperatorBase {
 
   bool Run(int stream_id = 0) final { return RunImpl(stream_id, true); }
   bool RunAsync(int stream_id = 0) final { return RunImpl(stream_id, false); }
+  bool OnDeviceStream() const final { return Context::device_type() != CPU; }
+  bool Finish() final { return context_.FinishDeviceComputation(); }
   virtual bool RunOnDevice() = 0;
 
  protected:

@@ -122,9 +122,54 @@ string write_device(const DeviceOption& d) {
 
 }  // namespace
 
+static bool parse_operator(Reader r, OperatorDef* out);
+
 bool ParseOperatorDef(const void* data, size_t n, OperatorDef* out) {
-  *out = OperatorDef();
+  return parse_operator(Reader{(const uint8_t*)data, (const uint8_t*)data + n}, out);
+}
+
+bool ParseNetDef(const void* data, size_t n, NetDef* out) {
+  *out = NetDef();
   Reader r{(const uint8_t*)data, (const uint8_t*)data + n};
+  while (r.ok && !r.done()) {
+    const uint64_t key = r.varint();
+    const int field = (int)(key >> 3), wire = (int)(key & 7);
+    if (wire == 2 && field == 1) out->name = r.bytes();
+    else if (wire == 2 && field == 2) {
+      OperatorDef op;
+      if (!parse_operator(r.sub(), &op)) return false;
+      out->op.push_back(std::move(op));
+    } else if (wire == 2 && field == 3) out->type = r.bytes();
+    else if (wire == 0 && field == 4) out->num_workers = (int)r.varint();
+    else if (wire == 2 && field == 5) {
+      if (!parse_device(r.sub(), &out->device_option)) return false;
+      out->has_device_option = true;
+    } else if (wire == 2 && field == 6) {
+      Argument a;
+      if (!parse_argument(r.sub(), &a)) return false;
+      out->arg.push_back(a);
+    } else if (wire == 2 && field == 7) out->external_input.push_back(r.bytes());
+    else if (wire == 2 && field == 8) out->external_output.push_back(r.bytes());
+    else r.skip(wire);
+  }
+  return r.ok;
+}
+
+string SerializeNetDef(const NetDef& def) {
+  Writer w;
+  if (!def.name.empty()) w.bytes(1, def.name);
+  for (const OperatorDef& op : def.op) w.bytes(2, SerializeOperatorDef(op));
+  if (!def.type.empty()) w.bytes(3, def.type);
+  if (def.num_workers) w.i64(4, def.num_workers);
+  if (def.has_device_option) w.bytes(5, write_device(def.device_option));
+  for (const Argument& a : def.arg) w.bytes(6, write_argument(a));
+  for (const string& s : def.external_input) w.bytes(7, s);
+  for (const string& s : def.external_output) w.bytes(8, s);
+  return w.out;
+}
+
+static bool parse_operator(Reader r, OperatorDef* out) {
+  *out = OperatorDef();
   while (r.ok && !r.done()) {
     const uint64_t key = r.varint();
     const int field = (int)(key >> 3), wire = (int)(key & 7);

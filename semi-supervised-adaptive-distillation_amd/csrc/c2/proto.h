@@ -1,6 +1,6 @@
-// proto.h -- plain-struct mirror of the three messages an operator sees
+// proto.h -- plain-struct mirror of the messages an operator / a net sees
 // (caffe2/proto/caffe2.proto:97-106 Argument, :128-138 DeviceOption,
-// :142-172 OperatorDef) plus a hand-written protobuf wire codec, so the C-ABI
+// :142-172 OperatorDef, :176-215 NetDef) plus a hand-written protobuf wire codec, so the C-ABI
 // accepts exactly the bytes `op.SerializeToString()` produces in the
 // reference's Python layer (caffe2/python/pybind_state.cc RunOperatorOnce).
 // No protobuf dependency.
@@ -48,7 +48,24 @@ struct OperatorDef {
   bool is_gradient_op = false;   // 9
 };
 
+// caffe2.proto:176-215.  `type` names the executor ("simple", "dag", ...: caffe2/core/net.cc
+// REGISTER_NET); `arg` carries executor options; external_input / external_output declare the
+// blobs that must hold their real contents when a run returns.
+struct NetDef {
+  string name;                     // 1
+  vector<OperatorDef> op;          // 2
+  string type;                     // 3
+  int num_workers = 0;             // 4 (deprecated upstream; detector.py:67 still sets it)
+  DeviceOption device_option;      // 5
+  bool has_device_option = false;
+  vector<Argument> arg;            // 6
+  vector<string> external_input;   // 7
+  vector<string> external_output;  // 8
+};
+
 C2HIP_API bool ParseOperatorDef(const void* data, size_t n, OperatorDef* out);
+C2HIP_API bool ParseNetDef(const void* data, size_t n, NetDef* out);
+C2HIP_API string SerializeNetDef(const NetDef& def);
 C2HIP_API string SerializeOperatorDef(const OperatorDef& def);
 C2HIP_API string ProtoDebugString(const OperatorDef& def);
 

@@ -5,6 +5,7 @@
 #ifndef C2HIP_TENSOR_H_
 #define C2HIP_TENSOR_H_
 
+#include <atomic>
 #include <initializer_list>
 #include <memory>
 
@@ -53,6 +54,11 @@ template <> inline TypeMeta TypeMeta::Make<uint8_t>() { return {DataType::UINT8,
 template <> inline TypeMeta TypeMeta::Make<int8_t>() { return {DataType::INT8, 1}; }
 template <> inline TypeMeta TypeMeta::Make<bool>() { return {DataType::BOOL, 1}; }
 
+inline uint64_t NextTensorUid() {
+  static std::atomic<uint64_t> next{1};
+  return next.fetch_add(1, std::memory_order_relaxed);
+}
+
 template <class Context>
 class Tensor {
  public:
@@ -98,6 +104,7 @@ class Tensor {
     return static_cast<T*>(raw_mutable_data(TypeMeta::Make<T>()));
   }
   void* raw_mutable_data(const TypeMeta& meta) {
+    ++version_;   // whoever asks for mutable data is about to write
     const size_t need = (size_t)size_ * meta.itemsize;
     if (data_ && meta_ == meta && capacity_ >= need) return data_.get();
     CAFFE_ENFORCE(!external_ || (meta_ == meta && capacity_ >= need),
@@ -128,7 +135,19 @@ class Tensor {
     data_.reset(p, [](void*) {});
     capacity_ = capacity_bytes ? capacity_bytes : (size_t)size_ * meta.itemsize;
     external_ = true;
+    ++version_;
   }
+
+  // Write generation of the tensor: bumped by every raw_mutable_data / mutable_data<T> /
+  // ShareExternalPointer, i.e. by every writer that goes through the tensor API (FeedBlob, an
+  // operator's Output(i)->mutable_data<T>()).  Operators cache derived data (a packed filter)
+  // under (pointer, version, dims).  Memory the tensor does not own can change behind its back
+  // (a torch tensor wrapped by c2hip_share_external), so external() tensors are never cached.
+  uint64_t version() const { return version_; }
+  bool external() const { return external_; }
+  // process-unique identity of this tensor object (a cache keyed on the data pointer alone could
+  // mistake a new tensor that landed on a freed address for the old one)
+  uint64_t uid() const { return uid_; }
 
   template <class SrcContext, class Ctx>
   void CopyFrom(const Tensor<SrcContext>& src, Ctx* context) {
@@ -155,6 +174,8 @@ class Tensor {
   std::shared_ptr<void> data_;
   size_t capacity_ = 0;
   bool external_ = false;
+  uint64_t version_ = 0;
+  uint64_t uid_ = NextTensorUid();
 };
 
 using TensorCPU = Tensor<CPUContext>;

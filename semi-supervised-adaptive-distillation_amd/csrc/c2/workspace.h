@@ -1,7 +1,8 @@
 // workspace.h -- Blob and Workspace (caffe2/core/blob.h:41-130,
 // caffe2/core/workspace.h:63-300): a workspace owns named blobs, a blob owns
 // one typed object (here a TensorCPU or a TensorHIP), operators hold raw
-// Blob* resolved at construction (caffe2/core/operator.cc:44-66).
+// Blob* resolved at construction (caffe2/core/operator.cc:44-66); it also owns the nets created
+// in it (workspace.h:209-233; implementation in c2/net.cc).
 #ifndef C2HIP_WORKSPACE_H_
 #define C2HIP_WORKSPACE_H_
 
@@ -54,9 +55,24 @@ class Blob {
   void (*destroy_)(void*) = nullptr;
 };
 
-class Workspace {
+class NetBase;
+struct NetDef;
+
+class C2HIP_API Workspace {
  public:
-  Workspace() {}
+  Workspace();
+  ~Workspace();   // out of line (net.cc): the nets hold operators that hold Blob*, so they go first
+  Workspace(const Workspace&) = delete;
+  Workspace& operator=(const Workspace&) = delete;
+
+  // caffe2/core/workspace.h:209-233: the workspace owns its nets by name.  CreateNet instantiates
+  // (and lowers, net.h) the definition once; RunNet runs the instantiated object.
+  NetBase* CreateNet(const NetDef& def, bool overwrite = false);
+  NetBase* GetNet(const string& name);
+  void DeleteNet(const string& name);
+  bool RunNet(const string& name);
+  vector<string> Nets() const;
+
   Blob* CreateBlob(const string& name) {
     auto it = blobs_.find(name);
     if (it != blobs_.end()) return it->second.get();
@@ -82,6 +98,7 @@ class Workspace {
 
  private:
   std::map<string, std::unique_ptr<Blob>> blobs_;
+  std::map<string, std::unique_ptr<NetBase>> net_map_;
 };
 
 }  // namespace caffe2

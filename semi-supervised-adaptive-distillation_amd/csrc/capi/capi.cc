@@ -2,7 +2,9 @@
 
 #include <cstring>
 
+#include "c2/net.h"
 #include "c2/operator.h"
+#include "ops/conv_op.h"
 
 using namespace caffe2;
 
@@ -55,6 +57,25 @@ vector<string> split_lines(const char* s) {
     }
   }
   return out;
+}
+
+NetDef parse_net(const void* bytes, size_t n) {
+  NetDef def;
+  CAFFE_ENFORCE(ParseNetDef(bytes, n, &def), "Cannot parse the serialized NetDef");
+  return def;
+}
+
+size_t pack_defs(const vector<OperatorDef>& ops, void* buf, size_t buflen, int* n_ops) {
+  string packed;
+  for (const OperatorDef& g : ops) {
+    const string s = SerializeOperatorDef(g);
+    const uint32_t len = (uint32_t)s.size();
+    packed.append((const char*)&len, 4);
+    packed += s;
+  }
+  if (n_ops) *n_ops = (int)ops.size();
+  if (buf && buflen >= packed.size() && !packed.empty()) memcpy(buf, packed.data(), packed.size());
+  return packed.size();
 }
 
 OperatorDef parse_def(const void* bytes, size_t n) {
@@ -193,6 +214,70 @@ int c2hip_run_operator(c2hip_operator* op, int sync) {
 }
 
 void c2hip_destroy_operator(c2hip_operator* op) { delete op; }
+
+int c2hip_create_net(c2hip_workspace* ws, const void* netdef_bytes, size_t n, int overwrite) {
+  return guarded([&] { ws->ws.CreateNet(parse_net(netdef_bytes, n), overwrite != 0); });
+}
+
+int c2hip_run_net(c2hip_workspace* ws, const char* name, int num_iter) {
+  return guarded([&] {
+    for (int i = 0; i < num_iter; ++i)
+      CAFFE_ENFORCE(ws->ws.RunNet(name), "Error running net ", name);
+  });
+}
+
+int c2hip_run_net_once(c2hip_workspace* ws, const void* netdef_bytes, size_t n) {
+  return guarded([&] {
+    // pybind_state.cc run_net_once -> Workspace::RunNetOnce: a temporary net, run, destroyed
+    std::unique_ptr<NetBase> net = CreateNet(parse_net(netdef_bytes, n), &ws->ws);
+    CAFFE_ENFORCE(net->Run(), "Error running net ", net->Name());
+  });
+}
+
+int c2hip_delete_net(c2hip_workspace* ws, const char* name) {
+  return guarded([&] { ws->ws.DeleteNet(name); });
+}
+
+size_t c2hip_nets(c2hip_workspace* ws, char* buf, size_t buflen) {
+  return join_to(ws->ws.Nets(), buf, buflen);
+}
+
+size_t c2hip_net_lowered_ops(c2hip_workspace* ws, const char* name, void* buf, size_t buflen, int* n_ops) {
+  size_t need = 0;
+  guarded([&] {
+    NetBase* net = ws->ws.GetNet(name);
+    CAFFE_ENFORCE(net != nullptr, "Network ", name, " does not exist yet.");
+    need = pack_defs(net->lowered_ops(), buf, buflen, n_ops);
+  });
+  return need;
+}
+
+size_t c2hip_lower_net(const void* netdef_bytes, size_t n, void* buf, size_t buflen, int* n_ops,
+                       char* report_buf, size_t report_buflen) {
+  size_t need = 0;
+  guarded([&] {
+    LoweringOptions opt;           // no dtype probe: filters are taken to be fp32
+    LoweringReport rep;
+    const NetDef def = parse_net(netdef_bytes, n);
+    for (const string& s : def.external_output) opt.keep.insert(s);
+    const vector<OperatorDef> ops = LowerNet(def, opt, &rep);
+    need = pack_defs(ops, buf, buflen, n_ops);
+    if (report_buf && report_buflen) {
+      const string r = rep.ToString();
+      const size_t m = r.size() < report_buflen - 1 ? r.size() : report_buflen - 1;
+      memcpy(report_buf, r.data(), m);
+      report_buf[m] = 0;
+    }
+  });
+  return need;
+}
+
+long long c2hip_counter(const char* name) {
+  const string n = name ? name : "";
+  if (n == "filter_packs") return g_filter_packs_issued.load();
+  if (n == "conv_launch_calls") return g_conv_launch_calls.load();
+  return -1;
+}
 
 size_t c2hip_registered_operators(int device_type, char* buf, size_t buflen) {
   size_t need = 0;

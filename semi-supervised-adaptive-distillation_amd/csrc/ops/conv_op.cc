@@ -5,56 +5,8 @@
 
 namespace caffe2 {
 
-// caffe2/operators/conv_pool_op_base.h:45-194, restated.
-ConvGeometry ParseConvGeometry(const OperatorBase& op) {
-  ConvGeometry g;
-  g.kernel = op.GetRepeatedArgument<int>("kernels");
-  g.stride = op.GetRepeatedArgument<int>("strides");
-  g.pads = op.GetRepeatedArgument<int>("pads");
-  g.dilation = op.GetRepeatedArgument<int>("dilations");
-  g.group = op.GetSingleArgument<int>("group", 1);
-  g.order = op.GetSingleArgument<string>("order", "NCHW");
-  const int legacy_pad = op.GetSingleArgument<int>("legacy_pad", 0);   // NOTSET
-  CAFFE_ENFORCE(legacy_pad == 0 || legacy_pad == 3,
-                "legacy padding VALID/SAME is not supported by the HIP conv operators");
-
-  auto pair_arg = [&](const char* single, const char* h, const char* w, vector<int>* out) {
-    if (op.HasArgument(single)) {
-      out->assign(2, op.GetSingleArgument<int>(single, 0));
-    } else if (op.HasArgument(h) && op.HasArgument(w)) {
-      out->push_back(op.GetSingleArgument<int>(h, 0));
-      out->push_back(op.GetSingleArgument<int>(w, 0));
-    }
-  };
-  pair_arg("kernel", "kernel_h", "kernel_w", &g.kernel);
-  pair_arg("stride", "stride_h", "stride_w", &g.stride);
-  pair_arg("dilation", "dilation_h", "dilation_w", &g.dilation);
-  if (op.HasArgument("pad")) {
-    g.pads.assign(4, op.GetSingleArgument<int>("pad", 0));
-  } else if (op.HasArgument("pad_t") && op.HasArgument("pad_l") && op.HasArgument("pad_b") &&
-             op.HasArgument("pad_r")) {
-    g.pads = {op.GetSingleArgument<int>("pad_t", 0), op.GetSingleArgument<int>("pad_l", 0),
-              op.GetSingleArgument<int>("pad_b", 0), op.GetSingleArgument<int>("pad_r", 0)};
-  }
-  if (g.kernel.empty()) g.kernel.assign(2, 0);
-  if (g.stride.empty()) g.stride.assign(g.kernel.size(), 1);
-  if (g.pads.empty()) g.pads.assign(g.kernel.size() * 2, 0);
-  if (g.dilation.empty()) g.dilation.assign(g.kernel.size(), 1);
-  CAFFE_ENFORCE_EQ(g.stride.size(), g.kernel.size());
-  CAFFE_ENFORCE_EQ(g.dilation.size(), g.kernel.size());
-  CAFFE_ENFORCE_EQ(g.pads.size(), 2 * g.kernel.size());
-  for (size_t d = 0; d < g.kernel.size(); ++d) {
-    CAFFE_ENFORCE_GE(g.pads[d], 0);
-    CAFFE_ENFORCE_GE(g.pads[g.kernel.size() + d], 0);
-    CAFFE_ENFORCE(g.kernel[d],
-                  "If you are doing convolution or pooling, you will need to set explicitly "
-                  "the kernel size.");
-    CAFFE_ENFORCE_GE(g.dilation[d], 0);
-    CAFFE_ENFORCE_GE(g.stride[d], 0);
-  }
-  CAFFE_ENFORCE(g.order == "NCHW" || g.order == "NHWC", "Unknown storage order: ", g.order);
-  return g;
-}
+ConvGeometry ParseConvGeometry(const OperatorBase& op) { return ParseConvGeometryFrom(op); }
+ConvGeometry ParseConvGeometry(const OperatorDef& def) { return ParseConvGeometryFrom(DefArgs(def)); }
 
 bool IsSubnetGeometry(const ConvGeometry& g) {
   return g.order == "NCHW" && g.group == 1 && g.kernel == vector<int>{3, 3} &&
@@ -135,18 +87,18 @@ bool ConvOp<float, HIPContext>::RunOnDevice() {
   ssad_conv_level lv{X.data<float>(), Y->mutable_data<float>(), nullptr, N, H, W, nullptr, nullptr};
   const int flags = fuse_relu_ ? SSAD_CONV_RELU : 0;
   int rc;
-  if (UseWinograd(algo_, M)) {
-    packed_filter_.Resize((TIndex)ssad_conv_wino_filter_floats(M, C));
-    float* packed = packed_filter_.mutable_data<float>();
-    CAFFE_ENFORCE_EQ(ssad_conv_wino_pack_filter(filter.data<float>(), M, C, packed, nullptr, s), 0);
-    rc = ssad_conv3x3_forward_wino(&lv, 1, packed, bias, M, C, flags, s);
-  } else {
-    packed_filter_.Resize((TIndex)ssad_conv_packed_filter_floats(M, C));
-    float* packed = packed_filter_.mutable_data<float>();
-    CAFFE_ENFORCE_EQ(ssad_conv_pack_filter(filter.data<float>(), M, C, packed, nullptr, s), 0);
-    rc = ssad_conv3x3_forward(&lv, 1, packed, bias, M, C, flags, s);
-  }
+  // the packed filter is rebuilt only when the filter blob was written since (ops/filter_pack_cache.h)
+  const bool wino = UseWinograd(algo_, M);
+  const auto kind = wino ? FilterPackCache::WINO_FWD : FilterPackCache::DIRECT_FWD;
+  const long long before = pack_cache_.packs_issued();
+  pack_cache_.Want(filter, kind);
+  pack_cache_.Flush(s);
+  g_filter_packs_issued += pack_cache_.packs_issued() - before;
+  const float* packed = pack_cache_.Packed(filter, kind);
+  rc = wino ? ssad_conv3x3_forward_wino(&lv, 1, packed, bias, M, C, flags, s)
+            : ssad_conv3x3_forward(&lv, 1, packed, bias, M, C, flags, s);
   CAFFE_ENFORCE_EQ(rc, 0, "Conv launch failed");
+  ++g_conv_launch_calls;
   return true;
 }
 
@@ -464,6 +416,7 @@ bool ConvGradientOp<float, HIPContext>::RunOnDevice() {
   int rc = ssad_conv3x3_wgrad(&wl, 1, dfilter->mutable_data<float>(), db, M, C, 0,
                               workspace_.mutable_data<uint8_t>(), wsb, s);
   CAFFE_ENFORCE_EQ(rc, 0, "ConvGradient (filter) launch failed");
+  ++g_conv_launch_calls;
 
   if (OutputSize() == 3 || (no_bias_ && OutputSize() == 2)) {
     auto* dX = Output(no_bias_ ? BIAS_OR_INPUT_GRAD : INPUT_GRAD);
@@ -471,18 +424,17 @@ bool ConvGradientOp<float, HIPContext>::RunOnDevice() {
     ssad_conv_level dl{dY.data<float>(), dX->mutable_data<float>(),
                        relu_grad_on_input_ ? X.data<float>() : nullptr, N, H, W, nullptr, nullptr};
     const int flags = relu_grad_on_input_ ? SSAD_CONV_MASK_AUX : 0;
-    if (UseWinograd(algo_, C)) {      // the data gradient has C output channels
-      packed_filter_.Resize((TIndex)ssad_conv_wino_filter_floats(C, M));
-      float* packed = packed_filter_.mutable_data<float>();
-      CAFFE_ENFORCE_EQ(ssad_conv_wino_pack_filter(filter.data<float>(), M, C, nullptr, packed, s), 0);
-      rc = ssad_conv3x3_forward_wino(&dl, 1, packed, nullptr, C, M, flags, s);
-    } else {
-      packed_filter_.Resize((TIndex)ssad_conv_packed_filter_floats(C, M));
-      float* packed = packed_filter_.mutable_data<float>();
-      CAFFE_ENFORCE_EQ(ssad_conv_pack_filter(filter.data<float>(), M, C, nullptr, packed, s), 0);
-      rc = ssad_conv3x3_forward(&dl, 1, packed, nullptr, C, M, flags, s);
-    }
+    const bool wino = UseWinograd(algo_, C);      // the data gradient has C output channels
+    const auto kind = wino ? FilterPackCache::WINO_DGRAD : FilterPackCache::DIRECT_DGRAD;
+    const long long before = pack_cache_.packs_issued();
+    pack_cache_.Want(filter, kind);
+    pack_cache_.Flush(s);
+    g_filter_packs_issued += pack_cache_.packs_issued() - before;
+    const float* packed = pack_cache_.Packed(filter, kind);
+    rc = wino ? ssad_conv3x3_forward_wino(&dl, 1, packed, nullptr, C, M, flags, s)
+              : ssad_conv3x3_forward(&dl, 1, packed, nullptr, C, M, flags, s);
     CAFFE_ENFORCE_EQ(rc, 0, "ConvGradient (data) launch failed");
+    ++g_conv_launch_calls;
   }
   return true;
 }
