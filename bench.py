@@ -348,6 +348,77 @@ def also_leg(dev, dom_klass, steps=5, warmup=2, **cfgkw):
         torch.cuda.empty_cache()
 
 
+def operator_surface_leg(dev, steps=5, warmup=2, N=16):
+    """The subnets' training iteration on the DROP-IN route: the reference's graph --
+    teacher net + student net with the 121 forward operators of retinanet_heads.py, their gradient operators,
+    one NCCLAllreduce per parameter (no-ops without a communicator) and optimizer.py's update operators --
+    created once by workspace.CreateNet from the serialized NetDefs and run with one workspace.RunNet per net
+    and iteration, as detectron/tools/train_net.py:165-189 does; bs 16, 600 px, FPN features / labels /
+    targets resident in workspace blobs.  Timed twice: the lowered nets (csrc/ops/net_lowering.cc; one
+    synchronisation per net) and the operator lists as written (`hip_lowering` = 0); beside them the same
+    iteration on the hand-built program (head_pipeline.DistillHeads, `bench.py --workload heads`)."""
+    import gc
+    from ssad_amd import synth
+    from ssad_amd.caffe2_hip import workspace
+    from ssad_amd.operator_surface import HeadsNetStep
+    from ssad_amd.modeling.retinanet_heads import HeadConfig
+    out = {"workload": "RetinaNet subnets (teacher + student) + PowSum + SigmoidAdaptiveDistillLoss + SigmoidFocalLoss + "
+                       "SelectSmoothL1Loss + backward + NCCLAllreduce + MomentumSGDUpdate as Caffe2-shaped nets: "
+                       "CreateNet once, RunNet(teacher) + RunNet(student) per iteration, through the C-ABI",
+           "batch_per_gpu": N, "fpn_levels": [list(s) for s in synth.LEVEL_SHAPES_600], "dtype": "f32",
+           "steps": steps, "warmup": warmup}
+    try:
+        for key, lowering in (("lowered", True), ("as_written", False)):
+            workspace.ResetWorkspace()
+            st = HeadsNetStep(HeadConfig(num_gpus=1), N=N, shapes=synth.LEVEL_SHAPES_600, update=True,
+                              lowering=lowering)
+            st.feed_params()
+            st.feed_synthetic()
+            st.create()
+            for _ in range(warmup):
+                st.step()
+            torch.cuda.synchronize()
+            p0, c0 = workspace.Counter("filter_packs"), workspace.Counter("conv_launch_calls")
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                st.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            low = st.lowered()
+            losses = st.losses()
+            out[key] = {"ms_per_step": round(dt / steps * 1e3, 3), "images_per_s": round(N * steps / dt, 2),
+                        "operators_written": st.total_ops, "operators_run": len(low["teacher"]) + len(low["student"]),
+                        "filter_packs_per_step": (workspace.Counter("filter_packs") - p0) / steps,
+                        "conv_launcher_calls_per_step": (workspace.Counter("conv_launch_calls") - c0) / steps,
+                        "distill_loss": [losses["fl_distill_fpn%d" % l] for l in st.levels],
+                        "finite": bool(np.all(np.isfinite(list(losses.values()))))}
+            del st
+            workspace.ResetWorkspace()
+        # the same iteration on the hand-built program, same sizes, same number of steps (bench.py --workload heads)
+        a = argparse.Namespace(workload="heads", backbone="auto", student="r50", teacher="r101", px=600,
+                               precision="f32", batch_per_gpu=N)
+        W = make_workload(a, dev, 1, None, 0)
+        try:
+            for _ in range(warmup):
+                W["step"]()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                W["step"]()
+            torch.cuda.synchronize()
+            prog = (time.perf_counter() - t0) / steps * 1e3
+        finally:
+            W.clear()
+        out["program_ms_per_step"] = round(prog, 3)
+        out["lowered_over_program"] = round(out["lowered"]["ms_per_step"] / prog, 3)
+        out["as_written_over_program"] = round(out["as_written"]["ms_per_step"] / prog, 3)
+        return out
+    finally:
+        workspace.ResetWorkspace()
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) of this
     same script under torch.distributed.run on the loopback rendezvous -- the command the driver
@@ -589,10 +660,15 @@ def main():
                     also[key] = also_leg(dev, kl, **kw)
                 except Exception as e:      # never lose the headline line to a side leg
                     also[key] = {"error": repr(e)}
+            try:
+                also["operator_surface"] = operator_surface_leg(dev)
+            except Exception as e:
+                also["operator_surface"] = {"error": repr(e)}
             out["also"] = also
             out["also_note"] = ("other BASELINE configs on the same GPU, each built from scratch and run for a few "
-                                "steps AFTER the timed region of the headline; `value` / `ms_per_step` above are "
-                                "config 3 only")
+                                "steps AFTER the timed region of the headline, on the same high-priority stream; "
+                                "`value` / `ms_per_step` above are config 3 only.  operator_surface = the subnets' "
+                                "iteration through workspace.CreateNet / RunNet (the drop-in route) beside the program")
         # the ONE result line, last on rank 0's stdout (with NCCL_DEBUG=VERSION in the environment
         # RCCL prints its version banner to stdout when the communicator is created, i.e. earlier)
         # ... into C stdio's buffer, which is flushed at process exit, i.e. AFTER anything Python prints: measured on

@@ -117,6 +117,27 @@ class HeadsNetStep(object):
         workspace.RunNet(self.teacher.net, sync_every_op=sync_every_op)
         workspace.RunNet(self.student.net, sync_every_op=sync_every_op)
 
+    # -- learning rate (detector.py:594-648) -------------------------------------------------------
+    SCALE_MOMENTUM = True                 # config.py:634
+    SCALE_MOMENTUM_THRESHOLD = 1.1        # config.py:638
+
+    def update_lr(self, new_lr):
+        """UpdateWorkspaceLr + _SetNewLr + _CorrectMomentum: the workspace's `lr` blob is the one source
+        of truth; when it changes by more than the threshold every `<param>_momentum` is rescaled by
+        new / old with one Scale operator per parameter (RunOperatorOnce), as the reference does."""
+        cur_lr = np.float32(workspace.FetchBlob("lr")[0])
+        new_lr = np.float32(new_lr)
+        if cur_lr != new_lr:
+            with core.DeviceScope(self.dev):
+                workspace.FeedBlob("lr", np.array([new_lr], np.float32))
+                eps = 1e-10
+                ratio = max(new_lr / max(cur_lr, eps), cur_lr / max(new_lr, eps))
+                if self.SCALE_MOMENTUM and cur_lr > 1e-7 and ratio > self.SCALE_MOMENTUM_THRESHOLD:
+                    for p in opt.trainable_params(self.student):
+                        workspace.RunOperatorOnce(core.CreateOperator(
+                            "Scale", [p + "_momentum"], [p + "_momentum"], scale=float(new_lr / cur_lr)))
+        return new_lr
+
     def lowered(self):
         return {"teacher": workspace.LoweredOps(self.teacher.net), "student": workspace.LoweredOps(self.student.net)}
 
