@@ -187,6 +187,15 @@ class NativeResNetFPN(object):
         else:
             sd = src if isinstance(src, dict) else src.state_dict()
             sd = {k: v.detach() for k, v in sd.items()}
+            if any((l.name + ".weight") not in sd for l in L.values()):
+                # a weights file that holds only part of the network (the reference's standard TRAIN.WEIGHTS
+                # is an ImageNet body without fpn_* / retnet_* blobs): what it lacks keeps the initialisation
+                init_sd, init_scales = self._default_init()
+                for l in L.values():
+                    if (l.name + ".weight") not in sd:
+                        sd[l.name + ".weight"], sd[l.name + ".bias"] = init_sd[l.name + ".weight"], init_sd[l.name + ".bias"]
+                        if l.name in init_scales:
+                            scales.setdefault(l.name, init_scales[l.name])
         # the folded scales as given (utils/net.py writes them back as <conv>_bn_s when saving)
         self.affine_scale_values = {k: torch.as_tensor(v, dtype=torch.float32).reshape(-1).cpu().clone()
                                     for k, v in scales.items() if k in L and L[k].affine}
@@ -241,14 +250,18 @@ class NativeResNetFPN(object):
             l.w.copy_(sd[l.name + ".weight"].to(device=dev, dtype=torch.float32))
             l.b.copy_(sd[l.name + ".bias"].to(device=dev, dtype=torch.float32))
 
-    def load_from(self, src, affine_scales=None):
+    def load_from(self, src, affine_scales=None, strict=True):
         """Copy parameters from a {name.weight / name.bias: tensor} dict or a module with such a
-        state_dict() (filters with the AffineChannel scale folded in).  affine_scales: {layer: s} of
+        state_dict() (filters with the AffineChannel scale folded in).  strict=False: a layer the
+        dict does not hold keeps its current values (detectron/lib/utils/net.py:96-99 logs
+        "<name> not found" and leaves the initialised blob alone).  affine_scales: {layer: s} of
         the folded scales when they differ from the ones the network was built with -- the update of
         a trainable folded filter multiplies its gradient rows by s^2 (see the module docstring), so
         the network needs a scale slot for that layer (built with src= / affine_scales=)."""
         sd = src if isinstance(src, dict) else src.state_dict()
         for l in self._layers.values():
+            if not strict and (l.name + ".weight") not in sd:
+                continue
             l.w.copy_(sd[l.name + ".weight"].detach().to(device=self.device, dtype=torch.float32))
             l.b.copy_(sd[l.name + ".bias"].detach().to(device=self.device, dtype=torch.float32))
         if affine_scales is not None:
@@ -736,7 +749,20 @@ class NativeResNetFPN(object):
         self.prog.run("sgd", "end", timing=self.timing)
 
     def broadcast_params(self, src=0):
-        self.dp.broadcast([self.params_flat, self.moms_flat], src=src)
+        """detectron/lib/utils/net.py:185-208 broadcasts every blob of model.params from GPU 0: here the
+        trained parameters and their history, the FROZEN values (conv1 / res2 filters, every folded
+        AffineChannel bias) and the s^2 row scales of the folded trainable filters -- a replica that
+        did not load the weights file itself must not keep its own initialisation in any of them.
+        The un-folded scales kept for saving (`affine_scale_values`, host side) follow as an object."""
+        if not self.dp.active:
+            return
+        slots = [l.s2 for l in self._layers.values() if l.s2 is not None]
+        self.dp.broadcast([self.params_flat, self.moms_flat, self.frozen_flat] + slots, src=src)
+        import torch.distributed as dist
+        box = [self.affine_scale_values]
+        dist.broadcast_object_list(box, src=src, group=self.dp.pg)
+        self.affine_scale_values = box[0]
+        self._packed_frozen = False
 
     SCALE_MOMENTUM = True             # cfg.SOLVER.SCALE_MOMENTUM (config.py:634)
     SCALE_MOMENTUM_THRESHOLD = 1.1    # config.py:638
@@ -788,13 +814,17 @@ class NativeDistillModel(object):
                 heads_io=dict(fpn_out=heads.in_blk["student"], inv_scale=heads.ls_state[1:2],
                               d_fpn_in=(heads.dbuf["cls"][0], heads.dbuf["bbox"][0])), **kw)
             self.teacher = NativeResNetFPNF16(
-                teacher_arch, N, image_hw, device, train=False, src=teacher_src,
-                heads_io=dict(fpn_out=heads.in_blk["teacher"])) if self.has_teacher else None
+                teacher_arch, N, image_hw, device, train=False, src=teacher_src, process_group=process_group,
+                world_size=world_size, heads_io=dict(fpn_out=heads.in_blk["teacher"])) if self.has_teacher else None
         else:
             self.student = NativeResNetFPN(student_arch, N, image_hw, device, train=True, src=student_src, **kw)
-            self.teacher = NativeResNetFPN(teacher_arch, N, image_hw, device, train=False,
-                                           src=teacher_src) if self.has_teacher else None
+            self.teacher = NativeResNetFPN(teacher_arch, N, image_hw, device, train=False, src=teacher_src,
+                                           process_group=process_group,
+                                           world_size=world_size) if self.has_teacher else None
+        # every replica starts from rank 0's values: trained AND frozen (utils/net.py:185-208)
         self.student.broadcast_params()
+        if self.teacher is not None:
+            self.teacher.broadcast_params()
         if two_streams is None:
             two_streams = os.environ.get("SSAD_NATIVE_TWO_STREAMS", "1") == "1"
         self.side = torch.cuda.Stream() if (two_streams and self.has_teacher) else None      # normal priority: high measured worse

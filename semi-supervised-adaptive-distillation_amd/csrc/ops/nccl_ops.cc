@@ -34,6 +34,7 @@ struct Rccl {
   int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  std::string load_error;     // why the library or a symbol is missing, captured once
 };
 
 Rccl& rccl() {
@@ -43,17 +44,28 @@ Rccl& rccl() {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (r.lib) break;
+      const char* e = dlerror();          // dlerror() clears itself: read it once, keep the text
+      r.load_error += std::string(r.load_error.empty() ? "" : "; ") + (e ? e : name);
     }
     if (!r.lib) return;
-    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
-    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
-    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
-    r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
-    r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
-    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    r.load_error.clear();
+    auto sym = [&](const char* n) {
+      void* p = dlsym(r.lib, n);
+      if (!p) {
+        const char* e = dlerror();
+        r.load_error += std::string(r.load_error.empty() ? "" : "; ") + (e ? e : n);
+      }
+      return p;
+    };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+    r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
   });
   CAFFE_ENFORCE(r.lib && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.Broadcast,
-                "RCCL (librccl.so.1) could not be loaded: ", dlerror() ? dlerror() : "missing symbol");
+                "RCCL (librccl.so.1) could not be loaded: ", r.load_error.empty() ? "missing symbol" : r.load_error);
   return r;
 }
 
@@ -178,11 +190,18 @@ int c2hip_comm_init(const void* id, size_t nbytes, int world, int rank, int devi
     std::lock_guard<std::mutex> g(comm_mutex());
     Comm& c = comm();
     CAFFE_ENFORCE(!c.comm, "c2hip_comm_init: this process already has a communicator (c2hip_comm_destroy first)");
+    int previous = 0;
+    HIP_ENFORCE(hipGetDevice(&previous));
     HIP_ENFORCE(hipSetDevice(device_id));
     UniqueId u;
     memcpy(&u, id, sizeof(u));
     ncclComm_t nc = nullptr;
-    RCCL_ENFORCE(rccl().CommInitRank(&nc, world, u, rank));
+    try {
+      RCCL_ENFORCE(rccl().CommInitRank(&nc, world, u, rank));
+    } catch (...) {
+      (void)hipSetDevice(previous);     // a failed init leaves the caller's device selection alone
+      throw;
+    }
     c.comm = nc; c.world = world; c.rank = rank; c.device = device_id;
   });
 }

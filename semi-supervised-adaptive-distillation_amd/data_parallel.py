@@ -56,7 +56,8 @@ class BucketedAllReduce(object):
             return
         import torch.distributed as dist
         for t in tensors:
-            dist.broadcast(t, src=src, group=self.pg)
+            if t.numel():
+                dist.broadcast(t, src=src, group=self.pg)
 
 
 class GradBuckets(object):

@@ -571,8 +571,16 @@ class DistillHeads(object):
         self.dp.wait()
 
     def broadcast_params(self, src=0):
-        """Initial parameter sync (detectron/lib/utils/net.py:185-208)."""
-        self.dp.broadcast([self.params.flat, self.moms.flat], src=src)
+        """Initial parameter sync (detectron/lib/utils/net.py:185-208 walks all of model.params, which in a
+        distillation model holds the teacher's blobs too): student parameters, their history and the frozen
+        teacher's parameters."""
+        if not self.dp.active:
+            return
+        tensors = [self.params.flat, self.moms.flat]
+        if self.teacher is not None:
+            tensors.append(self.teacher.flat)
+            self._teacher_packed = False         # repack from the received values
+        self.dp.broadcast(tensors, src=src)
 
     # -- learning rate (detector.py:594-648) ------------------------------------------
     SCALE_MOMENTUM = True             # cfg.SOLVER.SCALE_MOMENTUM (config.py:634)

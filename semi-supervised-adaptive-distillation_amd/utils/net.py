@@ -214,8 +214,13 @@ def backbone_from_blobs(blobs, arch, prefix="", strict=True):
         if sn is not None:
             sc = torch.as_tensor(np.asarray(blobs[prefix + sn], dtype=np.float32)).reshape(-1)
             if sc.numel() != w.shape[0] or b.numel() != w.shape[0]:
-                raise ValueError("%s: AffineChannel blobs of %d / %d channels for a filter with %d outputs" % (
-                    prefix + wn, sc.numel(), b.numel(), w.shape[0]))
+                msg = "%s: AffineChannel blobs of %d / %d channels for a filter with %d outputs" % (
+                    prefix + wn, sc.numel(), b.numel(), w.shape[0])
+                if strict:
+                    raise ValueError(msg)
+                logger.info("Shape missmatch: %s", msg)      # net.py:106-119: reported and skipped
+                missing += [prefix + n for n in need]
+                continue
             scales[layer] = sc
             w = w * sc.view(-1, 1, 1, 1)
         state[layer + ".weight"], state[layer + ".bias"] = w, b
@@ -228,18 +233,38 @@ def backbone_from_blobs(blobs, arch, prefix="", strict=True):
     return state, scales, moms, missing
 
 
-def load_backbone(net, blobs, prefix="", load_momentum=True):
+def load_backbone(net, blobs, prefix="", load_momentum=True, strict=False):
     """Feed an existing NativeResNetFPN / NativeResNetFPNF16 from a Detectron blob dict (the
     network must have been built with per-layer scale slots: src= / affine_scales= given, which
-    the constructors of this module's callers do).  Remembers the scale blobs for saving."""
-    state, scales, moms, _ = backbone_from_blobs(blobs, net.arch, prefix)
+    the constructors of this module's callers do).  Remembers the scale blobs for saving.
+
+    strict=False is the reference's behaviour (net.py:96-99, :106-119): a layer whose blobs the file
+    does not hold is logged as "<name> not found" and keeps its initialised filter, bias and scale slot;
+    a blob of another shape is logged and skipped the same way.  The names are left in
+    `net.missing_blobs`.  strict=True raises KeyError / ValueError instead (a body with holes computes
+    garbage unless the caller meant it: the reference's standard TRAIN.WEIGHTS is an ImageNet body that
+    holds no fpn_* blob)."""
+    state, scales, moms, missing = backbone_from_blobs(blobs, net.arch, prefix, strict=strict)
+    for n in missing:
+        logger.info("%s not found", n)
+    names = backbone_blob_names(net.arch)
     for name, layer in net._layers.items():
+        if name + ".weight" not in state:
+            continue
         want = tuple(state[name + ".weight"].shape)
         have = (layer.cout, layer.wcin, layer.k, layer.k)
         if want != have:
-            raise ValueError("%s: filter blob %s of shape %s, the %s network has %s" % (
-                name, backbone_blob_names(net.arch)[name][0], want, net.arch, have))
-    net.load_from(state, affine_scales=scales)
+            if strict:
+                raise ValueError("%s: filter blob %s of shape %s, the %s network has %s" % (
+                    name, names[name][0], want, net.arch, have))
+            logger.info("Shape missmatch: name: %s src: %s, dst: %s", prefix + names[name][0], want, have)
+            missing += [prefix + n for n in names[name] if n is not None]
+            for d in (state, moms):
+                d.pop(name + ".weight", None)
+                d.pop(name + ".bias", None)
+            scales.pop(name, None)
+    net.missing_blobs = list(missing)
+    net.load_from(state, affine_scales=scales, strict=strict)
     if load_momentum and net.train and moms:
         for name, layer in net._layers.items():
             if not layer.train:
@@ -292,11 +317,13 @@ def backbone_to_blobs(net, prefix="", momentum=True):
 
 
 def native_model_from_weights_files(heads, weights_file, teacher_weights_file=None, student_arch="r50",
-                                    teacher_arch="r101", **model_kw):
+                                    teacher_arch="r101", strict=False, **model_kw):
     """initialize_from_weights_file (net.py:50-147) for the whole detector: builds a
     backbone_pipeline.NativeDistillModel whose backbones AND subnets hold the weights of
     `weights_file` (student; its `teacher/` blobs or `teacher_weights_file` for the teacher:
-    net.py:71-78), momentum included.  -> (model, loaded names, missing names)"""
+    net.py:71-78), momentum included.  Blobs the file lacks keep the model's initialisation and are
+    returned in `missing`, as the reference does (an ImageNet body-only R-50.pkl is the standard
+    TRAIN.WEIGHTS); strict=True raises on the first hole.  -> (model, loaded names, missing names)"""
     from ..backbone_pipeline import NativeDistillModel
     src, _ = _blobs_and_cfg(load_object(weights_file))
     src = dict(src)
@@ -304,31 +331,37 @@ def native_model_from_weights_files(heads, weights_file, teacher_weights_file=No
         tsrc, _ = _blobs_and_cfg(load_object(teacher_weights_file))
         for k, v in tsrc.items():
             src["teacher/" + k] = v
-    s_state, s_scales, _, _ = backbone_from_blobs(src, student_arch)
+    s_state, s_scales, _, _ = backbone_from_blobs(src, student_arch, strict=strict)
     has_teacher = teacher_arch not in (None, "none")
     t_state = t_scales = None
     if has_teacher:
-        t_state, t_scales, _, _ = backbone_from_blobs(src, teacher_arch, "teacher/")
+        t_state, t_scales, _, _ = backbone_from_blobs(src, teacher_arch, "teacher/", strict=strict)
     model = NativeDistillModel(heads, student_arch, teacher_arch if has_teacher else None, student_src=s_state,
                                teacher_src=t_state, student_scales=s_scales, **model_kw)
-    loaded, missing = initialize_from_blobs(model, src)
+    loaded, missing = initialize_from_blobs(model, src, strict=strict)
     return model, loaded, missing
 
 
-def initialize_from_blobs(model, src):
+def initialize_from_blobs(model, src, strict=False):
     """Feed a built NativeDistillModel (subnets + both backbones) from a blob dict that already
-    carries the teacher under `teacher/`."""
+    carries the teacher under `teacher/`.  strict: see load_backbone."""
     loaded, missing = _initialize_heads(model.heads, src)
-    load_backbone(model.student, src, "")
-    loaded += [n for t in backbone_blob_names(model.student.arch).values() for n in t if n is not None]
-    if model.teacher is not None:
-        load_backbone(model.teacher, src, "teacher/", load_momentum=False)
-        loaded += ["teacher/" + n for t in backbone_blob_names(model.teacher.arch).values() for n in t if n is not None]
+    nets = [(model.student, "")] + ([(model.teacher, "teacher/")] if model.teacher is not None else [])
+    for net, prefix in nets:
+        load_backbone(net, src, prefix, load_momentum=not prefix, strict=strict)
+        gone = set(net.missing_blobs)
+        missing += net.missing_blobs
+        loaded += [prefix + n for t in backbone_blob_names(net.arch).values() for n in t
+                   if n is not None and prefix + n not in gone]
     owned = set(loaded) | set(n + "_momentum" for n in loaded)
     for k in list(model.heads.preserved):
         if k in owned:
             del model.heads.preserved[k]          # the backbones own these now
-    # rank 0's loaded state is what every replica starts from (net.py:185-208 broadcast_parameters)
+    # rank 0's loaded state is what every replica starts from (net.py:185-208 broadcast_parameters walks all of
+    # model.params): trained parameters and history, the frozen values and s^2 slots of the student's backbone,
+    # the whole frozen teacher -- subnets and backbone
     model.heads.broadcast_params()
     model.student.broadcast_params()
+    if model.teacher is not None:
+        model.teacher.broadcast_params()
     return loaded, missing

@@ -245,3 +245,82 @@ def test_backbone_fold_and_unfold_round_trip_cpu():
     from ssad_amd.kernels import KernelError
     with pytest.raises(KernelError):
         net.load_backbone(rnd, blobs)
+
+
+def test_body_only_weights_file_loads_like_the_reference_cpu():
+    """the reference's standard TRAIN.WEIGHTS is an ImageNet body (R-50.pkl: conv1 / res* blobs, no
+    fpn_* / retnet_*).  initialize_gpu_from_weights_file logs '<name> not found' and keeps the initialised
+    value (net.py:96-99); so does load_backbone(strict=False): the body is loaded, every FPN layer keeps its
+    initialisation and its names come back as missing; a blob of another shape is skipped the same way;
+    strict=True raises."""
+    from ssad_amd.backbone_pipeline import NativeResNetFPN
+    rng = np.random.default_rng(5)
+    blobs, _ = reference_backbone_blobs("r50", rng)
+    body = OrderedDict((k, v) for k, v in blobs.items() if not k.startswith("fpn_"))
+    assert len(body) < len(blobs) and "conv1_w" in body
+    state, scales, moms, missing = net.backbone_from_blobs(body, "r50", strict=False)
+    assert "lat.0.weight" not in state and "fpn_6_w" in missing and "res5_2_branch2c_w" not in missing
+    nat = NativeResNetFPN("r50", 1, (128, 128), "cpu", train=True, src=state, affine_scales=scales)
+    fpn_before = {n: nat._layers[n].w.clone() for n in ("lat.0", "out.2", "p6", "p7")}
+    assert all(torch.isfinite(v).all() and float(v.abs().max()) > 0 for v in fpn_before.values())
+    net.load_backbone(nat, body)                                   # default: the reference's behaviour
+    assert sorted(nat.missing_blobs) == sorted(k for k in blobs if k.startswith("fpn_") and not k.endswith("_momentum"))
+    for n, v in fpn_before.items():
+        assert torch.equal(nat._layers[n].w, v)                   # kept
+    sc = body["res4_1_branch2b_bn_s"]
+    assert np.array_equal(nat._layers["res4.1.c2"].w.numpy(), body["res4_1_branch2b_w"] * sc.reshape(-1, 1, 1, 1))
+    assert np.allclose(nat._layers["res4.1.c2"].s2.numpy(), sc * sc, rtol=1e-6)
+    with pytest.raises(KeyError):
+        net.load_backbone(nat, body, strict=True)
+    # a filter of another shape: logged and skipped (net.py:106-119), the layer keeps what it had
+    odd = OrderedDict(body)
+    odd["res3_0_branch2a_w"] = np.zeros((64, 256, 1, 1), np.float32)
+    kept = nat._layers["res3.0.c1"].w.clone()
+    net.load_backbone(nat, odd)
+    assert "res3_0_branch2a_w" in nat.missing_blobs and torch.equal(nat._layers["res3.0.c1"].w, kept)
+    with pytest.raises((ValueError, KeyError)):
+        net.load_backbone(nat, odd, strict=True)
+
+
+def _bcast_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssad_amd.backbone_pipeline import NativeResNetFPN
+    blobs, _ = reference_backbone_blobs("r50", np.random.default_rng(6))
+    state, scales, _, _ = net.backbone_from_blobs(blobs, "r50")
+    ones = {k: torch.ones_like(v) for k, v in scales.items()}
+    kw = dict(process_group=dist.group.WORLD, world_size=world)
+    # rank 0 holds the file's weights; rank 1 was built from something else (slots present, other values)
+    student = NativeResNetFPN("r50", 1, (128, 128), "cpu", train=True, src=state if rank == 0 else
+                              {k: torch.zeros_like(v) for k, v in state.items()},
+                              affine_scales=scales if rank == 0 else ones, **kw)
+    teacher = NativeResNetFPN("r50", 1, (128, 128), "cpu", train=False, src=state if rank == 0 else None, **kw)
+    if rank == 0:
+        student.moms_flat.normal_(generator=torch.Generator().manual_seed(1))
+    student.broadcast_params()
+    teacher.broadcast_params()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), params=student.params_flat.numpy(),
+             moms=student.moms_flat.numpy(), frozen=student.frozen_flat.numpy(),
+             s2=student._layers["res4.1.c2"].s2.numpy(), t_frozen=teacher.frozen_flat.numpy(),
+             aff=student.affine_scale_values["res4.1.c2"].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_covers_frozen_values_scale_slots_and_teacher_gloo():
+    """broadcast_parameters covers all of model.params (net.py:185-208).  A replica that did not
+    load the file must end with rank 0's frozen filters / folded biases, s^2 row scales and teacher."""
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_bcast_worker, args=(2, port, d), nprocs=2, join=True)
+        r = [np.load(os.path.join(d, "rank%d.npz" % i)) for i in range(2)]
+    for k in ("params", "moms", "frozen", "s2", "t_frozen", "aff"):
+        assert np.array_equal(r[0][k], r[1][k]), k
+    assert np.any(r[0]["frozen"] != 0) and np.any(r[0]["moms"] != 0) and np.any(r[0]["s2"] != 1)

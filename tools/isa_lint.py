@@ -79,10 +79,10 @@ def lint(lines):
             m = re.match(r"ds_read_b64_tr_b16\s+(v\[\d+:\d+\]),", code)
             if m:
                 owned_ds |= expand(m.group(1))
-            if code.startswith("s_waitcnt") and "lgkmcnt(0)" in code:
+            if code.startswith("s_waitcnt") and re.search(r"\blgkmcnt\(0\)", code):
                 owned_ds.clear()          # the hand-written wait: LDS reads have returned
-            if code.startswith("s_waitcnt") and "vmcnt(0)" in code:
-                owned.clear()
+            if code.startswith("s_waitcnt") and re.search(r"\bvmcnt\(0\)", code):
+                owned.clear()             # exactly vmcnt(0): a wait on any other count frees nothing here
             continue
         if len(parts) < 2:
             continue
