@@ -112,22 +112,47 @@ def kernel_report(classes, steps):
     return out
 
 
+# which kernel source a timing class's dominant kernel lives in (for the staleness check of `traffic`)
+_KERNEL_SOURCE = {"wino_conv_z_kernel": "conv3x3_winograd.hip", "wino_wgrad_kernel": "conv3x3_wgrad_winograd.hip",
+                  "pow_sum_kernel": "distill_loss.hip", "cls_losses_fused_kernel": "distill_loss.hip",
+                  "sgd_flat_kernel": "elementwise.hip"}
+
+
 def pmc_traffic(klass):
     """HBM bytes per launch of one timing class from the committed counter passes over THIS
     command's launches (profiles/rNN_pmc_classes.json: tools/profile_round.sh runs separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --workload heads` and
     tools/pmc_by_class.py attributes the dispatches to classes; read side x 2, the gfx950
-    correction calibrated in profiles/r02_pmc_fetch_calib.md).  -> (bytes or None, note)"""
+    correction calibrated in profiles/r02_pmc_fetch_calib.md).  It is a builder-side capture by
+    construction (counters need rocprofv3 around the process), so the line says which round's capture it is
+    (`traffic_from_profile_round`) and the figure is WITHHELD -- None, with a warning on stderr -- when the
+    capture records the hashes of the kernel sources it ran (r05 onwards) and the class's source has changed
+    since.  -> (bytes or None, note, round tag)"""
     try:
         import glob
+        import hashlib
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_classes.json")))
-        e = json.load(open(files[-1]))["classes"].get(str(klass))
+        doc = json.load(open(files[-1]))
+        tag = os.path.basename(files[-1]).split("_")[0]
+        e = doc["classes"].get(str(klass))
         if not e or "hbm_bytes" not in e:
-            return None, None
-        return int(e["hbm_bytes"]), ("2 x FETCH_SIZE + WRITE_SIZE per dispatch of this class, separate rocprofv3 "
-                                     "--pmc passes over bench.py --workload heads (%s)" % os.path.basename(files[-1]))
+            return None, None, tag
+        src = _KERNEL_SOURCE.get(e.get("kernel", ""))
+        recorded = (doc.get("kernel_sources") or {}).get(src) if src else None
+        note = ("2 x FETCH_SIZE + WRITE_SIZE per dispatch of this class, separate rocprofv3 "
+                "--pmc passes over bench.py --workload heads (%s)" % os.path.basename(files[-1]))
+        if recorded is None:
+            return int(e["hbm_bytes"]), note + "; the capture predates source hashes (not verifiable against this build)", tag
+        path = os.path.join(ROOT, "semi-supervised-adaptive-distillation_amd", "csrc", "kernels", src)
+        now = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+        if now != recorded:
+            sys.stderr.write("bench.py: profiles/%s was captured on another version of %s (%s then, %s now): "
+                             "`traffic` of class %s withheld; re-run tools/profile_round.sh\n"
+                             % (os.path.basename(files[-1]), src, recorded, now, klass))
+            return None, "STALE: %s changed since %s was captured; traffic withheld" % (src, os.path.basename(files[-1])), tag
+        return int(e["hbm_bytes"]), note + "; kernel source %s unchanged since the capture" % src, tag
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def cpu_reference_conv(budget_s=25.0):
@@ -496,6 +521,8 @@ def main():
     heads.timing = timing
     if args.workload == "full":
         model.timing = timing
+    from ssad_amd.data_parallel import BucketedAllReduce
+    coll0 = BucketedAllReduce.issued_total
     t0 = time.perf_counter()
     host = 0.0                      # time the launching thread spends inside step()
     for _ in range(args.steps):
@@ -507,6 +534,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    collectives_per_step = (BucketedAllReduce.issued_total - coll0) / float(args.steps)
     # every family, in `args.profile_steps` instrumented steps outside the timed region (all ranks:
     # the steps contain collectives)
     timing_all = PR.Timing()
@@ -554,7 +582,7 @@ def main():
         by = {r["class"]: r for r in kernel_report(timing.collect(), args.steps)}     # the timed region
         dom_k = 34 if f16 else (2 if 2 in by else 18)
         dom = by.get(dom_k)
-        traffic, traffic_note = pmc_traffic(dom_k) if not f16 else (None, None)
+        traffic, traffic_note, traffic_round = pmc_traffic(dom_k) if not f16 else (None, None, None)
         # algorithmic HBM bytes of one launch of the dominant class: the four towers' inputs + outputs of
         # all levels + the packed filters, each once (fp32)
         px = N * sum(h * w for h, w in shapes)
@@ -582,6 +610,9 @@ def main():
             "config": {"workload": wl, "batch_per_gpu": N, "image": "3x%dx%d" % image_hw,
                        "fpn_levels": [list(s) for s in shapes], "anchors": 9, "classes": 80,
                        "parallelism": "dp%d" % world,
+                       # bucket all-reduces this rank started per timed step (RCCL; 0 on one GPU unless
+                       # SSAD_DP_FORCE=1 forces them onto a one-rank communicator)
+                       "collectives_per_step": collectives_per_step,
                        "schedule": ("one process, HIP streams: student on the main stream%s, filter gradients on "
                                     "auxiliary streams, frozen teacher on a side stream" % (
                                         " (high priority)" if _prio < 0 else "") + (
@@ -598,6 +629,7 @@ def main():
             # the dominant kernel: frac = EXECUTED MFMA flops / dense peak (a hardware fraction)
             "roofline": dict(kernel=dom["kernel"], bound="mfma", achieved=dom["achieved"], peak=dom["peak"],
                              unit="TFLOP/s", frac=dom["frac"], traffic=traffic, traffic_note=traffic_note,
+                             traffic_from_profile_round=traffic_round,
                              algorithmic_bytes=dom_alg_bytes,
                              traffic_over_algorithmic=(round(traffic / dom_alg_bytes, 2)
                                                        if (traffic and dom_alg_bytes) else None),
@@ -618,11 +650,11 @@ def main():
         for key, k in (("roofline_loss", 9 if distill else 15), ("roofline_pow_sum", 8)):
             r = by.get(k)
             if r:
-                tr, tnote = pmc_traffic(k) if not f16 else (None, None)
+                tr, tnote, tround = pmc_traffic(k) if not f16 else (None, None, None)
                 out[key] = dict(kernel=r["kernel"], bound="hbm", achieved=r["achieved"], peak=r["peak"],
                                 unit="GB/s", frac=r["frac"], launches_per_step=r["launches_per_step"],
                                 avg_launch_ms=r["avg_launch_ms"], bytes_per_launch=r["bytes_per_launch"],
-                                traffic=tr, traffic_note=tnote,
+                                traffic=tr, traffic_note=tnote, traffic_from_profile_round=tround,
                                 traffic_over_algorithmic=(round(tr / r["bytes_per_launch"], 3) if tr else None))
         if not args.no_cpu_baseline and world == 1 and distill:     # rank 0 at N=1 only
             cb = cpu_baseline(args, cfg)

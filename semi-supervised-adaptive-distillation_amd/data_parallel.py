@@ -20,6 +20,8 @@ import torch
 
 
 class BucketedAllReduce(object):
+    issued_total = 0        # collectives started by every instance of this process (bench.py reports the rate)
+
     def __init__(self, process_group=None, world_size=1):
         self.pg = process_group
         self.world_size = world_size
@@ -43,6 +45,7 @@ class BucketedAllReduce(object):
         # orders later kernels after it.
         self._pending.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg,
                                              async_op=True))
+        BucketedAllReduce.issued_total += 1
 
     def wait(self):
         for w in self._pending:

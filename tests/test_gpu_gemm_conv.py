@@ -256,3 +256,54 @@ def test_general_gemm_matches_float64(K, ta, tb):
     assert rc == 0
     got = Cm[:, :, :N].double()
     assert float((got - want * (1.0 / 1.5)).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("shape", [
+    (16, 256, 64, 160, 224),     # res2 c1 at config 3's real size: the HBM-bound 64-wide-output tile
+    (16, 1024, 256, 40, 56),     # res4 c1: 560 tiles of 128 x 128 (the workgroup-quantisation case of DESIGN 3.5)
+    (16, 512, 2048, 20, 28),     # res5 c3: P = 560 does not fill the last 128-column tile of an image
+], ids=lambda s: "N%d_C%d_M%d_%dx%d" % s)
+def test_gemm_conv_full_size_vs_oracle_and_adjoints(K, shape):
+    """the pointwise GEMM kernels at the backbone's REAL bs-16 shapes (640 x 896 input)
+    against the oracle, as test_default_engine_headline_size_vs_oracle_and_adjoints does for the 3x3 engines:
+    forward (bias + shortcut + ReLU) and data gradient (mask) of one image of the bs-16 launch against
+    oracle.conv_forward / conv_backward; the filter gradient by linearity (only image n0's dY non-zero in the
+    bs-16 launch); and the three adjoint identities over the whole batch."""
+    N, Cin, M, H, W = shape
+    n0 = 9
+    gen = torch.Generator(device="cuda").manual_seed(sum(shape))
+    X = torch.randn((N, Cin, H, W), device="cuda", generator=gen)
+    dY = torch.randn((N, M, H, W), device="cuda", generator=gen)
+    Wt = torch.randn((M, Cin, 1, 1), device="cuda", generator=gen) * float(1.0 / np.sqrt(Cin))
+    b = torch.randn(M, device="cuda", generator=gen)
+    wt = K.transpose_filter(Wt)
+    Y = K.conv1x1_forward(X, wt, M, b)
+    dX = K.conv1x1_dgrad(dY, Wt)
+    dW = K.conv1x1_wgrad(X, dY)
+    Yl = Y.double() - b.double().view(1, M, 1, 1)
+    a = float((Yl * dY.double()).sum())
+    bb = float((X.double() * dX.double()).sum())
+    c = float((Wt.double().view(M, Cin) * dW.double()).sum())
+    scale = float((Yl.abs() * dY.double().abs()).sum())
+    assert abs(a - bb) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, bb, c, scale)
+    # one image of the launch against the oracle
+    x1, dy1, w_np, b_np = X[n0:n0 + 1].cpu().numpy(), dY[n0:n0 + 1].cpu().numpy(), Wt.cpu().numpy(), b.cpu().numpy()
+    ref = oracle.conv_forward(x1, w_np, b_np, kernel=1, stride=1, pad=0)
+    close(Y[n0:n0 + 1].cpu().numpy(), ref, CONV_RTOL, CONV_FLOOR, "full-size fwd slice")
+    R = torch.randn((N, M, H, W), device="cuda", generator=gen)
+    Yr = K.conv1x1_forward(X, wt, M, b, R, relu=True)
+    close(Yr[n0:n0 + 1].cpu().numpy(), np.maximum(ref + R[n0:n0 + 1].cpu().numpy(), 0), CONV_RTOL, CONV_FLOOR,
+          "full-size relu(Y + R) slice")
+    del R, Yr
+    ref_dW, _, ref_dX = oracle.conv_backward(x1, w_np, dy1, kernel=1, stride=1, pad=0)
+    close(dX[n0:n0 + 1].cpu().numpy(), ref_dX, CONV_RTOL, CONV_FLOOR, "full-size dgrad slice")
+    mask = torch.randn((N, Cin, H, W), device="cuda", generator=gen).clamp_(min=0)
+    dXm = K.conv1x1_dgrad(dY, Wt, mask=mask)
+    close(dXm[n0:n0 + 1].cpu().numpy(), np.where(mask[n0:n0 + 1].cpu().numpy() > 0, ref_dX, 0), CONV_RTOL, CONV_FLOOR,
+          "full-size masked dgrad slice")
+    del mask, dXm
+    dY0 = torch.zeros_like(dY)
+    dY0[n0].copy_(dY[n0])
+    dW0 = K.conv1x1_wgrad(X, dY0)
+    close(dW0.cpu().numpy(), ref_dW.reshape(M, Cin), CONV_RTOL, CONV_FLOOR, "full-size wgrad (one contributing image)")
+    assert torch.equal(K.conv1x1_wgrad(X, dY), dW)            # deterministic at this size too

@@ -151,7 +151,9 @@ def main():
             e["l2_fill_bytes"] = 128.0 * e["TCC_EA0_RDREQ_sum"]
     doc = {"workload": "python bench.py --workload heads%s (bs 16, 600 px), per-dispatch averages by timing class "
                        "(ssad_amd/program.py: KLASS)" % (" --precision f16" if f16 else ""),
-           "attribution": notes, "classes": {str(k): merged[k] for k in sorted(merged)}}
+           "attribution": notes, "classes": {str(k): merged[k] for k in sorted(merged)},
+           # the build the counters were taken on: bench.py refuses to quote them for other kernel sources
+           "kernel_sources": kernel_source_hashes()}
     if out_path:
         json.dump(doc, open(out_path, "w"), indent=1, sort_keys=True)
     lines = ["# Counters of the timed launches, by timing class", "", doc["workload"], ""] + ["* " + n for n in notes]
@@ -167,6 +169,17 @@ def main():
     if md_path:
         open(md_path, "w").write(text)
     print(text)
+
+
+def kernel_source_hashes():
+    """sha256[:16] of every kernel source of the product library (csrc/kernels/*): what `traffic` in bench.py's
+    line is valid for."""
+    import glob
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kdir = os.path.join(root, "semi-supervised-adaptive-distillation_amd", "csrc", "kernels")
+    return {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest()[:16]
+            for f in sorted(glob.glob(os.path.join(kdir, "*")))}
 
 
 if __name__ == "__main__":
