@@ -322,6 +322,19 @@ SSAD_API int ssad_conv3x3_forward_wino(
  * are staged as 8 x 16-pixel patches and others as pairs of 8 x 8 sub-patches (host-side query, no device
  * work; profiling tools attribute hardware counters to calls by launch order). */
 SSAD_API int ssad_conv3x3_forward_wino_launches(const ssad_conv_level* levels_host, int n_levels);
+/* ... for these channel counts, the split-tail launches included (see ssad_conv_wino_split_tail) */
+SSAD_API int ssad_conv3x3_forward_wino_launches_for(const ssad_conv_level* levels_host, int n_levels, int Cout,
+                                                    int Cin);
+/* The split tail of the persistent Winograd kernel (round 5): the items of the last, partial round of the grid are
+ * cut along the reduction into 2 / 4 / 8 units each, one per workgroup; the last-arriving unit of an item adds the
+ * partial results in unit order (deterministic) and applies bias / ReLU / mask.  Setting 1 (default, or
+ * SSAD_WINO_SPLIT_TAIL): only launches WITHOUT a full round are split (FPN's small levels, small batches: P6 at
+ * bs 16 -36 %, BASELINE config 2's step -3.6 %); setting 2: also the partial round behind full rounds, as a second
+ * launch (res4 256 -> 256 at 40 x 56 x 16: 2.19 rounds took 3, -11 % isolated; res5 -16 %; the single-stream step
+ * -1.0 ms -- but +1.1 ms in the overlapped step, whose other streams already fill those tails, hence not the
+ * default); 0: off.  on < 0 only queries; returns the previous setting.  Results with and without it agree to fp32
+ * round-off (another summation order over the input channels), each is reproducible bit for bit. */
+SSAD_API int ssad_conv_wino_split_tail(int on);
 /* ssad_conv_wino_pack_filter for a whole table of filters in one launch (the training step
  * repacks every filter after each update: 20 student filters x {forward, data gradient}). */
 #define SSAD_MAX_PACK_ENTRIES 32   /* per launch; longer tables are chunked */

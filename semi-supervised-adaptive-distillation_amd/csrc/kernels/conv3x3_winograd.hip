@@ -32,6 +32,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 #include "conv_internal.h"
@@ -153,6 +156,14 @@ struct WArgs {
   int M, K, chunks, flags;
   int patches, mblocks;   // persistent variant: tiles = patches x mblocks
   int xcd_group;          // consecutive tiles per XCD inside a round of the grid (1 = round robin)
+  int items;              // persistent variant: the items [0, items) of the patches x mblocks this launch walks
+  // split tail (wino_conv_z_kernel<.., .., true>, a launch of its own): the items [full_items, patches x mblocks)
+  // of the last, partial round of the grid, cut along the reduction into `split_parts` units each, one per
+  // workgroup (see the kernel's header)
+  int full_items;
+  int split_parts;        // units per tail item; divides `chunks`
+  float* split_ws;        // [grid][BM * 128] partial outputs, one slot per unit
+  unsigned* split_tickets;   // [grid] arrival counters, zero between launches
 };
 
 __global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) {
@@ -442,8 +453,25 @@ static_assert(ZRAW <= ZRAWP && STEPS == 16 && AD == 8, "variant Z is written for
 // NHALF (Cout <= 64: res2 of the backbones, bbox_pred): a 128-channel block would leave waves 4-7 (and their
 // half of every SIMD's MFMA issue) idle; instead waves w and w + 4 share output channels 16 (w & 3) .. and
 // split the work item's two tile groups between them (8 accumulator quads per wave instead of 16).
-template <bool PAIRS, bool NHALF>
+// SPLIT (round 5): the tail of the persistent grid.  `total` equal-cost items on G workgroups take ceil(total / G)
+// rounds; the backbones' mid-sized layers pay for that (res4, 256 -> 256 at 40 x 56 x 16: 560 items = 2.19 rounds take
+// 3; res5: 1.5 take 2 -- measured 0.55 of the matrix peak where the towers' exact 39 + 9 rounds reach 0.75).  With
+// the split the T = total mod G items of the partial round are cut along the REDUCTION into p <= G / T units of
+// chunks / p input-channel chunks each (p a power of two dividing `chunks`), and that round is a LAUNCH OF ITS OWN
+// of this instantiation, T p workgroups of one unit each, behind the launch of the full rounds: it costs ~1 / p of
+// a round.  (A unit as the last item of the main kernel's workgroups was the first form: the extra scalar state
+// pushed the kernel from 250 to 256 VGPRs with spills -- among them ring registers in flight, which
+// tools/isa_lint.py caught; a workgroup that runs one unit and nothing else needs no tile hand-over at all.)
+// A unit writes its partial result -- already through A^T . A, 4 floats per (channel, tile), no bias -- to its slot
+// of the launcher's scratch with agent-scope write-through stores, bumps the item's arrival counter, and the LAST
+// unit of an item to arrive sums the p slots in unit order (so the bits do not depend on who is last), adds the
+// bias and applies ReLU / Sigmoid / the ReluGradient mask as the ordinary epilogue does.  Nobody waits for anybody:
+// all units of an item are resident in the same round.  Cross-XCD visibility: sc1 (write-through) stores, every
+// wave's s_waitcnt vmcnt(0), barrier, one relaxed agent-scope arrival; sc1 loads in the last arrival -- the
+// counter form of the hand-off in cdna_hip_programming.md 5.4 / MI355X_MICROARCH.md "valid forms".
+template <bool PAIRS, bool NHALF, bool SPLIT = false>
 __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args) {
+  static_assert(!(SPLIT && NHALF), "the split tail is instantiated for 128-channel blocks");
   constexpr int NG = NHALF ? 1 : 2;        // tile groups per wave
   __shared__ float raw[NRAW * ZRAWP];
   __shared__ float vbuf[2 * VBUF];
@@ -458,7 +486,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wv = NHALF ? (wave & 3) : wave;          // this wave's 16-channel slice of the block
   const int g0 = NHALF ? (wave >> 2) : 0;            // its first tile group
-  const int total = args.patches * args.mblocks;
+  const int total = args.items;
   // Which tiles a workgroup walks: round i of the grid covers tiles [i G, (i + 1) G); inside a round
   // the workgroups of ONE XCD (ids b, b + 8, ...: they share an L2) take runs of `xg` CONTIGUOUS
   // tiles, i.e. patches that are neighbours in x (and, for long runs, in y).  A patch row is 18
@@ -475,8 +503,14 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
       slot = (r / xg) * (8 * xg) + x * xg + (r % xg);
     }
   }
-  const int my_n = total > slot ? (total - slot + G - 1) / G : 0;
-  const int S = my_n * chunks;     // flattened (tile, chunk) sequence length
+  // SPLIT: the launch IS the partial round -- workgroup b runs unit b % sp of tail item b / sp, i.e. the
+  // `nch` = chunks / sp input-channel chunks from chunk t_c0 on, and nothing else
+  const int sp = SPLIT ? args.split_parts : 1;
+  const int t_item = SPLIT ? (int)blockIdx.x / sp : 0;
+  const int nch = SPLIT ? __builtin_amdgcn_readfirstlane(chunks / sp) : chunks;       // chunks an item runs over here
+  const int t_c0 = SPLIT ? __builtin_amdgcn_readfirstlane(((int)blockIdx.x - t_item * sp) * nch) : 0;
+  const int my_n = SPLIT ? 1 : (total > slot ? (total - slot + G - 1) / G : 0);
+  const int S = my_n * nch;     // flattened (tile, chunk) sequence length
   // static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves
   // per SIMD, item 4): waves 4-7 lose VALU arbitration to their older SIMD partners on every chunk;
   // one s_setprio for them, no per-segment flips
@@ -495,7 +529,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   }
   __syncthreads();
   for (int i = tid; i < my_n; i += kBlock) {
-    const int t = slot + i * G;
+    const int t = SPLIT ? args.full_items + t_item : slot + i * G;
     const int mb = t / args.patches;
     int pid = t - mb * args.patches;
     int l = -1;
@@ -572,7 +606,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
         myvoff[j * 64] = ok ? (unsigned)(((n * K + 2 * p + hi) * HW + gy * W + gx) * 4) : kOOBOff;
       }
     }
-    dma_soff = __builtin_amdgcn_readfirstlane(real ? ld_ch * chunk_bytes : 0);
+    dma_soff = __builtin_amdgcn_readfirstlane(real ? (ld_ch + t_c0) * chunk_bytes : 0);
     dma_dst = __builtin_amdgcn_readfirstlane(raw_lds + (unsigned)(ld_buf * ZRAWP + wave * 64) * 4u);
   };
   // real = false: the same instruction with every lane out of range (zeros into the buffer nobody reads any
@@ -585,7 +619,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   auto dma_issue = [&](int j, unsigned vo) { ssad_dev::lds_dma<4>(xrs, dma_dst + j * 2048, vo, dma_soff); };
   auto dma_end = [&]() {
     if (dma_real) {
-      if (++ld_ch == chunks) { ld_ch = 0; ++ld_tile; }
+      if (++ld_ch == nch) { ld_ch = 0; ++ld_tile; }
       if (++ld_buf == NRAW) ld_buf = 0;
     }
   };
@@ -705,11 +739,12 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   // ---- prologue: chunks 0..2 by DMA, chunk 0 transformed, filter ring primed ----
   WTile T = get_tile(0);
   ssad_dev::rsrc_words arsrc = ssad_dev::uniform_rsrc_words(args.lv[T.l].packed, (unsigned)stream_bytes);
-  int abase = stream_off(T);
+  int abase = stream_off(T) + t_c0 * STEPS * 1024;
   f32x4 ar[AD];
 #pragma unroll
   for (int k = 0; k < AD; ++k) a_load(ar[k], arsrc, abase + k * 1024);
   f32x4 bv = load_bias(T);
+  if (SPLIT) bv = f32x4{0.f, 0.f, 0.f, 0.f};      // a unit's partial sum carries no bias
   dma_next(true);
   if (S > 1) dma_next(true);
   if (S > 2) dma_next(true);
@@ -723,8 +758,8 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
   WTile Tn = T;
   ssad_dev::rsrc_words nrsrc = arsrc;
   int nbase = abase;
-  const int look = chunks > 1 ? 1 : 0;
   for (int i = 0; i < my_n; ++i) {
+    const int look = nch > 1 ? 1 : 0;
     const int mt = T.mb * (BM / 16) + wv;
     const bool active = mt < mtiles;
     f32x4 acc[16][NG];
@@ -734,7 +769,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
 #pragma unroll
       for (int g = 0; g < NG; ++g)
         acc[x][g] = (x == 0 || x == 15) ? bv : (x == 3 || x == 12) ? -bv : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int ch = 0; ch < chunks; ++ch, ++s) {
+    for (int ch = 0; ch < nch; ++ch, ++s) {
       DBG(1, s, 0);
       // Side jobs, issued from inside the MFMA steps (active waves) so that they
       // run under MFMAs instead of in front of them:
@@ -757,7 +792,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
       // operands 8 steps ahead: steps 8..15 request those of the NEXT chunk's steps 0..7 -- of this tile only; in
       // the tile's last chunk the same instructions go out with every lane out of range, and the next tile's first
       // operands are requested after the chunk loop (nrsrc / nbase: side_look, chunk `look`)
-      const bool last = ch == chunks - 1;
+      const bool last = ch == nch - 1;
       const unsigned tail_voff = last ? kOOBOff : a_voff;
       if (active) {
         const float* vb = bbase + (s & 1) * VBUF;
@@ -854,6 +889,99 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
 #pragma unroll
     for (int k = 0; k < AD; ++k) a_load(ar[k], nrsrc, nbase + k * 1024);
     if (i + 1 < my_n) bv = load_bias(Tn);
+    if (SPLIT) {
+      // ---- a unit of a split tail item: publish the partial output, the last arrival finishes the item ----
+      // (it is the workgroup's last item: the operands just requested are the harmless re-read; let them land
+      // first, so that the compiler may do what it likes with the ring registers in the code below)
+      ring_landed(ar);
+      constexpr int SLOT = BM * 32 * 4;                // floats per unit: 128 channels x 32 tiles x (2 x 2)
+      constexpr int kSc1 = 16;                         // cache policy sc1: agent scope, written through / read past L2
+      const __amdgpu_buffer_rsrc_t wrs = uniform_rsrc(args.split_ws, (unsigned)((long long)G * SLOT * 4));
+      const unsigned my_off = (unsigned)(((wave * 16 + kq * 4) * 32 + jn) * 16);    // + r * 512 + g * 256 bytes
+      if (active) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float m0 = acc[j][g][r], m1 = acc[4 + j][g][r], m2 = acc[8 + j][g][r], m3 = acc[12 + j][g][r];
+              t[0][j] = m0 + m1 + m2;
+              t[1][j] = m1 - m2 - m3;
+            }
+            f32x4 v;
+            v[0] = t[0][0] + t[0][1] + t[0][2]; v[1] = t[0][1] - t[0][2] - t[0][3];
+            v[2] = t[1][0] + t[1][1] + t[1][2]; v[3] = t[1][1] - t[1][2] - t[1][3];
+            // sc1 = written through at agent scope (cdna_hip_programming.md 5.4: the counter form of the hand-off).
+            // The nop keeps the data registers untouched while the store still reads them: without it hipcc put
+            // the next tile's v_pk_add right behind the store and the last four lanes of every 16-lane row lost their
+            // leading dwords to it -- wrong, irreproducible values in a fixed lane pattern (tools/dbg/r5_split_debug.py);
+            // the guide asks the same of hand-written wide stores (5.7 item 1).
+            __builtin_amdgcn_raw_buffer_store_b128(
+                __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), wrs,
+                my_off + r * 512 + g * 256, (int)blockIdx.x * SLOT * 4, kSc1);
+            __builtin_amdgcn_sched_barrier(0);           // (the nop must FOLLOW the store: hipcc floats it otherwise)
+            asm volatile("s_nop 7" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+      // Publish: every wave's write-through stores have left (vmcnt counts stores on gfx9), then the barrier, then ONE
+      // relaxed agent-scope arrival; the last arrival reads the slots with sc1 loads.  (An agent-scope RELEASE fence
+      // here -- buffer_wbl2 -- writes back every dirty line of the XCD's L2, i.e. the megabytes of output the full
+      // rounds just wrote: measured, it ate the whole gain of the split.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int& split_last = lv_per[31];                   // the level tables have 24 entries: slot 31 is free
+      if (tid == 0) {
+        unsigned* tk = args.split_tickets + t_item;
+        const unsigned old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        split_last = old == (unsigned)sp - 1u;
+        if (split_last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next launch
+      }
+      __syncthreads();
+      if (split_last && active) {
+        const WLevel& L = args.lv[T.l];
+        const int H = L.H, W = L.W, HW = H * W;
+        const int flags = args.flags;
+        const bool relu = flags & SSAD_CONV_RELU, sigm = flags & SSAD_CONV_SIGMOID;
+        const bool masked = flags & SSAD_CONV_MASK_AUX;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int sy0 = g ? T.y0[1] : T.y0[0], sx0 = g ? T.x0[1] : T.x0[0], sn = g ? T.n[1] : T.n[0];
+          float* yout = L.y + (long long)sn * M * HW;
+          const float* aux = masked ? L.aux + (long long)sn * M * HW : nullptr;
+          const int tile = g * 16 + jn;
+          const int py = PAIRS ? sy0 + 2 * (jn >> 2) : T.y0[0] + 2 * (tile >> 3);
+          const int px = PAIRS ? sx0 + 2 * (jn & 3) : T.x0[0] + 2 * (tile & 7);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mt * 16 + kq * 4 + r;
+            f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < sp; ++q)                  // unit order: the same bits whoever arrives last
+              sum += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                  wrs, my_off + r * 512 + g * 256, (t_item * sp + q) * SLOT * 4, kSc1));
+            const float bias = (L.bias && m < M) ? L.bias[m] : 0.0f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              const int yy = py + a;
+              if (m < M && yy < H) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                  if (px + b < W) {
+                    float o = sum[2 * a + b] + bias;
+                    if (relu) o = o > 0.0f ? o : 0.0f;
+                    if (sigm) o = 1.0f / (1.0f + expf(-o));
+                    const int off = m * HW + yy * W + px + b;
+                    if (aux) o = aux[off] > 0.0f ? o : 0.0f;
+                    yout[off] = o;
+                  }
+              }
+            }
+          }
+        }
+      }
+    } else
     if (active && !(WINO_ABLATE & 16)) {
       const WLevel& L = args.lv[T.l];
       const int H = L.H, W = L.W, HW = H * W;
@@ -942,6 +1070,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
                   __builtin_amdgcn_raw_buffer_store_b64(
                       __builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, make_float2(o0, o1)),
                       yrsrc, vo[g][a], (2 * h + rr) * HW * 4, 0);
+
                 }
               }
             }
@@ -991,6 +1120,47 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
 }
 
 }  // namespace
+
+// Scratch of the split tail: one 64 KB slot per workgroup of the grid + the arrival counters, per (device, stream)
+// -- launches on different streams run concurrently and must not share it; launches on one stream are ordered.
+// Allocated on a stream's first split launch (during warm-up), never freed, never grown (the size depends on the
+// device's CU count only); the counters are zeroed once and left zero by every launch.
+static std::atomic<int>& split_tail_setting() {
+  static std::atomic<int> on([] { const char* e = getenv("SSAD_WINO_SPLIT_TAIL"); return (e && *e) ? atoi(e) : 1; }());
+  return on;
+}
+
+// Units per tail item (1 = no split): the largest power of two p with  p <= 8,  tail * p <= grid,  p | chunks  and
+// chunks / p >= 2.  *full = items of the whole rounds, *tail = items of the partial round.
+static int split_plan(long long total, int chunks, int cus, long long* full, long long* tail) {
+  *full = (total / cus) * cus;
+  *tail = total - *full;
+  int p = 1;
+  while (*tail > 0 && p * 2 <= 8 && *tail * (p * 2) <= cus && chunks % (p * 2) == 0 && chunks / (p * 2) >= 2) p *= 2;
+  static const int force = [] { const char* e = getenv("SSAD_WINO_SPLIT_FORCE_P"); return (e && *e) ? atoi(e) : 0; }();
+  if (force > 0 && *tail > 0 && *tail * force <= cus && chunks % force == 0) p = force;      // debugging aid
+  return p;
+}
+
+static int split_scratch(hipStream_t stream, int units, void** ws, unsigned** tickets) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, void*> table;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  const size_t slot_bytes = (size_t)BM * 32 * 4 * sizeof(float);
+  const size_t ws_bytes = (size_t)units * slot_bytes;
+  std::lock_guard<std::mutex> lock(mu);
+  void*& base = table[{dev, stream}];
+  if (!base) {
+    void* p = nullptr;
+    if (hipMalloc(&p, ws_bytes + (size_t)units * sizeof(unsigned) + 256) != hipSuccess) return -1;
+    if (hipMemset((char*)p + ws_bytes, 0, (size_t)units * sizeof(unsigned) + 256) != hipSuccess) return -1;
+    base = p;
+  }
+  *ws = base;
+  *tickets = (unsigned*)((char*)base + ws_bytes);
+  return 0;
+}
 
 extern "C" {
 
@@ -1060,6 +1230,42 @@ int ssad_conv3x3_forward_wino_launches(const ssad_conv_level* lv, int n_levels) 
   return (with_pairs > 0) + (with_patches > 0);
 }
 
+// ... and with the split tails of this (Cout, Cin): + 1 per geometry whose partial round is split
+int ssad_conv3x3_forward_wino_launches_for(const ssad_conv_level* lv, int n_levels, int Cout, int Cin) {
+  if (!lv || n_levels < 1 || Cout <= 0 || Cin <= 0) return 0;
+  static const int variant = [] { const char* e = getenv("SSAD_WINO_VARIANT"); return e ? atoi(e) : 2; }();
+  if (variant != 2) return 1;
+  static const int nhalf = [] { const char* e = getenv("SSAD_WINO_NHALF"); return (e && *e) ? atoi(e) : 1; }();
+  const bool half = nhalf && Cout <= 64;
+  const int cus = ssad_cu_count();
+  int launches = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    long long blocks = 0, pairs = 0;
+    int nl = 0;
+    for (int l = 0; l < n_levels; ++l) {
+      if ((long long)lv[l].N * lv[l].H * lv[l].W == 0) continue;
+      if (level_wants_pairs(lv[l].N, lv[l].H, lv[l].W) != (pass == 1)) continue;
+      ++nl;
+      blocks += (long long)lv[l].N * cdiv(lv[l].W, PC) * cdiv(lv[l].H, PR);
+      pairs += ((long long)lv[l].N * cdiv(lv[l].W, SP) * cdiv(lv[l].H, SP) + 1) / 2;
+    }
+    if (!nl) continue;
+    const long long total = (pass == 1 ? pairs : blocks) * cdiv(Cout, BM);
+    long long full = 0, tail = 0;
+    const int mode = split_tail_setting().load();
+    int p = (mode && !half && total <= (long long)cus * ZNT) ? split_plan(total, cdiv(Cin, KC), cus, &full, &tail) : 1;
+    if (mode < 2 && full > 0) p = 1;
+    launches += p >= 2 ? (full > 0) + 1 : 1;
+  }
+  return launches;
+}
+
+int ssad_conv_wino_split_tail(int on) {
+  const int prev = split_tail_setting().load();
+  if (on >= 0) split_tail_setting().store(on > 2 ? 2 : on);
+  return prev;
+}
+
 int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const float* packed,
                               const float* bias, int Cout, int Cin, int flags,
                               ssad_stream_t stream) {
@@ -1112,12 +1318,52 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
       static const int xg = [] { const char* e = getenv("SSAD_WINO_XCD_GROUP"); return e ? atoi(e) : 8; }();
       static const int nhalf = [] { const char* e = getenv("SSAD_WINO_NHALF"); return (e && *e) ? atoi(e) : 1; }();
       a.xcd_group = xg;
-      const dim3 g3((unsigned)grid), b3(kBlock);
       const bool half = nhalf && Cout <= 64;
-      if (use_pairs && half) hipLaunchKernelGGL((wino_conv_z_kernel<true, true>), g3, b3, 0, (hipStream_t)stream, a);
-      else if (use_pairs) hipLaunchKernelGGL((wino_conv_z_kernel<true, false>), g3, b3, 0, (hipStream_t)stream, a);
-      else if (half) hipLaunchKernelGGL((wino_conv_z_kernel<false, true>), g3, b3, 0, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL((wino_conv_z_kernel<false, false>), g3, b3, 0, (hipStream_t)stream, a);
+      // Split tail (round 5, the kernel's header): the items of the last, partial round are cut along the
+      // reduction into p units each and run as a second launch behind the full rounds.  Taken when the partial
+      // round is at most half full (p >= 2); p is a power of two that divides `chunks`, <= 8 and <= chunks / 2,
+      // so that a unit is at least two chunks (its fixed costs: prologue, epilogue, the partial round trip).
+      // SSAD_WINO_SPLIT_TAIL=0: rounds 1-4's behaviour.
+      const int split_on = split_tail_setting().load();
+      a.items = (int)total;
+      a.full_items = a.split_parts = 0;
+      a.split_ws = nullptr;
+      a.split_tickets = nullptr;
+      long long tail = 0;
+      int parts = 0;
+      if (split_on && !half && grid == (total < cus2 ? total : cus2)) {
+        long long full = 0;
+        const int p = split_plan(total, a.chunks, cus2, &full, &tail);
+        void* ws = nullptr;
+        unsigned* tk = nullptr;
+        static const bool force1 = getenv("SSAD_WINO_SPLIT_FORCE_P") != nullptr;
+        // setting 1 (default): only launches WITHOUT a full round are split -- there the units replace the launch, no
+        // second kernel; setting 2: also the partial round behind full rounds, as a second launch
+        if ((p >= 2 || (force1 && tail > 0)) && (split_on >= 2 || full == 0) &&
+            split_scratch((hipStream_t)stream, cus2, &ws, &tk) == 0) {
+          parts = p;
+          a.items = (int)full;
+          a.full_items = (int)full;
+          a.split_parts = p;
+          a.split_ws = (float*)ws;
+          a.split_tickets = tk;
+          grid = cus2;
+        } else {
+          tail = 0;
+        }
+      }
+      const dim3 g3((unsigned)grid), b3(kBlock);
+      if (a.items > 0) {
+        if (use_pairs && half) hipLaunchKernelGGL((wino_conv_z_kernel<true, true>), g3, b3, 0, (hipStream_t)stream, a);
+        else if (use_pairs) hipLaunchKernelGGL((wino_conv_z_kernel<true, false>), g3, b3, 0, (hipStream_t)stream, a);
+        else if (half) hipLaunchKernelGGL((wino_conv_z_kernel<false, true>), g3, b3, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((wino_conv_z_kernel<false, false>), g3, b3, 0, (hipStream_t)stream, a);
+      }
+      if (parts) {
+        const dim3 t3((unsigned)(tail * parts));
+        if (use_pairs) hipLaunchKernelGGL((wino_conv_z_kernel<true, false, true>), t3, b3, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((wino_conv_z_kernel<false, false, true>), t3, b3, 0, (hipStream_t)stream, a);
+      }
     } else {
       // SSAD_WINO_VARIANT=0: the non-persistent kernel
       a.patches = (int)blocks;

@@ -180,6 +180,8 @@ def lib():
     L.ssad_conv_wino_pack_filter.argtypes = [vp, i32, i32, vp, vp, vp]
     L.ssad_conv3x3_forward_wino.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp]
     L.ssad_conv3x3_forward_wino_launches.argtypes = [C.POINTER(ConvLevel), i32]
+    L.ssad_conv3x3_forward_wino_launches_for.argtypes = [C.POINTER(ConvLevel), i32, i32, i32]
+    L.ssad_conv_wino_split_tail.argtypes = [i32]
     L.ssad_conv3x3_wgrad_workspace_bytes.restype = sz
     L.ssad_conv3x3_wgrad_workspace_bytes.argtypes = [C.POINTER(ConvLevel), i32, i32, i32]
     L.ssad_conv3x3_wgrad.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp, sz, vp]

@@ -752,3 +752,54 @@ def test_conv_engines_vs_reference_operator_golden(K, golden_dir, wgrad_engine, 
         ref = g["%s_%s" % (name, key)]
         close(arr.ravel()[g["%s_%s_idx" % (name, key)]], ref, CONV_RTOL, CONV_FLOOR, "%s %s %s" % (engine, name, key))
     close(db.cpu().numpy(), g[name + "_db"], CONV_RTOL, CONV_FLOOR, name + " db")
+
+
+# ---------------------------------------------------------------------------
+# Round 5: the split tail of the persistent Winograd kernel
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("case", [
+    # (Cin, Cout, H, W, relu, masked, bias)            grid rounds at bs 16 on 256 CUs -> units per tail item
+    (256, 256, 40, 56, True, False, True),             # res4 / P4: 560 pair items = 2.19 rounds -> 48 x 4 units
+    (256, 256, 40, 56, False, True, False),            # ... its masked data-gradient form
+    (512, 512, 20, 28, True, False, True),             # res5: 384 patch items = 1.5 rounds -> 128 x 2
+    (128, 128, 80, 112, True, False, True),            # res3: 1120 = 4.4 rounds -> 96 x 2 (8 chunks: 4 each)
+    (256, 720, 80, 112, False, False, True),           # cls_pred on P3: 6 channel blocks (the last 80 wide), 64 x 4 units
+    (256, 256, 10, 14, True, False, True),             # P6: 64 items, no full round at all -> 64 x 4 units
+], ids=lambda c: "%d_%d_%dx%d_%s%s" % (c[0], c[1], c[2], c[3], "relu" if c[4] else "lin", "_mask" if c[5] else ""))
+def test_wino_split_tail_vs_unsplit_vs_oracle(K, case):
+    """The tail items of the persistent grid cut along the input channels (conv3x3_winograd.hip, SPLIT): same
+    results as the unsplit kernel to fp32 round-off (another summation order), bit-reproducible, and one image
+    of the bs-16 launch against the oracle."""
+    Cin, Cout, H, W, relu, masked, use_bias = case
+    N, n0 = 16, 5
+    gen = torch.Generator(device="cuda").manual_seed(Cin + Cout + H)
+    X = torch.randn((N, Cin, H, W), device="cuda", generator=gen)
+    Wt = torch.randn((Cout, Cin, 3, 3), device="cuda", generator=gen) * float(1.0 / (3 * np.sqrt(Cin)))
+    b = torch.randn(Cout, device="cuda", generator=gen) if use_bias else None
+    mask = [torch.randn((N, Cout, H, W), device="cuda", generator=gen)] if masked else None
+    wf, _ = K.conv_wino_pack_filter(Wt, True, False)
+    L = K.lib()
+    arr = K._conv_levels([X], [torch.empty((N, Cout, H, W), device="cuda")], mask)
+    prev = L.ssad_conv_wino_split_tail(2)         # 2: every partial round (the default, 1, splits only launches without a full round)
+    try:
+        with_split = L.ssad_conv3x3_forward_wino_launches_for(arr, 1, Cout, Cin)
+        Ys = K.conv3x3_forward([X], wf, b, Cout, relu=relu, mask_by=mask, wino=True)[0].clone()
+        Ys2 = K.conv3x3_forward([X], wf, b, Cout, relu=relu, mask_by=mask, wino=True)[0]
+        assert torch.equal(Ys, Ys2)                                  # whoever arrives last: the same bits
+        L.ssad_conv_wino_split_tail(0)
+        assert L.ssad_conv3x3_forward_wino_launches_for(arr, 1, Cout, Cin) == 1
+        assert with_split == (2 if N * ((H + 7) // 8) * ((W + 7) // 8) * ((Cout + 127) // 128) >= 512 else 1)
+        Yu = K.conv3x3_forward([X], wf, b, Cout, relu=relu, mask_by=mask, wino=True)[0]
+    finally:
+        L.ssad_conv_wino_split_tail(prev)
+    d = (Ys - Yu).abs().max().item()
+    assert d <= 2e-5 * Yu.abs().max().item(), d                      # round-off of another summation order
+    assert not torch.equal(Ys, Yu) or Cin <= 32                      # ... and it IS another order
+    ref = oracle.conv_forward(X[n0:n0 + 1].cpu().numpy(), Wt.cpu().numpy(), b.cpu().numpy() if use_bias else None)
+    if relu:
+        ref = np.maximum(ref, 0)
+    if masked:
+        ref = np.where(mask[0][n0:n0 + 1].cpu().numpy() > 0, ref, 0)
+    close(Ys[n0:n0 + 1].cpu().numpy(), ref, CONV_RTOL, CONV_FLOOR, "split tail vs oracle")
+    close(Yu[n0:n0 + 1].cpu().numpy(), ref, CONV_RTOL, CONV_FLOOR, "unsplit vs oracle")

@@ -11,6 +11,14 @@ import ssad_amd  # noqa
 from ssad_amd import kernels as K
 
 def run(iters=150, verbose=True):
+    prev = K.lib().ssad_conv_wino_split_tail(2)     # round 5: every partial round of the Winograd grid is split (default: tiny launches only)
+    try:
+        return _run(iters, verbose)
+    finally:
+        K.lib().ssad_conv_wino_split_tail(prev)
+
+
+def _run(iters, verbose):
     N = 16
     g = torch.Generator(device="cuda").manual_seed(3)
     R = lambda *s: torch.randn(s, device="cuda", generator=g)
@@ -79,6 +87,9 @@ def run(iters=150, verbose=True):
         ("wino 256->720 40x56 (pairs)", wino_case(256, 720, 40, 56, relu=False)),
         ("wino 256->36 80x112 (NHALF, 3 of 4 slices)", wino_case(256, 36, 80, 112, relu=False)),
         ("wino 512->512 20x28", wino_case(512, 512, 20, 28)),
+        ("wino 256->256 40x56 (split tail: 48 items x 4 units)", wino_case(256, 256, 40, 56)),
+        ("wino 256->256 40x56 masked (split tail)", wino_case(256, 256, 40, 56, mask=True, relu=False, bias=False)),
+        ("wino 256->256 10x14 (no full round: 64 x 4 units)", wino_case(256, 256, 10, 14)),
         ("wino filter gradient 256x256 five levels", wgrad_case(256, 256, [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)])),
         ("wino filter gradient 128x128 80x112", wgrad_case(128, 128, [(80, 112)])),
         ("gemm nn 256->1024 40x56 + shortcut", pw_case(256, 1024, 40, 56)),

@@ -54,7 +54,9 @@ def class_sequences(f16=False):
             # one call = one launch per staging geometry present among its levels (8 x 16 patches / sub-patch
             # pairs, conv3x3_winograd.hip); the levels of the batch-1 program have the bench's map sizes
             import ctypes as C
-            launches = K.lib().ssad_conv3x3_forward_wino_launches(C.cast(op.p[0], C.POINTER(K.ConvLevel)), op.i[0])
+            # (+ the split-tail launch of a geometry whose partial round is split, round 5)
+            launches = K.lib().ssad_conv3x3_forward_wino_launches_for(C.cast(op.p[0], C.POINTER(K.ConvLevel)), op.i[0],
+                                                                      op.i[1], op.i[2])
         for k in range(launches):
             seq.setdefault(n, []).append((op.klass, k == 0))
     return seq
