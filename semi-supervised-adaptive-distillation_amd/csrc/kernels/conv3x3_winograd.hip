@@ -839,7 +839,8 @@ __global__ __launch_bounds__(kBlock, 1) void wino_conv_z_kernel(const WArgs args
             const int xi = xq * 4 + xr;
 #pragma unroll
             for (int g = 0; g < NG; ++g)
-              acc[xi][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[xr], bc[xr][g], acc[xi][g], 0, 0, 0);
+              if (!((WINO_ABLATE & 64) && xq == 3))        // 64: a quarter of the MFMAs gone (what F(2x2) x F(4x4) would save)
+                acc[xi][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[xr], bc[xr][g], acc[xi][g], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (step < STEPS - 1 && !(WINO_ABLATE & 8)) b_read(bc[xr], vb + ((nxq * 4 + xr) * KC + nks * 4) * VP);
             __builtin_amdgcn_sched_barrier(0);
