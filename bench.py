@@ -100,7 +100,7 @@ def kernel_report(classes, steps):
                "ms_per_step": round(c["ms"] / steps, 4)}
         rate = c["work"] / (c["ms"] * 1e-3)
         if meta["bound"] in ("mfma", "mfma16"):
-            executed = rate / 2.25 if meta.get("wino") else rate
+            executed = rate / meta.get("exec_div", 2.25) if meta.get("wino") else rate
             row.update(unit="TFLOP/s", achieved=round(executed / 1e12, 2),
                        direct_equiv_tflops=round(rate / 1e12, 2), peak=PR.PEAK[meta["bound"]] / 1e12,
                        frac=round(executed / PR.PEAK[meta["bound"]], 4),

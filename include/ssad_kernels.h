@@ -298,6 +298,9 @@ SSAD_API int ssad_conv_pack_filter(
 #define SSAD_CONV_MASK_AUX 2  /* y = aux > 0 ? y : 0 (fused ReluGradient) */
 #define SSAD_CONV_SIGMOID 4   /* y = 1/(1+exp(-y)) (teacher cls_pred -> prob,
                                  caffe2/operators/sigmoid_op.cu:25-29 fused) */
+#define SSAD_CONV_SPLIT_TAIL 8 /* Winograd F(2x2) engine only, a scheduling hint: split this launch's partial round
+                                 even behind full rounds (ssad_conv_wino_split_tail setting 2 for one launch) -- for
+                                 launches that have the chip to themselves, e.g. the subnets' forward pass */
 
 /* y = conv3x3(x, packed) (+ bias) for every level in one launch
  * (n_levels <= SSAD_MAX_CONV_PROBLEMS).
@@ -322,9 +325,9 @@ SSAD_API int ssad_conv3x3_forward_wino(
  * are staged as 8 x 16-pixel patches and others as pairs of 8 x 8 sub-patches (host-side query, no device
  * work; profiling tools attribute hardware counters to calls by launch order). */
 SSAD_API int ssad_conv3x3_forward_wino_launches(const ssad_conv_level* levels_host, int n_levels);
-/* ... for these channel counts, the split-tail launches included (see ssad_conv_wino_split_tail) */
+/* ... for these channel counts and flags, the split-tail launches included (see ssad_conv_wino_split_tail) */
 SSAD_API int ssad_conv3x3_forward_wino_launches_for(const ssad_conv_level* levels_host, int n_levels, int Cout,
-                                                    int Cin);
+                                                    int Cin, int flags);
 /* The split tail of the persistent Winograd kernel (round 5): the items of the last, partial round of the grid are
  * cut along the reduction into 2 / 4 / 8 units each, one per workgroup; the last-arriving unit of an item adds the
  * partial results in unit order (deterministic) and applies bias / ReLU / mask.  Setting 1 (default, or
@@ -346,6 +349,18 @@ typedef struct ssad_pack_entry {
 } ssad_pack_entry;
 SSAD_API int ssad_conv_wino_pack_filters(const ssad_pack_entry* entries_host, int n_entries,
                                          ssad_stream_t stream);
+
+/* Winograd F(2x4, 3x3) forward engine for networks that are only EVALUATED (round 5; conv3x3_winograd24.hip):
+ * 3 multiplies per output where F(2x2) does 4, fp32 error ~2e-6 of the output scale where F(2x2) has ~3e-7 -- inside
+ * the parity bar for a forward pass, not for a trained chain with its gradients, so the training step uses it for the
+ * frozen teacher only (model_builder.py:373-411 builds the teacher in test mode).  Same level / flag contract as
+ * ssad_conv3x3_forward_wino (bias, SSAD_CONV_RELU, SSAD_CONV_SIGMOID; no SSAD_CONV_MASK_AUX: forward only), its own
+ * filter pack (entries with packed_fwd set and packed_dgrad NULL).  Meant for Cout >= 128. */
+SSAD_API size_t ssad_conv_wino24_filter_floats(int M, int K);
+SSAD_API int ssad_conv_wino24_pack_filters(const ssad_pack_entry* entries_host, int n_entries, ssad_stream_t stream);
+SSAD_API int ssad_conv3x3_forward_wino24(
+    const ssad_conv_level* levels_host, int n_levels, const float* packed,
+    const float* bias, int Cout, int Cin, int flags, ssad_stream_t stream);
 
 SSAD_API size_t ssad_conv3x3_wgrad_workspace_bytes(
     const ssad_conv_level* levels_host, int n_levels, int Cout, int Cin);

@@ -33,6 +33,7 @@ Program.run() calls (ssad_program_run) -- a few segments when data parallel, so 
 gradient bucket is all-reduced while the earlier stages are still in backward.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -50,13 +51,14 @@ GROUPED = {"x101-64x4d": (64, 4)}
 
 class _Layer(object):
     __slots__ = ("name", "k", "cin", "cout", "stride", "train", "group", "affine", "w", "b", "gw", "gb", "wt",
-                 "pf", "pd", "s2")
+                 "pf", "pd", "s2", "f24")
 
     def __init__(self, name, k, cin, cout, stride, train, group=1, affine=False):
         self.name, self.k, self.cin, self.cout, self.stride, self.train = name, k, cin, cout, stride, train
         self.group = group
         self.affine = affine       # followed by a frozen AffineChannel (folded): the bias is not a parameter
         self.w = self.b = self.gw = self.gb = self.wt = self.pf = self.pd = self.s2 = None
+        self.f24 = False           # 3x3 forward on the F(2x4, 3x3) engine (frozen networks, >= 128 outputs)
 
     @property
     def wcin(self):
@@ -311,16 +313,18 @@ class NativeResNetFPN(object):
         P.add(PR.GEMM_CONV, klass, p=(d,), work=2.0 * px * Kc * M,
               keep=[t for t in (a, x, y, bias, res, mask) if t is not None])
 
-    def _conv3(self, P, probs, Cout, Cin, flags, klass=48):
+    def _conv3(self, P, probs, Cout, Cin, flags, klass=48, f24=False):
         """probs: [(x, y, mask or None, packed, bias or None)]: independent 3x3 convolutions of one
-        (Cout, Cin) in one launch."""
+        (Cout, Cin) in one launch; f24: on the F(2x4, 3x3) engine (packs from ssad_conv_wino24_pack_filters)."""
+        if f24:
+            klass = 47
         arr = (K.ConvLevel * len(probs))()
         for i, (x, y, mask, packed, bias) in enumerate(probs):
             arr[i] = K.ConvLevel(x.data_ptr(), y.data_ptr(), mask.data_ptr() if mask is not None else 0,
                                  x.shape[0], x.shape[2], x.shape[3], packed.data_ptr(),
                                  bias.data_ptr() if bias is not None else 0)
         px = sum(p[0].shape[0] * p[0].shape[2] * p[0].shape[3] for p in probs)
-        P.add(PR.CONV3X3, klass, i=(len(probs), Cout, Cin, flags, 1), p=(arr, None, None),
+        P.add(PR.CONV3X3, klass, i=(len(probs), Cout, Cin, flags, 2 if f24 else 1), p=(arr, None, None),
               work=2.0 * 9 * Cout * Cin * px, keep=[t for p in probs for t in p if t is not None])
 
     def _wgrad3(self, P, x, dy, layer):
@@ -434,7 +438,11 @@ class NativeResNetFPN(object):
         # packed filters: frozen layers once (prepare program), trainable layers every step (pack segment)
         prep, P = PR.Program(), PR.Program()
         self.prep, self.prog = prep, P
-        wino_frozen, wino_train = [], []
+        wino_frozen, wino_train, wino24_frozen = [], [], []
+        # A network that is only evaluated (the distillation step's frozen teacher) runs its 3x3 layers of >= 128
+        # outputs on the F(2x4, 3x3) engine: 3 multiplies per output instead of 4, fp32 error ~2e-6 of the output
+        # scale (conv3x3_winograd24.hip; SSAD_TEACHER_F24=0: the F(2x2) engine as in rounds 1-4)
+        use_f24 = (not self.train) and int(os.environ.get("SSAD_TEACHER_F24", "1")) >= 1
         tr_frozen, tr_train = [], []          # (w, wt, M, K, ldm): every transposed filter of a program in one launch
         P.mark("pack")
         for l in L.values():
@@ -452,6 +460,10 @@ class NativeResNetFPN(object):
                 # gradients read the filter in its natural layout)
                 l.wt = self._t(l.cin * 9, l.cout)
                 trs.append((l.w, l.wt, l.cout, l.cin * 9, l.cout))
+            elif l.k == 3 and use_f24 and not l.train and l.cout >= 128:
+                l.pf = self._t(lib.ssad_conv_wino24_filter_floats(l.cout, l.cin))
+                l.f24 = True
+                wino24_frozen.append(l)
             elif l.k == 3:
                 l.pf = self._t(lib.ssad_conv_wino_filter_floats(l.cout, l.cin))
                 need_pd = l.train                  # every trainable 3x3 sends a gradient further down
@@ -479,6 +491,12 @@ class NativeResNetFPN(object):
                 tgt.add(PR.WINO_PACK_FILTERS, 54, i=(len(ls),), p=(tab,),
                         work=4.0 * sum(l.w.numel() + l.pf.numel() + (l.pd.numel() if l.pd is not None else 0)
                                        for l in ls))
+        if wino24_frozen:
+            tab = (K.PackEntry * len(wino24_frozen))()
+            for i, l in enumerate(wino24_frozen):
+                tab[i] = K.PackEntry(l.w.data_ptr(), l.cout, l.cin, l.pf.data_ptr(), 0)
+            prep.add(PR.WINO_PACK_FILTERS, 54, i=(len(wino24_frozen), 2), p=(tab,),
+                     work=4.0 * sum(l.w.numel() + l.pf.numel() for l in wino24_frozen))
         prep.build()
         self._packed_frozen = False
         P.mark("forward")
@@ -544,7 +562,7 @@ class NativeResNetFPN(object):
                 P.add(PR.GROUPED_CONV3X3, 56, i=(N, cmid, y1.shape[2], y1.shape[3], l2.group, l2.stride, 1),
                       p=(y1, l2.pf, l2.b, y2), work=2.0 * 9 * cmid * l2.wcin * y2.shape[0] * h * w)
             else:
-                self._conv3(P, [(y1, y2, None, l2.pf, l2.b)], cmid, cmid, K.CONV_RELU)
+                self._conv3(P, [(y1, y2, None, l2.pf, l2.b)], cmid, cmid, K.CONV_RELU, f24=l2.f24)
             sc = xs
             if proj:
                 lp = L[pre + ".proj"]
@@ -569,7 +587,8 @@ class NativeResNetFPN(object):
                 self._ew(P, PR.UPSAMPLE, i=(N, D, src.shape[2], src.shape[3], 2), p=(src, t, t), nbytes=9.0 * t.numel())
         p5, p4, p3 = (self._like(t) for t in (t5, t4, t3))
         self._conv3(P, [(t, p, None, L[name].pf, L[name].b)                # three filters, one launch
-                        for t, p, name in ((t5, p5, "out.0"), (t4, p4, "out.1"), (t3, p3, "out.2"))], D, D, 0)
+                        for t, p, name in ((t5, p5, "out.0"), (t4, p4, "out.1"), (t3, p3, "out.2"))], D, D, 0,
+                   f24=L["out.0"].f24)
         l6, l7 = L["p6"], L["p7"]
         if self._strided_own:
             # P6 / P7 (3x3, stride 2) at their own size
@@ -583,13 +602,13 @@ class NativeResNetFPN(object):
         else:
             # SSAD_STRIDED_3X3=winograd: stride-1 convolution, then the even positions
             p6f = self._t(N, D, c5.shape[2], c5.shape[3])
-            self._conv3(P, [(c5, p6f, None, l6.pf, l6.b)], D, l6.cin, 0)
+            self._conv3(P, [(c5, p6f, None, l6.pf, l6.b)], D, l6.cin, 0, f24=l6.f24)
             p6 = self._t(N, D, c5.shape[2] // 2, c5.shape[3] // 2)
             self._ew(P, PR.SUBSAMPLE, i=(N, D, c5.shape[2], c5.shape[3], 2), p=(p6f, p6), nbytes=8.0 * p6.numel())
             r6 = self._like(p6)
             self._ew(P, PR.RELU, p=(p6, r6), l=(p6.numel(),), nbytes=8.0 * p6.numel())
             p7f = self._like(p6)
-            self._conv3(P, [(r6, p7f, None, l7.pf, l7.b)], D, D, 0)
+            self._conv3(P, [(r6, p7f, None, l7.pf, l7.b)], D, D, 0, f24=l7.f24)
             p7 = self._t(N, D, (p6.shape[2] + 1) // 2, (p6.shape[3] + 1) // 2)
             self._ew(P, PR.SUBSAMPLE, i=(N, D, p6.shape[2], p6.shape[3], 2), p=(p7f, p7), nbytes=8.0 * p7.numel())
         self.fpn = [p3, p4, p5, p6, p7]                   # finest first (synth.LEVEL_SHAPES_*)

@@ -1232,7 +1232,7 @@ int ssad_conv3x3_forward_wino_launches(const ssad_conv_level* lv, int n_levels) 
 }
 
 // ... and with the split tails of this (Cout, Cin): + 1 per geometry whose partial round is split
-int ssad_conv3x3_forward_wino_launches_for(const ssad_conv_level* lv, int n_levels, int Cout, int Cin) {
+int ssad_conv3x3_forward_wino_launches_for(const ssad_conv_level* lv, int n_levels, int Cout, int Cin, int flags) {
   if (!lv || n_levels < 1 || Cout <= 0 || Cin <= 0) return 0;
   static const int variant = [] { const char* e = getenv("SSAD_WINO_VARIANT"); return e ? atoi(e) : 2; }();
   if (variant != 2) return 1;
@@ -1253,7 +1253,8 @@ int ssad_conv3x3_forward_wino_launches_for(const ssad_conv_level* lv, int n_leve
     if (!nl) continue;
     const long long total = (pass == 1 ? pairs : blocks) * cdiv(Cout, BM);
     long long full = 0, tail = 0;
-    const int mode = split_tail_setting().load();
+    int mode = split_tail_setting().load();
+    if (mode && (flags & SSAD_CONV_SPLIT_TAIL)) mode = 2;
     int p = (mode && !half && total <= (long long)cus * ZNT) ? split_plan(total, cdiv(Cin, KC), cus, &full, &tail) : 1;
     if (mode < 2 && full > 0) p = 1;
     launches += p >= 2 ? (full > 0) + 1 : 1;
@@ -1325,7 +1326,8 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
       // round is at most half full (p >= 2); p is a power of two that divides `chunks`, <= 8 and <= chunks / 2,
       // so that a unit is at least two chunks (its fixed costs: prologue, epilogue, the partial round trip).
       // SSAD_WINO_SPLIT_TAIL=0: rounds 1-4's behaviour.
-      const int split_on = split_tail_setting().load();
+      int split_on = split_tail_setting().load();
+      if (split_on && (flags & SSAD_CONV_SPLIT_TAIL)) split_on = 2;
       a.items = (int)total;
       a.full_items = a.split_parts = 0;
       a.split_ws = nullptr;

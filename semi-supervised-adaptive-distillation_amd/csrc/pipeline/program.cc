@@ -88,11 +88,11 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
   const float* f = o.f;
   switch (o.code) {
     case SSAD_OP_WINO_PACK_FILTERS:
-      return ssad_conv_wino_pack_filters((const ssad_pack_entry*)p[0], i[0], s);
+      return (i[1] == 2 ? ssad_conv_wino24_pack_filters : ssad_conv_wino_pack_filters)((const ssad_pack_entry*)p[0], i[0], s);
     case SSAD_OP_PACK_FILTER:
       return ssad_conv_pack_filter((const float*)p[0], i[0], i[1], (float*)p[1], (float*)p[2], s);
     case SSAD_OP_CONV3X3:
-      return (i[4] ? ssad_conv3x3_forward_wino : ssad_conv3x3_forward)(
+      return (i[4] == 2 ? ssad_conv3x3_forward_wino24 : i[4] ? ssad_conv3x3_forward_wino : ssad_conv3x3_forward)(
           (const ssad_conv_level*)p[0], i[0], (const float*)p[1], (const float*)p[2], i[1], i[2], i[3], s);
     case SSAD_OP_CONV3X3_WGRAD:
       return ssad_conv3x3_wgrad((const ssad_conv_level*)p[0], i[0], (float*)p[1], (float*)p[2], i[1], i[2],

@@ -102,6 +102,11 @@ class DistillHeads(object):
         self.teacher_bbox_tower = teacher_bbox_tower and self.distill
         import os
         self.wino = os.environ.get("SSAD_CONV_ENGINE", "winograd").lower() != "direct"
+        # The frozen teacher on the F(2x4, 3x3) engine (conv3x3_winograd24.hip: 3 multiplies per output instead of
+        # F(2x2)'s 4, fp32 error ~2e-6 of the output scale -- admissible where nothing back-propagates):
+        #   1 (default) its cls_pred layer;  2: also its tower layers, which then leave the launch they shared with the
+        #   student's (SSAD_TEACHER_F24; 0 = everything on the F(2x2) engine as in rounds 1-4)
+        self.teacher_f24 = int(os.environ.get("SSAD_TEACHER_F24", "1")) if (self.wino and not self.F16) else 0
         self.momentum, self.weight_decay = momentum, weight_decay
         self.pg, self.world_size = process_group, world_size
         self.dp = BucketedAllReduce(process_group, world_size)
@@ -192,14 +197,14 @@ class DistillHeads(object):
                 k += 1
         return arr
 
-    def _emit_conv(self, P, problems, Cout, Cin, flags, klass):
-        """One launch of independent convolutions of equal (Cout, Cin)."""
+    def _emit_conv(self, P, problems, Cout, Cin, flags, klass, f24=False):
+        """One launch of independent convolutions of equal (Cout, Cin); f24: on the F(2x4, 3x3) engine."""
         arr = self._conv_table(problems)
         px = sum(x.shape[0] * x.shape[2] * x.shape[3] for p in problems for x in p[0])
         wino = self._use_wino(Cout)
         if not wino and klass in (2, 3, 4, 16):
             klass = 18
-        idx = P.add(PR.CONV3X3, klass, i=(len(arr), Cout, Cin, flags, int(wino)), p=(arr, None, None),
+        idx = P.add(PR.CONV3X3, klass, i=(len(arr), Cout, Cin, flags, 2 if (f24 and wino) else int(wino)), p=(arr, None, None),
                     work=2.0 * 9 * Cout * Cin * px,
                     keep=[t for p in problems for t in (list(p[0]) + list(p[1] or []) + list(p[2] or []))
                           ] + [t for p in problems for t in p[3:] if t is not None])
@@ -219,17 +224,29 @@ class DistillHeads(object):
         self._wgrad_ops.append(idx)
         return idx, arr
 
-    def _alloc_packed(self, params, want_dgrad):
+    def _f24_layer(self, name, cout):
+        """Does the TEACHER's layer `name` run on the F(2x4, 3x3) engine?"""
+        if not self.teacher_f24 or cout < 128:
+            return False
+        return "_pred_" in name or self.teacher_f24 >= 2
+
+    def _alloc_packed(self, params, want_dgrad, f24=False):
         """Packed-filter buffers per layer in the layout of the engine that consumes them:
-        -> ({name: (fwd, dgrad)}, wino pack entries, direct pack ops)."""
+        -> ({name: (fwd, dgrad)}, wino pack entries, direct pack ops[, F(2x4) pack entries])."""
         L = K.lib()
-        packed, entries, direct = {}, [], []
+        packed, entries, direct, entries24 = {}, [], [], []
         for tower in ("cls", "bbox"):
             for name in self._layers(tower):
                 w = params[name + "_w"]
                 cout, cin = w.shape[0], w.shape[1]
                 pf = pd = None
                 fw, dw = self._use_wino(cout), self._use_wino(cin)
+                if f24 and fw and self._f24_layer(name, cout):
+                    pf = torch.empty(L.ssad_conv_wino24_filter_floats(cout, cin), dtype=torch.float32,
+                                     device=self.device)
+                    packed[name] = (pf, None)
+                    entries24.append((w, cout, cin, pf, None))
+                    continue
                 nf = (L.ssad_conv_wino_filter_floats if fw else L.ssad_conv_packed_filter_floats)(cout, cin)
                 pf = torch.empty(nf, dtype=torch.float32, device=self.device)
                 if want_dgrad:
@@ -242,9 +259,17 @@ class DistillHeads(object):
                 df, dd = (pf if not fw else None), (pd if (not dw and want_dgrad) else None)
                 if df is not None or dd is not None:
                     direct.append((w, cout, cin, df, dd))
-        return packed, entries, direct
+        return (packed, entries, direct, entries24) if f24 else (packed, entries, direct)
 
-    def _emit_pack(self, P, entries, direct):
+    def _emit_pack(self, P, entries, direct, entries24=()):
+        if entries24:
+            tab = (K.PackEntry * len(entries24))()
+            nbytes = 0
+            for k, (w, cout, cin, pf, _) in enumerate(entries24):
+                tab[k] = K.PackEntry(w.data_ptr(), cout, cin, pf.data_ptr(), 0)
+                nbytes += 4 * (w.numel() + pf.numel())
+            P.add(PR.WINO_PACK_FILTERS, 1, i=(len(entries24), 2), p=(tab,), work=nbytes,
+                  keep=[t for e in entries24 for t in e if isinstance(t, torch.Tensor)])
         if entries:
             tab = (K.PackEntry * len(entries))()
             nbytes = 0
@@ -270,10 +295,15 @@ class DistillHeads(object):
         # filters (the teacher's are frozen: packed by a program of their own, run when they change)
         self.packed, s_entries, s_direct = self._alloc_packed(self.params, True)
         if self.distill:
-            self.t_packed_pairs, t_entries, t_direct = self._alloc_packed(self.teacher, False)
+            if self.F16:            # (the fp16 subclass has its own pack layouts and no F(2x4) engine)
+                self.t_packed_pairs, t_entries, t_direct = self._alloc_packed(self.teacher, False)
+                t_extra = ()
+            else:
+                self.t_packed_pairs, t_entries, t_direct, t_entries24 = self._alloc_packed(self.teacher, False, f24=True)
+                t_extra = (t_entries24,)
             self.t_packed = {k: v[0] for k, v in self.t_packed_pairs.items()}
             T = self.prog_teacher_pack = PR.Program()
-            self._emit_pack(T, t_entries, t_direct)
+            self._emit_pack(T, t_entries, t_direct, *t_extra)
             T.build()
         P = self.prog = PR.Program()
         P.mark("pack")
@@ -325,6 +355,22 @@ class DistillHeads(object):
                 probs.append((sx[t], out, None, self.packed[name][0], self.params[name + "_b"]))
                 who.append("student")
                 sx[t] = out
+            if self.distill and self._f24_layer(self._layers("cls")[i], D):
+                # the teacher's towers on the F(2x4) engine: a launch of their own (class 21), the student's on F(2x2)
+                tp = [p for p, w in zip(probs, who) if w == "teacher"]
+                sp_ = [p for p, w in zip(probs, who) if w == "student"]
+                _, arr_t = self._emit_conv(P, tp, D, D, K.CONV_RELU, 21, f24=True)
+                # (the student's half alone is 19.5 + 4.5 rounds of the 256 CUs where the four towers together were
+                # 39 + 9: these launches have the chip to themselves, so their partial rounds are split)
+                _, arr_s = self._emit_conv(P, sp_, D, D, K.CONV_RELU | K.CONV_SPLIT_TAIL, 2)
+                if i == 0:
+                    for arr, plist, w in ((arr_t, tp, "teacher"), (arr_s, sp_, "student")):
+                        k = 0
+                        for (xs, _, _, _, _) in plist:
+                            for l in range(len(xs)):
+                                self._in_slots.append((arr, k, w, l))
+                                k += 1
+                continue
             _, arr = self._emit_conv(P, probs, D, D, K.CONV_RELU, 2)
             if i == 0:
                 k = 0
@@ -334,8 +380,9 @@ class DistillHeads(object):
                         k += 1
         cp, bp = self._layers("cls")[-1], self._layers("bbox")[-1]
         if self.distill:
+            f24 = self._f24_layer(cp, AC)
             self._emit_conv(P, [(tx["cls"], self.t_prob, None, self.t_packed_for(cp), self.teacher[cp + "_b"])],
-                            AC, D, K.CONV_SIGMOID, 3)
+                            AC, D, K.CONV_SIGMOID, 20 if f24 else 3, f24=f24)
         self._emit_conv(P, [(sx["cls"], self.cls_logits, None, self.packed[cp][0], self.params[cp + "_b"])],
                         AC, D, 0, 3)
         probs = [(sx["bbox"], self.bbox_pred, None, self.packed[bp][0], self.params[bp + "_b"])]

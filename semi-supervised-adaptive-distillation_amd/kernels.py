@@ -18,6 +18,7 @@ MAX_LEVELS = 8
 CONV_RELU = 1
 CONV_MASK_AUX = 2
 CONV_SIGMOID = 4
+CONV_SPLIT_TAIL = 8
 
 
 class KernelError(RuntimeError):
@@ -179,8 +180,12 @@ def lib():
     L.ssad_conv_wino_filter_floats.argtypes = [i32, i32]
     L.ssad_conv_wino_pack_filter.argtypes = [vp, i32, i32, vp, vp, vp]
     L.ssad_conv3x3_forward_wino.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp]
+    L.ssad_conv3x3_forward_wino24.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp]
+    L.ssad_conv_wino24_filter_floats.restype = sz
+    L.ssad_conv_wino24_filter_floats.argtypes = [i32, i32]
+    L.ssad_conv_wino24_pack_filters.argtypes = [C.POINTER(PackEntry), i32, vp]
     L.ssad_conv3x3_forward_wino_launches.argtypes = [C.POINTER(ConvLevel), i32]
-    L.ssad_conv3x3_forward_wino_launches_for.argtypes = [C.POINTER(ConvLevel), i32, i32, i32]
+    L.ssad_conv3x3_forward_wino_launches_for.argtypes = [C.POINTER(ConvLevel), i32, i32, i32, i32]
     L.ssad_conv_wino_split_tail.argtypes = [i32]
     L.ssad_conv3x3_wgrad_workspace_bytes.restype = sz
     L.ssad_conv3x3_wgrad_workspace_bytes.argtypes = [C.POINTER(ConvLevel), i32, i32, i32]
@@ -631,6 +636,34 @@ def conv_wino_pack_filter(w, want_fwd=True, want_dgrad=True):
     _check(L.ssad_conv_wino_pack_filter(_ptr(w), Cout, Cin, _ptr(pf), _ptr(pd), _stream()),
            "conv_wino_pack_filter")
     return pf, pd
+
+
+def conv_wino24_pack_filter(w):
+    """F(2x4, 3x3) filter pack U = G2 g G4^T (forward only: the engine of evaluated, frozen networks)."""
+    L = lib()
+    _f32c(w, "filter")
+    Cout, Cin, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise KernelError("only 3x3 filters")
+    pf = torch.empty(L.ssad_conv_wino24_filter_floats(Cout, Cin), dtype=torch.float32, device="cuda")
+    tab = (PackEntry * 1)(PackEntry(w.data_ptr(), Cout, Cin, pf.data_ptr(), 0))
+    _check(L.ssad_conv_wino24_pack_filters(tab, 1, _stream()), "conv_wino24_pack_filters")
+    return pf
+
+
+def conv3x3_forward_wino24(xs, packed, bias, Cout, *, relu=False, sigmoid=False, out=None):
+    """conv3x3_forward on the F(2x4, 3x3) engine (xs: levels sharing the filter; forward only)."""
+    L = lib()
+    for x in xs:
+        _f32c(x, "conv input")
+    Cin = xs[0].shape[1]
+    ys = out if out is not None else [
+        torch.empty((x.shape[0], Cout, x.shape[2], x.shape[3]), dtype=torch.float32, device="cuda") for x in xs]
+    flags = (CONV_RELU if relu else 0) | (CONV_SIGMOID if sigmoid else 0)
+    arr = _conv_levels(xs, ys, None)
+    _check(L.ssad_conv3x3_forward_wino24(arr, len(xs), _ptr(packed), _ptr(bias), Cout, Cin, flags, _stream()),
+           "conv3x3_forward_wino24")
+    return ys
 
 
 def _conv_levels(xs, ys, auxs, packs=None, biases=None):

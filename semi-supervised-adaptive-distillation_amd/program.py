@@ -51,6 +51,10 @@ KLASS = {
     13: dict(name="SigmoidAdaptiveDistillLoss bwd (distill_bwd_kernel)", bound="hbm"),
     14: dict(name="SigmoidFocalLoss fwd (focal_fwd_kernel + finalize)", bound="hbm"),
     15: dict(name="SigmoidFocalLoss bwd (focal_bwd_kernel)", bound="hbm"),
+    # the frozen teacher on the Winograd F(2x4, 3x3) engine: executed multiplies = direct-form / 3
+    20: dict(name="teacher cls_pred conv3x3 fwd + sigmoid, 720-wide, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma",
+             wino=True, exec_div=3.0),
+    21: dict(name="teacher tower conv3x3 fwd, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma", wino=True, exec_div=3.0),
     # direct (non-Winograd) engine
     18: dict(name="subnet conv3x3 fwd/dgrad, direct engine (conv3x3_kernel)", bound="mfma", wino=False),
     19: dict(name="subnet conv3x3 filter gradient, direct engine (conv3x3_wgrad_kernel + reduce)",
@@ -65,6 +69,8 @@ KLASS = {
     38: dict(name="gradient finiteness check + loss-scale update", bound="hbm"),
     # backbone (row f1)
     48: dict(name="backbone conv3x3 fwd/dgrad (wino_conv_z_kernel)", bound="mfma", wino=True),
+    47: dict(name="frozen teacher backbone conv3x3 fwd, >= 128 wide, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma",
+             wino=True, exec_div=3.0),
     49: dict(name="backbone conv3x3 filter gradient (wino_wgrad_kernel)", bound="mfma", wino=True),
     50: dict(name="backbone pointwise conv fwd / data gradient (gemm_conv_nn_kernel)", bound="mfma", wino=False),
     51: dict(name="backbone elementwise: subsample / scatter, ReluGradient + bias sums, upsample, pool, adds",

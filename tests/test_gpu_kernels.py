@@ -783,12 +783,12 @@ def test_wino_split_tail_vs_unsplit_vs_oracle(K, case):
     arr = K._conv_levels([X], [torch.empty((N, Cout, H, W), device="cuda")], mask)
     prev = L.ssad_conv_wino_split_tail(2)         # 2: every partial round (the default, 1, splits only launches without a full round)
     try:
-        with_split = L.ssad_conv3x3_forward_wino_launches_for(arr, 1, Cout, Cin)
+        with_split = L.ssad_conv3x3_forward_wino_launches_for(arr, 1, Cout, Cin, 0)
         Ys = K.conv3x3_forward([X], wf, b, Cout, relu=relu, mask_by=mask, wino=True)[0].clone()
         Ys2 = K.conv3x3_forward([X], wf, b, Cout, relu=relu, mask_by=mask, wino=True)[0]
         assert torch.equal(Ys, Ys2)                                  # whoever arrives last: the same bits
         L.ssad_conv_wino_split_tail(0)
-        assert L.ssad_conv3x3_forward_wino_launches_for(arr, 1, Cout, Cin) == 1
+        assert L.ssad_conv3x3_forward_wino_launches_for(arr, 1, Cout, Cin, 0) == 1
         assert with_split == (2 if N * ((H + 7) // 8) * ((W + 7) // 8) * ((Cout + 127) // 128) >= 512 else 1)
         Yu = K.conv3x3_forward([X], wf, b, Cout, relu=relu, mask_by=mask, wino=True)[0]
     finally:
@@ -803,3 +803,56 @@ def test_wino_split_tail_vs_unsplit_vs_oracle(K, case):
         ref = np.where(mask[0][n0:n0 + 1].cpu().numpy() > 0, ref, 0)
     close(Ys[n0:n0 + 1].cpu().numpy(), ref, CONV_RTOL, CONV_FLOOR, "split tail vs oracle")
     close(Yu[n0:n0 + 1].cpu().numpy(), ref, CONV_RTOL, CONV_FLOOR, "unsplit vs oracle")
+
+
+# ---------------------------------------------------------------------------
+# Round 5: Winograd F(2x4, 3x3), the forward engine of frozen (evaluated-only) networks
+# ---------------------------------------------------------------------------
+
+F24_RTOL, F24_FLOOR = 1e-4, 2e-5      # the direct kernel's bar; the floor covers F(4,3)'s ~2e-6-of-scale round-off
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 16, 128, 8, 16), (2, 36, 256, 5, 7), (1, 256, 256, 10, 14), (1, 24, 130, 17, 33), (3, 40, 129, 2, 31),
+    (2, 256, 720, 3, 4), (2, 128, 128, 9, 12)], ids=lambda s: "N%d_C%d_M%d_%dx%d" % s)
+def test_winograd24_vs_oracle(K, shape):
+    """conv3x3_winograd24.hip against the oracle (conv_op_impl.h:31-202): bias, ReLU and Sigmoid epilogues,
+    channel tails (Cin, Cout not multiples of 16 / 128), maps that need the scalar edge stores."""
+    N, Cin, M, H, W = shape
+    rng = np.random.default_rng(2400 + sum(shape))
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, 3, 3)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    pf = K.conv_wino24_pack_filter(dev(Wt))
+    ref = oracle.conv_forward(X, Wt, b)
+    close(K.conv3x3_forward_wino24([dev(X)], pf, dev(b), M)[0].cpu().numpy(), ref, F24_RTOL, F24_FLOOR, "wino24 Y")
+    close(K.conv3x3_forward_wino24([dev(X)], pf, dev(b), M, relu=True)[0].cpu().numpy(), oracle.relu(ref), F24_RTOL,
+          F24_FLOOR, "wino24 relu")
+    sig = 1.0 / (1.0 + np.exp(-ref.astype(np.float64)))
+    close(K.conv3x3_forward_wino24([dev(X)], pf, dev(b), M, sigmoid=True)[0].cpu().numpy(), sig, F24_RTOL, F24_FLOOR,
+          "wino24 sigmoid")
+    close(K.conv3x3_forward_wino24([dev(X)], pf, None, M)[0].cpu().numpy(), oracle.conv_forward(X, Wt, None), F24_RTOL,
+          F24_FLOOR, "wino24 no bias")
+
+
+def test_winograd24_levels_full_size_vs_winograd22_and_oracle(K):
+    """The teacher's tower layer at config 3's size (bs 16, all five levels in one call: both staging geometries):
+    against the F(2x2) engine on every element (both are fp32 Winograd: agreement to ~3e-6 of the scale), one image of
+    P3 against the oracle, bit-reproducible."""
+    gen = torch.Generator(device="cuda").manual_seed(24)
+    N, C, M = 16, 256, 256
+    shapes = [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)]
+    Xs = [torch.randn((N, C, h, w), device="cuda", generator=gen).clamp_(min=0) for h, w in shapes]
+    Wt = torch.randn((M, C, 3, 3), device="cuda", generator=gen) * 0.02
+    b = torch.randn(M, device="cuda", generator=gen)
+    p24 = K.conv_wino24_pack_filter(Wt)
+    p22, _ = K.conv_wino_pack_filter(Wt, True, False)
+    Y24 = K.conv3x3_forward_wino24(Xs, p24, b, M, relu=True)
+    Y22 = K.conv3x3_forward(Xs, p22, b, M, relu=True, wino=True)
+    for a, c in zip(Y24, Y22):
+        assert (a - c).abs().max().item() <= 1e-5 * c.abs().max().item()
+    again = K.conv3x3_forward_wino24(Xs, p24, b, M, relu=True)
+    assert all(torch.equal(a, c) for a, c in zip(Y24, again))
+    n0 = 7
+    ref = oracle.relu(oracle.conv_forward(Xs[0][n0:n0 + 1].cpu().numpy(), Wt.cpu().numpy(), b.cpu().numpy()))
+    close(Y24[0][n0:n0 + 1].cpu().numpy(), ref, F24_RTOL, F24_FLOOR, "wino24 P3 slice")

@@ -13,7 +13,7 @@ def run(N, Cin, Cout, H, W):
     Yu = K.conv3x3_forward([X], wf, b, Cout, wino=True)[0].clone()
     L.ssad_conv_wino_split_tail(1)
     arr = K._conv_levels([X], [Yu], None)
-    nl = L.ssad_conv3x3_forward_wino_launches_for(arr, 1, Cout, Cin)
+    nl = L.ssad_conv3x3_forward_wino_launches_for(arr, 1, Cout, Cin, 0)
     outs = []
     for rep in range(3):
         Ys = K.conv3x3_forward([X], wf, b, Cout, wino=True)[0].clone()

@@ -54,9 +54,19 @@ def class_sequences(f16=False):
             # one call = one launch per staging geometry present among its levels (8 x 16 patches / sub-patch
             # pairs, conv3x3_winograd.hip); the levels of the batch-1 program have the bench's map sizes
             import ctypes as C
-            # (+ the split-tail launch of a geometry whose partial round is split, round 5)
-            launches = K.lib().ssad_conv3x3_forward_wino_launches_for(C.cast(op.p[0], C.POINTER(K.ConvLevel)), op.i[0],
-                                                                      op.i[1], op.i[2])
+            # (+ the split-tail launch of a geometry whose partial round is split, round 5: that depends on the
+            # batch, so the batch-1 program's levels are asked about at the bench's batch of 16)
+            src = C.cast(op.p[0], C.POINTER(K.ConvLevel))
+            lv16 = (K.ConvLevel * op.i[0])()
+            for q in range(op.i[0]):
+                lv16[q] = src[q]
+                lv16[q].N = 16
+            launches = K.lib().ssad_conv3x3_forward_wino_launches_for(lv16, op.i[0], op.i[1], op.i[2], op.i[3])
+            if op.i[4] == 2:      # the F(2x4) engine: another kernel name, one launch per staging geometry
+                launches = K.lib().ssad_conv3x3_forward_wino_launches(lv16, op.i[0])
+                for k in range(launches):
+                    seq.setdefault("wino24_conv_kernel", []).append((op.klass, k == 0))
+                continue
         for k in range(launches):
             seq.setdefault(n, []).append((op.klass, k == 0))
     return seq

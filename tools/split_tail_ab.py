@@ -40,7 +40,7 @@ def main():
             res.setdefault(on, []).append(timeit(fn))
         arr = K._conv_levels([x], out, None)
         L.ssad_conv_wino_split_tail(1)
-        nl = L.ssad_conv3x3_forward_wino_launches_for(arr, 1, co, ci)
+        nl = L.ssad_conv3x3_forward_wino_launches_for(arr, 1, co, ci, 0)
         t0, t1 = min(res[0]), min(res[1])
         print("%4d->%3d @%3dx%3d %6.1f GF | unsplit %.3f ms %5.1f TF/s exec | split %.3f ms %5.1f TF/s exec (%d launches) | %+.1f %%"
               % (ci, co, H, W, fl, t0, fl / t0 / 2.25, t1, fl / t1 / 2.25, nl, 100.0 * (t1 - t0) / t0), flush=True)
