@@ -34,7 +34,8 @@ string LoweringReport::ToString() const {
                     relu_grad_fused, "; ConvGroup ", conv_groups, " (", conv_group_members,
                     " Conv); ConvGradientGroup ", conv_grad_groups, " (", conv_grad_group_members,
                     " ConvGradient); Sum absorbed ", sums_absorbed, "; loss groups ", loss_groups, " (",
-                    loss_group_members, " ops)", fell_back ? "; FELL BACK to the list as written" : "");
+                    loss_group_members, " ops); F(2x4) Conv ", frozen_f24,
+                    fell_back ? "; FELL BACK to the list as written" : "");
 }
 
 NetBase::NetBase(const NetDef& def, Workspace* ws) : name_(def.name) {
@@ -56,6 +57,8 @@ NetBase::NetBase(const NetDef& def, Workspace* ws) : name_(def.name) {
     opt.fuse_relu = EnvFlag("C2HIP_NET_FUSE_RELU", true);
     opt.group_convs = EnvFlag("C2HIP_NET_GROUP_CONVS", true);
     opt.group_losses = EnvFlag("C2HIP_NET_GROUP_LOSSES", true);
+    const Argument* f24 = FindArg(def, "hip_frozen_f24");
+    opt.frozen_f24 = EnvFlag("C2HIP_NET_FROZEN_F24", !(f24 && f24->has_i && f24->i == 0));
     opt.blob_dtype = [ws](const string& n) { return BlobDtype(ws, n); };
     for (const string& s : def.external_output) opt.keep.insert(s);
     if (const Argument* k = FindArg(def, "hip_keep_blobs"))

@@ -34,6 +34,7 @@ struct LoweringOptions {
   bool fuse_relu = true;        // Conv + Relu, ReluGradient + ConvGradient
   bool group_convs = true;      // ConvGroup / ConvGradientGroup (+ Sum absorption)
   bool group_losses = true;     // per-level loss operators of one kind -> one multi-level launch
+  bool frozen_f24 = true;       // nets without gradient operators: Conv on the F(2x4, 3x3) engine (hip_algo = winograd24)
   // TensorProto::DataType id of a blob that exists already (parameters do when a net is created:
   // the reference runs param_init_net first), 0 if unknown.  The fused 3x3 paths are fp32-only.
   std::function<int(const string&)> blob_dtype;
@@ -48,6 +49,7 @@ struct LoweringReport {
   int conv_groups = 0, conv_group_members = 0;
   int conv_grad_groups = 0, conv_grad_group_members = 0;
   int sums_absorbed = 0, loss_groups = 0, loss_group_members = 0;
+  int frozen_f24 = 0;           // Conv operators of an evaluated-only net sent to the F(2x4, 3x3) engine
   bool fell_back = false;       // the lowered list failed its own verification: list kept as written
   string ToString() const;
 };

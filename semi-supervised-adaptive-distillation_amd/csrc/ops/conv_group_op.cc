@@ -93,15 +93,19 @@ class ConvGroupOp final : public Operator<HIPContext> {
     }
     hipStream_t s = context_.hip_stream();
     const long long before = cache_.packs_issued();
-    for (const Problem& p : probs)
-      cache_.Want(*p.w, UseWinograd(algo_, p.M) ? FilterPackCache::WINO_FWD : FilterPackCache::DIRECT_FWD);
+    // hip_algo = "winograd24" (set by the net lowering for nets without gradient operators): the F(2x4, 3x3)
+    // engine of evaluated-only networks for the problems it serves (>= 128 outputs), "auto" for the rest
+    auto kind_of = [&](const Problem& p) {
+      if (algo_ == "winograd24") return p.M >= 128 ? FilterPackCache::WINO24_FWD : FilterPackCache::WINO_FWD;
+      return UseWinograd(algo_, p.M) ? FilterPackCache::WINO_FWD : FilterPackCache::DIRECT_FWD;
+    };
+    for (const Problem& p : probs) cache_.Want(*p.w, kind_of(p));
     cache_.Flush(s);
     g_filter_packs_issued += cache_.packs_issued() - before;
     const int flags = fuse_relu_ ? SSAD_CONV_RELU : 0;
     for (const vector<int>& cls : Classes(probs)) {
       const Problem& p0 = probs[cls[0]];
-      const bool wino = UseWinograd(algo_, p0.M);
-      const auto kind = wino ? FilterPackCache::WINO_FWD : FilterPackCache::DIRECT_FWD;
+      const auto kind = kind_of(p0);
       for (size_t at = 0; at < cls.size(); at += SSAD_MAX_CONV_PROBLEMS) {
         const int n = (int)std::min<size_t>(SSAD_MAX_CONV_PROBLEMS, cls.size() - at);
         ssad_conv_level lv[SSAD_MAX_CONV_PROBLEMS];
@@ -112,8 +116,11 @@ class ConvGroupOp final : public Operator<HIPContext> {
         }
         // per-problem filter / bias; the launch-wide bias only says whether one is added at all
         const float* any_bias = lv[0].bias;
-        const int rc = wino ? ssad_conv3x3_forward_wino(lv, n, lv[0].packed, any_bias, p0.M, p0.C, flags, s)
-                            : ssad_conv3x3_forward(lv, n, lv[0].packed, any_bias, p0.M, p0.C, flags, s);
+        const int rc = kind == FilterPackCache::WINO24_FWD
+                           ? ssad_conv3x3_forward_wino24(lv, n, lv[0].packed, any_bias, p0.M, p0.C, flags, s)
+                       : kind == FilterPackCache::WINO_FWD
+                           ? ssad_conv3x3_forward_wino(lv, n, lv[0].packed, any_bias, p0.M, p0.C, flags, s)
+                           : ssad_conv3x3_forward(lv, n, lv[0].packed, any_bias, p0.M, p0.C, flags, s);
         CAFFE_ENFORCE_EQ(rc, 0, "ConvGroup launch failed");
         ++g_conv_launch_calls;
       }

@@ -32,6 +32,8 @@ bool IsDefaultEngineGeometry(const ConvGeometry& g) {
 bool UseWinograd(const string& algo, int out_channels) {
   if (algo == "direct") return false;
   if (algo == "winograd") return true;
+  // ("winograd24" names the forward engine of evaluated-only nets; wherever it does not apply -- narrow layers,
+  // a gradient operator that inherited the argument -- the choice is the automatic one)
   return out_channels >= 32;
 }
 
@@ -88,15 +90,17 @@ bool ConvOp<float, HIPContext>::RunOnDevice() {
   const int flags = fuse_relu_ ? SSAD_CONV_RELU : 0;
   int rc;
   // the packed filter is rebuilt only when the filter blob was written since (ops/filter_pack_cache.h)
-  const bool wino = UseWinograd(algo_, M);
-  const auto kind = wino ? FilterPackCache::WINO_FWD : FilterPackCache::DIRECT_FWD;
+  const bool f24 = algo_ == "winograd24" && M >= 128;      // evaluated-only nets (net_lowering.cc)
+  const bool wino = UseWinograd(algo_ == "winograd24" ? string("auto") : algo_, M);
+  const auto kind = f24 ? FilterPackCache::WINO24_FWD : wino ? FilterPackCache::WINO_FWD : FilterPackCache::DIRECT_FWD;
   const long long before = pack_cache_.packs_issued();
   pack_cache_.Want(filter, kind);
   pack_cache_.Flush(s);
   g_filter_packs_issued += pack_cache_.packs_issued() - before;
   const float* packed = pack_cache_.Packed(filter, kind);
-  rc = wino ? ssad_conv3x3_forward_wino(&lv, 1, packed, bias, M, C, flags, s)
-            : ssad_conv3x3_forward(&lv, 1, packed, bias, M, C, flags, s);
+  rc = f24 ? ssad_conv3x3_forward_wino24(&lv, 1, packed, bias, M, C, flags, s)
+       : wino ? ssad_conv3x3_forward_wino(&lv, 1, packed, bias, M, C, flags, s)
+              : ssad_conv3x3_forward(&lv, 1, packed, bias, M, C, flags, s);
   CAFFE_ENFORCE_EQ(rc, 0, "Conv launch failed");
   ++g_conv_launch_calls;
   return true;

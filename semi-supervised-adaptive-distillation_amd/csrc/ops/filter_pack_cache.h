@@ -18,7 +18,7 @@ namespace caffe2 {
 
 class FilterPackCache {
  public:
-  enum Kind { WINO_FWD = 0, WINO_DGRAD = 1, DIRECT_FWD = 2, DIRECT_DGRAD = 3 };
+  enum Kind { WINO_FWD = 0, WINO_DGRAD = 1, DIRECT_FWD = 2, DIRECT_DGRAD = 3, WINO24_FWD = 4 };
 
   // Queue `filter` ([M][C][3][3], fp32) for layout `kind`; Flush() issues the packs that are stale
   // (one multi-filter launch for the Winograd layouts) on `stream`; Packed() is valid after it.
@@ -35,7 +35,8 @@ class FilterPackCache {
     const bool dgrad = kind == WINO_DGRAD || kind == DIRECT_DGRAD;
     const bool wino = kind == WINO_FWD || kind == WINO_DGRAD;
     const int po = dgrad ? C : M, pi = dgrad ? M : C;       // the pack's (outputs, inputs)
-    e.packed.Resize((TIndex)(wino ? ssad_conv_wino_filter_floats(po, pi) : ssad_conv_packed_filter_floats(po, pi)));
+    e.packed.Resize((TIndex)(kind == WINO24_FWD ? ssad_conv_wino24_filter_floats(po, pi)
+                             : wino ? ssad_conv_wino_filter_floats(po, pi) : ssad_conv_packed_filter_floats(po, pi)));
     e.packed.mutable_data<float>();
     e.queued = true;
     e.src = filter.data<float>();
@@ -43,13 +44,14 @@ class FilterPackCache {
   }
 
   void Flush(hipStream_t stream) {
-    vector<ssad_pack_entry> wino;
+    vector<ssad_pack_entry> wino, wino24;
     for (const Key& k : queue_) {
       Entry& e = entries_[k];
       float* p = e.packed.mutable_data<float>();
       switch ((Kind)k.second) {
         case WINO_FWD: wino.push_back({e.src, e.M, e.C, p, nullptr}); break;
         case WINO_DGRAD: wino.push_back({e.src, e.M, e.C, nullptr, p}); break;
+        case WINO24_FWD: wino24.push_back({e.src, e.M, e.C, p, nullptr}); break;
         case DIRECT_FWD:
           CAFFE_ENFORCE_EQ(ssad_conv_pack_filter(e.src, e.M, e.C, p, nullptr, stream), 0);
           break;
@@ -63,6 +65,9 @@ class FilterPackCache {
     }
     if (!wino.empty())
       CAFFE_ENFORCE_EQ(ssad_conv_wino_pack_filters(wino.data(), (int)wino.size(), stream), 0,
+                       "filter pack launch failed");
+    if (!wino24.empty())
+      CAFFE_ENFORCE_EQ(ssad_conv_wino24_pack_filters(wino24.data(), (int)wino24.size(), stream), 0,
                        "filter pack launch failed");
     queue_.clear();
   }

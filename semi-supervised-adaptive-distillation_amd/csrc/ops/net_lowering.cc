@@ -174,6 +174,23 @@ struct Lowering {
     }
   }
 
+  // ---- F24: a net without gradient operators is only evaluated (the teacher net, model_builder.py:373-411 in test
+  //      mode; an inference net): its 3x3 convolutions may take the F(2x4, 3x3) engine (conv3x3_winograd24.hip: 3
+  //      multiplies per output, fp32 error ~2e-6 of the output scale).  hip_algo given by the graph wins.
+  void MarkFrozen() {
+    for (const Node& n : nodes) {
+      const string& t = n.def.type;
+      if (n.def.is_gradient_op || (t.size() > 8 && t.compare(t.size() - 8, 8, "Gradient") == 0) ||
+          t == "MomentumSGDUpdate" || t == "WeightedSum")
+        return;
+    }
+    for (Node& n : nodes)
+      if (!n.removed && n.def.type == "Conv" && IsFusedPathConv(n) && !FindArg(n.def, "hip_algo")) {
+        n.def.arg.push_back(MakeArgument("hip_algo", string("winograd24")));
+        ++rep.frozen_f24;
+      }
+  }
+
   // ---- F3 -----------------------------------------------------------------------------------
   // A Sum whose inputs are exactly the slot-`slot` outputs of ConvGradients that share one filter value.
   bool SumOfFilterGradients(const Node& s, size_t slot, vector<int>* members) const {
@@ -464,6 +481,7 @@ vector<OperatorDef> LowerNet(const NetDef& def, const LoweringOptions& opt, Lowe
   Lowering L(opt, rep);
   L.Build(def.op);
   if (opt.fuse_relu) L.FuseRelu();
+  if (opt.frozen_f24) L.MarkFrozen();
   if (opt.group_convs) L.AbsorbSums();
   L.MakeUnits();
   vector<vector<int>> order;

@@ -184,3 +184,23 @@ def test_write_after_read_and_keep():
     ops, report = workspace.LowerNet(net2)
     assert "Sum absorbed 0" in report and collections.Counter(o.type for o in ops)["Sum"] == 2
     assert gm["w"] == "w_grad"
+
+
+def test_evaluated_only_nets_take_the_f24_engine_training_nets_do_not():
+    """A net without gradient operators (the teacher net, an inference net) is only evaluated: its 3x3 convolutions
+    get hip_algo = "winograd24" (conv3x3_winograd24.hip; 3 multiplies per output, fp32 error ~2e-6 of the scale).
+    A net that trains keeps the F(2x2) engine everywhere; an explicit hip_algo in the graph is respected."""
+    _, teacher, student, _ = head_nets(update=True)
+    t_ops, t_rep = workspace.LowerNet(teacher.net)
+    for g in [o for o in t_ops if o.type == "ConvGroup"]:
+        assert [a.s for a in g.arg if a.name == "hip_algo"] == [b"winograd24"], g.arg
+    assert "F(2x4) Conv 50" in t_rep
+    s_ops, s_rep = workspace.LowerNet(student.net)
+    assert not any(a.name == "hip_algo" for o in s_ops for a in o.arg) and "F(2x4) Conv 0" in s_rep
+    net = core.Net("pinned")
+    with core.DeviceScope(GPU):
+        net.Conv(["x", "w", "b"], ["y"], kernel=3, pad=1, stride=1, order="NCHW", hip_algo="direct")
+        net.Conv(["y", "w2", "b2"], ["z"], kernel=3, pad=1, stride=1, order="NCHW")
+    ops, _ = workspace.LowerNet(net)
+    algos = [[a.s for a in o.arg if a.name == "hip_algo"] for o in ops]
+    assert algos == [[b"direct"], [b"winograd24"]], algos
