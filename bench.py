@@ -101,6 +101,7 @@ def kernel_report(classes, steps):
         rate = c["work"] / (c["ms"] * 1e-3)
         if meta["bound"] in ("mfma", "mfma16"):
             executed = rate / meta.get("exec_div", 2.25) if meta.get("wino") else rate
+            row["exec_div"] = meta.get("exec_div", 2.25) if meta.get("wino") else 1.0
             row.update(unit="TFLOP/s", achieved=round(executed / 1e12, 2),
                        direct_equiv_tflops=round(rate / 1e12, 2), peak=PR.PEAK[meta["bound"]] / 1e12,
                        frac=round(executed / PR.PEAK[meta["bound"]], 4),
@@ -113,7 +114,7 @@ def kernel_report(classes, steps):
 
 
 # which kernel source a timing class's dominant kernel lives in (for the staleness check of `traffic`)
-_KERNEL_SOURCE = {"wino_conv_z_kernel": "conv3x3_winograd.hip", "wino_wgrad_kernel": "conv3x3_wgrad_winograd.hip",
+_KERNEL_SOURCE = {"wino_conv_z_kernel": "conv3x3_winograd.hip", "wino24_conv_kernel": "conv3x3_winograd24.hip", "wino_wgrad_kernel": "conv3x3_wgrad_winograd.hip",
                   "pow_sum_kernel": "distill_loss.hip", "cls_losses_fused_kernel": "distill_loss.hip",
                   "sgd_flat_kernel": "elementwise.hip"}
 
@@ -516,7 +517,7 @@ def main():
     # dominant convolution, the loss kernels, PowSum): events between all ~500 launches of a step keep
     # consecutive kernels from overlapping their tails and cost 1 % of the step (2.5 % with collectives
     # in flight).  `kernels[]` comes from instrumented steps after the timed region.
-    ROOFLINE_CLASSES = [2, 18, 34, 8, 9, 15]
+    ROOFLINE_CLASSES = [2, 23, 18, 34, 8, 9, 15]
     timing = PR.Timing().select(ROOFLINE_CLASSES)
     heads.timing = timing
     if args.workload == "full":
@@ -580,14 +581,14 @@ def main():
     if rank == 0:
         rows = kernel_report(timing_all.collect(), max(args.profile_steps, 1))      # all families
         by = {r["class"]: r for r in kernel_report(timing.collect(), args.steps)}     # the timed region
-        dom_k = 34 if f16 else (2 if 2 in by else 18)
+        dom_k = 34 if f16 else (2 if 2 in by else 23 if 23 in by else 18)      # 23: SSAD_STUDENT_F24 & 4
         dom = by.get(dom_k)
         traffic, traffic_note, traffic_round = pmc_traffic(dom_k) if not f16 else (None, None, None)
         # algorithmic HBM bytes of one launch of the dominant class: the four towers' inputs + outputs of
         # all levels + the packed filters, each once (fp32)
         px = N * sum(h * w for h, w in shapes)
-        ntow = (4 if distill else 2) if dom_k == 2 else 1
-        dom_alg_bytes = ntow * (2 * 256 * px * 4 + 16 * 256 * 256 * 4) if dom_k == 2 else None
+        ntow = (4 if distill else 2) if dom_k in (2, 23) else 1
+        dom_alg_bytes = ntow * (2 * 256 * px * 4 + 16 * 256 * 256 * 4) if dom_k in (2, 23) else None
         heads_ms = sum(r["ms_per_step"] for r in rows if r["class"] < 48)
         backbone_ms = sum(r["ms_per_step"] for r in rows if r["class"] >= 48)
         out = {
@@ -634,9 +635,11 @@ def main():
                              traffic_over_algorithmic=(round(traffic / dom_alg_bytes, 2)
                                                        if (traffic and dom_alg_bytes) else None),
                              direct_equiv_tflops=dom["direct_equiv_tflops"],
+                             exec_div=dom.get("exec_div"),
                              achieved_note=("executed MFMA FLOP/s: algorithmic direct-form flops (2*9*Cout*Cin "
-                                            "per output pixel, SURVEY 8d) / 2.25 for the Winograd F(2x2,3x3) "
-                                            "engine; direct_equiv_tflops is the direct-form rate" if not f16
+                                            "per output pixel, SURVEY 8d) / exec_div -- 3 for the Winograd "
+                                            "F(2x4,3x3) engine (24 products per 8 outputs), 2.25 for F(2x2,3x3) "
+                                            "(16 per 4); direct_equiv_tflops is the direct-form rate" if not f16
                                             else "algorithmic direct-form FLOP/s; the kernel executes exactly these"),
                              launches_per_step=dom["launches_per_step"], avg_launch_ms=dom["avg_launch_ms"],
                              flops_per_launch=dom["flops_per_launch"]) if dom else None,

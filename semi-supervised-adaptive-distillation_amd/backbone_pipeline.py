@@ -317,7 +317,7 @@ class NativeResNetFPN(object):
         """probs: [(x, y, mask or None, packed, bias or None)]: independent 3x3 convolutions of one
         (Cout, Cin) in one launch; f24: on the F(2x4, 3x3) engine (packs from ssad_conv_wino24_pack_filters)."""
         if f24:
-            klass = 47
+            klass = 46 if self.train else 47
         arr = (K.ConvLevel * len(probs))()
         for i, (x, y, mask, packed, bias) in enumerate(probs):
             arr[i] = K.ConvLevel(x.data_ptr(), y.data_ptr(), mask.data_ptr() if mask is not None else 0,
@@ -438,11 +438,14 @@ class NativeResNetFPN(object):
         # packed filters: frozen layers once (prepare program), trainable layers every step (pack segment)
         prep, P = PR.Program(), PR.Program()
         self.prep, self.prog = prep, P
-        wino_frozen, wino_train, wino24_frozen = [], [], []
+        wino_frozen, wino_train, wino24_frozen, wino24_train = [], [], [], []
         # A network that is only evaluated (the distillation step's frozen teacher) runs its 3x3 layers of >= 128
         # outputs on the F(2x4, 3x3) engine: 3 multiplies per output instead of 4, fp32 error ~2e-6 of the output
         # scale (conv3x3_winograd24.hip; SSAD_TEACHER_F24=0: the F(2x2) engine as in rounds 1-4)
         use_f24 = (not self.train) and int(os.environ.get("SSAD_TEACHER_F24", "1")) >= 1
+        # SSAD_STUDENT_F24 bit 8 (default on): the TRAINED network's 3x3 layers of >= 128 channels too, forward and data
+        # gradient (the filter gradient keeps its F(3x3, 2x2) engine); DESIGN 3.10e has the error and step-time A/B
+        use_f24_train = self.train and (int(os.environ.get("SSAD_STUDENT_F24", "15")) & 8) != 0
         tr_frozen, tr_train = [], []          # (w, wt, M, K, ldm): every transposed filter of a program in one launch
         P.mark("pack")
         for l in L.values():
@@ -464,6 +467,11 @@ class NativeResNetFPN(object):
                 l.pf = self._t(lib.ssad_conv_wino24_filter_floats(l.cout, l.cin))
                 l.f24 = True
                 wino24_frozen.append(l)
+            elif l.k == 3 and use_f24_train and l.train and l.cout >= 128 and l.cin >= 128:
+                l.pf = self._t(lib.ssad_conv_wino24_filter_floats(l.cout, l.cin))
+                l.pd = self._t(lib.ssad_conv_wino24_filter_floats(l.cin, l.cout))
+                l.f24 = True
+                wino24_train.append(l)
             elif l.k == 3:
                 l.pf = self._t(lib.ssad_conv_wino_filter_floats(l.cout, l.cin))
                 need_pd = l.train                  # every trainable 3x3 sends a gradient further down
@@ -491,12 +499,15 @@ class NativeResNetFPN(object):
                 tgt.add(PR.WINO_PACK_FILTERS, 54, i=(len(ls),), p=(tab,),
                         work=4.0 * sum(l.w.numel() + l.pf.numel() + (l.pd.numel() if l.pd is not None else 0)
                                        for l in ls))
-        if wino24_frozen:
-            tab = (K.PackEntry * len(wino24_frozen))()
-            for i, l in enumerate(wino24_frozen):
-                tab[i] = K.PackEntry(l.w.data_ptr(), l.cout, l.cin, l.pf.data_ptr(), 0)
-            prep.add(PR.WINO_PACK_FILTERS, 54, i=(len(wino24_frozen), 2), p=(tab,),
-                     work=4.0 * sum(l.w.numel() + l.pf.numel() for l in wino24_frozen))
+        for tgt, ls in ((prep, wino24_frozen), (P, wino24_train)):
+            if ls:
+                tab = (K.PackEntry * len(ls))()
+                for i, l in enumerate(ls):
+                    tab[i] = K.PackEntry(l.w.data_ptr(), l.cout, l.cin, l.pf.data_ptr(),
+                                         l.pd.data_ptr() if l.pd is not None else 0)
+                tgt.add(PR.WINO_PACK_FILTERS, 54, i=(len(ls), 2), p=(tab,),
+                        work=4.0 * sum(l.w.numel() + l.pf.numel() + (l.pd.numel() if l.pd is not None else 0)
+                                       for l in ls))
         prep.build()
         self._packed_frozen = False
         P.mark("forward")
@@ -641,20 +652,21 @@ class NativeResNetFPN(object):
             self._ew(P, PR.SUBSAMPLE_GRAD, i=(N, D, d7f.shape[2], d7f.shape[3], 2, 0), p=(d7, d7f), nbytes=4.0 * d7f.numel())
             self._wgrad3(P, r6, d7f, l7)
             dr6 = self._like(r6)
-            self._conv3(P, [(d7f, dr6, r6, l7.pd, None)], D, D, K.CONV_MASK_AUX)          # masked by p6 > 0
+            self._conv3(P, [(d7f, dr6, r6, l7.pd, None)], D, D, K.CONV_MASK_AUX, f24=l7.f24)   # masked by p6 > 0
             ptrs = (C.c_void_p * 2)(d6.data_ptr(), dr6.data_ptr())
             P.add(PR.SUM_N, 51, i=(2,), l=(d6.numel(),), p=(ptrs, d6), work=12.0 * d6.numel(), keep=[d6, dr6])
             # P6 = sub(conv(c5))
             d6f = self._like(S["p6f"])
             self._ew(P, PR.SUBSAMPLE_GRAD, i=(N, D, d6f.shape[2], d6f.shape[3], 2, 0), p=(d6, d6f), nbytes=4.0 * d6f.numel())
             self._wgrad3(P, c5, d6f, l6)
-            self._conv3(P, [(d6f, dc5, None, l6.pd, None)], l6.cin, D, 0)
+            self._conv3(P, [(d6f, dc5, None, l6.pd, None)], l6.cin, D, 0, f24=l6.f24)
         # output convs: filter gradients and the three data gradients in one launch
         dt5, dt4, dt3 = self._like(t5), self._like(t4), self._like(t3)
         for t, d, name in ((t5, d5, "out.0"), (t4, d4, "out.1"), (t3, d3, "out.2")):
             self._wgrad3(P, t, d, L[name])
         self._conv3(P, [(d, dt, None, L[name].pd, None)
-                        for d, dt, name in ((d5, dt5, "out.0"), (d4, dt4, "out.1"), (d3, dt3, "out.2"))], D, D, 0)
+                        for d, dt, name in ((d5, dt5, "out.0"), (d4, dt4, "out.1"), (d3, dt3, "out.2"))], D, D, 0,
+                   f24=L["out.0"].f24)
         # top-down path: t3 = lat2(c3) + up(t4), t4 = lat1(c4) + up(t5)
         up4, up5 = self._like(t4), self._like(t5)
         self._ew(P, PR.UPSAMPLE_GRAD, i=(N, D, t4.shape[2], t4.shape[3], 2), p=(dt3, up4), nbytes=5.0 * dt3.numel())
@@ -703,7 +715,7 @@ class NativeResNetFPN(object):
             self._gemm(P, l3.w.view(cout, cmid), cmid, dz, dz2, cout, cmid, mask=y2)
             self._wgrad3(P, y1, dz2, l2)                                   # + bias gradient of c2
             dz1 = self._like(y1)
-            self._conv3(P, [(dz2, dz1, y1, l2.pd, None)], cmid, cmid, K.CONV_MASK_AUX)
+            self._conv3(P, [(dz2, dz1, y1, l2.pd, None)], cmid, cmid, K.CONV_MASK_AUX, f24=l2.f24)
             self._wgrad1(P, xs, dz1, l1)
             first_trainable = (stage == 3 and j == 0)
             if proj:

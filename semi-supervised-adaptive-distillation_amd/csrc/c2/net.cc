@@ -34,8 +34,23 @@ string LoweringReport::ToString() const {
                     relu_grad_fused, "; ConvGroup ", conv_groups, " (", conv_group_members,
                     " Conv); ConvGradientGroup ", conv_grad_groups, " (", conv_grad_group_members,
                     " ConvGradient); Sum absorbed ", sums_absorbed, "; loss groups ", loss_groups, " (",
-                    loss_group_members, " ops); F(2x4) Conv ", frozen_f24,
+                    loss_group_members, " ops); F(2x4) Conv ", frozen_f24, " evaluated / ", train_f24, " trained",
                     fell_back ? "; FELL BACK to the list as written" : "");
+}
+
+LoweringOptions LoweringOptionsFor(const NetDef& def) {
+  LoweringOptions opt;
+  opt.fuse_relu = EnvFlag("C2HIP_NET_FUSE_RELU", true);
+  opt.group_convs = EnvFlag("C2HIP_NET_GROUP_CONVS", true);
+  opt.group_losses = EnvFlag("C2HIP_NET_GROUP_LOSSES", true);
+  const Argument* f24 = FindArg(def, "hip_frozen_f24");
+  opt.frozen_f24 = EnvFlag("C2HIP_NET_FROZEN_F24", !(f24 && f24->has_i && f24->i == 0));
+  const Argument* t24 = FindArg(def, "hip_train_f24");
+  opt.train_f24 = EnvFlag("C2HIP_NET_TRAIN_F24", !(t24 && t24->has_i && t24->i == 0));
+  for (const string& s : def.external_output) opt.keep.insert(s);
+  if (const Argument* k = FindArg(def, "hip_keep_blobs"))
+    for (const string& s : k->strings) opt.keep.insert(s);
+  return opt;
 }
 
 NetBase::NetBase(const NetDef& def, Workspace* ws) : name_(def.name) {
@@ -53,16 +68,8 @@ NetBase::NetBase(const NetDef& def, Workspace* ws) : name_(def.name) {
         op.has_device_option = true;
       }
   if (lowering) {
-    LoweringOptions opt;
-    opt.fuse_relu = EnvFlag("C2HIP_NET_FUSE_RELU", true);
-    opt.group_convs = EnvFlag("C2HIP_NET_GROUP_CONVS", true);
-    opt.group_losses = EnvFlag("C2HIP_NET_GROUP_LOSSES", true);
-    const Argument* f24 = FindArg(def, "hip_frozen_f24");
-    opt.frozen_f24 = EnvFlag("C2HIP_NET_FROZEN_F24", !(f24 && f24->has_i && f24->i == 0));
+    LoweringOptions opt = LoweringOptionsFor(def);
     opt.blob_dtype = [ws](const string& n) { return BlobDtype(ws, n); };
-    for (const string& s : def.external_output) opt.keep.insert(s);
-    if (const Argument* k = FindArg(def, "hip_keep_blobs"))
-      for (const string& s : k->strings) opt.keep.insert(s);
     lowered_ = LowerNet(scoped, opt, &report_);
   } else {
     lowered_ = scoped.op;

@@ -35,6 +35,7 @@ struct LoweringOptions {
   bool group_convs = true;      // ConvGroup / ConvGradientGroup (+ Sum absorption)
   bool group_losses = true;     // per-level loss operators of one kind -> one multi-level launch
   bool frozen_f24 = true;       // nets without gradient operators: Conv on the F(2x4, 3x3) engine (hip_algo = winograd24)
+  bool train_f24 = true;        // trained nets: Conv and ConvGradient's data gradient on it too
   // TensorProto::DataType id of a blob that exists already (parameters do when a net is created:
   // the reference runs param_init_net first), 0 if unknown.  The fused 3x3 paths are fp32-only.
   std::function<int(const string&)> blob_dtype;
@@ -50,9 +51,15 @@ struct LoweringReport {
   int conv_grad_groups = 0, conv_grad_group_members = 0;
   int sums_absorbed = 0, loss_groups = 0, loss_group_members = 0;
   int frozen_f24 = 0;           // Conv operators of an evaluated-only net sent to the F(2x4, 3x3) engine
+  int train_f24 = 0;            // Conv / ConvGradient operators of a trained net sent to it
   bool fell_back = false;       // the lowered list failed its own verification: list kept as written
   string ToString() const;
 };
+
+// The options a net asks for: NetDef args hip_frozen_f24 / hip_train_f24 / hip_keep_blobs + external_output, each
+// switch overridable by its environment variable (C2HIP_NET_FUSE_RELU, _GROUP_CONVS, _GROUP_LOSSES, _FROZEN_F24,
+// _TRAIN_F24); blob_dtype is left to the caller.
+C2HIP_API LoweringOptions LoweringOptionsFor(const NetDef& def);
 
 // Pure function of the definition (+ the dtype probe): no device, no workspace.
 C2HIP_API vector<OperatorDef> LowerNet(const NetDef& def, const LoweringOptions& opt,

@@ -256,10 +256,9 @@ size_t c2hip_lower_net(const void* netdef_bytes, size_t n, void* buf, size_t buf
                        char* report_buf, size_t report_buflen) {
   size_t need = 0;
   guarded([&] {
-    LoweringOptions opt;           // no dtype probe: filters are taken to be fp32
     LoweringReport rep;
     const NetDef def = parse_net(netdef_bytes, n);
-    for (const string& s : def.external_output) opt.keep.insert(s);
+    LoweringOptions opt = LoweringOptionsFor(def);           // no dtype probe: filters are taken to be fp32
     const vector<OperatorDef> ops = LowerNet(def, opt, &rep);
     need = pack_defs(ops, buf, buflen, n_ops);
     if (report_buf && report_buflen) {

@@ -83,8 +83,12 @@ struct PackTable {
 };
 __global__ void wino24_pack_multi_kernel(const PackTable t) {
   const ssad_pack_entry& e = t.e[blockIdx.y];
-  if (!e.packed_fwd) return;
-  const int M = e.Cout, K = e.Cin;
+  // z = 0: forward filter (M = Cout outputs, K = Cin inputs); z = 1: the data gradient's filter, flipped and
+  // transposed (M = Cin, K = Cout: dX = conv(dY, W'), W'[ci][co][k] = W[co][ci][8 - k])
+  const bool dg = blockIdx.z == 1;
+  float* dst = dg ? e.packed_dgrad : e.packed_fwd;
+  if (!dst) return;
+  const int M = dg ? e.Cin : e.Cout, K = dg ? e.Cout : e.Cin;
   const int mtiles = cdiv(M, 16), chunks = cdiv(K, KC);
   const long long total = (long long)mtiles * chunks * STEPS * 256;
   for (long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x; tid < total + 1024;
@@ -99,18 +103,20 @@ __global__ void wino24_pack_multi_kernel(const PackTable t) {
       const int out = mt * 16 + (lane & 15), in = chunk * KC + ks * 4 + (lane >> 4);
       if (out < M && in < K) {
         float g[9];
+        const float* w = dg ? e.w + ((long long)in * e.Cin + out) * 9 : e.w + ((long long)out * e.Cin + in) * 9;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) g[k] = e.w[((long long)out * K + in) * 9 + k];
+        for (int k = 0; k < 9; ++k) g[k] = w[dg ? 8 - k : k];
         v = wino24_u(g, xr, xq);
       }
     }
-    e.packed_fwd[tid] = v;
+    dst[tid] = v;
   }
 }
 
 struct WLevel {
   const float* x;
   float* y;
+  const float* aux;                      // SSAD_CONV_MASK_AUX: the forward output whose sign masks y (fused ReluGradient)
   const float* packed;
   const float* bias;
   int N, H, W;
@@ -435,12 +441,14 @@ __global__ __launch_bounds__(kBlock, 1) void wino24_conv_kernel(const WArgs args
       const int H = L.H, W = L.W, HW = H * W;
       const int flags = args.flags;
       const bool relu = flags & SSAD_CONV_RELU, sigm = flags & SSAD_CONV_SIGMOID;
+      const bool masked = flags & SSAD_CONV_MASK_AUX;
       // this lane's tile: 2 rows x 4 columns at (py, px) of image sn
       const int sub = PAIRS ? (jn >> 3) : 0;
       const int sy0 = sub ? T.y0[1] : T.y0[0], sx0 = sub ? T.x0[1] : T.x0[0], sn = sub ? T.n[1] : T.n[0];
       const int py = PAIRS ? sy0 + 2 * ((jn & 7) >> 1) : T.y0[0] + 2 * (jn >> 2);
       const int px = PAIRS ? sx0 + 4 * (jn & 1) : T.x0[0] + 4 * (jn & 3);
       const __amdgpu_buffer_rsrc_t yrsrc = uniform_rsrc(L.y, (unsigned)((long long)L.N * M * HW * 4));
+      const __amdgpu_buffer_rsrc_t krsrc = uniform_rsrc(masked ? L.aux : L.y, (unsigned)((long long)L.N * M * HW * 4));
       const bool whole = px + 3 < W && !sigm && mt * 16 + 16 <= M;      // four pixels inside: one 16-byte store per row
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -469,6 +477,12 @@ __global__ __launch_bounds__(kBlock, 1) void wino24_conv_kernel(const WArgs args
           const int yy = py + a;
           if (whole) {
             const unsigned vo = (yy < H) ? (unsigned)((((long long)sn * M + m) * HW + yy * W + px) * 4) : kOOBOff;
+            if (masked) {
+              const f32x4 kv = __builtin_bit_cast(
+                  f32x4, __builtin_amdgcn_raw_buffer_load_b128(krsrc, vo, 0, 0));
+#pragma unroll
+              for (int k = 0; k < 4; ++k) o[k] = kv[k] > 0.0f ? o[k] : 0.0f;
+            }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o),
                                                    yrsrc, vo, 0, 0);
             // keep the data registers untouched while the store reads them (conv3x3_winograd.hip, split tail)
@@ -482,6 +496,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino24_conv_kernel(const WArgs args
               if (px + k < W) {
                 float v = o[k];
                 if (sigm) v = 1.0f / (1.0f + expf(-v));
+                if (masked) v = L.aux[((long long)sn * M + m) * HW + yy * W + px + k] > 0.0f ? v : 0.0f;
                 yout[px + k] = v;
               }
           }
@@ -518,17 +533,19 @@ int ssad_conv_wino24_pack_filters(const ssad_pack_entry* entries_host, int n_ent
     const int cnt = n_entries - base < SSAD_MAX_PACK_ENTRIES ? n_entries - base : SSAD_MAX_PACK_ENTRIES;
     PackTable t;
     size_t nmax = 0;
+    bool any_dgrad = false;
     for (int i = 0; i < cnt; ++i) {
       const ssad_pack_entry& e = entries_host[base + i];
-      if (e.Cout <= 0 || e.Cin <= 0 || !e.w || !e.packed_fwd || e.packed_dgrad) return SSAD_E_BADARG;   // forward only
+      if (e.Cout <= 0 || e.Cin <= 0 || !e.w || (!e.packed_fwd && !e.packed_dgrad)) return SSAD_E_BADARG;
       t.e[i] = e;
-      const size_t nf = ssad_conv_wino24_filter_floats(e.Cout, e.Cin);
+      const size_t nf = ssad_conv_wino24_filter_floats(e.Cout, e.Cin), nd = ssad_conv_wino24_filter_floats(e.Cin, e.Cout);
       nmax = nf > nmax ? nf : nmax;
+      if (e.packed_dgrad) { nmax = nd > nmax ? nd : nmax; any_dgrad = true; }
     }
     for (int i = cnt; i < SSAD_MAX_PACK_ENTRIES; ++i) t.e[i] = ssad_pack_entry{};
     size_t bx = (nmax + 255) / 256;
     if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(wino24_pack_multi_kernel, dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0,
+    hipLaunchKernelGGL(wino24_pack_multi_kernel, dim3((unsigned)bx, (unsigned)cnt, any_dgrad ? 2u : 1u), dim3(256), 0,
                        (hipStream_t)stream, t);
   }
   return (int)hipGetLastError();
@@ -537,9 +554,10 @@ int ssad_conv_wino24_pack_filters(const ssad_pack_entry* entries_host, int n_ent
 int ssad_conv3x3_forward_wino24(const ssad_conv_level* lv, int n_levels, const float* packed, const float* bias,
                                 int Cout, int Cin, int flags, ssad_stream_t stream) {
   if (n_levels < 1 || n_levels > SSAD_MAX_CONV_PROBLEMS || Cout <= 0 || Cin <= 0) return SSAD_E_BADARG;
-  if (flags & SSAD_CONV_MASK_AUX) return SSAD_E_BADARG;           // forward of an evaluated network only
+  if ((flags & SSAD_CONV_MASK_AUX) && (flags & SSAD_CONV_SIGMOID)) return SSAD_E_BADARG;
   for (int l = 0; l < n_levels; ++l) {
     if (!(lv[l].packed ? lv[l].packed : packed)) return SSAD_E_BADARG;
+    if ((flags & SSAD_CONV_MASK_AUX) && !lv[l].aux) return SSAD_E_BADARG;
     if (lv[l].N < 0 || lv[l].H < 0 || lv[l].W < 0) return SSAD_E_BADARG;
     if ((long long)lv[l].N * lv[l].H * lv[l].W * (Cin > Cout ? Cin : Cout) >= (1LL << 29)) return SSAD_E_BADARG;
   }
@@ -554,7 +572,7 @@ int ssad_conv3x3_forward_wino24(const ssad_conv_level* lv, int n_levels, const f
       if ((long long)lv[l].N * lv[l].H * lv[l].W == 0) continue;
       if (level_wants_pairs(lv[l].H, lv[l].W) != use_pairs) continue;
       WLevel& L = a.lv[nl++];
-      L.x = lv[l].x; L.y = lv[l].y;
+      L.x = lv[l].x; L.y = lv[l].y; L.aux = lv[l].aux;
       L.packed = lv[l].packed ? lv[l].packed : packed;
       L.bias = lv[l].packed ? lv[l].bias : bias;
       L.N = lv[l].N; L.H = lv[l].H; L.W = lv[l].W;

@@ -93,8 +93,8 @@ class ConvGroupOp final : public Operator<HIPContext> {
     }
     hipStream_t s = context_.hip_stream();
     const long long before = cache_.packs_issued();
-    // hip_algo = "winograd24" (set by the net lowering for nets without gradient operators): the F(2x4, 3x3)
-    // engine of evaluated-only networks for the problems it serves (>= 128 outputs), "auto" for the rest
+    // hip_algo = "winograd24" (set by the net lowering): the F(2x4, 3x3) engine for the problems it serves
+    // (>= 128 outputs), "auto" for the rest
     auto kind_of = [&](const Problem& p) {
       if (algo_ == "winograd24") return p.M >= 128 ? FilterPackCache::WINO24_FWD : FilterPackCache::WINO_FWD;
       return UseWinograd(algo_, p.M) ? FilterPackCache::WINO_FWD : FilterPackCache::DIRECT_FWD;
@@ -217,15 +217,17 @@ class ConvGradientGroupOp final : public Operator<HIPContext> {
 
     // data gradients: the forward kernel on the flipped / transposed pack, dX has C channels
     const long long before = cache_.packs_issued();
-    for (const Problem& p : probs)
-      cache_.Want(*p.w, UseWinograd(algo_, p.C) ? FilterPackCache::WINO_DGRAD : FilterPackCache::DIRECT_DGRAD);
+    auto dkind_of = [&](const Problem& p) {
+      if (algo_ == "winograd24" && p.C >= 128) return FilterPackCache::WINO24_DGRAD;
+      return UseWinograd(algo_, p.C) ? FilterPackCache::WINO_DGRAD : FilterPackCache::DIRECT_DGRAD;
+    };
+    for (const Problem& p : probs) cache_.Want(*p.w, dkind_of(p));
     cache_.Flush(s);
     g_filter_packs_issued += cache_.packs_issued() - before;
     const int flags = relu_grad_on_input_ ? SSAD_CONV_MASK_AUX : 0;
     for (const vector<int>& cls : Classes(probs)) {
       const Problem& p0 = probs[cls[0]];
-      const bool wino = UseWinograd(algo_, p0.C);
-      const auto kind = wino ? FilterPackCache::WINO_DGRAD : FilterPackCache::DIRECT_DGRAD;
+      const auto kind = dkind_of(p0);
       for (size_t at = 0; at < cls.size(); at += SSAD_MAX_CONV_PROBLEMS) {
         const int n = (int)std::min<size_t>(SSAD_MAX_CONV_PROBLEMS, cls.size() - at);
         ssad_conv_level lv[SSAD_MAX_CONV_PROBLEMS];
@@ -235,8 +237,11 @@ class ConvGradientGroupOp final : public Operator<HIPContext> {
                                   relu_grad_on_input_ ? p.x->data<float>() : nullptr, p.N, p.H, p.W,
                                   cache_.Packed(*p.w, kind), nullptr};
         }
-        const int rc = wino ? ssad_conv3x3_forward_wino(lv, n, lv[0].packed, nullptr, p0.C, p0.M, flags, s)
-                            : ssad_conv3x3_forward(lv, n, lv[0].packed, nullptr, p0.C, p0.M, flags, s);
+        const int rc = kind == FilterPackCache::WINO24_DGRAD
+                           ? ssad_conv3x3_forward_wino24(lv, n, lv[0].packed, nullptr, p0.C, p0.M, flags, s)
+                       : kind == FilterPackCache::WINO_DGRAD
+                           ? ssad_conv3x3_forward_wino(lv, n, lv[0].packed, nullptr, p0.C, p0.M, flags, s)
+                           : ssad_conv3x3_forward(lv, n, lv[0].packed, nullptr, p0.C, p0.M, flags, s);
         CAFFE_ENFORCE_EQ(rc, 0, "ConvGradientGroup (data) launch failed");
         ++g_conv_launch_calls;
       }

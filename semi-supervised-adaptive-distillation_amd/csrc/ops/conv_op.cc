@@ -32,8 +32,8 @@ bool IsDefaultEngineGeometry(const ConvGeometry& g) {
 bool UseWinograd(const string& algo, int out_channels) {
   if (algo == "direct") return false;
   if (algo == "winograd") return true;
-  // ("winograd24" names the forward engine of evaluated-only nets; wherever it does not apply -- narrow layers,
-  // a gradient operator that inherited the argument -- the choice is the automatic one)
+  // ("winograd24" names the F(2x4, 3x3) engine the net lowering assigns; wherever it does not apply -- narrow
+  // layers, the filter gradient -- the choice is the automatic one)
   return out_channels >= 32;
 }
 
@@ -90,7 +90,7 @@ bool ConvOp<float, HIPContext>::RunOnDevice() {
   const int flags = fuse_relu_ ? SSAD_CONV_RELU : 0;
   int rc;
   // the packed filter is rebuilt only when the filter blob was written since (ops/filter_pack_cache.h)
-  const bool f24 = algo_ == "winograd24" && M >= 128;      // evaluated-only nets (net_lowering.cc)
+  const bool f24 = algo_ == "winograd24" && M >= 128;      // assigned by the net lowering (net_lowering.cc F24)
   const bool wino = UseWinograd(algo_ == "winograd24" ? string("auto") : algo_, M);
   const auto kind = f24 ? FilterPackCache::WINO24_FWD : wino ? FilterPackCache::WINO_FWD : FilterPackCache::DIRECT_FWD;
   const long long before = pack_cache_.packs_issued();
@@ -428,15 +428,17 @@ bool ConvGradientOp<float, HIPContext>::RunOnDevice() {
     ssad_conv_level dl{dY.data<float>(), dX->mutable_data<float>(),
                        relu_grad_on_input_ ? X.data<float>() : nullptr, N, H, W, nullptr, nullptr};
     const int flags = relu_grad_on_input_ ? SSAD_CONV_MASK_AUX : 0;
+    const bool f24 = algo_ == "winograd24" && C >= 128;      // trained nets under hip_train_f24 (net_lowering.cc)
     const bool wino = UseWinograd(algo_, C);      // the data gradient has C output channels
-    const auto kind = wino ? FilterPackCache::WINO_DGRAD : FilterPackCache::DIRECT_DGRAD;
+    const auto kind = f24 ? FilterPackCache::WINO24_DGRAD : wino ? FilterPackCache::WINO_DGRAD : FilterPackCache::DIRECT_DGRAD;
     const long long before = pack_cache_.packs_issued();
     pack_cache_.Want(filter, kind);
     pack_cache_.Flush(s);
     g_filter_packs_issued += pack_cache_.packs_issued() - before;
     const float* packed = pack_cache_.Packed(filter, kind);
-    rc = wino ? ssad_conv3x3_forward_wino(&dl, 1, packed, nullptr, C, M, flags, s)
-              : ssad_conv3x3_forward(&dl, 1, packed, nullptr, C, M, flags, s);
+    rc = f24 ? ssad_conv3x3_forward_wino24(&dl, 1, packed, nullptr, C, M, flags, s)
+         : wino ? ssad_conv3x3_forward_wino(&dl, 1, packed, nullptr, C, M, flags, s)
+                : ssad_conv3x3_forward(&dl, 1, packed, nullptr, C, M, flags, s);
     CAFFE_ENFORCE_EQ(rc, 0, "ConvGradient (data) launch failed");
     ++g_conv_launch_calls;
   }

@@ -18,7 +18,7 @@ namespace caffe2 {
 
 class FilterPackCache {
  public:
-  enum Kind { WINO_FWD = 0, WINO_DGRAD = 1, DIRECT_FWD = 2, DIRECT_DGRAD = 3, WINO24_FWD = 4 };
+  enum Kind { WINO_FWD = 0, WINO_DGRAD = 1, DIRECT_FWD = 2, DIRECT_DGRAD = 3, WINO24_FWD = 4, WINO24_DGRAD = 5 };
 
   // Queue `filter` ([M][C][3][3], fp32) for layout `kind`; Flush() issues the packs that are stale
   // (one multi-filter launch for the Winograd layouts) on `stream`; Packed() is valid after it.
@@ -32,10 +32,10 @@ class FilterPackCache {
     e.C = C;
     e.version = filter.version();
     e.uid = filter.uid();
-    const bool dgrad = kind == WINO_DGRAD || kind == DIRECT_DGRAD;
+    const bool dgrad = kind == WINO_DGRAD || kind == DIRECT_DGRAD || kind == WINO24_DGRAD;
     const bool wino = kind == WINO_FWD || kind == WINO_DGRAD;
     const int po = dgrad ? C : M, pi = dgrad ? M : C;       // the pack's (outputs, inputs)
-    e.packed.Resize((TIndex)(kind == WINO24_FWD ? ssad_conv_wino24_filter_floats(po, pi)
+    e.packed.Resize((TIndex)((kind == WINO24_FWD || kind == WINO24_DGRAD) ? ssad_conv_wino24_filter_floats(po, pi)
                              : wino ? ssad_conv_wino_filter_floats(po, pi) : ssad_conv_packed_filter_floats(po, pi)));
     e.packed.mutable_data<float>();
     e.queued = true;
@@ -52,6 +52,7 @@ class FilterPackCache {
         case WINO_FWD: wino.push_back({e.src, e.M, e.C, p, nullptr}); break;
         case WINO_DGRAD: wino.push_back({e.src, e.M, e.C, nullptr, p}); break;
         case WINO24_FWD: wino24.push_back({e.src, e.M, e.C, p, nullptr}); break;
+        case WINO24_DGRAD: wino24.push_back({e.src, e.M, e.C, nullptr, p}); break;
         case DIRECT_FWD:
           CAFFE_ENFORCE_EQ(ssad_conv_pack_filter(e.src, e.M, e.C, p, nullptr, stream), 0);
           break;

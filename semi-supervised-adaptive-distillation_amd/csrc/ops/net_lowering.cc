@@ -174,21 +174,27 @@ struct Lowering {
     }
   }
 
-  // ---- F24: a net without gradient operators is only evaluated (the teacher net, model_builder.py:373-411 in test
-  //      mode; an inference net): its 3x3 convolutions may take the F(2x4, 3x3) engine (conv3x3_winograd24.hip: 3
-  //      multiplies per output, fp32 error ~2e-6 of the output scale).  hip_algo given by the graph wins.
-  void MarkFrozen() {
+  // ---- F24: 3x3 convolutions on the F(2x4, 3x3) engine (conv3x3_winograd24.hip: 3 multiplies per output where
+  //      F(2x2) does 4; fp32 error 1.5-2.2e-6 of the output scale against 0.8-1.9e-6).  A net without gradient
+  //      operators is only evaluated (the teacher net, model_builder.py:373-411 in test mode; an inference net):
+  //      option frozen_f24.  A trained net: option train_f24 -- Conv (>= 128 outputs) and the data gradient of
+  //      ConvGradient (>= 128 input channels); the filter gradient keeps its own engine.  The operators apply the
+  //      channel limits; hip_algo given by the graph wins.
+  void MarkF24() {
+    bool trained = false;
     for (const Node& n : nodes) {
       const string& t = n.def.type;
       if (n.def.is_gradient_op || (t.size() > 8 && t.compare(t.size() - 8, 8, "Gradient") == 0) ||
           t == "MomentumSGDUpdate" || t == "WeightedSum")
-        return;
+        trained = true;
     }
-    for (Node& n : nodes)
-      if (!n.removed && n.def.type == "Conv" && IsFusedPathConv(n) && !FindArg(n.def, "hip_algo")) {
-        n.def.arg.push_back(MakeArgument("hip_algo", string("winograd24")));
-        ++rep.frozen_f24;
-      }
+    if (trained ? !opt.train_f24 : !opt.frozen_f24) return;
+    for (Node& n : nodes) {
+      if (n.removed || FindArg(n.def, "hip_algo") || !IsFusedPathConv(n)) continue;
+      if (n.def.type == "ConvGradient" && !trained) continue;
+      n.def.arg.push_back(MakeArgument("hip_algo", string("winograd24")));
+      ++(trained ? rep.train_f24 : rep.frozen_f24);
+    }
   }
 
   // ---- F3 -----------------------------------------------------------------------------------
@@ -481,7 +487,7 @@ vector<OperatorDef> LowerNet(const NetDef& def, const LoweringOptions& opt, Lowe
   Lowering L(opt, rep);
   L.Build(def.op);
   if (opt.fuse_relu) L.FuseRelu();
-  if (opt.frozen_f24) L.MarkFrozen();
+  if (opt.frozen_f24 || opt.train_f24) L.MarkF24();
   if (opt.group_convs) L.AbsorbSums();
   L.MakeUnits();
   vector<vector<int>> order;

@@ -107,6 +107,11 @@ class DistillHeads(object):
         #   1 (default) its cls_pred layer;  2: also its tower layers, which then leave the launch they shared with the
         #   student's (SSAD_TEACHER_F24; 0 = everything on the F(2x2) engine as in rounds 1-4)
         self.teacher_f24 = int(os.environ.get("SSAD_TEACHER_F24", "1")) if (self.wino and not self.F16) else 0
+        # the TRAINED subnets on the F(2x4) engine, a bit mask: 1 = data gradients, 2 = cls_pred forward,
+        # 4 = tower forward (with the teacher's towers, one launch)
+        self.student_f24 = int(os.environ.get("SSAD_STUDENT_F24", "15")) & 7 if (self.wino and not self.F16) else 0
+        if self.student_f24 & 4 and self.teacher_f24:
+            self.teacher_f24 = 2
         self.momentum, self.weight_decay = momentum, weight_decay
         self.pg, self.world_size = process_group, world_size
         self.dp = BucketedAllReduce(process_group, world_size)
@@ -230,9 +235,21 @@ class DistillHeads(object):
             return False
         return "_pred_" in name or self.teacher_f24 >= 2
 
-    def _alloc_packed(self, params, want_dgrad, f24=False):
+    def _f24_use(self, who, name, cout, cin, which):
+        """Engine of one convolution: who = "teacher" | "student", which = "fwd" | "dgrad" (M = cout / cin)."""
+        if who == "teacher":
+            return which == "fwd" and self._f24_layer(name, cout)
+        m = self.student_f24
+        if which == "dgrad":
+            return bool(m & 1) and cin >= 128
+        if cout < 128:
+            return False
+        return bool(m & 2) if "_pred_" in name else bool(m & 4)
+
+    def _alloc_packed(self, params, want_dgrad, f24=None):
         """Packed-filter buffers per layer in the layout of the engine that consumes them:
-        -> ({name: (fwd, dgrad)}, wino pack entries, direct pack ops[, F(2x4) pack entries])."""
+        -> ({name: (fwd, dgrad)}, wino pack entries, direct pack ops[, F(2x4) pack entries]); f24 = "teacher" |
+        "student": whose layers these are (None: no F(2x4) engine, three results)."""
         L = K.lib()
         packed, entries, direct, entries24 = {}, [], [], []
         for tower in ("cls", "bbox"):
@@ -241,19 +258,21 @@ class DistillHeads(object):
                 cout, cin = w.shape[0], w.shape[1]
                 pf = pd = None
                 fw, dw = self._use_wino(cout), self._use_wino(cin)
-                if f24 and fw and self._f24_layer(name, cout):
-                    pf = torch.empty(L.ssad_conv_wino24_filter_floats(cout, cin), dtype=torch.float32,
-                                     device=self.device)
-                    packed[name] = (pf, None)
-                    entries24.append((w, cout, cin, pf, None))
-                    continue
-                nf = (L.ssad_conv_wino_filter_floats if fw else L.ssad_conv_packed_filter_floats)(cout, cin)
+                f_24 = bool(f24) and fw and self._f24_use(f24, name, cout, cin, "fwd")
+                d_24 = bool(f24) and want_dgrad and dw and self._f24_use(f24, name, cout, cin, "dgrad")
+                nf = (L.ssad_conv_wino24_filter_floats if f_24 else L.ssad_conv_wino_filter_floats if fw
+                      else L.ssad_conv_packed_filter_floats)(cout, cin)
                 pf = torch.empty(nf, dtype=torch.float32, device=self.device)
                 if want_dgrad:
-                    nd = (L.ssad_conv_wino_filter_floats if dw else L.ssad_conv_packed_filter_floats)(cin, cout)
+                    nd = (L.ssad_conv_wino24_filter_floats if d_24 else L.ssad_conv_wino_filter_floats if dw
+                          else L.ssad_conv_packed_filter_floats)(cin, cout)
                     pd = torch.empty(nd, dtype=torch.float32, device=self.device)
                 packed[name] = (pf, pd)
-                wf, wd = (pf if fw else None), (pd if (dw and want_dgrad) else None)
+                xf, xd = (pf if f_24 else None), (pd if d_24 else None)
+                if xf is not None or xd is not None:
+                    entries24.append((w, cout, cin, xf, xd))
+                wf = pf if (fw and not f_24) else None
+                wd = pd if (dw and want_dgrad and not d_24) else None
                 if wf is not None or wd is not None:
                     entries.append((w, cout, cin, wf, wd))
                 df, dd = (pf if not fw else None), (pd if (not dw and want_dgrad) else None)
@@ -265,9 +284,11 @@ class DistillHeads(object):
         if entries24:
             tab = (K.PackEntry * len(entries24))()
             nbytes = 0
-            for k, (w, cout, cin, pf, _) in enumerate(entries24):
-                tab[k] = K.PackEntry(w.data_ptr(), cout, cin, pf.data_ptr(), 0)
-                nbytes += 4 * (w.numel() + pf.numel())
+            for k, (w, cout, cin, pf, pd) in enumerate(entries24):
+                tab[k] = K.PackEntry(w.data_ptr(), cout, cin, pf.data_ptr() if pf is not None else 0,
+                                     pd.data_ptr() if pd is not None else 0)
+                nbytes += 4 * (w.numel() + (pf.numel() if pf is not None else 0)
+                               + (pd.numel() if pd is not None else 0))
             P.add(PR.WINO_PACK_FILTERS, 1, i=(len(entries24), 2), p=(tab,), work=nbytes,
                   keep=[t for e in entries24 for t in e if isinstance(t, torch.Tensor)])
         if entries:
@@ -293,13 +314,18 @@ class DistillHeads(object):
         self._wgrad_ops, self._wgrad_ws_need = [], 0
         self._in_slots = []          # (table, index, which): entries that read the bound inputs
         # filters (the teacher's are frozen: packed by a program of their own, run when they change)
-        self.packed, s_entries, s_direct = self._alloc_packed(self.params, True)
+        if self.F16:
+            self.packed, s_entries, s_direct = self._alloc_packed(self.params, True)
+            s_extra = ()
+        else:
+            self.packed, s_entries, s_direct, s_entries24 = self._alloc_packed(self.params, True, f24="student")
+            s_extra = (s_entries24,)
         if self.distill:
             if self.F16:            # (the fp16 subclass has its own pack layouts and no F(2x4) engine)
                 self.t_packed_pairs, t_entries, t_direct = self._alloc_packed(self.teacher, False)
                 t_extra = ()
             else:
-                self.t_packed_pairs, t_entries, t_direct, t_entries24 = self._alloc_packed(self.teacher, False, f24=True)
+                self.t_packed_pairs, t_entries, t_direct, t_entries24 = self._alloc_packed(self.teacher, False, f24="teacher")
                 t_extra = (t_entries24,)
             self.t_packed = {k: v[0] for k, v in self.t_packed_pairs.items()}
             T = self.prog_teacher_pack = PR.Program()
@@ -307,7 +333,7 @@ class DistillHeads(object):
             T.build()
         P = self.prog = PR.Program()
         P.mark("pack")
-        self._emit_pack(P, s_entries, s_direct)
+        self._emit_pack(P, s_entries, s_direct, *s_extra)
         P.mark("forward")
         self._emit_forward(P)
         P.mark("losses")
@@ -355,6 +381,16 @@ class DistillHeads(object):
                 probs.append((sx[t], out, None, self.packed[name][0], self.params[name + "_b"]))
                 who.append("student")
                 sx[t] = out
+            if self.student_f24 & 4 and (not self.distill or self._f24_layer(self._layers("cls")[i], D)):
+                # every tower of this depth on the F(2x4) engine, one launch (class 23)
+                _, arr = self._emit_conv(P, probs, D, D, K.CONV_RELU, 23, f24=True)
+                if i == 0:
+                    k = 0
+                    for (xs, _, _, _, _), w in zip(probs, who):
+                        for l in range(len(xs)):
+                            self._in_slots.append((arr, k, w, l))
+                            k += 1
+                continue
             if self.distill and self._f24_layer(self._layers("cls")[i], D):
                 # the teacher's towers on the F(2x4) engine: a launch of their own (class 21), the student's on F(2x2)
                 tp = [p for p, w in zip(probs, who) if w == "teacher"]
@@ -383,8 +419,9 @@ class DistillHeads(object):
             f24 = self._f24_layer(cp, AC)
             self._emit_conv(P, [(tx["cls"], self.t_prob, None, self.t_packed_for(cp), self.teacher[cp + "_b"])],
                             AC, D, K.CONV_SIGMOID, 20 if f24 else 3, f24=f24)
+        f24 = self._f24_use("student", cp, AC, D, "fwd")
         self._emit_conv(P, [(sx["cls"], self.cls_logits, None, self.packed[cp][0], self.params[cp + "_b"])],
-                        AC, D, 0, 3)
+                        AC, D, 0, 22 if f24 else 3, f24=f24)
         probs = [(sx["bbox"], self.bbox_pred, None, self.packed[bp][0], self.params[bp + "_b"])]
         if self.teacher_bbox_tower:
             probs.append((tx["bbox"], self.t_bbox, None, self.t_packed_for(bp), self.teacher[bp + "_b"]))
@@ -489,7 +526,9 @@ class DistillHeads(object):
             Cout = self.params[name + "_b"].numel()
             self._emit_wgrad(P, x_in, dy[t], name, Cout, klass_w)
             out = self.dbuf[t][nl]
-            self._emit_conv(P, [(dy[t], out, x_in, self.packed[name][1], None)], D, Cout, K.CONV_MASK_AUX, 16)
+            f24 = self._f24_use("student", name, Cout, D, "dgrad")
+            self._emit_conv(P, [(dy[t], out, x_in, self.packed[name][1], None)], D, Cout, K.CONV_MASK_AUX,
+                            24 if f24 else 16, f24=f24)
             dy[t] = out
         for li in range(nl - 1, -1, -1):
             probs = []
@@ -503,7 +542,8 @@ class DistillHeads(object):
                 out = self.dbuf[t][li] if li > 0 else self.d_fpn[t]
                 probs.append((dy[t], out, x_in if li > 0 else None, self.packed[name][1], None))
                 dy[t] = out
-            self._emit_conv(P, probs, D, D, K.CONV_MASK_AUX if li > 0 else 0, 16)
+            f24 = self._f24_use("student", name, D, D, "dgrad")
+            self._emit_conv(P, probs, D, D, K.CONV_MASK_AUX if li > 0 else 0, 24 if f24 else 16, f24=f24)
             if li == nl // 2:
                 P.mark("backward_late_done")
         if "backward_late_done" not in P.marks:

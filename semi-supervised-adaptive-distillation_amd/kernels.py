@@ -638,29 +638,33 @@ def conv_wino_pack_filter(w, want_fwd=True, want_dgrad=True):
     return pf, pd
 
 
-def conv_wino24_pack_filter(w):
-    """F(2x4, 3x3) filter pack U = G2 g G4^T (forward only: the engine of evaluated, frozen networks)."""
+def conv_wino24_pack_filter(w, want_dgrad=False):
+    """F(2x4, 3x3) filter pack U = G2 g G4^T; want_dgrad: -> (forward, data-gradient) packs (the latter of the
+    flipped, transposed filter, Cin x Cout)."""
     L = lib()
     _f32c(w, "filter")
     Cout, Cin, kh, kw = w.shape
     if (kh, kw) != (3, 3):
         raise KernelError("only 3x3 filters")
     pf = torch.empty(L.ssad_conv_wino24_filter_floats(Cout, Cin), dtype=torch.float32, device="cuda")
-    tab = (PackEntry * 1)(PackEntry(w.data_ptr(), Cout, Cin, pf.data_ptr(), 0))
+    pd = torch.empty(L.ssad_conv_wino24_filter_floats(Cin, Cout), dtype=torch.float32,
+                     device="cuda") if want_dgrad else None
+    tab = (PackEntry * 1)(PackEntry(w.data_ptr(), Cout, Cin, pf.data_ptr(), pd.data_ptr() if want_dgrad else 0))
     _check(L.ssad_conv_wino24_pack_filters(tab, 1, _stream()), "conv_wino24_pack_filters")
-    return pf
+    return (pf, pd) if want_dgrad else pf
 
 
-def conv3x3_forward_wino24(xs, packed, bias, Cout, *, relu=False, sigmoid=False, out=None):
-    """conv3x3_forward on the F(2x4, 3x3) engine (xs: levels sharing the filter; forward only)."""
+def conv3x3_forward_wino24(xs, packed, bias, Cout, *, relu=False, sigmoid=False, out=None, mask_by=None):
+    """conv3x3_forward on the F(2x4, 3x3) engine (xs: levels sharing the filter).  mask_by: the data-gradient form --
+    y = mask > 0 ? y : 0 (fused ReluGradient), packed = the data-gradient pack, Cout = the layer's input channels."""
     L = lib()
     for x in xs:
         _f32c(x, "conv input")
     Cin = xs[0].shape[1]
     ys = out if out is not None else [
         torch.empty((x.shape[0], Cout, x.shape[2], x.shape[3]), dtype=torch.float32, device="cuda") for x in xs]
-    flags = (CONV_RELU if relu else 0) | (CONV_SIGMOID if sigmoid else 0)
-    arr = _conv_levels(xs, ys, None)
+    flags = (CONV_RELU if relu else 0) | (CONV_SIGMOID if sigmoid else 0) | (CONV_MASK_AUX if mask_by is not None else 0)
+    arr = _conv_levels(xs, ys, mask_by)
     _check(L.ssad_conv3x3_forward_wino24(arr, len(xs), _ptr(packed), _ptr(bias), Cout, Cin, flags, _stream()),
            "conv3x3_forward_wino24")
     return ys

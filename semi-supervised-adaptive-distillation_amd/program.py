@@ -55,6 +55,10 @@ KLASS = {
     20: dict(name="teacher cls_pred conv3x3 fwd + sigmoid, 720-wide, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma",
              wino=True, exec_div=3.0),
     21: dict(name="teacher tower conv3x3 fwd, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma", wino=True, exec_div=3.0),
+    # SSAD_STUDENT_F24: the trained subnets on the same engine (off by default)
+    22: dict(name="cls_pred conv3x3 fwd, 720-wide, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma", wino=True, exec_div=3.0),
+    23: dict(name="subnet tower conv3x3 forward, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma", wino=True, exec_div=3.0),
+    24: dict(name="subnet conv3x3 data gradient, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma", wino=True, exec_div=3.0),
     # direct (non-Winograd) engine
     18: dict(name="subnet conv3x3 fwd/dgrad, direct engine (conv3x3_kernel)", bound="mfma", wino=False),
     19: dict(name="subnet conv3x3 filter gradient, direct engine (conv3x3_wgrad_kernel + reduce)",
@@ -71,6 +75,8 @@ KLASS = {
     48: dict(name="backbone conv3x3 fwd/dgrad (wino_conv_z_kernel)", bound="mfma", wino=True),
     47: dict(name="frozen teacher backbone conv3x3 fwd, >= 128 wide, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma",
              wino=True, exec_div=3.0),
+    46: dict(name="backbone conv3x3 fwd/dgrad, >= 128 wide, F(2x4,3x3) (wino24_conv_kernel; SSAD_STUDENT_F24)",
+             bound="mfma", wino=True, exec_div=3.0),
     49: dict(name="backbone conv3x3 filter gradient (wino_wgrad_kernel)", bound="mfma", wino=True),
     50: dict(name="backbone pointwise conv fwd / data gradient (gemm_conv_nn_kernel)", bound="mfma", wino=False),
     51: dict(name="backbone elementwise: subsample / scatter, ReluGradient + bias sums, upsample, pool, adds",

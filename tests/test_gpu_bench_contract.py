@@ -35,7 +35,9 @@ def test_default_bench_line_and_also_legs():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert 0.3 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert abs(r["achieved"] * 1e12 - r["flops_per_launch"] / 2.25 / (r["avg_launch_ms"] * 1e-3)) <= 0.01 * r["achieved"] * 1e12
+    # executed flops = direct-form / exec_div: 3 on the F(2x4, 3x3) engine (the default), 2.25 on F(2x2)
+    assert r["exec_div"] == (3.0 if "F(2x4" in r["kernel"] else 2.25)
+    assert abs(r["achieved"] * 1e12 - r["flops_per_launch"] / r["exec_div"] / (r["avg_launch_ms"] * 1e-3)) <= 0.01 * r["achieved"] * 1e12
     for key in ("roofline_loss", "roofline_pow_sum"):
         assert d[key]["bound"] == "hbm" and d[key]["peak"] == 8000.0 and 0.1 < d[key]["frac"] < 1.0
     also = d["also"]

@@ -856,3 +856,42 @@ def test_winograd24_levels_full_size_vs_winograd22_and_oracle(K):
     n0 = 7
     ref = oracle.relu(oracle.conv_forward(Xs[0][n0:n0 + 1].cpu().numpy(), Wt.cpu().numpy(), b.cpu().numpy()))
     close(Y24[0][n0:n0 + 1].cpu().numpy(), ref, F24_RTOL, F24_FLOOR, "wino24 P3 slice")
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 128, 128, 8, 16), (2, 256, 36, 5, 7), (1, 256, 256, 10, 14), (1, 130, 24, 17, 33), (2, 256, 720, 3, 4),
+    (3, 129, 40, 2, 31)], ids=lambda s: "N%d_C%d_M%d_%dx%d" % s)
+def test_winograd24_data_gradient_vs_oracle(K, shape):
+    """The F(2x4) engine's data-gradient form (flipped + transposed pack, fused ReluGradient mask; SSAD_STUDENT_F24):
+    dX of conv_op_impl.h:358-577 for a layer of Cin inputs and M outputs, unmasked and masked."""
+    N, Cin, M, H, W = shape
+    rng = np.random.default_rng(2450 + sum(shape))
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)          # doubles as the mask (the layer's ReLU'd input)
+    Wt = (rng.standard_normal((M, Cin, 3, 3)) * 0.05).astype(np.float32)
+    dY = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    _, pd = K.conv_wino24_pack_filter(dev(Wt), want_dgrad=True)
+    dX = oracle.conv_backward(X, Wt, dY, want_db=False)[2]
+    got = K.conv3x3_forward_wino24([dev(dY)], pd, None, Cin)[0].cpu().numpy()
+    close(got, dX, F24_RTOL, F24_FLOOR, "wino24 dX")
+    got = K.conv3x3_forward_wino24([dev(dY)], pd, None, Cin, mask_by=[dev(X)])[0].cpu().numpy()
+    close(got, np.where(X > 0, dX, 0), F24_RTOL, F24_FLOOR, "wino24 masked dX")
+
+
+def test_winograd24_data_gradient_full_size_vs_winograd22(K):
+    """Tower data gradient at config 3's size (two filters x five levels in one call, masked) against the F(2x2)
+    engine element by element, and bit-reproducible."""
+    gen = torch.Generator(device="cuda").manual_seed(25)
+    N, C = 16, 256
+    shapes = [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)]
+    dYs = [torch.randn((N, C, h, w), device="cuda", generator=gen) * 1e-3 for h, w in shapes]
+    Ms = [torch.randn((N, C, h, w), device="cuda", generator=gen) for h, w in shapes]
+    Wt = torch.randn((C, C, 3, 3), device="cuda", generator=gen) * 0.02
+    _, d24 = K.conv_wino24_pack_filter(Wt, want_dgrad=True)
+    _, d22 = K.conv_wino_pack_filter(Wt, False, True)
+    A = K.conv3x3_forward_wino24(dYs, d24, None, C, mask_by=Ms)
+    B = K.conv3x3_forward(dYs, d22, None, C, mask_by=Ms, wino=True)
+    for a, c, m in zip(A, B, Ms):
+        assert (a - c).abs().max().item() <= 1e-5 * c.abs().max().item()
+        assert torch.equal(a == 0, (m <= 0) | (a == 0))
+    again = K.conv3x3_forward_wino24(dYs, d24, None, C, mask_by=Ms)
+    assert all(torch.equal(a, c) for a, c in zip(A, again))

@@ -284,18 +284,19 @@ def test_sgd_update_ops_follow_optimizer_py():
 SHAPES = [(10, 14), (5, 7), (3, 4), (2, 2), (1, 1)]     # P3..P7 of a tiny image
 
 
-def close_chain(got, ref, what, errs=None):
-    """End-to-end tolerance for quantities behind a CHAIN of convolutions and
-    ReLU masks.  Each kernel is held to 1e-4 on its own (test_gpu_kernels.py;
-    measured ~5e-7 relative L2 for both conv engines, tools/conv_error.py).
-    Through a chain the typical error stays ~5e-6, but an activation within
-    fp32 rounding of zero can take the other side of a ReLU mask in two
-    implementations that are equivalent in exact arithmetic (im2col+GEMM
-    oracle, direct MFMA, Winograd) and moves the few affected gradient entries
-    by O(|dY|): tools/chain_error.py shows sporadic 2e-4..1e-3 relative L2 on
-    single tensors for EITHER engine on these tiny maps.  So each tensor is
-    bounded at 2e-3 relative L2 / 5e-3 of max per entry, and callers check
-    that the typical (median) tensor is within 5e-5 (assert_typical)."""
+def close_chain(got, ref, what, errs=None, flips=None):
+    """End-to-end tolerance for quantities behind a CHAIN of convolutions and ReLU masks.  Each kernel is held
+    to 1e-4 on its own (test_gpu_kernels.py).  Through the chain the error stays ~5e-6 (F(2x2)) / ~9e-6 (F(2x4))
+    relative L2 on EVERY gradient tensor -- unless an activation within fp32 rounding of zero takes the other
+    side of a ReLU mask than in the oracle (two implementations that are equivalent in exact arithmetic:
+    im2col+GEMM, direct MFMA, either Winograd engine), which moves the affected gradient entries by O(|dY|):
+    tools/dbg/r5_chain_flips.py, 20 seeds of this tiny problem: F(2x2) 17 seeds without such an activation (worst
+    tensor 5.1e-6) and 3 with one (up to 4.9e-3 relative L2, 1.9e-2 of max on one entry); F(2x4) 13 without
+    (9.3e-6) and 7 with (forward error 3.3e-6 against 1.9e-6 of the scale: proportionally more often).
+    So: flips == 0 (the caller counted the activations on the other side of zero, count_flips) -> every tensor
+    within 1e-4 relative L2 and 1e-4 of max per entry, the parity bar itself; otherwise (unknown, or some) each
+    tensor is bounded at 2e-3 relative L2 / 5e-3 of max per entry and callers check that the typical (median)
+    tensor is within 5e-5 (assert_typical)."""
     got = np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
     assert got.shape == ref.shape and np.all(np.isfinite(got)), what
@@ -303,16 +304,36 @@ def close_chain(got, ref, what, errs=None):
     rel = num / max(den, 1e-300)
     if errs is not None:
         errs.append(rel)
-    assert num <= 2e-3 * den + 1e-12, "%s: rel L2 %.3e" % (what, rel)
-    assert np.max(np.abs(got - ref)) <= 5e-3 * np.max(np.abs(ref)) + 1e-12, \
-        "%s: max abs err %.3e of max %.3e" % (what, np.max(np.abs(got - ref)), np.max(np.abs(ref)))
+    l2, entry = (1e-4, 1e-4) if flips == 0 else (2e-3, 5e-3)
+    assert num <= l2 * den + 1e-12, "%s: rel L2 %.3e (flips: %r)" % (what, rel, flips)
+    assert np.max(np.abs(got - ref)) <= entry * np.max(np.abs(ref)) + 1e-12, \
+        "%s: max abs err %.3e of max %.3e (flips: %r)" % (what, np.max(np.abs(got - ref)), np.max(np.abs(ref)), flips)
+
+
+def oracle_tower_acts(S, fs):
+    """The student's post-ReLU tower activations as the oracle computes them: {tower: [depth][level]}."""
+    acts = {"cls": [], "bbox": []}
+    head_step.tower_forward(S, "cls", fs, acts["cls"])
+    head_step.tower_forward(S, "bbox", fs, acts["bbox"])
+    return acts
+
+
+def count_flips(get_act, acts):
+    """Activations that are positive in one implementation and not in the other: get_act(tower, depth, level) ->
+    array.  The backward pass multiplies by these masks (ReluGradient), see close_chain."""
+    n = 0
+    for tower, per_depth in acts.items():
+        for d, per_level in enumerate(per_depth):
+            for l, a in enumerate(per_level):
+                n += int(((np.asarray(get_act(tower, d, l)) > 0) != (a > 0)).sum())
+    return n
 
 
 def assert_typical(errs, what):
     assert np.median(errs) <= 5e-5, "%s: median rel L2 %.3e" % (what, float(np.median(errs)))
 
 
-def small_problem(seed=31, N=2):
+def small_problem(seed=30, N=2):
     rng = np.random.default_rng(seed)
     cfg = rh.HeadConfig(num_gpus=1)
     S, T = synth.head_params(rng), synth.head_params(rng)
@@ -381,13 +402,16 @@ def test_head_graph_through_workspace_vs_oracle_and_fused():
         close(workspace.FetchBlob("fl_fpn%d" % l), ref["focal_losses"][i], 2e-4, 0, "focal loss")
         close(workspace.FetchBlob("retnet_loss_bbox_fpn%d" % l), ref["bbox_losses"][i], 2e-4, 1e-9,
               "bbox loss")
+    acts = oracle_tower_acts(S, fs)
+    flips = count_flips(lambda tw, d, l: workspace.FetchBlob("retnet_%s_conv_n%d_fpn%d" % (tw, d, levels[l])), acts)
+    assert flips == 0, "seed with an activation on the other side of zero: pick another (close_chain)"
     errs = []
     for name, g in ref["grads"].items():
-        close_chain(workspace.FetchBlob(grad_map[name]), g, "graph grad " + name, errs)
+        close_chain(workspace.FetchBlob(grad_map[name]), g, "graph grad " + name, errs, flips)
     assert_typical(errs, "graph grads")
     for i, l in enumerate(levels):
         want = ref["d_fpn"]["cls"][i] + ref["d_fpn"]["bbox"][i]
-        close_chain(workspace.FetchBlob(grad_map["fpn_%d" % l]), want, "d fpn")
+        close_chain(workspace.FetchBlob(grad_map["fpn_%d" % l]), want, "d fpn", None, flips)
 
     # fused pipeline: same numbers
     from ssad_amd.head_pipeline import DistillHeads
@@ -400,15 +424,16 @@ def test_head_graph_through_workspace_vs_oracle_and_fused():
     close(losses.cpu().numpy(), ref["losses"], 2e-4, 0, "fused distill losses")
     close(heads.focal_losses.cpu().numpy(), ref["focal_losses"], 2e-4, 0, "fused focal losses")
     close(heads.bbox_losses.cpu().numpy(), ref["bbox_losses"], 2e-4, 1e-9, "fused bbox losses")
+    flips = count_flips(lambda tw, d, l: heads.act[tw][d][l].cpu().numpy(), acts)
     errs = []
     for name, g in ref["grads"].items():
-        close_chain(heads.grads[name].cpu().numpy(), g, "fused grad " + name, errs)
+        close_chain(heads.grads[name].cpu().numpy(), g, "fused grad " + name, errs, flips)
         close_chain(heads.grads[name].cpu().numpy(), workspace.FetchBlob(grad_map[name]),
-                    "fused vs graph " + name)
+                    "fused vs graph " + name, None, flips)
     assert_typical(errs, "fused grads")
     for tower in ("cls", "bbox"):
         for i in range(len(SHAPES)):
-            close_chain(heads.d_fpn[tower][i].cpu().numpy(), ref["d_fpn"][tower][i], "d_fpn")
+            close_chain(heads.d_fpn[tower][i].cpu().numpy(), ref["d_fpn"][tower][i], "d_fpn", None, flips)
 
 
 def test_executor_timing_classes_and_selection():
@@ -430,7 +455,9 @@ def test_executor_timing_classes_and_selection():
     heads.step(*args, **kw)
     torch.cuda.synchronize()
     allc = everything.collect()
-    assert {2, 8, 9, 16}.issubset(allc) and allc[9]["launches"] == 1 and allc[8]["launches"] == 1
+    # (tower forward / data gradient classes: 23 / 24 on the F(2x4) engine, 2 / 16 with SSAD_STUDENT_F24=0)
+    assert ({23, 8, 9, 24}.issubset(allc) or {2, 8, 9, 16}.issubset(allc)) and allc[9]["launches"] == 1 \
+        and allc[8]["launches"] == 1
     assert all(c["ms"] > 0 for c in allc.values())
     only = PR.Timing().select([9, 8])
     heads.timing = only

@@ -23,6 +23,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc (ROCm) to produce the assembly")
 @pytest.mark.parametrize("src,expect", [("conv3x3_winograd.hip", "wino_conv_z_kernel"),
+                                        ("conv3x3_winograd24.hip", "wino24_conv_kernel"),
                                         ("conv3x3_f16.hip", "conv3x3_wgrad_f16_kernel")])
 def test_no_access_to_in_flight_asm_load_destinations(tmp_path, src, expect):
     import isa_lint

@@ -104,6 +104,15 @@ def test_student_training_net_lowering():
     assert hist["MomentumSGDUpdate"] == 20 and hist["NCCLAllreduce"] == 20
     assert "Sum absorbed 20" in report and "ReluGradient fused 40" in report
     assert len(ops) < n_in // 2
+    # trained nets: forward and data gradient on the F(2x4, 3x3) engine unless the net says hip_train_f24 = 0
+    assert "50 trained" not in report and " 100 trained" in report, report          # 50 Conv + 50 ConvGradient
+    for g in [o for o in ops if o.type in ("ConvGroup", "ConvGradientGroup")]:
+        assert [a.s for a in g.arg if a.name == "hip_algo"] in (["winograd24"], [b"winograd24"]), g.type
+    proto = student.net.Proto()
+    proto.arg.append(core.MakeArgument("hip_train_f24", 0))
+    ops0, report0 = workspace.LowerNet(student.net)
+    assert " 0 trained" in report0 and not any(a.name == "hip_algo" for o in ops0 for a in o.arg), report0
+    proto.arg.pop()
     groups = [o for o in ops if o.type == "ConvGradientGroup"]
     for g in groups:
         nf = [a for a in g.arg if a.name == "n_filters"][0].i
@@ -139,7 +148,8 @@ def test_lowered_list_computes_the_same_values():
         if op.type == "ConvGroup":
             per = len(op.input) // len(op.output)
             relu = any(a.name == "fuse_relu" for a in op.arg)
-            args = [a for a in op.arg if a.name != "fuse_relu"]
+            # (hip_algo picks the engine that computes the same convolution: not part of the value)
+            args = [a for a in op.arg if a.name not in ("fuse_relu", "hip_algo")]
             for k, y in enumerate(op.output):
                 c = caffe2_pb2.OperatorDef()
                 c.type, c.input, c.output, c.arg = "Conv", op.input[per * k:per * k + per], [y], args
@@ -186,17 +196,26 @@ def test_write_after_read_and_keep():
     assert gm["w"] == "w_grad"
 
 
-def test_evaluated_only_nets_take_the_f24_engine_training_nets_do_not():
+def test_f24_engine_marking_of_evaluated_and_trained_nets():
     """A net without gradient operators (the teacher net, an inference net) is only evaluated: its 3x3 convolutions
-    get hip_algo = "winograd24" (conv3x3_winograd24.hip; 3 multiplies per output, fp32 error ~2e-6 of the scale).
-    A net that trains keeps the F(2x2) engine everywhere; an explicit hip_algo in the graph is respected."""
+    get hip_algo = "winograd24" (conv3x3_winograd24.hip; 3 multiplies per output, fp32 error ~2e-6 of the scale) --
+    switch hip_frozen_f24.  A net that trains gets it on Conv and ConvGradient (the operators apply it to the forward
+    pass and the data gradient of >= 128-wide layers) -- switch hip_train_f24, independent of the first; an explicit
+    hip_algo in the graph is respected."""
     _, teacher, student, _ = head_nets(update=True)
     t_ops, t_rep = workspace.LowerNet(teacher.net)
     for g in [o for o in t_ops if o.type == "ConvGroup"]:
         assert [a.s for a in g.arg if a.name == "hip_algo"] == [b"winograd24"], g.arg
     assert "F(2x4) Conv 50" in t_rep
     s_ops, s_rep = workspace.LowerNet(student.net)
-    assert not any(a.name == "hip_algo" for o in s_ops for a in o.arg) and "F(2x4) Conv 0" in s_rep
+    assert "F(2x4) Conv 0 evaluated / 100 trained" in s_rep, s_rep
+    student.net.Proto().arg.append(core.MakeArgument("hip_train_f24", 0))
+    s_ops, s_rep = workspace.LowerNet(student.net)
+    assert not any(a.name == "hip_algo" for o in s_ops for a in o.arg) and "F(2x4) Conv 0 evaluated / 0 trained" in s_rep
+    teacher.net.Proto().arg.append(core.MakeArgument("hip_train_f24", 0))        # not the teacher's switch
+    assert "F(2x4) Conv 50 evaluated" in workspace.LowerNet(teacher.net)[1]
+    teacher.net.Proto().arg.append(core.MakeArgument("hip_frozen_f24", 0))
+    assert "F(2x4) Conv 0 evaluated" in workspace.LowerNet(teacher.net)[1]
     net = core.Net("pinned")
     with core.DeviceScope(GPU):
         net.Conv(["x", "w", "b"], ["y"], kernel=3, pad=1, stride=1, order="NCHW", hip_algo="direct")

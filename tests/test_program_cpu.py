@@ -39,11 +39,18 @@ def test_distillation_step_program_structure():
     assert list(m) == ["pack", "forward", "losses", "backward", "backward_late_done", "sgd", "sgd_update",
                        "ls_update", "end"]
     assert m["sgd"] == m["sgd_update"] and m["ls_update"] == m["end"]      # fp32: nothing around the update
-    assert _codes(h, "pack", "forward") == [PR.WINO_PACK_FILTERS]        # 10 filters x {fwd, dgrad}: 1 launch
+    # 10 filters x {fwd, dgrad}: one launch per pack layout -- F(2x4) (every forward but bbox_pred's 36 outputs,
+    # every data gradient) and F(2x2) (bbox_pred forward)
+    assert _codes(h, "pack", "forward") == [PR.WINO_PACK_FILTERS] * 2
+    assert [(o.i[0], o.i[1]) for o in h.prog.ops[m["pack"]:m["forward"]]] == [(10, 2), (1, 0)]
     # 4 tower depths (teacher+student x cls+bbox in one launch each), teacher cls_pred (sigmoid),
     # student cls_pred, bbox_pred (student + teacher)
     assert _codes(h, "forward", "losses") == [PR.CONV3X3] * 7
     assert [o.i[0] for o in h.prog.ops[m["forward"]:m["losses"]]] == [8, 8, 8, 8, 2, 2, 4]
+    # engine (i[4]: 1 = F(2x2), 2 = F(2x4)) and timing class per launch
+    assert [(o.i[4], o.klass) for o in h.prog.ops[m["forward"]:m["losses"]]] == \
+        [(2, 23)] * 4 + [(2, 20), (2, 22), (1, 4)]
+    assert {(o.i[4], o.klass) for o in h.prog.ops[m["backward"]:m["sgd"]] if o.code == PR.CONV3X3} == {(2, 24)}
     assert _codes(h, "losses", "backward") == [PR.POW_SUM, PR.CLS_LOSSES_FUSED, PR.SMOOTH_L1]
     bw = _codes(h, "backward", "sgd")
     assert bw.count(PR.CONV3X3_WGRAD) == 10 and bw.count(PR.CONV3X3) == 6
@@ -54,7 +61,7 @@ def test_distillation_step_program_structure():
     # direct-form flops of SURVEY 8d: 2*9*Cout*Cin per output pixel
     px = sum(hh * ww for hh, ww in SHAPES)
     first = h.prog.ops[m["forward"]]
-    assert first.work == 2.0 * 9 * 256 * 256 * px * 4 and first.klass == 2
+    assert first.work == 2.0 * 9 * 256 * 256 * px * 4 and first.klass == 23
     # every wgrad shares the one workspace, sized for the largest
     ws = {o.p[3] for o in h.prog.ops if o.code == PR.CONV3X3_WGRAD}
     assert ws == {h.wgrad_ws.data_ptr()}
