@@ -350,12 +350,12 @@ typedef struct ssad_pack_entry {
 SSAD_API int ssad_conv_wino_pack_filters(const ssad_pack_entry* entries_host, int n_entries,
                                          ssad_stream_t stream);
 
-/* Winograd F(2x4, 3x3) forward engine for networks that are only EVALUATED (round 5; conv3x3_winograd24.hip):
- * 3 multiplies per output where F(2x2) does 4, fp32 error ~2e-6 of the output scale where F(2x2) has ~3e-7 -- inside
- * the parity bar for a forward pass, not for a trained chain with its gradients, so the training step uses it for the
- * frozen teacher only (model_builder.py:373-411 builds the teacher in test mode).  Same level / flag contract as
- * ssad_conv3x3_forward_wino (bias, SSAD_CONV_RELU, SSAD_CONV_SIGMOID; no SSAD_CONV_MASK_AUX: forward only), its own
- * filter pack (entries with packed_fwd set and packed_dgrad NULL).  Meant for Cout >= 128. */
+/* Winograd F(2x4, 3x3) engine (round 5; conv3x3_winograd24.hip): 3 multiplies per output where F(2x2) does 4; fp32
+ * error 1.5-2.2e-6 of the output scale against a float64 convolution where F(2x2) has 0.8-1.9e-6.  First the frozen
+ * teacher's engine (model_builder.py:373-411 builds the teacher in test mode), then the trained networks' forward
+ * pass and data gradient as well.  Same level / flag contract as ssad_conv3x3_forward_wino (bias,
+ * SSAD_CONV_RELU, SSAD_CONV_SIGMOID, SSAD_CONV_MASK_AUX with the data-gradient pack), its own filter pack (entries
+ * with packed_fwd and / or packed_dgrad).  Meant for >= 128 outputs. */
 SSAD_API size_t ssad_conv_wino24_filter_floats(int M, int K);
 SSAD_API int ssad_conv_wino24_pack_filters(const ssad_pack_entry* entries_host, int n_entries, ssad_stream_t stream);
 SSAD_API int ssad_conv3x3_forward_wino24(

@@ -38,13 +38,13 @@ extern "C" {
  * names ending in _host). */
 enum ssad_opcode {
   /* ssad_conv_wino_pack_filters(p0 = entries_host, i0 = n); i1 == 2: ssad_conv_wino24_pack_filters (the F(2x4)
-   * engine of frozen networks: forward packs only) */
+   * engine: forward and / or data-gradient packs) */
   SSAD_OP_WINO_PACK_FILTERS = 1,
   /* ssad_conv_pack_filter(p0 = w, i0 = Cout, i1 = Cin, p1 = packed_fwd, p2 = packed_dgrad) */
   SSAD_OP_PACK_FILTER = 2,
   /* ssad_conv3x3_forward[_wino](p0 = levels_host, i0 = n, p1 = packed, p2 = bias, i1 = Cout,
    * i2 = Cin, i3 = flags); i4: 0 the direct engine, 1 Winograd F(2x2, 3x3), 2 Winograd F(2x4, 3x3)
-   * (ssad_conv3x3_forward_wino24: evaluated networks only) */
+   * (ssad_conv3x3_forward_wino24) */
   SSAD_OP_CONV3X3 = 3,
   /* ssad_conv3x3_wgrad(p0 = levels_host, i0 = n, p1 = dW, p2 = db, i1 = Cout, i2 = Cin,
    * i3 = accumulate, p3 = workspace, l0 = workspace_bytes) */

@@ -1,9 +1,9 @@
-// conv3x3_winograd24.hip -- Winograd F(2x4, 3x3) forward engine for FROZEN networks (round 5).
+// conv3x3_winograd24.hip -- Winograd F(2x4, 3x3) forward / data-gradient engine (round 5).
 //
 // Same operator contract as conv3x3_winograd.hip (3x3, stride 1, pad 1, NCHW fp32;
-// caffe2/operators/conv_op_cudnn.cc:567-617), same persistent kernel skeleton -- LDS-DMA staging of the raw
-// 10 x 18 patch (or two 10 x 10 sub-patches), filter operands through a hand-counted register ring, input
-// transform threaded through the MFMA steps -- but the tile is 2 rows x 4 columns:
+// caffe2/operators/conv_op_cudnn.cc:567-617 forward, :1040-1058 data gradient), same persistent kernel skeleton --
+// LDS-DMA staging of the raw 10 x 18 patch (or two 10 x 10 sub-patches), filter operands through a hand-counted
+// register ring, input transform threaded through the MFMA steps -- but the tile is 2 rows x 4 columns:
 //
 //     Y = A2^T [ (G2 g G4^T) (.) (B2^T d B4) ] A4        F(2,3) down the rows, F(4,3) along them
 //
@@ -14,12 +14,15 @@
 // it was.  Measured on the F(2x2) kernel with a quarter of its MFMAs compiled out (WINO_ABLATE 64): -19 % per
 // launch; this kernel: see DESIGN.md 3.10.
 //
-// Accuracy: F(4,3)'s transforms multiply by 4, 5, 8 where F(2,3) only adds: fp32 error ~2e-6 of the output scale
-// against ~3e-7 (tools/f44_accuracy.py; F(4x4) in both directions: 4-8e-6).  That is inside the 1e-4 parity
-// bar for one layer but not for a trained chain of ten with its gradients, so the engine serves
-// networks that are only EVALUATED -- the frozen teacher of the distillation step (model_builder.py:373-411 builds
-// it in test mode; nothing back-propagates through it): the subnets' towers and cls_pred, the R-101 body's
-// 128- / 256- / 512-wide 3x3 layers.  Forward only; Cout <= 64 layers stay on the F(2x2) kernel.
+// Accuracy: F(4,3)'s transforms multiply by 4, 5, 8 where F(2,3) only adds.  Against a float64 convolution:
+// 1.5-2.2e-6 of the output scale, F(2x2) 0.8-1.9e-6 on the same inputs (tools/dbg/r5_f24_check.py); through the
+// whole subnets step (ten layers forward, ten backward) every gradient tensor within 9.3e-6 relative L2 of the
+// oracle where F(2x2) is within 5.1e-6 (tools/dbg/r5_chain_flips.py, seeds without a ReLU-mask flip) -- an order
+// inside the 1e-4 parity bar either way (F(4x4) in both directions measured 4-8e-6 per layer and was not built).
+// Who uses it: the frozen teacher (round 5, first: model_builder.py:373-411 builds it in test mode) and, since the
+// end of round 5, the trained networks' forward pass and data gradient too (the same kernel on the flipped /
+// transposed pack with the fused ReluGradient mask); the filter gradient keeps its F(3x3, 2x2) engine.  Layers with
+// fewer than 128 outputs stay on the F(2x2) kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -30,6 +33,13 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// W24_ABLATE (debug builds only, wrong results): 1 no input transform, 2 no B-operand LDS reads in the step loop,
+// 4 no filter-operand ring reloads / waits, 8 no end-of-chunk barrier, 16 no patch DMA, 32 no epilogue stores
+// (tools/dbg/r5_w24_ablate.sh: what a chunk's time is made of)
+#ifndef W24_ABLATE
+#define W24_ABLATE 0
+#endif
 
 constexpr int KC = 16;                   // input channels per chunk
 constexpr int KS = KC / 4;               // MFMA k-steps per chunk
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino24_conv_kernel(const WArgs args
         for (int step = 0; step < STEPS; ++step) {       // step = ks * 6 + xq
           const int xq = step % XQ;
           const int nks = (step + 1) / XQ, nxq = (step + 1) % XQ;
-          {
+          if (!(W24_ABLATE & 4)) {
             // ring slot of this step: 7 younger ring loads + the DMA instructions issued since it was requested
             // (conv3x3_winograd.hip: R(j) is requested at step j - 8, D_k at the end of step k <= 6)
             const int younger = step < AD ? (step < ZL ? step : ZL) : (ZL + AD - step > 0 ? ZL + AD - step : 0);
@@ -403,20 +413,25 @@ __global__ __launch_bounds__(kBlock, 1) void wino24_conv_kernel(const WArgs args
             const int xi = xq * 4 + xr;
             acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[xr], bc[xr], acc[xi], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (step < STEPS - 1) bc[xr] = vb[((nxq * 4 + xr) * KC + nks * 4) * VP];
+            if (!(W24_ABLATE & 2) && step < STEPS - 1) bc[xr] = vb[((nxq * 4 + xr) * KC + nks * 4) * VP];
             __builtin_amdgcn_sched_barrier(0);
           }
-          a_load_at(ar[step & (AD - 1)], step + AD >= STEPS ? tail_voff : a_voff, arsrc,
-                    abase + (ch * STEPS + step + AD) * 1024);
+          if (!(W24_ABLATE & 4))
+            a_load_at(ar[step & (AD - 1)], step + AD >= STEPS ? tail_voff : a_voff, arsrc,
+                      abase + (ch * STEPS + step + AD) * 1024);
           // F24 transform of chunk s + 1: two rounds of 8 channels
-          if (xf && step == 2) xf_load(xsrc, 0, xd);
-          if (xf && step == 8) xf_store(xdst, 0, xd);
-          if (xf && step == 14) xf_load(xsrc, 1, xd);
-          if (xf && step == 20) xf_store(xdst, 1, xd);
-          if (step == 0) { dma_begin(s + 3 < S); dma_vo = dma_offset(0); }
-          if (step < ZL) dma_issue(step, dma_vo);
-          if (step + 1 < ZL) dma_vo = dma_offset(step + 1);
-          if (step == ZL - 1) dma_end();
+          if (!(W24_ABLATE & 1)) {
+            if (xf && step == 2) xf_load(xsrc, 0, xd);
+            if (xf && step == 8) xf_store(xdst, 0, xd);
+            if (xf && step == 14) xf_load(xsrc, 1, xd);
+            if (xf && step == 20) xf_store(xdst, 1, xd);
+          }
+          if (!(W24_ABLATE & 16)) {
+            if (step == 0) { dma_begin(s + 3 < S); dma_vo = dma_offset(0); }
+            if (step < ZL) dma_issue(step, dma_vo);
+            if (step + 1 < ZL) dma_vo = dma_offset(step + 1);
+            if (step == ZL - 1) dma_end();
+          }
           if (step == ZL) side_look();
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -429,14 +444,15 @@ __global__ __launch_bounds__(kBlock, 1) void wino24_conv_kernel(const WArgs args
       if (++rbuf == NRAW) rbuf = 0;
       // end of chunk: this wave's LDS traffic done, the DMA of the previous chunk landed (younger than its last
       // instruction: that chunk's STEPS - ZL ring loads and this chunk's STEPS + ZL instructions)
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((STEPS - ZL) + STEPS + ZL) : "memory");
-      __builtin_amdgcn_s_barrier();
+      if (W24_ABLATE & (4 | 16)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((STEPS - ZL) + STEPS + ZL) : "memory");
+      if (!(W24_ABLATE & 8)) __builtin_amdgcn_s_barrier();
     }
     // the next item's first operands fly during the epilogue (every wave: one definition of the ring, see
     // conv3x3_winograd.hip "IN-FLIGHT RING REGISTERS AND THE COMPILER")
 #pragma unroll
     for (int k = 0; k < AD; ++k) a_load(ar[k], nrsrc, nbase + k * 1024);
-    if (active) {
+    if (active && !(W24_ABLATE & 32)) {
       const WLevel& L = args.lv[T.l];
       const int H = L.H, W = L.W, HW = H * W;
       const int flags = args.flags;
