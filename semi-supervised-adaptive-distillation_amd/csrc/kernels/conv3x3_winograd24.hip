@@ -36,6 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // W24_ABLATE (debug builds only, wrong results): 1 no input transform, 2 no B-operand LDS reads in the step loop,
 // 4 no filter-operand ring reloads / waits, 8 no end-of-chunk barrier, 16 no patch DMA, 32 no epilogue stores
+// 64 patch DMA issued but every lane out of range (no memory traffic), 128 filter ring loads issued out of range
 // (tools/dbg/r5_w24_ablate.sh: what a chunk's time is made of)
 #ifndef W24_ABLATE
 #define W24_ABLATE 0
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino24_conv_kernel(const WArgs args
     dma_soff = __builtin_amdgcn_readfirstlane(real ? ld_ch * chunk_bytes : 0);
     dma_dst = __builtin_amdgcn_readfirstlane(raw_lds + (unsigned)(ld_buf * ZRAWP + wave * 64) * 4u);
   };
-  auto dma_offset = [&](int j) { return dma_real ? myvoff[j * 64] : kOOBOff; };
+  auto dma_offset = [&](int j) { return (dma_real && !(W24_ABLATE & 64)) ? myvoff[j * 64] : kOOBOff; };
   auto dma_issue = [&](int j, unsigned vo) { ssad_dev::lds_dma<4>(xrs, dma_dst + j * 2048, vo, dma_soff); };
   auto dma_end = [&]() {
     if (dma_real) {
@@ -380,6 +381,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino24_conv_kernel(const WArgs args
       float* xdst = vbuf + ((s + 1) & 1) * VBUF;
       const bool last = ch == chunks - 1;
       const unsigned tail_voff = last ? kOOBOff : a_voff;
+      const unsigned tail_voff_ab = (W24_ABLATE & 128) ? kOOBOff : tail_voff;
       if (active) {
         const float* vb = bbase + (s & 1) * VBUF;
         float bc[4];
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino24_conv_kernel(const WArgs args
             __builtin_amdgcn_sched_barrier(0);
           }
           if (!(W24_ABLATE & 4))
-            a_load_at(ar[step & (AD - 1)], step + AD >= STEPS ? tail_voff : a_voff, arsrc,
+            a_load_at(ar[step & (AD - 1)], (step + AD >= STEPS || (W24_ABLATE & 128)) ? tail_voff_ab : a_voff, arsrc,
                       abase + (ch * STEPS + step + AD) * 1024);
           // F24 transform of chunk s + 1: two rounds of 8 channels
           if (!(W24_ABLATE & 1)) {
