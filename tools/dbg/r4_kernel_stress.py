@@ -41,6 +41,27 @@ def _run(iters, verbose):
         return lambda: torch.cat([t.reshape(-1) for t in K.conv3x3_forward(xs, pf, b, Cout, relu=True, wino=True, out=outs)])
 
 
+    def w24_case(Cin, Cout, shapes, mask=False, relu=True, bias=True, nfilters=1):
+        """wino24_conv_kernel (round 5: the default forward / data-gradient engine of >= 128-wide layers): `nfilters`
+        problems per level list in one launch, like a tower depth."""
+        xs, packs, outs, masks, biases = [], [], [], [], []
+        for _ in range(nfilters):
+            pf = K.conv_wino24_pack_filter(R(Cout, Cin, 3, 3) / (3 * Cin ** 0.5))
+            b = R(Cout) if bias else None
+            for h, w in shapes:
+                xs.append(R(N, Cin, h, w)); packs.append(pf); biases.append(b)
+                outs.append(torch.empty(N, Cout, h, w, device="cuda"))
+                masks.append(R(N, Cout, h, w) if mask else None)
+        arr = K._conv_levels(xs, outs, masks if mask else None, packs, biases)
+        flags = (K.CONV_MASK_AUX if mask else 0) | (K.CONV_RELU if relu else 0)
+        L = K.lib()
+        def run():
+            K._check(L.ssad_conv3x3_forward_wino24(arr, len(xs), K._ptr(packs[0]), K._ptr(biases[0]), Cout, Cin, flags,
+                                                   K._stream()), "conv3x3_forward_wino24")
+            return torch.cat([t.reshape(-1) for t in outs])
+        return run
+
+
     def wgrad_case(Cin, Cout, shapes):
         xs = [R(N, Cin, h, w) for h, w in shapes]
         dys = [R(N, Cout, h, w) for h, w in shapes]
@@ -90,6 +111,11 @@ def _run(iters, verbose):
         ("wino 256->256 40x56 (split tail: 48 items x 4 units)", wino_case(256, 256, 40, 56)),
         ("wino 256->256 40x56 masked (split tail)", wino_case(256, 256, 40, 56, mask=True, relu=False, bias=False)),
         ("wino 256->256 10x14 (no full round: 64 x 4 units)", wino_case(256, 256, 10, 14)),
+        ("wino24 256->256 tower depth (2 filters x five levels)", w24_case(256, 256, [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)], nfilters=2)),
+        ("wino24 256->256 data-gradient form, masked, five levels", w24_case(256, 256, [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)], mask=True, relu=False, bias=False)),
+        ("wino24 256->720 40x56 + 5x7 (pairs)", w24_case(256, 720, [(40, 56), (5, 7)], relu=False)),
+        ("wino24 720->256 80x112 masked (cls_pred data gradient)", w24_case(720, 256, [(80, 112)], mask=True, relu=False, bias=False)),
+        ("wino24 512->512 20x28", w24_case(512, 512, [(20, 28)])),
         ("wino filter gradient 256x256 five levels", wgrad_case(256, 256, [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)])),
         ("wino filter gradient 128x128 80x112", wgrad_case(128, 128, [(80, 112)])),
         ("gemm nn 256->1024 40x56 + shortcut", pw_case(256, 1024, 40, 56)),
@@ -107,6 +133,7 @@ def _run(iters, verbose):
     bg_pw = pw_case(256, 1024, 80, 112)
     bg_w = wino_case(64, 64, 160, 224)
     bg_w2 = wino_case(256, 256, 40, 56)
+    bg_w24 = w24_case(256, 256, [(40, 56)])
     big = R(64, 1024, 1024)
     torch.cuda.synchronize()
     bad_total, skipped = 0, 0
@@ -123,7 +150,7 @@ def _run(iters, verbose):
         t0 = time.time()
         for it in range(iters):
             with torch.cuda.stream(s1):
-                bg_pw(); bg_w(); bg_w2()
+                bg_pw(); bg_w(); bg_w2(); bg_w24()
             with torch.cuda.stream(s2):
                 big.mul_(1.0000001)
             out = fn()
