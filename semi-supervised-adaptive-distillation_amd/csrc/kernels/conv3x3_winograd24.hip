@@ -468,10 +468,28 @@ __global__ __launch_bounds__(kBlock, 1) void wino24_conv_kernel(const WArgs args
       const __amdgpu_buffer_rsrc_t yrsrc = uniform_rsrc(L.y, (unsigned)((long long)L.N * M * HW * 4));
       const __amdgpu_buffer_rsrc_t krsrc = uniform_rsrc(masked ? L.aux : L.y, (unsigned)((long long)L.N * M * HW * 4));
       const bool whole = px + 3 < W && !sigm && mt * 16 + 16 <= M;      // four pixels inside: one 16-byte store per row
+      // Everything the epilogue reads from memory is requested FIRST -- the four biases and, for the data gradient,
+      // the eight 16-byte mask rows of this lane -- and consumed after the inverse transform: with the load beside
+      // each store the wave waited out a memory round trip eight times per item.
+      float bv[4];
+      unsigned vos[4][2];
+      f32x4 kvs[4][2];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = mt * 16 + kq * 4 + r;
-        const float bias = (L.bias && m < M) ? L.bias[m] : 0.0f;
+        bv[r] = (L.bias && m < M) ? L.bias[m] : 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int yy = py + a;
+          vos[r][a] = (whole && yy < H) ? (unsigned)((((long long)sn * M + m) * HW + yy * W + px) * 4) : kOOBOff;
+          if (masked)
+            kvs[r][a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krsrc, vos[r][a], 0, 0));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mt * 16 + kq * 4 + r;
+        const float bias = bv[r];
         float t[2][XQ];
 #pragma unroll
         for (int b = 0; b < XQ; ++b) {
@@ -494,10 +512,9 @@ __global__ __launch_bounds__(kBlock, 1) void wino24_conv_kernel(const WArgs args
           }
           const int yy = py + a;
           if (whole) {
-            const unsigned vo = (yy < H) ? (unsigned)((((long long)sn * M + m) * HW + yy * W + px) * 4) : kOOBOff;
+            const unsigned vo = vos[r][a];
             if (masked) {
-              const f32x4 kv = __builtin_bit_cast(
-                  f32x4, __builtin_amdgcn_raw_buffer_load_b128(krsrc, vo, 0, 0));
+              const f32x4 kv = kvs[r][a];
 #pragma unroll
               for (int k = 0; k < 4; ++k) o[k] = kv[k] > 0.0f ? o[k] : 0.0f;
             }
