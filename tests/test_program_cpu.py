@@ -67,6 +67,32 @@ def test_distillation_step_program_structure():
     assert ws == {h.wgrad_ws.data_ptr()}
 
 
+def test_f24_switches_select_the_engine_per_launch(monkeypatch):
+    """SSAD_STUDENT_F24 (bit mask) / SSAD_TEACHER_F24: 0 restores the F(2x2) engine and the round-4 timing classes;
+    the bits move one family each."""
+    def engines(student, teacher):
+        monkeypatch.setenv("SSAD_STUDENT_F24", str(student))
+        monkeypatch.setenv("SSAD_TEACHER_F24", str(teacher))
+        h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu")
+        m = h.prog.marks
+        fwd = [(o.i[4], o.klass) for o in h.prog.ops[m["forward"]:m["losses"]]]
+        bwd = {(o.i[4], o.klass) for o in h.prog.ops[m["backward"]:m["sgd"]] if o.code == PR.CONV3X3}
+        packs = [(o.i[0], o.i[1]) for o in h.prog.ops[m["pack"]:m["forward"]]]
+        return fwd, bwd, packs
+    fwd, bwd, packs = engines(0, 0)
+    assert fwd == [(1, 2)] * 4 + [(1, 3), (1, 3), (1, 4)] and bwd == {(1, 16)} and packs == [(10, 0)]
+    fwd, bwd, packs = engines(0, 1)                  # round 5, first half: the frozen teacher's cls_pred only
+    assert fwd == [(1, 2)] * 4 + [(2, 20), (1, 3), (1, 4)] and bwd == {(1, 16)}
+    fwd, bwd, packs = engines(1, 1)                  # + data gradients
+    assert fwd[:4] == [(1, 2)] * 4 and bwd == {(2, 24)} and packs == [(10, 2), (10, 0)]
+    fwd, bwd, packs = engines(3, 1)                  # + cls_pred forward
+    assert fwd == [(1, 2)] * 4 + [(2, 20), (2, 22), (1, 4)]
+    fwd, bwd, packs = engines(7, 1)                  # + towers (the teacher's join them: one launch per depth)
+    assert fwd == [(2, 23)] * 4 + [(2, 20), (2, 22), (1, 4)]
+    fwd, bwd, packs = engines(0, 2)                  # teacher towers alone: their own launch beside the student's
+    assert [k for _, k in fwd[:8]] == [21, 2] * 4 and [e for e, _ in fwd[:8]] == [2, 1] * 4
+
+
 def test_student_only_program_has_no_teacher_and_no_distillation():
     h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu", distill=False)
     assert h.teacher is None and not hasattr(h, "t_prob")
@@ -146,6 +172,30 @@ def test_fp32_backbone_program_trains_no_body_bias_and_scales_folded_filters():
     # four gradient buckets in the order the backward pass completes them
     assert list(bb.bucket) == ["fpn", "res5", "res4", "res3"]
     assert sum(b.numel() for b in bb.bucket.values()) == bb.grads_flat.numel()
+
+
+def test_backbone_engines_follow_the_f24_switches(monkeypatch):
+    """3x3 layers of >= 128 channels run on the F(2x4) engine (i[4] == 2): trained network forward + data gradient
+    under SSAD_STUDENT_F24 bit 8, frozen network forward under SSAD_TEACHER_F24; the 64-wide res2 layers and the
+    filter gradients keep their engines."""
+    from ssad_amd.backbone_pipeline import NativeResNetFPN
+    def engines(train, env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        bb = NativeResNetFPN("r50", 1, (128, 128), "cpu", train=train)
+        return [(o.i[4], o.klass) for o in bb.prog.ops if o.code == PR.CONV3X3], bb
+    e, bb = engines(True, {"SSAD_STUDENT_F24": "15"})
+    # forward: res2 x3 on F(2x2); res3 x4, res4 x6, res5 x3 and the FPN output launch on F(2x4); backward: their data
+    # gradients (res3.0's block is the last one that sends a gradient down)
+    assert e.count((1, 48)) == 3 and e.count((2, 46)) == (4 + 6 + 3 + 1) * 2, e
+    assert sum(o.code == PR.WINO_PACK_FILTERS and o.i[1] == 2 for o in bb.prog.ops) == 1      # trained packs: per step
+    e, _ = engines(True, {"SSAD_STUDENT_F24": "7"})
+    assert all(x == (1, 48) for x in e) and len(e) == 3 + 14 * 2
+    e, bb = engines(False, {"SSAD_TEACHER_F24": "1"})
+    assert e.count((1, 48)) == 3 and e.count((2, 47)) == 14
+    assert sum(o.code == PR.WINO_PACK_FILTERS and o.i[1] == 2 for o in bb.prep.ops) == 1      # frozen packs: once
+    e, _ = engines(False, {"SSAD_TEACHER_F24": "0"})
+    assert all(x == (1, 48) for x in e)
 
 
 def test_fp16_backbone_program_uses_only_fp16_convolutions_after_the_stem():
