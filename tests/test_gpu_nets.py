@@ -11,7 +11,7 @@ torch = pytest.importorskip("torch")
 import ssad_amd  # noqa: E402,F401
 from oracle import head_step, oracle  # noqa: E402
 from ssad_amd import synth  # noqa: E402
-from ssad_amd.caffe2_hip import dyndep, workspace  # noqa: E402
+from ssad_amd.caffe2_hip import core, dyndep, workspace  # noqa: E402
 from ssad_amd.operator_surface import HeadsNetStep  # noqa: E402
 from test_gpu_kernels import CONV_FLOOR, CONV_RTOL, close  # noqa: E402
 from test_gpu_operators import (SHAPES, assert_typical, close_chain, count_flips, oracle_tower_acts,  # noqa: E402
@@ -94,6 +94,36 @@ def test_lowered_net_vs_operator_by_operator_vs_oracle():
     # filter gradient summed in one launch instead of five + a Sum
     for k in got:
         close_chain(got[k], plain[k], "lowered vs as written: " + k)
+
+
+def test_f24_net_arguments_switch_the_engine_and_the_engines_agree():
+    """`hip_train_f24` / `hip_frozen_f24` = 0 on a NetDef keep the F(2x2) engine (no hip_algo in the lowered list);
+    with the defaults the same nets run on F(2x4).  Both are fp32 Winograd engines: losses agree to 1e-5 relative,
+    teacher probabilities to 2e-5 of their scale, every logit to 1e-5 of the tensor's scale."""
+    cfg, S, T, fs, ft, labs, tg, fg = small_problem()
+    out = {}
+    for tag, off in (("f24", False), ("f22", True)):
+        workspace.ResetWorkspace()
+        step = HeadsNetStep(cfg, N=fs[0].shape[0], shapes=SHAPES, student_init=S, teacher_init=T, update=False)
+        if off:
+            step.teacher.net.Proto().arg.append(core.MakeArgument("hip_frozen_f24", 0))
+            step.student.net.Proto().arg.append(core.MakeArgument("hip_train_f24", 0))
+        step.feed_params()
+        step.feed_inputs(fs, ft, labs, tg, fg)
+        step.create()
+        algos = {a.s for ops in step.lowered().values() for o in ops for a in o.arg if a.name == "hip_algo"}
+        assert algos == (set() if off else {b"winograd24"}) or algos == (set() if off else {"winograd24"}), algos
+        step.step()
+        out[tag] = fetch_all(step)
+    a, b = out["f24"], out["f22"]
+    for l in step.levels:
+        for stem, tol in (("fl_distill_fpn%d", 1e-5), ("fl_fpn%d", 1e-5), ("retnet_loss_bbox_fpn%d", 1e-5)):
+            assert abs(float(a[stem % l]) - float(b[stem % l])) <= tol * abs(float(b[stem % l])) + 1e-12, stem % l
+        for stem, tol in (("teacher/retnet_cls_prob_fpn%d", 2e-5), ("retnet_cls_pred_fpn%d", 1e-5),
+                          ("retnet_bbox_pred_fpn%d", 1e-5)):
+            x, y = np.asarray(a[stem % l], np.float64), np.asarray(b[stem % l], np.float64)
+            assert np.abs(x - y).max() <= tol * np.abs(y).max(), (stem % l, np.abs(x - y).max(), np.abs(y).max())
+        assert not np.array_equal(a["retnet_cls_pred_fpn%d" % l], b["retnet_cls_pred_fpn%d" % l])   # another engine
 
 
 def test_filter_pack_cache_follows_the_blob_version():
