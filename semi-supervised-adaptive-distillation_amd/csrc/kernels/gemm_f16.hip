@@ -52,7 +52,18 @@ using ssad_dev::uniform_rsrc_words;
 
 constexpr int kThreads = 256;
 constexpr int MT = 128;                    // output channels per workgroup
-constexpr int CBC = 4;                     // 8-channel blocks per K chunk (32 channels)
+// (PW_CBC / PW_S256 / PW_S128: compile-time A/B of the K chunk and ring depth, tools/dbg/r5_pw_f16_cbc.sh; 64-channel
+// chunks measured 0.974 against 0.718 ms over config 5's shapes: the LDS they take costs a resident workgroup)
+#ifndef PW_CBC
+#define PW_CBC 4
+#endif
+#ifndef PW_S256
+#define PW_S256 3
+#endif
+#ifndef PW_S128
+#define PW_S128 4
+#endif
+constexpr int CBC = PW_CBC;                // 8-channel blocks per K chunk (32 channels)
 constexpr unsigned kOob = 0x80000000u;     // buffer offset past any descriptor: loads 0, stores dropped
 
 struct PwF16 {
@@ -79,7 +90,7 @@ struct Geo {
   static constexpr int B_SLOTS = CBC * PT;           // pixel-tile slots per stage
   static constexpr int A_SLOTS = CBC * MT;           // filter-tile slots per stage
   static constexpr int STAGE = B_SLOTS + A_SLOTS;    // 16-byte slots
-  static constexpr int S = PT == 256 ? 3 : 4;        // ring depth: 72 KiB / 64 KiB per workgroup
+  static constexpr int S = PT == 256 ? PW_S256 : PW_S128;        // ring depth: 72 KiB / 64 KiB per workgroup
   static constexpr int B_PIECES = B_SLOTS / 64 / 4;  // DMA instructions per wave and chunk
   static constexpr int A_PIECES = A_SLOTS / 64 / 4;
   static constexpr int OPS = B_PIECES + A_PIECES;
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_f16_kernel(const PwF16 p) {
     const uint4* st = lds + slot * G::STAGE;
     slot = slot + 1 == S ? 0 : slot + 1;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < CBC / 2; ++ks) {
       half8 a[2], b[G::NT];
 #pragma unroll
       for (int i = 0; i < 2; ++i) a[i] = as_half8(st[G::B_SLOTS + (2 * ks + h) * MT + wo * 64 + i * 32 + j]);

@@ -1,5 +1,4 @@
 #!/bin/bash
-# (needs the three macros PW_CBC / PW_S256 / PW_S128 in gemm_f16.hip: see the header of this script in git history, commit "pw_f16 CBC experiment"; the kernel source as committed has CBC = 4 fixed)
 # GPU box: the fp16 pointwise GEMM with 64-channel K chunks (PW_CBC=8) at ring depths that fit the LDS (VERDICT r4 item 4's
 # prescription), throw-away rebuilds; isolated shapes of config 5 (tools/pw_f16_probe.py)
 set -u
