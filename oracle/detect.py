@@ -5,10 +5,13 @@ implementation.
 Follows detectron/lib/core/test_retinanet.py:108-206 (per-level score threshold,
 top-k, anchor decode, clipping, per-class NMS, final top-N), utils/boxes.py:132-190
 (clip_tiled_boxes, bbox_transform) and utils/cython_nms.pyx:37-92 (greedy NMS).
-PARITY UNPINNED: restated from the code.  The reference's cython_nms.pyx is
-unbuildable in this image (it uses `np.int_t` / `np.int`, which Cython 3 / numpy 2
-no longer provide) and the reference holds no stored detections.  argpartition /
-argsort tie orders are unspecified in the reference; tests use distinct scores.
+Pinned where the reference can be run: box decoding / clipping by fixtures of the imported utils/boxes.py
+(tests/golden/anchor_labels_ref.npz), greedy NMS by the survivors that cython_nms.pyx:37-92 itself leaves when
+its text is executed as Python after stripping the C type declarations (tests/golden/make_nms_golden.py ->
+nms_ref.npz; the .pyx does not build here: it uses `np.int_t` / `np.int`, which Cython 3 / numpy 2 no longer
+provide).  PARITY UNPINNED for the rest: the per-level threshold / top-k / final top-N composition of
+test_retinanet.py is restated from the code (it needs a Caffe2 workspace; the reference holds no stored
+detections).  argpartition / argsort tie orders are unspecified in the reference; tests use distinct scores.
 """
 import numpy as np
 

@@ -229,6 +229,24 @@ def test_oracle_labelling_reproduces_the_reference_blobs_exactly():
     assert [OA.field_size(2.0 ** (3 + k // 9)) for k in range(45)] == [int(v) for v in z["field_sizes"]]
 
 
+def test_oracle_nms_reproduces_the_reference_nms():
+    """Greedy NMS pinned by the reference's own text: tests/golden/nms_ref.npz holds the survivors that
+    detectron/lib/utils/cython_nms.pyx:37-92 -- executed as Python after its C type declarations were stripped
+    (tests/golden/make_nms_golden.py; the .pyx does not build under Cython 3 / numpy 2) -- leaves of seeded detections:
+    1 ... 400 boxes at three thresholds, duplicates, a box swallowed by a larger one.  Same survivors, same order."""
+    from oracle import detect as OD
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nms_ref.npz"))
+    n = int(z["n_cases"])
+    assert n == 18
+    sizes = set()
+    for k in range(n):
+        dets, thresh, keep = z["dets_%d" % k], float(z["thresh_%d" % k]), z["keep_%d" % k]
+        got = OD.nms(dets, thresh)
+        assert np.array_equal(np.asarray(got, np.int64), keep), (k, thresh)
+        sizes.add((dets.shape[0], keep.size))
+    assert any(a > b for a, b in sizes) and any(a == 400 for a, _ in sizes)       # something was suppressed, at size
+
+
 def test_oracle_box_decoding_reproduces_the_reference():
     """bbox_transform (with the BBOX_XFORM_CLIP clamp) and clip_tiled_boxes of utils/boxes.py:193-260."""
     from oracle import detect as OD
