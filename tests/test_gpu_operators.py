@@ -787,3 +787,53 @@ def test_conv_gradient_batched_engine_respects_its_workspace_budget(golden_dir, 
         close(workspace.FetchBlob("b_grad"), g[name + "_db"], CONV_RTOL, CONV_FLOOR, name + " db")
         ran += 1
     assert ran >= 2, ran
+
+
+def test_full_map_subnets_step_against_the_oracle_composition():
+    """VERDICT r4 (parity, item 2): the composed subnets step at config 3's FULL map sizes (P3 80 x 112 ... P7 5 x 7,
+    one image: the oracle composition takes ~15 s) against the oracle -- not only against itself.  24.4 M tower
+    activations: a handful land on the other side of zero than the oracle's (measured 12 on F(2x4), 9 on F(2x2)), so
+    the per-tensor bound is close_chain's flip bound; what does not depend on masks is held tight: every logit within
+    1e-5 of the map's scale (measured 2e-6), losses 1e-4 relative (1.3e-5), the median gradient tensor 1e-4 (3.6e-5)."""
+    from ssad_amd.head_pipeline import DistillHeads
+    shapes = synth.LEVEL_SHAPES_600
+    rng = np.random.default_rng(77)
+    cfg = rh.HeadConfig(num_gpus=1)
+    S, T = synth.head_params(rng), synth.head_params(rng)
+    for P in (S, T):
+        for k in P:
+            if k.endswith("_w"):
+                P[k] = (P[k] * 3).astype(np.float32)
+    fs, ft = synth.fpn_features(rng, 1, shapes), synth.fpn_features(rng, 1, shapes)
+    labs = []
+    for h, w in shapes:
+        lab = synth.distill_inputs(rng, 1, 9, 80, h, w)[2]
+        u = rng.random(lab.shape)
+        lab[u < 0.02] = rng.integers(1, 81, size=int((u < 0.02).sum()))
+        labs.append(lab)
+    tg = [synth.bbox_targets(rng, l) for l in labs]
+    fg = np.array([float(sum(t[0].shape[0] for t in tg))], np.float32)
+    ref = head_step.head_step(S, T, fs, ft, labs, scale=cfg.loss_scale, bbox_targets=tg, fg_num=fg,
+                              focal_gamma=cfg.focal_gamma, focal_alpha=cfg.focal_alpha, bbox_beta=cfg.bbox_reg_beta)
+    acts = oracle_tower_acts(S, fs)
+    dev = torch.device("cuda", 0)
+    t = lambda arrs: [torch.from_numpy(a).to(dev) for a in arrs]
+    heads = DistillHeads(cfg, N=1, shapes=shapes, device=dev, student_init=S, teacher_init=T)
+    losses = heads.step(t(fs), t(ft), t(labs), update=False, bbox_targets=[tuple(t(p)) for p in tg],
+                        fg_num=torch.from_numpy(fg).to(dev))
+    n_act = sum(a.size for tw in acts.values() for d in tw for a in d)
+    flips = count_flips(lambda tw, d, l: heads.act[tw][d][l].cpu().numpy(), acts)
+    assert n_act == 2 * 4 * 256 * 11935 and flips <= n_act // 100000, flips           # <= 1e-5 of the activations
+    close(losses.cpu().numpy(), ref["losses"], 1e-4, 0, "full-map distill losses")
+    close(heads.focal_losses.cpu().numpy(), ref["focal_losses"], 1e-4, 0, "full-map focal losses")
+    close(heads.bbox_losses.cpu().numpy(), ref["bbox_losses"], 1e-4, 1e-9, "full-map bbox losses")
+    for i in range(len(shapes)):
+        for got, want, what in ((heads.cls_logits[i], ref["cls_logits"][i], "logits"),
+                                (heads.bbox_pred[i], ref["bbox_pred"][i], "bbox pred"),
+                                (heads.t_prob[i], ref["t_prob"][i], "teacher prob")):
+            g, w_ = got.cpu().numpy().astype(np.float64), np.asarray(want, np.float64)
+            assert np.abs(g - w_).max() <= 1e-5 * np.abs(w_).max(), (what, i, np.abs(g - w_).max(), np.abs(w_).max())
+    errs = []
+    for name, g in ref["grads"].items():
+        close_chain(heads.grads[name].cpu().numpy(), g, "full-map grad " + name, errs, flips)
+    assert np.median(errs) <= 1e-4, float(np.median(errs))
