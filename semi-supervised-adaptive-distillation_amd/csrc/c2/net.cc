@@ -30,7 +30,7 @@ int BlobDtype(const Workspace* ws, const string& name) {
 }  // namespace
 
 string LoweringReport::ToString() const {
-  return MakeString("ops ", ops_in, " -> ", ops_out, "; Relu fused ", relu_fused, ", ReluGradient fused ",
+  return MakeString("ops ", ops_in, " -> ", ops_out, "; Relu fused ", relu_fused, ", Sigmoid fused ", sigmoid_fused, ", ReluGradient fused ",
                     relu_grad_fused, "; ConvGroup ", conv_groups, " (", conv_group_members,
                     " Conv); ConvGradientGroup ", conv_grad_groups, " (", conv_grad_group_members,
                     " ConvGradient); Sum absorbed ", sums_absorbed, "; loss groups ", loss_groups, " (",

@@ -46,7 +46,7 @@ struct LoweringOptions {
 
 struct LoweringReport {
   int ops_in = 0, ops_out = 0;
-  int relu_fused = 0, relu_grad_fused = 0;
+  int relu_fused = 0, relu_grad_fused = 0, sigmoid_fused = 0;
   int conv_groups = 0, conv_group_members = 0;
   int conv_grad_groups = 0, conv_grad_group_members = 0;
   int sums_absorbed = 0, loss_groups = 0, loss_group_members = 0;

@@ -70,6 +70,7 @@ class ConvGroupOp final : public Operator<HIPContext> {
       : Operator<HIPContext>(def, ws),
         geom_(ParseConvGeometry(*this)),
         fuse_relu_(GetSingleArgument<int>("fuse_relu", 0)),
+        fuse_sigmoid_(GetSingleArgument<int>("fuse_sigmoid", 0)),
         algo_(GetSingleArgument<string>("hip_algo", "auto")) {
     CAFFE_ENFORCE(IsSubnetGeometry(geom_), "ConvGroup implements kernel 3 / stride 1 / pad 1 / group 1 / NCHW");
     CAFFE_ENFORCE(OutputSize() >= 1 && InputSize() % OutputSize() == 0, "ConvGroup: [X, W, (b)] per output");
@@ -102,7 +103,7 @@ class ConvGroupOp final : public Operator<HIPContext> {
     for (const Problem& p : probs) cache_.Want(*p.w, kind_of(p));
     cache_.Flush(s);
     g_filter_packs_issued += cache_.packs_issued() - before;
-    const int flags = fuse_relu_ ? SSAD_CONV_RELU : 0;
+    const int flags = (fuse_relu_ ? SSAD_CONV_RELU : 0) | (fuse_sigmoid_ ? SSAD_CONV_SIGMOID : 0);
     for (const vector<int>& cls : Classes(probs)) {
       const Problem& p0 = probs[cls[0]];
       const auto kind = kind_of(p0);
@@ -131,6 +132,7 @@ class ConvGroupOp final : public Operator<HIPContext> {
  private:
   ConvGeometry geom_;
   int fuse_relu_;
+  int fuse_sigmoid_;
   string algo_;
   int per_ = 3;
   FilterPackCache cache_;

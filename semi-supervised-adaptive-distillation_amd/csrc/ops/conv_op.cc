@@ -66,6 +66,8 @@ bool ConvOp<float, HIPContext>::RunOnDevice() {
   auto& X = Input(INPUT);
   auto& filter = Input(FILTER);
   auto* Y = Output(0);
+  CAFFE_ENFORCE(!fuse_sigmoid_ || (!X.IsType<float16>() && IsSubnetGeometry(geom_)),
+                "Conv(fuse_sigmoid): only the fp32 3x3 / stride 1 / pad 1 engines carry the Sigmoid epilogue");
   if (X.IsType<float16>()) return RunFloat16();
   CAFFE_ENFORCE_EQ(X.ndim(), 4);
   CAFFE_ENFORCE_EQ(X.ndim(), filter.ndim());
@@ -87,7 +89,7 @@ bool ConvOp<float, HIPContext>::RunOnDevice() {
 
   hipStream_t s = context_.hip_stream();
   ssad_conv_level lv{X.data<float>(), Y->mutable_data<float>(), nullptr, N, H, W, nullptr, nullptr};
-  const int flags = fuse_relu_ ? SSAD_CONV_RELU : 0;
+  const int flags = (fuse_relu_ ? SSAD_CONV_RELU : 0) | (fuse_sigmoid_ ? SSAD_CONV_SIGMOID : 0);
   int rc;
   // the packed filter is rebuilt only when the filter blob was written since (ops/filter_pack_cache.h)
   const bool f24 = algo_ == "winograd24" && M >= 128;      // assigned by the net lowering (net_lowering.cc F24)

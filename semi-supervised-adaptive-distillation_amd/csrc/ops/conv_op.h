@@ -28,6 +28,7 @@
 // Two optional arguments exist for graph-level fusion and are NOT emitted by
 // the reference graph builder (absent = reference behaviour):
 //   Conv          fuse_relu=1             Y = max(conv, 0)  (Conv + in-place Relu)
+//   Conv          fuse_sigmoid=1          Y = 1 / (1 + exp(-conv))  (Conv + Sigmoid; the 3x3 fp32 engines)
 //   ConvGradient  relu_grad_on_input=1    dX masked by X > 0 (= ReluGradient of
 //                                         the in-place Relu that produced X)
 //   both          hip_algo="direct"|"winograd"   pin the algorithm (default: by width)
@@ -152,6 +153,7 @@ class ConvOp final : public Operator<Context> {
       : Operator<Context>(def, ws),
         geom_(ParseConvGeometry(*this)),
         fuse_relu_(OperatorBase::GetSingleArgument<int>("fuse_relu", 0)),
+        fuse_sigmoid_(OperatorBase::GetSingleArgument<int>("fuse_sigmoid", 0)),
         algo_(OperatorBase::GetSingleArgument<string>("hip_algo", "auto")) {
     if (!IsDefaultEngineGeometry(geom_))
       throw UnsupportedOperatorFeature("HIP Conv engines implement order=NCHW, 2-D only");
@@ -163,6 +165,7 @@ class ConvOp final : public Operator<Context> {
   bool RunFloat16();
   ConvGeometry geom_;
   int fuse_relu_;
+  int fuse_sigmoid_;                    // Y = sigmoid(conv) (set by the net lowering: Conv -> Sigmoid; 3x3 fp32 path only)
   string algo_;
   Tensor<Context> packed_filter_;
   FilterPackCache pack_cache_;

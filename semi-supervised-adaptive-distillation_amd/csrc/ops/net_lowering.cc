@@ -8,6 +8,7 @@
 // transform, in the style of caffe2/core/transform.h passes:
 //
 //   F1  Conv -> Relu (in place, only reader)                =>  Conv(fuse_relu = 1)
+//   F1s Conv -> Sigmoid (only reader, logits not kept)      =>  Conv(fuse_sigmoid = 1)
 //   F2  ConvGradient -> ReluGradient on its dX, masked by the convolution's own input
 //                                                            =>  ConvGradient(relu_grad_on_input = 1)
 //   F3  Sum(pieces) where every piece is the filter (bias) gradient of a ConvGradient on ONE
@@ -150,6 +151,25 @@ struct Lowering {
       c.out[0] = r.out[0];                     // the convolution now writes the activated value
       r.removed = true;
       ++rep.relu_fused;
+      Reindex();
+    }
+    // F1s: Conv -> Sigmoid (retinanet_heads.py:153-163: the test-mode graph turns cls_pred into probabilities), the
+    // logits read by nothing else and not asked for: Conv(fuse_sigmoid = 1) writes the probabilities, the logits
+    // blob is not produced (sigmoid_op.cu:25-29 in the convolution's epilogue).  Not combined with fuse_relu.
+    for (size_t j = 0; j < nodes.size(); ++j) {
+      Node& r = nodes[j];
+      if (r.removed || r.def.type != "Sigmoid" || r.in.size() != 1 || r.out.size() != 1) continue;
+      auto pit = producer.find(r.in[0]);
+      if (pit == producer.end()) continue;
+      Node& c = nodes[pit->second];
+      if (c.removed || c.def.type != "Conv" || !IsFusedPathConv(c)) continue;
+      if (FindArg(c.def, "fuse_relu") || FindArg(c.def, "fuse_sigmoid") || !OnlyReader(r.in[0], (int)j)) continue;
+      if (r.in[0].first != r.out[0].first && opt.keep.count(r.in[0].first)) continue;
+      if (!(c.def.device_option.gpu_id == r.def.device_option.gpu_id && OnGpu(r.def))) continue;
+      c.def.arg.push_back(MakeArgument("fuse_sigmoid", 1));
+      c.out[0] = r.out[0];
+      r.removed = true;
+      ++rep.sigmoid_fused;
       Reindex();
     }
     for (size_t j = 0; j < nodes.size(); ++j) {

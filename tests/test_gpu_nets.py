@@ -53,7 +53,7 @@ def test_lowered_net_vs_operator_by_operator_vs_oracle():
     step.feed_inputs(fs, ft, labs, tg, fg)
     step.create()
     low = step.lowered()
-    assert [o.type for o in low["teacher"]].count("ConvGroup") == 5
+    assert [o.type for o in low["teacher"]].count("ConvGroup") == 6 and not any(o.type == "Sigmoid" for o in low["teacher"])
     assert [o.type for o in low["student"]].count("ConvGradientGroup") == 5
     assert len(low["student"]) < (step.forward_ops + step.backward_ops) // 2
 

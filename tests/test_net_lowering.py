@@ -78,17 +78,26 @@ def test_teacher_net_lowers_to_one_launch_per_depth():
     ops, report = workspace.LowerNet(teacher.net)
     hist = collections.Counter(o.type for o in ops)
     # 50 Conv + 40 Relu + 5 Sigmoid -> 4 tower depths (cls and bbox towers, five levels: 10 problems each)
-    # + the two prediction layers in one group operator + 5 Sigmoid
-    assert hist == {"ConvGroup": 5, "Sigmoid": 5}, hist
+    # + the cls prediction layer with the Sigmoid in its epilogue + the bbox prediction layer
+    assert hist == {"ConvGroup": 6}, hist
     for g in [o for o in ops if o.type == "ConvGroup"][:4]:
         assert len(g.output) == 10 and len(g.input) == 30
         assert any(a.name == "fuse_relu" and a.i == 1 for a in g.arg)
         assert any(a.name == "engine" for a in g.arg) or g.engine == "CUDNN"
-    pred = [o for o in ops if o.type == "ConvGroup"][4]
-    assert not any(a.name == "fuse_relu" for a in pred.arg)
-    assert sorted(pred.output) == sorted(["teacher/retnet_%s_pred_fpn%d" % (t, l)
-                                          for t in ("cls", "bbox") for l in range(3, 8)])
-    assert "FELL BACK" not in report and "Relu fused 40" in report
+    preds = [o for o in ops if o.type == "ConvGroup"][4:]
+    assert not any(a.name == "fuse_relu" for p in preds for a in p.arg)
+    cls = [p for p in preds if any(a.name == "fuse_sigmoid" and a.i == 1 for a in p.arg)]
+    box = [p for p in preds if not any(a.name == "fuse_sigmoid" for a in p.arg)]
+    assert len(cls) == 1 and len(box) == 1
+    # the probabilities are what the cls group writes; the logits blob is not produced
+    assert sorted(cls[0].output) == sorted(["teacher/retnet_cls_prob_fpn%d" % l for l in range(3, 8)])
+    assert sorted(box[0].output) == sorted(["teacher/retnet_bbox_pred_fpn%d" % l for l in range(3, 8)])
+    assert "FELL BACK" not in report and "Relu fused 40" in report and "Sigmoid fused 5" in report
+    # ... unless somebody asks for the logits
+    teacher.net.Proto().external_output.append("teacher/retnet_cls_pred_fpn3")
+    ops2, report2 = workspace.LowerNet(teacher.net)
+    assert "Sigmoid fused 4" in report2 and collections.Counter(o.type for o in ops2)["Sigmoid"] == 1, report2
+    teacher.net.Proto().external_output.pop()
 
 
 def test_student_training_net_lowering():
