@@ -67,7 +67,9 @@ C2HIP_CAPI int c2hip_blob_info(c2hip_workspace* ws, const char* name, int* dtype
 /* Copies the tensor to host memory (nbytes must match). */
 C2HIP_CAPI int c2hip_fetch_blob(c2hip_workspace* ws, const char* name, void* host_out,
                                 size_t nbytes);
-/* Device pointer of a HIP tensor blob (NULL + error if absent / CPU). */
+/* Device pointer of a HIP tensor blob (NULL + error if absent / CPU).  The pointer is writable: the call counts
+ * as a write to the blob (derived data cached by operators, e.g. packed filters, is rebuilt on their next run);
+ * writes made LATER through a pointer kept from an earlier call are not seen -- ask again after writing. */
 C2HIP_CAPI void* c2hip_blob_data_ptr(c2hip_workspace* ws, const char* name);
 /* Wrap externally owned device memory (e.g. a torch tensor) as a HIP tensor
  * blob without copying (Tensor::ShareExternalPointer, tensor.h). */

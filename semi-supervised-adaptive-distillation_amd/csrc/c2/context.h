@@ -42,6 +42,7 @@ class CPUContext {
   }
   void SwitchToDevice(int /*stream_id*/ = 0) {}
   bool FinishDeviceComputation() { return true; }
+  int device_key() const { return -1; }
   static void* New(size_t nbytes) {
     void* p = nullptr;
     if (posix_memalign(&p, 64, nbytes ? nbytes : 1) != 0) CAFFE_THROW("host allocation failed");
@@ -64,6 +65,7 @@ class C2HIP_API HIPContext {
   void SwitchToDevice(int stream_id = 0);
   bool FinishDeviceComputation();
   int hip_gpu_id() const { return gpu_id_; }
+  int device_key() const { return gpu_id_; }
   hipStream_t hip_stream() const;
   static void* New(size_t nbytes);
   static void Delete(void* p);

@@ -1,6 +1,10 @@
 // net.cc -- the net object of Workspace::CreateNet / RunNet for HIPContext (see net.h).
 #include "c2/net.h"
 
+#include <set>
+#include <utility>
+#include <vector>
+
 #include <cstdlib>
 
 namespace caffe2 {
@@ -33,8 +37,7 @@ string LoweringReport::ToString() const {
   return MakeString("ops ", ops_in, " -> ", ops_out, "; Relu fused ", relu_fused, ", Sigmoid fused ", sigmoid_fused, ", ReluGradient fused ",
                     relu_grad_fused, "; ConvGroup ", conv_groups, " (", conv_group_members,
                     " Conv); ConvGradientGroup ", conv_grad_groups, " (", conv_grad_group_members,
-                    " ConvGradient); Sum absorbed ", sums_absorbed, "; loss groups ", loss_groups, " (",
-                    loss_group_members, " ops); F(2x4) Conv ", frozen_f24, " evaluated / ", train_f24, " trained",
+                    " ConvGradient); Sum absorbed ", sums_absorbed, "; F(2x4) Conv ", frozen_f24, " evaluated / ", train_f24, " trained",
                     fell_back ? "; FELL BACK to the list as written" : "");
 }
 
@@ -42,7 +45,6 @@ LoweringOptions LoweringOptionsFor(const NetDef& def) {
   LoweringOptions opt;
   opt.fuse_relu = EnvFlag("C2HIP_NET_FUSE_RELU", true);
   opt.group_convs = EnvFlag("C2HIP_NET_GROUP_CONVS", true);
-  opt.group_losses = EnvFlag("C2HIP_NET_GROUP_LOSSES", true);
   const Argument* f24 = FindArg(def, "hip_frozen_f24");
   opt.frozen_f24 = EnvFlag("C2HIP_NET_FROZEN_F24", !(f24 && f24->has_i && f24->i == 0));
   const Argument* t24 = FindArg(def, "hip_train_f24");
@@ -53,7 +55,7 @@ LoweringOptions LoweringOptionsFor(const NetDef& def) {
   return opt;
 }
 
-NetBase::NetBase(const NetDef& def, Workspace* ws) : name_(def.name) {
+NetBase::NetBase(const NetDef& def, Workspace* ws) : name_(def.name), ws_(ws) {
   const Argument* sync = FindArg(def, "hip_sync_every_op");
   sync_every_op_ = EnvFlag("C2HIP_NET_SYNC_EVERY_OP", sync && sync->has_i && sync->i != 0);
   const Argument* low = FindArg(def, "hip_lowering");
@@ -75,21 +77,45 @@ NetBase::NetBase(const NetDef& def, Workspace* ws) : name_(def.name) {
     lowered_ = scoped.op;
     report_.ops_in = report_.ops_out = (int)lowered_.size();
   }
+  {
+    std::set<string> made;
+    for (const OperatorDef& op : lowered_) made.insert(op.output.begin(), op.output.end());
+    produced_.assign(made.begin(), made.end());
+    std::set<string> gone;
+    for (const OperatorDef& op : scoped.op)
+      for (const string& o : op.output)
+        if (!made.count(o)) gone.insert(o);
+    skipped_.assign(gone.begin(), gone.end());
+  }
   operators_.reserve(lowered_.size());
   for (const OperatorDef& op : lowered_) operators_.push_back(CreateOperator(op, ws));
 }
 
 bool NetBase::Run() {
-  OperatorBase* last = nullptr;
+  // the last operator enqueued per device: net_simple.cc / net_dag.cc finish every operator, so a net that spans
+  // devices (or whose caller moved one device's operators to its own stream) must not return with work in flight
+  // on any of them
+  std::vector<std::pair<int, OperatorBase*>> last;
   for (auto& op : operators_) {
     const bool ok = sync_every_op_ ? op->Run() : op->RunAsync();
     if (!ok) return false;
-    if (op->OnDeviceStream()) last = op.get();
+    if (!op->OnDeviceStream()) continue;
+    const int key = op->DeviceKey();
+    bool seen = false;
+    for (auto& kv : last)
+      if (kv.first == key) { kv.second = op.get(); seen = true; }
+    if (!seen) last.emplace_back(key, op.get());
   }
-  // one synchronisation per run: every operator of a process enqueues on the one device stream
+  // one synchronisation per run and device: every operator of a device enqueues on that device's one stream
   // (context.cc: per-(gpu, stream id) pool stream, or the caller's via c2hip_set_stream)
-  if (!sync_every_op_ && last) return last->Finish();
-  return true;
+  bool ok = true;
+  if (!sync_every_op_)
+    for (auto& kv : last) ok = kv.second->Finish() && ok;
+  if (ws_) {
+    ws_->MarkWritten(produced_);
+    ws_->MarkSkipped(skipped_, name_);
+  }
+  return ok;
 }
 
 std::unique_ptr<NetBase> CreateNet(const NetDef& def, Workspace* ws) {

@@ -33,7 +33,6 @@ namespace caffe2 {
 struct LoweringOptions {
   bool fuse_relu = true;        // Conv + Relu, ReluGradient + ConvGradient
   bool group_convs = true;      // ConvGroup / ConvGradientGroup (+ Sum absorption)
-  bool group_losses = true;     // per-level loss operators of one kind -> one multi-level launch
   bool frozen_f24 = true;       // nets without gradient operators: Conv on the F(2x4, 3x3) engine (hip_algo = winograd24)
   bool train_f24 = true;        // trained nets: Conv and ConvGradient's data gradient on it too
   // TensorProto::DataType id of a blob that exists already (parameters do when a net is created:
@@ -49,7 +48,7 @@ struct LoweringReport {
   int relu_fused = 0, relu_grad_fused = 0, sigmoid_fused = 0;
   int conv_groups = 0, conv_group_members = 0;
   int conv_grad_groups = 0, conv_grad_group_members = 0;
-  int sums_absorbed = 0, loss_groups = 0, loss_group_members = 0;
+  int sums_absorbed = 0;
   int frozen_f24 = 0;           // Conv operators of an evaluated-only net sent to the F(2x4, 3x3) engine
   int train_f24 = 0;            // Conv / ConvGradient operators of a trained net sent to it
   bool fell_back = false;       // the lowered list failed its own verification: list kept as written
@@ -57,7 +56,7 @@ struct LoweringReport {
 };
 
 // The options a net asks for: NetDef args hip_frozen_f24 / hip_train_f24 / hip_keep_blobs + external_output, each
-// switch overridable by its environment variable (C2HIP_NET_FUSE_RELU, _GROUP_CONVS, _GROUP_LOSSES, _FROZEN_F24,
+// switch overridable by its environment variable (C2HIP_NET_FUSE_RELU, _GROUP_CONVS, _FROZEN_F24,
 // _TRAIN_F24); blob_dtype is left to the caller.
 C2HIP_API LoweringOptions LoweringOptionsFor(const NetDef& def);
 
@@ -73,9 +72,12 @@ class C2HIP_API NetBase {
   const string& Name() const { return name_; }
   const vector<OperatorDef>& lowered_ops() const { return lowered_; }
   const LoweringReport& report() const { return report_; }
+  const vector<string>& skipped_blobs() const { return skipped_; }
 
  protected:
   string name_;
+  Workspace* ws_ = nullptr;
+  vector<string> produced_, skipped_;     // outputs of the lowered list / outputs of the definition it dropped
   bool sync_every_op_ = false;
   vector<OperatorDef> lowered_;
   LoweringReport report_;

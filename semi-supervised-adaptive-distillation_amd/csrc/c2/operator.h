@@ -63,6 +63,8 @@ class C2HIP_API OperatorBase {
   // enqueue on a device stream, and wait for + check that stream
   virtual bool OnDeviceStream() const { return false; }
   virtual bool Finish() { return true; }
+  // which device's stream that is (-1: none): a net finishes the last operator of EVERY device it touched
+  virtual int DeviceKey() const { return -1; }
 
  protected:
   OperatorDef def_;
@@ -96,6 +98,7 @@ class Operator : public OperatorBase {
   bool RunAsync(int stream_id = 0) final { return RunImpl(stream_id, false); }
   bool OnDeviceStream() const final { return Context::device_type() != CPU; }
   bool Finish() final { return context_.FinishDeviceComputation(); }
+  int DeviceKey() const final { return context_.device_key(); }
   virtual bool RunOnDevice() = 0;
 
  protected:

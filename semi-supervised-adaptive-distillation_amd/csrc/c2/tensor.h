@@ -144,6 +144,8 @@ class Tensor {
   // under (pointer, version, dims).  Memory the tensor does not own can change behind its back
   // (a torch tensor wrapped by c2hip_share_external), so external() tensors are never cached.
   uint64_t version() const { return version_; }
+  // a writer that does not go through mutable_data (the C-ABI hands out the device pointer) announces itself
+  void MarkWritten() { ++version_; }
   bool external() const { return external_; }
   // process-unique identity of this tensor object (a cache keyed on the data pointer alone could
   // mistake a new tensor that landed on a freed address for the old one)

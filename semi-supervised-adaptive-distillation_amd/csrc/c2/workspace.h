@@ -89,7 +89,19 @@ class C2HIP_API Workspace {
     auto it = blobs_.find(name);
     return it == blobs_.end() ? nullptr : it->second.get();
   }
-  bool RemoveBlob(const string& name) { return blobs_.erase(name) != 0; }
+  bool RemoveBlob(const string& name) { stale_.erase(name); return blobs_.erase(name) != 0; }
+  // Blobs a LOWERED net no longer produces (net_lowering.cc fuses them away: logits under fuse_sigmoid, the dX
+  // feeding a fused ReluGradient, the _grad_autosplit pieces).  The reference could fetch any blob of a net;
+  // here a fetch of such a blob must not silently return stale contents: a net marks what its last run skipped,
+  // any later writer (another net, an operator run once, FeedBlob) clears the mark, FetchBlob refuses a marked
+  // blob and names the remedy (NetDef.external_output / hip_keep_blobs).
+  void MarkSkipped(const vector<string>& names, const string& net) { for (const string& n : names) stale_[n] = net; }
+  void MarkWritten(const vector<string>& names) { for (const string& n : names) stale_.erase(n); }
+  void MarkWritten(const string& name) { stale_.erase(name); }
+  const string* SkippedBy(const string& name) const {
+    auto it = stale_.find(name);
+    return it == stale_.end() ? nullptr : &it->second;
+  }
   vector<string> Blobs() const {
     vector<string> names;
     for (const auto& kv : blobs_) names.push_back(kv.first);
@@ -99,6 +111,7 @@ class C2HIP_API Workspace {
  private:
   std::map<string, std::unique_ptr<Blob>> blobs_;
   std::map<string, std::unique_ptr<NetBase>> net_map_;
+  std::map<string, string> stale_;
 };
 
 }  // namespace caffe2

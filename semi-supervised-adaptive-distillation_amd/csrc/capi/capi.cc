@@ -98,6 +98,14 @@ size_t c2hip_blobs(c2hip_workspace* ws, char* buf, size_t buflen) {
   return join_to(ws->ws.Blobs(), buf, buflen);
 }
 
+// FetchBlob / blob info of a blob that a lowered net fused away (workspace.h, MarkSkipped)
+static void ThrowIfSkipped(const Workspace& w, const char* name) {
+  if (const string* net = w.SkippedBy(name))
+    CAFFE_THROW("blob ", name, " was not produced by the last run of net ", *net,
+                ": the lowering fused its producer away.  List it in NetDef.external_output or in the net "
+                "argument hip_keep_blobs (or create the net with hip_lowering = 0) to keep it");
+}
+
 int c2hip_feed_blob(c2hip_workspace* ws, const char* name, const void* host_data,
                     const int64_t* dims, int ndim, int dtype, int device_type, int device_id) {
   return guarded([&] {
@@ -105,6 +113,7 @@ int c2hip_feed_blob(c2hip_workspace* ws, const char* name, const void* host_data
     const TypeMeta meta = TypeMeta::FromId(dtype);
     const vector<TIndex> d(dims, dims + ndim);
     Blob* blob = ws->ws.CreateBlob(name);
+    ws->ws.MarkWritten(name);
     if (device_type == C2HIP_CPU) {
       TensorCPU* t = blob->GetMutable<TensorCPU>();
       t->Resize(d);
@@ -130,6 +139,7 @@ int c2hip_blob_info(c2hip_workspace* ws, const char* name, int* dtype, int* devi
                     int* ndim, int64_t* dims) {
   return guarded([&] {
     const Blob* b = ws->ws.GetBlob(name);
+    ThrowIfSkipped(ws->ws, name);
     CAFFE_ENFORCE(b != nullptr, "Can't find blob: ", name);
     auto fill = [&](const auto& t, int dev) {
       *dtype = (int)t.meta().id;
@@ -147,6 +157,7 @@ int c2hip_blob_info(c2hip_workspace* ws, const char* name, int* dtype, int* devi
 int c2hip_fetch_blob(c2hip_workspace* ws, const char* name, void* host_out, size_t nbytes) {
   return guarded([&] {
     const Blob* b = ws->ws.GetBlob(name);
+    ThrowIfSkipped(ws->ws, name);
     CAFFE_ENFORCE(b != nullptr, "Can't find blob: ", name);
     if (b->IsType<TensorCPU>()) {
       const TensorCPU& t = b->Get<TensorCPU>();
@@ -170,7 +181,11 @@ void* c2hip_blob_data_ptr(c2hip_workspace* ws, const char* name) {
     const Blob* b = ws->ws.GetBlob(name);
     CAFFE_ENFORCE(b != nullptr, "Can't find blob: ", name);
     CAFFE_ENFORCE(b->IsType<TensorHIP>(), "blob ", name, " is not a HIP tensor");
-    p = const_cast<void*>(b->Get<TensorHIP>().raw_data());
+    // the caller gets a WRITABLE device pointer (a torch view may update a filter through it): count it as a
+    // write, so that caches keyed on the tensor's write generation (filter_pack_cache.h) repack
+    TensorHIP& t = const_cast<TensorHIP&>(b->Get<TensorHIP>());
+    t.MarkWritten();
+    p = const_cast<void*>(t.raw_data());
   });
   return p;
 }
@@ -193,6 +208,7 @@ int c2hip_run_operator_once(c2hip_workspace* ws, const void* def_bytes, size_t n
     const OperatorDef def = parse_def(def_bytes, n);
     auto op = CreateOperator(def, &ws->ws);
     CAFFE_ENFORCE(op->Run(), "Error when running operator ", def.type);
+    ws->ws.MarkWritten(def.output);
   });
 }
 

@@ -23,7 +23,13 @@ class FilterPackCache {
   // Queue `filter` ([M][C][3][3], fp32) for layout `kind`; Flush() issues the packs that are stale
   // (one multi-filter launch for the Winograd layouts) on `stream`; Packed() is valid after it.
   void Want(const Tensor<HIPContext>& filter, Kind kind) {
-    Entry& e = entries_[{filter.raw_data(), (int)kind}];
+    const Key key{filter.raw_data(), (int)kind};
+    if (entries_.size() >= kMaxEntries && !entries_.count(key)) {
+      // filters that were reallocated leave entries under their old addresses: drop everything that is not queued
+      // (an operator packs a handful of filters; the next Want() of a live one repacks it once)
+      for (auto it = entries_.begin(); it != entries_.end();) it = it->second.queued ? std::next(it) : entries_.erase(it);
+    }
+    Entry& e = entries_[key];
     const int M = filter.dim32(0), C = filter.dim32(1);
     const bool fresh = e.valid && !filter.external() && e.uid == filter.uid() && e.version == filter.version() &&
                        e.M == M && e.C == C;
@@ -90,6 +96,7 @@ class FilterPackCache {
     int M = 0, C = 0;
     bool valid = false, queued = false;
   };
+  static constexpr size_t kMaxEntries = 256;
   std::map<Key, Entry> entries_;
   vector<Key> queue_;
   long long packs_issued_ = 0;

@@ -204,7 +204,9 @@ struct Lowering {
     bool trained = false;
     for (const Node& n : nodes) {
       const string& t = n.def.type;
-      if (n.def.is_gradient_op || (t.size() > 8 && t.compare(t.size() - 8, 8, "Gradient") == 0) ||
+      // (StopGradient ends in "Gradient" and appears in evaluated-only graphs: it is not a gradient operator)
+      if (n.def.is_gradient_op ||
+          (t != "StopGradient" && t.size() > 8 && t.compare(t.size() - 8, 8, "Gradient") == 0) ||
           t == "MomentumSGDUpdate" || t == "WeightedSum")
         trained = true;
     }

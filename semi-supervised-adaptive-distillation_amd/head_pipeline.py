@@ -110,8 +110,14 @@ class DistillHeads(object):
         # the TRAINED subnets on the F(2x4) engine, a bit mask: 1 = data gradients, 2 = cls_pred forward,
         # 4 = tower forward (with the teacher's towers, one launch)
         self.student_f24 = int(os.environ.get("SSAD_STUDENT_F24", "15")) & 7 if (self.wino and not self.F16) else 0
-        if self.student_f24 & 4 and self.teacher_f24:
-            self.teacher_f24 = 2
+        # The towers of one depth (teacher + student) are ONE launch on ONE engine, and a filter is packed in the
+        # layout of the engine that reads it: decide once.  Bit 4 takes the teacher's towers along; with the teacher
+        # pinned to F(2x2) (SSAD_TEACHER_F24=0) a distillation step keeps the shared launch there and bit 4 is void.
+        if self.student_f24 & 4:
+            if self.teacher_f24:
+                self.teacher_f24 = 2
+            elif self.distill:
+                self.student_f24 &= ~4
         self.momentum, self.weight_decay = momentum, weight_decay
         self.pg, self.world_size = process_group, world_size
         self.dp = BucketedAllReduce(process_group, world_size)

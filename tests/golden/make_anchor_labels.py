@@ -4,8 +4,8 @@
 _get_retinanet_blobs), roi_data/data_utils.py:50-103, modeling/generate_anchors.py and, for the
 decode arithmetic, utils/boxes.py (bbox_transform, clip_tiled_boxes) -- imported from
 /root/reference under python 3 with the sys.modules stubs of make_head_graph.py, the reference's
-IoU routine compiled from its own cython_bbox.pyx (oracle/_ref/cython_bbox.so, `make -C oracle
-ref`), cfg fields set by assignment.  utils/cython_nms.pyx cannot be built here (numpy 2's
+IoU routine compiled from its own cython_bbox.pyx (oracle/_pyref/cython_bbox.so, `make -C oracle
+pyref`; build container only, never shipped), cfg fields set by assignment.  utils/cython_nms.pyx cannot be built here (numpy 2's
 Cython declarations have no `int_t`), so greedy NMS stays unpinned; nothing in this fixture goes
 through it.
 
@@ -34,8 +34,8 @@ def install():
     import make_head_graph as mh
     mh.install_stubs()
     sys.path.insert(0, REF)
-    # the reference's compiled IoU (cython_bbox.pyx -> oracle/_ref/cython_bbox.so)
-    so = os.path.join(ROOT, "oracle", "_ref", "cython_bbox.so")
+    # the reference's compiled IoU (cython_bbox.pyx -> oracle/_pyref/cython_bbox.so)
+    so = os.path.join(ROOT, "oracle", "_pyref", "cython_bbox.so")
     spec = importlib.util.spec_from_file_location("utils.cython_bbox", so)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

@@ -8,7 +8,7 @@ import pytest
 from oracle import anchors as OA
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-REF_SO = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "cython_bbox.so")
+REF_SO = os.path.join(os.path.dirname(HERE), "oracle", "_pyref", "cython_bbox.so")
 
 
 def rand_gts(rng, n, H=640, W=896, integer=False):
@@ -41,8 +41,8 @@ def test_cell_anchors_known_answers_and_product_module():
     assert anchors.shape == (9 * (128 ** 2 + 64 ** 2 + 32 ** 2 + 16 ** 2 + 8 ** 2), 4)
 
 
-@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/cython_bbox.so not built "
-                    "(make -C oracle ref, needs /root/reference)")
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_pyref/cython_bbox.so not built "
+                    "(make -C oracle pyref, needs /root/reference)")
 def test_oracle_iou_bit_exact_vs_compiled_reference():
     spec = importlib.util.spec_from_file_location("cython_bbox", REF_SO)
     ref = importlib.util.module_from_spec(spec)

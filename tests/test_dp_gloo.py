@@ -205,3 +205,97 @@ def test_two_rank_backbone_buckets_cover_every_gradient_exactly_once():
     assert not np.array_equal(r[0]["local"], r[1]["local"])
     for k in range(world):
         assert np.array_equal(r[k]["reduced"], total)               # every element reduced once, bit for bit
+
+
+# ---------------------------------------------------------------------------
+# world 8 (the size SCALE_rNN is measured at), without hardware: the subnets' flat buckets at their REAL
+# size (6.46 M parameters, HeadConfig defaults) and the R-50-FPN backbone's four buckets, 8 gloo ranks
+# ---------------------------------------------------------------------------
+
+def _world8_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssad_amd.backbone_pipeline import NativeResNetFPN
+    from ssad_amd.head_pipeline import FlatParams
+    cfg = HeadConfig(num_gpus=world)
+    params, grads, moms = (FlatParams(cfg, "cpu") for _ in range(3))
+    torch.manual_seed(500 + rank)                     # every rank starts somewhere else
+    params.flat.copy_(torch.randn(params.flat.shape))
+    bb = NativeResNetFPN("r50", 1, (128, 128), "cpu", train=True, lr=0.01, process_group=dist.group.WORLD,
+                         world_size=world)
+    bb.params_flat.add_(float(rank))
+    dp = BucketedAllReduce(dist.group.WORLD, world)
+    dp.broadcast([params.flat, moms.flat], src=0)
+    bb.broadcast_params()
+    gr = torch.Generator().manual_seed(900 + rank)
+    grads.flat.copy_(torch.randn(grads.flat.shape, generator=gr))
+    bb.grads_flat.copy_(torch.randn(bb.grads_flat.shape, generator=gr))
+    # the step's order: the subnets' "late" bucket, then "early", then the backbone's four as backward reaches them
+    for name in ("late", "early"):
+        dp.issue(grads.bucket[name])
+    for n in bb.bucket:
+        bb.dp.issue(bb.bucket[n])
+    dp.wait()
+    bb.dp.wait()
+    # identical SGD on every rank (subnets: the oracle's update of optimizer.py:95-130)
+    for name, _, is_bias, _ in params.specs[:4]:
+        w, g, m = oracle.sgd_update(params[name].numpy(), grads[name].numpy(), moms[name].numpy(),
+                                    0.01 / world, 0.9, 1e-4, is_bias)
+        params[name].copy_(torch.from_numpy(w))
+    import hashlib
+    h = lambda t: hashlib.sha256(t.numpy().tobytes()).hexdigest()
+    lo, hi = shard_images(16 * world, rank, world)
+    with open(os.path.join(outdir, "w8_%d.txt" % rank), "w") as f:
+        f.write("\n".join([h(grads.flat), h(bb.grads_flat), h(params.flat), h(bb.params_flat), h(moms.flat),
+                           "%d %d" % (lo, hi), "%d %d" % (grads.flat.numel(), bb.grads_flat.numel()),
+                           repr(float(grads.flat[:1000].double().sum())), repr(sorted(grads.bucket)),
+                           repr(list(bb.bucket))]))
+    if rank == 0:
+        np.save(os.path.join(outdir, "w8_head.npy"), grads.flat[:4096].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_exchange_of_the_real_bucket_sizes():
+    """no 8-GPU node was ever available, so the world-8 exchange is exercised here -- 8 gloo
+    ranks (this box has 8 cores), the subnets' buckets at full size (25.9 MB) + the R-50-FPN backbone's four:
+    reduced buckets, broadcast parameters and the updated parameters bitwise identical on ALL ranks
+    (nccl_ops_test.py:77-79), the reduced values = the sum of the eight rank-local gradients, and shard_images tiling a
+    128-image global batch."""
+    world = 8
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_world8_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        r = [open(os.path.join(d, "w8_%d.txt" % i)).read().split("\n") for i in range(world)]
+        head = np.load(os.path.join(d, "w8_head.npy"))
+    for i in range(1, world):
+        for k in (0, 1, 2, 3, 4, 6, 7, 8, 9):
+            assert r[i][k] == r[0][k], (i, k)
+    assert r[0][6].split()[0] == "6463220"                       # SURVEY 8(a12): head parameters
+    assert r[0][8] == "['early', 'late']" and r[0][9] == "['fpn', 'res5', 'res4', 'res3']"
+    # the shards tile the global batch in rank order
+    spans = [tuple(int(v) for v in r[i][5].split()) for i in range(world)]
+    assert spans == [(16 * i, 16 * i + 16) for i in range(world)]
+    # the reduced gradient = sum over ranks of the rank-local gradients (8 fp32 addends: order-dependent in the last
+    # bit, so a tolerance here -- and bit equality ACROSS ranks above)
+    want = np.zeros(4096, np.float64)
+    for i in range(world):
+        g = torch.Generator().manual_seed(900 + i)
+        want += torch.randn(6463220, generator=g)[:4096].double().numpy()
+    assert np.allclose(head, want, rtol=0, atol=1e-5)
+
+
+def test_bench_launcher_refuses_a_short_node():
+    """`python bench.py --gpus 8` on a box with fewer GPUs must refuse (exit 2) BEFORE starting any rank: the launcher
+    path of bench.py up to its device check (a SCALE run can never silently shrink)."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        pytest.skip("this node has 8 GPUs: the refusal cannot be exercised")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2, (p.returncode, p.stderr[-400:])
+    assert "--gpus 8 asked for" in p.stderr and "refusing" in p.stderr
+    assert p.stdout.strip() == ""                                # no JSON line from a refused run

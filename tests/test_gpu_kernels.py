@@ -809,7 +809,21 @@ def test_wino_split_tail_vs_unsplit_vs_oracle(K, case):
 # Round 5: Winograd F(2x4, 3x3), the forward engine of frozen (evaluated-only) networks
 # ---------------------------------------------------------------------------
 
-F24_RTOL, F24_FLOOR = 1e-4, 2e-5      # the direct kernel's bar; the floor covers F(4,3)'s ~2e-6-of-scale round-off
+F24_RTOL, F24_FLOOR = 1e-4, 1e-5      # the direct kernel's bar, unwidened (round 5 ran this engine at a 2e-5 floor)
+F24_REL_OVER = 1e-2                   # north_star's "1e-4 rel": asserted on every element >= 1e-2 of the tensor's scale
+
+
+def rel_err_over(got, ref, frac=F24_REL_OVER):
+    """max |got - ref| / |ref| over the elements with |ref| >= frac * max|ref| (and how many there are)"""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    big = np.abs(ref) >= frac * np.abs(ref).max()
+    return float((np.abs(got - ref)[big] / np.abs(ref)[big]).max()), int(big.sum())
+
+
+def close24(got, ref, what):
+    close(got, ref, F24_RTOL, F24_FLOOR, what)
+    rel, n = rel_err_over(got, ref)
+    assert rel <= 1e-4, "%s: max relative error %.3e over the %d elements >= %g of the scale" % (what, rel, n, F24_REL_OVER)
 
 
 @pytest.mark.parametrize("shape", [
@@ -825,14 +839,11 @@ def test_winograd24_vs_oracle(K, shape):
     b = rng.standard_normal(M).astype(np.float32)
     pf = K.conv_wino24_pack_filter(dev(Wt))
     ref = oracle.conv_forward(X, Wt, b)
-    close(K.conv3x3_forward_wino24([dev(X)], pf, dev(b), M)[0].cpu().numpy(), ref, F24_RTOL, F24_FLOOR, "wino24 Y")
-    close(K.conv3x3_forward_wino24([dev(X)], pf, dev(b), M, relu=True)[0].cpu().numpy(), oracle.relu(ref), F24_RTOL,
-          F24_FLOOR, "wino24 relu")
+    close24(K.conv3x3_forward_wino24([dev(X)], pf, dev(b), M)[0].cpu().numpy(), ref, "wino24 Y")
+    close24(K.conv3x3_forward_wino24([dev(X)], pf, dev(b), M, relu=True)[0].cpu().numpy(), oracle.relu(ref), "wino24 relu")
     sig = 1.0 / (1.0 + np.exp(-ref.astype(np.float64)))
-    close(K.conv3x3_forward_wino24([dev(X)], pf, dev(b), M, sigmoid=True)[0].cpu().numpy(), sig, F24_RTOL, F24_FLOOR,
-          "wino24 sigmoid")
-    close(K.conv3x3_forward_wino24([dev(X)], pf, None, M)[0].cpu().numpy(), oracle.conv_forward(X, Wt, None), F24_RTOL,
-          F24_FLOOR, "wino24 no bias")
+    close24(K.conv3x3_forward_wino24([dev(X)], pf, dev(b), M, sigmoid=True)[0].cpu().numpy(), sig, "wino24 sigmoid")
+    close24(K.conv3x3_forward_wino24([dev(X)], pf, None, M)[0].cpu().numpy(), oracle.conv_forward(X, Wt, None), "wino24 no bias")
 
 
 def test_winograd24_levels_full_size_vs_winograd22_and_oracle(K):
@@ -855,7 +866,7 @@ def test_winograd24_levels_full_size_vs_winograd22_and_oracle(K):
     assert all(torch.equal(a, c) for a, c in zip(Y24, again))
     n0 = 7
     ref = oracle.relu(oracle.conv_forward(Xs[0][n0:n0 + 1].cpu().numpy(), Wt.cpu().numpy(), b.cpu().numpy()))
-    close(Y24[0][n0:n0 + 1].cpu().numpy(), ref, F24_RTOL, F24_FLOOR, "wino24 P3 slice")
+    close24(Y24[0][n0:n0 + 1].cpu().numpy(), ref, "wino24 P3 slice")
 
 
 @pytest.mark.parametrize("shape", [
@@ -872,9 +883,9 @@ def test_winograd24_data_gradient_vs_oracle(K, shape):
     _, pd = K.conv_wino24_pack_filter(dev(Wt), want_dgrad=True)
     dX = oracle.conv_backward(X, Wt, dY, want_db=False)[2]
     got = K.conv3x3_forward_wino24([dev(dY)], pd, None, Cin)[0].cpu().numpy()
-    close(got, dX, F24_RTOL, F24_FLOOR, "wino24 dX")
+    close24(got, dX, "wino24 dX")
     got = K.conv3x3_forward_wino24([dev(dY)], pd, None, Cin, mask_by=[dev(X)])[0].cpu().numpy()
-    close(got, np.where(X > 0, dX, 0), F24_RTOL, F24_FLOOR, "wino24 masked dX")
+    close24(got, np.where(X > 0, dX, 0), "wino24 masked dX")
 
 
 def test_winograd24_data_gradient_full_size_vs_winograd22(K):

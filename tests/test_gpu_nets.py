@@ -207,6 +207,18 @@ def test_net_errors_surface_like_the_reference():
     assert sorted(workspace.Nets()) == ["student", "teacher"]
     # a shape error inside a group names the operator
     workspace.RunNet(step.teacher.net)
+    # a blob the lowering fused away (the teacher's logits under Conv -> Sigmoid) is refused by name, with the remedy,
+    # instead of returning stale or missing contents; the list as written produces it again
+    lvl = step.levels[0]
+    with pytest.raises(_capi.C2Error, match="hip_keep_blobs"):
+        workspace.FetchBlob("teacher/retnet_cls_pred_fpn%d" % lvl)
+    prob = workspace.FetchBlob("teacher/retnet_cls_prob_fpn%d" % lvl)
+    workspace.RunNet(step.teacher.net, sync_every_op=True)
+    logits = workspace.FetchBlob("teacher/retnet_cls_pred_fpn%d" % lvl)
+    assert np.allclose(1.0 / (1.0 + np.exp(-logits.astype(np.float64))), prob, rtol=1e-4, atol=1e-7)
+    workspace.RunNet(step.teacher.net)                    # lowered again: skipped again
+    with pytest.raises(_capi.C2Error, match="fused its producer away"):
+        workspace.FetchBlob("teacher/retnet_cls_pred_fpn%d" % lvl)
     workspace.FeedBlob("fpn_5", fs[2][:, :100], device_option=step.dev)
     with pytest.raises(_capi.C2Error, match="input channels does not match"):
         workspace.RunNet(step.student.net)

@@ -91,6 +91,27 @@ def test_f24_switches_select_the_engine_per_launch(monkeypatch):
     assert fwd == [(2, 23)] * 4 + [(2, 20), (2, 22), (1, 4)]
     fwd, bwd, packs = engines(0, 2)                  # teacher towers alone: their own launch beside the student's
     assert [k for _, k in fwd[:8]] == [21, 2] * 4 and [e for e, _ in fwd[:8]] == [2, 1] * 4
+    # the teacher pinned to F(2x2): the shared tower launch stays there, and the student's tower filters must be
+    # packed for THAT engine (round-5 advisor finding: they were packed for F(2x4) and read by F(2x2))
+    L = K.lib()
+    for student in (7, 15):
+        monkeypatch.setenv("SSAD_STUDENT_F24", str(student))
+        monkeypatch.setenv("SSAD_TEACHER_F24", "0")
+        h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu")
+        m = h.prog.marks
+        fwd = [(o.i[4], o.klass) for o in h.prog.ops[m["forward"]:m["losses"]]]
+        assert fwd == [(1, 2)] * 4 + [(1, 3), (2, 22), (1, 4)]
+        for t in ("cls", "bbox"):
+            for name in h._layers(t)[:-1]:
+                assert h.packed[name][0].numel() == L.ssad_conv_wino_filter_floats(256, 256), name
+                assert h.packed[name][1].numel() == L.ssad_conv_wino24_filter_floats(256, 256), name   # dgrad: bit 1
+        assert h.packed[h._layers("cls")[-1]][0].numel() == L.ssad_conv_wino24_filter_floats(720, 256)
+    # without a teacher the student's towers are alone in their launch and follow bit 4
+    monkeypatch.setenv("SSAD_STUDENT_F24", "7")
+    h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu", distill=False)
+    m = h.prog.marks
+    assert [(o.i[4], o.klass) for o in h.prog.ops[m["forward"]:m["losses"]]][:4] == [(2, 23)] * 4
+    assert h.packed[h._layers("cls")[0]][0].numel() == L.ssad_conv_wino24_filter_floats(256, 256)
 
 
 def test_student_only_program_has_no_teacher_and_no_distillation():
