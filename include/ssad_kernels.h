@@ -362,6 +362,30 @@ SSAD_API int ssad_conv3x3_forward_wino24(
     const ssad_conv_level* levels_host, int n_levels, const float* packed,
     const float* bias, int Cout, int Cin, int flags, ssad_stream_t stream);
 
+/* fp32 convolution on the 2.5 PFLOP/s fp16 matrix pipes by operand splitting (round 6, conv3x3_split.hip).
+ * gfx950's fp32 MFMA runs at 1/16 of the fp16 rate and there is no xf32 mode (MI355X_MICROARCH.md).  Each fp32
+ * operand is written as  x * s = hi + lo  with hi = fp16(x s), lo = fp16(x s - hi): 22 significant bits, s = a power
+ * of two per tensor chosen from the tensor's measured |max| so that hi never overflows; the direct-form product is
+ * three v_mfma_f32_32x32x16_f16 per operand pair (hi hi + lo hi + hi lo, the 2^-22 lo lo term dropped) accumulated
+ * in fp32, and the exact power-of-two scales are divided out in the epilogue.  Same operator contract as
+ * ssad_conv3x3_forward_wino24 (conv_op_cudnn.cc:567-617 / :1040-1058: NCHW fp32 in and out, bias, SSAD_CONV_RELU,
+ * SSAD_CONV_SIGMOID, SSAD_CONV_MASK_AUX with the data-gradient pack); error against a float64 convolution
+ * ~3e-7 of the output scale (Winograd F(2x4) fp32: ~2e-6).  Elements below 2^-29 of a tensor's |max| keep fewer
+ * than 22 bits (absolute error <= 2^-40 |max|); a tensor holding Inf / NaN is passed through unscaled.
+ *   workspace: the split, channel-blocked copy of every level's input + one |max| word per level
+ *   (ssad_conv3x3_split_workspace_bytes); the call = |max| pass + split pass + convolution, on `stream`.
+ *   amax_in  (device, n_levels words, or NULL): the inputs' |max| as float bit patterns, when a producer already
+ *            measured them -- the |max| pass is skipped;
+ *   amax_out (device, n_levels words the caller has zeroed, or NULL): the kernel folds the |max| of each level's
+ *            OUTPUT into word l (atomicMax), ready to be the next layer's amax_in. */
+SSAD_API size_t ssad_conv_split_filter_floats(int M, int K);
+SSAD_API int ssad_conv_split_pack_filters(const ssad_pack_entry* entries_host, int n_entries, ssad_stream_t stream);
+SSAD_API size_t ssad_conv3x3_split_workspace_bytes(const ssad_conv_level* levels_host, int n_levels, int Cin);
+SSAD_API int ssad_conv3x3_forward_split(
+    const ssad_conv_level* levels_host, int n_levels, const float* packed,
+    const float* bias, int Cout, int Cin, int flags, void* workspace, size_t workspace_bytes,
+    const unsigned* amax_in, unsigned* amax_out, ssad_stream_t stream);
+
 SSAD_API size_t ssad_conv3x3_wgrad_workspace_bytes(
     const ssad_conv_level* levels_host, int n_levels, int Cout, int Cin);
 

@@ -184,6 +184,12 @@ def lib():
     L.ssad_conv_wino24_filter_floats.restype = sz
     L.ssad_conv_wino24_filter_floats.argtypes = [i32, i32]
     L.ssad_conv_wino24_pack_filters.argtypes = [C.POINTER(PackEntry), i32, vp]
+    L.ssad_conv_split_filter_floats.restype = sz
+    L.ssad_conv_split_filter_floats.argtypes = [i32, i32]
+    L.ssad_conv_split_pack_filters.argtypes = [C.POINTER(PackEntry), i32, vp]
+    L.ssad_conv3x3_split_workspace_bytes.restype = sz
+    L.ssad_conv3x3_split_workspace_bytes.argtypes = [C.POINTER(ConvLevel), i32, i32]
+    L.ssad_conv3x3_forward_split.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp, sz, vp, vp, vp]
     L.ssad_conv3x3_forward_wino_launches.argtypes = [C.POINTER(ConvLevel), i32]
     L.ssad_conv3x3_forward_wino_launches_for.argtypes = [C.POINTER(ConvLevel), i32, i32, i32, i32]
     L.ssad_conv_wino_split_tail.argtypes = [i32]
@@ -652,6 +658,43 @@ def conv_wino24_pack_filter(w, want_dgrad=False):
     tab = (PackEntry * 1)(PackEntry(w.data_ptr(), Cout, Cin, pf.data_ptr(), pd.data_ptr() if want_dgrad else 0))
     _check(L.ssad_conv_wino24_pack_filters(tab, 1, _stream()), "conv_wino24_pack_filters")
     return (pf, pd) if want_dgrad else pf
+
+
+def conv_split_pack_filter(w, want_dgrad=False):
+    """Split-operand (3 x fp16 MFMA) filter pack: header with the filter's |max| + hi / lo fp16 planes; want_dgrad:
+    -> (forward, data-gradient) packs (conv3x3_split.hip)."""
+    L = lib()
+    _f32c(w, "filter")
+    Cout, Cin, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise KernelError("only 3x3 filters")
+    pf = torch.empty(L.ssad_conv_split_filter_floats(Cout, Cin), dtype=torch.float32, device="cuda")
+    pd = torch.empty(L.ssad_conv_split_filter_floats(Cin, Cout), dtype=torch.float32,
+                     device="cuda") if want_dgrad else None
+    tab = (PackEntry * 1)(PackEntry(w.data_ptr(), Cout, Cin, pf.data_ptr(), pd.data_ptr() if want_dgrad else 0))
+    _check(L.ssad_conv_split_pack_filters(tab, 1, _stream()), "conv_split_pack_filters")
+    return (pf, pd) if want_dgrad else pf
+
+
+def conv3x3_forward_split(xs, packed, bias, Cout, *, relu=False, sigmoid=False, out=None, mask_by=None, workspace=None,
+                          amax_in=None, amax_out=None):
+    """conv3x3_forward on the split-operand engine (fp32 operands as hi + lo fp16, three fp16 MFMAs per pair, fp32
+    accumulation; xs: levels sharing the filter).  mask_by: the data-gradient form, as conv3x3_forward_wino24."""
+    L = lib()
+    for x in xs:
+        _f32c(x, "conv input")
+    Cin = xs[0].shape[1]
+    ys = out if out is not None else [
+        torch.empty((x.shape[0], Cout, x.shape[2], x.shape[3]), dtype=torch.float32, device="cuda") for x in xs]
+    flags = (CONV_RELU if relu else 0) | (CONV_SIGMOID if sigmoid else 0) | (CONV_MASK_AUX if mask_by is not None else 0)
+    arr = _conv_levels(xs, ys, mask_by)
+    need = L.ssad_conv3x3_split_workspace_bytes(arr, len(xs), Cin)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
+    _check(L.ssad_conv3x3_forward_split(arr, len(xs), _ptr(packed), _ptr(bias), Cout, Cin, flags, _ptr(workspace),
+                                        workspace.numel(), _ptr(amax_in), _ptr(amax_out), _stream()),
+           "conv3x3_forward_split")
+    return ys
 
 
 def conv3x3_forward_wino24(xs, packed, bias, Cout, *, relu=False, sigmoid=False, out=None, mask_by=None):

@@ -906,3 +906,123 @@ def test_winograd24_data_gradient_full_size_vs_winograd22(K):
         assert torch.equal(a == 0, (m <= 0) | (a == 0))
     again = K.conv3x3_forward_wino24(dYs, d24, None, C, mask_by=Ms)
     assert all(torch.equal(a, c) for a, c in zip(A, again))
+
+
+# ---------------------------------------------------------------------------
+# Round 6: the split-operand engine (fp32 operands as hi + lo fp16, three fp16 MFMAs per pair: conv3x3_split.hip)
+# held to the DIRECT fp32 kernel's bar (CONV_FLOOR, unwidened) plus the relative-error assertion
+# ---------------------------------------------------------------------------
+
+def close_split(got, ref, what):
+    close(got, ref, CONV_RTOL, CONV_FLOOR, what)
+    rel, n = rel_err_over(got, ref)
+    assert rel <= 1e-4, "%s: max relative error %.3e over the %d elements >= %g of the scale" % (what, rel, n, F24_REL_OVER)
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 16, 128, 8, 16), (2, 36, 256, 5, 7), (1, 256, 256, 10, 14), (1, 24, 130, 17, 33), (3, 40, 129, 2, 31),
+    (2, 256, 720, 3, 4), (2, 128, 128, 9, 12), (1, 8, 36, 20, 28), (2, 3, 5, 6, 6)], ids=lambda s: "N%d_C%d_M%d_%dx%d" % s)
+def test_split_engine_vs_oracle(K, shape):
+    """conv3x3_split.hip against the oracle (conv_op_impl.h:31-202): bias, ReLU, Sigmoid epilogues, channel tails
+    (Cin not a multiple of 8 / 16, Cout not a multiple of 32 / 128), ragged maps."""
+    N, Cin, M, H, W = shape
+    rng = np.random.default_rng(2600 + sum(shape))
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, 3, 3)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    pf = K.conv_split_pack_filter(dev(Wt))
+    ref = oracle.conv_forward(X, Wt, b)
+    close_split(K.conv3x3_forward_split([dev(X)], pf, dev(b), M)[0].cpu().numpy(), ref, "split Y")
+    close_split(K.conv3x3_forward_split([dev(X)], pf, dev(b), M, relu=True)[0].cpu().numpy(), oracle.relu(ref), "split relu")
+    sig = 1.0 / (1.0 + np.exp(-ref.astype(np.float64)))
+    close_split(K.conv3x3_forward_split([dev(X)], pf, dev(b), M, sigmoid=True)[0].cpu().numpy(), sig, "split sigmoid")
+    close_split(K.conv3x3_forward_split([dev(X)], pf, None, M)[0].cpu().numpy(), oracle.conv_forward(X, Wt, None), "split no bias")
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 128, 128, 8, 16), (2, 256, 36, 5, 7), (1, 256, 256, 10, 14), (1, 130, 24, 17, 33), (2, 256, 720, 3, 4),
+    (3, 129, 40, 2, 31)], ids=lambda s: "N%d_C%d_M%d_%dx%d" % s)
+def test_split_engine_data_gradient_vs_oracle(K, shape):
+    """The data-gradient form (flipped + transposed pack, fused ReluGradient mask): dX of conv_op_impl.h:358-577."""
+    N, Cin, M, H, W = shape
+    rng = np.random.default_rng(2650 + sum(shape))
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, 3, 3)) * 0.05).astype(np.float32)
+    dY = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    _, pd = K.conv_split_pack_filter(dev(Wt), want_dgrad=True)
+    dX = oracle.conv_backward(X, Wt, dY, want_db=False)[2]
+    close_split(K.conv3x3_forward_split([dev(dY)], pd, None, Cin)[0].cpu().numpy(), dX, "split dX")
+    got = K.conv3x3_forward_split([dev(dY)], pd, None, Cin, mask_by=[dev(X)])[0].cpu().numpy()
+    close_split(got, np.where(X > 0, dX, 0), "split masked dX")
+
+
+@pytest.mark.parametrize("xs,ws", [(1e-30, 1.0), (1e30, 1e-3), (1.0, 1e-25), (3e-39, 1.0), (1e18, 1e18), (65504.0, 65504.0)],
+                         ids=lambda v: "%g" % v)
+def test_split_engine_extreme_magnitudes(K, xs, ws):
+    """Per-tensor power-of-two scales: tiny / huge / denormal-range operands keep the fp32 bar (the fp16 halves never
+    see the tensors' magnitudes).  Reference in float64 (the products leave fp32's range in one case)."""
+    rng = np.random.default_rng(77)
+    N, Cin, M, H, W = 1, 32, 64, 9, 11
+    X = (rng.standard_normal((N, Cin, H, W)) * xs).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, 3, 3)) * ws).astype(np.float32)
+    ref = oracle.conv_forward(X.astype(np.float64), Wt.astype(np.float64), None)
+    got = K.conv3x3_forward_split([dev(X)], K.conv_split_pack_filter(dev(Wt)), None, M)[0].cpu().numpy()
+    assert np.all(np.isfinite(got))
+    if float(np.abs(ref).max()) < 1e-37:            # the result itself is in fp32's denormal range: absolute bar
+        assert np.abs(got - ref).max() <= 2e-45 + 1e-5 * np.abs(ref).max()
+    else:
+        close_split(got, ref, "split extreme %g x %g" % (xs, ws))
+
+
+def test_split_engine_wide_dynamic_range_within_a_tensor(K):
+    """What is NOT fp32-like, pinned: elements far below the tensor's |max| lose bits gracefully -- absolute error
+    <= 2^-40 of |max| per operand, i.e. the output error stays under 1e-5 of the output scale; and a tensor with an
+    Inf passes through unscaled (Inf / NaN where fp32 has them)."""
+    rng = np.random.default_rng(78)
+    N, Cin, M, H, W = 1, 16, 32, 8, 8
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    X[0, :, :4] *= 1e-7                                  # half the map 2^-23 below the other half
+    Wt = (rng.standard_normal((M, Cin, 3, 3)) * 0.1).astype(np.float32)
+    ref = oracle.conv_forward(X.astype(np.float64), Wt.astype(np.float64), None)
+    pf = K.conv_split_pack_filter(dev(Wt))
+    got = K.conv3x3_forward_split([dev(X)], pf, None, M)[0].cpu().numpy()
+    close(got, ref, CONV_RTOL, CONV_FLOOR, "wide range, whole tensor")
+    small = np.abs(got[0, :, :2] - ref[0, :, :2]).max() / np.abs(ref[0, :, :2]).max()
+    assert small <= 1e-4, small                          # rows that see only the small half: still 1e-4 of THEIR scale
+    X[0, 3, 5, 5] = np.inf
+    got = K.conv3x3_forward_split([dev(X)], pf, None, M)[0].cpu().numpy()
+    want = oracle.conv_forward(X, Wt, None)
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+
+
+def test_split_engine_levels_full_size_vs_float64_and_winograd(K):
+    """A tower layer at config 3's size (bs 16, five levels, one call): one image of P3 against a float64 convolution
+    -- and the error of the Winograd F(2x4) fp32 engine on the same data beside it (this engine must be the more
+    accurate one); every level against F(2x2) on all elements; bit-reproducible."""
+    gen = torch.Generator(device="cuda").manual_seed(26)
+    N, C, M = 16, 256, 256
+    shapes = [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)]
+    Xs = [torch.randn((N, C, h, w), device="cuda", generator=gen).clamp_(min=0) for h, w in shapes]
+    Wt = torch.randn((M, C, 3, 3), device="cuda", generator=gen) * 0.02
+    b = torch.randn(M, device="cuda", generator=gen)
+    ps = K.conv_split_pack_filter(Wt)
+    p24 = K.conv_wino24_pack_filter(Wt)
+    p22, _ = K.conv_wino_pack_filter(Wt, True, False)
+    Ys = K.conv3x3_forward_split(Xs, ps, b, M, relu=True)
+    Y24 = K.conv3x3_forward_wino24(Xs, p24, b, M, relu=True)
+    Y22 = K.conv3x3_forward(Xs, p22, b, M, relu=True, wino=True)
+    for a, c in zip(Ys, Y22):
+        assert (a - c).abs().max().item() <= 1e-5 * c.abs().max().item()
+    again = K.conv3x3_forward_split(Xs, ps, b, M, relu=True)
+    assert all(torch.equal(a, c) for a, c in zip(Ys, again))
+    n0 = 7
+    ref = np.maximum(oracle.conv_forward(Xs[0][n0:n0 + 1].double().cpu().numpy(), Wt.double().cpu().numpy(),
+                                         b.double().cpu().numpy()), 0)
+    scale = np.abs(ref).max()
+    e_split = np.abs(Ys[0][n0:n0 + 1].double().cpu().numpy() - ref).max() / scale
+    e_24 = np.abs(Y24[0][n0:n0 + 1].double().cpu().numpy() - ref).max() / scale
+    e_22 = np.abs(Y22[0][n0:n0 + 1].double().cpu().numpy() - ref).max() / scale
+    print("max error / scale vs float64: split %.3e, F(2x4) %.3e, F(2x2) %.3e" % (e_split, e_24, e_22))
+    # (fp32 accumulation over K = 2304 non-negative terms is what is left: the direct fp32 kernel measures the same)
+    assert e_split <= 2e-6 and e_split <= 1.05 * e_24, (e_split, e_24, e_22)
+    close_split(Ys[0][n0:n0 + 1].cpu().numpy(), ref, "split P3 slice vs float64")

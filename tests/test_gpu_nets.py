@@ -223,7 +223,7 @@ def test_net_errors_surface_like_the_reference():
     with pytest.raises(_capi.C2Error, match="input channels does not match"):
         workspace.RunNet(step.student.net)
     workspace.DeleteNet("student")
-    assert workspace.Nets() == ["teacher"]
+    assert sorted(workspace.Nets()) == ["teacher", "teacher__sync_every_op"]     # (+ the as-written twin made above)
 
 
 def test_lr_schedule_drives_both_routes_with_momentum_correction():
