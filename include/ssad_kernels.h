@@ -495,6 +495,15 @@ typedef struct ssad_gemm_conv {
   int lda, N, K, P, M, flags;
 } ssad_gemm_conv;
 SSAD_API int ssad_conv1x1_gemm(const ssad_gemm_conv* desc_host, ssad_stream_t stream);
+/* The same contract on the split-operand engine (round 6, gemm_split.hip): x and a as hi + lo fp16 under per-tensor
+ * power-of-two scales from their measured |max|, three fp16 MFMAs per operand pair, fp32 accumulation (see
+ * ssad_conv3x3_forward_split for the arithmetic and its limits).  No alignment requirements beyond 16-byte aligned
+ * x / a; any K, M, P.  workspace: ssad_conv1x1_gemm_split_workspace_bytes(desc) bytes (the split copies of x and a);
+ * the call = |max| pass + two split passes + the GEMM on `stream`.  Meant for the compute-bound layers (K >= 256,
+ * M >= 256: res3 - res5 of the backbones); the HBM-bound ones (res2) stay on ssad_conv1x1_gemm. */
+SSAD_API size_t ssad_conv1x1_gemm_split_workspace_bytes(const ssad_gemm_conv* desc_host);
+SSAD_API int ssad_conv1x1_gemm_split(const ssad_gemm_conv* desc_host, void* workspace, size_t workspace_bytes,
+                                     ssad_stream_t stream);
 /* Convolution of any kernel / stride / pad (group 1) as an IMPLICIT GEMM, forward: the same kernel as
  * ssad_conv1x1_gemm with the im2col view of the image gathered by the DMA itself -- no column buffer
  * (caffe2/operators/conv_op_impl.h:126-173 materialises one per image; the 7x7/2 stem's is 1.35 GB at

@@ -197,6 +197,9 @@ def lib():
     L.ssad_conv3x3_wgrad_workspace_bytes.argtypes = [C.POINTER(ConvLevel), i32, i32, i32]
     L.ssad_conv3x3_wgrad.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp, sz, vp]
     L.ssad_conv1x1_gemm.argtypes = [C.POINTER(GemmConv), vp]
+    L.ssad_conv1x1_gemm_split_workspace_bytes.restype = sz
+    L.ssad_conv1x1_gemm_split_workspace_bytes.argtypes = [C.POINTER(GemmConv)]
+    L.ssad_conv1x1_gemm_split.argtypes = [C.POINTER(GemmConv), vp, sz, vp]
     L.ssad_transpose_filter.argtypes = [vp, i32, i32, i32, vp, vp]
     L.ssad_conv1x1_wgrad_workspace_bytes.restype = sz
     L.ssad_conv1x1_wgrad_workspace_bytes.argtypes = [i32, i32, i32, i32]
@@ -953,17 +956,28 @@ def gemm_conv_desc(a, lda, x, y, K, M, bias=None, residual=None, mask=None, relu
                     (GEMM_RELU if relu else 0) | (GEMM_ACCUMULATE if accumulate else 0))
 
 
-def conv1x1_forward(x, wt, M, bias=None, residual=None, relu=False, out=None):
+def _run_gemm(d, what, split):
+    """ssad_conv1x1_gemm, or (split) the same descriptor on the split-operand engine of gemm_split.hip"""
+    L = lib()
+    if not split:
+        _check(L.ssad_conv1x1_gemm(C.byref(d), _stream()), what)
+        return
+    need = L.ssad_conv1x1_gemm_split_workspace_bytes(C.byref(d))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
+    _check(L.ssad_conv1x1_gemm_split(C.byref(d), _ptr(ws), ws.numel(), _stream()), what + " (split)")
+
+
+def conv1x1_forward(x, wt, M, bias=None, residual=None, relu=False, out=None, split=False):
     """act(conv1x1(x, W) + bias (+ residual)) with W^T from transpose_filter (x: N x K x H x W)."""
     _f32c(x, "x"); _f32c(wt, "wt")
     N, Kc, H, W = x.shape
     y = out if out is not None else torch.empty((N, M, H, W), dtype=torch.float32, device="cuda")
     d = gemm_conv_desc(wt, wt.shape[1], x, y, Kc, M, bias, residual, None, relu, False)
-    _check(lib().ssad_conv1x1_gemm(C.byref(d), _stream()), "conv1x1_gemm")
+    _run_gemm(d, "conv1x1_gemm", split)
     return y
 
 
-def conv1x1_dgrad(dy, w, mask=None, accumulate_into=None):
+def conv1x1_dgrad(dy, w, mask=None, accumulate_into=None, split=False):
     """dX = W^T . dY (w: [M][C](x1x1) natural layout), optionally masked by mask > 0, optionally
     added onto `accumulate_into`."""
     _f32c(dy, "dy")
@@ -973,7 +987,7 @@ def conv1x1_dgrad(dy, w, mask=None, accumulate_into=None):
     dx = accumulate_into if accumulate_into is not None else torch.empty((N, Cc, H, W), dtype=torch.float32,
                                                                      device="cuda")
     d = gemm_conv_desc(w2, Cc, dy, dx, M, Cc, None, None, mask, False, accumulate_into is not None)
-    _check(lib().ssad_conv1x1_gemm(C.byref(d), _stream()), "conv1x1_gemm (dgrad)")
+    _run_gemm(d, "conv1x1_gemm (dgrad)", split)
     return dx
 
 

@@ -307,3 +307,63 @@ def test_gemm_conv_full_size_vs_oracle_and_adjoints(K, shape):
     dW0 = K.conv1x1_wgrad(X, dY0)
     close(dW0.cpu().numpy(), ref_dW.reshape(M, Cin), CONV_RTOL, CONV_FLOOR, "full-size wgrad (one contributing image)")
     assert torch.equal(K.conv1x1_wgrad(X, dY), dW)            # deterministic at this size too
+
+
+# ---------------------------------------------------------------------------
+# Round 6: the same descriptor on the split-operand engine (gemm_split.hip), at the exact-fp32 GEMM's bar
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [
+    (2, 64, 64, 12, 16), (2, 24, 40, 9, 12), (3, 256, 128, 10, 14), (1, 128, 512, 20, 28), (2, 2048, 512, 5, 8),
+    (1, 16, 8, 2, 2), (2, 256, 1024, 6, 7), (1, 1024, 256, 11, 13), (2, 72, 300, 5, 5),
+], ids=lambda s: "N%d_C%d_M%d_%dx%d" % s)
+def test_gemm_split_forward_and_dgrad_vs_oracle(K, shape):
+    """ssad_conv1x1_gemm_split against the oracle: bias, shortcut + ReLU, data gradient with the fused ReluGradient
+    mask and with accumulation -- K / M tails (not multiples of 8 / 64 / 256), pixel tiles that end inside an image."""
+    N, Cin, M, H, W = shape
+    rng = np.random.default_rng(600 + sum(shape))
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, 1, 1)) * (1.0 / np.sqrt(Cin))).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    R = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    dY = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    tw, tx = dev(Wt), dev(X)
+    wt = K.transpose_filter(tw)
+    ref = oracle.conv_forward(X, Wt, b, kernel=1, stride=1, pad=0)
+    close(K.conv1x1_forward(tx, wt, M, dev(b), split=True).cpu().numpy(), ref, CONV_RTOL, CONV_FLOOR, "Y")
+    close(K.conv1x1_forward(tx, wt, M, dev(b), dev(R), relu=True, split=True).cpu().numpy(), np.maximum(ref + R, 0),
+          CONV_RTOL, CONV_FLOOR, "relu(Y + R)")
+    close(K.conv1x1_forward(tx, wt, M, split=True).cpu().numpy(), oracle.conv_forward(X, Wt, None, kernel=1, stride=1, pad=0),
+          CONV_RTOL, CONV_FLOOR, "Y no bias")
+    rdW, rdb, rdX = oracle.conv_backward(X, Wt, dY, kernel=1, stride=1, pad=0)
+    tdy = dev(dY)
+    close(K.conv1x1_dgrad(tdy, tw, split=True).cpu().numpy(), rdX, CONV_RTOL, CONV_FLOOR, "dX")
+    mask = np.maximum(rng.standard_normal(X.shape), 0).astype(np.float32)
+    close(K.conv1x1_dgrad(tdy, tw, mask=dev(mask), split=True).cpu().numpy(), np.where(mask > 0, rdX, 0), CONV_RTOL,
+          CONV_FLOOR, "masked dX")
+    base = rng.standard_normal(X.shape).astype(np.float32)
+    got = K.conv1x1_dgrad(tdy, tw, accumulate_into=dev(base), split=True).cpu().numpy()
+    close(got, base + rdX, CONV_RTOL, CONV_FLOOR, "dX accumulated")
+
+
+def test_gemm_split_full_size_vs_exact_fp32_gemm_and_float64(K):
+    """res4's two pointwise shapes at config 3's size (bs 16, 40 x 56): every element against the exact-fp32 MFMA GEMM
+    (1e-5 of the scale), one image against float64, bit-reproducible, many work items per workgroup."""
+    gen = torch.Generator(device="cuda").manual_seed(61)
+    for Cin, M in ((1024, 256), (256, 1024)):
+        N, H, W = 16, 40, 56
+        X = torch.randn((N, Cin, H, W), device="cuda", generator=gen).clamp_(min=0)
+        Wt = torch.randn((M, Cin, 1, 1), device="cuda", generator=gen) * (1.0 / np.sqrt(Cin))
+        b = torch.randn(M, device="cuda", generator=gen)
+        R = torch.randn((N, M, H, W), device="cuda", generator=gen)
+        wt = K.transpose_filter(Wt)
+        want = K.conv1x1_forward(X, wt, M, b, R, relu=True)
+        got = K.conv1x1_forward(X, wt, M, b, R, relu=True, split=True)
+        assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+        assert torch.equal(got, K.conv1x1_forward(X, wt, M, b, R, relu=True, split=True))
+        n0 = 9
+        ref = torch.einsum("mc,chw->mhw", Wt[:, :, 0, 0].double(), X[n0].double()) + b.double()[:, None, None] + R[n0].double()
+        ref = ref.clamp_(min=0).cpu().numpy()
+        e_s = np.abs(got[n0].double().cpu().numpy() - ref).max() / np.abs(ref).max()
+        e_f = np.abs(want[n0].double().cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert e_s <= 2e-6 and e_s <= 4 * e_f + 1e-7, (e_s, e_f)
