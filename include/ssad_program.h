@@ -38,13 +38,14 @@ extern "C" {
  * names ending in _host). */
 enum ssad_opcode {
   /* ssad_conv_wino_pack_filters(p0 = entries_host, i0 = n); i1 == 2: ssad_conv_wino24_pack_filters (the F(2x4)
-   * engine: forward and / or data-gradient packs) */
+   * engine: forward and / or data-gradient packs); i1 == 3: ssad_conv_split_pack_filters (the split-operand engine) */
   SSAD_OP_WINO_PACK_FILTERS = 1,
   /* ssad_conv_pack_filter(p0 = w, i0 = Cout, i1 = Cin, p1 = packed_fwd, p2 = packed_dgrad) */
   SSAD_OP_PACK_FILTER = 2,
   /* ssad_conv3x3_forward[_wino](p0 = levels_host, i0 = n, p1 = packed, p2 = bias, i1 = Cout,
    * i2 = Cin, i3 = flags); i4: 0 the direct engine, 1 Winograd F(2x2, 3x3), 2 Winograd F(2x4, 3x3)
-   * (ssad_conv3x3_forward_wino24) */
+   * (ssad_conv3x3_forward_wino24), 3 the split-operand engine (ssad_conv3x3_forward_split: p3 = workspace, l0 =
+   * workspace bytes, p4 = amax_in or NULL, p5 = amax_out or NULL) */
   SSAD_OP_CONV3X3 = 3,
   /* ssad_conv3x3_wgrad(p0 = levels_host, i0 = n, p1 = dW, p2 = db, i1 = Cout, i2 = Cin,
    * i3 = accumulate, p3 = workspace, l0 = workspace_bytes) */
@@ -178,7 +179,9 @@ enum ssad_opcode {
   /* ssad_transpose_filters(p0 = const ssad_transpose_entry* (host), i0 = n_entries) */
   SSAD_OP_TRANSPOSE_FILTERS = 77,
   /* p0 = const ssad_f16_pack_entry* (host table, kept alive by the caller), i0 = entries */
-  SSAD_OP_F16_PACK_FILTERS = 78
+  SSAD_OP_F16_PACK_FILTERS = 78,
+  /* ssad_conv1x1_gemm_split(p0 = const ssad_gemm_conv* (host), p1 = workspace, l0 = workspace bytes) */
+  SSAD_OP_GEMM_CONV_SPLIT = 79
 };
 
 typedef struct ssad_op {

@@ -88,10 +88,14 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
   const float* f = o.f;
   switch (o.code) {
     case SSAD_OP_WINO_PACK_FILTERS:
-      return (i[1] == 2 ? ssad_conv_wino24_pack_filters : ssad_conv_wino_pack_filters)((const ssad_pack_entry*)p[0], i[0], s);
+      return (i[1] == 3 ? ssad_conv_split_pack_filters : i[1] == 2 ? ssad_conv_wino24_pack_filters
+                                                                   : ssad_conv_wino_pack_filters)((const ssad_pack_entry*)p[0], i[0], s);
     case SSAD_OP_PACK_FILTER:
       return ssad_conv_pack_filter((const float*)p[0], i[0], i[1], (float*)p[1], (float*)p[2], s);
     case SSAD_OP_CONV3X3:
+      if (i[4] == 3)
+        return ssad_conv3x3_forward_split((const ssad_conv_level*)p[0], i[0], (const float*)p[1], (const float*)p[2], i[1],
+                                          i[2], i[3], (void*)p[3], (size_t)o.l[0], (const unsigned*)p[4], (unsigned*)p[5], s);
       return (i[4] == 2 ? ssad_conv3x3_forward_wino24 : i[4] ? ssad_conv3x3_forward_wino : ssad_conv3x3_forward)(
           (const ssad_conv_level*)p[0], i[0], (const float*)p[1], (const float*)p[2], i[1], i[2], i[3], s);
     case SSAD_OP_CONV3X3_WGRAD:
@@ -167,6 +171,8 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
       return ssad_relu_grad((const float*)p[0], (const float*)p[1], (float*)p[2], o.l[0], s);
     case SSAD_OP_GEMM_CONV:
       return ssad_conv1x1_gemm((const ssad_gemm_conv*)p[0], s);
+    case SSAD_OP_GEMM_CONV_SPLIT:
+      return ssad_conv1x1_gemm_split((const ssad_gemm_conv*)p[0], (void*)p[1], (size_t)o.l[0], s);
     case SSAD_OP_CONV1X1_WGRAD:
       return ssad_conv1x1_wgrad((const float*)p[0], (const float*)p[1], i[0], i[1], i[2], i[3], (float*)p[2],
                                 i[4], (void*)p[3], (size_t)o.l[0], s);

@@ -118,6 +118,12 @@ class DistillHeads(object):
                 self.teacher_f24 = 2
             elif self.distill:
                 self.student_f24 &= ~4
+        # The split-operand engine (conv3x3_split.hip: fp32 operands as hi + lo fp16, three fp16 MFMAs per pair; meets the
+        # direct kernel's parity floor where F(2x4) needs 2e-5) where it measured faster than F(2x4) at config 3's size --
+        # the 720-wide prediction layer: bit 1 = cls_pred forward (student and teacher), bit 2 = its data gradient
+        # (SSAD_SPLIT_CONV; 0 = off)
+        self.split_conv = int(os.environ.get("SSAD_SPLIT_CONV", "3")) if (self.wino and not self.F16) else 0
+        self._split_ops, self._split_ws_need = [], 0
         self.momentum, self.weight_decay = momentum, weight_decay
         self.pg, self.world_size = process_group, world_size
         self.dp = BucketedAllReduce(process_group, world_size)
@@ -208,13 +214,23 @@ class DistillHeads(object):
                 k += 1
         return arr
 
-    def _emit_conv(self, P, problems, Cout, Cin, flags, klass, f24=False):
-        """One launch of independent convolutions of equal (Cout, Cin); f24: on the F(2x4, 3x3) engine."""
+    def _emit_conv(self, P, problems, Cout, Cin, flags, klass, f24=False, split=False):
+        """One launch of independent convolutions of equal (Cout, Cin); f24: on the F(2x4, 3x3) engine; split: on the
+        split-operand engine (its workspace is bound by _finish_workspaces)."""
         arr = self._conv_table(problems)
         px = sum(x.shape[0] * x.shape[2] * x.shape[3] for p in problems for x in p[0])
         wino = self._use_wino(Cout)
         if not wino and klass in (2, 3, 4, 16):
             klass = 18
+        if split:
+            nb = K.lib().ssad_conv3x3_split_workspace_bytes(arr, len(arr), Cin)
+            self._split_ws_need = max(self._split_ws_need, nb)
+            idx = P.add(PR.CONV3X3, klass, i=(len(arr), Cout, Cin, flags, 3), l=(nb,), p=(arr, None, None, None, None, None),
+                        work=2.0 * 9 * Cout * Cin * px,
+                        keep=[t for p in problems for t in (list(p[0]) + list(p[1] or []) + list(p[2] or []))
+                              ] + [t for p in problems for t in p[3:] if t is not None])
+            self._split_ops.append((P, idx))
+            return idx, arr
         idx = P.add(PR.CONV3X3, klass, i=(len(arr), Cout, Cin, flags, 2 if (f24 and wino) else int(wino)), p=(arr, None, None),
                     work=2.0 * 9 * Cout * Cin * px,
                     keep=[t for p in problems for t in (list(p[0]) + list(p[1] or []) + list(p[2] or []))
@@ -252,41 +268,62 @@ class DistillHeads(object):
             return False
         return bool(m & 2) if "_pred_" in name else bool(m & 4)
 
+    def _split_use(self, name, cout, cin, which):
+        """Does this convolution run on the split-operand engine?  (the 720-wide prediction layer, SSAD_SPLIT_CONV)"""
+        if not self.split_conv or "_cls_pred_" not in name:
+            return False
+        return bool(self.split_conv & (1 if which == "fwd" else 2))
+
     def _alloc_packed(self, params, want_dgrad, f24=None):
         """Packed-filter buffers per layer in the layout of the engine that consumes them:
         -> ({name: (fwd, dgrad)}, wino pack entries, direct pack ops[, F(2x4) pack entries]); f24 = "teacher" |
         "student": whose layers these are (None: no F(2x4) engine, three results)."""
         L = K.lib()
-        packed, entries, direct, entries24 = {}, [], [], []
+        packed, entries, direct, entries24, entries_sp = {}, [], [], [], []
         for tower in ("cls", "bbox"):
             for name in self._layers(tower):
                 w = params[name + "_w"]
                 cout, cin = w.shape[0], w.shape[1]
                 pf = pd = None
                 fw, dw = self._use_wino(cout), self._use_wino(cin)
-                f_24 = bool(f24) and fw and self._f24_use(f24, name, cout, cin, "fwd")
-                d_24 = bool(f24) and want_dgrad and dw and self._f24_use(f24, name, cout, cin, "dgrad")
-                nf = (L.ssad_conv_wino24_filter_floats if f_24 else L.ssad_conv_wino_filter_floats if fw
-                      else L.ssad_conv_packed_filter_floats)(cout, cin)
+                f_sp = bool(f24) and fw and self._split_use(name, cout, cin, "fwd")
+                d_sp = bool(f24) and want_dgrad and dw and self._split_use(name, cout, cin, "dgrad")
+                f_24 = bool(f24) and fw and not f_sp and self._f24_use(f24, name, cout, cin, "fwd")
+                d_24 = bool(f24) and want_dgrad and dw and not d_sp and self._f24_use(f24, name, cout, cin, "dgrad")
+                nf = (L.ssad_conv_split_filter_floats if f_sp else L.ssad_conv_wino24_filter_floats if f_24
+                      else L.ssad_conv_wino_filter_floats if fw else L.ssad_conv_packed_filter_floats)(cout, cin)
                 pf = torch.empty(nf, dtype=torch.float32, device=self.device)
                 if want_dgrad:
-                    nd = (L.ssad_conv_wino24_filter_floats if d_24 else L.ssad_conv_wino_filter_floats if dw
-                          else L.ssad_conv_packed_filter_floats)(cin, cout)
+                    nd = (L.ssad_conv_split_filter_floats if d_sp else L.ssad_conv_wino24_filter_floats if d_24
+                          else L.ssad_conv_wino_filter_floats if dw else L.ssad_conv_packed_filter_floats)(cin, cout)
                     pd = torch.empty(nd, dtype=torch.float32, device=self.device)
                 packed[name] = (pf, pd)
+                if f_sp or d_sp:
+                    entries_sp.append((w, cout, cin, pf if f_sp else None, pd if d_sp else None))
                 xf, xd = (pf if f_24 else None), (pd if d_24 else None)
                 if xf is not None or xd is not None:
                     entries24.append((w, cout, cin, xf, xd))
-                wf = pf if (fw and not f_24) else None
-                wd = pd if (dw and want_dgrad and not d_24) else None
+                wf = pf if (fw and not f_24 and not f_sp) else None
+                wd = pd if (dw and want_dgrad and not d_24 and not d_sp) else None
                 if wf is not None or wd is not None:
                     entries.append((w, cout, cin, wf, wd))
                 df, dd = (pf if not fw else None), (pd if (not dw and want_dgrad) else None)
                 if df is not None or dd is not None:
                     direct.append((w, cout, cin, df, dd))
+        if f24:
+            self._entries_split[f24] = entries_sp
         return (packed, entries, direct, entries24) if f24 else (packed, entries, direct)
 
-    def _emit_pack(self, P, entries, direct, entries24=()):
+    def _emit_pack(self, P, entries, direct, entries24=(), entries_sp=()):
+        if entries_sp:
+            tab = (K.PackEntry * len(entries_sp))()
+            nbytes = 0
+            for k, (w, cout, cin, pf, pd) in enumerate(entries_sp):
+                tab[k] = K.PackEntry(w.data_ptr(), cout, cin, pf.data_ptr() if pf is not None else 0,
+                                     pd.data_ptr() if pd is not None else 0)
+                nbytes += 4 * (w.numel() + (pf.numel() if pf is not None else 0) + (pd.numel() if pd is not None else 0))
+            P.add(PR.WINO_PACK_FILTERS, 1, i=(len(entries_sp), 3), p=(tab,), work=nbytes,
+                  keep=[t for e in entries_sp for t in e if isinstance(t, torch.Tensor)])
         if entries24:
             tab = (K.PackEntry * len(entries24))()
             nbytes = 0
@@ -319,20 +356,21 @@ class DistillHeads(object):
         self._wstream = 1 if (os.environ.get("SSAD_OVERLAP_WGRAD", "1") == "1" if ov is None else ov) else 0
         self._wgrad_ops, self._wgrad_ws_need = [], 0
         self._in_slots = []          # (table, index, which): entries that read the bound inputs
+        self._entries_split = {}
         # filters (the teacher's are frozen: packed by a program of their own, run when they change)
         if self.F16:
             self.packed, s_entries, s_direct = self._alloc_packed(self.params, True)
             s_extra = ()
         else:
             self.packed, s_entries, s_direct, s_entries24 = self._alloc_packed(self.params, True, f24="student")
-            s_extra = (s_entries24,)
+            s_extra = (s_entries24, self._entries_split.get("student", []))
         if self.distill:
             if self.F16:            # (the fp16 subclass has its own pack layouts and no F(2x4) engine)
                 self.t_packed_pairs, t_entries, t_direct = self._alloc_packed(self.teacher, False)
                 t_extra = ()
             else:
                 self.t_packed_pairs, t_entries, t_direct, t_entries24 = self._alloc_packed(self.teacher, False, f24="teacher")
-                t_extra = (t_entries24,)
+                t_extra = (t_entries24, self._entries_split.get("teacher", []))
             self.t_packed = {k: v[0] for k, v in self.t_packed_pairs.items()}
             T = self.prog_teacher_pack = PR.Program()
             self._emit_pack(T, t_entries, t_direct, *t_extra)
@@ -359,6 +397,10 @@ class DistillHeads(object):
         P.build()
 
     def _finish_workspaces(self, P):
+        # one workspace for every split-engine convolution: they run one after the other on the program's stream
+        self.split_ws = torch.empty(max(self._split_ws_need, 16), dtype=torch.uint8, device=self.device)
+        for prog, idx in self._split_ops:
+            prog.set_ptr(idx, 3, self.split_ws)
         self.wgrad_ws = torch.empty(max(self._wgrad_ws_need, 16), dtype=torch.uint8, device=self.device)
         for idx in self._wgrad_ops:
             P.set_ptr(idx, 3, self.wgrad_ws)
@@ -421,13 +463,14 @@ class DistillHeads(object):
                         self._in_slots.append((arr, k, w, l))
                         k += 1
         cp, bp = self._layers("cls")[-1], self._layers("bbox")[-1]
+        sp = self._split_use(cp, AC, D, "fwd")
         if self.distill:
             f24 = self._f24_layer(cp, AC)
             self._emit_conv(P, [(tx["cls"], self.t_prob, None, self.t_packed_for(cp), self.teacher[cp + "_b"])],
-                            AC, D, K.CONV_SIGMOID, 20 if f24 else 3, f24=f24)
+                            AC, D, K.CONV_SIGMOID, 25 if sp else 20 if f24 else 3, f24=f24, split=sp)
         f24 = self._f24_use("student", cp, AC, D, "fwd")
         self._emit_conv(P, [(sx["cls"], self.cls_logits, None, self.packed[cp][0], self.params[cp + "_b"])],
-                        AC, D, 0, 22 if f24 else 3, f24=f24)
+                        AC, D, 0, 26 if sp else 22 if f24 else 3, f24=f24, split=sp)
         probs = [(sx["bbox"], self.bbox_pred, None, self.packed[bp][0], self.params[bp + "_b"])]
         if self.teacher_bbox_tower:
             probs.append((tx["bbox"], self.t_bbox, None, self.t_packed_for(bp), self.teacher[bp + "_b"]))
@@ -532,9 +575,10 @@ class DistillHeads(object):
             Cout = self.params[name + "_b"].numel()
             self._emit_wgrad(P, x_in, dy[t], name, Cout, klass_w)
             out = self.dbuf[t][nl]
+            sp = self._split_use(name, Cout, D, "dgrad")
             f24 = self._f24_use("student", name, Cout, D, "dgrad")
             self._emit_conv(P, [(dy[t], out, x_in, self.packed[name][1], None)], D, Cout, K.CONV_MASK_AUX,
-                            24 if f24 else 16, f24=f24)
+                            27 if sp else 24 if f24 else 16, f24=f24, split=sp)
             dy[t] = out
         for li in range(nl - 1, -1, -1):
             probs = []

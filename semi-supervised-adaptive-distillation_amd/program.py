@@ -27,6 +27,7 @@ FORK, JOIN = 62, 63
 GROUPED_CONV3X3, GROUPED_PACK, CONV_IMPLICIT = 64, 65, 66
 PW_F16, PW_F16_PACK, PW_F16_WGRAD, F16_EW, STEM_POOL_F16, GROUPED_F16, GROUPED_F16_PACK = 67, 68, 69, 70, 71, 72, 73
 CONV_IMPLICIT_WS, CONV_KXK_WGRAD, CONV_KXK_DGRAD, TRANSPOSE_FILTERS, F16_PACK_FILTERS = 74, 75, 76, 77, 78
+GEMM_CONV_SPLIT = 79
 
 # timing classes: one per kernel family.  bound "mfma": work = direct-form FLOPs
 # (2*9*Cout*Cin per output pixel; the Winograd engine executes 1/2.25 of them);
@@ -58,6 +59,14 @@ KLASS = {
     # SSAD_STUDENT_F24: the trained subnets on the same engine (off by default)
     22: dict(name="cls_pred conv3x3 fwd, 720-wide, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma", wino=True, exec_div=3.0),
     23: dict(name="subnet tower conv3x3 forward, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma", wino=True, exec_div=3.0),
+    # split-operand engine (conv3x3_split.hip): executes 3 x the direct-form flops, on the fp16 pipes (exec_div = 1/3:
+    # executed = direct-form x 3); the launch includes its |max| and split passes
+    25: dict(name="teacher cls_pred conv3x3 fwd + sigmoid, split-operand engine (conv3x3_split_kernel + |max| + split passes)",
+             bound="mfma16", wino=True, exec_div=1.0 / 3.0),
+    26: dict(name="cls_pred conv3x3 fwd, split-operand engine (conv3x3_split_kernel + |max| + split passes)", bound="mfma16",
+             wino=True, exec_div=1.0 / 3.0),
+    27: dict(name="cls_pred data gradient, split-operand engine (conv3x3_split_kernel + |max| + split passes)", bound="mfma16",
+             wino=True, exec_div=1.0 / 3.0),
     24: dict(name="subnet conv3x3 data gradient, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma", wino=True, exec_div=3.0),
     # direct (non-Winograd) engine
     18: dict(name="subnet conv3x3 fwd/dgrad, direct engine (conv3x3_kernel)", bound="mfma", wino=False),

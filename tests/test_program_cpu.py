@@ -39,18 +39,22 @@ def test_distillation_step_program_structure():
     assert list(m) == ["pack", "forward", "losses", "backward", "backward_late_done", "sgd", "sgd_update",
                        "ls_update", "end"]
     assert m["sgd"] == m["sgd_update"] and m["ls_update"] == m["end"]      # fp32: nothing around the update
-    # 10 filters x {fwd, dgrad}: one launch per pack layout -- F(2x4) (every forward but bbox_pred's 36 outputs,
-    # every data gradient) and F(2x2) (bbox_pred forward)
-    assert _codes(h, "pack", "forward") == [PR.WINO_PACK_FILTERS] * 2
-    assert [(o.i[0], o.i[1]) for o in h.prog.ops[m["pack"]:m["forward"]]] == [(10, 2), (1, 0)]
+    # 10 filters x {fwd, dgrad}: one launch per pack layout -- the split-operand engine (cls_pred forward + data
+    # gradient), F(2x4) (every other forward but bbox_pred's 36 outputs, every other data gradient) and F(2x2)
+    # (bbox_pred forward)
+    assert _codes(h, "pack", "forward") == [PR.WINO_PACK_FILTERS] * 3
+    assert [(o.i[0], o.i[1]) for o in h.prog.ops[m["pack"]:m["forward"]]] == [(1, 3), (9, 2), (1, 0)]
     # 4 tower depths (teacher+student x cls+bbox in one launch each), teacher cls_pred (sigmoid),
     # student cls_pred, bbox_pred (student + teacher)
     assert _codes(h, "forward", "losses") == [PR.CONV3X3] * 7
     assert [o.i[0] for o in h.prog.ops[m["forward"]:m["losses"]]] == [8, 8, 8, 8, 2, 2, 4]
-    # engine (i[4]: 1 = F(2x2), 2 = F(2x4)) and timing class per launch
+    # engine (i[4]: 1 = F(2x2), 2 = F(2x4), 3 = split-operand) and timing class per launch
     assert [(o.i[4], o.klass) for o in h.prog.ops[m["forward"]:m["losses"]]] == \
-        [(2, 23)] * 4 + [(2, 20), (2, 22), (1, 4)]
-    assert {(o.i[4], o.klass) for o in h.prog.ops[m["backward"]:m["sgd"]] if o.code == PR.CONV3X3} == {(2, 24)}
+        [(2, 23)] * 4 + [(3, 25), (3, 26), (1, 4)]
+    assert {(o.i[4], o.klass) for o in h.prog.ops[m["backward"]:m["sgd"]] if o.code == PR.CONV3X3} == {(2, 24), (3, 27)}
+    # the split-engine launches share one workspace, sized for the largest (the 720-channel gradient of cls_pred)
+    sp = [o for o in h.prog.ops if o.code == PR.CONV3X3 and o.i[4] == 3]
+    assert len(sp) == 3 and {o.p[3] for o in sp} == {h.split_ws.data_ptr()} and max(o.l[0] for o in sp) <= h.split_ws.numel()
     assert _codes(h, "losses", "backward") == [PR.POW_SUM, PR.CLS_LOSSES_FUSED, PR.SMOOTH_L1]
     bw = _codes(h, "backward", "sgd")
     assert bw.count(PR.CONV3X3_WGRAD) == 10 and bw.count(PR.CONV3X3) == 6
@@ -70,6 +74,7 @@ def test_distillation_step_program_structure():
 def test_f24_switches_select_the_engine_per_launch(monkeypatch):
     """SSAD_STUDENT_F24 (bit mask) / SSAD_TEACHER_F24: 0 restores the F(2x2) engine and the round-4 timing classes;
     the bits move one family each."""
+    monkeypatch.setenv("SSAD_SPLIT_CONV", "0")       # (the F(2x4) / F(2x2) switches alone; the split engine below)
     def engines(student, teacher):
         monkeypatch.setenv("SSAD_STUDENT_F24", str(student))
         monkeypatch.setenv("SSAD_TEACHER_F24", str(teacher))
@@ -106,6 +111,19 @@ def test_f24_switches_select_the_engine_per_launch(monkeypatch):
                 assert h.packed[name][0].numel() == L.ssad_conv_wino_filter_floats(256, 256), name
                 assert h.packed[name][1].numel() == L.ssad_conv_wino24_filter_floats(256, 256), name   # dgrad: bit 1
         assert h.packed[h._layers("cls")[-1]][0].numel() == L.ssad_conv_wino24_filter_floats(720, 256)
+    # SSAD_SPLIT_CONV: bit 1 = cls_pred forward (both networks), bit 2 = its data gradient
+    monkeypatch.setenv("SSAD_STUDENT_F24", "15")
+    monkeypatch.setenv("SSAD_TEACHER_F24", "1")
+    for bits, want_f, want_b in ((1, [(3, 25), (3, 26)], {(2, 24)}), (2, [(2, 20), (2, 22)], {(2, 24), (3, 27)})):
+        monkeypatch.setenv("SSAD_SPLIT_CONV", str(bits))
+        h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu")
+        m = h.prog.marks
+        assert [(o.i[4], o.klass) for o in h.prog.ops[m["forward"]:m["losses"]]][4:6] == want_f
+        assert {(o.i[4], o.klass) for o in h.prog.ops[m["backward"]:m["sgd"]] if o.code == PR.CONV3X3} == want_b
+        cp = h._layers("cls")[-1]
+        assert h.packed[cp][0].numel() == (L.ssad_conv_split_filter_floats if bits & 1 else L.ssad_conv_wino24_filter_floats)(720, 256)
+        assert h.packed[cp][1].numel() == (L.ssad_conv_split_filter_floats if bits & 2 else L.ssad_conv_wino24_filter_floats)(256, 720)
+    monkeypatch.setenv("SSAD_SPLIT_CONV", "0")
     # without a teacher the student's towers are alone in their launch and follow bit 4
     monkeypatch.setenv("SSAD_STUDENT_F24", "7")
     h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu", distill=False)
