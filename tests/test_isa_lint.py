@@ -24,7 +24,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc (ROCm) to produce the assembly")
 @pytest.mark.parametrize("src,expect", [("conv3x3_winograd.hip", "wino_conv_z_kernel"),
                                         ("conv3x3_winograd24.hip", "wino24_conv_kernel"),
-                                        ("conv3x3_f16.hip", "conv3x3_wgrad_f16_kernel")])
+                                        ("conv3x3_f16.hip", "conv3x3_wgrad_f16_kernel"),
+                                        ("conv3x3_split.hip", "conv3x3_split_kernel"),
+                                        ("gemm_split.hip", "gemm_split_kernel")])
 def test_no_access_to_in_flight_asm_load_destinations(tmp_path, src, expect):
     import isa_lint
     out = str(tmp_path / (src + ".s"))
@@ -38,7 +40,11 @@ def test_no_access_to_in_flight_asm_load_destinations(tmp_path, src, expect):
         if ring and expect in name:
             seen += 1
         findings += [(name, no, code) for no, code in bad]
-    assert seen >= 2, "the lint found no asm-issued loads in %s: has the kernel changed shape?" % src
+        # round 6: a VALU-written scalar operand (spill restore, readfirstlane) inside 5 wait states of an asm VMEM
+        findings += [(name, no, code, "s%s after %d wait states" % (reg, ws))
+                     for no, code, reg, ws in isa_lint.lint_scalar_operands(lines)]
+    assert seen >= (1 if src == "gemm_split.hip" else 2), \
+        "the lint found no asm-issued loads in %s: has the kernel changed shape?" % src
     assert not findings, findings[:10]
 
 
@@ -73,3 +79,22 @@ def test_lint_releases_ownership_only_on_an_exact_vmcnt_zero():
     assert run("s_waitcnt vmcnt(0) lgkmcnt(0)") == []
     assert run("s_waitcnt lgkmcnt(0)") == ["v_mov_b64_e32 v[34:35], v[2:3]"]
     assert run("s_waitcnt vmcnt(10)") == ["v_mov_b64_e32 v[34:35], v[2:3]"]
+
+
+def test_lint_recognises_the_round6_spill_restore_hazard():
+    """conv3x3_split.hip's first persistent version, in miniature: hipcc restores a spilled offset with v_readlane and the
+    inline-asm load behind it reads the scalar register before the write has landed; with the s_nop 4 the statement now
+    carries, the same sequence is clean."""
+    import isa_lint
+    def kernel(nop):
+        return ["_Zk:", "\tv_readlane_b32 s15, v255, 25", "\t;;#ASMSTART"] + ([nop] if nop else []) + [
+            "\tbuffer_load_dwordx4 v[10:13], v195, s[28:31], s15 offen", "\t;;#ASMEND",
+            "\tbuffer_load_dwordx4 v[14:17], v196, s[28:31], s15 offen",        # hipcc's own load: its business
+            "\t.set _Zk.uses_flat_scratch, 0"]
+    (_, lines), = list(isa_lint.kernels("\n".join(kernel(None))))
+    bad = isa_lint.lint_scalar_operands(lines)
+    assert [(code.split()[0], reg, ws) for _, code, reg, ws in bad] == [("buffer_load_dwordx4", 15, 0)]
+    (_, lines), = list(isa_lint.kernels("\n".join(kernel("\ts_nop 4"))))
+    assert isa_lint.lint_scalar_operands(lines) == []
+    (_, lines), = list(isa_lint.kernels("\n".join(kernel("\ts_nop 2"))))
+    assert len(isa_lint.lint_scalar_operands(lines)) == 1

@@ -101,6 +101,63 @@ def lint(lines):
     return ring, bad
 
 
+def sgprs(tok):
+    tok = tok.strip()
+    m = re.match(r"s\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"s(\d+)$", tok)
+    if m:
+        return {int(m.group(1))}
+    return {"vcc"} if tok in ("vcc", "vcc_lo", "vcc_hi") else set()
+
+
+def lint_scalar_operands(lines, need=5):
+    """Round 6.  A scalar register written by a VALU instruction (v_readlane restoring a spilled SGPR, v_readfirstlane,
+    v_cmp into an SGPR pair) may not be read by a vector-memory instruction for 5 wait states.  hipcc inserts the
+    s_nop for its own loads; it cannot for a buffer_load / buffer_store inside an inline-asm statement, whose operands
+    it only sees as "s" constraints -- conv3x3_split.hip's first version read the PREVIOUS value of a spilled offset in
+    the first load behind every restore (wrong filter rows for one wave's half of an item, only when the register
+    allocator spilled, i.e. only in the persistent form of the kernel).  Reports (line, instruction, register, wait
+    states seen) for every asm VMEM instruction closer than `need` wait states to such a write."""
+    recent = []          # [wait states since, registers]
+    bad, in_asm = [], False
+    for no, l in enumerate(lines):
+        if "#ASMSTART" in l:
+            in_asm = True
+            continue
+        if "#ASMEND" in l:
+            in_asm = False
+            continue
+        code = l.split(";")[0].strip()
+        if not code or code.startswith(".") or code.endswith(":"):
+            continue
+        parts = code.split(None, 1)
+        op = parts[0]
+        ops = [t.strip() for t in parts[1].split(",")] if len(parts) > 1 else []
+        if in_asm and op.startswith(("buffer_load", "buffer_store", "global_load", "global_store")):
+            read = set()
+            for t in ops:
+                for w in t.split():
+                    read |= sgprs(w)
+            for ws, regs in recent:
+                hit = read & regs
+                if hit and ws < need:
+                    bad.append((no, code, sorted(hit, key=str)[0], ws))
+        ws = int(ops[0]) + 1 if op == "s_nop" and ops else 1
+        recent = [[w + ws, r] for w, r in recent if w + ws < 16]
+        written = set()
+        if op.startswith(("v_readlane_b32", "v_readfirstlane_b32")) and ops:
+            written = sgprs(ops[0])
+        elif op.startswith("v_cmp") and ops and op.endswith("_e64"):
+            written = sgprs(ops[0])
+        elif op.startswith("v_cmp"):
+            written = {"vcc"}
+        if written:
+            recent.append([0, written])
+    return bad
+
+
 def main():
     text = open(sys.argv[1]).read()
     want = sys.argv[2] if len(sys.argv) > 2 else ""
@@ -109,12 +166,16 @@ def main():
         if want not in name:
             continue
         ring, bad = lint(lines)
-        if not ring:
+        hz = lint_scalar_operands(lines)
+        if not ring and not hz:
             continue
-        print("%s: %d ring registers, %d non-MFMA reads" % (name, len(ring), len(bad)))
+        print("%s: %d ring registers, %d non-MFMA reads, %d asm VMEM reads of a VALU-written SGPR inside 5 wait states"
+              % (name, len(ring), len(bad), len(hz)))
         for no, code in bad[:20]:
             print("    +%d  %s" % (no, code))
-        rc |= 1 if bad else 0
+        for no, code, reg, ws in hz[:20]:
+            print("    +%d  %s   <- s%s written %d wait state(s) earlier" % (no, code, reg, ws))
+        rc |= 1 if (bad or hz) else 0
     return rc
 
 
