@@ -156,17 +156,10 @@ def pmc_traffic(klass):
         return None, None, None
 
 
-def cpu_reference_conv(budget_s=25.0):
-    """The reference's OWN CPU operators for the convolutions of the subnets step:
-    oracle/_ref/libref_conv.so = ConvOp / ConvGradientOp<float, CPUContext> (conv_op_impl.h:31-202,
-    358-577: per-image im2col + Eigen GEMM, one thread as the reference builds them) compiled from
-    /root/reference by oracle/build_ref_conv.sh.  One image; every convolution a step runs on it (student
-    towers + predictors forward and gradient, teacher forward) on the FPN levels from the coarsest
-    upwards for as long as the budget lasts.  None when the library was not built."""
-    from oracle import oracle
+def _cpu_conv_sample(fwd, bwd, budget_s):
+    """The convolutions of the subnets step on ONE image, FPN levels from the coarsest upwards while the budget lasts:
+    -> (levels used, seconds, flops, pixel share)."""
     from ssad_amd import synth
-    if oracle.load_ref_conv() is None:
-        return None
     rng = np.random.default_rng(7)
     used, t_total, fl_total, px_used = [], 0.0, 0.0, 0
     last = None
@@ -181,9 +174,9 @@ def cpu_reference_conv(budget_s=25.0):
             b = np.zeros(M, np.float32)
             t0 = time.perf_counter()
             for _ in range(n_fwd):
-                y = oracle.ref_conv_forward(x, Wt, b)
+                y = fwd(x, Wt, b)
             for _ in range(n_bwd):
-                oracle.ref_conv_backward(x, Wt, y)
+                bwd(x, Wt, y)
             t_level += time.perf_counter() - t0
             fl_total += 2.0 * 9 * 256 * M * h * w * (n_fwd + 2 * n_bwd)
         t_total += t_level
@@ -191,7 +184,41 @@ def cpu_reference_conv(budget_s=25.0):
         px_used += h * w
         used.append("P%d" % (li + 3))
     frac = px_used / float(sum(h * w for h, w in synth.LEVEL_SHAPES_600))
+    return used, t_total, fl_total, frac
+
+
+def cpu_port_conv(budget_s=12.0):
+    """The SAME scope and thread count as `reference_conv` for the repo's own CPU restatement (oracle/ssad_oracle.c:
+    im2col + GEMM, ONE thread): the convolutions of the subnets step on one image.  Lets `reference_conv` and the port
+    be compared like for like; the multi-threaded `value` above covers more (the losses) on more threads."""
+    from oracle import oracle
+    prev = oracle.num_threads()
+    oracle.set_num_threads(1)
+    try:
+        used, t_total, fl_total, frac = _cpu_conv_sample(
+            lambda x, w, b: oracle.conv_forward(x, w, b), lambda x, w, y: oracle.conv_backward(x, w, y), budget_s)
+    finally:
+        oracle.set_num_threads(prev)
+    return {"value": round(frac / t_total, 5), "unit": "images/s", "cores": 1, "kind": "port",
+            "scope": "convolutions of the subnets step only (= reference_conv's scope)",
+            "gflops": round(fl_total / t_total / 1e9, 2),
+            "sample": "1 image, FPN levels %s (%.1f%% of the pixels, scaled by pixel share), 1 thread, %.1f s" % (
+                "+".join(reversed(used)), 100 * frac, t_total)}
+
+
+def cpu_reference_conv(budget_s=25.0):
+    """The reference's OWN CPU operators for the convolutions of the subnets step:
+    oracle/_ref/libref_conv.so = ConvOp / ConvGradientOp<float, CPUContext> (conv_op_impl.h:31-202,
+    358-577: per-image im2col + Eigen GEMM, one thread as the reference builds them) compiled from
+    /root/reference by oracle/build_ref_conv.sh.  One image; every convolution a step runs on it (student
+    towers + predictors forward and gradient, teacher forward) on the FPN levels from the coarsest
+    upwards for as long as the budget lasts.  None when the library was not built."""
+    from oracle import oracle
+    if oracle.load_ref_conv() is None:
+        return None
+    used, t_total, fl_total, frac = _cpu_conv_sample(oracle.ref_conv_forward, oracle.ref_conv_backward, budget_s)
     return {"value": round(frac / t_total, 5), "unit": "images/s", "cores": 1, "kind": "reference",
+            "scope": "convolutions of the subnets step only",
             "gflops": round(fl_total / t_total / 1e9, 2),
             "sample": "1 image, the convolutions of the subnets step only (no losses, no backbone): student towers + "
                       "predictors forward and gradient, teacher forward, FPN levels %s (%.1f%% of the pixels, scaled by "
@@ -226,6 +253,8 @@ def cpu_baseline(args, cfg):
     out = {
         "value": round(frac / dt, 5), "unit": "images/s", "cores": oracle.num_threads(),
         "kind": "port",
+        "scope": "subnets + losses (no backbone); like-for-like with the reference's operators: port_conv_1thread vs "
+                 "reference_conv (same scope, both 1 thread)",
         "sample": "1 image, subnets+losses only (no backbone), FPN levels %s of 5 (%.1f%% of "
                   "the pixels, scaled by pixel share), OpenMP im2col+GEMM oracle, %.1f s" % (
                       "P3-P7" if len(shapes) == 5 else "P4-P7", 100 * frac, dt)}
@@ -233,6 +262,10 @@ def cpu_baseline(args, cfg):
         out["reference_conv"] = cpu_reference_conv()
     except Exception as e:          # the checker library is optional on the box
         out["reference_conv"] = {"error": repr(e)}
+    try:
+        out["port_conv_1thread"] = cpu_port_conv()
+    except Exception as e:
+        out["port_conv_1thread"] = {"error": repr(e)}
     return out
 
 

@@ -58,7 +58,10 @@ constexpr int STAGE = GM * SY + GC * SX; // floats per stage
 constexpr unsigned kOOB = 0x80000000u;
 
 // WGRAD_ABLATE (debug builds only, results are wrong): 1 = no staging DMA inside the loop, 2 = raw values
-// instead of B^T d B / A d A^T, 4 = no per-unit barrier, 8 = no operand reads inside the loop
+// instead of B^T d B / A d A^T, 4 = no per-unit barrier, 8 = no operand reads inside the loop,
+// 16 = the work of an F(3x3, 2x4) engine per 16 pixels emulated on this skeleton (round 6 prediction): 24 of the 32
+// MFMAs of a k-step and 24 more transform operations (F(4,3)'s 6-point transforms: 160 VALU per 48 MFMAs against
+// 56 per 32 here), same staging traffic per pixel -- a LOWER bound on what such an engine would take
 #ifndef WGRAD_ABLATE
 #define WGRAD_ABLATE 0
 #endif
@@ -312,6 +315,12 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
         }
         }
       }
+      if (WGRAD_ABLATE & 16) {
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+          for (int k = 0; k < 12; ++k) v[k] = fmaf(v[(k + 5) % 12], 0.5f, v[k]);
+      }
       // ---- A operand per 16-channel group: raw 2x2 -> A d A^T without the signs of
       //      A's last row (re-applied by the reduce kernel) ----
 #pragma unroll
@@ -324,8 +333,9 @@ __global__ __launch_bounds__(kBlock, 1) void wino_wgrad_kernel(const GArgs args)
           const float dm[4] = {p[i], (WGRAD_ABLATE & 2) ? q[i] : p[i] + q[i], (WGRAD_ABLATE & 2) ? p[i] : p[i] - q[i], q[i]};
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[i * 4 + j][mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(dm[j], v[i * 4 + j],
-                                                                      acc[i * 4 + j][mg], 0, 0, 0);
+            if (!(WGRAD_ABLATE & 16) || i * 4 + j < 12)
+              acc[i * 4 + j][mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(dm[j], v[i * 4 + j],
+                                                                        acc[i * 4 + j][mg], 0, 0, 0);
         }
       }
     }

@@ -36,7 +36,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // W24_ABLATE (debug builds only, wrong results): 1 no input transform, 2 no B-operand LDS reads in the step loop,
 // 4 no filter-operand ring reloads / waits, 8 no end-of-chunk barrier, 16 no patch DMA, 32 no epilogue stores
-// 64 patch DMA issued but every lane out of range (no memory traffic), 128 filter ring loads issued out of range
+// 64 patch DMA issued but every lane out of range (no memory traffic), 128 filter ring loads issued out of range,
+// 512 every OTHER filter ring load out of range (round 6: the filter traffic of an A-operand-reuse-2 design, patch
+// traffic unchanged -- the best case of that design on this skeleton)
 // (tools/dbg/r5_w24_ablate.sh: what a chunk's time is made of)
 #ifndef W24_ABLATE
 #define W24_ABLATE 0
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino24_conv_kernel(const WArgs args
             __builtin_amdgcn_sched_barrier(0);
           }
           if (!(W24_ABLATE & 4))
-            a_load_at(ar[step & (AD - 1)], (step + AD >= STEPS || (W24_ABLATE & 128)) ? tail_voff_ab : a_voff, arsrc,
+            a_load_at(ar[step & (AD - 1)], (step + AD >= STEPS || (W24_ABLATE & 128) || ((W24_ABLATE & 512) && (step & 1))) ? ((W24_ABLATE & 512) && (step & 1) ? kOOBOff : tail_voff_ab) : a_voff, arsrc,
                       abase + (ch * STEPS + step + AD) * 1024);
           // F24 transform of chunk s + 1: two rounds of 8 channels
           if (!(W24_ABLATE & 1)) {

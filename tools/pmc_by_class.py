@@ -62,6 +62,9 @@ def class_sequences(f16=False):
                 lv16[q] = src[q]
                 lv16[q].N = 16
             launches = K.lib().ssad_conv3x3_forward_wino_launches_for(lv16, op.i[0], op.i[1], op.i[2], op.i[3])
+            if op.i[4] == 3:      # the split-operand engine: one convolution launch per call (+ its |max| / split passes)
+                seq.setdefault("conv3x3_split_kernel", []).append((op.klass, True))
+                continue
             if op.i[4] == 2:      # the F(2x4) engine: another kernel name, one launch per staging geometry
                 launches = K.lib().ssad_conv3x3_forward_wino_launches(lv16, op.i[0])
                 for k in range(launches):

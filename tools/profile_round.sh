@@ -18,7 +18,11 @@ trace() { # name, marker, title, bench args...
   rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o t -- python bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline --no-also --profile-steps 0 > $O/$name.log 2>&1
   local db=$(ls /tmp/prof_$name/*.db 2>/dev/null | head -1)
   if [ -n "$db" ]; then
-    python tools/rocpd_summary.py $db $O/$name.md --json $O/$name.json --title "$title" --marker $marker --last 5 --busy > /dev/null
+    local cls=""
+    # the subnets-only capture: rows of kernels that serve several timing classes are also split by class, so that
+    # roofline.avg_launch_ms (class 23) can be read from this file
+    [ "$name" = "bench_heads_trace" ] && cls="--classes heads"
+    python tools/rocpd_summary.py $db $O/$name.md --json $O/$name.json --title "$title" --marker $marker --last 5 --busy $cls > /dev/null
   fi
   tail -2 $O/$name.log | cut -c1-400 > $O/$name.tail; rm -f $O/$name.log
 }

@@ -19,6 +19,46 @@ def short(name):
     return name[:80]
 
 
+def class_table(rows, f16):
+    """One kernel serves several timing classes (wino24_conv_kernel: tower forward = 23, data gradients = 24, ...): the
+    launches of a subnets-only capture are told apart by their order inside a step, the way tools/pmc_by_class.py
+    attributes counters (the program of the step gives, per kernel name, the class of its 1st, 2nd, ... launch).  The
+    avg per CALL of class 23 is what bench.py reports as roofline.avg_launch_ms."""
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import pmc_by_class as P
+    from ssad_amd import program as PR
+    seq = P.class_sequences(f16)
+    steps, cur = [], []
+    for n, s, e in sorted(rows, key=lambda r: r[1]):
+        cur.append((P.short(n), e - s))
+        if cur[-1][0] == "sgd_flat_kernel":
+            steps.append(cur)
+            cur = []
+    acc, used = {}, 0
+    for st in steps:
+        per = {}
+        for n, d in st:
+            if n in seq:
+                per.setdefault(n, []).append(d)
+        if any(len(per.get(n, [])) != len(q) for n, q in seq.items()):
+            continue
+        used += 1
+        for n, q in seq.items():
+            for d, (k, first) in zip(per[n], q):
+                a = acc.setdefault(k, [n, 0, 0])
+                a[1] += int(first)
+                a[2] += d
+    out = ["", "By timing class (%d of %d captured steps matched the program's launch sequence; a call's launches are "
+           "summed):" % (used, len(steps)), "", "| class | kernel | what | calls / step | avg ms per call |", "|---|---|---|---|---|"]
+    for k in sorted(acc):
+        n, calls, tot = acc[k]
+        out.append("| %d | %s | %s | %.1f | %.4f |" % (k, n, PR.KLASS.get(k, {}).get("name", "")[:70], calls / max(used, 1),
+                                                        tot / max(calls, 1) / 1e6))
+    return out
+
+
 def main():
     args = [a for a in sys.argv[1:] if a != "--busy"]
     js = title = None
@@ -33,6 +73,9 @@ def main():
     if "--marker" in args:          # keep only the last K periods of a once-per-step kernel
         i = args.index("--marker"); marker = args[i + 1]; del args[i:i + 2]
         i = args.index("--last"); last = int(args[i + 1]); del args[i:i + 2]
+    by_class = None
+    if "--classes" in args:         # heads | heads-f16: split the rows of kernels that serve several timing classes
+        i = args.index("--classes"); by_class = args[i + 1]; del args[i:i + 2]
     db = sqlite3.connect(args[0])
     cur = db.cursor()
     rows = cur.execute("select name, start, end from kernels").fetchall()
@@ -90,6 +133,8 @@ def main():
         out["kernels"][n] = {"calls": a[0], "avg_us": a[1] / a[0] / 1e3}
     if busy_note and "--busy" in sys.argv:
         lines += busy_note
+    if by_class:
+        lines += class_table(rows, by_class == "heads-f16")
     try:
         q = ("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) "
              "from counters_collection group by 1, 2")
