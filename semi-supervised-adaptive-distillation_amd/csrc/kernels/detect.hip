@@ -8,19 +8,21 @@
 // Pipeline (all on the caller's stream, no host round trip):
 //   1. one 64-bit key per (level, anchor, class, y, x):
 //        [63:61] level order | [60:29] score bits (0 when not a candidate) | [28:0] ~index
-//      and ONE descending radix sort (hipCUB) over all levels: each level's block
-//      then starts with its candidates in score order -- the top-k are a prefix;
+//      and, per level, the pre_nms_topn LARGEST keys: a radix select (eight 8-bit passes: histogram of the
+//      digit among the keys that match the prefix found so far, then the digit in which the k-th largest
+//      lies) gives the k-th largest key exactly (keys are unique), a compaction collects the keys >= it, a
+//      rank sort orders those <= topn keys;
 //   2. decode the <= levels * pre_nms_topn survivors to boxes;
-//   3. sort them by (class, score descending);
+//   3. order them by (class, score descending) -- rank sort;
 //   4. 64 x 64 suppression bit-matrix for same-class pairs, then one workgroup per
 //      class walks its segment in score order (the serial part of greedy NMS);
-//   5. sort the survivors by score, emit the first dets_per_im.
+//   5. order the survivors by score (rank sort), emit the first dets_per_im.
 // Score ties are broken by element index (the reference's argpartition / argsort
-// leave them unspecified).  The sorts use rocPRIM's radix sort through hipCUB; the
-// selection / decode / NMS kernels are this file's.
+// leave them unspecified).  Every kernel is this file's: rounds 1-5 sorted with rocPRIM's radix sort through
+// hipCUB (the whole 8.6 M-key array of an image for the top 1000 per level); the rank sort is O(n^2) comparisons
+// on n = levels x topn <= 65 535 keys, exact and stable, a few microseconds at the reference's n = 5000.
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <math.h>
 #include <stdint.h>
 
@@ -65,6 +67,103 @@ __global__ __launch_bounds__(kT) void det_keys_kernel(const DArgs p, unsigned lo
   }
 }
 
+// ---- top-k per level: radix select -------------------------------------------------------------------------------
+struct SelState {
+  unsigned long long prefix[SSAD_MAX_LEVELS];   // the bits of the k-th largest key found so far
+  int want[SSAD_MAX_LEVELS];                    // its rank among the keys that match the prefix (1 = largest)
+  int k[SSAD_MAX_LEVELS];                       // min(topn, elements of the level)
+  int count[SSAD_MAX_LEVELS];                   // compaction cursor
+};
+
+__global__ void det_select_init_kernel(const DArgs p, SelState* st, unsigned* hist, unsigned long long* sel) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < SSAD_MAX_LEVELS) {
+    const long long E = t < p.levels ? p.estart[t + 1] - p.estart[t] : 0;
+    const int k = (int)(E < p.topn ? E : p.topn);
+    st->prefix[t] = 0; st->want[t] = k; st->k[t] = k; st->count[t] = 0;
+  }
+  if (t < SSAD_MAX_LEVELS * 256) hist[t] = 0;
+  for (int i = t; i < p.n; i += gridDim.x * blockDim.x) sel[i] = 0;   // slots past a level's k: key 0 = "not a candidate"
+}
+
+// histogram of digit (key >> shift) & 255 over the keys of level blockIdx.y whose bits above the digit equal the prefix
+__global__ __launch_bounds__(kT) void det_select_hist_kernel(const DArgs p, const unsigned long long* keys,
+                                                             const SelState* st, unsigned* hist, int shift) {
+  __shared__ unsigned h[256];
+  const int l = blockIdx.y;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned long long prefix = st->prefix[l];
+  const long long lo = p.estart[l], hi = p.estart[l + 1];
+  for (long long e = lo + (long long)blockIdx.x * kT + threadIdx.x; e < hi; e += (long long)gridDim.x * kT) {
+    const unsigned long long key = keys[e];
+    const bool match = shift >= 56 || ((key ^ prefix) >> (shift + 8)) == 0;
+    if (match) atomicAdd(&h[(unsigned)(key >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[l * 256 + threadIdx.x], h[threadIdx.x]);
+}
+
+// the digit in which the wanted key lies; one thread per level
+__global__ void det_select_pick_kernel(int levels, SelState* st, unsigned* hist, int shift) {
+  const int l = threadIdx.x;
+  if (l >= levels) return;
+  int want = st->want[l];
+  if (st->k[l] > 0) {
+    for (int d = 255; d >= 0; --d) {
+      const int c = (int)hist[l * 256 + d];
+      if (want <= c) { st->prefix[l] |= (unsigned long long)d << shift; break; }
+      want -= c;
+    }
+    st->want[l] = want;
+  }
+  for (int d = 0; d < 256; ++d) hist[l * 256 + d] = 0;
+}
+
+// the keys >= the k-th largest, in arrival order (exactly k of them: keys are unique)
+__global__ __launch_bounds__(kT) void det_select_compact_kernel(const DArgs p, const unsigned long long* keys,
+                                                                SelState* st, unsigned long long* sel) {
+  const int l = blockIdx.y;
+  if (st->k[l] == 0) return;
+  const unsigned long long kth = st->prefix[l];
+  const long long lo = p.estart[l], hi = p.estart[l + 1];
+  for (long long e = lo + (long long)blockIdx.x * kT + threadIdx.x; e < hi; e += (long long)gridDim.x * kT) {
+    const unsigned long long key = keys[e];
+    if (key >= kth) {
+      const int slot = atomicAdd(&st->count[l], 1);
+      if (slot < p.topn) sel[(long long)l * p.topn + slot] = key;
+    }
+  }
+}
+
+// Rank sort of `segs` segments of seg_len keys each (blockIdx.y = segment): out[rank] = key, rank = the number of keys
+// that precede it (descending: larger first; ascending: smaller first; equal keys in index order -- stable).  vals
+// (may be null) travel with their keys.  O(seg_len^2) comparisons through LDS tiles.
+__global__ __launch_bounds__(kT) void det_rank_sort_kernel(const unsigned long long* in, const int* vals_in, int seg_len,
+                                                           int descending, unsigned long long* out, int* vals_out) {
+  __shared__ unsigned long long tile[kT];
+  const long long base = (long long)blockIdx.y * seg_len;
+  const int i = blockIdx.x * kT + threadIdx.x;
+  const unsigned long long mine = i < seg_len ? in[base + i] : 0;
+  int rank = 0;
+  for (int j0 = 0; j0 < seg_len; j0 += kT) {
+    const int j = j0 + threadIdx.x;
+    tile[threadIdx.x] = j < seg_len ? in[base + j] : 0;
+    __syncthreads();
+    const int m = seg_len - j0 < kT ? seg_len - j0 : kT;
+    for (int u = 0; u < m; ++u) {
+      const unsigned long long o = tile[u];
+      const bool before = descending ? (o > mine) : (o < mine);
+      rank += (before || (o == mine && j0 + u < i)) ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  if (i < seg_len) {
+    out[base + rank] = mine;
+    if (vals_in) vals_out[base + rank] = vals_in[base + i];
+  }
+}
+
 // slot = l * topn + r: the r-th best element of level l
 __global__ __launch_bounds__(kT) void det_decode_kernel(const DArgs p,
                                                         const unsigned long long* keys,
@@ -72,10 +171,8 @@ __global__ __launch_bounds__(kT) void det_decode_kernel(const DArgs p,
                                                         unsigned long long* ckeys, int* cvals) {
   const int slot = blockIdx.x * kT + threadIdx.x;
   if (slot >= p.n) return;
-  const int l = slot / p.topn, r = slot - l * p.topn;
-  const long long E = p.estart[l + 1] - p.estart[l];
-  unsigned long long key = 0;
-  if (r < E) key = keys[p.estart[l] + r];
+  const int l = slot / p.topn;
+  const unsigned long long key = keys[slot];       // the level's r-th largest key (0 past its last element)
   const unsigned sb = (unsigned)((key >> 29) & 0xffffffffull);
   cvals[slot] = slot;
   if (sb == 0) {                                   // not a candidate
@@ -267,12 +364,9 @@ int make_plan(int levels, int A, int C, const int* H, const int* W, int topn, Pl
   p->total = t;
   p->n = levels * topn;
   p->words = (p->n + 63) / 64;
-  unsigned long long* k = nullptr;
-  int* v = nullptr;
-  p->sort1 = p->sort2 = p->sort3 = 0;
-  (void)hipcub::DeviceRadixSort::SortKeysDescending(nullptr, p->sort1, k, k, (int)t);
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, p->sort2, k, k, v, v, p->n);
-  (void)hipcub::DeviceRadixSort::SortKeysDescending(nullptr, p->sort3, k, k, p->n);
+  // (sort1: the selection's state + histograms; the former radix-sort scratch sizes stay in the plan as zero)
+  p->sort1 = al(sizeof(SelState)) + al(SSAD_MAX_LEVELS * 256 * sizeof(unsigned));
+  p->sort2 = p->sort3 = 0;
   return 0;
 }
 
@@ -288,7 +382,8 @@ size_t ssad_retinanet_detect_workspace_bytes(int levels, int A, int C, const int
   size_t tmp = p.sort1 > p.sort2 ? p.sort1 : p.sort2;
   if (p.sort3 > tmp) tmp = p.sort3;
   const size_t n = (size_t)p.n;
-  return 2 * al((size_t)p.total * 8) + al(tmp) + al(n * 16) + al(n * 4) + 2 * al(n * 8) +
+  const size_t ks = (size_t)p.total > n ? (size_t)p.total : n;       // keys_s holds the levels' top-k (n slots) too
+  return al((size_t)p.total * 8) + al(ks * 8) + al(tmp) + al(n * 16) + al(n * 4) + 2 * al(n * 8) +
          2 * al(n * 4) + al(n * 16) + al(n * 4) + al(n * 4) + al(n * (size_t)p.words * 8) +
          2 * al(n * 8);
 }
@@ -326,7 +421,7 @@ int ssad_retinanet_detect(
   char* w = (char*)workspace;
   auto take = [&](size_t b) { char* r = w; w += al(b); return r; };
   unsigned long long* keys = (unsigned long long*)take((size_t)pl.total * 8);
-  unsigned long long* keys_s = (unsigned long long*)take((size_t)pl.total * 8);
+  unsigned long long* keys_s = (unsigned long long*)take(((size_t)pl.total > n ? (size_t)pl.total : n) * 8);
   size_t tmp_bytes = pl.sort1 > pl.sort2 ? pl.sort1 : pl.sort2;
   if (pl.sort3 > tmp_bytes) tmp_bytes = pl.sort3;
   void* tmp = take(tmp_bytes);
@@ -347,20 +442,30 @@ int ssad_retinanet_detect(
     long long blocks = (pl.total + kT - 1) / kT;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(det_keys_kernel, dim3((unsigned)blocks), dim3(kT), 0, s, a, keys);
-    size_t tb = tmp_bytes;
-    if (hipcub::DeviceRadixSort::SortKeysDescending(tmp, tb, keys, keys_s, (int)pl.total, 0, 64,
-                                                    s) != hipSuccess)
-      return SSAD_E_BADARG;
+  }
+  // top-k per level: keys_s[l * topn + r] = the level's r-th largest key
+  {
+    SelState* st = (SelState*)tmp;
+    unsigned* hist = (unsigned*)((char*)tmp + al(sizeof(SelState)));
+    unsigned long long* sel = fkeys;             // scratch until the NMS scan claims it (stream order)
+    hipLaunchKernelGGL(det_select_init_kernel, dim3(8), dim3(kT), 0, s, a, st, hist, sel);
+    if (pl.total > 0) {
+      long long per = (pl.total / levels + kT - 1) / kT;
+      if (per > 512) per = 512;
+      if (per < 1) per = 1;
+      for (int shift = 56; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(det_select_hist_kernel, dim3((unsigned)per, (unsigned)levels), dim3(kT), 0, s, a, keys, st, hist, shift);
+        hipLaunchKernelGGL(det_select_pick_kernel, dim3(1), dim3(64), 0, s, levels, st, hist, shift);
+      }
+      hipLaunchKernelGGL(det_select_compact_kernel, dim3((unsigned)per, (unsigned)levels), dim3(kT), 0, s, a, keys, st, sel);
+    }
+    hipLaunchKernelGGL(det_rank_sort_kernel, dim3((unsigned)((pre_nms_topn + kT - 1) / kT), (unsigned)levels), dim3(kT), 0, s,
+                       sel, (const int*)nullptr, pre_nms_topn, 1, keys_s, (int*)nullptr);
   }
   const int nb = (pl.n + kT - 1) / kT;
   hipLaunchKernelGGL(det_decode_kernel, dim3(nb), dim3(kT), 0, s, a, keys_s, boxes, scores, ckeys,
                      cvals);
-  {
-    size_t tb = tmp_bytes;
-    if (hipcub::DeviceRadixSort::SortPairs(tmp, tb, ckeys, ckeys_s, cvals, cvals_s, pl.n, 0, 64,
-                                           s) != hipSuccess)
-      return SSAD_E_BADARG;
-  }
+  hipLaunchKernelGGL(det_rank_sort_kernel, dim3((unsigned)nb, 1), dim3(kT), 0, s, ckeys, cvals, pl.n, 0, ckeys_s, cvals_s);
   hipLaunchKernelGGL(det_gather_kernel, dim3(nb), dim3(kT), 0, s, pl.n, ckeys_s, cvals_s, boxes,
                      scores, sboxes, sscores, scls);
   hipLaunchKernelGGL(det_nms_mask_kernel, dim3(pl.words, pl.words), dim3(64), 0, s, pl.n, pl.words,
@@ -368,12 +473,8 @@ int ssad_retinanet_detect(
   (void)hipMemsetAsync(fkeys, 0, n * 8, s);
   hipLaunchKernelGGL(det_nms_scan_kernel, dim3(C), dim3(kT), (size_t)pl.words * 8, s, pl.n, pl.words,
                      C, scls, sscores, mask, fkeys);
-  {
-    size_t tb = tmp_bytes;
-    if (hipcub::DeviceRadixSort::SortKeysDescending(tmp, tb, fkeys, fkeys_s, pl.n, 0, 64, s) !=
-        hipSuccess)
-      return SSAD_E_BADARG;
-  }
+  hipLaunchKernelGGL(det_rank_sort_kernel, dim3((unsigned)nb, 1), dim3(kT), 0, s, fkeys, (const int*)nullptr, pl.n, 1, fkeys_s,
+                     (int*)nullptr);
   hipLaunchKernelGGL(det_emit_kernel, dim3((dets_per_im + kT - 1) / kT), dim3(kT), 0, s, pl.n,
                      dets_per_im, fkeys_s, sboxes, scls, dets_out, count_out);
   return (int)hipGetLastError();
