@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-per-gpu", type=int, default=16)
-    ap.add_argument("--workload", default=os.environ.get("SSAD_BENCH_WORKLOAD", "full"),
+    ap.add_argument("--workload", default="full",
                     choices=["heads", "full"])
     # BASELINE config 3 by default; config 5: --student r101 --teacher x101-64x4d --px 500
     # --precision f16
@@ -292,7 +292,7 @@ def make_workload(args, dev, world, pg, rank):
     # every precision runs on native programs of this repo's kernels by default ("harness" = round
     # 1's PyTorch backbones, kept under tools/ for A/B runs)
     native = args.workload == "full" and (args.backbone == "native" or (args.backbone == "auto" and native_ok))
-    hkw = dict(blocked_io=True) if (f16 and native and os.environ.get("SSAD_F16_BACKBONE", "1") == "1") else {}
+    hkw = dict(blocked_io=True) if (f16 and native and True) else {}
     heads = (DistillHeadsF16 if f16 else DistillHeads)(cfg, N=N, shapes=shapes, device=dev,
                          student_init=synth.head_params(np.random.default_rng(1)),
                          teacher_init=synth.head_params(np.random.default_rng(2)) if distill else None,
@@ -534,8 +534,8 @@ def main():
     # The step's critical path is the stream step() is called on (student forward, subnets, data gradients); the
     # teacher, the filter gradients and the collectives run on other streams and fill the chip beside it.
     # The step therefore runs on a high-priority stream (HIP has two levels: 0 and -1): config 3 94.3 -> 93.3 ms,
-    # config 5 26.7 -> 26.5 ms in same-call A/B (tools/dbg/main_prio_ab.sh); SSAD_MAIN_PRIORITY=0: the default stream.
-    _prio = int(os.environ.get("SSAD_MAIN_PRIORITY", "-1"))
+    # config 5 26.7 -> 26.5 ms in same-call A/B (round 4).
+    _prio = -1
     if _prio:
         _main = torch.cuda.Stream(priority=_prio)
         _main.wait_stream(torch.cuda.current_stream())

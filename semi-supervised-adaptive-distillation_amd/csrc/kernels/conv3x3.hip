@@ -631,10 +631,6 @@ int ssad_conv3x3_forward(const ssad_conv_level* levels_host, int n_levels,
   if (n_levels < 1 || n_levels > SSAD_MAX_CONV_PROBLEMS || Cout <= 0 || Cin <= 0)
     return SSAD_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  static const int variant = [] {
-    const char* e = getenv("SSAD_CONV_VARIANT");
-    return e ? atoi(e) : -1;
-  }();
   if (Cout <= 64)
     return launch_fwd<2, 4, 2, true>(levels_host, n_levels, packed, bias, Cout, Cin, flags, s);
   // patch = 8 rows (PT = 4) or 4 rows (PT = 2): pick the one whose workgroup
@@ -654,14 +650,9 @@ int ssad_conv3x3_forward(const ssad_conv_level* levels_host, int n_levels,
     };
     use_pt2 = makespan(t2, 0.52) < makespan(t4, 1.0);
   }
-  if (variant >= 0) use_pt2 = variant & 1;
-  const bool fence = variant >= 0 ? ((variant >> 1) & 1) : true;
-  if (use_pt2) {
-    if (fence) return launch_fwd<8, 1, 2, true>(levels_host, n_levels, packed, bias, Cout, Cin, flags, s);
-    return launch_fwd<8, 1, 2, false>(levels_host, n_levels, packed, bias, Cout, Cin, flags, s);
-  }
-  if (fence) return launch_fwd<8, 1, 4, true>(levels_host, n_levels, packed, bias, Cout, Cin, flags, s);
-  return launch_fwd<8, 1, 4, false>(levels_host, n_levels, packed, bias, Cout, Cin, flags, s);
+  // (TAP_FENCE on: 5-10 % faster than free scheduling, round 1; the unfenced instantiations are gone)
+  if (use_pt2) return launch_fwd<8, 1, 2, true>(levels_host, n_levels, packed, bias, Cout, Cin, flags, s);
+  return launch_fwd<8, 1, 4, true>(levels_host, n_levels, packed, bias, Cout, Cin, flags, s);
 }
 
 static int wgrad_plan(const ssad_conv_level* lv, int n_levels, int Cout, int Cin, WgArgs* a) {

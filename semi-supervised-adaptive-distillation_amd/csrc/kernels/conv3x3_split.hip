@@ -638,8 +638,7 @@ int ssad_conv3x3_forward_split(const ssad_conv_level* lv, int n_levels, const fl
   hipLaunchKernelGGL(split_pack_act_kernel, dim3((unsigned)pblocks), dim3(kThreads), 0, stream, pt);
   q.items = cdiv(tiles, 8) * 8 * q.mblocks;
   const int cus = ssad_cu_count();
-  static const int grid_all = [] { const char* e = getenv("SSAD_SPLIT_GRID_ALL"); return e ? atoi(e) : 0; }();   // debug
-  const unsigned grid = (unsigned)((q.items < cus || grid_all) ? q.items : cus);
+  const unsigned grid = (unsigned)(q.items < cus ? q.items : cus);
   if (flags & SSAD_CONV_MASK_AUX)
     hipLaunchKernelGGL((conv3x3_split_kernel<true>), dim3(grid), dim3(kThreads), 0, stream, q);
   else

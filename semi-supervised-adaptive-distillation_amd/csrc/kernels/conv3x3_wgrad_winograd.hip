@@ -479,7 +479,6 @@ int ssad_wino_wgrad_launch(const ssad_conv_level* lv, int n_levels, float* dW, i
   }
   {
     // runs of one whole split per XCD when that divides evenly, else the largest common run length
-    static const int force = [] { const char* e = getenv("SSAD_WGRAD_XCD_GROUP"); return e ? atoi(e) : 0; }();
     const int pairs = a.mblocks * a.cblocks, total = pairs * a.splits;
     int g = 1;
     if ((total & 7) == 0) {
@@ -487,7 +486,7 @@ int ssad_wino_wgrad_launch(const ssad_conv_level* lv, int n_levels, float* dW, i
       while (y) { const int t = x % y; x = y; y = t; }       // gcd(total / 8, pairs)
       g = x;
     }
-    a.xcd_group = force > 0 ? force : g;
+    a.xcd_group = g;
     hipLaunchKernelGGL(wino_wgrad_kernel, dim3(total), dim3(kBlock), 0, stream, a);
   }
   hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(Cin, 64), Cout), dim3(256), 0,

@@ -8,18 +8,16 @@
 // 16 element-wise products summed over input channels, i.e. 16 independent
 // [Cout x Cin] x [Cin x tiles] GEMMs that run on v_mfma_f32_16x16x4_f32.
 //
-// Two kernels share the data layout (8 wavefronts = 128 output channels x one
+// The data layout (8 wavefronts = 128 output channels x one
 // 8x16-pixel output patch = 4 x 8 tiles; per KC-channel chunk the 10x18 raw
 // patch goes to LDS, B^T d B turns it into V[xi][channel][tile], and each wave
 // (16 output channels x 32 tiles x 16 xi = 128 accumulator VGPRs) issues 8*KC
 // MFMAs whose A operand is a linear 16-byte-per-lane stream from the
 // pre-packed filter and whose B operands are `ds_read_b64 base+imm` of V):
-//   wino_conv_kernel    one workgroup per tile, register-staged raw patch,
-//                       transform burst.  (SSAD_WINO_VARIANT=0, kept as the
-//                       simple reference implementation of the engine)
-//   wino_conv_z_kernel  the default: persistent workgroups,
-//                       LDS-DMA staging, transform / staging / tile bookkeeping
-//                       threaded through the MFMA steps (see its header).
+//   wino_conv_z_kernel  persistent workgroups, LDS-DMA staging, transform / staging / tile
+//                       bookkeeping threaded through the MFMA steps (see its header).
+//                       (rounds 1-5 kept a non-persistent one-workgroup-per-tile kernel beside it
+//                       as a reference implementation; retired in round 6 with its switch)
 // The epilogue applies A^T M A lane-locally (the 16 xi accumulators of one
 // (channel, tile) sit in the same lane/register slot), then bias / ReLU /
 // Sigmoid / ReLU-gradient mask as the direct kernel.
@@ -165,218 +163,6 @@ struct WArgs {
   float* split_ws;        // [grid][BM * 128] partial outputs, one slot per unit
   unsigned* split_tickets;   // [grid] arrival counters, zero between launches
 };
-
-__global__ __launch_bounds__(kBlock, 2) void wino_conv_kernel(const WArgs args) {
-  __shared__ float raw[2 * RAW];
-  __shared__ float vbuf[2 * VBUF];
-
-  int l = 0;
-#pragma unroll
-  for (int i = 1; i < SSAD_MAX_CONV_PROBLEMS; ++i)
-    if (i < args.n_levels && (int)blockIdx.x >= args.lv[i].block_start) l = i;
-  const WLevel& L = args.lv[l];
-  const int H = L.H, W = L.W, HW = H * W;
-  int pid = blockIdx.x - L.block_start;
-  const int per_img = L.tiles_x * L.tiles_y;
-  const int n = pid / per_img;
-  pid -= n * per_img;
-  const int ty0 = pid / L.tiles_x, tx0 = pid - ty0 * L.tiles_x;
-  const int y0 = ty0 * PR, x0 = tx0 * PC;
-  const int K = args.K, M = args.M;
-  const float* xin = L.x + (long long)n * K * HW;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mt = blockIdx.y * (BM / 16) + wave;
-  const bool active = mt * 16 < M;
-
-  // ---- raw staging map ------------------------------------------------------
-  constexpr int STAGE = KC * (PR + 2) * (PC + 2);      // 1440
-  constexpr int SITER = cdiv(STAGE, kBlock);           // 3
-  constexpr unsigned kOOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t xrsrc = uniform_rsrc(xin, K * HW * 4);
-  int s_lds[SITER];
-  unsigned s_voff[SITER];
-#pragma unroll
-  for (int it = 0; it < SITER; ++it) {
-    const int e = tid + it * kBlock;
-    const int c = e / ((PR + 2) * (PC + 2));
-    const int rem = e - c * ((PR + 2) * (PC + 2));
-    const int r = rem / (PC + 2), q = rem - r * (PC + 2);
-    const int gy = y0 - 1 + r, gx = x0 - 1 + q;
-    const bool ok = (e < STAGE) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    s_lds[it] = (e < STAGE) ? c * RS + r * RP + q : -1;
-    s_voff[it] = ok ? (unsigned)((c * HW + gy * W + gx) * 4) : kOOB;
-  }
-  const int chunk_bytes = KC * HW * 4;
-  float sreg[SITER];
-  auto stage_load = [&](int ch) {
-    const int soff = __builtin_amdgcn_readfirstlane(ch * chunk_bytes);
-#pragma unroll
-    for (int it = 0; it < SITER; ++it)
-      sreg[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-          xrsrc, s_voff[it], soff, 0));
-  };
-  auto stage_store = [&](float* buf) {
-#pragma unroll
-    for (int it = 0; it < SITER; ++it)
-      if (s_lds[it] >= 0) buf[s_lds[it]] = sreg[it];
-  };
-
-  // ---- input transform map: thread = (half, channel mod 8, tile), KC/8 rounds ----
-  const int t_tile = tid & 31, t_c = (tid >> 5) & 7, t_half = tid >> 8;
-  const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
-  const int t_src = t_c * RS + (2 * t_ty + t_half) * RP + 2 * t_tx;   // rows half..half+2
-  // tile t is stored at (t & 15) * 2 + (t >> 4): the two tile groups a lane
-  // feeds to its MFMAs are adjacent, one ds_read_b64 fetches both
-  const int t_dst = (t_half * 8 * KC + t_c) * VP + (t_tile & 15) * 2 + (t_tile >> 4);   // xi = 8*half + ...
-  auto transform = [&](const float* rb0, float* vb0) {
-#pragma unroll
-   for (int rnd = 0; rnd < KC / 8; ++rnd) {
-    const float* rb = rb0 + rnd * 8 * RS;
-    float* vb = vb0 + rnd * 8 * VP;
-    float d[3][4];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) d[i][j] = rb[t_src + i * RP + j];
-    // B^T d: half 0 -> rows {d0-d2, d1+d2}; half 1 -> rows {d2-d1, d1-d3}
-    // (with this thread's d[0..2] = patch rows half..half+2)
-    float t[2][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (t_half == 0) { t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; }
-      else             { t[0][j] = d[1][j] - d[0][j]; t[1][j] = d[0][j] - d[2][j]; }
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      float* o = vb + t_dst + a * 4 * KC * VP;
-      o[0 * KC * VP] = t[a][0] - t[a][2];
-      o[1 * KC * VP] = t[a][1] + t[a][2];
-      o[2 * KC * VP] = t[a][2] - t[a][1];
-      o[3 * KC * VP] = t[a][1] - t[a][3];
-    }
-   }
-  };
-
-  // ---- MFMA operands -------------------------------------------------------------
-  const int kq = lane >> 4, jn = lane & 15;
-  const float* bbase = vbuf + kq * VP + jn * 2;
-  const float4* astream = reinterpret_cast<const float4*>(L.packed) +
-                          (long long)(active ? mt : 0) * args.chunks * STEPS * 64 + lane;
-
-  f32x4 acc[16][2];
-#pragma unroll
-  for (int x = 0; x < 16; ++x)
-#pragma unroll
-    for (int g = 0; g < 2; ++g) acc[x][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- prologue: raw[0] staged + transformed, raw[1] staged ------------------------
-  const int chunks = args.chunks;
-  stage_load(0);
-  stage_store(raw);
-  if (chunks > 1) stage_load(1);
-  __syncthreads();
-  transform(raw, vbuf);
-  if (chunks > 1) stage_store(raw + RAW);
-  __syncthreads();
-
-  float4 a0 = astream[0], a1 = astream[64], a2 = astream[128];
-  for (int ch = 0; ch < chunks; ++ch) {
-    // global loads for chunk ch+2 (land during this chunk's MFMAs)
-    if (ch + 2 < chunks) stage_load(ch + 2);
-    // transform chunk ch+1 (staged into raw[(ch+1)&1] one iteration ago)
-    if (ch + 1 < chunks) transform(raw + ((ch + 1) & 1) * RAW, vbuf + ((ch + 1) & 1) * VBUF);
-    if (active) {
-      const float* vb = bbase + (ch & 1) * VBUF;
-      // B operands are double-buffered in registers: the four LDS reads of
-      // step+1 are issued before the eight MFMAs of step, so a 32-cycle MFMA
-      // never waits on an LDS round trip.
-      float bc[4][2], bn[4][2];
-#pragma unroll
-      for (int xr = 0; xr < 4; ++xr) {
-        const float2 b2 = *reinterpret_cast<const float2*>(vb + (xr * KC) * VP);
-        bc[xr][0] = b2.x; bc[xr][1] = b2.y;
-      }
-#pragma unroll
-      for (int step = 0; step < STEPS; ++step) {       // step = ks*4 + xq
-        const float4 a3 = astream[(long long)(ch * STEPS + step + 3) * 64];
-        if (step < STEPS - 1) {
-          const int ks = (step + 1) >> 2, xq = (step + 1) & 3;
-#pragma unroll
-          for (int xr = 0; xr < 4; ++xr) {
-            const float2 b2 = *reinterpret_cast<const float2*>(vb + ((xq * 4 + xr) * KC + ks * 4) * VP);
-            bn[xr][0] = b2.x; bn[xr][1] = b2.y;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const int xq = step & 3;
-        const float av[4] = {a0.x, a0.y, a0.z, a0.w};
-#pragma unroll
-        for (int xr = 0; xr < 4; ++xr) {
-          const int xi = xq * 4 + xr;
-#pragma unroll
-          for (int g = 0; g < 2; ++g)
-            acc[xi][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[xr], bc[xr][g], acc[xi][g], 0, 0, 0);
-        }
-        a0 = a1; a1 = a2; a2 = a3;
-        if (step < STEPS - 1) {
-#pragma unroll
-          for (int xr = 0; xr < 4; ++xr)
-#pragma unroll
-            for (int g = 0; g < 2; ++g) bc[xr][g] = bn[xr][g];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    // raw[ch&1] was consumed by the transform of iteration ch-1: refill it
-    if (ch + 2 < chunks) stage_store(raw + (ch & 1) * RAW);
-    __syncthreads();
-  }
-  if (!active) return;
-
-  // ---- epilogue: Y = A^T M A, lane-local ----------------------------------------------
-  const int flags = args.flags;
-  float* yout = L.y + (long long)n * M * HW;
-  const float* aux = (flags & SSAD_CONV_MASK_AUX) ? L.aux + (long long)n * M * HW : nullptr;
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int tile = g * 16 + jn;
-    const int py = y0 + 2 * (tile >> 3), px = x0 + 2 * (tile & 7);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = mt * 16 + kq * 4 + r;
-      if (m >= M) continue;
-      float t[2][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float m0 = acc[j][g][r], m1 = acc[4 + j][g][r], m2 = acc[8 + j][g][r],
-                    m3 = acc[12 + j][g][r];
-        t[0][j] = m0 + m1 + m2;
-        t[1][j] = m1 - m2 - m3;
-      }
-      const float bias = L.bias ? L.bias[m] : 0.0f;
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        float v[2] = {t[a][0] + t[a][1] + t[a][2] + bias, t[a][1] - t[a][2] - t[a][3] + bias};
-        const int yy = py + a;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int xx = px + b;
-          if (yy < H && xx < W) {
-            float o = v[b];
-            if (flags & SSAD_CONV_RELU) o = o > 0.0f ? o : 0.0f;
-            if (flags & SSAD_CONV_SIGMOID) o = 1.0f / (1.0f + expf(-o));
-            const int off = m * HW + yy * W + xx;
-            if (aux) o = aux[off] > 0.0f ? o : 0.0f;
-            yout[off] = o;
-          }
-        }
-      }
-    }
-  }
-}
 
 constexpr int NRAW = 3;
 constexpr unsigned kOOBOff = 0x80000000u;
@@ -1138,8 +924,6 @@ static int split_plan(long long total, int chunks, int cus, long long* full, lon
   *tail = total - *full;
   int p = 1;
   while (*tail > 0 && p * 2 <= 8 && *tail * (p * 2) <= cus && chunks % (p * 2) == 0 && chunks / (p * 2) >= 2) p *= 2;
-  static const int force = [] { const char* e = getenv("SSAD_WINO_SPLIT_FORCE_P"); return (e && *e) ? atoi(e) : 0; }();
-  if (force > 0 && *tail > 0 && *tail * force <= cus && chunks % force == 0) p = force;      // debugging aid
   return p;
 }
 
@@ -1221,8 +1005,6 @@ static bool level_wants_pairs(int N, int H, int W) {
 // attributes counters to timing classes by launch order
 int ssad_conv3x3_forward_wino_launches(const ssad_conv_level* lv, int n_levels) {
   if (!lv || n_levels < 1) return 0;
-  static const int variant = [] { const char* e = getenv("SSAD_WINO_VARIANT"); return e ? atoi(e) : 2; }();
-  if (variant != 2) return 1;
   int with_pairs = 0, with_patches = 0;
   for (int l = 0; l < n_levels; ++l) {
     if ((long long)lv[l].N * lv[l].H * lv[l].W == 0) continue;
@@ -1234,9 +1016,7 @@ int ssad_conv3x3_forward_wino_launches(const ssad_conv_level* lv, int n_levels) 
 // ... and with the split tails of this (Cout, Cin): + 1 per geometry whose partial round is split
 int ssad_conv3x3_forward_wino_launches_for(const ssad_conv_level* lv, int n_levels, int Cout, int Cin, int flags) {
   if (!lv || n_levels < 1 || Cout <= 0 || Cin <= 0) return 0;
-  static const int variant = [] { const char* e = getenv("SSAD_WINO_VARIANT"); return e ? atoi(e) : 2; }();
-  if (variant != 2) return 1;
-  static const int nhalf = [] { const char* e = getenv("SSAD_WINO_NHALF"); return (e && *e) ? atoi(e) : 1; }();
+  constexpr int nhalf = 1;
   const bool half = nhalf && Cout <= 64;
   const int cus = ssad_cu_count();
   int launches = 0;
@@ -1279,9 +1059,8 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
     if ((long long)lv[l].N * lv[l].H * lv[l].W * (Cin > Cout ? Cin : Cout) >= (1LL << 29)) return SSAD_E_BADARG;
     if ((flags & SSAD_CONV_MASK_AUX) && !lv[l].aux) return SSAD_E_BADARG;
   }
-  static const int variant = [] { const char* e = getenv("SSAD_WINO_VARIANT"); return e ? atoi(e) : 2; }();
   // pass 0: the levels staged as 8 x 16 patches; pass 1: those staged as sub-patch pairs (persistent kernel
-  // only; SSAD_WINO_VARIANT=0, the non-persistent kernel, takes every level in pass 0)
+  // only)
   for (int pass = 0; pass < 2; ++pass) {
     const bool use_pairs = pass == 1;
     WArgs a;
@@ -1291,7 +1070,7 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
     long long blocks = 0, pairs = 0;
     for (int l = 0; l < n_levels; ++l) {
       if ((long long)lv[l].N * lv[l].H * lv[l].W == 0) continue;
-      if (variant == 2 ? level_wants_pairs(lv[l].N, lv[l].H, lv[l].W) != use_pairs : use_pairs) continue;
+      if (level_wants_pairs(lv[l].N, lv[l].H, lv[l].W) != use_pairs) continue;
       WLevel& L = a.lv[nl++];
       L.x = lv[l].x; L.y = lv[l].y; L.aux = lv[l].aux;
       L.packed = lv[l].packed ? lv[l].packed : packed;
@@ -1308,17 +1087,16 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
     if (nl == 0) continue;
     a.n_levels = nl;
     for (int l = nl; l < SSAD_MAX_CONV_PROBLEMS; ++l) a.lv[l] = WLevel{};
-    if (variant == 2) {   // any Cin: channels past Cin read as zero (buffer range check, zero-padded filter)
+    {   // any Cin: channels past Cin read as zero (buffer range check, zero-padded filter)
       const int cus2 = ssad_cu_count();
       a.patches = (int)(use_pairs ? pairs : blocks);
       const long long total = (long long)a.patches * a.mblocks;
       if (total >= (1LL << 31)) return SSAD_E_BADARG;
       long long grid = total < cus2 ? total : cus2;
       if (grid * ZNT < total) grid = (total + ZNT - 1) / ZNT;
-      // SSAD_WINO_XCD_GROUP: tiles per XCD run (1 = round 2's round-robin order).  (Non-temporal output stores,
-      // SSAD_WINO_NT in earlier rounds, measured +-0 and are gone.)
-      static const int xg = [] { const char* e = getenv("SSAD_WINO_XCD_GROUP"); return e ? atoi(e) : 8; }();
-      static const int nhalf = [] { const char* e = getenv("SSAD_WINO_NHALF"); return (e && *e) ? atoi(e) : 1; }();
+      // tiles per XCD run: 8 (1 = round 2's round-robin order: +4 %, profiles/r03_pmc_classes_roundrobin.md)
+      constexpr int xg = 8;
+      constexpr int nhalf = 1;
       a.xcd_group = xg;
       const bool half = nhalf && Cout <= 64;
       // Split tail (round 5, the kernel's header): the items of the last, partial round are cut along the
@@ -1339,10 +1117,9 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
         const int p = split_plan(total, a.chunks, cus2, &full, &tail);
         void* ws = nullptr;
         unsigned* tk = nullptr;
-        static const bool force1 = getenv("SSAD_WINO_SPLIT_FORCE_P") != nullptr;
         // setting 1 (default): only launches WITHOUT a full round are split -- there the units replace the launch, no
         // second kernel; setting 2: also the partial round behind full rounds, as a second launch
-        if ((p >= 2 || (force1 && tail > 0)) && (split_on >= 2 || full == 0) &&
+        if (p >= 2 && (split_on >= 2 || full == 0) &&
             split_scratch((hipStream_t)stream, cus2, &ws, &tk) == 0) {
           parts = p;
           a.items = (int)full;
@@ -1367,12 +1144,6 @@ int ssad_conv3x3_forward_wino(const ssad_conv_level* lv, int n_levels, const flo
         if (use_pairs) hipLaunchKernelGGL((wino_conv_z_kernel<true, false, true>), t3, b3, 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((wino_conv_z_kernel<false, false, true>), t3, b3, 0, (hipStream_t)stream, a);
       }
-    } else {
-      // SSAD_WINO_VARIANT=0: the non-persistent kernel
-      a.patches = (int)blocks;
-      a.xcd_group = 1;
-      hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)blocks, cdiv(Cout, BM)), dim3(kBlock), 0,
-                         (hipStream_t)stream, a);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

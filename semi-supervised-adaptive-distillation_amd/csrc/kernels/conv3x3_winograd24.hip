@@ -39,7 +39,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // 64 patch DMA issued but every lane out of range (no memory traffic), 128 filter ring loads issued out of range,
 // 512 every OTHER filter ring load out of range (round 6: the filter traffic of an A-operand-reuse-2 design, patch
 // traffic unchanged -- the best case of that design on this skeleton)
-// (tools/dbg/r5_w24_ablate.sh: what a chunk's time is made of)
+// (tools/dbg/w24_ablate.sh: what a chunk's time is made of)
 #ifndef W24_ABLATE
 #define W24_ABLATE 0
 #endif

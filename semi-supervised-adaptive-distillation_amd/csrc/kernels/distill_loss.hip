@@ -913,7 +913,7 @@ int build_args(const ssad_distill_level* lv, int n_levels,
     const long long chunks = units > 0 ? (units + (1LL << shift) - 1) >> shift : 0;
     // class groups: >= 4 iterations per thread, about C/4 classes per item
     const int cl = kThreads >> shift;
-    static const int cg_want = [] { const char* e = getenv("SSAD_LOSS_CGROUPS"); return e ? atoi(e) : 4; }();
+    constexpr int cg_want = 4;        // (sweep: tools/loss_sweep.py, round 2)
     int cper = (P->num_classes + cg_want - 1) / cg_want;
     if (cper < 4 * cl) cper = 4 * cl;
     cper = (cper + cl - 1) / cl * cl;
@@ -928,7 +928,7 @@ int build_args(const ssad_distill_level* lv, int n_levels,
   // distribute at most kMaxBlocks blocks proportionally to the work
   // tuning override, clamped: the workspace holds kMaxBlocks partial slots (the fused kernel's
   // focal partials start at slot kMaxBlocks) and every level owns at least one block
-  static const int max_blocks_env = [] { const char* e = getenv("SSAD_LOSS_MAXBLOCKS"); return e ? atoi(e) : kMaxBlocks; }();
+  constexpr int max_blocks_env = kMaxBlocks;
   const int lo = 2 * n_levels + 1;
   const int max_blocks = max_blocks_env > kMaxBlocks ? kMaxBlocks : (max_blocks_env < lo ? lo : max_blocks_env);
   int start = 0;

@@ -723,10 +723,8 @@ int ssad_conv_implicit_gemm_ws(const ssad_gemm_conv* d, int C, int H, int W, int
       (long long)K * d->lda * 4 >= (1LL << 31))
     return SSAD_E_BADARG;
   {
-    // the ResNet stem has its own kernel (stem.hip: raw patch staged once in LDS instead of a 12x im2col gather);
-    // SSAD_STEM_ENGINE=gemm keeps it on the general path
-    static const bool stem_fast = [] { const char* e = getenv("SSAD_STEM_ENGINE"); return !(e && e[0] == 'g'); }();
-    if (stem_fast && C == 3 && kernel == 7 && stride == 2 && pad == 3 && d->M == 64 && !d->bias && !d->residual &&
+    // the ResNet stem has its own kernel (stem.hip: raw patch staged once in LDS instead of a 12x im2col gather)
+    if (C == 3 && kernel == 7 && stride == 2 && pad == 3 && d->M == 64 && !d->bias && !d->residual &&
         !d->mask && d->flags == 0)
       return ssad_stem7x7s2_launch(d->x, d->a, d->lda, d->N, H, W, d->y, (hipStream_t)stream);
   }

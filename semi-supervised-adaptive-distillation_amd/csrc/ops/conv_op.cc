@@ -127,8 +127,7 @@ static bool PointwiseGemmEligible(const ConvGeometry& g, int N, int C, int M, in
 static bool ImplicitGemmEligible(const ConvGeometry& g, int N, int C, int H, int W, int M, int P) {
   static const bool off = [] {
     const char* e = getenv("SSAD_CONV1X1_ENGINE");
-    const char* f = getenv("SSAD_CONV_IMPLICIT");
-    return (e && std::string(e) == "blas") || (f && std::string(f) == "0");
+    return e && std::string(e) == "blas";
   }();
   if (off || g.group != 1 || g.kernel[0] != g.kernel[1] || g.dilation != vector<int>{1, 1}) return false;
   if (g.stride[0] != g.stride[1] || g.stride[0] < 1) return false;
@@ -287,8 +286,8 @@ bool ConvGradientOp<float, HIPContext>::RunDefaultEngine() {
     // flattened into the GEMM's column index, filter gradient on the nt GEMM kernel (deterministic split
     // reduction), data gradient = nn GEMM + gather-form col2im (kernels/conv_strided.hip).  The per-image loop
     // below (conv_op_impl.h:451-560 as written) stays for grouped / dilated / rectangular / asymmetric geometries;
-    // SSAD_CONVGRAD_ENGINE=im2col forces it.
-    static const bool batched = [] { const char* e = getenv("SSAD_CONVGRAD_ENGINE"); return !(e && e[0] == 'i'); }();
+    // (rounds 3-5 could force the per-image path with an environment switch; retired)
+    constexpr bool batched = true;
     const bool square = kh == kw && geom_.stride[0] == geom_.stride[1] && geom_.dilation == vector<int>{1, 1} &&
                         geom_.pads[0] == geom_.pads[1] && geom_.pads[0] == geom_.pads[2] &&
                         geom_.pads[0] == geom_.pads[3];

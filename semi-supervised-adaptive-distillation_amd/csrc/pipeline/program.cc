@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -70,6 +71,9 @@ AuxStreams* aux_streams(hipError_t* why) {
   if (it != per_device.end()) return it->second;
   AuxStreams* a = new AuxStreams();
   for (int k = 0; k < SSAD_MAX_AUX_STREAMS; ++k) {
+    // (Round 6 measured the step with these streams confined to n compute units, hipExtStreamCreateWithCUMask:
+    // 86.0 ms free-for-all, 90.3 at 192 CUs, 95.3 at 128, 109.5 at 96 -- profiles/r06_experiments.md.  The filter
+    // gradients do not lose to sharing, they live off it; the switch is gone again.)
     err = hipStreamCreateWithFlags(&a->s[k], hipStreamNonBlocking);
     if (err != hipSuccess) {
       for (int j = 0; j < k; ++j) (void)hipStreamDestroy(a->s[j]);

@@ -18,5 +18,5 @@ for ab in 0 512 128 4; do
   /opt/rocm/bin/hipcc $FLAGS -DW24_ABLATE=$ab -c kernels/conv3x3_winograd24.hip -o build/kernels/conv3x3_winograd24.o || exit 1
   link
   echo "== W24_ABLATE=$ab"
-  (cd $R && timeout 300 python tools/dbg/r5_w24_time.py 2>&1 | grep -v amdgpu.ids | head -2)
+  (cd $R && timeout 300 python tools/dbg/w24_time.py 2>&1 | grep -v amdgpu.ids | head -2)
 done
