@@ -114,7 +114,8 @@ def kernel_report(classes, steps):
 
 
 # which kernel source a timing class's dominant kernel lives in (for the staleness check of `traffic`)
-_KERNEL_SOURCE = {"wino_conv_z_kernel": "conv3x3_winograd.hip", "wino24_conv_kernel": "conv3x3_winograd24.hip", "wino_wgrad_kernel": "conv3x3_wgrad_winograd.hip",
+_KERNEL_SOURCE = {"wino_conv_z_kernel": "conv3x3_winograd.hip", "wino24_conv_kernel": "conv3x3_winograd24.hip",
+                  "conv3x3_split_kernel": "conv3x3_split.hip", "wino_wgrad_kernel": "conv3x3_wgrad_winograd.hip",
                   "pow_sum_kernel": "distill_loss.hip", "cls_losses_fused_kernel": "distill_loss.hip",
                   "sgd_flat_kernel": "elementwise.hip"}
 
@@ -395,6 +396,10 @@ def also_leg(dev, dom_klass, steps=5, warmup=2, **cfgkw):
                "ms_per_step": round(dt / steps * 1e3, 3), "images_per_s": round(W["N"] * steps / dt, 2),
                "finite": ok, ("distill_loss" if W["distill"] else "focal_loss"): losses,
                "roofline": dict(kernel=dom["kernel"], bound="mfma", achieved=dom["achieved"], peak=dom["peak"],
+                             peak_note=("dense fp16 MFMA peak (the split-operand engine executes 3 fp16 products per "
+                                        "direct-form product); against the fp32 MFMA peak of 157.3 TFLOP/s the "
+                                        "direct-form rate is x%.2f" % (dom["direct_equiv_tflops"] / 157.3)
+                                        if dom_k == 28 else None),
                                 unit="TFLOP/s", frac=dom["frac"], launches_per_step=dom["launches_per_step"],
                                 avg_launch_ms=dom["avg_launch_ms"], flops_per_launch=dom["flops_per_launch"],
                                 direct_equiv_tflops=dom["direct_equiv_tflops"]) if dom else None}
@@ -550,7 +555,7 @@ def main():
     # dominant convolution, the loss kernels, PowSum): events between all ~500 launches of a step keep
     # consecutive kernels from overlapping their tails and cost 1 % of the step (2.5 % with collectives
     # in flight).  `kernels[]` comes from instrumented steps after the timed region.
-    ROOFLINE_CLASSES = [2, 23, 18, 34, 8, 9, 15]
+    ROOFLINE_CLASSES = [2, 23, 28, 18, 34, 8, 9, 15]
     timing = PR.Timing().select(ROOFLINE_CLASSES)
     heads.timing = timing
     if args.workload == "full":
@@ -614,14 +619,16 @@ def main():
     if rank == 0:
         rows = kernel_report(timing_all.collect(), max(args.profile_steps, 1))      # all families
         by = {r["class"]: r for r in kernel_report(timing.collect(), args.steps)}     # the timed region
-        dom_k = 34 if f16 else (2 if 2 in by else 23 if 23 in by else 18)      # 23: SSAD_STUDENT_F24 & 4
+        # the subnet tower forward launch: 28 on the split-operand engine (SSAD_SPLIT_CONV & 4, the default), 23 on
+        # F(2x4), 2 on F(2x2), 18 on the direct kernel
+        dom_k = 34 if f16 else (28 if 28 in by else 2 if 2 in by else 23 if 23 in by else 18)
         dom = by.get(dom_k)
         traffic, traffic_note, traffic_round = pmc_traffic(dom_k) if not f16 else (None, None, None)
         # algorithmic HBM bytes of one launch of the dominant class: the four towers' inputs + outputs of
         # all levels + the packed filters, each once (fp32)
         px = N * sum(h * w for h, w in shapes)
-        ntow = (4 if distill else 2) if dom_k in (2, 23) else 1
-        dom_alg_bytes = ntow * (2 * 256 * px * 4 + 16 * 256 * 256 * 4) if dom_k in (2, 23) else None
+        ntow = (4 if distill else 2) if dom_k in (2, 23, 28) else 1
+        dom_alg_bytes = ntow * (2 * 256 * px * 4 + 16 * 256 * 256 * 4) if dom_k in (2, 23, 28) else None
         heads_ms = sum(r["ms_per_step"] for r in rows if r["class"] < 48)
         backbone_ms = sum(r["ms_per_step"] for r in rows if r["class"] >= 48)
         out = {
@@ -670,9 +677,11 @@ def main():
                              direct_equiv_tflops=dom["direct_equiv_tflops"],
                              exec_div=dom.get("exec_div"),
                              achieved_note=("executed MFMA FLOP/s: algorithmic direct-form flops (2*9*Cout*Cin "
-                                            "per output pixel, SURVEY 8d) / exec_div -- 3 for the Winograd "
-                                            "F(2x4,3x3) engine (24 products per 8 outputs), 2.25 for F(2x2,3x3) "
-                                            "(16 per 4); direct_equiv_tflops is the direct-form rate" if not f16
+                                            "per output pixel, SURVEY 8d) / exec_div -- 1/3 for the split-operand "
+                                            "engine (three fp16 MFMA products per direct-form product, the launch "
+                                            "includes its |max| and split passes), 3 for Winograd F(2x4,3x3) (24 "
+                                            "products per 8 outputs), 2.25 for F(2x2,3x3); direct_equiv_tflops is "
+                                            "the direct-form rate" if not f16
                                             else "algorithmic direct-form FLOP/s; the kernel executes exactly these"),
                              launches_per_step=dom["launches_per_step"], avg_launch_ms=dom["avg_launch_ms"],
                              flops_per_launch=dom["flops_per_launch"]) if dom else None,

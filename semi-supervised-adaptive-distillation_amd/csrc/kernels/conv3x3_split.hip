@@ -74,11 +74,21 @@ __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 struct FPackTable {
   ssad_pack_entry e[SSAD_MAX_PACK_ENTRIES];
 };
-__global__ __launch_bounds__(kThreads) void split_filter_amax_kernel(const FPackTable t) {
+// header words of both packs to zero (the |max| below is an atomicMax)
+__global__ void split_filter_zero_kernel(const FPackTable t) {
   const ssad_pack_entry& e = t.e[blockIdx.x];
+  if (threadIdx.x < HDR) {
+    if (e.packed_fwd) reinterpret_cast<unsigned*>(e.packed_fwd)[threadIdx.x] = 0u;
+    if (e.packed_dgrad) reinterpret_cast<unsigned*>(e.packed_dgrad)[threadIdx.x] = 0u;
+  }
+}
+// |max| of filter blockIdx.y: one atomic per workgroup (a single workgroup per filter took 0.77 ms per step on the
+// 720 x 256 x 9 filter of cls_pred, profiles/r06_bench_heads_trace.md)
+__global__ __launch_bounds__(kThreads) void split_filter_amax_kernel(const FPackTable t) {
+  const ssad_pack_entry& e = t.e[blockIdx.y];
   const long long n = (long long)e.Cout * e.Cin * 9;
   unsigned m = 0;
-  for (long long i = threadIdx.x; i < n; i += kThreads) {
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
     const unsigned a = __float_as_uint(e.w[i]) & 0x7fffffffu;
     m = m > a ? m : a;
   }
@@ -90,12 +100,13 @@ __global__ __launch_bounds__(kThreads) void split_filter_amax_kernel(const FPack
   }
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x < HDR) {
+  if (threadIdx.x == 0) {
     unsigned r = red[0];
     for (int w = 1; w < kThreads / 64; ++w) r = r > red[w] ? r : red[w];
-    const unsigned word = threadIdx.x == 0 ? r : 0u;
-    if (e.packed_fwd) reinterpret_cast<unsigned*>(e.packed_fwd)[threadIdx.x] = word;
-    if (e.packed_dgrad) reinterpret_cast<unsigned*>(e.packed_dgrad)[threadIdx.x] = word;
+    if (r) {
+      if (e.packed_fwd) atomicMax(reinterpret_cast<unsigned*>(e.packed_fwd), r);
+      if (e.packed_dgrad) atomicMax(reinterpret_cast<unsigned*>(e.packed_dgrad), r);
+    }
   }
 }
 __global__ __launch_bounds__(kThreads) void split_filter_pack_kernel(const FPackTable t) {
@@ -551,7 +562,8 @@ int ssad_conv_split_pack_filters(const ssad_pack_entry* entries_host, int n_entr
       if (e.packed_dgrad) { smax = sd > smax ? sd : smax; any_dgrad = true; }
     }
     for (int i = cnt; i < SSAD_MAX_PACK_ENTRIES; ++i) t.e[i] = ssad_pack_entry{};
-    hipLaunchKernelGGL(split_filter_amax_kernel, dim3((unsigned)cnt), dim3(kThreads), 0, (hipStream_t)stream, t);
+    hipLaunchKernelGGL(split_filter_zero_kernel, dim3((unsigned)cnt), dim3(64), 0, (hipStream_t)stream, t);
+    hipLaunchKernelGGL(split_filter_amax_kernel, dim3(64u, (unsigned)cnt), dim3(kThreads), 0, (hipStream_t)stream, t);
     long long bx = (smax + kThreads - 1) / kThreads;
     if (bx > 512) bx = 512;
     hipLaunchKernelGGL(split_filter_pack_kernel, dim3((unsigned)bx, (unsigned)cnt, any_dgrad ? 2u : 1u), dim3(kThreads), 0,

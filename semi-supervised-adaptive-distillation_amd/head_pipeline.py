@@ -120,9 +120,11 @@ class DistillHeads(object):
                 self.student_f24 &= ~4
         # The split-operand engine (conv3x3_split.hip: fp32 operands as hi + lo fp16, three fp16 MFMAs per pair; meets the
         # direct kernel's parity floor where F(2x4) needs 2e-5) where it measured faster than F(2x4) at config 3's size --
-        # the 720-wide prediction layer: bit 1 = cls_pred forward (student and teacher), bit 2 = its data gradient
-        # (SSAD_SPLIT_CONV; 0 = off)
-        self.split_conv = int(os.environ.get("SSAD_SPLIT_CONV", "3")) if (self.wino and not self.F16) else 0
+        # bit mask SSAD_SPLIT_CONV: 1 = cls_pred forward (student and teacher), 2 = its data gradient, 4 = tower forward
+        # (both networks, one launch per depth), 8 = tower data gradients; 0 = off.  Default 15: same-box A/B of the
+        # step 86.0 -> 83.9 ms, subnets 37.3 -> 35.8 (profiles/r06_experiments.md) -- every bit pays in the step although
+        # the isolated launches are level with F(2x4): the step is power-bound, and the engine spends less of it.
+        self.split_conv = int(os.environ.get("SSAD_SPLIT_CONV", "15")) if (self.wino and not self.F16) else 0
         self._split_ops, self._split_ws_need = [], 0
         self.momentum, self.weight_decay = momentum, weight_decay
         self.pg, self.world_size = process_group, world_size
@@ -269,10 +271,14 @@ class DistillHeads(object):
         return bool(m & 2) if "_pred_" in name else bool(m & 4)
 
     def _split_use(self, name, cout, cin, which):
-        """Does this convolution run on the split-operand engine?  (the 720-wide prediction layer, SSAD_SPLIT_CONV)"""
-        if not self.split_conv or "_cls_pred_" not in name:
+        """Does this convolution run on the split-operand engine?  SSAD_SPLIT_CONV bits: 1 cls_pred forward (both
+        networks), 2 its data gradient, 4 tower forward (both networks: one launch per depth), 8 tower data gradient."""
+        m = self.split_conv
+        if not m or "bbox_pred" in name:
             return False
-        return bool(self.split_conv & (1 if which == "fwd" else 2))
+        if "_cls_pred_" in name:
+            return bool(m & (1 if which == "fwd" else 2))
+        return bool(m & (4 if which == "fwd" else 8))
 
     def _alloc_packed(self, params, want_dgrad, f24=None):
         """Packed-filter buffers per layer in the layout of the engine that consumes them:
@@ -429,6 +435,16 @@ class DistillHeads(object):
                 probs.append((sx[t], out, None, self.packed[name][0], self.params[name + "_b"]))
                 who.append("student")
                 sx[t] = out
+            if self.split_conv & 4:
+                # every tower of this depth on the split-operand engine, one launch (class 28)
+                _, arr = self._emit_conv(P, probs, D, D, K.CONV_RELU, 28, split=True)
+                if i == 0:
+                    k = 0
+                    for (xs, _, _, _, _), w in zip(probs, who):
+                        for l in range(len(xs)):
+                            self._in_slots.append((arr, k, w, l))
+                            k += 1
+                continue
             if self.student_f24 & 4 and (not self.distill or self._f24_layer(self._layers("cls")[i], D)):
                 # every tower of this depth on the F(2x4) engine, one launch (class 23)
                 _, arr = self._emit_conv(P, probs, D, D, K.CONV_RELU, 23, f24=True)
@@ -592,8 +608,9 @@ class DistillHeads(object):
                 out = self.dbuf[t][li] if li > 0 else self.d_fpn[t]
                 probs.append((dy[t], out, x_in if li > 0 else None, self.packed[name][1], None))
                 dy[t] = out
+            sp = self._split_use(name, D, D, "dgrad")
             f24 = self._f24_use("student", name, D, D, "dgrad")
-            self._emit_conv(P, probs, D, D, K.CONV_MASK_AUX if li > 0 else 0, 24 if f24 else 16, f24=f24)
+            self._emit_conv(P, probs, D, D, K.CONV_MASK_AUX if li > 0 else 0, 29 if sp else 24 if f24 else 16, f24=f24, split=sp)
             if li == nl // 2:
                 P.mark("backward_late_done")
         if "backward_late_done" not in P.marks:

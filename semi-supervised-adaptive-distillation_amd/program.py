@@ -67,6 +67,10 @@ KLASS = {
              wino=True, exec_div=1.0 / 3.0),
     27: dict(name="cls_pred data gradient, split-operand engine (conv3x3_split_kernel + |max| + split passes)", bound="mfma16",
              wino=True, exec_div=1.0 / 3.0),
+    28: dict(name="subnet tower conv3x3 forward, split-operand engine (conv3x3_split_kernel + |max| + split passes)",
+             bound="mfma16", wino=True, exec_div=1.0 / 3.0),
+    29: dict(name="subnet tower data gradient, split-operand engine (conv3x3_split_kernel + |max| + split passes)",
+             bound="mfma16", wino=True, exec_div=1.0 / 3.0),
     24: dict(name="subnet conv3x3 data gradient, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma", wino=True, exec_div=3.0),
     # direct (non-Winograd) engine
     18: dict(name="subnet conv3x3 fwd/dgrad, direct engine (conv3x3_kernel)", bound="mfma", wino=False),

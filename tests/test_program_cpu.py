@@ -39,22 +39,22 @@ def test_distillation_step_program_structure():
     assert list(m) == ["pack", "forward", "losses", "backward", "backward_late_done", "sgd", "sgd_update",
                        "ls_update", "end"]
     assert m["sgd"] == m["sgd_update"] and m["ls_update"] == m["end"]      # fp32: nothing around the update
-    # 10 filters x {fwd, dgrad}: one launch per pack layout -- the split-operand engine (cls_pred forward + data
-    # gradient), F(2x4) (every other forward but bbox_pred's 36 outputs, every other data gradient) and F(2x2)
-    # (bbox_pred forward)
+    # 10 filters x {fwd, dgrad}: one launch per pack layout -- the split-operand engine (towers + cls_pred, forward
+    # and data gradient), F(2x4) (bbox_pred's data gradient: 256 outputs) and F(2x2) (bbox_pred forward: 36 outputs)
     assert _codes(h, "pack", "forward") == [PR.WINO_PACK_FILTERS] * 3
-    assert [(o.i[0], o.i[1]) for o in h.prog.ops[m["pack"]:m["forward"]]] == [(1, 3), (9, 2), (1, 0)]
+    assert [(o.i[0], o.i[1]) for o in h.prog.ops[m["pack"]:m["forward"]]] == [(9, 3), (1, 2), (1, 0)]
     # 4 tower depths (teacher+student x cls+bbox in one launch each), teacher cls_pred (sigmoid),
     # student cls_pred, bbox_pred (student + teacher)
     assert _codes(h, "forward", "losses") == [PR.CONV3X3] * 7
     assert [o.i[0] for o in h.prog.ops[m["forward"]:m["losses"]]] == [8, 8, 8, 8, 2, 2, 4]
     # engine (i[4]: 1 = F(2x2), 2 = F(2x4), 3 = split-operand) and timing class per launch
     assert [(o.i[4], o.klass) for o in h.prog.ops[m["forward"]:m["losses"]]] == \
-        [(2, 23)] * 4 + [(3, 25), (3, 26), (1, 4)]
-    assert {(o.i[4], o.klass) for o in h.prog.ops[m["backward"]:m["sgd"]] if o.code == PR.CONV3X3} == {(2, 24), (3, 27)}
-    # the split-engine launches share one workspace, sized for the largest (the 720-channel gradient of cls_pred)
+        [(3, 28)] * 4 + [(3, 25), (3, 26), (1, 4)]
+    assert {(o.i[4], o.klass) for o in h.prog.ops[m["backward"]:m["sgd"]] if o.code == PR.CONV3X3} == \
+        {(2, 24), (3, 27), (3, 29)}
+    # the split-engine launches share one workspace, sized for the largest (the four towers of one depth)
     sp = [o for o in h.prog.ops if o.code == PR.CONV3X3 and o.i[4] == 3]
-    assert len(sp) == 3 and {o.p[3] for o in sp} == {h.split_ws.data_ptr()} and max(o.l[0] for o in sp) <= h.split_ws.numel()
+    assert len(sp) == 11 and {o.p[3] for o in sp} == {h.split_ws.data_ptr()} and max(o.l[0] for o in sp) <= h.split_ws.numel()
     assert _codes(h, "losses", "backward") == [PR.POW_SUM, PR.CLS_LOSSES_FUSED, PR.SMOOTH_L1]
     bw = _codes(h, "backward", "sgd")
     assert bw.count(PR.CONV3X3_WGRAD) == 10 and bw.count(PR.CONV3X3) == 6
@@ -65,7 +65,7 @@ def test_distillation_step_program_structure():
     # direct-form flops of SURVEY 8d: 2*9*Cout*Cin per output pixel
     px = sum(hh * ww for hh, ww in SHAPES)
     first = h.prog.ops[m["forward"]]
-    assert first.work == 2.0 * 9 * 256 * 256 * px * 4 and first.klass == 23
+    assert first.work == 2.0 * 9 * 256 * 256 * px * 4 and first.klass == 28
     # every wgrad shares the one workspace, sized for the largest
     ws = {o.p[3] for o in h.prog.ops if o.code == PR.CONV3X3_WGRAD}
     assert ws == {h.wgrad_ws.data_ptr()}
@@ -114,7 +114,8 @@ def test_f24_switches_select_the_engine_per_launch(monkeypatch):
     # SSAD_SPLIT_CONV: bit 1 = cls_pred forward (both networks), bit 2 = its data gradient
     monkeypatch.setenv("SSAD_STUDENT_F24", "15")
     monkeypatch.setenv("SSAD_TEACHER_F24", "1")
-    for bits, want_f, want_b in ((1, [(3, 25), (3, 26)], {(2, 24)}), (2, [(2, 20), (2, 22)], {(2, 24), (3, 27)})):
+    for bits, want_f, want_b in ((1, [(3, 25), (3, 26)], {(2, 24)}), (2, [(2, 20), (2, 22)], {(2, 24), (3, 27)}),
+                                 (4, [(2, 20), (2, 22)], {(2, 24)}), (8, [(2, 20), (2, 22)], {(2, 24), (3, 29)})):
         monkeypatch.setenv("SSAD_SPLIT_CONV", str(bits))
         h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu")
         m = h.prog.marks
@@ -123,6 +124,11 @@ def test_f24_switches_select_the_engine_per_launch(monkeypatch):
         cp = h._layers("cls")[-1]
         assert h.packed[cp][0].numel() == (L.ssad_conv_split_filter_floats if bits & 1 else L.ssad_conv_wino24_filter_floats)(720, 256)
         assert h.packed[cp][1].numel() == (L.ssad_conv_split_filter_floats if bits & 2 else L.ssad_conv_wino24_filter_floats)(256, 720)
+        tw = h._layers("cls")[0]
+        assert [(o.i[4], o.klass) for o in h.prog.ops[m["forward"]:m["losses"]]][:4] == [(3, 28) if bits & 4 else (2, 23)] * 4
+        assert h.packed[tw][0].numel() == (L.ssad_conv_split_filter_floats if bits & 4 else L.ssad_conv_wino24_filter_floats)(256, 256)
+        assert h.packed[tw][1].numel() == (L.ssad_conv_split_filter_floats if bits & 8 else L.ssad_conv_wino24_filter_floats)(256, 256)
+        assert h.t_packed[tw].numel() == h.packed[tw][0].numel()          # the teacher's towers share the launch
     monkeypatch.setenv("SSAD_SPLIT_CONV", "0")
     # without a teacher the student's towers are alone in their launch and follow bit 4
     monkeypatch.setenv("SSAD_STUDENT_F24", "7")
