@@ -1,5 +1,5 @@
 """Every hand-synchronised kernel family under contention from other streams, bit for bit against its own quiet
-run (tools/dbg/r4_kernel_stress.py).  The kernels wait for their own loads with counted `s_waitcnt`s and raw
+run (tools/kernel_stress.py).  The kernels wait for their own loads with counted `s_waitcnt`s and raw
 barriers; a wrong count is invisible while memory is fast and shows only when another stream makes it late -- how
 round 4's corruption in wino_conv_z_kernel escaped three rounds of tests.  Short here (the tool runs longer: 1500
 iterations per case were clean after the fix)."""
@@ -13,8 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_kernels_give_the_same_bits_while_other_streams_load_the_chip():
-    sys.path.insert(0, os.path.join(ROOT, "tools", "dbg"))
-    import r4_kernel_stress
-    bad, cases = r4_kernel_stress.run(iters=60, verbose=True)
-    assert cases >= 21            # (round 5: + five wino24_conv_kernel cases)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_stress
+    bad, cases = kernel_stress.run(iters=60, verbose=True)
+    assert cases >= 27            # (round 5: + five wino24_conv_kernel cases; round 6: + six split-engine cases)
     assert bad == 0
