@@ -37,7 +37,7 @@ string LoweringReport::ToString() const {
   return MakeString("ops ", ops_in, " -> ", ops_out, "; Relu fused ", relu_fused, ", Sigmoid fused ", sigmoid_fused, ", ReluGradient fused ",
                     relu_grad_fused, "; ConvGroup ", conv_groups, " (", conv_group_members,
                     " Conv); ConvGradientGroup ", conv_grad_groups, " (", conv_grad_group_members,
-                    " ConvGradient); Sum absorbed ", sums_absorbed, "; F(2x4) Conv ", frozen_f24, " evaluated / ", train_f24, " trained",
+                    " ConvGradient); Sum absorbed ", sums_absorbed, "; F(2x4) Conv ", frozen_f24, " evaluated / ", train_f24, " trained (", split, " of them marked split)",
                     fell_back ? "; FELL BACK to the list as written" : "");
 }
 
@@ -49,6 +49,8 @@ LoweringOptions LoweringOptionsFor(const NetDef& def) {
   opt.frozen_f24 = EnvFlag("C2HIP_NET_FROZEN_F24", !(f24 && f24->has_i && f24->i == 0));
   const Argument* t24 = FindArg(def, "hip_train_f24");
   opt.train_f24 = EnvFlag("C2HIP_NET_TRAIN_F24", !(t24 && t24->has_i && t24->i == 0));
+  const Argument* sp = FindArg(def, "hip_split");
+  opt.split = EnvFlag("C2HIP_NET_SPLIT", !(sp && sp->has_i && sp->i == 0));
   for (const string& s : def.external_output) opt.keep.insert(s);
   if (const Argument* k = FindArg(def, "hip_keep_blobs"))
     for (const string& s : k->strings) opt.keep.insert(s);

@@ -34,7 +34,9 @@ struct LoweringOptions {
   bool fuse_relu = true;        // Conv + Relu, ReluGradient + ConvGradient
   bool group_convs = true;      // ConvGroup / ConvGradientGroup (+ Sum absorption)
   bool frozen_f24 = true;       // nets without gradient operators: Conv on the F(2x4, 3x3) engine (hip_algo = winograd24)
-  bool train_f24 = true;        // trained nets: Conv and ConvGradient's data gradient on it too (DESIGN 3.10e)
+  bool train_f24 = true;        // trained nets: Conv and ConvGradient's data gradient on it too
+  bool split = true;            // ... and, of those, the >= 256-wide ones on the split-operand engine (hip_algo = split:
+                                // conv3x3_split.hip; round 6) -- NetDef arg hip_split, environment C2HIP_NET_SPLIT
   // TensorProto::DataType id of a blob that exists already (parameters do when a net is created:
   // the reference runs param_init_net first), 0 if unknown.  The fused 3x3 paths are fp32-only.
   std::function<int(const string&)> blob_dtype;
@@ -51,6 +53,7 @@ struct LoweringReport {
   int sums_absorbed = 0;
   int frozen_f24 = 0;           // Conv operators of an evaluated-only net sent to the F(2x4, 3x3) engine
   int train_f24 = 0;            // Conv / ConvGradient operators of a trained net sent to it
+  int split = 0;                // of both: marked hip_algo = split (the operators apply the width limits)
   bool fell_back = false;       // the lowered list failed its own verification: list kept as written
   string ToString() const;
 };

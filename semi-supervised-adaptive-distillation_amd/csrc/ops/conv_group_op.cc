@@ -97,6 +97,9 @@ class ConvGroupOp final : public Operator<HIPContext> {
     // hip_algo = "winograd24" (set by the net lowering): the F(2x4, 3x3) engine for the problems it serves
     // (>= 128 outputs), "auto" for the rest
     auto kind_of = [&](const Problem& p) {
+      // "split": the split-operand engine where it measured ahead (>= 256 outputs), F(2x4) for 128..255, F(2x2) below
+      if (algo_ == "split")
+        return p.M >= 256 ? FilterPackCache::SPLIT_FWD : p.M >= 128 ? FilterPackCache::WINO24_FWD : FilterPackCache::WINO_FWD;
       if (algo_ == "winograd24") return p.M >= 128 ? FilterPackCache::WINO24_FWD : FilterPackCache::WINO_FWD;
       return UseWinograd(algo_, p.M) ? FilterPackCache::WINO_FWD : FilterPackCache::DIRECT_FWD;
     };
@@ -117,7 +120,9 @@ class ConvGroupOp final : public Operator<HIPContext> {
         }
         // per-problem filter / bias; the launch-wide bias only says whether one is added at all
         const float* any_bias = lv[0].bias;
-        const int rc = kind == FilterPackCache::WINO24_FWD
+        const int rc = kind == FilterPackCache::SPLIT_FWD
+                           ? split_.Run(lv, n, lv[0].packed, any_bias, p0.M, p0.C, flags, s)
+                       : kind == FilterPackCache::WINO24_FWD
                            ? ssad_conv3x3_forward_wino24(lv, n, lv[0].packed, any_bias, p0.M, p0.C, flags, s)
                        : kind == FilterPackCache::WINO_FWD
                            ? ssad_conv3x3_forward_wino(lv, n, lv[0].packed, any_bias, p0.M, p0.C, flags, s)
@@ -136,6 +141,7 @@ class ConvGroupOp final : public Operator<HIPContext> {
   string algo_;
   int per_ = 3;
   FilterPackCache cache_;
+  SplitEngine split_;
 };
 
 class ConvGradientGroupOp final : public Operator<HIPContext> {
@@ -220,6 +226,8 @@ class ConvGradientGroupOp final : public Operator<HIPContext> {
     // data gradients: the forward kernel on the flipped / transposed pack, dX has C channels
     const long long before = cache_.packs_issued();
     auto dkind_of = [&](const Problem& p) {
+      if (algo_ == "split" && p.C >= 256) return FilterPackCache::SPLIT_DGRAD;
+      if (algo_ == "split" && p.C >= 128) return FilterPackCache::WINO24_DGRAD;
       if (algo_ == "winograd24" && p.C >= 128) return FilterPackCache::WINO24_DGRAD;
       return UseWinograd(algo_, p.C) ? FilterPackCache::WINO_DGRAD : FilterPackCache::DIRECT_DGRAD;
     };
@@ -239,7 +247,9 @@ class ConvGradientGroupOp final : public Operator<HIPContext> {
                                   relu_grad_on_input_ ? p.x->data<float>() : nullptr, p.N, p.H, p.W,
                                   cache_.Packed(*p.w, kind), nullptr};
         }
-        const int rc = kind == FilterPackCache::WINO24_DGRAD
+        const int rc = kind == FilterPackCache::SPLIT_DGRAD
+                           ? split_.Run(lv, n, lv[0].packed, nullptr, p0.C, p0.M, flags, s)
+                       : kind == FilterPackCache::WINO24_DGRAD
                            ? ssad_conv3x3_forward_wino24(lv, n, lv[0].packed, nullptr, p0.C, p0.M, flags, s)
                        : kind == FilterPackCache::WINO_DGRAD
                            ? ssad_conv3x3_forward_wino(lv, n, lv[0].packed, nullptr, p0.C, p0.M, flags, s)
@@ -262,6 +272,7 @@ class ConvGradientGroupOp final : public Operator<HIPContext> {
   bool want_dx_ = false;
   Tensor<HIPContext> workspace_;
   FilterPackCache cache_;
+  SplitEngine split_;
 };
 
 REGISTER_HIP_OPERATOR(ConvGroup, ConvGroupOp);

@@ -92,15 +92,20 @@ bool ConvOp<float, HIPContext>::RunOnDevice() {
   const int flags = (fuse_relu_ ? SSAD_CONV_RELU : 0) | (fuse_sigmoid_ ? SSAD_CONV_SIGMOID : 0);
   int rc;
   // the packed filter is rebuilt only when the filter blob was written since (ops/filter_pack_cache.h)
-  const bool f24 = algo_ == "winograd24" && M >= 128;      // assigned by the net lowering (net_lowering.cc F24)
-  const bool wino = UseWinograd(algo_ == "winograd24" ? string("auto") : algo_, M);
-  const auto kind = f24 ? FilterPackCache::WINO24_FWD : wino ? FilterPackCache::WINO_FWD : FilterPackCache::DIRECT_FWD;
+  // "split" / "winograd24" are assigned by the net lowering (net_lowering.cc): the split-operand engine from 256
+  // outputs up, F(2x4) from 128
+  const bool sp = algo_ == "split" && M >= 256;
+  const bool f24 = (algo_ == "winograd24" || algo_ == "split") && M >= 128 && !sp;
+  const bool wino = UseWinograd((algo_ == "winograd24" || algo_ == "split") ? string("auto") : algo_, M);
+  const auto kind = sp ? FilterPackCache::SPLIT_FWD : f24 ? FilterPackCache::WINO24_FWD
+                       : wino ? FilterPackCache::WINO_FWD : FilterPackCache::DIRECT_FWD;
   const long long before = pack_cache_.packs_issued();
   pack_cache_.Want(filter, kind);
   pack_cache_.Flush(s);
   g_filter_packs_issued += pack_cache_.packs_issued() - before;
   const float* packed = pack_cache_.Packed(filter, kind);
-  rc = f24 ? ssad_conv3x3_forward_wino24(&lv, 1, packed, bias, M, C, flags, s)
+  rc = sp ? split_.Run(&lv, 1, packed, bias, M, C, flags, s)
+       : f24 ? ssad_conv3x3_forward_wino24(&lv, 1, packed, bias, M, C, flags, s)
        : wino ? ssad_conv3x3_forward_wino(&lv, 1, packed, bias, M, C, flags, s)
               : ssad_conv3x3_forward(&lv, 1, packed, bias, M, C, flags, s);
   CAFFE_ENFORCE_EQ(rc, 0, "Conv launch failed");
@@ -429,15 +434,18 @@ bool ConvGradientOp<float, HIPContext>::RunOnDevice() {
     ssad_conv_level dl{dY.data<float>(), dX->mutable_data<float>(),
                        relu_grad_on_input_ ? X.data<float>() : nullptr, N, H, W, nullptr, nullptr};
     const int flags = relu_grad_on_input_ ? SSAD_CONV_MASK_AUX : 0;
-    const bool f24 = algo_ == "winograd24" && C >= 128;      // trained nets under hip_train_f24 (net_lowering.cc)
+    const bool sp = algo_ == "split" && C >= 256;            // trained nets (net_lowering.cc)
+    const bool f24 = (algo_ == "winograd24" || algo_ == "split") && C >= 128 && !sp;
     const bool wino = UseWinograd(algo_, C);      // the data gradient has C output channels
-    const auto kind = f24 ? FilterPackCache::WINO24_DGRAD : wino ? FilterPackCache::WINO_DGRAD : FilterPackCache::DIRECT_DGRAD;
+    const auto kind = sp ? FilterPackCache::SPLIT_DGRAD : f24 ? FilterPackCache::WINO24_DGRAD
+                         : wino ? FilterPackCache::WINO_DGRAD : FilterPackCache::DIRECT_DGRAD;
     const long long before = pack_cache_.packs_issued();
     pack_cache_.Want(filter, kind);
     pack_cache_.Flush(s);
     g_filter_packs_issued += pack_cache_.packs_issued() - before;
     const float* packed = pack_cache_.Packed(filter, kind);
-    rc = f24 ? ssad_conv3x3_forward_wino24(&dl, 1, packed, nullptr, C, M, flags, s)
+    rc = sp ? split_.Run(&dl, 1, packed, nullptr, C, M, flags, s)
+         : f24 ? ssad_conv3x3_forward_wino24(&dl, 1, packed, nullptr, C, M, flags, s)
          : wino ? ssad_conv3x3_forward_wino(&dl, 1, packed, nullptr, C, M, flags, s)
                 : ssad_conv3x3_forward(&dl, 1, packed, nullptr, C, M, flags, s);
     CAFFE_ENFORCE_EQ(rc, 0, "ConvGradient (data) launch failed");

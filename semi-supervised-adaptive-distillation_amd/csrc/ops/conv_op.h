@@ -169,6 +169,7 @@ class ConvOp final : public Operator<Context> {
   string algo_;
   Tensor<Context> packed_filter_;
   FilterPackCache pack_cache_;
+  SplitEngine split_;
   Tensor<Context> col_buffer_;
   Tensor<Context> f16_scratch_[4];
   bool RunFloat16Pointwise();
@@ -201,6 +202,7 @@ class ConvGradientOp final : public Operator<Context> {
   bool RunFloat16();
   Tensor<Context> packed_filter_;
   FilterPackCache pack_cache_;
+  SplitEngine split_;
   Tensor<Context> workspace_;
   Tensor<Context> col_buffer_;
   Tensor<Context> f16_scratch_[8];

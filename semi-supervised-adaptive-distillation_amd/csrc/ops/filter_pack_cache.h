@@ -18,7 +18,8 @@ namespace caffe2 {
 
 class FilterPackCache {
  public:
-  enum Kind { WINO_FWD = 0, WINO_DGRAD = 1, DIRECT_FWD = 2, DIRECT_DGRAD = 3, WINO24_FWD = 4, WINO24_DGRAD = 5 };
+  enum Kind { WINO_FWD = 0, WINO_DGRAD = 1, DIRECT_FWD = 2, DIRECT_DGRAD = 3, WINO24_FWD = 4, WINO24_DGRAD = 5,
+              SPLIT_FWD = 6, SPLIT_DGRAD = 7 };     // 6 / 7: the split-operand engine's packs (conv3x3_split.hip)
 
   // Queue `filter` ([M][C][3][3], fp32) for layout `kind`; Flush() issues the packs that are stale
   // (one multi-filter launch for the Winograd layouts) on `stream`; Packed() is valid after it.
@@ -38,10 +39,11 @@ class FilterPackCache {
     e.C = C;
     e.version = filter.version();
     e.uid = filter.uid();
-    const bool dgrad = kind == WINO_DGRAD || kind == DIRECT_DGRAD || kind == WINO24_DGRAD;
+    const bool dgrad = kind == WINO_DGRAD || kind == DIRECT_DGRAD || kind == WINO24_DGRAD || kind == SPLIT_DGRAD;
     const bool wino = kind == WINO_FWD || kind == WINO_DGRAD;
     const int po = dgrad ? C : M, pi = dgrad ? M : C;       // the pack's (outputs, inputs)
-    e.packed.Resize((TIndex)((kind == WINO24_FWD || kind == WINO24_DGRAD) ? ssad_conv_wino24_filter_floats(po, pi)
+    e.packed.Resize((TIndex)((kind == SPLIT_FWD || kind == SPLIT_DGRAD) ? ssad_conv_split_filter_floats(po, pi)
+                             : (kind == WINO24_FWD || kind == WINO24_DGRAD) ? ssad_conv_wino24_filter_floats(po, pi)
                              : wino ? ssad_conv_wino_filter_floats(po, pi) : ssad_conv_packed_filter_floats(po, pi)));
     e.packed.mutable_data<float>();
     e.queued = true;
@@ -50,7 +52,7 @@ class FilterPackCache {
   }
 
   void Flush(hipStream_t stream) {
-    vector<ssad_pack_entry> wino, wino24;
+    vector<ssad_pack_entry> wino, wino24, split;
     for (const Key& k : queue_) {
       Entry& e = entries_[k];
       float* p = e.packed.mutable_data<float>();
@@ -59,6 +61,8 @@ class FilterPackCache {
         case WINO_DGRAD: wino.push_back({e.src, e.M, e.C, nullptr, p}); break;
         case WINO24_FWD: wino24.push_back({e.src, e.M, e.C, p, nullptr}); break;
         case WINO24_DGRAD: wino24.push_back({e.src, e.M, e.C, nullptr, p}); break;
+        case SPLIT_FWD: split.push_back({e.src, e.M, e.C, p, nullptr}); break;
+        case SPLIT_DGRAD: split.push_back({e.src, e.M, e.C, nullptr, p}); break;
         case DIRECT_FWD:
           CAFFE_ENFORCE_EQ(ssad_conv_pack_filter(e.src, e.M, e.C, p, nullptr, stream), 0);
           break;
@@ -75,6 +79,9 @@ class FilterPackCache {
                        "filter pack launch failed");
     if (!wino24.empty())
       CAFFE_ENFORCE_EQ(ssad_conv_wino24_pack_filters(wino24.data(), (int)wino24.size(), stream), 0,
+                       "filter pack launch failed");
+    if (!split.empty())
+      CAFFE_ENFORCE_EQ(ssad_conv_split_pack_filters(split.data(), (int)split.size(), stream), 0,
                        "filter pack launch failed");
     queue_.clear();
   }
@@ -100,6 +107,23 @@ class FilterPackCache {
   std::map<Key, Entry> entries_;
   vector<Key> queue_;
   long long packs_issued_ = 0;
+};
+
+// hip_algo = "split" (assigned by the net lowering): the split-operand engine for >= 128-wide problems.  Its
+// workspace (the split copy of the launch's inputs) belongs to the operator and grows to the largest launch seen.
+class SplitEngine {
+ public:
+  int Run(const ssad_conv_level* lv, int n, const float* packed, const float* bias, int M, int C, int flags,
+          hipStream_t s) {
+    const size_t need = ssad_conv3x3_split_workspace_bytes(lv, n, C);
+    CAFFE_ENFORCE(need > 0, "split-operand engine: unsupported geometry");
+    if ((size_t)ws_.size() < need) ws_.Resize((TIndex)need);
+    return ssad_conv3x3_forward_split(lv, n, packed, bias, M, C, flags, ws_.mutable_data<uint8_t>(), need, nullptr,
+                                      nullptr, s);
+  }
+
+ private:
+  Tensor<HIPContext> ws_;
 };
 
 }  // namespace caffe2

@@ -214,8 +214,9 @@ struct Lowering {
     for (Node& n : nodes) {
       if (n.removed || FindArg(n.def, "hip_algo") || !IsFusedPathConv(n)) continue;
       if (n.def.type == "ConvGradient" && !trained) continue;
-      n.def.arg.push_back(MakeArgument("hip_algo", string("winograd24")));
+      n.def.arg.push_back(MakeArgument("hip_algo", string(opt.split ? "split" : "winograd24")));
       ++(trained ? rep.train_f24 : rep.frozen_f24);
+      rep.split += opt.split ? 1 : 0;
     }
   }
 

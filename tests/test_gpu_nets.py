@@ -98,32 +98,37 @@ def test_lowered_net_vs_operator_by_operator_vs_oracle():
 
 def test_f24_net_arguments_switch_the_engine_and_the_engines_agree():
     """`hip_train_f24` / `hip_frozen_f24` = 0 on a NetDef keep the F(2x2) engine (no hip_algo in the lowered list);
-    with the defaults the same nets run on F(2x4).  Both are fp32 Winograd engines: losses agree to 1e-5 relative,
-    teacher probabilities to 2e-5 of their scale, every logit to 1e-5 of the tensor's scale."""
+    with the defaults the same nets run on the split-operand engine (>= 256 wide) / F(2x4) (hip_algo = split), with
+    `hip_split` = 0 on F(2x4) alone.  Losses agree to 1e-5 relative, teacher probabilities to 2e-5 of their scale,
+    every logit to 1e-5 of the tensor's scale."""
     cfg, S, T, fs, ft, labs, tg, fg = small_problem()
     out = {}
-    for tag, off in (("f24", False), ("f22", True)):
+    for tag, off in (("split", False), ("f24", None), ("f22", True)):
         workspace.ResetWorkspace()
         step = HeadsNetStep(cfg, N=fs[0].shape[0], shapes=SHAPES, student_init=S, teacher_init=T, update=False)
         if off:
             step.teacher.net.Proto().arg.append(core.MakeArgument("hip_frozen_f24", 0))
             step.student.net.Proto().arg.append(core.MakeArgument("hip_train_f24", 0))
+        if off is None:
+            step.teacher.net.Proto().arg.append(core.MakeArgument("hip_split", 0))
+            step.student.net.Proto().arg.append(core.MakeArgument("hip_split", 0))
         step.feed_params()
         step.feed_inputs(fs, ft, labs, tg, fg)
         step.create()
         algos = {a.s for ops in step.lowered().values() for o in ops for a in o.arg if a.name == "hip_algo"}
-        assert algos == (set() if off else {b"winograd24"}) or algos == (set() if off else {"winograd24"}), algos
+        want = set() if off else {b"winograd24"} if off is None else {b"split"}
+        assert algos == want or algos == {w.decode() for w in want}, algos
         step.step()
         out[tag] = fetch_all(step)
-    a, b = out["f24"], out["f22"]
-    for l in step.levels:
-        for stem, tol in (("fl_distill_fpn%d", 1e-5), ("fl_fpn%d", 1e-5), ("retnet_loss_bbox_fpn%d", 1e-5)):
-            assert abs(float(a[stem % l]) - float(b[stem % l])) <= tol * abs(float(b[stem % l])) + 1e-12, stem % l
-        for stem, tol in (("teacher/retnet_cls_prob_fpn%d", 2e-5), ("retnet_cls_pred_fpn%d", 1e-5),
-                          ("retnet_bbox_pred_fpn%d", 1e-5)):
-            x, y = np.asarray(a[stem % l], np.float64), np.asarray(b[stem % l], np.float64)
-            assert np.abs(x - y).max() <= tol * np.abs(y).max(), (stem % l, np.abs(x - y).max(), np.abs(y).max())
-        assert not np.array_equal(a["retnet_cls_pred_fpn%d" % l], b["retnet_cls_pred_fpn%d" % l])   # another engine
+    for a, b in ((out["f24"], out["f22"]), (out["split"], out["f22"])):
+      for l in step.levels:
+          for stem, tol in (("fl_distill_fpn%d", 1e-5), ("fl_fpn%d", 1e-5), ("retnet_loss_bbox_fpn%d", 1e-5)):
+              assert abs(float(a[stem % l]) - float(b[stem % l])) <= tol * abs(float(b[stem % l])) + 1e-12, stem % l
+          for stem, tol in (("teacher/retnet_cls_prob_fpn%d", 2e-5), ("retnet_cls_pred_fpn%d", 1e-5),
+                            ("retnet_bbox_pred_fpn%d", 1e-5)):
+              x, y = np.asarray(a[stem % l], np.float64), np.asarray(b[stem % l], np.float64)
+              assert np.abs(x - y).max() <= tol * np.abs(y).max(), (stem % l, np.abs(x - y).max(), np.abs(y).max())
+          assert not np.array_equal(a["retnet_cls_pred_fpn%d" % l], b["retnet_cls_pred_fpn%d" % l])   # another engine
 
 
 def test_filter_pack_cache_follows_the_blob_version():

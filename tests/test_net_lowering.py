@@ -113,10 +113,11 @@ def test_student_training_net_lowering():
     assert hist["MomentumSGDUpdate"] == 20 and hist["NCCLAllreduce"] == 20
     assert "Sum absorbed 20" in report and "ReluGradient fused 40" in report
     assert len(ops) < n_in // 2
-    # trained nets: forward and data gradient on the F(2x4, 3x3) engine unless the net says hip_train_f24 = 0
-    assert "50 trained" not in report and " 100 trained" in report, report          # 50 Conv + 50 ConvGradient
+    # trained nets: forward and data gradient marked for the split-operand / F(2x4) engines (hip_algo = split: the
+    # operators take the split engine from 256 channels up, F(2x4) from 128) unless the net says hip_train_f24 = 0
+    assert "50 trained" not in report and " 100 trained (100 of them marked split)" in report, report   # 50 Conv + 50 ConvGradient
     for g in [o for o in ops if o.type in ("ConvGroup", "ConvGradientGroup")]:
-        assert [a.s for a in g.arg if a.name == "hip_algo"] in (["winograd24"], [b"winograd24"]), g.type
+        assert [a.s for a in g.arg if a.name == "hip_algo"] in (["split"], [b"split"]), g.type
     proto = student.net.Proto()
     proto.arg.append(core.MakeArgument("hip_train_f24", 0))
     ops0, report0 = workspace.LowerNet(student.net)
@@ -214,8 +215,15 @@ def test_f24_engine_marking_of_evaluated_and_trained_nets():
     _, teacher, student, _ = head_nets(update=True)
     t_ops, t_rep = workspace.LowerNet(teacher.net)
     for g in [o for o in t_ops if o.type == "ConvGroup"]:
+        assert [a.s for a in g.arg if a.name == "hip_algo"] == [b"split"], g.arg
+    assert "F(2x4) Conv 50" in t_rep and "(50 of them marked split)" in t_rep
+    # hip_split = 0: the same marks name the F(2x4) engine alone (round 5's behaviour)
+    teacher.net.Proto().arg.append(core.MakeArgument("hip_split", 0))
+    t_ops0, t_rep0 = workspace.LowerNet(teacher.net)
+    for g in [o for o in t_ops0 if o.type == "ConvGroup"]:
         assert [a.s for a in g.arg if a.name == "hip_algo"] == [b"winograd24"], g.arg
-    assert "F(2x4) Conv 50" in t_rep
+    assert "(0 of them marked split)" in t_rep0
+    teacher.net.Proto().arg.pop()
     s_ops, s_rep = workspace.LowerNet(student.net)
     assert "F(2x4) Conv 0 evaluated / 100 trained" in s_rep, s_rep
     student.net.Proto().arg.append(core.MakeArgument("hip_train_f24", 0))
@@ -231,4 +239,4 @@ def test_f24_engine_marking_of_evaluated_and_trained_nets():
         net.Conv(["y", "w2", "b2"], ["z"], kernel=3, pad=1, stride=1, order="NCHW")
     ops, _ = workspace.LowerNet(net)
     algos = [[a.s for a in o.arg if a.name == "hip_algo"] for o in ops]
-    assert algos == [[b"direct"], [b"winograd24"]], algos
+    assert algos == [[b"direct"], [b"split"]], algos
