@@ -310,12 +310,29 @@ class NativeResNetFPN(object):
     def _gemm(self, P, a, lda, x, y, Kc, M, bias=None, res=None, mask=None, relu=False, acc=False, klass=50):
         d = K.gemm_conv_desc(a, lda, x, y, Kc, M, bias, res, mask, relu, acc)
         px = x.numel() // Kc
+        # (Round 6 tried the split-operand GEMM of gemm_split.hip here for the compute-bound layers -- K, M >= 256, res4 /
+        # res5 / upper laterals: the step got 1.2-1.5 ms SLOWER, profiles/r06_experiments.md section 3; not wired in.)
         P.add(PR.GEMM_CONV, klass, p=(d,), work=2.0 * px * Kc * M,
               keep=[t for t in (a, x, y, bias, res, mask) if t is not None])
 
     def _conv3(self, P, probs, Cout, Cin, flags, klass=48, f24=False):
         """probs: [(x, y, mask or None, packed, bias or None)]: independent 3x3 convolutions of one
-        (Cout, Cin) in one launch; f24: on the F(2x4, 3x3) engine (packs from ssad_conv_wino24_pack_filters)."""
+        (Cout, Cin) in one launch; f24: truthy = on the F(2x4, 3x3) engine (packs from ssad_conv_wino24_pack_filters),
+        3 = on the split-operand engine (conv3x3_split.hip; its workspace is bound when the program is finished)."""
+        if f24 == 3:
+            arr = (K.ConvLevel * len(probs))()
+            for i, (x, y, mask, packed, bias) in enumerate(probs):
+                arr[i] = K.ConvLevel(x.data_ptr(), y.data_ptr(), mask.data_ptr() if mask is not None else 0,
+                                     x.shape[0], x.shape[2], x.shape[3], packed.data_ptr(),
+                                     bias.data_ptr() if bias is not None else 0)
+            nb = K.lib().ssad_conv3x3_split_workspace_bytes(arr, len(probs), Cin)
+            self._split_need = max(getattr(self, "_split_need", 0), nb)
+            px = sum(p[0].shape[0] * p[0].shape[2] * p[0].shape[3] for p in probs)
+            idx = P.add(PR.CONV3X3, 66 if self.train else 67, i=(len(probs), Cout, Cin, flags, 3), l=(nb,),
+                        p=(arr, None, None, None, None, None), work=2.0 * 9 * Cout * Cin * px,
+                        keep=[t for p in probs for t in p if t is not None])
+            self._split_ops.append(idx)
+            return
         if f24:
             klass = 46 if self.train else 47
         arr = (K.ConvLevel * len(probs))()
@@ -446,6 +463,11 @@ class NativeResNetFPN(object):
         # SSAD_STUDENT_F24 bit 8 (default on): the TRAINED network's 3x3 layers of >= 128 channels too, forward and data
         # gradient (the filter gradient keeps its F(3x3, 2x2) engine); DESIGN 3.10e has the error and step-time A/B
         use_f24_train = self.train and (int(os.environ.get("SSAD_STUDENT_F24", "15")) & 8) != 0
+        # SSAD_SPLIT_CONV bit 16: the >= 256-wide stride-1 3x3 layers (res4, res5, FPN outputs) on the split-operand engine
+        # (default on: step -0.1 ... -1.3 ms in four same-box A/B pairs, profiles/r06_experiments.md)
+        use_split = (int(os.environ.get("SSAD_SPLIT_CONV", "31")) & 16) != 0 and (use_f24 or use_f24_train)
+        split_frozen, split_train = [], []
+        self._split_ops, self._split_need = [], 0
         tr_frozen, tr_train = [], []          # (w, wt, M, K, ldm): every transposed filter of a program in one launch
         P.mark("pack")
         for l in L.values():
@@ -463,6 +485,11 @@ class NativeResNetFPN(object):
                 # gradients read the filter in its natural layout)
                 l.wt = self._t(l.cin * 9, l.cout)
                 trs.append((l.w, l.wt, l.cout, l.cin * 9, l.cout))
+            elif l.k == 3 and use_split and l.cout >= 256 and l.cin >= 256:
+                l.pf = self._t(lib.ssad_conv_split_filter_floats(l.cout, l.cin))
+                l.pd = self._t(lib.ssad_conv_split_filter_floats(l.cin, l.cout)) if l.train else None
+                l.f24 = 3
+                (split_train if l.train else split_frozen).append(l)
             elif l.k == 3 and use_f24 and not l.train and l.cout >= 128:
                 l.pf = self._t(lib.ssad_conv_wino24_filter_floats(l.cout, l.cin))
                 l.f24 = True
@@ -508,6 +535,15 @@ class NativeResNetFPN(object):
                 tgt.add(PR.WINO_PACK_FILTERS, 54, i=(len(ls), 2), p=(tab,),
                         work=4.0 * sum(l.w.numel() + l.pf.numel() + (l.pd.numel() if l.pd is not None else 0)
                                        for l in ls))
+        for tgt, ls in ((prep, split_frozen), (P, split_train)):
+            if ls:
+                tab = (K.PackEntry * len(ls))()
+                for i, l in enumerate(ls):
+                    tab[i] = K.PackEntry(l.w.data_ptr(), l.cout, l.cin, l.pf.data_ptr(),
+                                         l.pd.data_ptr() if l.pd is not None else 0)
+                tgt.add(PR.WINO_PACK_FILTERS, 54, i=(len(ls), 3), p=(tab,),
+                        work=4.0 * sum(l.w.numel() + l.pf.numel() + (l.pd.numel() if l.pd is not None else 0)
+                                       for l in ls))
         prep.build()
         self._packed_frozen = False
         P.mark("forward")
@@ -529,6 +565,10 @@ class NativeResNetFPN(object):
         self.ws = self.wss[self._wstreams[0]]
         for idx, slot, k in self._ws_ops:
             P.set_ptr(idx, slot, self.wss[k])
+        # the split-engine 3x3 launches of this network run one after the other on its stream: one workspace
+        self.split_ws = torch.empty(max(self._split_need, 16), dtype=torch.uint8, device=dev)
+        for idx in self._split_ops:
+            P.set_ptr(idx, 3, self.split_ws)
         P.build()
 
     # -- forward ----------------------------------------------------------------------------------------

@@ -121,10 +121,11 @@ class DistillHeads(object):
         # The split-operand engine (conv3x3_split.hip: fp32 operands as hi + lo fp16, three fp16 MFMAs per pair; meets the
         # direct kernel's parity floor where F(2x4) needs 2e-5) where it measured faster than F(2x4) at config 3's size --
         # bit mask SSAD_SPLIT_CONV: 1 = cls_pred forward (student and teacher), 2 = its data gradient, 4 = tower forward
-        # (both networks, one launch per depth), 8 = tower data gradients; 0 = off.  Default 15: same-box A/B of the
+        # (both networks, one launch per depth), 8 = tower data gradients (16: the backbones' >= 256-wide 3x3 layers,
+        # backbone_pipeline.py); 0 = off.  Default 31: same-box A/B of the
         # step 86.0 -> 83.9 ms, subnets 37.3 -> 35.8 (profiles/r06_experiments.md) -- every bit pays in the step although
         # the isolated launches are level with F(2x4): the step is power-bound, and the engine spends less of it.
-        self.split_conv = int(os.environ.get("SSAD_SPLIT_CONV", "15")) if (self.wino and not self.F16) else 0
+        self.split_conv = int(os.environ.get("SSAD_SPLIT_CONV", "31")) if (self.wino and not self.F16) else 0
         self._split_ops, self._split_ws_need = [], 0
         self.momentum, self.weight_decay = momentum, weight_decay
         self.pg, self.world_size = process_group, world_size

@@ -100,6 +100,10 @@ KLASS = {
     54: dict(name="backbone filter packs (transpose / Winograd)", bound="hbm"),
     56: dict(name="grouped 3x3 conv, ResNeXt (grouped_conv3x3_kernel)", bound="mfma", wino=False),
     55: dict(name="backbone momentum SGD (sgd_flat_kernel)", bound="hbm"),
+    66: dict(name="backbone conv3x3 fwd/dgrad, >= 256 wide, split-operand engine (conv3x3_split_kernel + passes; SSAD_SPLIT_CONV & 16)",
+             bound="mfma16", wino=True, exec_div=1.0 / 3.0),
+    67: dict(name="teacher backbone conv3x3 fwd, >= 256 wide, split-operand engine (conv3x3_split_kernel + passes)",
+             bound="mfma16", wino=True, exec_div=1.0 / 3.0),
     64: dict(name="P6 / P7 3x3 stride-2 conv fwd / data gradient at their own size (implicit GEMM with split-K; "
                   "flattened-batch GEMM + col2im)", bound="mfma", wino=False),
     65: dict(name="P6 / P7 3x3 stride-2 filter gradient (im2col + gemm_conv_nt_kernel + reduce)", bound="mfma",

@@ -229,11 +229,22 @@ def test_backbone_engines_follow_the_f24_switches(monkeypatch):
             monkeypatch.setenv(k, v)
         bb = NativeResNetFPN("r50", 1, (128, 128), "cpu", train=train)
         return [(o.i[4], o.klass) for o in bb.prog.ops if o.code == PR.CONV3X3], bb
-    e, bb = engines(True, {"SSAD_STUDENT_F24": "15"})
+    e, bb = engines(True, {"SSAD_STUDENT_F24": "15", "SSAD_SPLIT_CONV": "15"})
     # forward: res2 x3 on F(2x2); res3 x4, res4 x6, res5 x3 and the FPN output launch on F(2x4); backward: their data
     # gradients (res3.0's block is the last one that sends a gradient down)
     assert e.count((1, 48)) == 3 and e.count((2, 46)) == (4 + 6 + 3 + 1) * 2, e
     assert sum(o.code == PR.WINO_PACK_FILTERS and o.i[1] == 2 for o in bb.prog.ops) == 1      # trained packs: per step
+    # SSAD_SPLIT_CONV bit 16 (default): the >= 256-wide ones (res4, res5, FPN outputs) on the split-operand engine,
+    # one workspace for all of them; res3's 128-wide layers stay on F(2x4)
+    e, bb = engines(True, {"SSAD_STUDENT_F24": "15", "SSAD_SPLIT_CONV": "31"})
+    assert e.count((1, 48)) == 3 and e.count((2, 46)) == 4 * 2 and e.count((3, 66)) == (6 + 3 + 1) * 2, e
+    assert sum(o.code == PR.WINO_PACK_FILTERS and o.i[1] == 3 for o in bb.prog.ops) == 1
+    sp = [o for o in bb.prog.ops if o.code == PR.CONV3X3 and o.i[4] == 3]
+    assert {o.p[3] for o in sp} == {bb.split_ws.data_ptr()} and max(o.l[0] for o in sp) <= bb.split_ws.numel()
+    e, bb = engines(False, {"SSAD_TEACHER_F24": "1", "SSAD_SPLIT_CONV": "31"})
+    assert e.count((1, 48)) == 3 and e.count((2, 47)) == 4 and e.count((3, 67)) == 10
+    assert sum(o.code == PR.WINO_PACK_FILTERS and o.i[1] == 3 for o in bb.prep.ops) == 1      # frozen: packed once
+    monkeypatch.setenv("SSAD_SPLIT_CONV", "15")
     e, _ = engines(True, {"SSAD_STUDENT_F24": "7"})
     assert all(x == (1, 48) for x in e) and len(e) == 3 + 14 * 2
     e, bb = engines(False, {"SSAD_TEACHER_F24": "1"})
