@@ -62,7 +62,9 @@ def class_sequences(f16=False):
                 lv16[q] = src[q]
                 lv16[q].N = 16
             launches = K.lib().ssad_conv3x3_forward_wino_launches_for(lv16, op.i[0], op.i[1], op.i[2], op.i[3])
-            if op.i[4] == 3:      # the split-operand engine: one convolution launch per call (+ its |max| / split passes)
+            if op.i[4] == 3:      # the split-operand engine: a call = |max| pass + split pass + convolution, all its class
+                seq.setdefault("ssad_split::split_absmax_kernel", []).append((op.klass, False))
+                seq.setdefault("ssad_split::split_pack_act_kernel", []).append((op.klass, False))
                 seq.setdefault("conv3x3_split_kernel", []).append((op.klass, True))
                 continue
             if op.i[4] == 2:      # the F(2x4) engine: another kernel name, one launch per staging geometry
@@ -107,6 +109,8 @@ def attribute(dispatches, seq):
         for n, s in seq.items():
             for d, (k, first) in zip(per[n], s):
                 a = acc.setdefault(k, {"kernel": n, "dispatches": 0, "sum": {}})
+                if first:
+                    a["kernel"] = n                    # the call's main kernel names the row (not a helper pass)
                 a["dispatches"] += int(first)          # per CALL: a call's launches are summed
                 for cn, v in d["c"].items():
                     a["sum"][cn] = a["sum"].get(cn, 0.0) + v

@@ -48,6 +48,8 @@ def class_table(rows, f16):
         for n, q in seq.items():
             for d, (k, first) in zip(per[n], q):
                 a = acc.setdefault(k, [n, 0, 0])
+                if first:
+                    a[0] = n
                 a[1] += int(first)
                 a[2] += d
     out = ["", "By timing class (%d of %d captured steps matched the program's launch sequence; a call's launches are "
