@@ -643,6 +643,14 @@ def main():
                           "; backbones: this repo's fp16 kernels)" if (native and hkw) else
                           "; backbones: this repo's fp32 kernels)" if native else
                           "; backbones: torch autocast on MIOpen / rocBLAS)")),
+            "dtype_note": (None if f16 else
+                           "fp32 storage and fp32 accumulation everywhere.  The 3x3 convolutions of the subnets' towers and "
+                           "cls_pred and of the backbones' >= 256-wide layers run on the split-operand engine by default: "
+                           "each fp32 operand enters the fp16 matrix pipe as hi + lo (22 significant bits under a "
+                           "per-tensor power-of-two scale), three MFMAs per operand pair, measured error against "
+                           "float64 1.2e-6 of the output scale at K = 2304 (fp32 accumulation order; F(2x4) fp32 "
+                           "Winograd: 1.5-2.2e-6) and held to the direct fp32 kernel's parity bar.  "
+                           "also.cfg3_fp32_mfma_only = the same step with that engine off (fp32 MFMA instructions only)."),
             "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": N, "image": "3x%dx%d" % image_hw,
                        "fpn_levels": [list(s) for s in shapes], "anchors": 9, "classes": 80,
@@ -741,6 +749,21 @@ def main():
                 also["operator_surface"] = operator_surface_leg(dev)
             except Exception as e:
                 also["operator_surface"] = {"error": repr(e)}
+            # the headline configuration with every 3x3 convolution on fp32 MFMA instructions only (the split-operand
+            # engine off: SSAD_SPLIT_CONV=0 -> Winograd F(2x4) / F(2x2) as in round 5), for whoever wants the step
+            # without fp16-pipe products
+            prev = os.environ.get("SSAD_SPLIT_CONV")
+            os.environ["SSAD_SPLIT_CONV"] = "0"
+            try:
+                also["cfg3_fp32_mfma_only"] = also_leg(dev, 23, student="r50", teacher="r101", px=600, precision="f32",
+                                                       batch_per_gpu=16)
+            except Exception as e:
+                also["cfg3_fp32_mfma_only"] = {"error": repr(e)}
+            finally:
+                if prev is None:
+                    os.environ.pop("SSAD_SPLIT_CONV", None)
+                else:
+                    os.environ["SSAD_SPLIT_CONV"] = prev
             out["also"] = also
             out["also_note"] = ("other BASELINE configs on the same GPU, each built from scratch and run for a few "
                                 "steps AFTER the timed region of the headline, on the same high-priority stream; "

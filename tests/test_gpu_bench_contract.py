@@ -60,6 +60,12 @@ def test_default_bench_line_and_also_legs():
     assert osf["lowered"]["filter_packs_per_step"] == 20 and osf["as_written"]["filter_packs_per_step"] == 100
     assert osf["lowered"]["ms_per_step"] < osf["as_written"]["ms_per_step"]
     assert osf["lowered_over_program"] < 1.3, osf            # VERDICT r4 item 2's bar
+    # round 6: the headline configuration with the split-operand engine off (fp32 MFMA instructions only) in the same
+    # line, its dominant launch on F(2x4) against the fp32 MFMA peak; the headline's dtype note says what differs
+    f32 = also["cfg3_fp32_mfma_only"]
+    assert "error" not in f32 and f32["finite"] and f32["batch_per_gpu"] == 16 and f32["dtype"] == "f32", f32
+    assert f32["roofline"]["peak"] == 157.3 and "F(2x4" in f32["roofline"]["kernel"]
+    assert "split-operand" in d["dtype_note"] and d["dtype"] == "f32"
     assert np.allclose(osf["lowered"]["distill_loss"], osf["as_written"]["distill_loss"], rtol=1e-4)
     assert r.get("traffic_from_profile_round", "").startswith("r")
     assert d["config"]["collectives_per_step"] == 0 and d["config"]["parallelism"] == "dp1"
