@@ -1,11 +1,11 @@
-"""Round 4: every hand-synchronised kernel family under contention.  Each case runs repeatedly on the current stream
+"""Every hand-synchronised kernel family under contention (round 4; round 6: + the split-operand engines).  Each case runs repeatedly on the current stream
 while two other streams keep the chip busy with GEMM-shaped, Winograd and streaming work; every output is compared bit
 for bit with the output of a quiet run of the same call (all kernels are deterministic, so a difference is a
 synchronisation bug that only shows when memory is late -- how the in-flight-ring corruption of wino_conv_z_kernel
-was reproduced).      python tools/dbg/r4_kernel_stress.py [iterations]"""
+was reproduced).      python tools/kernel_stress.py [iterations]"""
 import os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ssad_amd  # noqa
 from ssad_amd import kernels as K
