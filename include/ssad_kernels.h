@@ -397,6 +397,17 @@ SSAD_API int ssad_conv3x3_wgrad(
     int Cout, int Cin, int accumulate, void* workspace, size_t workspace_bytes,
     ssad_stream_t stream);
 
+/* The same contract (dW, db, accumulate, deterministic reduction) on the split-operand engine: dY and X are scaled by a
+ * power of two from their measured |max| and split on the fly into hi + lo fp16; hi.hi + lo.hi + hi.lo run on
+ * v_mfma_f32_32x32x16_f16 into fp32 accumulators (22-bit products, direct form: no Winograd transform error).
+ * The call = |max| pass + main kernel + slab reduction (+ the bias gradient) on `stream`. */
+SSAD_API size_t ssad_conv3x3_wgrad_split_workspace_bytes(
+    const ssad_conv_level* levels_host, int n_levels, int Cout, int Cin);
+SSAD_API int ssad_conv3x3_wgrad_split(
+    const ssad_conv_level* levels_host, int n_levels, float* dW, float* db,
+    int Cout, int Cin, int accumulate, void* workspace, size_t workspace_bytes,
+    ssad_stream_t stream);
+
 /* ---------------------------------------------------------------------- */
 /* RetinaNet anchor labelling on the device (row f4)                       */
 /* ---------------------------------------------------------------------- */

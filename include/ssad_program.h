@@ -48,7 +48,7 @@ enum ssad_opcode {
    * workspace bytes, p4 = amax_in or NULL, p5 = amax_out or NULL) */
   SSAD_OP_CONV3X3 = 3,
   /* ssad_conv3x3_wgrad(p0 = levels_host, i0 = n, p1 = dW, p2 = db, i1 = Cout, i2 = Cin,
-   * i3 = accumulate, p3 = workspace, l0 = workspace_bytes) */
+   * i3 = accumulate, p3 = workspace, l0 = workspace_bytes); i4 == 1: ssad_conv3x3_wgrad_split, same arguments */
   SSAD_OP_CONV3X3_WGRAD = 4,
   /* ssad_pow_sum(p0 = inputs_host, p1 = sizes_host, i0 = n, f0 = power, p2 = out,
    * p3 = workspace, l0 = workspace_bytes) */

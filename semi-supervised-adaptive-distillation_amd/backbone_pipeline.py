@@ -347,10 +347,13 @@ class NativeResNetFPN(object):
     def _wgrad3(self, P, x, dy, layer):
         arr = (K.ConvLevel * 1)()
         arr[0] = K.ConvLevel(x.data_ptr(), 0, dy.data_ptr(), x.shape[0], x.shape[2], x.shape[3], 0, 0)
-        nb = K.lib().ssad_conv3x3_wgrad_workspace_bytes(arr, 1, layer.cout, layer.cin)
+        # SSAD_SPLIT_CONV bit 64: the >= 128-wide 3x3 filter gradients on the split-operand engine
+        split = (int(os.environ.get("SSAD_SPLIT_CONV", "31")) & 64) != 0 and layer.cout >= 128 and layer.cin >= 128
+        size_fn = K.lib().ssad_conv3x3_wgrad_split_workspace_bytes if split else K.lib().ssad_conv3x3_wgrad_workspace_bytes
+        nb = size_fn(arr, 1, layer.cout, layer.cin)
         self._ws_need = max(self._ws_need, nb)
         self._aux(P)
-        idx = P.add(PR.CONV3X3_WGRAD, 49, i=(1, layer.cout, layer.cin, 0), l=(nb,),
+        idx = P.add(PR.CONV3X3_WGRAD, 70 if split else 49, i=(1, layer.cout, layer.cin, 0, 1 if split else 0), l=(nb,),
                     p=(arr, layer.gw, layer.gb, None),
                     work=2.0 * 9 * layer.cout * layer.cin * x.shape[0] * x.shape[2] * x.shape[3], keep=[x, dy],
                     stream=self._wstream)

@@ -570,6 +570,20 @@ __global__ void bias_grad_finalize_kernel(const double* __restrict__ partials, i
   db[m] = accumulate ? db[m] + (float)t : (float)t;
 }
 
+void launch_bias_grad(const ssad_conv_level* levels_host, int n_levels, int Cout, float* db, int accumulate,
+                      double* partials, hipStream_t s) {
+  BiasArgs b;
+  b.n_levels = n_levels; b.M = Cout;
+  for (int l = 0; l < SSAD_MAX_LEVELS; ++l) {
+    b.dy[l] = l < n_levels ? levels_host[l].aux : nullptr;
+    b.N[l] = l < n_levels ? levels_host[l].N : 0;
+    b.HW[l] = l < n_levels ? levels_host[l].H * levels_host[l].W : 0;
+  }
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout, kBiasParts), dim3(256), 0, s, b, partials);
+  hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s,
+                     (const double*)partials, Cout, db, accumulate);
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -728,19 +742,28 @@ int ssad_conv3x3_wgrad(const ssad_conv_level* levels_host, int n_levels, float* 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per_split + 255) / 256)), dim3(256),
                        0, s, (const float*)a.slabs, a.splits, mtp, ctp, Cout, Cin, dW, accumulate);
   }
-  if (db) {
-    BiasArgs b;
-    b.n_levels = n_levels; b.M = Cout;
-    for (int l = 0; l < SSAD_MAX_LEVELS; ++l) {
-      b.dy[l] = l < n_levels ? levels_host[l].aux : nullptr;
-      b.N[l] = l < n_levels ? levels_host[l].N : 0;
-      b.HW[l] = l < n_levels ? levels_host[l].H * levels_host[l].W : 0;
-    }
-    double* bp = (double*)((char*)workspace + slab_bytes);
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout, kBiasParts), dim3(256), 0, s, b, bp);
-    hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s,
-                       (const double*)bp, Cout, db, accumulate);
-  }
+  if (db) launch_bias_grad(levels_host, n_levels, Cout, db, accumulate, (double*)((char*)workspace + slab_bytes), s);
+  return (int)hipGetLastError();
+}
+
+/* The same contract on the split-operand engine (conv3x3_wgrad_split.hip). */
+size_t ssad_conv3x3_wgrad_split_workspace_bytes(const ssad_conv_level* levels_host, int n_levels, int Cout, int Cin) {
+  const size_t slab = ssad_split_wgrad_workspace_bytes(levels_host, n_levels, Cout, Cin);
+  if (!slab) return 0;
+  return ((slab + 255) & ~(size_t)255) + sizeof(double) * (size_t)Cout * kBiasParts;
+}
+
+int ssad_conv3x3_wgrad_split(const ssad_conv_level* levels_host, int n_levels, float* dW, float* db, int Cout, int Cin,
+                             int accumulate, void* workspace, size_t workspace_bytes, ssad_stream_t stream) {
+  if (!levels_host || !dW) return SSAD_E_BADARG;
+  const size_t slab = ssad_split_wgrad_workspace_bytes(levels_host, n_levels, Cout, Cin);
+  if (!slab) return SSAD_E_BADARG;
+  const size_t slab_bytes = (slab + 255) & ~(size_t)255;
+  if (!workspace || workspace_bytes < slab_bytes + sizeof(double) * (size_t)Cout * kBiasParts) return SSAD_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = ssad_split_wgrad_launch(levels_host, n_levels, dW, Cout, Cin, accumulate, workspace, slab_bytes, s);
+  if (rc) return rc;
+  if (db) launch_bias_grad(levels_host, n_levels, Cout, db, accumulate, (double*)((char*)workspace + slab_bytes), s);
   return (int)hipGetLastError();
 }
 

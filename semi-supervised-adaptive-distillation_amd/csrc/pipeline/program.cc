@@ -103,6 +103,9 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
       return (i[4] == 2 ? ssad_conv3x3_forward_wino24 : i[4] ? ssad_conv3x3_forward_wino : ssad_conv3x3_forward)(
           (const ssad_conv_level*)p[0], i[0], (const float*)p[1], (const float*)p[2], i[1], i[2], i[3], s);
     case SSAD_OP_CONV3X3_WGRAD:
+      if (i[4] == 1)
+        return ssad_conv3x3_wgrad_split((const ssad_conv_level*)p[0], i[0], (float*)p[1], (float*)p[2], i[1], i[2],
+                                        i[3], (void*)p[3], (size_t)o.l[0], s);
       return ssad_conv3x3_wgrad((const ssad_conv_level*)p[0], i[0], (float*)p[1], (float*)p[2], i[1], i[2],
                                 i[3], (void*)p[3], (size_t)o.l[0], s);
     case SSAD_OP_POW_SUM:

@@ -242,13 +242,18 @@ class DistillHeads(object):
 
     def _emit_wgrad(self, P, xs, dys, name, Cout, klass):
         arr = self._conv_table([(xs, None, dys, None, None)])
-        nb = K.lib().ssad_conv3x3_wgrad_workspace_bytes(arr, len(arr), Cout, self.D)
+        # SSAD_SPLIT_CONV bit 32: the >= 128-wide filter gradients on the split-operand engine
+        split = bool(self.split_conv & 32) and Cout >= 128 and self.D >= 64
+        size_fn = K.lib().ssad_conv3x3_wgrad_split_workspace_bytes if split else K.lib().ssad_conv3x3_wgrad_workspace_bytes
+        nb = size_fn(arr, len(arr), Cout, self.D)
         self._wgrad_ws_need = max(getattr(self, "_wgrad_ws_need", 0), nb)
         px = sum(x.shape[0] * x.shape[2] * x.shape[3] for x in xs)
         if self._wstream:
             P.fork(self._wstream)       # behind everything enqueued so far (the producer of dys)
+        if split:
+            klass = {5: 68, 6: 69}.get(klass, klass)
         idx = P.add(PR.CONV3X3_WGRAD, klass if self._use_wino(Cout) else 19,
-                    i=(len(arr), Cout, self.D, 0), l=(nb,),
+                    i=(len(arr), Cout, self.D, 0, 1 if split else 0), l=(nb,),
                     p=(arr, self.grads[name + "_w"], self.grads[name + "_b"], None),
                     work=2.0 * 9 * Cout * self.D * px, keep=list(xs) + list(dys), stream=self._wstream)
         self._wgrad_ops.append(idx)

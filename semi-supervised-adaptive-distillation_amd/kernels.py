@@ -196,6 +196,9 @@ def lib():
     L.ssad_conv3x3_wgrad_workspace_bytes.restype = sz
     L.ssad_conv3x3_wgrad_workspace_bytes.argtypes = [C.POINTER(ConvLevel), i32, i32, i32]
     L.ssad_conv3x3_wgrad.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp, sz, vp]
+    L.ssad_conv3x3_wgrad_split_workspace_bytes.restype = sz
+    L.ssad_conv3x3_wgrad_split_workspace_bytes.argtypes = [C.POINTER(ConvLevel), i32, i32, i32]
+    L.ssad_conv3x3_wgrad_split.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp, sz, vp]
     L.ssad_conv1x1_gemm.argtypes = [C.POINTER(GemmConv), vp]
     L.ssad_conv1x1_gemm_split_workspace_bytes.restype = sz
     L.ssad_conv1x1_gemm_split_workspace_bytes.argtypes = [C.POINTER(GemmConv)]
@@ -774,22 +777,25 @@ def conv3x3_forward_multi(problems, Cout, *, relu=False, sigmoid=False, wino=Fal
     return ys
 
 
-def conv3x3_wgrad(xs, dys, Cout, *, want_db=True, accumulate=False, dW=None, db=None):
-    """dW[Cout,Cin,3,3] and db[Cout] summed over all levels and images."""
+def conv3x3_wgrad(xs, dys, Cout, *, want_db=True, accumulate=False, dW=None, db=None, split=False):
+    """dW[Cout,Cin,3,3] and db[Cout] summed over all levels and images.  split: the split-operand engine
+    (ssad_conv3x3_wgrad_split) instead of the exact-fp32 ones."""
     L = lib()
     Cin = xs[0].shape[1]
     for x, d in zip(xs, dys):
         _f32c(x, "x"); _f32c(d, "dy")
     arr = _conv_levels(xs, None, dys)
-    nb = L.ssad_conv3x3_wgrad_workspace_bytes(arr, len(xs), Cout, Cin)
+    size_fn = L.ssad_conv3x3_wgrad_split_workspace_bytes if split else L.ssad_conv3x3_wgrad_workspace_bytes
+    fn = L.ssad_conv3x3_wgrad_split if split else L.ssad_conv3x3_wgrad
+    nb = size_fn(arr, len(xs), Cout, Cin)
     ws = _workspace(nb, "wgrad")
     if dW is None:
         dW = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device="cuda")
     if db is None and want_db:
         db = torch.empty(Cout, dtype=torch.float32, device="cuda")
-    _check(L.ssad_conv3x3_wgrad(arr, len(xs), _ptr(dW), _ptr(db) if want_db else None, Cout,
-                                Cin, int(accumulate), _ptr(ws), nb, _stream()),
-           "conv3x3_wgrad")
+    _check(fn(arr, len(xs), _ptr(dW), _ptr(db) if want_db else None, Cout,
+              Cin, int(accumulate), _ptr(ws), nb, _stream()),
+           "conv3x3_wgrad_split" if split else "conv3x3_wgrad")
     return dW, db
 
 

@@ -104,6 +104,12 @@ KLASS = {
              bound="mfma16", wino=True, exec_div=1.0 / 3.0),
     67: dict(name="teacher backbone conv3x3 fwd, >= 256 wide, split-operand engine (conv3x3_split_kernel + passes)",
              bound="mfma16", wino=True, exec_div=1.0 / 3.0),
+    68: dict(name="subnet conv3x3 filter gradient, tower layers, split-operand engine (wsplit_kernel + |max| + reduce + bias "
+                  "grad; SSAD_SPLIT_CONV & 32)", bound="mfma16", wino=True, exec_div=1.0 / 3.0),
+    69: dict(name="cls_pred filter gradient, split-operand engine (wsplit_kernel + |max| + reduce + bias grad)",
+             bound="mfma16", wino=True, exec_div=1.0 / 3.0),
+    70: dict(name="backbone conv3x3 filter gradient, >= 128 wide, split-operand engine (wsplit_kernel + passes; "
+                  "SSAD_SPLIT_CONV & 64)", bound="mfma16", wino=True, exec_div=1.0 / 3.0),
     64: dict(name="P6 / P7 3x3 stride-2 conv fwd / data gradient at their own size (implicit GEMM with split-K; "
                   "flattened-batch GEMM + col2im)", bound="mfma", wino=False),
     65: dict(name="P6 / P7 3x3 stride-2 filter gradient (im2col + gemm_conv_nt_kernel + reduce)", bound="mfma",

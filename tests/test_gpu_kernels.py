@@ -643,6 +643,68 @@ def test_winograd_wgrad_multilevel_matches_direct_full_size(K, wgrad_engine):
 
 
 # ---------------------------------------------------------------------------
+# Split-operand filter gradient (conv3x3_wgrad_split.hip): the same contract at the same (unwidened) tolerance
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [
+    (1, 64, 64, 8, 16), (2, 16, 40, 9, 17), (2, 36, 256, 5, 7), (1, 256, 256, 10, 14),
+    (1, 24, 130, 17, 33), (3, 8, 65, 2, 31), (1, 720, 256, 5, 7), (2, 256, 36, 13, 20), (1, 70, 130, 1, 1),
+    (2, 128, 128, 20, 28)],
+    ids=lambda s: "N%d_C%d_M%d_%dx%d" % s)
+def test_split_wgrad_vs_oracle(K, shape):
+    N, Cin, M, H, W = shape
+    rng = np.random.default_rng(2100 + sum(shape))
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((M, Cin, 3, 3)) * 0.05).astype(np.float32)
+    dY = rng.standard_normal((N, M, H, W)).astype(np.float32)
+    ref_dW, ref_db, _ = oracle.conv_backward(X, Wt, dY, want_db=True)
+    dW, db = K.conv3x3_wgrad([dev(X)], [dev(dY)], M, split=True)
+    close(dW.cpu().numpy(), ref_dW, CONV_RTOL, CONV_FLOOR, "split dW")
+    close(db.cpu().numpy(), ref_db, CONV_RTOL, CONV_FLOOR, "db")
+    base = dev(np.full_like(ref_dW, 0.25))
+    K.conv3x3_wgrad([dev(X)], [dev(dY)], M, dW=base, want_db=False, accumulate=True, split=True)
+    close(base.cpu().numpy(), ref_dW + 0.25, CONV_RTOL, CONV_FLOOR, "split dW accumulate")
+
+
+@pytest.mark.parametrize("scales", [(1e-6, 1e4), (3e7, 1e-9), (1.0, 1.0)], ids=lambda s: "x%g_dy%g" % s)
+def test_split_wgrad_extreme_magnitudes_and_wide_dynamic_range(K, scales):
+    """The power-of-two scales come from the measured |max|: tiny gradients against large activations (and the
+    reverse) must not lose anything, and elements 2^-12 below the tensor's largest must still count."""
+    sx, sdy = scales
+    rng = np.random.default_rng(77)
+    N, Cin, M, H, W = 2, 64, 128, 12, 20
+    X = (rng.standard_normal((N, Cin, H, W)) * sx).astype(np.float32)
+    dY = (rng.standard_normal((N, M, H, W)) * sdy).astype(np.float32)
+    X[:, ::2] *= np.float32(2.0 ** -12)          # half the channels far below the |max|
+    dY[:, 1::2] *= np.float32(2.0 ** -12)
+    Wt = np.zeros((M, Cin, 3, 3), np.float32)
+    ref_dW, _, _ = oracle.conv_backward(X, Wt, dY, want_db=False)
+    dW, _ = K.conv3x3_wgrad([dev(X)], [dev(dY)], M, want_db=False, split=True)
+    got = dW.cpu().numpy()
+    close(got, ref_dW, CONV_RTOL, CONV_FLOOR, "split dW, scaled")
+    # the quiet block on its own scale: (even input channel, odd output channel) is 2^-24 of the loudest
+    q_ref, q_got = ref_dW[1::2, ::2], got[1::2, ::2]
+    assert np.abs(q_got - q_ref).max() <= 2e-3 * np.abs(q_ref).max(), np.abs(q_got - q_ref).max() / np.abs(q_ref).max()
+
+
+def test_split_wgrad_multilevel_full_size_vs_winograd_and_deterministic(K, wgrad_engine):
+    gen = torch.Generator(device="cuda").manual_seed(33)
+    N, C, M = 4, 256, 256
+    shapes = [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)]
+    Xs = [torch.randn((N, C, h, w), device="cuda", generator=gen) for h, w in shapes]
+    dYs = [torch.randn((N, M, h, w), device="cuda", generator=gen) for h, w in shapes]
+    wgrad_engine("direct")
+    dWd, dbd = K.conv3x3_wgrad(Xs, dYs, M)
+    dWd, dbd = dWd.clone(), dbd.clone()
+    dWs, dbs = K.conv3x3_wgrad(Xs, dYs, M, split=True)
+    dWs = dWs.clone()
+    close(dWs.cpu().numpy(), dWd.cpu().numpy(), CONV_RTOL, CONV_FLOOR, "split wgrad vs direct")
+    assert torch.equal(dbs, dbd)
+    dW2, _ = K.conv3x3_wgrad(Xs, dYs, M, want_db=False, split=True)
+    assert torch.equal(dW2, dWs)
+
+
+# ---------------------------------------------------------------------------
 # The DEFAULT engine (Winograd forward / data gradient / filter gradient) at the headline
 # size, bs 16 on P3 (80 x 112), against the oracle -- not against another HIP kernel
 # ---------------------------------------------------------------------------
