@@ -116,6 +116,7 @@ def kernel_report(classes, steps):
 # which kernel source a timing class's dominant kernel lives in (for the staleness check of `traffic`)
 _KERNEL_SOURCE = {"wino_conv_z_kernel": "conv3x3_winograd.hip", "wino24_conv_kernel": "conv3x3_winograd24.hip",
                   "conv3x3_split_kernel": "conv3x3_split.hip", "wino_wgrad_kernel": "conv3x3_wgrad_winograd.hip",
+                  "wsplit_kernel": "conv3x3_wgrad_split.hip",
                   "pow_sum_kernel": "distill_loss.hip", "cls_losses_fused_kernel": "distill_loss.hip",
                   "sgd_flat_kernel": "elementwise.hip"}
 

@@ -347,8 +347,9 @@ class NativeResNetFPN(object):
     def _wgrad3(self, P, x, dy, layer):
         arr = (K.ConvLevel * 1)()
         arr[0] = K.ConvLevel(x.data_ptr(), 0, dy.data_ptr(), x.shape[0], x.shape[2], x.shape[3], 0, 0)
-        # SSAD_SPLIT_CONV bit 64: the >= 128-wide 3x3 filter gradients on the split-operand engine
-        split = (int(os.environ.get("SSAD_SPLIT_CONV", "31")) & 64) != 0 and layer.cout >= 128 and layer.cin >= 128
+        # SSAD_SPLIT_CONV bit 64 (default): the >= 256-wide 3x3 filter gradients on the split-operand engine (the
+        # 128-wide res3 layers are level with the F(3x3, 2x2) engine there: 2 blocks of dW, 128 slabs to reduce)
+        split = (int(os.environ.get("SSAD_SPLIT_CONV", "127")) & 64) != 0 and layer.cout >= 256 and layer.cin >= 256
         size_fn = K.lib().ssad_conv3x3_wgrad_split_workspace_bytes if split else K.lib().ssad_conv3x3_wgrad_workspace_bytes
         nb = size_fn(arr, 1, layer.cout, layer.cin)
         self._ws_need = max(self._ws_need, nb)
@@ -468,7 +469,7 @@ class NativeResNetFPN(object):
         use_f24_train = self.train and (int(os.environ.get("SSAD_STUDENT_F24", "15")) & 8) != 0
         # SSAD_SPLIT_CONV bit 16: the >= 256-wide stride-1 3x3 layers (res4, res5, FPN outputs) on the split-operand engine
         # (default on: step -0.1 ... -1.3 ms in four same-box A/B pairs, profiles/r06_experiments.md)
-        use_split = (int(os.environ.get("SSAD_SPLIT_CONV", "31")) & 16) != 0 and (use_f24 or use_f24_train)
+        use_split = (int(os.environ.get("SSAD_SPLIT_CONV", "127")) & 16) != 0 and (use_f24 or use_f24_train)
         split_frozen, split_train = [], []
         self._split_ops, self._split_need = [], 0
         tr_frozen, tr_train = [], []          # (w, wt, M, K, ldm): every transposed filter of a program in one launch

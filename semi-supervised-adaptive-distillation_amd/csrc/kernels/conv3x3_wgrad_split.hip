@@ -35,7 +35,8 @@ using namespace ssad_split;
 
 namespace {
 
-constexpr int CO_T = 64, CI_T = 64;         // workgroup block of dW
+constexpr int CO_T = 128, CI_T = 64;        // workgroup block of dW
+constexpr int kWG = 512;                    // 8 waves, two per SIMD
 constexpr int RW = 4, XR = RW + 2;          // rows of dY / of X per chunk
 constexpr int SW = 16;                      // strip width = the MFMA's reduction depth
 // LDS records: one per channel, the 16-byte groups (row, half strip) side by side, padded so that 16 consecutive
@@ -130,28 +131,32 @@ __device__ __forceinline__ Chunk decode(const WArgs& a, int q) {
   return c;
 }
 
-// What one thread fetches for a chunk: 2 groups (8 pixels) of dY, 3 groups of X and 3 halo pixels of X.
-//   dY: thread -> (half strip g = t & 1, row r = (t >> 1) & 3, channel (t >> 3) + 32 i), i = 0..1
-//   X:  thread -> (half strip g = t & 1, row 2 i + ((t >> 1) & 1), channel t >> 2),       i = 0..2
-// Groups outside the tensor are sent to an offset the descriptor rejects (they read 0) and are zeroed again when the
-// group is split (a group that straddles the end of a row is cut there).
+// What one thread (of 512) fetches for a chunk: 2 groups (8 pixels) of dY, 3 quads (4 pixels) of X and 2 halo pixels of X.
+//   dY:   thread -> (half strip g = t & 1, row r = (t >> 1) & 3, channel (t >> 3) + 64 i),            i = 0..1
+//   X:    thread -> (quad t & 3 of the strip, row 2 i + ((t >> 2) & 1), channel t >> 3),              i = 0..2
+//   halo: thread -> (side t & 1: left / right of the strip, row 4 i + ((t >> 1) & 3), channel t >> 3), i = 0..1 (rows < 6)
+// Anything outside the tensor is sent to an offset the descriptor rejects and reads 0; a group that straddles the end
+// of a row is cut when it is split (MASKED: only the last strip of a level whose width is not a multiple of 16).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
 struct Fetch {
   float dy[2][8];
-  float x[3][8];
-  float h[3];
+  f32x4 x[3];
+  float h[2];
 };
 
 template <bool VEC>
-__device__ __forceinline__ void load8(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, int soff, float (&v)[8]) {
+__device__ __forceinline__ void load8(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float (&v)[8]) {
   if (VEC) {
-    const f32x4 p = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, soff, 0));
-    const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, soff + 16, 0));
+    const f32x4 p = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+    const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 16, 0));
     v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3];
     v[4] = q[0]; v[5] = q[1]; v[6] = q[2]; v[7] = q[3];
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, soff + 4 * e, 0));
+      v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 4 * e, 0));
   }
 }
 
@@ -161,97 +166,102 @@ __device__ __forceinline__ void fetch_chunk(const WArgs& a, const Chunk& c, int 
   const int H = L.H, W = L.W;
   const __amdgpu_buffer_rsrc_t drs = uniform_rsrc(L.dy, L.dy_bytes);
   const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(L.x, L.x_bytes);
-  const int g = t & 1;
   {
-    const int r = (t >> 1) & 3, m = m0 + (t >> 3), y = c.y0 + r, x = c.x0 + 8 * g;
+    const int g = t & 1, r = (t >> 1) & 3, m = m0 + (t >> 3), y = c.y0 + r, x = c.x0 + 8 * g;
     const unsigned off = (unsigned)((((c.n * a.M + m) * H + y) * W + x) * 4);
-    const unsigned stride = (unsigned)(32 * H * W * 4);
+    const unsigned stride = (unsigned)(64 * H * W * 4);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      load8<VEC>(drs, (y < H && x < W && m + 32 * i < a.M) ? off + i * stride : kOob, 0, f.dy[i]);
+      load8<VEC>(drs, (y < H && x < W && m + 64 * i < a.M) ? off + i * stride : kOob, f.dy[i]);
   }
   {
-    // (per-i vector offsets here: row -1 of channel 0 would be a negative vector offset, which the range check rejects
-    // whatever the scalar offset adds)
-    const int ch = c0 + (t >> 2), x = c.x0 + 8 * g;
-    const int hx = g ? c.x0 + SW : c.x0 - 1;           // the halo pixel: left of the strip (g = 0) or right of it
+    const int ch = c0 + (t >> 3);
+    const int chrow = (c.n * a.C + ch) * H;
+    const bool chok = ch < a.C;
+    const int x = c.x0 + 4 * (t & 3);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int y = c.y0 - 1 + 2 * i + ((t >> 1) & 1);
-      const bool ok = y >= 0 && y < H;
-      const int row = ((c.n * a.C + ch) * H + y) * W;
-      load8<VEC>(xrs, ok && x < W ? (unsigned)((row + x) * 4) : kOob, 0, f.x[i]);
+      const int y = c.y0 - 1 + 2 * i + ((t >> 2) & 1);
+      const unsigned off = (chok && y >= 0 && y < H && x < W) ? (unsigned)(((chrow + y) * W + x) * 4) : kOob;
+      if (VEC) {
+        f.x[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          f.x[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, 4 * e, 0));
+      }
+    }
+    const int hx = (t & 1) ? c.x0 + SW : c.x0 - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rr = 4 * i + ((t >> 1) & 3), y = c.y0 - 1 + rr;
+      const bool ok = chok && rr < XR && y >= 0 && y < H && hx >= 0 && hx < W;
       f.h[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-          xrs, ok && hx >= 0 && hx < W ? (unsigned)((row + hx) * 4) : kOob, 0, 0));
+          xrs, ok ? (unsigned)(((chrow + y) * W + hx) * 4) : kOob, 0, 0));
     }
   }
 }
 
-// Geometry of the chunk whose fetch is in the registers (all wave-uniform).
-struct Geo {
-  int W, H, y0, x0;
-};
-
-// Split and write to LDS the dY groups [d0, d1) and the X groups (+ halo pixels) [x0, x1) of a fetched chunk.
-template <int D0, int D1, int X0, int X1>
-__device__ __forceinline__ void stage_part(const Geo& G, int mleft, int cleft, int t, const Fetch& f, char* stage,
-                                           float sx, float sdy) {
-  const int g = t & 1;
-  const int nv = G.W - (G.x0 + 8 * g);                // valid pixels of the group (<= 0: none)
+// Split and write to LDS part of a fetched chunk: the dY groups [D0, D1), the X quads [X0, X1), the halo pixels
+// [H0, H1).  nv = the strip's valid pixels (MASKED only).
+template <bool MASKED, int D0, int D1, int X0, int X1, int H0, int H1>
+__device__ __forceinline__ void stage_part(int nv, int t, const Fetch& f, char* stage, float sx, float sdy) {
   if (D0 < D1) {
-    const int r = (t >> 1) & 3, co = t >> 3;
-    const int nvr = G.y0 + r < G.H ? nv : 0;
+    const int g = t & 1, r = (t >> 1) & 3, co = t >> 3;
     char* p0 = stage + co * A_REC + (2 * r + g) * 16;
 #pragma unroll
     for (int i = D0; i < D1; ++i) {
-      const int n = co + 32 * i < mleft ? nvr : 0;
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = e < n ? f.dy[i][e] : 0.0f;
+      for (int e = 0; e < 8; ++e) v[e] = (!MASKED || 8 * g + e < nv) ? f.dy[i][e] : 0.0f;
       half8 hi, lo;
       split8(v, sdy, hi, lo);
-      char* p = p0 + i * 32 * A_REC;
+      char* p = p0 + i * 64 * A_REC;
       *reinterpret_cast<half8*>(p) = hi;
       *reinterpret_cast<half8*>(p + A_PLANE) = lo;
     }
   }
   if (X0 < X1) {
-    const int rlo = (t >> 1) & 1, ci = t >> 2;
-    const int hx = g ? G.x0 + SW : G.x0 - 1;
-    const bool chok = ci < cleft;
-    char* p0 = stage + 2 * A_PLANE + ci * B_REC + (2 * rlo + g) * 16;
-    char* q0 = stage + 2 * A_PLANE + ci * B_REC + B_HALO + (2 * rlo + g) * 4;
+    const int q4 = t & 3, rlo = (t >> 2) & 1, ci = t >> 3;
+    char* p0 = stage + 2 * A_PLANE + ci * B_REC + rlo * 32 + q4 * 8;
 #pragma unroll
     for (int i = X0; i < X1; ++i) {
-      const int y = G.y0 - 1 + 2 * i + rlo;
-      const bool rowok = chok && y >= 0 && y < G.H;
-      const int n = rowok ? nv : 0;
-      float v[8];
+      half4 hi, lo;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = e < n ? f.x[i][e] : 0.0f;
-      half8 hi, lo;
-      split8(v, sx, hi, lo);
+      for (int e = 0; e < 4; ++e) {
+        const float xs = ((!MASKED || 4 * q4 + e < nv) ? f.x[i][e] : 0.0f) * sx;
+        const _Float16 h = (_Float16)xs;
+        hi[e] = h;
+        lo[e] = (_Float16)(xs - (float)h);
+      }
       char* p = p0 + i * 64;
-      *reinterpret_cast<half8*>(p) = hi;
-      *reinterpret_cast<half8*>(p + B_PLANE) = lo;
-      // halo word: the left pixel sits in the HIGH half (it is shifted in from below), the right one in the LOW half
-      const float hs = (rowok && hx >= 0 && hx < G.W) ? f.h[i] * sx : 0.0f;
+      *reinterpret_cast<half4*>(p) = hi;
+      *reinterpret_cast<half4*>(p + B_PLANE) = lo;
+    }
+  }
+  if (H0 < H1) {
+    const int side = t & 1, ci = t >> 3;
+    // halo word: the left pixel sits in the HIGH half (it is shifted in from below), the right one in the LOW half
+    char* q0 = stage + 2 * A_PLANE + ci * B_REC + B_HALO + (2 * ((t >> 1) & 3) + side) * 4;
+#pragma unroll
+    for (int i = H0; i < H1; ++i) {
+      const float hs = f.h[i] * sx;
       const _Float16 hh = (_Float16)hs;
       const _Float16 hl = (_Float16)(hs - (float)hh);
       const unsigned bh = (unsigned)__builtin_bit_cast(unsigned short, hh), bl = (unsigned)__builtin_bit_cast(unsigned short, hl);
-      char* q = q0 + i * 16;
-      *reinterpret_cast<unsigned*>(q) = g ? bh : bh << 16;
-      *reinterpret_cast<unsigned*>(q + B_PLANE) = g ? bl : bl << 16;
+      if (i == 0 || ((t >> 1) & 3) < XR - 4) {
+        char* q = q0 + i * 32;
+        *reinterpret_cast<unsigned*>(q) = side ? bh : bh << 16;
+        *reinterpret_cast<unsigned*>(q + B_PLANE) = side ? bl : bl << 16;
+      }
     }
   }
 }
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(kThreads, 1) void wsplit_kernel(const WArgs a) {
+__global__ __launch_bounds__(kWG, 1) void wsplit_kernel(const WArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wco = wave & 1, wci = wave >> 1;
+  const int wco = wave & 3, wci = wave >> 2;
   const int g = lane >> 5, ln = lane & 31;
 
   // block -> (share, tile): the tiles of one share read the same pixels, so they sit on one XCD (blocks go to the
@@ -271,7 +281,6 @@ __global__ __launch_bounds__(kThreads, 1) void wsplit_kernel(const WArgs a) {
   const int q_begin = share * a.per_share;
   const int q_end = q_begin + a.per_share < a.total ? q_begin + a.per_share : a.total;
 
-  const int mleft = a.M - m0, cleft = a.C - c0;       // channels of the tile that exist
   const float sx = pow2f(15 - split_exponent(a.amax[0]));
   const float sdy = pow2f(15 - split_exponent(a.amax[1]));
 
@@ -289,109 +298,112 @@ __global__ __launch_bounds__(kThreads, 1) void wsplit_kernel(const WArgs a) {
   const int prev_base = g ? 12 : B_HALO, prev_step = g ? 32 : 8;              // the word left of the group
   const int next_base = g ? B_HALO + 4 : 16, next_step = g ? 8 : 32;          // the word right of it
 
-  // A REGION = one row of the chunk (16 pixels) x one filter row ky: 9 MFMAs.  The three products of an accumulator
-  // block are issued three blocks apart, so no MFMA waits for the one before it.  The LDS reads of a region are issued
-  // one region ahead (raw words; the shifted operands are made where they are used), and a sixth of the next
-  // chunk's split runs in the shadow of each of the first six regions' MFMAs; sched_barriers keep the compiler from
-  // merging regions (it then hoists every read of the chunk and spills).
-  struct BRaw { u32x4 m[2]; unsigned pv[2], nx[2]; };
-  struct ARaw { half8 hi, lo; };
+  // One row of X (16 + 2 pixels, 32 channels of the wave) is read and shifted ONCE and multiplies every (dY row r,
+  // filter row ky) pair with r + ky = that row: up to 3 x 9 MFMAs.  The three products of an accumulator block are
+  // issued three blocks apart, so no MFMA waits for the one before it.
+  struct BOps { half8 b[2][3]; };                     // [hi / lo][kx]
+  struct ARow { half8 hi, lo; };
   auto load_b = [&](const char* stage, int rr) {
-    BRaw w;
+    BOps w;
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
       const char* rec = stage + b_off + pl * B_PLANE;
-      w.m[pl] = *reinterpret_cast<const u32x4*>(rec + rr * 32 + g * 16);
-      w.pv[pl] = *reinterpret_cast<const unsigned*>(rec + prev_base + rr * prev_step);
-      w.nx[pl] = *reinterpret_cast<const unsigned*>(rec + next_base + rr * next_step);
-    }
-    return w;
-  };
-  auto load_a = [&](const char* stage, int r) {
-    ARaw w;
-    const char* p = stage + a_off + r * 32;
-    w.hi = *reinterpret_cast<const half8*>(p);
-    w.lo = *reinterpret_cast<const half8*>(p + A_PLANE);
-    return w;
-  };
-  auto mul = [&](auto KY, const ARaw& A, const BRaw& w) {
-    constexpr int ky = decltype(KY)::value;
-    half8 b[2][3];                                    // [hi / lo][kx]
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-      const u32x4 m = w.m[pl];
+      const u32x4 m = *reinterpret_cast<const u32x4*>(rec + rr * 32 + g * 16);
+      const unsigned pv = *reinterpret_cast<const unsigned*>(rec + prev_base + rr * prev_step);
+      const unsigned nx = *reinterpret_cast<const unsigned*>(rec + next_base + rr * next_step);
       u32x4 lft, rgt;
-      lft[0] = __builtin_amdgcn_alignbit(m[0], w.pv[pl], 16);
+      lft[0] = __builtin_amdgcn_alignbit(m[0], pv, 16);
       lft[1] = __builtin_amdgcn_alignbit(m[1], m[0], 16);
       lft[2] = __builtin_amdgcn_alignbit(m[2], m[1], 16);
       lft[3] = __builtin_amdgcn_alignbit(m[3], m[2], 16);
       rgt[0] = lft[1];
       rgt[1] = lft[2];
       rgt[2] = lft[3];
-      rgt[3] = __builtin_amdgcn_alignbit(w.nx[pl], m[3], 16);
-      b[pl][0] = __builtin_bit_cast(half8, lft);
-      b[pl][1] = __builtin_bit_cast(half8, m);
-      b[pl][2] = __builtin_bit_cast(half8, rgt);
+      rgt[3] = __builtin_amdgcn_alignbit(nx, m[3], 16);
+      w.b[pl][0] = __builtin_bit_cast(half8, lft);
+      w.b[pl][1] = __builtin_bit_cast(half8, m);
+      w.b[pl][2] = __builtin_bit_cast(half8, rgt);
     }
+    return w;
+  };
+  auto load_a = [&](const char* stage, int r) {
+    ARow w;
+    const char* p = stage + a_off + r * 32;
+    w.hi = *reinterpret_cast<const half8*>(p);
+    w.lo = *reinterpret_cast<const half8*>(p + A_PLANE);
+    return w;
+  };
+  auto mul = [&](auto KY, const ARow& A, const BOps& w) {
+    constexpr int ky = decltype(KY)::value;
 #pragma unroll
     for (int pr = 0; pr < ((WSPLIT_ABLATE & 8) ? 0 : (WSPLIT_ABLATE & 4) ? 1 : 3); ++pr)   // hi.hi, lo.hi, hi.lo
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx)
-        acc[ky][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 1 ? A.lo : A.hi, b[pr == 2][kx], acc[ky][kx], 0, 0, 0);
+        acc[ky][kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 1 ? A.lo : A.hi, w.b[pr == 2][kx], acc[ky][kx], 0, 0, 0);
   };
   using K0 = std::integral_constant<int, 0>;
   using K1 = std::integral_constant<int, 1>;
   using K2 = std::integral_constant<int, 2>;
 
-  // Schedule of one chunk q (stage s): rows 0 and 1 multiply while chunk q+1 is split into stage s^1; then chunk q+2
-  // is fetched into the registers just freed; rows 2 and 3; barrier.  The fetch has two rows and a barrier to land.
-  // Past the end the fetch repeats the last chunk and the split writes a stage nobody reads: no branches.
+  // Schedule of one chunk q (stage s): X rows 0-2 multiply while chunk q+1 is split into stage s^1; then chunk q+2
+  // is fetched into the registers just freed; X rows 3-5; barrier.  Two waves share a SIMD, so one wave's split,
+  // address arithmetic and waits run under the other's MFMAs.  Past the end the fetch repeats the last chunk and
+  // the split writes a stage nobody reads: no branches.
   Fetch f;
   Chunk c1{0, 0, 0, 0};
   if (q_begin < q_end) {
     const Chunk c = decode(a, q_begin);
     if (a.lv[c.l].vec) fetch_chunk<true>(a, c, m0, c0, t, f); else fetch_chunk<false>(a, c, m0, c0, t, f);
-    const Geo G0{a.lv[c.l].W, a.lv[c.l].H, c.y0, c.x0};
-    stage_part<0, 2, 0, 3>(G0, mleft, cleft, t, f, lds, sx, sdy);
+    stage_part<true, 0, 2, 0, 3, 0, 2>(a.lv[c.l].W - c.x0, t, f, lds, sx, sdy);
     c1 = decode(a, q_begin + 1 < q_end ? q_begin + 1 : q_end - 1);
     if (a.lv[c1.l].vec) fetch_chunk<true>(a, c1, m0, c0, t, f); else fetch_chunk<false>(a, c1, m0, c0, t, f);
   }
   __syncthreads();
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
+#define STAGE_PART(...)                                                              \
+  if (!(WSPLIT_ABLATE & 2)) {                                                        \
+    if (nv >= SW) stage_part<false, __VA_ARGS__>(nv, t, f, other, sx, sdy);          \
+    else stage_part<true, __VA_ARGS__>(nv, t, f, other, sx, sdy);                    \
+  }
   for (int q = q_begin; q < q_end; ++q) {
     const char* stage = lds + ((q - q_begin) & 1) * STAGE;
     char* other = lds + (((q - q_begin) & 1) ^ 1) * STAGE;
-    const Geo G{a.lv[c1.l].W, a.lv[c1.l].H, c1.y0, c1.x0};
-    ARaw A = load_a(stage, 0);
-    BRaw b0 = load_b(stage, 0), b1;
+    const int nv = __builtin_amdgcn_readfirstlane(a.lv[c1.l].W - c1.x0);
     SB();
-    // row 0
-    b1 = load_b(stage, 1); mul(K0{}, A, b0); if (!(WSPLIT_ABLATE & 2)) stage_part<0, 1, 0, 0>(G, mleft, cleft, t, f, other, sx, sdy); SB();
-    b0 = load_b(stage, 2); mul(K1{}, A, b1); if (!(WSPLIT_ABLATE & 2)) stage_part<1, 2, 0, 0>(G, mleft, cleft, t, f, other, sx, sdy); SB();
-    b1 = load_b(stage, 1); ARaw A1 = load_a(stage, 1);
-    mul(K2{}, A, b0); if (!(WSPLIT_ABLATE & 2)) stage_part<0, 0, 0, 1>(G, mleft, cleft, t, f, other, sx, sdy); SB();
-    // row 1
-    b0 = load_b(stage, 2); mul(K0{}, A1, b1); if (!(WSPLIT_ABLATE & 2)) stage_part<0, 0, 1, 2>(G, mleft, cleft, t, f, other, sx, sdy); SB();
-    b1 = load_b(stage, 3); mul(K1{}, A1, b0); if (!(WSPLIT_ABLATE & 2)) stage_part<0, 0, 2, 3>(G, mleft, cleft, t, f, other, sx, sdy); SB();
-    b0 = load_b(stage, 2); A = load_a(stage, 2);
-    mul(K2{}, A1, b1); SB();
+    ARow A0 = load_a(stage, 0);
+    BOps B = load_b(stage, 0);
+    mul(K0{}, A0, B);
+    STAGE_PART(0, 1, 0, 0, 0, 0)
+    SB();
+    ARow A1 = load_a(stage, 1);
+    B = load_b(stage, 1);
+    mul(K0{}, A1, B); mul(K1{}, A0, B);
+    STAGE_PART(1, 2, 0, 0, 0, 0)
+    SB();
+    ARow A2 = load_a(stage, 2);
+    B = load_b(stage, 2);
+    mul(K0{}, A2, B); mul(K1{}, A1, B); mul(K2{}, A0, B);
+    STAGE_PART(0, 0, 0, 3, 0, 2)
+    SB();
     // the registers of the fetch are free: chunk q + 2
     c1 = decode(a, q + 2 < q_end ? q + 2 : q_end - 1);
     if (!(WSPLIT_ABLATE & 1)) {
       if (a.lv[c1.l].vec) fetch_chunk<true>(a, c1, m0, c0, t, f); else fetch_chunk<false>(a, c1, m0, c0, t, f);
     }
     SB();
-    // row 2
-    b1 = load_b(stage, 3); mul(K0{}, A, b0); SB();
-    b0 = load_b(stage, 4); mul(K1{}, A, b1); SB();
-    b1 = load_b(stage, 3); A1 = load_a(stage, 3); mul(K2{}, A, b0); SB();
-    // row 3
-    b0 = load_b(stage, 4); mul(K0{}, A1, b1); SB();
-    b1 = load_b(stage, 5); mul(K1{}, A1, b0); SB();
-    mul(K2{}, A1, b1);
+    ARow A3 = load_a(stage, 3);
+    B = load_b(stage, 3);
+    mul(K0{}, A3, B); mul(K1{}, A2, B); mul(K2{}, A1, B);
+    SB();
+    B = load_b(stage, 4);
+    mul(K1{}, A3, B); mul(K2{}, A2, B);
+    SB();
+    B = load_b(stage, 5);
+    mul(K2{}, A3, B);
     if (!(WSPLIT_ABLATE & 16)) __syncthreads();
   }
+#undef STAGE_PART
 #undef SB
 
   // ---- partial block -> slab [share][tap][Mp][Cp] ----
@@ -521,7 +533,7 @@ int ssad_split_wgrad_launch(const ssad_conv_level* lv, int n_levels, float* dW, 
     (void)hipFuncSetAttribute((const void*)wsplit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   });
   const int tiles = a.mtiles * a.ctiles;
-  hipLaunchKernelGGL(wsplit_kernel, dim3(tiles * a.shares), dim3(kThreads), LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(wsplit_kernel, dim3(tiles * a.shares), dim3(kWG), LDS_BYTES, stream, a);
   hipLaunchKernelGGL(wsplit_reduce_kernel, dim3((Cin + 63) / 64, Cout), dim3(256), 0, stream, (const float*)a.slabs,
                      a.shares, a.mtiles * CO_T, a.ctiles * CI_T, Cout, Cin, (const unsigned*)amax, dW, accumulate);
   return (int)hipGetLastError();

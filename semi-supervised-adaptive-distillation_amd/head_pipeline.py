@@ -122,10 +122,11 @@ class DistillHeads(object):
         # direct kernel's parity floor where F(2x4) needs 2e-5) where it measured faster than F(2x4) at config 3's size --
         # bit mask SSAD_SPLIT_CONV: 1 = cls_pred forward (student and teacher), 2 = its data gradient, 4 = tower forward
         # (both networks, one launch per depth), 8 = tower data gradients (16: the backbones' >= 256-wide 3x3 layers,
-        # backbone_pipeline.py); 0 = off.  Default 31: same-box A/B of the
-        # step 86.0 -> 83.9 ms, subnets 37.3 -> 35.8 (profiles/r06_experiments.md) -- every bit pays in the step although
-        # the isolated launches are level with F(2x4): the step is power-bound, and the engine spends less of it.
-        self.split_conv = int(os.environ.get("SSAD_SPLIT_CONV", "31")) if (self.wino and not self.F16) else 0
+        # backbone_pipeline.py), 32 = the subnets' >= 128-wide filter gradients (conv3x3_wgrad_split.hip; 64: the
+        # backbones' >= 256-wide ones); 0 = off.  Default 127: same-box A/B of the step 86.0 -> 83.9 ms for bits 1-16
+        # (every bit pays in the step although the isolated launches are level with F(2x4): the step is power-bound, and
+        # the engine spends less of it) and 82.6 -> 78.3 ms for bits 32 + 64 (profiles/r06_experiments.md).
+        self.split_conv = int(os.environ.get("SSAD_SPLIT_CONV", "127")) if (self.wino and not self.F16) else 0
         self._split_ops, self._split_ws_need = [], 0
         self.momentum, self.weight_decay = momentum, weight_decay
         self.pg, self.world_size = process_group, world_size
@@ -242,7 +243,7 @@ class DistillHeads(object):
 
     def _emit_wgrad(self, P, xs, dys, name, Cout, klass):
         arr = self._conv_table([(xs, None, dys, None, None)])
-        # SSAD_SPLIT_CONV bit 32: the >= 128-wide filter gradients on the split-operand engine
+        # SSAD_SPLIT_CONV bit 32 (default): the >= 128-wide filter gradients on the split-operand engine
         split = bool(self.split_conv & 32) and Cout >= 128 and self.D >= 64
         size_fn = K.lib().ssad_conv3x3_wgrad_split_workspace_bytes if split else K.lib().ssad_conv3x3_wgrad_workspace_bytes
         nb = size_fn(arr, len(arr), Cout, self.D)

@@ -129,6 +129,17 @@ def test_f24_switches_select_the_engine_per_launch(monkeypatch):
         assert h.packed[tw][0].numel() == (L.ssad_conv_split_filter_floats if bits & 4 else L.ssad_conv_wino24_filter_floats)(256, 256)
         assert h.packed[tw][1].numel() == (L.ssad_conv_split_filter_floats if bits & 8 else L.ssad_conv_wino24_filter_floats)(256, 256)
         assert h.t_packed[tw].numel() == h.packed[tw][0].numel()          # the teacher's towers share the launch
+    # bit 32: the >= 128-wide filter gradients (towers, cls_pred) on the split-operand engine with their own timing
+    # classes; bbox_pred (36 outputs) keeps the F(3x3, 2x2) engine.  One workspace serves both engines.
+    for bits, want in ((31, {(0, 5), (0, 6), (0, 7)}), (63, {(1, 68), (1, 69), (0, 7)})):
+        monkeypatch.setenv("SSAD_SPLIT_CONV", str(bits))
+        h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu")
+        wg = [o for o in h.prog.ops if o.code == PR.CONV3X3_WGRAD]
+        assert {(o.i[4], o.klass) for o in wg} == want and len(wg) == 10
+        assert {o.p[3] for o in wg} == {h.wgrad_ws.data_ptr()} and max(o.l[0] for o in wg) <= h.wgrad_ws.numel()
+    monkeypatch.delenv("SSAD_SPLIT_CONV")
+    h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu")
+    assert h.split_conv == 127
     monkeypatch.setenv("SSAD_SPLIT_CONV", "0")
     # without a teacher the student's towers are alone in their launch and follow bit 4
     monkeypatch.setenv("SSAD_STUDENT_F24", "7")
@@ -244,6 +255,16 @@ def test_backbone_engines_follow_the_f24_switches(monkeypatch):
     e, bb = engines(False, {"SSAD_TEACHER_F24": "1", "SSAD_SPLIT_CONV": "31"})
     assert e.count((1, 48)) == 3 and e.count((2, 47)) == 4 and e.count((3, 67)) == 10
     assert sum(o.code == PR.WINO_PACK_FILTERS and o.i[1] == 3 for o in bb.prep.ops) == 1      # frozen: packed once
+    # bit 64 (default): the >= 256-wide filter gradients (res4 x6, the three FPN output convolutions, res5 x3) on the
+    # split-operand engine, res3's stay on F(3x3, 2x2)
+    def wgrads(bits):
+        monkeypatch.setenv("SSAD_SPLIT_CONV", str(bits))
+        bb = NativeResNetFPN("r50", 1, (128, 128), "cpu", train=True)
+        return sorted((o.i[4], o.klass, o.i[1]) for o in bb.prog.ops if o.code == PR.CONV3X3_WGRAD)
+    w0, w1 = wgrads(31), wgrads(95)
+    assert all(x[0] == 0 for x in w0) and len(w0) == len(w1)
+    assert [x for x in w1 if x[0] == 1] == [(1, 70, 256)] * 9 + [(1, 70, 512)] * 3, w1
+    assert all(x[2] < 256 or x[1] != 49 for x in w1 if x[0] == 0), w1
     monkeypatch.setenv("SSAD_SPLIT_CONV", "15")
     e, _ = engines(True, {"SSAD_STUDENT_F24": "7"})
     assert all(x == (1, 48) for x in e) and len(e) == 3 + 14 * 2

@@ -72,6 +72,13 @@ def class_sequences(f16=False):
                 for k in range(launches):
                     seq.setdefault("wino24_conv_kernel", []).append((op.klass, k == 0))
                 continue
+        if op.code == PR.CONV3X3_WGRAD and op.i[4] == 1:
+            # the split-operand filter gradient: |max| pass + main kernel + slab reduction, all its class (the bias
+            # gradient's two launches follow every filter gradient and stay out of the counters, as before)
+            seq.setdefault("wsplit_absmax_kernel", []).append((op.klass, False))
+            seq.setdefault("wsplit_kernel", []).append((op.klass, True))
+            seq.setdefault("wsplit_reduce_kernel", []).append((op.klass, False))
+            continue
         for k in range(launches):
             seq.setdefault(n, []).append((op.klass, k == 0))
     return seq
