@@ -114,22 +114,36 @@ struct Chunk {
   int l, n, y0, x0;
 };
 
-__device__ __forceinline__ Chunk decode(const WArgs& a, int q) {
+// Chunk q -> coordinates (divisions: once per workgroup) and chunk -> the next one (scalar compares).  Chunks are
+// numbered strip-fastest, then row block, image, level.
+struct Cursor {
+  int l, n, yb, strip;
+};
+__device__ __forceinline__ Cursor decode(const WArgs& a, int q) {
   int l = 0;
-  for (int j = 1; j < a.n_levels; ++j) l += q >= a.lv[j].chunk_start;
+#pragma unroll
+  for (int j = 1; j < SSAD_MAX_LEVELS; ++j) l += (j < a.n_levels && q >= a.lv[j].chunk_start);
   l = __builtin_amdgcn_readfirstlane(l);
   const WLevel& L = a.lv[l];
   int r = q - L.chunk_start;
-  const int strip = r % L.strips;
-  r /= L.strips;
-  const int yb = r % L.yblocks;
-  Chunk c;
+  Cursor c;
   c.l = l;
+  c.strip = __builtin_amdgcn_readfirstlane(r % L.strips);
+  r /= L.strips;
+  c.yb = __builtin_amdgcn_readfirstlane(r % L.yblocks);
   c.n = __builtin_amdgcn_readfirstlane(r / L.yblocks);
-  c.y0 = __builtin_amdgcn_readfirstlane(yb * RW);
-  c.x0 = __builtin_amdgcn_readfirstlane(strip * SW);
   return c;
 }
+__device__ __forceinline__ void advance(const WArgs& a, Cursor& c) {
+  if (++c.strip < a.lv[c.l].strips) return;
+  c.strip = 0;
+  if (++c.yb < a.lv[c.l].yblocks) return;
+  c.yb = 0;
+  if (++c.n < a.lv[c.l].N) return;
+  c.n = 0;
+  do ++c.l; while (c.l < a.n_levels - 1 && a.lv[c.l + 1].chunk_start == a.lv[c.l].chunk_start);   // skip empty levels
+}
+__device__ __forceinline__ Chunk chunk_of(const Cursor& c) { return Chunk{c.l, c.n, c.yb * RW, c.strip * SW}; }
 
 // What one thread (of 512) fetches for a chunk: 2 groups (8 pixels) of dY, 3 quads (4 pixels) of X and 2 halo pixels of X.
 //   dY:   thread -> (half strip g = t & 1, row r = (t >> 1) & 3, channel (t >> 3) + 64 i),            i = 0..1
@@ -351,11 +365,14 @@ __global__ __launch_bounds__(kWG, 1) void wsplit_kernel(const WArgs a) {
   // the split writes a stage nobody reads: no branches.
   Fetch f;
   Chunk c1{0, 0, 0, 0};
+  Cursor cur{0, 0, 0, 0};
   if (q_begin < q_end) {
-    const Chunk c = decode(a, q_begin);
+    cur = decode(a, q_begin);
+    const Chunk c = chunk_of(cur);
     if (a.lv[c.l].vec) fetch_chunk<true>(a, c, m0, c0, t, f); else fetch_chunk<false>(a, c, m0, c0, t, f);
     stage_part<true, 0, 2, 0, 3, 0, 2>(a.lv[c.l].W - c.x0, t, f, lds, sx, sdy);
-    c1 = decode(a, q_begin + 1 < q_end ? q_begin + 1 : q_end - 1);
+    if (q_begin + 1 < q_end) advance(a, cur);
+    c1 = chunk_of(cur);
     if (a.lv[c1.l].vec) fetch_chunk<true>(a, c1, m0, c0, t, f); else fetch_chunk<false>(a, c1, m0, c0, t, f);
   }
   __syncthreads();
@@ -387,7 +404,8 @@ __global__ __launch_bounds__(kWG, 1) void wsplit_kernel(const WArgs a) {
     STAGE_PART(0, 0, 0, 3, 0, 2)
     SB();
     // the registers of the fetch are free: chunk q + 2
-    c1 = decode(a, q + 2 < q_end ? q + 2 : q_end - 1);
+    if (q + 2 < q_end) advance(a, cur);
+    c1 = chunk_of(cur);
     if (!(WSPLIT_ABLATE & 1)) {
       if (a.lv[c1.l].vec) fetch_chunk<true>(a, c1, m0, c0, t, f); else fetch_chunk<false>(a, c1, m0, c0, t, f);
     }
