@@ -310,8 +310,17 @@ class NativeResNetFPN(object):
     def _gemm(self, P, a, lda, x, y, Kc, M, bias=None, res=None, mask=None, relu=False, acc=False, klass=50):
         d = K.gemm_conv_desc(a, lda, x, y, Kc, M, bias, res, mask, relu, acc)
         px = x.numel() // Kc
-        # (Round 6 tried the split-operand GEMM of gemm_split.hip here for the compute-bound layers -- K, M >= 256, res4 /
-        # res5 / upper laterals: the step got 1.2-1.5 ms SLOWER, profiles/r06_experiments.md section 3; not wired in.)
+        # SSAD_SPLIT_CONV bit 128: the compute-bound pointwise layers (K, M >= 256: res4, res5, the laterals) on the
+        # split-operand GEMM that splits x on the fly (gemm_split.hip, gemm_fly_kernel).  (With a split PASS over x in
+        # front of the GEMM the step got 1.2-1.5 ms slower, profiles/r06_experiments.md section 3.)
+        if self._gemm_split and Kc >= 256 and M >= 256 and klass == 50:
+            nb = K.lib().ssad_conv1x1_gemm_split_workspace_bytes(C.byref(d))
+            if nb:
+                self._split_need = max(self._split_need, nb)
+                idx = P.add(PR.GEMM_CONV_SPLIT, 71, p=(d, None), l=(nb,), work=2.0 * px * Kc * M,
+                            keep=[t for t in (a, x, y, bias, res, mask) if t is not None])
+                self._gemm_split_ops.append(idx)
+                return
         P.add(PR.GEMM_CONV, klass, p=(d,), work=2.0 * px * Kc * M,
               keep=[t for t in (a, x, y, bias, res, mask) if t is not None])
 
@@ -349,7 +358,7 @@ class NativeResNetFPN(object):
         arr[0] = K.ConvLevel(x.data_ptr(), 0, dy.data_ptr(), x.shape[0], x.shape[2], x.shape[3], 0, 0)
         # SSAD_SPLIT_CONV bit 64 (default): the >= 256-wide 3x3 filter gradients on the split-operand engine (the
         # 128-wide res3 layers are level with the F(3x3, 2x2) engine there: 2 blocks of dW, 128 slabs to reduce)
-        split = (int(os.environ.get("SSAD_SPLIT_CONV", "127")) & 64) != 0 and layer.cout >= 256 and layer.cin >= 256
+        split = (int(os.environ.get("SSAD_SPLIT_CONV", "255")) & 64) != 0 and layer.cout >= 256 and layer.cin >= 256
         size_fn = K.lib().ssad_conv3x3_wgrad_split_workspace_bytes if split else K.lib().ssad_conv3x3_wgrad_workspace_bytes
         nb = size_fn(arr, 1, layer.cout, layer.cin)
         self._ws_need = max(self._ws_need, nb)
@@ -469,9 +478,11 @@ class NativeResNetFPN(object):
         use_f24_train = self.train and (int(os.environ.get("SSAD_STUDENT_F24", "15")) & 8) != 0
         # SSAD_SPLIT_CONV bit 16: the >= 256-wide stride-1 3x3 layers (res4, res5, FPN outputs) on the split-operand engine
         # (default on: step -0.1 ... -1.3 ms in four same-box A/B pairs, profiles/r06_experiments.md)
-        use_split = (int(os.environ.get("SSAD_SPLIT_CONV", "127")) & 16) != 0 and (use_f24 or use_f24_train)
+        use_split = (int(os.environ.get("SSAD_SPLIT_CONV", "255")) & 16) != 0 and (use_f24 or use_f24_train)
         split_frozen, split_train = [], []
         self._split_ops, self._split_need = [], 0
+        self._gemm_split_ops = []
+        self._gemm_split = (int(os.environ.get("SSAD_SPLIT_CONV", "255")) & 128) != 0
         tr_frozen, tr_train = [], []          # (w, wt, M, K, ldm): every transposed filter of a program in one launch
         P.mark("pack")
         for l in L.values():
@@ -573,6 +584,8 @@ class NativeResNetFPN(object):
         self.split_ws = torch.empty(max(self._split_need, 16), dtype=torch.uint8, device=dev)
         for idx in self._split_ops:
             P.set_ptr(idx, 3, self.split_ws)
+        for idx in self._gemm_split_ops:
+            P.set_ptr(idx, 1, self.split_ws)
         P.build()
 
     # -- forward ----------------------------------------------------------------------------------------

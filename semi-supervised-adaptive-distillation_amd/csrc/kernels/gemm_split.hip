@@ -18,6 +18,8 @@
 // loads + 8 ds_read_b128 feed 24 MFMAs.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "split_common.h"
 
 namespace {
@@ -327,6 +329,201 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_split_kernel(const GArgs q) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same GEMM with x split ON THE FLY (no split pass, no packed copy of x): 8 waves (two per SIMD, so one wave's
+// fetch, split and waits run under the other's MFMAs -- conv3x3_wgrad_split.hip), one 256-channel x 128-pixel item per
+// workgroup, K in chunks of 32 channels through two LDS stages.  A thread fetches 8 channels of one pixel as eight
+// coalesced dword loads (exactly one MFMA operand slot), splits them and writes hi / lo to LDS; the packed filter's
+// slots go global -> register -> LDS unchanged.  Wave tile 64 channels x 64 pixels: per 16-channel step 8 LDS reads
+// feed 12 MFMAs.
+constexpr int FKC = 32;                             // channels per chunk (2 MFMA steps)
+constexpr int FWG = 512;
+constexpr int F_XP = (FKC / 8) * PT * 16;           // bytes of one x plane of a stage (8 KB)
+constexpr int F_WP = (FKC / 8) * MT * 16;           // bytes of one filter plane of a stage (16 KB)
+constexpr int F_STAGE = 2 * F_XP + 2 * F_WP;        // 48 KB
+constexpr int F_LDS = 2 * F_STAGE;
+
+struct FArgs {
+  const float* x;
+  const float* ap;       // packed a (header + planes)
+  float* y;
+  const float* bias;
+  const float* residual;
+  const float* mask;
+  const unsigned* amax;  // [0] = x
+  int N, K, P, M, relu, accumulate;
+  int ptiles, mblocks, items;
+};
+
+__global__ __launch_bounds__(FWG, 1) void gemm_fly_kernel(const FArgs q) {
+  extern __shared__ __attribute__((aligned(16))) char flds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wp = wave >> 2;
+  const int j = lane & 31, h = lane >> 5;
+  const int K = q.K, M = q.M, P = q.P;
+  const int KB = (K + 7) >> 3;
+  const int nchunks = (K + FKC - 1) / FKC;
+
+  // item: ids b, b + 8, ... share an XCD's L2: the channel blocks of one pixel tile are adjacent along that sequence
+  int n, p0, ocb;
+  {
+    const int it = (int)blockIdx.x;
+    const int xcd = it & 7, seq = it >> 3;
+    const int mb = seq % q.mblocks;
+    const int t = (seq / q.mblocks) * 8 + xcd;
+    if (t >= q.N * q.ptiles) return;
+    n = t / q.ptiles;
+    p0 = (t - n * q.ptiles) * PT;
+    ocb = mb * MT;
+  }
+  const unsigned w_lo_off = (unsigned)((long long)KB * M * 16);
+  const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(q.x, (unsigned)((long long)q.N * K * P * 4));
+  const __amdgpu_buffer_rsrc_t wrs = uniform_rsrc(q.ap + HDR, 2u * w_lo_off);
+  const float sx = pow2f(15 - split_exponent(q.amax[0]));
+
+  // what a thread fetches per chunk: x: pixel tid & 127, 8-channel group tid >> 7; filter: channel tid & 255, groups
+  // (tid >> 8) and (tid >> 8) + 2 of both planes
+  float xv[8];
+  f32x4 wv[4];
+  const int fpx = tid & (PT - 1), fkg = tid >> 7;
+  const int fco = tid & (MT - 1), fkq = tid >> 8;
+  const unsigned xbase = p0 + fpx < P ? (unsigned)((((long long)n * K + 8 * fkg) * P + p0 + fpx) * 4) : kOob;
+  const int P4 = P * 4;
+  auto fetch = [&](int c) {
+    const int soff = __builtin_amdgcn_readfirstlane(c * FKC * P4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      xv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+          xrs, c * FKC + 8 * fkg + e < K ? xbase : kOob, soff + e * P4, 0));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kb = c * (FKC / 8) + fkq + 2 * i;
+      const unsigned vo = (kb < KB && ocb + fco < M) ? (unsigned)((kb * M + ocb + fco) * 16) : kOob;
+      wv[2 * i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, vo, 0, 0));
+      wv[2 * i + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, vo, (int)w_lo_off, 0));
+    }
+  };
+  auto put = [&](char* stage) {
+    half8 hi, lo;
+    split8(xv, sx, hi, lo);
+    char* px = stage + (fkg * PT + fpx) * 16;
+    *reinterpret_cast<half8*>(px) = hi;
+    *reinterpret_cast<half8*>(px + F_XP) = lo;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      char* pw = stage + 2 * F_XP + ((fkq + 2 * i) * MT + fco) * 16;
+      *reinterpret_cast<f32x4*>(pw) = wv[2 * i];
+      *reinterpret_cast<f32x4*>(pw + F_WP) = wv[2 * i + 1];
+    }
+  };
+
+  float16v acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][tt][r] = 0.0f;
+
+  auto step = [&](const char* stage, int st) {
+    half8 ah[2], al[2], bh[2], bl[2];
+    const int kg = 2 * st + h;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const char* pw = stage + 2 * F_XP + (kg * MT + wm * 64 + i * 32 + j) * 16;
+      ah[i] = *reinterpret_cast<const half8*>(pw);
+      al[i] = *reinterpret_cast<const half8*>(pw + F_WP);
+      const char* px = stage + (kg * PT + wp * 64 + i * 32 + j) * 16;
+      bh[i] = *reinterpret_cast<const half8*>(px);
+      bl[i] = *reinterpret_cast<const half8*>(px + F_XP);
+    }
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr)                    // hi.hi, lo(a).hi, hi.lo(x): a block's products four MFMAs apart
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+          acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 1 ? al[i] : ah[i], pr == 2 ? bl[tt] : bh[tt],
+                                                              acc[i][tt], 0, 0, 0);
+  };
+
+  // chunk c multiplies from stage c & 1 while chunk c + 1 (in the registers since the previous iteration) is split into
+  // the other stage, then chunk c + 2 is fetched; past the end the fetch returns zeros and the writes go to a stage
+  // nobody reads
+  fetch(0);
+  put(flds);
+  fetch(1);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const char* stage = flds + (c & 1) * F_STAGE;
+    char* other = flds + ((c & 1) ^ 1) * F_STAGE;
+    __builtin_amdgcn_sched_barrier(0);
+    step(stage, 0);
+    put(other);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(c + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    step(stage, 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D row = (r & 3) + 8 (r >> 2) + 4 h, column = j
+  const int oc_w = ocb + wm * 64;
+  unsigned pvo[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int px = p0 + wp * 64 + 32 * tt + j;
+    pvo[tt] = px < P ? (unsigned)((((long long)n * M + 4 * h) * P + px) * 4) : kOob;
+  }
+  const int e2 = split_exponent(q.amax[0]) + split_exponent(reinterpret_cast<const unsigned*>(q.ap)[0]) - 30;
+  const bool one_scale = e2 >= -126 && e2 <= 127;
+  const float sc1 = one_scale ? pow2f(e2) : pow2f(split_exponent(q.amax[0]) - 15);
+  const float sc2 = one_scale ? 1.0f : pow2f(split_exponent(reinterpret_cast<const unsigned*>(q.ap)[0]) - 15);
+  const unsigned ybytes = (unsigned)((long long)q.N * M * P * 4);
+  const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(q.y, ybytes);
+  const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(q.residual ? (const void*)q.residual : (const void*)q.y, q.residual ? ybytes : 0u);
+  const __amdgpu_buffer_rsrc_t mrs = uniform_rsrc(q.mask ? (const void*)q.mask : (const void*)q.y, q.mask ? ybytes : 0u);
+  const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(q.bias ? (const void*)q.bias : (const void*)q.y, q.bias ? (unsigned)M * 4u : 0u);
+  const bool relu = q.relu, has_res = q.residual != nullptr, has_mask = q.mask != nullptr, accum = q.accumulate;
+  const bool ragged = (M & 7) != 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int oc0 = oc_w + i * 32;
+    float4 bq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      bq[g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)h * 16u, (oc0 + 8 * g) * 4, 0));
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      float rs[16], mk[16], old[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = oc0 + 8 * (r >> 2) + (r & 3);
+        const unsigned vo = (ch < M && (!ragged || ch + 4 * h < M)) ? pvo[tt] : kOob;
+        rs[r] = has_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, vo, ch * P4, 0)) : 0.0f;
+        mk[r] = has_mask ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, vo, ch * P4, 0)) : 1.0f;
+        old[r] = accum ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, vo, ch * P4, 0)) : 0.0f;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (oc0 + 8 * g >= M) continue;               // wave-uniform
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          float v = one_scale ? fmaf(acc[i][tt][r], sc1, bq[g][e]) : acc[i][tt][r] * sc1 * sc2 + bq[g][e];
+          v += rs[r];
+          if (relu) v = fmaxf(v, 0.0f);
+          if (has_mask) v = mk[r] > 0.0f ? v : 0.0f;
+          v += old[r];
+          const unsigned vo = (!ragged || oc0 + 8 * g + 4 * h + e < M) ? pvo[tt] : kOob;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, vo, (oc0 + 8 * g + e) * P4, 0);
+        }
+      }
+    }
+  }
+}
+
 struct GPlan {
   size_t amax_off, a_off, x_off, total;
 };
@@ -380,7 +577,10 @@ int ssad_conv1x1_gemm_split(const ssad_gemm_conv* d, void* workspace, size_t wor
   for (int l = 2; l <= kMaxLv; ++l) at.block_start[l] = blocks;
   (void)hipMemsetAsync(amax, 0, 256, stream);
   hipLaunchKernelGGL(split_absmax_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, at);
+  const char* fe = getenv("TMP_GEMM_FLY");
+  const bool fly = !(fe && fe[0] == '0') && (long long)d->N * d->K * d->P * 4 < (1LL << 31);
   // x -> planes
+  if (!fly) {
   ActTable pt;
   for (int l = 0; l < kMaxLv; ++l) { pt.x[l] = nullptr; pt.planes[l] = nullptr; pt.N[l] = 0; pt.plane[l] = 0; pt.block_start[l] = 0; }
   pt.count = 1; pt.C = d->K; pt.amax = amax;
@@ -389,12 +589,32 @@ int ssad_conv1x1_gemm_split(const ssad_gemm_conv* d, void* workspace, size_t wor
   const int pblocks = (int)((xslots + kThreads - 1) / kThreads);
   for (int l = 1; l <= kMaxLv; ++l) pt.block_start[l] = pblocks;
   hipLaunchKernelGGL(split_pack_act_kernel, dim3((unsigned)pblocks), dim3(kThreads), 0, stream, pt);
+  }
   // a -> planes
   {
     long long bx = ((long long)KB * d->M + kThreads - 1) / kThreads;
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(gsplit_pack_a_kernel, dim3((unsigned)bx), dim3(kThreads), 0, stream, d->a, d->lda, d->K, d->M,
                        (const unsigned*)(amax + 1), apk);
+  }
+  if (fly) {
+    FArgs f;
+    f.x = d->x; f.ap = apk; f.y = d->y; f.bias = d->bias; f.residual = d->residual; f.mask = d->mask;
+    f.amax = amax;
+    f.N = d->N; f.K = d->K; f.P = d->P; f.M = d->M;
+    f.relu = (d->flags & SSAD_GEMM_RELU) ? 1 : 0;
+    f.accumulate = (d->flags & SSAD_GEMM_ACCUMULATE) ? 1 : 0;
+    f.ptiles = cdiv(d->P, PT);
+    f.mblocks = cdiv(d->M, MT);
+    const long long tiles = (long long)d->N * f.ptiles;
+    if (tiles * f.mblocks >= (1LL << 30)) return SSAD_E_BADARG;
+    f.items = (int)(cdiv((int)tiles, 8) * 8 * f.mblocks);
+    static std::once_flag lds_once;           // > 64 KiB of dynamic LDS needs the opt-in, once per process
+    std::call_once(lds_once, [&] {
+      (void)hipFuncSetAttribute((const void*)gemm_fly_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+    });
+    hipLaunchKernelGGL(gemm_fly_kernel, dim3((unsigned)f.items), dim3(FWG), F_LDS, stream, f);
+    return (int)hipGetLastError();
   }
   GArgs q;
   q.xp = xpl; q.ap = apk; q.y = d->y; q.bias = d->bias; q.residual = d->residual; q.mask = d->mask;

@@ -139,7 +139,7 @@ def test_f24_switches_select_the_engine_per_launch(monkeypatch):
         assert {o.p[3] for o in wg} == {h.wgrad_ws.data_ptr()} and max(o.l[0] for o in wg) <= h.wgrad_ws.numel()
     monkeypatch.delenv("SSAD_SPLIT_CONV")
     h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu")
-    assert h.split_conv == 127
+    assert h.split_conv == 255
     monkeypatch.setenv("SSAD_SPLIT_CONV", "0")
     # without a teacher the student's towers are alone in their launch and follow bit 4
     monkeypatch.setenv("SSAD_STUDENT_F24", "7")
