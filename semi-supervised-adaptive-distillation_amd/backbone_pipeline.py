@@ -43,6 +43,9 @@ from . import kernels as K
 from . import program as PR
 from .data_parallel import BucketedAllReduce
 
+# pixels (all images) a pointwise launch needs before the split-operand GEMM pays (see NativeResNetFPN._gemm)
+GEMM_SPLIT_MIN_PIXELS = 8192
+
 ARCHS = {"r50": (3, 4, 6, 3), "r101": (3, 4, 23, 3), "x101-64x4d": (3, 4, 23, 3)}
 # ResNeXt (ResNet.py:247-258): name -> (groups, width per group); the stride sits on the 3x3
 # (RESNETS.STRIDE_1X1 = False).  Forward only: it is the frozen teacher of BASELINE config 5.
@@ -312,8 +315,11 @@ class NativeResNetFPN(object):
         px = x.numel() // Kc
         # SSAD_SPLIT_CONV bit 128: the compute-bound pointwise layers (K, M >= 256: res4, res5, the laterals) on the
         # split-operand GEMM that splits x on the fly (gemm_split.hip, gemm_fly_kernel).  (With a split PASS over x in
-        # front of the GEMM the step got 1.2-1.5 ms slower, profiles/r06_experiments.md section 3.)
-        if self._gemm_split and Kc >= 256 and M >= 256 and klass == 50:
+        # front of the GEMM the step got 1.2-1.5 ms slower, profiles/r06_experiments.md section 3.)  Thresholds from
+        # same-box A/B pairs: K, M >= 128 costs the step +1.6 ms, >= 64 +3.2 ms (those layers are HBM-bound); at batch 2
+        # (config 2: < 8192 pixels per launch from res4 up) the call's three extra small launches cost more than the
+        # GEMM saves (+1.0 ms on a 12 ms step).
+        if self._gemm_split and Kc >= 256 and M >= 256 and px >= GEMM_SPLIT_MIN_PIXELS and klass == 50:
             nb = K.lib().ssad_conv1x1_gemm_split_workspace_bytes(C.byref(d))
             if nb:
                 self._split_need = max(self._split_need, nb)

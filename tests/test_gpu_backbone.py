@@ -79,10 +79,17 @@ def test_native_backbone_forward_backward_vs_torch():
     assert torch.allclose(nat.params_flat, want, rtol=1e-5, atol=1e-8)
 
 
-def test_native_backbone_meets_1e4_when_masks_cannot_flip():
+@pytest.mark.parametrize("small_launches_on_the_split_gemm", [False, True])
+def test_native_backbone_meets_1e4_when_masks_cannot_flip(monkeypatch, small_launches_on_the_split_gemm):
     """Every backbone gradient at north_star's 1e-4 once no pre-activation of the trainable part
-    can sit within round-off of zero (torch_ref.calibrate)."""
-    _, _, errs = _run("r50", mask_safe=True)
+    can sit within round-off of zero (torch_ref.calibrate).  The split-operand pointwise GEMM serves launches of
+    >= 8192 pixels by default (the bench's res4 / res5 / laterals); True sends this test's small maps through it too."""
+    if small_launches_on_the_split_gemm:
+        from ssad_amd import backbone_pipeline as BP
+        monkeypatch.setattr(BP, "GEMM_SPLIT_MIN_PIXELS", 0)
+    nat, _, errs = _run("r50", mask_safe=True)
+    from ssad_amd import program as PR
+    assert any(o.code == PR.GEMM_CONV_SPLIT for o in nat.prog.ops) == small_launches_on_the_split_gemm
     worst = max(errs, key=errs.get)
     assert errs[worst] < 1e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
 
@@ -101,8 +108,12 @@ def test_native_backbone_default_initialisation_needs_no_harness():
     assert 1e-3 < float(got[0].abs().mean()) < 1e3
 
 
-def test_native_backbone_frozen_teacher_matches_torch_r101_small():
+@pytest.mark.parametrize("small_launches_on_the_split_gemm", [False, True])
+def test_native_backbone_frozen_teacher_matches_torch_r101_small(monkeypatch, small_launches_on_the_split_gemm):
     from ssad_amd.backbone_pipeline import NativeResNetFPN
+    if small_launches_on_the_split_gemm:
+        from ssad_amd import backbone_pipeline as BP
+        monkeypatch.setattr(BP, "GEMM_SPLIT_MIN_PIXELS", 0)
     ref = RefResNetFPN("r101", seed=12)
     N, hw = 1, (128, 256)
     nat = NativeResNetFPN("r101", N, hw, "cuda", train=False, src=ref.state_dict())

@@ -265,6 +265,20 @@ def test_backbone_engines_follow_the_f24_switches(monkeypatch):
     assert all(x[0] == 0 for x in w0) and len(w0) == len(w1)
     assert [x for x in w1 if x[0] == 1] == [(1, 70, 256)] * 9 + [(1, 70, 512)] * 3, w1
     assert all(x[2] < 256 or x[1] != 49 for x in w1 if x[0] == 0), w1
+    # bit 128 (default): pointwise layers with K, M >= 256 and enough pixels on the split-operand GEMM, sharing the 3x3
+    # split engine's workspace; everything narrower keeps the exact-fp32 MFMA GEMM
+    from ssad_amd import backbone_pipeline as BP
+    def gemms(bits, min_px):
+        monkeypatch.setenv("SSAD_SPLIT_CONV", str(bits))
+        monkeypatch.setattr(BP, "GEMM_SPLIT_MIN_PIXELS", min_px)
+        bb = NativeResNetFPN("r50", 1, (128, 128), "cpu", train=True)
+        return bb, [o for o in bb.prog.ops if o.code == PR.GEMM_CONV_SPLIT], [o for o in bb.prog.ops if o.code == PR.GEMM_CONV]
+    _, sp0, g0 = gemms(127, 0)
+    _, sp1, g1 = gemms(255, 8192)            # a 128 x 128 image: no launch has 8192 pixels from res4 up
+    bb, sp2, g2 = gemms(255, 0)
+    assert not sp0 and not sp1 and len(g0) == len(g1) == len(sp2) + len(g2) and len(sp2) > 20
+    assert {o.klass for o in sp2} == {71} and {o.p[1] for o in sp2} == {bb.split_ws.data_ptr()}
+    assert max(o.l[0] for o in sp2) <= bb.split_ws.numel()
     monkeypatch.setenv("SSAD_SPLIT_CONV", "15")
     e, _ = engines(True, {"SSAD_STUDENT_F24": "7"})
     assert all(x == (1, 48) for x in e) and len(e) == 3 + 14 * 2
