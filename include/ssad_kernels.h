@@ -569,6 +569,13 @@ SSAD_API size_t ssad_conv1x1_wgrad_workspace_bytes(int N, int C, int P, int M);
 SSAD_API int ssad_conv1x1_wgrad(const float* x, const float* dy, int N, int C, int P, int M, float* dw,
                                 int accumulate, void* workspace, size_t workspace_bytes,
                                 ssad_stream_t stream);
+/* The same contract on the split-operand engine (gemm_split.hip, wpoint_split_kernel): dy and x scaled by a power
+ * of two from their measured |max| and split on the fly into hi + lo fp16, three v_mfma_f32_32x32x16_f16 per
+ * operand pair, fp32 accumulation.  P % 8 == 0. */
+SSAD_API size_t ssad_conv1x1_wgrad_split_workspace_bytes(int N, int C, int P, int M);
+SSAD_API int ssad_conv1x1_wgrad_split(const float* x, const float* dy, int N, int C, int P, int M, float* dw,
+                                      int accumulate, void* workspace, size_t workspace_bytes,
+                                      ssad_stream_t stream);
 /* y[n][c][oy][ox] = x[n][c][oy*stride][ox*stride], OH = (H-1)/stride + 1; and its gradient
  * dx (+)= scatter(dy) (zero off the sampled grid) */
 SSAD_API int ssad_subsample(const float* x, int N, int C, int H, int W, int stride, float* y,

@@ -122,7 +122,7 @@ enum ssad_opcode {
   /* ssad_channel_sum(p0 = dy, i0 = N, i1 = C, i2 = HW, p1 = out, i3 = accumulate) */
   SSAD_OP_CHANNEL_SUM = 55,
   /* ssad_conv1x1_wgrad(p0 = x, p1 = dy, i0..i3 = N, C, P, M, p2 = dw, i4 = accumulate,
-   * p3 = workspace, l0 = workspace_bytes) */
+   * p3 = workspace, l0 = workspace_bytes); i5 == 1: ssad_conv1x1_wgrad_split, same arguments */
   SSAD_OP_CONV1X1_WGRAD = 56,
   /* ssad_transpose_filter(p0 = w, i0 = M, i1 = K, i2 = ldm, p1 = wt) */
   SSAD_OP_TRANSPOSE_FILTER = 57,

@@ -364,7 +364,7 @@ class NativeResNetFPN(object):
         arr[0] = K.ConvLevel(x.data_ptr(), 0, dy.data_ptr(), x.shape[0], x.shape[2], x.shape[3], 0, 0)
         # SSAD_SPLIT_CONV bit 64 (default): the >= 256-wide 3x3 filter gradients on the split-operand engine (the
         # 128-wide res3 layers are level with the F(3x3, 2x2) engine there: 2 blocks of dW, 128 slabs to reduce)
-        split = (int(os.environ.get("SSAD_SPLIT_CONV", "255")) & 64) != 0 and layer.cout >= 256 and layer.cin >= 256
+        split = (int(os.environ.get("SSAD_SPLIT_CONV", "511")) & 64) != 0 and layer.cout >= 256 and layer.cin >= 256
         size_fn = K.lib().ssad_conv3x3_wgrad_split_workspace_bytes if split else K.lib().ssad_conv3x3_wgrad_workspace_bytes
         nb = size_fn(arr, 1, layer.cout, layer.cin)
         self._ws_need = max(self._ws_need, nb)
@@ -378,10 +378,15 @@ class NativeResNetFPN(object):
     def _wgrad1(self, P, x, dy, layer):
         N, Cc = x.shape[0], x.shape[1]
         pix = x.shape[2] * x.shape[3]
-        nb = K.lib().ssad_conv1x1_wgrad_workspace_bytes(N, Cc, pix, layer.cout)
+        # SSAD_SPLIT_CONV bit 256: the compute-bound pointwise filter gradients (C, M >= 256, the launch's pixels as for
+        # the forward GEMM) on the split-operand engine (gemm_split.hip, wpoint_split_kernel)
+        split = ((int(os.environ.get("SSAD_SPLIT_CONV", "511")) & 256) != 0 and Cc >= 256 and layer.cout >= 256
+                 and N * pix >= GEMM_SPLIT_MIN_PIXELS and pix % 8 == 0)
+        size_fn = K.lib().ssad_conv1x1_wgrad_split_workspace_bytes if split else K.lib().ssad_conv1x1_wgrad_workspace_bytes
+        nb = size_fn(N, Cc, pix, layer.cout)
         self._ws_need = max(self._ws_need, nb)
         self._aux(P)
-        idx = P.add(PR.CONV1X1_WGRAD, 52, i=(N, Cc, pix, layer.cout, 0), l=(nb,),
+        idx = P.add(PR.CONV1X1_WGRAD, 72 if split else 52, i=(N, Cc, pix, layer.cout, 0, 1 if split else 0), l=(nb,),
                     p=(x, dy, layer.gw, None), work=2.0 * N * pix * Cc * layer.cout, keep=[x, dy],
                     stream=self._wstream)
         self._ws_ops.append((idx, 3, self._wstream))
@@ -484,11 +489,11 @@ class NativeResNetFPN(object):
         use_f24_train = self.train and (int(os.environ.get("SSAD_STUDENT_F24", "15")) & 8) != 0
         # SSAD_SPLIT_CONV bit 16: the >= 256-wide stride-1 3x3 layers (res4, res5, FPN outputs) on the split-operand engine
         # (default on: step -0.1 ... -1.3 ms in four same-box A/B pairs, profiles/r06_experiments.md)
-        use_split = (int(os.environ.get("SSAD_SPLIT_CONV", "255")) & 16) != 0 and (use_f24 or use_f24_train)
+        use_split = (int(os.environ.get("SSAD_SPLIT_CONV", "511")) & 16) != 0 and (use_f24 or use_f24_train)
         split_frozen, split_train = [], []
         self._split_ops, self._split_need = [], 0
         self._gemm_split_ops = []
-        self._gemm_split = (int(os.environ.get("SSAD_SPLIT_CONV", "255")) & 128) != 0
+        self._gemm_split = (int(os.environ.get("SSAD_SPLIT_CONV", "511")) & 128) != 0
         tr_frozen, tr_train = [], []          # (w, wt, M, K, ldm): every transposed filter of a program in one launch
         P.mark("pack")
         for l in L.values():

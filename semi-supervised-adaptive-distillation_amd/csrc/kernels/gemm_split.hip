@@ -524,6 +524,194 @@ __global__ __launch_bounds__(FWG, 1) void gemm_fly_kernel(const FArgs q) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The pointwise FILTER GRADIENT the same way:  dw[m][c] (+)= sum_{n,p} dy[n][m][p] x[n][c][p]
+// (conv_op_impl.h:451-500 for a 1x1 kernel).  The reduction index is the pixel, which is the contiguous index of both
+// tensors: a thread fetches 8 consecutive pixels of one channel (two 16-byte loads = one MFMA operand slot), splits
+// them and writes hi / lo to LDS.  Workgroup = 8 waves, a 256 x 256 block of dw for one share of the pixels, chunks of
+// 32 pixels through two LDS stages; wave tile 128 x 64 (8 accumulator blocks): per 16-pixel step 12 LDS reads feed 24
+// MFMAs.  Partial blocks go to a slab per share; wpoint_reduce_kernel adds them in a fixed order and divides the
+// scales out.
+constexpr int WT = 256;                             // channels of dy and of x per workgroup
+constexpr int WPX = 32;                             // pixels per chunk (2 MFMA steps)
+constexpr int W_PL = (WPX / 8) * WT * 16;           // bytes of one plane of one operand of a stage (16 KB)
+constexpr int W_STAGE = 4 * W_PL;                   // dy hi, dy lo, x hi, x lo
+constexpr int W_LDS = 2 * W_STAGE;                  // 128 KB
+
+struct WPArgs {
+  const float* x;
+  const float* dy;
+  float* slabs;
+  const unsigned* amax;  // [0] = x, [1] = dy
+  int N, C, P, M;
+  int mtiles, ctiles, shares, per_share, total, cpi;     // cpi = chunks per image
+  int xcd_runs;
+};
+
+__global__ __launch_bounds__(FWG, 1) void wpoint_split_kernel(const WPArgs q) {
+  extern __shared__ __attribute__((aligned(16))) char wlds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wc = wave >> 1;          // wave block: 128 rows (m) x 64 columns (c)
+  const int j = lane & 31, h = lane >> 5;
+  const int P = q.P;
+
+  const int tiles = q.mtiles * q.ctiles;
+  int share, tile;
+  if (q.xcd_runs) {                                 // the tiles of a share read the same pixels: one XCD
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    share = xcd * q.xcd_runs + jj / tiles;
+    tile = jj % tiles;
+  } else {
+    share = blockIdx.x / tiles;
+    tile = blockIdx.x % tiles;
+  }
+  const int m0 = (tile / q.ctiles) * WT, c0 = (tile % q.ctiles) * WT;
+  const int q_begin = share * q.per_share;
+  const int q_end = q_begin + q.per_share < q.total ? q_begin + q.per_share : q.total;
+
+  const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(q.x, (unsigned)((long long)q.N * q.C * P * 4));
+  const __amdgpu_buffer_rsrc_t drs = uniform_rsrc(q.dy, (unsigned)((long long)q.N * q.M * P * 4));
+  const float sx = pow2f(15 - split_exponent(q.amax[0]));
+  const float sd = pow2f(15 - split_exponent(q.amax[1]));
+
+  // a thread's fetch per chunk: pixel group tid & 3, channels (tid >> 2) and (tid >> 2) + 128 of dy and of x
+  float dv[2][8], xv[2][8];
+  const int fpg = tid & 3, fch = tid >> 2;
+  auto fetch = [&](int ck) {
+    const int n = __builtin_amdgcn_readfirstlane(ck / q.cpi);
+    const int p = (ck - n * q.cpi) * WPX + 8 * fpg;
+    const bool pok = ck < q.total && p < P;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + fch + 128 * i, c = c0 + fch + 128 * i;
+      const unsigned od = (pok && m < q.M) ? (unsigned)((((long long)n * q.M + m) * P + p) * 4) : kOob;
+      const unsigned ox = (pok && c < q.C) ? (unsigned)((((long long)n * q.C + c) * P + p) * 4) : kOob;
+      const f32x4 d0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, od, 0, 0));
+      const f32x4 d1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, od, 16, 0));
+      const f32x4 x0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ox, 0, 0));
+      const f32x4 x1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ox, 16, 0));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dv[i][e] = d0[e]; dv[i][4 + e] = d1[e]; xv[i][e] = x0[e]; xv[i][4 + e] = x1[e]; }
+    }
+  };
+  auto put = [&](char* stage) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      half8 hi, lo;
+      char* pd = stage + (fpg * WT + fch + 128 * i) * 16;
+      split8(dv[i], sd, hi, lo);
+      *reinterpret_cast<half8*>(pd) = hi;
+      *reinterpret_cast<half8*>(pd + W_PL) = lo;
+      split8(xv[i], sx, hi, lo);
+      *reinterpret_cast<half8*>(pd + 2 * W_PL) = hi;
+      *reinterpret_cast<half8*>(pd + 3 * W_PL) = lo;
+    }
+  };
+
+  float16v acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][tt][r] = 0.0f;
+
+  auto step = [&](const char* stage, int st) {
+    const int kg = 2 * st + h;
+    half8 bh[2], bl[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const char* px = stage + 2 * W_PL + (kg * WT + wc * 64 + tt * 32 + j) * 16;
+      bh[tt] = *reinterpret_cast<const half8*>(px);
+      bl[tt] = *reinterpret_cast<const half8*>(px + W_PL);
+    }
+#pragma unroll
+    for (int ip = 0; ip < 2; ++ip) {                // two row blocks at a time: their operands, then 12 MFMAs
+      half8 ah[2], al[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const char* pd = stage + (kg * WT + wm * 128 + (2 * ip + i) * 32 + j) * 16;
+        ah[i] = *reinterpret_cast<const half8*>(pd);
+        al[i] = *reinterpret_cast<const half8*>(pd + W_PL);
+      }
+#pragma unroll
+      for (int pr = 0; pr < 3; ++pr)                // hi.hi, lo(dy).hi, hi.lo(x)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+            acc[2 * ip + i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 1 ? al[i] : ah[i], pr == 2 ? bl[tt] : bh[tt],
+                                                                         acc[2 * ip + i][tt], 0, 0, 0);
+    }
+  };
+
+  if (q_begin < q_end) {
+    fetch(q_begin);
+    put(wlds);
+    fetch(q_begin + 1 < q_end ? q_begin + 1 : q.total);
+  }
+  __syncthreads();
+  for (int ck = q_begin; ck < q_end; ++ck) {
+    const char* stage = wlds + ((ck - q_begin) & 1) * W_STAGE;
+    char* other = wlds + (((ck - q_begin) & 1) ^ 1) * W_STAGE;
+    __builtin_amdgcn_sched_barrier(0);
+    step(stage, 0);
+    put(other);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(ck + 2 < q_end ? ck + 2 : q.total);      // past the share's end: zeros (nobody reads that stage)
+    __builtin_amdgcn_sched_barrier(0);
+    step(stage, 1);
+    __syncthreads();
+  }
+
+  // ---- partial block -> slab [share][Mp][Cp]; C/D row = (r & 3) + 8 (r >> 2) + 4 h, column = j
+  const int Mp = q.mtiles * WT, Cp = q.ctiles * WT;
+  float* slab = q.slabs + (long long)share * Mp * Cp;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 128 + i * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        const int c = c0 + wc * 64 + tt * 32 + j;
+        slab[(long long)m * Cp + c] = acc[i][tt][r];
+      }
+}
+
+__global__ __launch_bounds__(256) void wpoint_reduce_kernel(const float* __restrict__ slabs, int shares, int Mp, int Cp,
+                                                            int M, int C, const unsigned* __restrict__ amax,
+                                                            float* __restrict__ dw, int accumulate) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)M * C) return;
+  const int m = (int)(e / C), c = (int)(e - (long long)m * C);
+  const float* p = slabs + (long long)m * Cp + c;
+  const long long stride = (long long)Mp * Cp;
+  float s = 0.0f;
+  for (int sh = 0; sh < shares; ++sh) s += p[sh * stride];
+  s = (s * pow2f(split_exponent(amax[0]) - 15)) * pow2f(split_exponent(amax[1]) - 15);
+  dw[e] = accumulate ? dw[e] + s : s;
+}
+
+int wpoint_plan(int N, int C, int P, int M, WPArgs* a) {
+  if (N <= 0 || C <= 0 || P <= 0 || M <= 0 || (P & 7)) return SSAD_E_BADARG;
+  if ((long long)N * C * P * 4 >= (1LL << 31) || (long long)N * M * P * 4 >= (1LL << 31)) return SSAD_E_BADARG;
+  a->N = N; a->C = C; a->P = P; a->M = M;
+  a->mtiles = cdiv(M, WT); a->ctiles = cdiv(C, WT);
+  a->cpi = cdiv(P, WPX);
+  a->total = N * a->cpi;
+  const int cus = ssad_cu_count(), tiles = a->mtiles * a->ctiles;
+  int s = cus / tiles;
+  if (s < 1) s = 1;
+  if (s >= 8) s &= ~7;
+  while (s > 1 && a->total / s < 4) --s;
+  a->per_share = cdiv(a->total, s);
+  a->shares = cdiv(a->total, a->per_share);
+  a->xcd_runs = (a->shares % 8 == 0) ? a->shares / 8 : 0;
+  return 0;
+}
+
 struct GPlan {
   size_t amax_off, a_off, x_off, total;
 };
@@ -630,6 +818,51 @@ int ssad_conv1x1_gemm_split(const ssad_gemm_conv* d, void* workspace, size_t wor
   const int cus = ssad_cu_count();
   const unsigned grid = (unsigned)(q.items < cus ? q.items : cus);
   hipLaunchKernelGGL(gemm_split_kernel, dim3(grid), dim3(kThreads), 0, stream, q);
+  return (int)hipGetLastError();
+}
+
+size_t ssad_conv1x1_wgrad_split_workspace_bytes(int N, int C, int P, int M) {
+  WPArgs a;
+  if (wpoint_plan(N, C, P, M, &a)) return 0;
+  return 256 + sizeof(float) * (size_t)a.shares * a.mtiles * WT * a.ctiles * WT;
+}
+
+int ssad_conv1x1_wgrad_split(const float* x, const float* dy, int N, int C, int P, int M, float* dw, int accumulate,
+                             void* workspace, size_t workspace_bytes, ssad_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  WPArgs a;
+  const int rc = wpoint_plan(N, C, P, M, &a);
+  if (rc) return rc;
+  if (!x || !dy || !dw) return SSAD_E_BADARG;
+  const size_t need = 256 + sizeof(float) * (size_t)a.shares * a.mtiles * WT * a.ctiles * WT;
+  if (!workspace || workspace_bytes < need) return SSAD_E_WORKSPACE;
+  unsigned* amax = (unsigned*)workspace;
+  a.x = x; a.dy = dy; a.amax = amax;
+  a.slabs = (float*)((char*)workspace + 256);
+  AmaxTable at;
+  for (int l = 0; l < kMaxLv; ++l) { at.x[l] = nullptr; at.n[l] = 0; at.block_start[l] = 0; }
+  at.count = 2;
+  at.amax = amax;
+  at.x[0] = x; at.n[0] = (long long)N * C * P;
+  at.x[1] = dy; at.n[1] = (long long)N * M * P;
+  int blocks = 0;
+  for (int l = 0; l < 2; ++l) {
+    at.block_start[l] = blocks;
+    long long nb = (at.n[l] / 4 + kThreads * 32 - 1) / (kThreads * 32);
+    blocks += (int)(nb < 1 ? 1 : nb > 512 ? 512 : nb);
+  }
+  for (int l = 2; l <= kMaxLv; ++l) at.block_start[l] = blocks;
+  (void)hipMemsetAsync(amax, 0, 256, stream);
+  hipLaunchKernelGGL(split_absmax_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, at);
+  static std::once_flag lds_once;
+  std::call_once(lds_once, [&] {
+    (void)hipFuncSetAttribute((const void*)wpoint_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+  });
+  hipLaunchKernelGGL(wpoint_split_kernel, dim3((unsigned)(a.mtiles * a.ctiles * a.shares)), dim3(FWG), W_LDS, stream, a);
+  const long long n = (long long)M * C;
+  hipLaunchKernelGGL(wpoint_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                     (const float*)a.slabs, a.shares, a.mtiles * WT, a.ctiles * WT, M, C, (const unsigned*)amax, dw,
+                     accumulate);
   return (int)hipGetLastError();
 }
 

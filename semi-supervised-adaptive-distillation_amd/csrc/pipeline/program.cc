@@ -181,6 +181,9 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
     case SSAD_OP_GEMM_CONV_SPLIT:
       return ssad_conv1x1_gemm_split((const ssad_gemm_conv*)p[0], (void*)p[1], (size_t)o.l[0], s);
     case SSAD_OP_CONV1X1_WGRAD:
+      if (i[5] == 1)
+        return ssad_conv1x1_wgrad_split((const float*)p[0], (const float*)p[1], i[0], i[1], i[2], i[3], (float*)p[2],
+                                        i[4], (void*)p[3], (size_t)o.l[0], s);
       return ssad_conv1x1_wgrad((const float*)p[0], (const float*)p[1], i[0], i[1], i[2], i[3], (float*)p[2],
                                 i[4], (void*)p[3], (size_t)o.l[0], s);
     case SSAD_OP_TRANSPOSE_FILTER:

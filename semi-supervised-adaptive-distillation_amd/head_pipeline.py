@@ -124,10 +124,11 @@ class DistillHeads(object):
         # (both networks, one launch per depth), 8 = tower data gradients (16: the backbones' >= 256-wide 3x3 layers,
         # backbone_pipeline.py), 32 = the subnets' >= 128-wide filter gradients (conv3x3_wgrad_split.hip; 64: the
         # backbones' >= 256-wide ones; 128: the backbones' pointwise layers with K, M >= 256 on the split-operand GEMM,
-        # gemm_split.hip); 0 = off.  Default 255: same-box A/B of the step 86.0 -> 83.9 ms for bits 1-16 (every bit pays
-        # in the step although the isolated launches are level with F(2x4): the step is power-bound, and the engine
-        # spends less of it), 82.6 -> 78.3 ms for bits 32 + 64, 78.9 -> 73.5 ms for bit 128 (profiles/r06_experiments.md).
-        self.split_conv = int(os.environ.get("SSAD_SPLIT_CONV", "255")) if (self.wino and not self.F16) else 0
+        # 256: their filter gradients, gemm_split.hip); 0 = off.  Default 511: same-box A/B of the step 86.0 -> 83.9 ms
+        # for bits 1-16 (every bit pays in the step although the isolated launches are level with F(2x4): the step is
+        # power-bound, and the engine spends less of it), 82.6 -> 78.3 ms for bits 32 + 64, 78.9 -> 73.5 ms for bit 128,
+        # 72.6 -> 70.4 ms for bit 256 (profiles/r06_experiments.md).
+        self.split_conv = int(os.environ.get("SSAD_SPLIT_CONV", "511")) if (self.wino and not self.F16) else 0
         self._split_ops, self._split_ws_need = [], 0
         self.momentum, self.weight_decay = momentum, weight_decay
         self.pg, self.world_size = process_group, world_size

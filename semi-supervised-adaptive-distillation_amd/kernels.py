@@ -207,6 +207,9 @@ def lib():
     L.ssad_conv1x1_wgrad_workspace_bytes.restype = sz
     L.ssad_conv1x1_wgrad_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.ssad_conv1x1_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]
+    L.ssad_conv1x1_wgrad_split_workspace_bytes.restype = sz
+    L.ssad_conv1x1_wgrad_split_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.ssad_conv1x1_wgrad_split.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]
     L.ssad_subsample.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_subsample_grad.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ssad_conv_implicit_gemm.argtypes = [C.POINTER(GemmConv), i32, i32, i32, i32, i32, i32, vp]
@@ -997,16 +1000,21 @@ def conv1x1_dgrad(dy, w, mask=None, accumulate_into=None, split=False):
     return dx
 
 
-def conv1x1_wgrad(x, dy, out=None, accumulate=False):
-    """dW [M][C] = sum_{n,p} dy[n][m][p] x[n][c][p]."""
+def conv1x1_wgrad(x, dy, out=None, accumulate=False, split=False):
+    """dW [M][C] = sum_{n,p} dy[n][m][p] x[n][c][p].  split: the split-operand engine (ssad_conv1x1_wgrad_split)."""
     _f32c(x, "x"); _f32c(dy, "dy")
     N, Cc, H, W = x.shape
     M = dy.shape[1]
     dw = out if out is not None else torch.empty((M, Cc), dtype=torch.float32, device="cuda")
-    nb = lib().ssad_conv1x1_wgrad_workspace_bytes(N, Cc, H * W, M)
+    L = lib()
+    size_fn = L.ssad_conv1x1_wgrad_split_workspace_bytes if split else L.ssad_conv1x1_wgrad_workspace_bytes
+    fn = L.ssad_conv1x1_wgrad_split if split else L.ssad_conv1x1_wgrad
+    nb = size_fn(N, Cc, H * W, M)
+    if split and not nb:
+        raise KernelError("conv1x1_wgrad_split: unsupported geometry")
     ws = _workspace(nb, "wgrad1x1")
-    _check(lib().ssad_conv1x1_wgrad(_ptr(x), _ptr(dy), N, Cc, H * W, M, _ptr(dw), int(accumulate), _ptr(ws), nb,
-                                    _stream()), "conv1x1_wgrad")
+    _check(fn(_ptr(x), _ptr(dy), N, Cc, H * W, M, _ptr(dw), int(accumulate), _ptr(ws), nb, _stream()),
+           "conv1x1_wgrad_split" if split else "conv1x1_wgrad")
     return dw
 
 

@@ -112,6 +112,8 @@ KLASS = {
                   "SSAD_SPLIT_CONV & 64)", bound="mfma16", wino=True, exec_div=1.0 / 3.0),
     71: dict(name="backbone pointwise conv fwd / data gradient, K and M >= 256, split-operand GEMM (gemm_fly_kernel + |max| "
                   "+ filter split; SSAD_SPLIT_CONV & 128)", bound="mfma16", wino=True, exec_div=1.0 / 3.0),
+    72: dict(name="backbone pointwise conv filter gradient, C and M >= 256, split-operand engine (wpoint_split_kernel + "
+                  "|max| + reduce; SSAD_SPLIT_CONV & 256)", bound="mfma16", wino=True, exec_div=1.0 / 3.0),
     64: dict(name="P6 / P7 3x3 stride-2 conv fwd / data gradient at their own size (implicit GEMM with split-K; "
                   "flattened-batch GEMM + col2im)", bound="mfma", wino=False),
     65: dict(name="P6 / P7 3x3 stride-2 filter gradient (im2col + gemm_conv_nt_kernel + reduce)", bound="mfma",

@@ -367,3 +367,36 @@ def test_gemm_split_full_size_vs_exact_fp32_gemm_and_float64(K):
         e_s = np.abs(got[n0].double().cpu().numpy() - ref).max() / np.abs(ref).max()
         e_f = np.abs(want[n0].double().cpu().numpy() - ref).max() / np.abs(ref).max()
         assert e_s <= 2e-6 and e_s <= 4 * e_f + 1e-7, (e_s, e_f)
+
+
+# ---------------------------------------------------------------------------
+# Split-operand pointwise filter gradient (gemm_split.hip, wpoint_split_kernel): conv1x1_wgrad's contract, same tolerance
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [(2, 256, 256, 8, 16), (3, 264, 520, 5, 8), (1, 64, 72, 4, 6), (2, 512, 256, 20, 28),
+                                   (1, 300, 40, 2, 4)], ids=lambda s: "N%d_C%d_M%d_%dx%d" % s)
+def test_split_pointwise_wgrad_vs_oracle(K, shape):
+    N, Cin, M, H, W = shape
+    rng = np.random.default_rng(3100 + sum(shape))
+    X = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    dY = (rng.standard_normal((N, M, H, W)) * 1e-3).astype(np.float32)
+    Wt = np.zeros((M, Cin, 1, 1), np.float32)
+    ref_dW, _, _ = oracle.conv_backward(X, Wt, dY, kernel=1, stride=1, pad=0)
+    ref_dW = ref_dW.reshape(M, Cin)
+    dW = K.conv1x1_wgrad(dev(X), dev(dY), split=True)
+    close(dW.cpu().numpy(), ref_dW, CONV_RTOL, CONV_FLOOR, "split pointwise dW")
+    base = dev(np.full_like(ref_dW, 0.25))
+    K.conv1x1_wgrad(dev(X), dev(dY), out=base, accumulate=True, split=True)
+    close(base.cpu().numpy(), ref_dW + 0.25, CONV_RTOL, CONV_FLOOR, "split pointwise dW accumulate")
+    assert torch.equal(K.conv1x1_wgrad(dev(X), dev(dY), split=True), dW)        # deterministic
+
+
+def test_split_pointwise_wgrad_full_size_vs_exact_engine(K):
+    """res4's 1024 <- 256 layer at the bench's size (bs 16, 40 x 56) against the exact-fp32 MFMA engine."""
+    gen = torch.Generator(device="cuda").manual_seed(17)
+    N, Cin, M, H, W = 16, 256, 1024, 40, 56
+    X = torch.randn((N, Cin, H, W), device="cuda", generator=gen).clamp_(min=0)
+    dY = torch.randn((N, M, H, W), device="cuda", generator=gen) * 1e-4
+    want = K.conv1x1_wgrad(X, dY).clone()
+    got = K.conv1x1_wgrad(X, dY, split=True)
+    close(got.cpu().numpy(), want.cpu().numpy(), CONV_RTOL, CONV_FLOOR, "split pointwise dW, full size")

@@ -139,7 +139,7 @@ def test_f24_switches_select_the_engine_per_launch(monkeypatch):
         assert {o.p[3] for o in wg} == {h.wgrad_ws.data_ptr()} and max(o.l[0] for o in wg) <= h.wgrad_ws.numel()
     monkeypatch.delenv("SSAD_SPLIT_CONV")
     h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu")
-    assert h.split_conv == 255
+    assert h.split_conv == 511
     monkeypatch.setenv("SSAD_SPLIT_CONV", "0")
     # without a teacher the student's towers are alone in their launch and follow bit 4
     monkeypatch.setenv("SSAD_STUDENT_F24", "7")
@@ -279,6 +279,15 @@ def test_backbone_engines_follow_the_f24_switches(monkeypatch):
     assert not sp0 and not sp1 and len(g0) == len(g1) == len(sp2) + len(g2) and len(sp2) > 20
     assert {o.klass for o in sp2} == {71} and {o.p[1] for o in sp2} == {bb.split_ws.data_ptr()}
     assert max(o.l[0] for o in sp2) <= bb.split_ws.numel()
+    # bit 256 (default): the pointwise filter gradients with C, M >= 256 likewise
+    def pw_wgrads(bits):
+        monkeypatch.setenv("SSAD_SPLIT_CONV", str(bits))
+        monkeypatch.setattr(BP, "GEMM_SPLIT_MIN_PIXELS", 0)
+        bb = NativeResNetFPN("r50", 1, (128, 128), "cpu", train=True)
+        return [(o.i[5], o.klass, o.i[1], o.i[3]) for o in bb.prog.ops if o.code == PR.CONV1X1_WGRAD]
+    p0, p1 = pw_wgrads(255), pw_wgrads(511)
+    assert all(x[0] == 0 and x[1] == 52 for x in p0) and len(p0) == len(p1)
+    assert all((x[0], x[1]) == ((1, 72) if min(x[2], x[3]) >= 256 else (0, 52)) for x in p1) and any(x[0] for x in p1)
     monkeypatch.setenv("SSAD_SPLIT_CONV", "15")
     e, _ = engines(True, {"SSAD_STUDENT_F24": "7"})
     assert all(x == (1, 48) for x in e) and len(e) == 3 + 14 * 2

@@ -46,8 +46,13 @@ def main():
         t_s = timeit(lambda: K._check(L.ssad_conv1x1_gemm_split(C.byref(d), K._ptr(ws), ws.numel(), K._stream()), "split"))
         fl = 2.0 * Cin * M * N * H * W
         byts = 4.0 * N * H * W * (Cin + 2 * M)
-        print("%-30s fp32 %.3f ms (%.0f TF/s, %.2f TB/s) | split %.3f ms (%.0f TF/s equiv) | split/fp32 %.2f" % (
-            name, t_f, fl / t_f / 1e9, byts / t_f / 1e9, t_s, fl / t_s / 1e9, t_s / t_f), flush=True)
+        dY = torch.randn((N, M, H, W), device="cuda", generator=gen) * 1e-3
+        t_wf = timeit(lambda: K.conv1x1_wgrad(X, dY))
+        t_ws = timeit(lambda: K.conv1x1_wgrad(X, dY, split=True))
+        print("%-30s fp32 %.3f ms (%.0f TF/s, %.2f TB/s) | split %.3f ms (%.0f TF/s equiv) | split/fp32 %.2f || filter "
+              "gradient fp32 %.3f ms | split %.3f ms | %.2f" % (
+                  name, t_f, fl / t_f / 1e9, byts / t_f / 1e9, t_s, fl / t_s / 1e9, t_s / t_f, t_wf, t_ws, t_ws / t_wf),
+              flush=True)
 
 
 if __name__ == "__main__":
