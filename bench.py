@@ -645,13 +645,15 @@ def main():
                           "; backbones: this repo's fp32 kernels)" if native else
                           "; backbones: torch autocast on MIOpen / rocBLAS)")),
             "dtype_note": (None if f16 else
-                           "fp32 storage and fp32 accumulation everywhere.  The 3x3 convolutions of the subnets' towers and "
-                           "cls_pred and of the backbones' >= 256-wide layers run on the split-operand engine by default: "
-                           "each fp32 operand enters the fp16 matrix pipe as hi + lo (22 significant bits under a "
-                           "per-tensor power-of-two scale), three MFMAs per operand pair, measured error against "
-                           "float64 1.2e-6 of the output scale at K = 2304 (fp32 accumulation order; F(2x4) fp32 "
-                           "Winograd: 1.5-2.2e-6) and held to the direct fp32 kernel's parity bar.  "
-                           "also.cfg3_fp32_mfma_only = the same step with that engine off (fp32 MFMA instructions only)."),
+                           "fp32 storage and fp32 accumulation everywhere.  The wide convolutions run on the split-operand "
+                           "engines by default -- forward, data gradient AND filter gradient of the subnets' towers and "
+                           "cls_pred, of the backbones' >= 256-wide 3x3 layers and of their pointwise layers with both "
+                           "channel counts >= 256: each fp32 operand enters the fp16 matrix pipe as hi + lo (22 significant "
+                           "bits under a per-tensor power-of-two scale from the tensor's measured |max|), three MFMAs per "
+                           "operand pair, measured error against float64 1.2e-6 of the output scale at K = 2304 (fp32 "
+                           "accumulation order; F(2x4) fp32 Winograd: 1.5-2.2e-6) and held to the direct fp32 kernels' "
+                           "parity bar (tests/test_gpu_kernels.py, test_gpu_gemm_conv.py).  also.cfg3_fp32_mfma_only = the "
+                           "same step with those engines off (SSAD_SPLIT_CONV=0: fp32 MFMA instructions only)."),
             "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": N, "image": "3x%dx%d" % image_hw,
                        "fpn_levels": [list(s) for s in shapes], "anchors": 9, "classes": 80,
