@@ -1,21 +1,17 @@
-// gemm_split.hip -- the pointwise (1x1) convolution as a split-operand GEMM on the fp16 matrix pipes (round 6).
+// gemm_split.hip -- the pointwise (1x1) convolution and its filter gradient as split-operand GEMMs on the fp16 matrix
+// pipes (round 6).
 //
-// Same contract as ssad_conv1x1_gemm (gemm_conv.hip; detectron/lib/modeling/ResNet.py:221-283, FPN.py:116-250;
-// caffe2/operators/conv_op_impl.h:126-173 with the identity im2col of a 1x1 kernel):
+// Same contracts as ssad_conv1x1_gemm / ssad_conv1x1_wgrad (gemm_conv.hip; detectron/lib/modeling/ResNet.py:221-283,
+// FPN.py:116-250; caffe2/operators/conv_op_impl.h:126-173, 451-500 with the identity im2col of a 1x1 kernel):
 //     y[n][m][p] = act( sum_k a[k][m] x[n][k][p] + bias[m] + residual[n][m][p] ),  optional mask, optional y +=
+//     dw[m][c]  (+)= sum_{n,p} dy[n][m][p] x[n][c][p]
 // with the arithmetic of conv3x3_split.hip: every fp32 operand as hi + lo fp16 under a per-tensor power-of-two scale
 // from the tensor's measured |max|, three v_mfma_f32_32x32x16_f16 per operand pair, fp32 accumulation, the scales
-// divided out exactly in the epilogue.  For the pointwise layers there is no Winograd to compete with: the exact-fp32
-// MFMA GEMM runs at 0.65 of 157 TFLOP/s, this one executes 3 x the flops on pipes 16 x as fast.
+// divided out exactly in the epilogue.  The activations are split ON THE FLY inside the GEMM kernels: a first version
+// with a split PASS in front of a persistent LDS-DMA kernel ran the GEMM itself at 800 TFLOP/s of fp16 products but
+// lost more to the pass than it saved (profiles/r06_experiments.md section 3) and was removed.
 //
-// One call = |max| of x and a (one launch) + split of x into channel-blocked hi / lo planes + split of a + the GEMM.
-// GEMM kernel: persistent, one workgroup of four waves per CU (one wave per SIMD, 512 registers: see
-// conv3x3_split.hip for why).  Work item = 256 output channels x 128 pixels of one image; the four waves take 64
-// channels each and share the pixel tile: wave tile = 2 x 4 MFMA tiles of 32 x 32 (128 accumulators).  K runs in
-// chunks of 64 channels = 4 steps of one MFMA K (16 channels); a chunk's 64 x 128 tile of both planes (32 KB) is
-// staged by LDS-DMA three chunks ahead through four LDS stages; the filter operands (4 x 16 bytes per lane and step)
-// come from the L2-resident pack through a four-step register ring with hand-counted waits.  Per step 4 filter
-// loads + 8 ds_read_b128 feed 24 MFMAs.
+// One forward call = |max| of x and a (one launch) + split of a (tiny) + gemm_fly_kernel.
 #include <stdlib.h>
 
 #include <mutex>
@@ -27,18 +23,8 @@ namespace {
 using namespace ssad_split;
 
 constexpr int PT = 128;                // pixels per work item
-constexpr int MT = 256;                // output channels per work item (4 waves x 64)
-constexpr int CBC = 8;                 // 8-channel blocks per K chunk (64 channels)
-constexpr int KS = CBC / 2;            // MFMA K steps per chunk (4)
-constexpr int STAGE = CBC * PT;        // 16-byte slots per plane and stage (1024 = 16 wave-level DMA instructions)
-constexpr int NLD = STAGE / 64 / 4;    // DMA instructions per wave, plane and chunk (4): one per step
-constexpr int NBUF = 4;                // LDS stages: chunk c + 3 is requested during chunk c
+constexpr int MT = 256;                // output channels per work item
 constexpr int HDR = 16;                // floats in front of the packed a: [0] = |max| bits
-static_assert(KS == 4 && NLD == KS && NBUF == 4, "the counted waits below are written for these");
-
-#ifndef GSPLIT_ABLATE    // debug builds (results wrong): 1 no tile DMA traffic, 2 no filter traffic, 4 only hi*hi
-#define GSPLIT_ABLATE 0
-#endif
 
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -62,276 +48,9 @@ __global__ __launch_bounds__(kThreads) void gsplit_pack_a_kernel(const float* __
   }
 }
 
-struct GArgs {
-  const uint4* xp;       // hi plane [N][KB][P]; lo plane at + N * KB * P slots
-  const float* ap;       // packed a (header + planes)
-  float* y;
-  const float* bias;
-  const float* residual;
-  const float* mask;
-  const unsigned* amax;  // [0] = x
-  int N, K, P, M, relu, accumulate;
-  int ptiles, mblocks, items;
-};
-
-__global__ __launch_bounds__(kThreads, 1) void gemm_split_kernel(const GArgs q) {
-  __shared__ uint4 lds[NBUF * 2 * STAGE];        // [stage][plane][block][pixel]  (128 KB)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  const int K = q.K, M = q.M, P = q.P;
-  const int KB = (K + 7) >> 3;
-  const int nchunks = (KB + CBC - 1) / CBC;
-  const int P16 = P * 16;
-  const unsigned x_lo_off = (unsigned)((long long)q.N * KB * P16);
-  const unsigned w_lo_off = (unsigned)((long long)KB * M * 16);
-  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr)lds;
-  const ssad_dev::rsrc_words xrs = ssad_dev::uniform_rsrc_words(q.xp, 2u * x_lo_off);
-  const ssad_dev::rsrc_words wrs = ssad_dev::uniform_rsrc_words(q.ap + HDR, 2u * w_lo_off);
-  const int bbase = h * PT + j;                            // + (2 st) * PT + 32 tt
-
-  struct Item {
-    int n, p0, ocb, ok;
-  };
-  auto decode = [&](int it) {
-    // ids b, b + 8, ... share an XCD's L2: the channel blocks of one pixel tile are adjacent along that sequence
-    Item o;
-    const int xcd = it & 7, seq = it >> 3;
-    const int mb = seq % q.mblocks;
-    const int t = (seq / q.mblocks) * 8 + xcd;
-    o.ok = t < q.N * q.ptiles;
-    o.n = t / q.ptiles;
-    o.p0 = (t - o.n * q.ptiles) * PT;
-    o.ocb = mb * MT;
-    return o;
-  };
-  unsigned dvo[NLD], avo[2];
-  int dblk[NLD];
-  auto bind = [&](const Item& I) {
-    // tile staging: slot s = (block, pixel) of the 8-block x 128-pixel tile of one plane; wave-level instruction k writes
-    // slots [64 k, 64 k + 64); wave w issues k = w, w + 4, w + 8, w + 12 (one per step) for each plane
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int s = 64 * (wave + 4 * i) + lane;
-      const int b = s / PT, px = I.p0 + s % PT;
-      dblk[i] = b;
-      dvo[i] = px < P ? (unsigned)((((long long)I.n * KB + b) * P + px) * 16) : kOob;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int oc = I.ocb + wave * 64 + i * 32 + j;
-      avo[i] = (unsigned)(h * M + (oc < M ? oc : M - 1)) * 16u;
-    }
-  };
-  auto dma_piece = [&](int chunk, int buf, int i, bool real) {
-    const unsigned vo = (real && !(GSPLIT_ABLATE & 1) && chunk * CBC + dblk[i] < KB) ? dvo[i] : kOob;
-    const int soff = __builtin_amdgcn_readfirstlane(real ? chunk * CBC * P16 : 0);
-    const unsigned dst = lds_base + (unsigned)((buf * 2 * STAGE + 64 * (wave + 4 * i)) * 16);
-    dma16(xrs, dst, vo, soff);
-    dma16(xrs, dst + STAGE * 16, vo, soff + (int)x_lo_off);
-  };
-  f32x4 ar[KS][4];                                 // ring slot = step: [hi half 0, hi half 1, lo half 0, lo half 1]
-  auto ring_load1 = [&](f32x4& dst, int chunk, int st, int k, bool real) {
-    const int soff = __builtin_amdgcn_readfirstlane(real ? ((chunk * CBC + 2 * st) * M) * 16 + (k >> 1) * (int)w_lo_off : 0);
-    const unsigned vo = (real && !(GSPLIT_ABLATE & 2)) ? avo[k & 1] : kOob;
-    // (s_nop 4: conv3x3_split.hip, ring_load1)
-    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(vo), "s"(wrs), "s"(soff));
-  };
-  auto ring_landed = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int a = 0; a < KS; ++a) asm volatile("" : "+v"(ar[a][0]), "+v"(ar[a][1]), "+v"(ar[a][2]), "+v"(ar[a][3]));
-  };
-  int gbuf = 0;
-  auto prologue = [&]() {
-#pragma unroll
-    for (int c = 0; c < NBUF - 1; ++c) {
-      int b = gbuf + c; if (b >= NBUF) b -= NBUF;
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) dma_piece(c, b, i, c < nchunks);
-    }
-#pragma unroll
-    for (int a = 0; a < KS; ++a)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) ring_load1(ar[a][k], 0, a, k, true);
-  };
-
-  const int G = (int)gridDim.x;
-  int it = (int)blockIdx.x;
-  Item cur = decode(it);
-  while (it < q.items && !cur.ok) { it += G; if (it < q.items) cur = decode(it); }
-  if (it >= q.items) return;
-  bind(cur);
-  prologue();
-  ring_landed();
-  __builtin_amdgcn_s_barrier();
-
-  while (true) {
-    float16v acc[2][4];
-    {
-      float zero;
-      asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][tt][r] = zero;
-    }
-    int buf = gbuf;
-    for (int c = 0; c < nchunks; ++c) {
-      const bool more = c + 1 < nchunks, more3 = c + NBUF - 1 < nchunks;
-      int buf3 = buf + NBUF - 1; if (buf3 >= NBUF) buf3 -= NBUF;
-      const uint4* tile_hi = lds + buf * 2 * STAGE;
-      const uint4* tile_lo = tile_hi + STAGE;
-      half8 bh[4], bl[4];
-      auto read_b = [&](const uint4* tile, int st, half8 (&bb)[4]) {
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) bb[tt] = __builtin_bit_cast(half8, tile[bbase + (2 * st) * PT + 32 * tt]);
-      };
-      read_b(tile_hi, 0, bh);
-      read_b(tile_lo, 0, bl);
-#pragma unroll
-      for (int st = 0; st < KS; ++st) {
-        f32x4 (&a)[4] = ar[st];
-        // counted waits: the issue order is conv3x3_split.hip's with four steps per chunk and a DMA piece behind every
-        // step -- lo refills inside this step's third MFMA group, hi refills + the previous step's piece inside the
-        // next step's first group, the last step's at its end (24 operations per chunk)
-        if (st == 0) asm volatile("s_waitcnt vmcnt(20)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
-        else asm volatile("s_waitcnt vmcnt(16)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
-        const half8 ah0 = __builtin_bit_cast(half8, a[0]), ah1 = __builtin_bit_cast(half8, a[1]);
-        const half8 al0 = __builtin_bit_cast(half8, a[2]), al1 = __builtin_bit_cast(half8, a[3]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {                       // hi x hi
-          acc[0][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[tt], acc[0][tt], 0, 0, 0);
-          acc[1][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh[tt], acc[1][tt], 0, 0, 0);
-          if (st >= 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (tt < 2) ring_load1(ar[st - 1][tt], c + 1, st - 1, tt, more);
-            if (tt == 2) dma_piece(c + NBUF - 1, buf3, st - 1, more3);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(GSPLIT_ABLATE & 4)) {
-#pragma unroll
-          for (int tt = 0; tt < 4; ++tt) {                     // lo(a) x hi
-            acc[0][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[tt], acc[0][tt], 0, 0, 0);
-            acc[1][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[tt], acc[1][tt], 0, 0, 0);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (st + 1 < KS) read_b(tile_hi, st + 1, bh);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {                       // hi x lo(x)
-          if (!(GSPLIT_ABLATE & 4)) {
-            acc[0][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[tt], acc[0][tt], 0, 0, 0);
-            acc[1][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl[tt], acc[1][tt], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (tt < 2) ring_load1(a[2 + tt], c + 1, st, 2 + tt, more);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (st + 1 < KS) read_b(tile_lo, st + 1, bl);
-        if (st == KS - 1) {
-          ring_load1(a[0], c + 1, st, 0, more);
-          ring_load1(a[1], c + 1, st, 1, more);
-          dma_piece(c + NBUF - 1, buf3, st, more3);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // the tile of chunk c + 1 (requested during chunk c - 2, or by the prologue) has landed: younger are the 2 x 24
-      // operations of chunks c - 1 and c; this wave's LDS reads are done; after the barrier everybody's are
-      asm volatile("s_waitcnt vmcnt(48) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (++buf == NBUF) buf = 0;
-    }
-    gbuf = buf;
-    ring_landed();                                  // (the out-of-range refills of the last chunk: conv3x3_split.hip)
-
-    const Item done = cur;
-    int nit = it + G;
-    Item nxt = done;
-    while (nit < q.items) { nxt = decode(nit); if (nxt.ok) break; nit += G; }
-    const bool have_next = nit < q.items;
-    const int oc_w = done.ocb + wave * 64;
-    unsigned pvo[4];
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      const int px = done.p0 + 32 * tt + j;
-      pvo[tt] = px < P ? (unsigned)((((long long)done.n * M + 4 * h) * P + px) * 4) : kOob;
-    }
-    if (have_next) {
-      bind(nxt);
-      prologue();
-    }
-
-    // ---- epilogue: C/D row = (r & 3) + 8 (r >> 2) + 4 h, column = j
-    {
-      const int e2 = split_exponent(q.amax[0]) + split_exponent(reinterpret_cast<const unsigned*>(q.ap)[0]) - 30;
-      const bool one_scale = e2 >= -126 && e2 <= 127;
-      const float sc1 = one_scale ? pow2f(e2) : pow2f(split_exponent(q.amax[0]) - 15);
-      const float sc2 = one_scale ? 1.0f : pow2f(split_exponent(reinterpret_cast<const unsigned*>(q.ap)[0]) - 15);
-      const unsigned ybytes = (unsigned)((long long)q.N * M * P * 4);
-      const __amdgpu_buffer_rsrc_t yrs = uniform_rsrc(q.y, ybytes);
-      const __amdgpu_buffer_rsrc_t rrs = uniform_rsrc(q.residual ? (const void*)q.residual : (const void*)q.y, q.residual ? ybytes : 0u);
-      const __amdgpu_buffer_rsrc_t mrs = uniform_rsrc(q.mask ? (const void*)q.mask : (const void*)q.y, q.mask ? ybytes : 0u);
-      const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(q.bias ? (const void*)q.bias : (const void*)q.y, q.bias ? (unsigned)M * 4u : 0u);
-      const bool relu = q.relu, has_res = q.residual != nullptr, has_mask = q.mask != nullptr, accum = q.accumulate;
-      const bool ragged = (M & 7) != 0;
-      const int P4 = P * 4;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int oc0 = oc_w + i * 32;
-        float4 bq[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          bq[g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)h * 16u, (oc0 + 8 * g) * 4, 0));
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-          float rs[16], mk[16], old[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int ch = oc0 + 8 * (r >> 2) + (r & 3);
-            const unsigned vo = (ch < M && (!ragged || ch + 4 * h < M)) ? pvo[tt] : kOob;
-            rs[r] = has_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, vo, ch * P4, 0)) : 0.0f;
-            mk[r] = has_mask ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mrs, vo, ch * P4, 0)) : 1.0f;
-            old[r] = accum ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, vo, ch * P4, 0)) : 0.0f;
-          }
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            if (oc0 + 8 * g >= M) continue;               // wave-uniform
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int r = 4 * g + e;
-              float v = one_scale ? fmaf(acc[i][tt][r], sc1, bq[g][e]) : acc[i][tt][r] * sc1 * sc2 + bq[g][e];
-              v += rs[r];
-              if (relu) v = fmaxf(v, 0.0f);
-              if (has_mask) v = mk[r] > 0.0f ? v : 0.0f;
-              v += old[r];
-              const unsigned vo = (!ragged || oc0 + 8 * g + 4 * h + e < M) ? pvo[tt] : kOob;
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, vo, (oc0 + 8 * g + e) * P4, 0);
-            }
-          }
-        }
-      }
-    }
-    if (!have_next) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      return;
-    }
-    ring_landed();
-    __builtin_amdgcn_s_barrier();
-    it = nit;
-    cur = nxt;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// The same GEMM with x split ON THE FLY (no split pass, no packed copy of x): 8 waves (two per SIMD, so one wave's
-// fetch, split and waits run under the other's MFMAs -- conv3x3_wgrad_split.hip), one 256-channel x 128-pixel item per
+// Forward / data gradient.  No packed copy of x exists: 8 waves (two per SIMD, so one wave's fetch, split and waits run
+// under the other's MFMAs -- conv3x3_wgrad_split.hip), one 256-channel x 128-pixel item per
 // workgroup, K in chunks of 32 channels through two LDS stages.  A thread fetches 8 channels of one pixel as eight
 // coalesced dword loads (exactly one MFMA operand slot), splits them and writes hi / lo to LDS; the packed filter's
 // slots go global -> register -> LDS unchanged.  Wave tile 64 channels x 64 pixels: per 16-channel step 8 LDS reads
@@ -713,17 +432,19 @@ int wpoint_plan(int N, int C, int P, int M, WPArgs* a) {
 }
 
 struct GPlan {
-  size_t amax_off, a_off, x_off, total;
+  size_t amax_off, a_off, total;
 };
 int make_plan(const ssad_gemm_conv* d, GPlan* p) {
   if (!d || d->N <= 0 || d->K <= 0 || d->P <= 0 || d->M <= 0 || d->lda < d->M) return SSAD_E_BADARG;
   const int KB = (d->K + 7) >> 3;
-  const long long xslots = (long long)d->N * KB * d->P, aslots = (long long)KB * d->M;
-  if (xslots * 32 >= (1LL << 32) || (long long)d->N * d->M * d->P * 4 >= (1LL << 32)) return SSAD_E_BADARG;
+  const long long aslots = (long long)KB * d->M;
+  // byte offsets are 32-bit and 2^31 means "outside": larger tensors stay on the exact-fp32 engine
+  if ((long long)d->N * d->K * d->P * 4 >= (1LL << 31) || (long long)d->N * d->M * d->P * 4 >= (1LL << 31) ||
+      aslots * 32 >= (1LL << 31))
+    return SSAD_E_BADARG;
   p->amax_off = 0;
   p->a_off = 256;
-  p->x_off = (p->a_off + (size_t)HDR * 4 + (size_t)aslots * 32 + 255) & ~(size_t)255;
-  p->total = p->x_off + (size_t)xslots * 32;
+  p->total = p->a_off + (size_t)HDR * 4 + (size_t)aslots * 32;
   return 0;
 }
 
@@ -747,7 +468,6 @@ int ssad_conv1x1_gemm_split(const ssad_gemm_conv* d, void* workspace, size_t wor
   char* ws = (char*)workspace;
   unsigned* amax = (unsigned*)(ws + p.amax_off);
   float* apk = (float*)(ws + p.a_off);
-  uint4* xpl = (uint4*)(ws + p.x_off);
   const int KB = (d->K + 7) >> 3;
   // |max| of x (word 0) and a (word 1), one launch
   AmaxTable at;
@@ -765,19 +485,6 @@ int ssad_conv1x1_gemm_split(const ssad_gemm_conv* d, void* workspace, size_t wor
   for (int l = 2; l <= kMaxLv; ++l) at.block_start[l] = blocks;
   (void)hipMemsetAsync(amax, 0, 256, stream);
   hipLaunchKernelGGL(split_absmax_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, at);
-  const char* fe = getenv("TMP_GEMM_FLY");
-  const bool fly = !(fe && fe[0] == '0') && (long long)d->N * d->K * d->P * 4 < (1LL << 31);
-  // x -> planes
-  if (!fly) {
-  ActTable pt;
-  for (int l = 0; l < kMaxLv; ++l) { pt.x[l] = nullptr; pt.planes[l] = nullptr; pt.N[l] = 0; pt.plane[l] = 0; pt.block_start[l] = 0; }
-  pt.count = 1; pt.C = d->K; pt.amax = amax;
-  pt.x[0] = d->x; pt.planes[0] = xpl; pt.N[0] = d->N; pt.plane[0] = d->P;
-  const long long xslots = (long long)d->N * KB * d->P;
-  const int pblocks = (int)((xslots + kThreads - 1) / kThreads);
-  for (int l = 1; l <= kMaxLv; ++l) pt.block_start[l] = pblocks;
-  hipLaunchKernelGGL(split_pack_act_kernel, dim3((unsigned)pblocks), dim3(kThreads), 0, stream, pt);
-  }
   // a -> planes
   {
     long long bx = ((long long)KB * d->M + kThreads - 1) / kThreads;
@@ -785,39 +492,22 @@ int ssad_conv1x1_gemm_split(const ssad_gemm_conv* d, void* workspace, size_t wor
     hipLaunchKernelGGL(gsplit_pack_a_kernel, dim3((unsigned)bx), dim3(kThreads), 0, stream, d->a, d->lda, d->K, d->M,
                        (const unsigned*)(amax + 1), apk);
   }
-  if (fly) {
-    FArgs f;
-    f.x = d->x; f.ap = apk; f.y = d->y; f.bias = d->bias; f.residual = d->residual; f.mask = d->mask;
-    f.amax = amax;
-    f.N = d->N; f.K = d->K; f.P = d->P; f.M = d->M;
-    f.relu = (d->flags & SSAD_GEMM_RELU) ? 1 : 0;
-    f.accumulate = (d->flags & SSAD_GEMM_ACCUMULATE) ? 1 : 0;
-    f.ptiles = cdiv(d->P, PT);
-    f.mblocks = cdiv(d->M, MT);
-    const long long tiles = (long long)d->N * f.ptiles;
-    if (tiles * f.mblocks >= (1LL << 30)) return SSAD_E_BADARG;
-    f.items = (int)(cdiv((int)tiles, 8) * 8 * f.mblocks);
-    static std::once_flag lds_once;           // > 64 KiB of dynamic LDS needs the opt-in, once per process
-    std::call_once(lds_once, [&] {
-      (void)hipFuncSetAttribute((const void*)gemm_fly_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
-    });
-    hipLaunchKernelGGL(gemm_fly_kernel, dim3((unsigned)f.items), dim3(FWG), F_LDS, stream, f);
-    return (int)hipGetLastError();
-  }
-  GArgs q;
-  q.xp = xpl; q.ap = apk; q.y = d->y; q.bias = d->bias; q.residual = d->residual; q.mask = d->mask;
-  q.amax = amax;
-  q.N = d->N; q.K = d->K; q.P = d->P; q.M = d->M;
-  q.relu = (d->flags & SSAD_GEMM_RELU) ? 1 : 0;
-  q.accumulate = (d->flags & SSAD_GEMM_ACCUMULATE) ? 1 : 0;
-  q.ptiles = cdiv(d->P, PT);
-  q.mblocks = cdiv(d->M, MT);
-  const long long tiles = (long long)d->N * q.ptiles;
-  if (tiles * q.mblocks >= (1LL << 30)) return SSAD_E_BADARG;
-  q.items = (int)(cdiv((int)tiles, 8) * 8 * q.mblocks);
-  const int cus = ssad_cu_count();
-  const unsigned grid = (unsigned)(q.items < cus ? q.items : cus);
-  hipLaunchKernelGGL(gemm_split_kernel, dim3(grid), dim3(kThreads), 0, stream, q);
+  FArgs f;
+  f.x = d->x; f.ap = apk; f.y = d->y; f.bias = d->bias; f.residual = d->residual; f.mask = d->mask;
+  f.amax = amax;
+  f.N = d->N; f.K = d->K; f.P = d->P; f.M = d->M;
+  f.relu = (d->flags & SSAD_GEMM_RELU) ? 1 : 0;
+  f.accumulate = (d->flags & SSAD_GEMM_ACCUMULATE) ? 1 : 0;
+  f.ptiles = cdiv(d->P, PT);
+  f.mblocks = cdiv(d->M, MT);
+  const long long tiles = (long long)d->N * f.ptiles;
+  if (tiles * f.mblocks >= (1LL << 30)) return SSAD_E_BADARG;
+  f.items = (int)(cdiv((int)tiles, 8) * 8 * f.mblocks);
+  static std::once_flag lds_once;           // > 64 KiB of dynamic LDS needs the opt-in, once per process
+  std::call_once(lds_once, [&] {
+    (void)hipFuncSetAttribute((const void*)gemm_fly_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+  });
+  hipLaunchKernelGGL(gemm_fly_kernel, dim3((unsigned)f.items), dim3(FWG), F_LDS, stream, f);
   return (int)hipGetLastError();
 }
 
