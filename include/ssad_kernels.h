@@ -407,6 +407,21 @@ SSAD_API int ssad_conv3x3_wgrad_split(
     const ssad_conv_level* levels_host, int n_levels, float* dW, float* db,
     int Cout, int Cin, int accumulate, void* workspace, size_t workspace_bytes,
     ssad_stream_t stream);
+/* ... with the |max| words of X and dY handed over (device, n_levels words each: word l = level l, 0 for a level
+ * without pixels) by whoever measured them -- an earlier split-engine call on the same tensors or
+ * ssad_split_absmax_levels: the call's own |max| pass and its memset are skipped.  Both or neither. */
+SSAD_API int ssad_conv3x3_wgrad_split_amax(
+    const ssad_conv_level* levels_host, int n_levels, float* dW, float* db,
+    int Cout, int Cin, int accumulate, void* workspace, size_t workspace_bytes,
+    const unsigned* x_amax, const unsigned* dy_amax, ssad_stream_t stream);
+
+/* The split engines' |max| pass on its own: the |max| (as float bit patterns) of every tensor of a level table, folded
+ * into caller-owned words with atomicMax -- word k = problem k; the caller zeroes the words (a program zeroes its whole
+ * table of words with ONE fill per step).  field 0: levels_host[k].x, 1: .aux; channels = their channel count.
+ * A tensor measured once serves every split-engine call that reads it (forward, data gradient, filter gradient). */
+SSAD_API int ssad_split_absmax_levels(const ssad_conv_level* levels_host, int n, int channels, int field,
+                                      unsigned* words, ssad_stream_t stream);
+SSAD_API int ssad_split_absmax(const float* x, long long n, unsigned* word, ssad_stream_t stream);
 
 /* ---------------------------------------------------------------------- */
 /* RetinaNet anchor labelling on the device (row f4)                       */
@@ -508,13 +523,28 @@ typedef struct ssad_gemm_conv {
 SSAD_API int ssad_conv1x1_gemm(const ssad_gemm_conv* desc_host, ssad_stream_t stream);
 /* The same contract on the split-operand engine (round 6, gemm_split.hip): x and a as hi + lo fp16 under per-tensor
  * power-of-two scales from their measured |max|, three fp16 MFMAs per operand pair, fp32 accumulation (see
- * ssad_conv3x3_forward_split for the arithmetic and its limits).  No alignment requirements beyond 16-byte aligned
- * x / a; any K, M, P.  workspace: ssad_conv1x1_gemm_split_workspace_bytes(desc) bytes (the split copies of x and a);
- * the call = |max| pass + two split passes + the GEMM on `stream`.  Meant for the compute-bound layers (K >= 256,
- * M >= 256: res3 - res5 of the backbones); the HBM-bound ones (res2) stay on ssad_conv1x1_gemm. */
+ * ssad_conv3x3_forward_split for the arithmetic and its limits).  x is split INSIDE the GEMM kernel (no packed copy of
+ * it exists); a is split into the workspace.  Any K, M, P; tensors below 2 GiB (SSAD_E_BADARG otherwise: use
+ * ssad_conv1x1_gemm).  workspace: ssad_conv1x1_gemm_split_workspace_bytes(desc) bytes; the call = |max| pass + split of
+ * a + the GEMM on `stream`.  Pays on the compute-bound layers (K >= 256, M >= 256: res4, res5, the laterals); the
+ * HBM-bound ones stay on ssad_conv1x1_gemm. */
 SSAD_API size_t ssad_conv1x1_gemm_split_workspace_bytes(const ssad_gemm_conv* desc_host);
 SSAD_API int ssad_conv1x1_gemm_split(const ssad_gemm_conv* desc_host, void* workspace, size_t workspace_bytes,
                                      ssad_stream_t stream);
+/* ... with what the caller already has handed over, either or both: packed_a = the filter split by
+ * ssad_gemm_split_pack_filters (desc->a is then not read), x_amax = x's |max| word (device; ssad_split_absmax or an
+ * earlier call's).  With both the call is the GEMM kernel alone. */
+SSAD_API int ssad_conv1x1_gemm_split_amax(const ssad_gemm_conv* desc_host, const float* packed_a, const unsigned* x_amax,
+                                          void* workspace, size_t workspace_bytes, ssad_stream_t stream);
+/* Split a table of filters a[K][lda] (as ssad_gemm_conv.a) into the engine's operand order in three launches: dst
+ * holds ssad_gemm_split_filter_floats(K, M) floats (a header with the filter's |max| + the hi and lo planes). */
+typedef struct ssad_gemm_pack_entry {
+  const float* a;
+  float* dst;
+  int lda, K, M;
+} ssad_gemm_pack_entry;
+SSAD_API size_t ssad_gemm_split_filter_floats(int K, int M);
+SSAD_API int ssad_gemm_split_pack_filters(const ssad_gemm_pack_entry* entries_host, int n_entries, ssad_stream_t stream);
 /* Convolution of any kernel / stride / pad (group 1) as an IMPLICIT GEMM, forward: the same kernel as
  * ssad_conv1x1_gemm with the im2col view of the image gathered by the DMA itself -- no column buffer
  * (caffe2/operators/conv_op_impl.h:126-173 materialises one per image; the 7x7/2 stem's is 1.35 GB at
@@ -576,6 +606,10 @@ SSAD_API size_t ssad_conv1x1_wgrad_split_workspace_bytes(int N, int C, int P, in
 SSAD_API int ssad_conv1x1_wgrad_split(const float* x, const float* dy, int N, int C, int P, int M, float* dw,
                                       int accumulate, void* workspace, size_t workspace_bytes,
                                       ssad_stream_t stream);
+/* ... with x's and dy's |max| words handed over (device, one word each; both or neither) */
+SSAD_API int ssad_conv1x1_wgrad_split_amax(const float* x, const float* dy, int N, int C, int P, int M, float* dw,
+                                           int accumulate, void* workspace, size_t workspace_bytes,
+                                           const unsigned* x_amax, const unsigned* dy_amax, ssad_stream_t stream);
 /* y[n][c][oy][ox] = x[n][c][oy*stride][ox*stride], OH = (H-1)/stride + 1; and its gradient
  * dx (+)= scatter(dy) (zero off the sampled grid) */
 SSAD_API int ssad_subsample(const float* x, int N, int C, int H, int W, int stride, float* y,

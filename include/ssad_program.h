@@ -48,7 +48,8 @@ enum ssad_opcode {
    * workspace bytes, p4 = amax_in or NULL, p5 = amax_out or NULL) */
   SSAD_OP_CONV3X3 = 3,
   /* ssad_conv3x3_wgrad(p0 = levels_host, i0 = n, p1 = dW, p2 = db, i1 = Cout, i2 = Cin,
-   * i3 = accumulate, p3 = workspace, l0 = workspace_bytes); i4 == 1: ssad_conv3x3_wgrad_split, same arguments */
+   * i3 = accumulate, p3 = workspace, l0 = workspace_bytes); i4 == 1: ssad_conv3x3_wgrad_split_amax, same arguments +
+   * p4 = X's |max| words, p5 = dY's (both NULL: measured by the call) */
   SSAD_OP_CONV3X3_WGRAD = 4,
   /* ssad_pow_sum(p0 = inputs_host, p1 = sizes_host, i0 = n, f0 = power, p2 = out,
    * p3 = workspace, l0 = workspace_bytes) */
@@ -122,7 +123,8 @@ enum ssad_opcode {
   /* ssad_channel_sum(p0 = dy, i0 = N, i1 = C, i2 = HW, p1 = out, i3 = accumulate) */
   SSAD_OP_CHANNEL_SUM = 55,
   /* ssad_conv1x1_wgrad(p0 = x, p1 = dy, i0..i3 = N, C, P, M, p2 = dw, i4 = accumulate,
-   * p3 = workspace, l0 = workspace_bytes); i5 == 1: ssad_conv1x1_wgrad_split, same arguments */
+   * p3 = workspace, l0 = workspace_bytes); i5 == 1: ssad_conv1x1_wgrad_split_amax, same arguments + p4 = x's |max|
+   * word, p5 = dy's (both NULL: measured by the call) */
   SSAD_OP_CONV1X1_WGRAD = 56,
   /* ssad_transpose_filter(p0 = w, i0 = M, i1 = K, i2 = ldm, p1 = wt) */
   SSAD_OP_TRANSPOSE_FILTER = 57,
@@ -180,8 +182,15 @@ enum ssad_opcode {
   SSAD_OP_TRANSPOSE_FILTERS = 77,
   /* p0 = const ssad_f16_pack_entry* (host table, kept alive by the caller), i0 = entries */
   SSAD_OP_F16_PACK_FILTERS = 78,
-  /* ssad_conv1x1_gemm_split(p0 = const ssad_gemm_conv* (host), p1 = workspace, l0 = workspace bytes) */
-  SSAD_OP_GEMM_CONV_SPLIT = 79
+  /* ssad_conv1x1_gemm_split_amax(p0 = const ssad_gemm_conv* (host), p1 = workspace, l0 = workspace bytes, p2 = packed
+   * filter or NULL, p3 = x's |max| word or NULL) */
+  SSAD_OP_GEMM_CONV_SPLIT = 79,
+  /* ssad_split_absmax_levels(p0 = levels_host, i0 = n, i1 = channels, i2 = field, p1 = words) */
+  SSAD_OP_SPLIT_ABSMAX_LEVELS = 80,
+  /* ssad_split_absmax(p0 = x, l0 = elements, p1 = word) */
+  SSAD_OP_SPLIT_ABSMAX = 81,
+  /* ssad_gemm_split_pack_filters(p0 = const ssad_gemm_pack_entry* (host), i0 = entries) */
+  SSAD_OP_GEMM_SPLIT_PACK = 82
 };
 
 typedef struct ssad_op {

@@ -301,6 +301,41 @@ class NativeResNetFPN(object):
         self._bufs.append(u)
         return u
 
+    # -- |max| words of the split-operand engines ------------------------------------------------------------
+    # One table of words per network, zeroed by ONE fill at the start of the forward pass.  A tensor is measured once,
+    # on the main stream, in front of its first split-engine consumer (SPLIT_ABSMAX / SPLIT_ABSMAX_LEVELS), and every
+    # later consumer -- the filter gradient on an auxiliary stream in particular -- is handed the word: no call measures
+    # or zeroes anything itself.  Tensors are identified by address: every activation and gradient buffer of a
+    # program is allocated once (_t / _like) and written once per step before its consumers.
+    AMAX_WORDS = 4096
+
+    def _measure(self, P, tensors, channels):
+        """Slot of the first of len(tensors) consecutive |max| words of these tensors (measured together, once)."""
+        key = tuple(t.data_ptr() for t in tensors)
+        if key in self._amax_groups:
+            return self._amax_groups[key]
+        base = self._amax_next
+        self._amax_next += len(tensors)
+        if self._amax_next > self.AMAX_WORDS:
+            raise K.KernelError("|max| table full")
+        addr = self.amax.data_ptr() + 4 * base
+        if len(tensors) == 1:
+            t = tensors[0]
+            P.add(PR.SPLIT_ABSMAX, 73, p=(t, addr), l=(t.numel(),), work=4.0 * t.numel(), keep=[t])
+        else:
+            arr = (K.ConvLevel * len(tensors))()
+            for i, t in enumerate(tensors):
+                arr[i] = K.ConvLevel(t.data_ptr(), 0, 0, t.shape[0], t.shape[2], t.shape[3], 0, 0)
+            P.add(PR.SPLIT_ABSMAX_LEVELS, 73, i=(len(tensors), channels, 0), p=(arr, addr),
+                  work=4.0 * sum(t.numel() for t in tensors), keep=list(tensors))
+        self._amax_groups[key] = base
+        for k, t in enumerate(tensors):
+            self._amax_groups.setdefault((t.data_ptr(),), base + k)
+        return base
+
+    def _amax_addr(self, slot):
+        return self.amax.data_ptr() + 4 * slot
+
     def poison(self, value=float("nan")):
         """Fill every activation / gradient / scratch buffer (debugging aid: anything the step
         reads before it writes shows up as NaN in the results)."""
@@ -323,12 +358,24 @@ class NativeResNetFPN(object):
             nb = K.lib().ssad_conv1x1_gemm_split_workspace_bytes(C.byref(d))
             if nb:
                 self._split_need = max(self._split_need, nb)
-                idx = P.add(PR.GEMM_CONV_SPLIT, 71, p=(d, None), l=(nb,), work=2.0 * px * Kc * M,
-                            keep=[t for t in (a, x, y, bias, res, mask) if t is not None])
+                xa = self._amax_addr(self._measure(P, [x], Kc))
+                idx = P.add(PR.GEMM_CONV_SPLIT, 71, p=(d, None, self._packed_a(a, lda, Kc, M), xa), l=(nb,),
+                            work=2.0 * px * Kc * M, keep=[t for t in (a, x, y, bias, res, mask) if t is not None])
                 self._gemm_split_ops.append(idx)
                 return
         P.add(PR.GEMM_CONV, klass, p=(d,), work=2.0 * px * Kc * M,
               keep=[t for t in (a, x, y, bias, res, mask) if t is not None])
+
+    def _packed_a(self, a, lda, Kc, M):
+        """The split copy of a pointwise filter operand a[Kc][lda] (made by the program's one GEMM_SPLIT_PACK op: per
+        step for a trained layer, once for a frozen one)."""
+        key = (a.data_ptr(), lda, Kc, M)
+        if key not in self._gemm_packs:
+            dst = self._t(K.lib().ssad_gemm_split_filter_floats(Kc, M))
+            train = self._a_train[a.data_ptr()]
+            self._gemm_packs[key] = dst
+            (self._gpack_train if train else self._gpack_frozen).append((a, lda, Kc, M, dst))
+        return self._gemm_packs[key]
 
     def _conv3(self, P, probs, Cout, Cin, flags, klass=48, f24=False):
         """probs: [(x, y, mask or None, packed, bias or None)]: independent 3x3 convolutions of one
@@ -343,8 +390,9 @@ class NativeResNetFPN(object):
             nb = K.lib().ssad_conv3x3_split_workspace_bytes(arr, len(probs), Cin)
             self._split_need = max(getattr(self, "_split_need", 0), nb)
             px = sum(p[0].shape[0] * p[0].shape[2] * p[0].shape[3] for p in probs)
+            xa = self._amax_addr(self._measure(P, [p[0] for p in probs], Cin))
             idx = P.add(PR.CONV3X3, 66 if self.train else 67, i=(len(probs), Cout, Cin, flags, 3), l=(nb,),
-                        p=(arr, None, None, None, None, None), work=2.0 * 9 * Cout * Cin * px,
+                        p=(arr, None, None, None, xa, None), work=2.0 * 9 * Cout * Cin * px,
                         keep=[t for p in probs for t in p if t is not None])
             self._split_ops.append(idx)
             return
@@ -368,9 +416,13 @@ class NativeResNetFPN(object):
         size_fn = K.lib().ssad_conv3x3_wgrad_split_workspace_bytes if split else K.lib().ssad_conv3x3_wgrad_workspace_bytes
         nb = size_fn(arr, 1, layer.cout, layer.cin)
         self._ws_need = max(self._ws_need, nb)
+        xa = da = None
+        if split:            # (measured on the main stream, before the fork)
+            xa = self._amax_addr(self._measure(P, [x], layer.cin))
+            da = self._amax_addr(self._measure(P, [dy], layer.cout))
         self._aux(P)
         idx = P.add(PR.CONV3X3_WGRAD, 70 if split else 49, i=(1, layer.cout, layer.cin, 0, 1 if split else 0), l=(nb,),
-                    p=(arr, layer.gw, layer.gb, None),
+                    p=(arr, layer.gw, layer.gb, None, xa, da),
                     work=2.0 * 9 * layer.cout * layer.cin * x.shape[0] * x.shape[2] * x.shape[3], keep=[x, dy],
                     stream=self._wstream)
         self._ws_ops.append((idx, 3, self._wstream))
@@ -385,9 +437,13 @@ class NativeResNetFPN(object):
         size_fn = K.lib().ssad_conv1x1_wgrad_split_workspace_bytes if split else K.lib().ssad_conv1x1_wgrad_workspace_bytes
         nb = size_fn(N, Cc, pix, layer.cout)
         self._ws_need = max(self._ws_need, nb)
+        xa = da = None
+        if split:
+            xa = self._amax_addr(self._measure(P, [x], Cc))
+            da = self._amax_addr(self._measure(P, [dy], layer.cout))
         self._aux(P)
         idx = P.add(PR.CONV1X1_WGRAD, 72 if split else 52, i=(N, Cc, pix, layer.cout, 0, 1 if split else 0), l=(nb,),
-                    p=(x, dy, layer.gw, None), work=2.0 * N * pix * Cc * layer.cout, keep=[x, dy],
+                    p=(x, dy, layer.gw, None, xa, da), work=2.0 * N * pix * Cc * layer.cout, keep=[x, dy],
                     stream=self._wstream)
         self._ws_ops.append((idx, 3, self._wstream))
 
@@ -494,6 +550,9 @@ class NativeResNetFPN(object):
         self._split_ops, self._split_need = [], 0
         self._gemm_split_ops = []
         self._gemm_split = (int(os.environ.get("SSAD_SPLIT_CONV", "511")) & 128) != 0
+        self.amax = torch.zeros(self.AMAX_WORDS, dtype=torch.int32, device=self.device)
+        self._amax_groups, self._amax_next = {}, 0
+        self._gemm_packs, self._gpack_train, self._gpack_frozen, self._a_train = {}, [], [], {}
         tr_frozen, tr_train = [], []          # (w, wt, M, K, ldm): every transposed filter of a program in one launch
         P.mark("pack")
         for l in L.values():
@@ -503,6 +562,7 @@ class NativeResNetFPN(object):
                 ldm = (l.cout + 3) // 4 * 4
                 l.wt = self._t(l.cin, ldm)
                 trs.append((l.w, l.wt, l.cout, l.cin, ldm))
+                self._a_train[l.wt.data_ptr()] = self._a_train[l.w.data_ptr()] = l.train
             elif l.k == 3 and l.group > 1:                       # ResNeXt: MFMA operand order, packed once
                 l.pf = self._t(lib.ssad_grouped_conv3x3_filter_floats(l.cout, l.group))
                 tgt.add(PR.GROUPED_PACK, 54, i=(l.cout, l.group), p=(l.w, l.pf), work=4.0 * (l.w.numel() + l.pf.numel()))
@@ -570,9 +630,15 @@ class NativeResNetFPN(object):
                 tgt.add(PR.WINO_PACK_FILTERS, 54, i=(len(ls), 3), p=(tab,),
                         work=4.0 * sum(l.w.numel() + l.pf.numel() + (l.pd.numel() if l.pd is not None else 0)
                                        for l in ls))
-        prep.build()
+        # the pointwise filters' split copies (which layers need one is known once the passes are emitted: the table is
+        # filled in below)
+        gp_max = 2 * sum(1 for l in L.values() if l.k == 1)
+        gtab = {True: (K.GemmPackEntry * max(gp_max, 1))(), False: (K.GemmPackEntry * max(gp_max, 1))()}
+        gidx = {True: P.add(PR.GEMM_SPLIT_PACK, 74, i=(0,), p=(gtab[True],)),
+                False: prep.add(PR.GEMM_SPLIT_PACK, 74, i=(0,), p=(gtab[False],))}
         self._packed_frozen = False
         P.mark("forward")
+        P.add(PR.FILL, 51, p=(self.amax,), f=(0.0,), l=(self.AMAX_WORDS,), work=4.0 * self.AMAX_WORDS)
         self._emit_forward(P)
         P.mark("backward")
         if self.train:
@@ -587,6 +653,13 @@ class NativeResNetFPN(object):
                   work=4.0 * 6 * self.params_flat.numel(),
                   keep=[s2 for (_, _, _, _, s2) in self.segments if s2 is not None])
         P.mark("end")
+        for train, entries, prog in ((True, self._gpack_train, P), (False, self._gpack_frozen, prep)):
+            for k, (a, lda, Kc, M, dst) in enumerate(entries):
+                gtab[train][k] = K.GemmPackEntry(a.data_ptr(), dst.data_ptr(), lda, Kc, M)
+            op = prog.ops[gidx[train]]
+            op.i[0] = len(entries)
+            op.work = 8.0 * sum(Kc * M for (_, _, Kc, M, _) in entries)
+        prep.build()
         self.wss = {k: torch.empty(max(self._ws_need, 16), dtype=torch.uint8, device=dev) for k in self._wstreams}
         self.ws = self.wss[self._wstreams[0]]
         for idx, slot, k in self._ws_ops:
@@ -730,6 +803,8 @@ class NativeResNetFPN(object):
             self._conv3(P, [(d6f, dc5, None, l6.pd, None)], l6.cin, D, 0, f24=l6.f24)
         # output convs: filter gradients and the three data gradients in one launch
         dt5, dt4, dt3 = self._like(t5), self._like(t4), self._like(t3)
+        if L["out.0"].f24 == 3:
+            self._measure(P, [d5, d4, d3], D)          # one pass for the three filter gradients and the data gradient
         for t, d, name in ((t5, d5, "out.0"), (t4, d4, "out.1"), (t3, d3, "out.2")):
             self._wgrad3(P, t, d, L[name])
         self._conv3(P, [(d, dt, None, L[name].pd, None)

@@ -755,13 +755,21 @@ size_t ssad_conv3x3_wgrad_split_workspace_bytes(const ssad_conv_level* levels_ho
 
 int ssad_conv3x3_wgrad_split(const ssad_conv_level* levels_host, int n_levels, float* dW, float* db, int Cout, int Cin,
                              int accumulate, void* workspace, size_t workspace_bytes, ssad_stream_t stream) {
-  if (!levels_host || !dW) return SSAD_E_BADARG;
+  return ssad_conv3x3_wgrad_split_amax(levels_host, n_levels, dW, db, Cout, Cin, accumulate, workspace, workspace_bytes,
+                                       nullptr, nullptr, stream);
+}
+
+int ssad_conv3x3_wgrad_split_amax(const ssad_conv_level* levels_host, int n_levels, float* dW, float* db, int Cout,
+                                  int Cin, int accumulate, void* workspace, size_t workspace_bytes,
+                                  const unsigned* x_amax, const unsigned* dy_amax, ssad_stream_t stream) {
+  if (!levels_host || !dW || (x_amax == nullptr) != (dy_amax == nullptr)) return SSAD_E_BADARG;
   const size_t slab = ssad_split_wgrad_workspace_bytes(levels_host, n_levels, Cout, Cin);
   if (!slab) return SSAD_E_BADARG;
   const size_t slab_bytes = (slab + 255) & ~(size_t)255;
   if (!workspace || workspace_bytes < slab_bytes + sizeof(double) * (size_t)Cout * kBiasParts) return SSAD_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const int rc = ssad_split_wgrad_launch(levels_host, n_levels, dW, Cout, Cin, accumulate, workspace, slab_bytes, s);
+  const int rc = ssad_split_wgrad_launch(levels_host, n_levels, dW, Cout, Cin, accumulate, workspace, slab_bytes,
+                                         x_amax, dy_amax, s);
   if (rc) return rc;
   if (db) launch_bias_grad(levels_host, n_levels, Cout, db, accumulate, (double*)((char*)workspace + slab_bytes), s);
   return (int)hipGetLastError();

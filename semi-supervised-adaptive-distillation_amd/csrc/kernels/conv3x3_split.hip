@@ -658,4 +658,28 @@ int ssad_conv3x3_forward_split(const ssad_conv_level* lv, int n_levels, const fl
   return (int)hipGetLastError();
 }
 
+/* |max| of the tensors of a level table into caller-owned words (word k = problem k; the caller zeroes them -- one
+ * fill per step for a whole program's table).  field 0: lv[k].x, 1: lv[k].aux; `channels` = their channel count. */
+int ssad_split_absmax_levels(const ssad_conv_level* lv, int n, int channels, int field, unsigned* words,
+                             ssad_stream_t stream_) {
+  if (!lv || !words || n < 1 || n > kMaxLv || channels <= 0) return SSAD_E_BADARG;
+  AmaxTable at;
+  int blocks = 0;
+  for (int l = 0; l < kMaxLv; ++l) {
+    at.x[l] = nullptr; at.n[l] = 0; at.block_start[l] = blocks;
+    if (l >= n) continue;
+    const long long cnt = (long long)lv[l].N * lv[l].H * lv[l].W * channels;
+    at.x[l] = field ? lv[l].aux : lv[l].x;
+    at.n[l] = cnt;
+    if (cnt && !at.x[l]) return SSAD_E_BADARG;
+    long long nb = (cnt / 4 + kThreads * 32 - 1) / (kThreads * 32);
+    blocks += (int)(nb < 1 ? 1 : nb > 512 ? 512 : nb);
+  }
+  at.block_start[kMaxLv] = blocks;
+  at.count = n;
+  at.amax = words;
+  hipLaunchKernelGGL(split_absmax_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream_, at);
+  return (int)hipGetLastError();
+}
+
 }  // extern "C"

@@ -62,8 +62,18 @@ struct WArgs {
   int mtiles, ctiles, shares, per_share, total;
   int xcd_runs;                             // shares per XCD when the grid is laid out share-major per XCD, else 0
   float* slabs;
-  const unsigned* amax;                     // [0] = |max| of X over the levels, [1] = of dY
+  // |max| words: the largest of xa[0 .. na) is X's, of da[0 .. na) dY's (one word each when this call measured them,
+  // one per level when the caller handed over words measured elsewhere)
+  const unsigned* xa;
+  const unsigned* da;
+  int na;
 };
+
+__device__ __forceinline__ unsigned max_word(const unsigned* w, int n) {
+  unsigned m = w[0];
+  for (int i = 1; i < n; ++i) m = m > w[i] ? m : w[i];
+  return m;
+}
 
 // ---- |max| of X (word 0) and dY (word 1) over all levels ---------------------------------------------------------
 struct StatTable {
@@ -295,8 +305,8 @@ __global__ __launch_bounds__(kWG, 1) void wsplit_kernel(const WArgs a) {
   const int q_begin = share * a.per_share;
   const int q_end = q_begin + a.per_share < a.total ? q_begin + a.per_share : a.total;
 
-  const float sx = pow2f(15 - split_exponent(a.amax[0]));
-  const float sdy = pow2f(15 - split_exponent(a.amax[1]));
+  const float sx = pow2f(15 - split_exponent(max_word(a.xa, a.na)));
+  const float sdy = pow2f(15 - split_exponent(max_word(a.da, a.na)));
 
   float16v acc[3][3];
 #pragma unroll
@@ -441,12 +451,13 @@ __global__ __launch_bounds__(kWG, 1) void wsplit_kernel(const WArgs a) {
 
 // dW[m][c][tap] (+)= 2^(ex - 15) 2^(edy - 15) sum over shares (fixed order) of slab[share][tap][m][c]
 __global__ __launch_bounds__(256) void wsplit_reduce_kernel(const float* __restrict__ slabs, int shares, int Mp, int Cp,
-                                                            int M, int C, const unsigned* __restrict__ amax,
+                                                            int M, int C, const unsigned* __restrict__ xa,
+                                                            const unsigned* __restrict__ da, int na,
                                                             float* __restrict__ dW, int accumulate) {
   __shared__ float o[64 * 9];
   const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;           // 4 parts x 64 channels; part p sums taps p, p+4, p+8
   const int c0 = blockIdx.x * 64, m = blockIdx.y;
-  const float ux = pow2f(split_exponent(amax[0]) - 15), udy = pow2f(split_exponent(amax[1]) - 15);
+  const float ux = pow2f(split_exponent(max_word(xa, na)) - 15), udy = pow2f(split_exponent(max_word(da, na)) - 15);
   const long long tap_stride = (long long)Mp * Cp, share_stride = 9 * tap_stride;
   for (int tap = part; tap < 9; tap += 4) {
     const float* p = slabs + tap * tap_stride + (long long)m * Cp + c0 + cl;
@@ -512,7 +523,8 @@ size_t ssad_split_wgrad_workspace_bytes(const ssad_conv_level* lv, int n_levels,
 }
 
 int ssad_split_wgrad_launch(const ssad_conv_level* lv, int n_levels, float* dW, int Cout, int Cin, int accumulate,
-                            void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                            void* workspace, size_t workspace_bytes, const unsigned* x_amax, const unsigned* dy_amax,
+                            hipStream_t stream) {
   WArgs a;
   const int rc = plan(lv, n_levels, Cout, Cin, &a);
   if (rc) return rc;
@@ -523,8 +535,11 @@ int ssad_split_wgrad_launch(const ssad_conv_level* lv, int n_levels, float* dW, 
     return (int)hipGetLastError();
   }
   unsigned* amax = (unsigned*)workspace;
-  a.amax = amax;
   a.slabs = (float*)((char*)workspace + kHeader);
+  if (x_amax && dy_amax) {                  // measured by the caller: word l = level l (levels without pixels hold 0)
+    a.xa = x_amax; a.da = dy_amax; a.na = n_levels;
+  } else {
+  a.xa = amax; a.da = amax + 1; a.na = 1;
   (void)hipMemsetAsync(amax, 0, 8, stream);
   {
     StatTable st{};
@@ -546,6 +561,7 @@ int ssad_split_wgrad_launch(const ssad_conv_level* lv, int n_levels, float* dW, 
     st.amax = amax;
     hipLaunchKernelGGL(wsplit_absmax_kernel, dim3(blocks), dim3(kThreads), 0, stream, st);
   }
+  }
   static std::once_flag lds_once;           // > 64 KiB of dynamic LDS needs the opt-in, once per process
   std::call_once(lds_once, [&] {
     (void)hipFuncSetAttribute((const void*)wsplit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -553,6 +569,6 @@ int ssad_split_wgrad_launch(const ssad_conv_level* lv, int n_levels, float* dW, 
   const int tiles = a.mtiles * a.ctiles;
   hipLaunchKernelGGL(wsplit_kernel, dim3(tiles * a.shares), dim3(kWG), LDS_BYTES, stream, a);
   hipLaunchKernelGGL(wsplit_reduce_kernel, dim3((Cin + 63) / 64, Cout), dim3(256), 0, stream, (const float*)a.slabs,
-                     a.shares, a.mtiles * CO_T, a.ctiles * CI_T, Cout, Cin, (const unsigned*)amax, dW, accumulate);
+                     a.shares, a.mtiles * CO_T, a.ctiles * CI_T, Cout, Cin, a.xa, a.da, a.na, dW, accumulate);
   return (int)hipGetLastError();
 }

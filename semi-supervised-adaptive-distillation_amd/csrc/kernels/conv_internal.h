@@ -19,7 +19,8 @@ int ssad_wino_wgrad_launch(const ssad_conv_level* lv, int n_levels, float* dW, i
 // Split-operand filter-gradient engine (conv3x3_wgrad_split.hip): |max| pass + main kernel + slab reduction on `stream`.
 size_t ssad_split_wgrad_workspace_bytes(const ssad_conv_level* lv, int n_levels, int Cout, int Cin);
 int ssad_split_wgrad_launch(const ssad_conv_level* lv, int n_levels, float* dW, int Cout, int Cin, int accumulate,
-                            void* workspace, size_t workspace_bytes, hipStream_t stream);
+                            void* workspace, size_t workspace_bytes, const unsigned* x_amax, const unsigned* dy_amax,
+                            hipStream_t stream);
 
 // The ResNet stem (7x7 / stride 2 / pad 3, 3 -> 64 channels) from an LDS-staged raw patch (stem.hip); taken by
 // ssad_conv_implicit_gemm for exactly that geometry when no epilogue term is asked for.

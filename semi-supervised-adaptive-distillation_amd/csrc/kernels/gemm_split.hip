@@ -48,6 +48,55 @@ __global__ __launch_bounds__(kThreads) void gsplit_pack_a_kernel(const float* __
   }
 }
 
+// The same for a whole table of filters in three launches (a program packs every filter of a network once per step --
+// trained -- or once -- frozen -- instead of inside every call): zero the headers, |max| (64 workgroups per filter,
+// one atomic each), split.
+struct GPackTable {
+  ssad_gemm_pack_entry e[SSAD_MAX_PACK_ENTRIES];
+  int count;
+};
+__global__ __launch_bounds__(kThreads) void gsplit_zero_kernel(const GPackTable t) {
+  for (int i = (int)threadIdx.x; i < t.count * HDR; i += kThreads) reinterpret_cast<unsigned*>(t.e[i / HDR].dst)[i % HDR] = 0u;
+}
+__global__ __launch_bounds__(kThreads) void gsplit_amax_kernel(const GPackTable t) {
+  const ssad_gemm_pack_entry& E = t.e[blockIdx.y];
+  unsigned m = 0;
+  for (int k = (int)blockIdx.x; k < E.K; k += (int)gridDim.x)
+    for (int j = (int)threadIdx.x; j < E.M; j += kThreads) {
+      const unsigned a = __float_as_uint(E.a[(long long)k * E.lda + j]) & 0x7fffffffu;
+      m = m > a ? m : a;
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned other = (unsigned)__shfl_xor((int)m, o, 64);
+    m = m > other ? m : other;
+  }
+  __shared__ unsigned red[kThreads / 64];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kThreads / 64; ++w) m = m > red[w] ? m : red[w];
+    if (m) atomicMax(reinterpret_cast<unsigned*>(E.dst), m);
+  }
+}
+__global__ __launch_bounds__(kThreads) void gsplit_pack_multi_kernel(const GPackTable t) {
+  const ssad_gemm_pack_entry& E = t.e[blockIdx.y];
+  const int KB = (E.K + 7) >> 3;
+  const long long slots = (long long)KB * E.M;
+  const float s = pow2f(15 - split_exponent(reinterpret_cast<const unsigned*>(E.dst)[0]));
+  uint4* out = reinterpret_cast<uint4*>(E.dst + HDR);
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < slots; i += (long long)gridDim.x * kThreads) {
+    const int m = (int)(i % E.M), kb = (int)(i / E.M);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = kb * 8 + j < E.K ? E.a[(long long)(kb * 8 + j) * E.lda + m] : 0.0f;
+    half8 hi, lo;
+    split8(v, s, hi, lo);
+    out[i] = __builtin_bit_cast(uint4, hi);
+    out[slots + i] = __builtin_bit_cast(uint4, lo);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Forward / data gradient.  No packed copy of x exists: 8 waves (two per SIMD, so one wave's fetch, split and waits run
 // under the other's MFMAs -- conv3x3_wgrad_split.hip), one 256-channel x 128-pixel item per
@@ -261,7 +310,8 @@ struct WPArgs {
   const float* x;
   const float* dy;
   float* slabs;
-  const unsigned* amax;  // [0] = x, [1] = dy
+  const unsigned* xa;    // |max| word of x
+  const unsigned* da;    // |max| word of dy
   int N, C, P, M;
   int mtiles, ctiles, shares, per_share, total, cpi;     // cpi = chunks per image
   int xcd_runs;
@@ -291,8 +341,8 @@ __global__ __launch_bounds__(FWG, 1) void wpoint_split_kernel(const WPArgs q) {
 
   const __amdgpu_buffer_rsrc_t xrs = uniform_rsrc(q.x, (unsigned)((long long)q.N * q.C * P * 4));
   const __amdgpu_buffer_rsrc_t drs = uniform_rsrc(q.dy, (unsigned)((long long)q.N * q.M * P * 4));
-  const float sx = pow2f(15 - split_exponent(q.amax[0]));
-  const float sd = pow2f(15 - split_exponent(q.amax[1]));
+  const float sx = pow2f(15 - split_exponent(q.xa[0]));
+  const float sd = pow2f(15 - split_exponent(q.da[0]));
 
   // a thread's fetch per chunk: pixel group tid & 3, channels (tid >> 2) and (tid >> 2) + 128 of dy and of x
   float dv[2][8], xv[2][8];
@@ -400,7 +450,8 @@ __global__ __launch_bounds__(FWG, 1) void wpoint_split_kernel(const WPArgs q) {
 }
 
 __global__ __launch_bounds__(256) void wpoint_reduce_kernel(const float* __restrict__ slabs, int shares, int Mp, int Cp,
-                                                            int M, int C, const unsigned* __restrict__ amax,
+                                                            int M, int C, const unsigned* __restrict__ xa,
+                                                            const unsigned* __restrict__ da,
                                                             float* __restrict__ dw, int accumulate) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= (long long)M * C) return;
@@ -409,7 +460,7 @@ __global__ __launch_bounds__(256) void wpoint_reduce_kernel(const float* __restr
   const long long stride = (long long)Mp * Cp;
   float s = 0.0f;
   for (int sh = 0; sh < shares; ++sh) s += p[sh * stride];
-  s = (s * pow2f(split_exponent(amax[0]) - 15)) * pow2f(split_exponent(amax[1]) - 15);
+  s = (s * pow2f(split_exponent(xa[0]) - 15)) * pow2f(split_exponent(da[0]) - 15);
   dw[e] = accumulate ? dw[e] + s : s;
 }
 
@@ -457,7 +508,40 @@ size_t ssad_conv1x1_gemm_split_workspace_bytes(const ssad_gemm_conv* d) {
   return make_plan(d, &p) ? 0 : p.total;
 }
 
+size_t ssad_gemm_split_filter_floats(int K, int M) {
+  if (K <= 0 || M <= 0) return 0;
+  return (size_t)HDR + (size_t)((K + 7) >> 3) * M * 8;
+}
+
+int ssad_gemm_split_pack_filters(const ssad_gemm_pack_entry* entries_host, int n_entries, ssad_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!entries_host || n_entries < 0) return SSAD_E_BADARG;
+  for (int base = 0; base < n_entries; base += SSAD_MAX_PACK_ENTRIES) {
+    GPackTable t;
+    const int cnt = n_entries - base < SSAD_MAX_PACK_ENTRIES ? n_entries - base : SSAD_MAX_PACK_ENTRIES;
+    long long most = 0;
+    for (int i = 0; i < cnt; ++i) {
+      t.e[i] = entries_host[base + i];
+      if (!t.e[i].a || !t.e[i].dst || t.e[i].K <= 0 || t.e[i].M <= 0 || t.e[i].lda < t.e[i].M) return SSAD_E_BADARG;
+      const long long slots = (long long)((t.e[i].K + 7) >> 3) * t.e[i].M;
+      if (slots > most) most = slots;
+    }
+    t.count = cnt;
+    hipLaunchKernelGGL(gsplit_zero_kernel, dim3(1), dim3(kThreads), 0, stream, t);
+    hipLaunchKernelGGL(gsplit_amax_kernel, dim3(64u, (unsigned)cnt), dim3(kThreads), 0, stream, t);
+    long long bx = (most + kThreads - 1) / kThreads;
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(gsplit_pack_multi_kernel, dim3((unsigned)bx, (unsigned)cnt), dim3(kThreads), 0, stream, t);
+  }
+  return (int)hipGetLastError();
+}
+
 int ssad_conv1x1_gemm_split(const ssad_gemm_conv* d, void* workspace, size_t workspace_bytes, ssad_stream_t stream_) {
+  return ssad_conv1x1_gemm_split_amax(d, nullptr, nullptr, workspace, workspace_bytes, stream_);
+}
+
+int ssad_conv1x1_gemm_split_amax(const ssad_gemm_conv* d, const float* packed_a, const unsigned* x_amax, void* workspace,
+                                 size_t workspace_bytes, ssad_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   GPlan p;
   const int rc = make_plan(d, &p);
@@ -483,18 +567,24 @@ int ssad_conv1x1_gemm_split(const ssad_gemm_conv* d, void* workspace, size_t wor
     blocks += (int)(nb < 1 ? 1 : nb > 512 ? 512 : nb);
   }
   for (int l = 2; l <= kMaxLv; ++l) at.block_start[l] = blocks;
-  (void)hipMemsetAsync(amax, 0, 256, stream);
-  hipLaunchKernelGGL(split_absmax_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, at);
-  // a -> planes
-  {
-    long long bx = ((long long)KB * d->M + kThreads - 1) / kThreads;
-    if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(gsplit_pack_a_kernel, dim3((unsigned)bx), dim3(kThreads), 0, stream, d->a, d->lda, d->K, d->M,
-                       (const unsigned*)(amax + 1), apk);
+  // what the caller did not hand over is measured here: x's |max| (word 0), the filter's (word 1) + its split
+  if (x_amax && packed_a) {
+    // nothing to do
+  } else {
+    if (x_amax) { at.n[0] = 0; }            // (entry 0 keeps one empty block)
+    if (packed_a) { at.n[1] = 0; }
+    (void)hipMemsetAsync(amax, 0, 256, stream);
+    hipLaunchKernelGGL(split_absmax_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, at);
+    if (!packed_a) {
+      long long bx = ((long long)KB * d->M + kThreads - 1) / kThreads;
+      if (bx > 1024) bx = 1024;
+      hipLaunchKernelGGL(gsplit_pack_a_kernel, dim3((unsigned)bx), dim3(kThreads), 0, stream, d->a, d->lda, d->K, d->M,
+                         (const unsigned*)(amax + 1), apk);
+    }
   }
   FArgs f;
-  f.x = d->x; f.ap = apk; f.y = d->y; f.bias = d->bias; f.residual = d->residual; f.mask = d->mask;
-  f.amax = amax;
+  f.x = d->x; f.ap = packed_a ? packed_a : apk; f.y = d->y; f.bias = d->bias; f.residual = d->residual; f.mask = d->mask;
+  f.amax = x_amax ? x_amax : amax;
   f.N = d->N; f.K = d->K; f.P = d->P; f.M = d->M;
   f.relu = (d->flags & SSAD_GEMM_RELU) ? 1 : 0;
   f.accumulate = (d->flags & SSAD_GEMM_ACCUMULATE) ? 1 : 0;
@@ -511,6 +601,21 @@ int ssad_conv1x1_gemm_split(const ssad_gemm_conv* d, void* workspace, size_t wor
   return (int)hipGetLastError();
 }
 
+/* |max| of one tensor into a caller-owned word (the caller zeroes it) */
+int ssad_split_absmax(const float* x, long long n, unsigned* word, ssad_stream_t stream_) {
+  if (!x || !word || n <= 0) return SSAD_E_BADARG;
+  AmaxTable at;
+  for (int l = 0; l < kMaxLv; ++l) { at.x[l] = nullptr; at.n[l] = 0; at.block_start[l] = 0; }
+  at.count = 1;
+  at.amax = word;
+  at.x[0] = x; at.n[0] = n;
+  long long nb = (n / 4 + kThreads * 32 - 1) / (kThreads * 32);
+  const int blocks = (int)(nb < 1 ? 1 : nb > 512 ? 512 : nb);
+  for (int l = 1; l <= kMaxLv; ++l) at.block_start[l] = blocks;
+  hipLaunchKernelGGL(split_absmax_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream_, at);
+  return (int)hipGetLastError();
+}
+
 size_t ssad_conv1x1_wgrad_split_workspace_bytes(int N, int C, int P, int M) {
   WPArgs a;
   if (wpoint_plan(N, C, P, M, &a)) return 0;
@@ -519,7 +624,15 @@ size_t ssad_conv1x1_wgrad_split_workspace_bytes(int N, int C, int P, int M) {
 
 int ssad_conv1x1_wgrad_split(const float* x, const float* dy, int N, int C, int P, int M, float* dw, int accumulate,
                              void* workspace, size_t workspace_bytes, ssad_stream_t stream_) {
+  return ssad_conv1x1_wgrad_split_amax(x, dy, N, C, P, M, dw, accumulate, workspace, workspace_bytes, nullptr, nullptr,
+                                       stream_);
+}
+
+int ssad_conv1x1_wgrad_split_amax(const float* x, const float* dy, int N, int C, int P, int M, float* dw, int accumulate,
+                                  void* workspace, size_t workspace_bytes, const unsigned* x_amax,
+                                  const unsigned* dy_amax, ssad_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if ((x_amax == nullptr) != (dy_amax == nullptr)) return SSAD_E_BADARG;
   WPArgs a;
   const int rc = wpoint_plan(N, C, P, M, &a);
   if (rc) return rc;
@@ -527,8 +640,11 @@ int ssad_conv1x1_wgrad_split(const float* x, const float* dy, int N, int C, int 
   const size_t need = 256 + sizeof(float) * (size_t)a.shares * a.mtiles * WT * a.ctiles * WT;
   if (!workspace || workspace_bytes < need) return SSAD_E_WORKSPACE;
   unsigned* amax = (unsigned*)workspace;
-  a.x = x; a.dy = dy; a.amax = amax;
+  a.x = x; a.dy = dy;
+  a.xa = x_amax ? x_amax : amax;
+  a.da = dy_amax ? dy_amax : amax + 1;
   a.slabs = (float*)((char*)workspace + 256);
+  if (!x_amax) {
   AmaxTable at;
   for (int l = 0; l < kMaxLv; ++l) { at.x[l] = nullptr; at.n[l] = 0; at.block_start[l] = 0; }
   at.count = 2;
@@ -544,6 +660,7 @@ int ssad_conv1x1_wgrad_split(const float* x, const float* dy, int N, int C, int 
   for (int l = 2; l <= kMaxLv; ++l) at.block_start[l] = blocks;
   (void)hipMemsetAsync(amax, 0, 256, stream);
   hipLaunchKernelGGL(split_absmax_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, at);
+  }
   static std::once_flag lds_once;
   std::call_once(lds_once, [&] {
     (void)hipFuncSetAttribute((const void*)wpoint_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
@@ -551,8 +668,7 @@ int ssad_conv1x1_wgrad_split(const float* x, const float* dy, int N, int C, int 
   hipLaunchKernelGGL(wpoint_split_kernel, dim3((unsigned)(a.mtiles * a.ctiles * a.shares)), dim3(FWG), W_LDS, stream, a);
   const long long n = (long long)M * C;
   hipLaunchKernelGGL(wpoint_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                     (const float*)a.slabs, a.shares, a.mtiles * WT, a.ctiles * WT, M, C, (const unsigned*)amax, dw,
-                     accumulate);
+                     (const float*)a.slabs, a.shares, a.mtiles * WT, a.ctiles * WT, M, C, a.xa, a.da, dw, accumulate);
   return (int)hipGetLastError();
 }
 

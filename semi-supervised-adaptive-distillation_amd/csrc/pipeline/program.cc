@@ -104,8 +104,9 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
           (const ssad_conv_level*)p[0], i[0], (const float*)p[1], (const float*)p[2], i[1], i[2], i[3], s);
     case SSAD_OP_CONV3X3_WGRAD:
       if (i[4] == 1)
-        return ssad_conv3x3_wgrad_split((const ssad_conv_level*)p[0], i[0], (float*)p[1], (float*)p[2], i[1], i[2],
-                                        i[3], (void*)p[3], (size_t)o.l[0], s);
+        return ssad_conv3x3_wgrad_split_amax((const ssad_conv_level*)p[0], i[0], (float*)p[1], (float*)p[2], i[1], i[2],
+                                             i[3], (void*)p[3], (size_t)o.l[0], (const unsigned*)p[4],
+                                             (const unsigned*)p[5], s);
       return ssad_conv3x3_wgrad((const ssad_conv_level*)p[0], i[0], (float*)p[1], (float*)p[2], i[1], i[2],
                                 i[3], (void*)p[3], (size_t)o.l[0], s);
     case SSAD_OP_POW_SUM:
@@ -179,11 +180,19 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
     case SSAD_OP_GEMM_CONV:
       return ssad_conv1x1_gemm((const ssad_gemm_conv*)p[0], s);
     case SSAD_OP_GEMM_CONV_SPLIT:
-      return ssad_conv1x1_gemm_split((const ssad_gemm_conv*)p[0], (void*)p[1], (size_t)o.l[0], s);
+      return ssad_conv1x1_gemm_split_amax((const ssad_gemm_conv*)p[0], (const float*)p[2], (const unsigned*)p[3],
+                                          (void*)p[1], (size_t)o.l[0], s);
+    case SSAD_OP_SPLIT_ABSMAX_LEVELS:
+      return ssad_split_absmax_levels((const ssad_conv_level*)p[0], i[0], i[1], i[2], (unsigned*)p[1], s);
+    case SSAD_OP_SPLIT_ABSMAX:
+      return ssad_split_absmax((const float*)p[0], (long long)o.l[0], (unsigned*)p[1], s);
+    case SSAD_OP_GEMM_SPLIT_PACK:
+      return ssad_gemm_split_pack_filters((const ssad_gemm_pack_entry*)p[0], i[0], s);
     case SSAD_OP_CONV1X1_WGRAD:
       if (i[5] == 1)
-        return ssad_conv1x1_wgrad_split((const float*)p[0], (const float*)p[1], i[0], i[1], i[2], i[3], (float*)p[2],
-                                        i[4], (void*)p[3], (size_t)o.l[0], s);
+        return ssad_conv1x1_wgrad_split_amax((const float*)p[0], (const float*)p[1], i[0], i[1], i[2], i[3],
+                                             (float*)p[2], i[4], (void*)p[3], (size_t)o.l[0], (const unsigned*)p[4],
+                                             (const unsigned*)p[5], s);
       return ssad_conv1x1_wgrad((const float*)p[0], (const float*)p[1], i[0], i[1], i[2], i[3], (float*)p[2],
                                 i[4], (void*)p[3], (size_t)o.l[0], s);
     case SSAD_OP_TRANSPOSE_FILTER:

@@ -88,6 +88,10 @@ class ConvLevel(C.Structure):
                 ("packed", C.c_void_p), ("bias", C.c_void_p)]
 
 
+class GemmPackEntry(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("dst", C.c_void_p), ("lda", C.c_int), ("K", C.c_int), ("M", C.c_int)]
+
+
 class F16WgradLevel(C.Structure):
     _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int)]
 
@@ -207,6 +211,14 @@ def lib():
     L.ssad_conv1x1_wgrad_workspace_bytes.restype = sz
     L.ssad_conv1x1_wgrad_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.ssad_conv1x1_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]
+    L.ssad_gemm_split_filter_floats.restype = sz
+    L.ssad_gemm_split_filter_floats.argtypes = [i32, i32]
+    L.ssad_gemm_split_pack_filters.argtypes = [C.POINTER(GemmPackEntry), i32, vp]
+    L.ssad_conv1x1_gemm_split_amax.argtypes = [vp, vp, vp, vp, sz, vp]
+    L.ssad_split_absmax.argtypes = [vp, C.c_longlong, vp, vp]
+    L.ssad_split_absmax_levels.argtypes = [C.POINTER(ConvLevel), i32, i32, i32, vp, vp]
+    L.ssad_conv3x3_wgrad_split_amax.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp, sz, vp, vp, vp]
+    L.ssad_conv1x1_wgrad_split_amax.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp, vp, vp]
     L.ssad_conv1x1_wgrad_split_workspace_bytes.restype = sz
     L.ssad_conv1x1_wgrad_split_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.ssad_conv1x1_wgrad_split.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]

@@ -28,6 +28,7 @@ GROUPED_CONV3X3, GROUPED_PACK, CONV_IMPLICIT = 64, 65, 66
 PW_F16, PW_F16_PACK, PW_F16_WGRAD, F16_EW, STEM_POOL_F16, GROUPED_F16, GROUPED_F16_PACK = 67, 68, 69, 70, 71, 72, 73
 CONV_IMPLICIT_WS, CONV_KXK_WGRAD, CONV_KXK_DGRAD, TRANSPOSE_FILTERS, F16_PACK_FILTERS = 74, 75, 76, 77, 78
 GEMM_CONV_SPLIT = 79
+SPLIT_ABSMAX_LEVELS, SPLIT_ABSMAX, GEMM_SPLIT_PACK = 80, 81, 82
 
 # timing classes: one per kernel family.  bound "mfma": work = direct-form FLOPs
 # (2*9*Cout*Cin per output pixel; the Winograd engine executes 1/2.25 of them);
@@ -114,6 +115,10 @@ KLASS = {
                   "+ filter split; SSAD_SPLIT_CONV & 128)", bound="mfma16", wino=True, exec_div=1.0 / 3.0),
     72: dict(name="backbone pointwise conv filter gradient, C and M >= 256, split-operand engine (wpoint_split_kernel + "
                   "|max| + reduce; SSAD_SPLIT_CONV & 256)", bound="mfma16", wino=True, exec_div=1.0 / 3.0),
+    73: dict(name="|max| passes of the split-operand engines (split_absmax_kernel: one per tensor and step, shared by the "
+                  "forward, data-gradient and filter-gradient calls that read it)", bound="hbm"),
+    74: dict(name="pointwise filter split for the split-operand GEMM (gsplit_*_kernel, all filters in 3 launches)",
+             bound="hbm"),
     64: dict(name="P6 / P7 3x3 stride-2 conv fwd / data gradient at their own size (implicit GEMM with split-K; "
                   "flattened-batch GEMM + col2im)", bound="mfma", wino=False),
     65: dict(name="P6 / P7 3x3 stride-2 filter gradient (im2col + gemm_conv_nt_kernel + reduce)", bound="mfma",
