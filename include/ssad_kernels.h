@@ -533,9 +533,12 @@ SSAD_API int ssad_conv1x1_gemm_split(const ssad_gemm_conv* desc_host, void* work
                                      ssad_stream_t stream);
 /* ... with what the caller already has handed over, either or both: packed_a = the filter split by
  * ssad_gemm_split_pack_filters (desc->a is then not read), x_amax = x's |max| word (device; ssad_split_absmax or an
- * earlier call's).  With both the call is the GEMM kernel alone. */
+ * earlier call's).  With both the call is the GEMM kernel alone.  y_amax_out (device word the caller has zeroed, or
+ * NULL): the kernel folds the |max| of what it stores to y into it (atomicMax, one per workgroup) -- the next
+ * layer's x_amax. */
 SSAD_API int ssad_conv1x1_gemm_split_amax(const ssad_gemm_conv* desc_host, const float* packed_a, const unsigned* x_amax,
-                                          void* workspace, size_t workspace_bytes, ssad_stream_t stream);
+                                          unsigned* y_amax_out, void* workspace, size_t workspace_bytes,
+                                          ssad_stream_t stream);
 /* Split a table of filters a[K][lda] (as ssad_gemm_conv.a) into the engine's operand order in three launches: dst
  * holds ssad_gemm_split_filter_floats(K, M) floats (a header with the filter's |max| + the hi and lo planes). */
 typedef struct ssad_gemm_pack_entry {

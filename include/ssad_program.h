@@ -183,7 +183,7 @@ enum ssad_opcode {
   /* p0 = const ssad_f16_pack_entry* (host table, kept alive by the caller), i0 = entries */
   SSAD_OP_F16_PACK_FILTERS = 78,
   /* ssad_conv1x1_gemm_split_amax(p0 = const ssad_gemm_conv* (host), p1 = workspace, l0 = workspace bytes, p2 = packed
-   * filter or NULL, p3 = x's |max| word or NULL) */
+   * filter or NULL, p3 = x's |max| word or NULL, p4 = word y's |max| is folded into, or NULL) */
   SSAD_OP_GEMM_CONV_SPLIT = 79,
   /* ssad_split_absmax_levels(p0 = levels_host, i0 = n, i1 = channels, i2 = field, p1 = words) */
   SSAD_OP_SPLIT_ABSMAX_LEVELS = 80,

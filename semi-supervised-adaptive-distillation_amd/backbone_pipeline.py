@@ -330,7 +330,20 @@ class NativeResNetFPN(object):
                   work=4.0 * sum(t.numel() for t in tensors), keep=list(tensors))
         self._amax_groups[key] = base
         for k, t in enumerate(tensors):
-            self._amax_groups.setdefault((t.data_ptr(),), base + k)
+            self._amax_groups[(t.data_ptr(),)] = base + k          # (the freshest measurement serves later readers)
+        return base
+
+    def _produces(self, *tensors):
+        """Slots for tensors whose PRODUCER (a split-engine kernel's epilogue) folds their |max| in: nobody has to
+        measure them.  Forward pass only: every activation is written exactly once there; in the backward pass gradient
+        buffers are also summed in place by element-wise kernels, which would leave a folded word stale."""
+        base = self._amax_next
+        self._amax_next += len(tensors)
+        if self._amax_next > self.AMAX_WORDS:
+            raise K.KernelError("|max| table full")
+        self._amax_groups[tuple(t.data_ptr() for t in tensors)] = base
+        for k, t in enumerate(tensors):
+            self._amax_groups[(t.data_ptr(),)] = base + k
         return base
 
     def _amax_addr(self, slot):
@@ -345,7 +358,8 @@ class NativeResNetFPN(object):
             w.view(torch.float32)[: w.numel() // 4].fill_(value)
         self._packed_frozen = False
 
-    def _gemm(self, P, a, lda, x, y, Kc, M, bias=None, res=None, mask=None, relu=False, acc=False, klass=50):
+    def _gemm(self, P, a, lda, x, y, Kc, M, bias=None, res=None, mask=None, relu=False, acc=False, klass=50, final=True):
+        """final=False: y is modified in place afterwards (the top-down sum of the FPN): its |max| is not folded in."""
         d = K.gemm_conv_desc(a, lda, x, y, Kc, M, bias, res, mask, relu, acc)
         px = x.numel() // Kc
         # SSAD_SPLIT_CONV bit 128: the compute-bound pointwise layers (K, M >= 256: res4, res5, the laterals) on the
@@ -359,7 +373,8 @@ class NativeResNetFPN(object):
             if nb:
                 self._split_need = max(self._split_need, nb)
                 xa = self._amax_addr(self._measure(P, [x], Kc))
-                idx = P.add(PR.GEMM_CONV_SPLIT, 71, p=(d, None, self._packed_a(a, lda, Kc, M), xa), l=(nb,),
+                ya = self._amax_addr(self._produces(y)) if self._fwd and final and not acc else None
+                idx = P.add(PR.GEMM_CONV_SPLIT, 71, p=(d, None, self._packed_a(a, lda, Kc, M), xa, ya), l=(nb,),
                             work=2.0 * px * Kc * M, keep=[t for t in (a, x, y, bias, res, mask) if t is not None])
                 self._gemm_split_ops.append(idx)
                 return
@@ -391,8 +406,9 @@ class NativeResNetFPN(object):
             self._split_need = max(getattr(self, "_split_need", 0), nb)
             px = sum(p[0].shape[0] * p[0].shape[2] * p[0].shape[3] for p in probs)
             xa = self._amax_addr(self._measure(P, [p[0] for p in probs], Cin))
+            ya = self._amax_addr(self._produces(*[p[1] for p in probs])) if self._fwd else None
             idx = P.add(PR.CONV3X3, 66 if self.train else 67, i=(len(probs), Cout, Cin, flags, 3), l=(nb,),
-                        p=(arr, None, None, None, xa, None), work=2.0 * 9 * Cout * Cin * px,
+                        p=(arr, None, None, None, xa, ya), work=2.0 * 9 * Cout * Cin * px,
                         keep=[t for p in probs for t in p if t is not None])
             self._split_ops.append(idx)
             return
@@ -639,7 +655,9 @@ class NativeResNetFPN(object):
         self._packed_frozen = False
         P.mark("forward")
         P.add(PR.FILL, 51, p=(self.amax,), f=(0.0,), l=(self.AMAX_WORDS,), work=4.0 * self.AMAX_WORDS)
+        self._fwd = True
         self._emit_forward(P)
+        self._fwd = False
         P.mark("backward")
         if self.train:
             self._emit_backward(P)
@@ -733,7 +751,7 @@ class NativeResNetFPN(object):
         t3 = self._t(N, D, c3.shape[2], c3.shape[3])
         for t, c, name in ((t5, c5, "lat.0"), (t4, c4, "lat.1"), (t3, c3, "lat.2")):
             l = L[name]
-            self._gemm(P, l.wt, l.wt.shape[1], c, t, l.cin, D, bias=l.b)
+            self._gemm(P, l.wt, l.wt.shape[1], c, t, l.cin, D, bias=l.b, final=t is t5)
             if t is not t5:
                 src = t5 if t is t4 else t4
                 self._ew(P, PR.UPSAMPLE, i=(N, D, src.shape[2], src.shape[3], 2), p=(src, t, t), nbytes=9.0 * t.numel())

@@ -119,6 +119,7 @@ struct FArgs {
   const float* residual;
   const float* mask;
   const unsigned* amax;  // [0] = x
+  unsigned* amax_out;    // or null: the |max| of y is folded into this word (atomicMax; the caller zeroes it)
   int N, K, P, M, relu, accumulate;
   int ptiles, mblocks, items;
 };
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(FWG, 1) void gemm_fly_kernel(const FArgs q) {
   const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(q.bias ? (const void*)q.bias : (const void*)q.y, q.bias ? (unsigned)M * 4u : 0u);
   const bool relu = q.relu, has_res = q.residual != nullptr, has_mask = q.mask != nullptr, accum = q.accumulate;
   const bool ragged = (M & 7) != 0;
+  unsigned ymax = 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int oc0 = oc_w + i * 32;
@@ -286,8 +288,25 @@ __global__ __launch_bounds__(FWG, 1) void gemm_fly_kernel(const FArgs q) {
           v += old[r];
           const unsigned vo = (!ragged || oc0 + 8 * g + 4 * h + e < M) ? pvo[tt] : kOob;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, vo, (oc0 + 8 * g + e) * P4, 0);
+          const unsigned av = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
+          if (vo != kOob) ymax = ymax > av ? ymax : av;
         }
       }
+    }
+  }
+  if (q.amax_out) {                                  // one atomic per workgroup
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned other = (unsigned)__shfl_xor((int)ymax, o, 64);
+      ymax = ymax > other ? ymax : other;
+    }
+    __syncthreads();                                 // (everybody is done with the LDS stages)
+    unsigned* red = reinterpret_cast<unsigned*>(flds);
+    if (lane == 0) red[wave] = ymax;
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < FWG / 64; ++w) ymax = ymax > red[w] ? ymax : red[w];
+      if (ymax) atomicMax(q.amax_out, ymax);
     }
   }
 }
@@ -537,11 +556,11 @@ int ssad_gemm_split_pack_filters(const ssad_gemm_pack_entry* entries_host, int n
 }
 
 int ssad_conv1x1_gemm_split(const ssad_gemm_conv* d, void* workspace, size_t workspace_bytes, ssad_stream_t stream_) {
-  return ssad_conv1x1_gemm_split_amax(d, nullptr, nullptr, workspace, workspace_bytes, stream_);
+  return ssad_conv1x1_gemm_split_amax(d, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream_);
 }
 
-int ssad_conv1x1_gemm_split_amax(const ssad_gemm_conv* d, const float* packed_a, const unsigned* x_amax, void* workspace,
-                                 size_t workspace_bytes, ssad_stream_t stream_) {
+int ssad_conv1x1_gemm_split_amax(const ssad_gemm_conv* d, const float* packed_a, const unsigned* x_amax,
+                                 unsigned* y_amax_out, void* workspace, size_t workspace_bytes, ssad_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   GPlan p;
   const int rc = make_plan(d, &p);
@@ -585,6 +604,7 @@ int ssad_conv1x1_gemm_split_amax(const ssad_gemm_conv* d, const float* packed_a,
   FArgs f;
   f.x = d->x; f.ap = packed_a ? packed_a : apk; f.y = d->y; f.bias = d->bias; f.residual = d->residual; f.mask = d->mask;
   f.amax = x_amax ? x_amax : amax;
+  f.amax_out = y_amax_out;
   f.N = d->N; f.K = d->K; f.P = d->P; f.M = d->M;
   f.relu = (d->flags & SSAD_GEMM_RELU) ? 1 : 0;
   f.accumulate = (d->flags & SSAD_GEMM_ACCUMULATE) ? 1 : 0;

@@ -181,7 +181,7 @@ int run_op(const ssad_op& o, ssad_stream_t s) {
       return ssad_conv1x1_gemm((const ssad_gemm_conv*)p[0], s);
     case SSAD_OP_GEMM_CONV_SPLIT:
       return ssad_conv1x1_gemm_split_amax((const ssad_gemm_conv*)p[0], (const float*)p[2], (const unsigned*)p[3],
-                                          (void*)p[1], (size_t)o.l[0], s);
+                                          (unsigned*)p[4], (void*)p[1], (size_t)o.l[0], s);
     case SSAD_OP_SPLIT_ABSMAX_LEVELS:
       return ssad_split_absmax_levels((const ssad_conv_level*)p[0], i[0], i[1], i[2], (unsigned*)p[1], s);
     case SSAD_OP_SPLIT_ABSMAX:

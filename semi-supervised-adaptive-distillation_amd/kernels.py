@@ -214,7 +214,7 @@ def lib():
     L.ssad_gemm_split_filter_floats.restype = sz
     L.ssad_gemm_split_filter_floats.argtypes = [i32, i32]
     L.ssad_gemm_split_pack_filters.argtypes = [C.POINTER(GemmPackEntry), i32, vp]
-    L.ssad_conv1x1_gemm_split_amax.argtypes = [vp, vp, vp, vp, sz, vp]
+    L.ssad_conv1x1_gemm_split_amax.argtypes = [vp, vp, vp, vp, vp, sz, vp]
     L.ssad_split_absmax.argtypes = [vp, C.c_longlong, vp, vp]
     L.ssad_split_absmax_levels.argtypes = [C.POINTER(ConvLevel), i32, i32, i32, vp, vp]
     L.ssad_conv3x3_wgrad_split_amax.argtypes = [C.POINTER(ConvLevel), i32, vp, vp, i32, i32, i32, vp, sz, vp, vp, vp]
@@ -792,7 +792,8 @@ def conv3x3_forward_multi(problems, Cout, *, relu=False, sigmoid=False, wino=Fal
     return ys
 
 
-def conv3x3_wgrad(xs, dys, Cout, *, want_db=True, accumulate=False, dW=None, db=None, split=False):
+def conv3x3_wgrad(xs, dys, Cout, *, want_db=True, accumulate=False, dW=None, db=None, split=False, x_amax=None,
+                  dy_amax=None):
     """dW[Cout,Cin,3,3] and db[Cout] summed over all levels and images.  split: the split-operand engine
     (ssad_conv3x3_wgrad_split) instead of the exact-fp32 ones."""
     L = lib()
@@ -808,6 +809,11 @@ def conv3x3_wgrad(xs, dys, Cout, *, want_db=True, accumulate=False, dW=None, db=
         dW = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device="cuda")
     if db is None and want_db:
         db = torch.empty(Cout, dtype=torch.float32, device="cuda")
+    if split and x_amax is not None:
+        _check(L.ssad_conv3x3_wgrad_split_amax(arr, len(xs), _ptr(dW), _ptr(db) if want_db else None, Cout, Cin,
+                                               int(accumulate), _ptr(ws), nb, _ptr(x_amax), _ptr(dy_amax), _stream()),
+               "conv3x3_wgrad_split_amax")
+        return dW, db
     _check(fn(arr, len(xs), _ptr(dW), _ptr(db) if want_db else None, Cout,
               Cin, int(accumulate), _ptr(ws), nb, _stream()),
            "conv3x3_wgrad_split" if split else "conv3x3_wgrad")
@@ -988,6 +994,47 @@ def _run_gemm(d, what, split):
     _check(L.ssad_conv1x1_gemm_split(C.byref(d), _ptr(ws), ws.numel(), _stream()), what + " (split)")
 
 
+def split_absmax(x, word=None):
+    """|max| of one tensor as a float bit pattern in a device word (ssad_split_absmax); word: a zeroed int32[1]."""
+    _f32c(x, "x")
+    if word is None:
+        word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _check(lib().ssad_split_absmax(_ptr(x), x.numel(), _ptr(word), _stream()), "split_absmax")
+    return word
+
+
+def split_absmax_levels(xs, words=None):
+    """|max| word per tensor of a list (one launch, ssad_split_absmax_levels)."""
+    if words is None:
+        words = torch.zeros(len(xs), dtype=torch.int32, device="cuda")
+    arr = _conv_levels(xs, None, None)
+    _check(lib().ssad_split_absmax_levels(arr, len(xs), xs[0].shape[1], 0, _ptr(words), _stream()), "split_absmax_levels")
+    return words
+
+
+def gemm_split_pack_filter(a, lda, Kc, M):
+    """The split copy of a pointwise filter operand a[Kc][lda] (ssad_gemm_split_pack_filters, one entry)."""
+    dst = torch.empty(lib().ssad_gemm_split_filter_floats(Kc, M), dtype=torch.float32, device="cuda")
+    tab = (GemmPackEntry * 1)(GemmPackEntry(a.data_ptr(), dst.data_ptr(), lda, Kc, M))
+    _check(lib().ssad_gemm_split_pack_filters(tab, 1, _stream()), "gemm_split_pack_filters")
+    return dst
+
+
+def conv1x1_forward_split_amax(x, wt, M, bias=None, residual=None, relu=False, packed_a=None, x_amax=None, y_amax=None):
+    """conv1x1_forward on the split-operand engine with the filter split / x's |max| word handed over and (y_amax: a
+    zeroed int32[1]) the |max| of the result folded into a word (ssad_conv1x1_gemm_split_amax)."""
+    _f32c(x, "x"); _f32c(wt, "wt")
+    N, Kc, H, W = x.shape
+    y = torch.empty((N, M, H, W), dtype=torch.float32, device="cuda")
+    d = gemm_conv_desc(wt, wt.shape[1], x, y, Kc, M, bias, residual, None, relu, False)
+    L = lib()
+    need = L.ssad_conv1x1_gemm_split_workspace_bytes(C.byref(d))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
+    _check(L.ssad_conv1x1_gemm_split_amax(C.byref(d), _ptr(packed_a), _ptr(x_amax), _ptr(y_amax), _ptr(ws), ws.numel(),
+                                          _stream()), "conv1x1_gemm_split_amax")
+    return y
+
+
 def conv1x1_forward(x, wt, M, bias=None, residual=None, relu=False, out=None, split=False):
     """act(conv1x1(x, W) + bias (+ residual)) with W^T from transpose_filter (x: N x K x H x W)."""
     _f32c(x, "x"); _f32c(wt, "wt")
@@ -1012,7 +1059,7 @@ def conv1x1_dgrad(dy, w, mask=None, accumulate_into=None, split=False):
     return dx
 
 
-def conv1x1_wgrad(x, dy, out=None, accumulate=False, split=False):
+def conv1x1_wgrad(x, dy, out=None, accumulate=False, split=False, x_amax=None, dy_amax=None):
     """dW [M][C] = sum_{n,p} dy[n][m][p] x[n][c][p].  split: the split-operand engine (ssad_conv1x1_wgrad_split)."""
     _f32c(x, "x"); _f32c(dy, "dy")
     N, Cc, H, W = x.shape
@@ -1025,6 +1072,10 @@ def conv1x1_wgrad(x, dy, out=None, accumulate=False, split=False):
     if split and not nb:
         raise KernelError("conv1x1_wgrad_split: unsupported geometry")
     ws = _workspace(nb, "wgrad1x1")
+    if split and x_amax is not None:
+        _check(L.ssad_conv1x1_wgrad_split_amax(_ptr(x), _ptr(dy), N, Cc, H * W, M, _ptr(dw), int(accumulate), _ptr(ws), nb,
+                                               _ptr(x_amax), _ptr(dy_amax), _stream()), "conv1x1_wgrad_split_amax")
+        return dw
     _check(fn(_ptr(x), _ptr(dy), N, Cc, H * W, M, _ptr(dw), int(accumulate), _ptr(ws), nb, _stream()),
            "conv1x1_wgrad_split" if split else "conv1x1_wgrad")
     return dw

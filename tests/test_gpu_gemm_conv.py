@@ -400,3 +400,49 @@ def test_split_pointwise_wgrad_full_size_vs_exact_engine(K):
     want = K.conv1x1_wgrad(X, dY).clone()
     got = K.conv1x1_wgrad(X, dY, split=True)
     close(got.cpu().numpy(), want.cpu().numpy(), CONV_RTOL, CONV_FLOOR, "split pointwise dW, full size")
+
+
+def test_split_engines_with_handed_over_max_words_match_the_self_measuring_calls(K):
+    """The |max| words measured once (ssad_split_absmax / _levels, or folded in by a producer's epilogue) and the filter
+    split by the table op give bit-identical results to the calls that measure and split for themselves."""
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    N, Cin, M, H, W = 2, 264, 300, 12, 20
+    X = torch.randn((N, Cin, H, W), device="cuda", generator=gen).clamp_(min=0) * 3.0
+    Wt = torch.randn((M, Cin, 1, 1), device="cuda", generator=gen) * 0.05
+    b = torch.randn(M, device="cuda", generator=gen)
+    wt = K.transpose_filter(Wt)
+    want = K.conv1x1_forward(X, wt, M, b, relu=True, split=True)
+    xw = K.split_absmax(X)
+    assert int(xw.item()) == int(X.abs().max().view(torch.int32).item())
+    pa = K.gemm_split_pack_filter(wt, wt.shape[1], Cin, M)
+    yw = torch.zeros(1, dtype=torch.int32, device="cuda")
+    got = K.conv1x1_forward_split_amax(X, wt, M, b, relu=True, packed_a=pa, x_amax=xw, y_amax=yw)
+    assert torch.equal(got, want)
+    assert int(yw.item()) == int(want.abs().max().view(torch.int32).item())
+    # only one of the two handed over
+    assert torch.equal(K.conv1x1_forward_split_amax(X, wt, M, b, relu=True, packed_a=pa), want)
+    assert torch.equal(K.conv1x1_forward_split_amax(X, wt, M, b, relu=True, x_amax=xw), want)
+    # pointwise filter gradient
+    dY = torch.randn((N, M, H, W), device="cuda", generator=gen) * 1e-3
+    dw = K.conv1x1_wgrad(X, dY, split=True).clone()
+    assert torch.equal(K.conv1x1_wgrad(X, dY, split=True, x_amax=xw, dy_amax=K.split_absmax(dY)), dw)
+    # 3x3: the producer's epilogue folds its output's |max| in (amax_out); the consumer takes the words (amax_in); the
+    # filter gradient takes one word per level
+    Cc = 256
+    shapes = [(10, 14), (5, 7)]
+    Xs = [torch.randn((N, Cc, h, w), device="cuda", generator=gen) for h, w in shapes]
+    W3 = torch.randn((Cc, Cc, 3, 3), device="cuda", generator=gen) * 0.02
+    pf = K.conv_split_pack_filter(W3, want_dgrad=False)
+    yw3 = torch.zeros(len(Xs), dtype=torch.int32, device="cuda")
+    Y1 = K.conv3x3_forward_split(Xs, pf, None, Cc, relu=True, amax_out=yw3)
+    assert [int(v) for v in yw3.tolist()] == [int(y.abs().max().view(torch.int32).item()) for y in Y1]
+    lw = K.split_absmax_levels(Y1)
+    assert torch.equal(lw, yw3)
+    Y2 = K.conv3x3_forward_split(Y1, pf, None, Cc)
+    Y2k = K.conv3x3_forward_split(Y1, pf, None, Cc, amax_in=yw3)
+    assert all(torch.equal(a, c) for a, c in zip(Y2, Y2k))
+    dYs = [torch.randn(y.shape, device="cuda", generator=gen) * 1e-2 for y in Y1]
+    dW, db = K.conv3x3_wgrad(Y1, dYs, Cc, split=True)
+    dW, db = dW.clone(), db.clone()
+    dWk, dbk = K.conv3x3_wgrad(Y1, dYs, Cc, split=True, x_amax=yw3, dy_amax=K.split_absmax_levels(dYs))
+    assert torch.equal(dWk, dW) and torch.equal(dbk, db)
