@@ -104,6 +104,9 @@ __global__ __launch_bounds__(kThreads) void gsplit_pack_multi_kernel(const GPack
 // coalesced dword loads (exactly one MFMA operand slot), splits them and writes hi / lo to LDS; the packed filter's
 // slots go global -> register -> LDS unchanged.  Wave tile 64 channels x 64 pixels: per 16-channel step 8 LDS reads
 // feed 12 MFMAs.
+#ifndef GFLY_ABLATE    // debug builds (results wrong): 1 no fetch in the loop, 2 no split / LDS write, 4 one product, 8 no MFMA
+#define GFLY_ABLATE 0
+#endif
 constexpr int FKC = 32;                             // channels per chunk (2 MFMA steps)
 constexpr int FWG = 512;
 constexpr int F_XP = (FKC / 8) * PT * 16;           // bytes of one x plane of a stage (8 KB)
@@ -208,13 +211,17 @@ __global__ __launch_bounds__(FWG, 1) void gemm_fly_kernel(const FArgs q) {
       bl[i] = *reinterpret_cast<const half8*>(px + F_XP);
     }
 #pragma unroll
-    for (int pr = 0; pr < 3; ++pr)                    // hi.hi, lo(a).hi, hi.lo(x): a block's products four MFMAs apart
+    for (int pr = 0; pr < ((GFLY_ABLATE & 8) ? 0 : (GFLY_ABLATE & 4) ? 1 : 3); ++pr)   // hi.hi, lo(a).hi, hi.lo(x)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
           acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 1 ? al[i] : ah[i], pr == 2 ? bl[tt] : bh[tt],
                                                               acc[i][tt], 0, 0, 0);
+    if (GFLY_ABLATE & 8) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { acc[i][0][0] += (float)ah[i][0] + (float)al[i][1]; acc[i][1][0] += (float)bh[i][0] + (float)bl[i][1]; }
+    }
   };
 
   // chunk c multiplies from stage c & 1 while chunk c + 1 (in the registers since the previous iteration) is split into
@@ -229,9 +236,9 @@ __global__ __launch_bounds__(FWG, 1) void gemm_fly_kernel(const FArgs q) {
     char* other = flds + ((c & 1) ^ 1) * F_STAGE;
     __builtin_amdgcn_sched_barrier(0);
     step(stage, 0);
-    put(other);
+    if (!(GFLY_ABLATE & 2)) put(other);
     __builtin_amdgcn_sched_barrier(0);
-    fetch(c + 2);
+    if (!(GFLY_ABLATE & 1)) fetch(c + 2);
     __builtin_amdgcn_sched_barrier(0);
     step(stage, 1);
     __syncthreads();
