@@ -213,10 +213,15 @@ class ConvGradientGroupOp final : public Operator<HIPContext> {
           const Problem& p = probs[mine[at + j]];
           lv[j] = ssad_conv_level{p.x->data<float>(), nullptr, p.b->data<float>(), p.N, p.H, p.W, nullptr, nullptr};
         }
-        const size_t wsb = ssad_conv3x3_wgrad_workspace_bytes(lv, n, p0.M, p0.C);
+        // hip_algo = "split": the >= 128-wide filter gradients on the split-operand engine too (conv3x3_wgrad_split.hip;
+        // same contract, same tolerance), like the native step's SSAD_SPLIT_CONV bit 32
+        const bool wsplit = algo_ == "split" && p0.M >= 128 && p0.C >= 64;
+        const size_t wsb = wsplit ? ssad_conv3x3_wgrad_split_workspace_bytes(lv, n, p0.M, p0.C)
+                                  : ssad_conv3x3_wgrad_workspace_bytes(lv, n, p0.M, p0.C);
         if ((size_t)workspace_.size() < wsb) workspace_.Resize((TIndex)wsb);
-        const int rc = ssad_conv3x3_wgrad(lv, n, dW->mutable_data<float>(), db, p0.M, p0.C, at > 0 ? 1 : 0,
-                                          workspace_.mutable_data<uint8_t>(), (size_t)workspace_.size(), s);
+        const int rc = (wsplit ? ssad_conv3x3_wgrad_split : ssad_conv3x3_wgrad)(
+            lv, n, dW->mutable_data<float>(), db, p0.M, p0.C, at > 0 ? 1 : 0, workspace_.mutable_data<uint8_t>(),
+            (size_t)workspace_.size(), s);
         CAFFE_ENFORCE_EQ(rc, 0, "ConvGradientGroup (filter) launch failed");
         ++g_conv_launch_calls;
       }

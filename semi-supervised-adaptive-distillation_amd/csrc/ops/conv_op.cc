@@ -421,10 +421,13 @@ bool ConvGradientOp<float, HIPContext>::RunOnDevice() {
 
   // filter (+ bias) gradient: overwrite, beta = 0 (conv_op_cudnn.cc:1037)
   ssad_conv_level wl{X.data<float>(), nullptr, dY.data<float>(), N, H, W, nullptr, nullptr};
-  const size_t wsb = ssad_conv3x3_wgrad_workspace_bytes(&wl, 1, M, C);
+  // hip_algo = "split": the >= 128-wide filter gradients on the split-operand engine (conv3x3_wgrad_split.hip)
+  const bool wsplit = algo_ == "split" && M >= 128 && C >= 64;
+  const size_t wsb = wsplit ? ssad_conv3x3_wgrad_split_workspace_bytes(&wl, 1, M, C)
+                            : ssad_conv3x3_wgrad_workspace_bytes(&wl, 1, M, C);
   workspace_.Resize((TIndex)wsb);
-  int rc = ssad_conv3x3_wgrad(&wl, 1, dfilter->mutable_data<float>(), db, M, C, 0,
-                              workspace_.mutable_data<uint8_t>(), wsb, s);
+  int rc = (wsplit ? ssad_conv3x3_wgrad_split : ssad_conv3x3_wgrad)(&wl, 1, dfilter->mutable_data<float>(), db, M, C, 0,
+                                                                     workspace_.mutable_data<uint8_t>(), wsb, s);
   CAFFE_ENFORCE_EQ(rc, 0, "ConvGradient (filter) launch failed");
   ++g_conv_launch_calls;
 
