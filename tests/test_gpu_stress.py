@@ -16,5 +16,5 @@ def test_kernels_give_the_same_bits_while_other_streams_load_the_chip():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_stress
     bad, cases = kernel_stress.run(iters=60, verbose=True)
-    assert cases >= 27            # (round 5: + five wino24_conv_kernel cases; round 6: + six split-engine cases)
+    assert cases >= 33            # (round 5: + five wino24_conv_kernel cases; round 6: + twelve split-engine cases)
     assert bad == 0

@@ -91,11 +91,12 @@ def _run(iters, verbose):
         return lambda: K.conv1x1_forward(x, wt, Cout, b, r, relu=True, out=out, split=True).reshape(-1)
 
 
-    def wgrad_case(Cin, Cout, shapes):
+    def wgrad_case(Cin, Cout, shapes, split=False):
+        """split: wsplit_kernel (round 6: 8 waves, two LDS stages, chunk c + 2 fetched while chunk c multiplies)"""
         xs = [R(N, Cin, h, w) for h, w in shapes]
         dys = [R(N, Cout, h, w) for h, w in shapes]
         def run():
-            r = K.conv3x3_wgrad(xs, dys, Cout)
+            r = K.conv3x3_wgrad(xs, dys, Cout, split=split)
             return torch.cat([t.reshape(-1) for t in (r if isinstance(r, (tuple, list)) else [r])])
         return run
 
@@ -108,10 +109,10 @@ def _run(iters, verbose):
         return lambda: K.conv1x1_forward(x, wt, Cout, bias=b, residual=r, relu=True, out=y)
 
 
-    def pw_wgrad_case(Cin, Cout, H, W):
+    def pw_wgrad_case(Cin, Cout, H, W, split=False):
         x, dy = R(N, Cin, H, W), R(N, Cout, H, W)
         out = torch.empty(Cout, Cin, device="cuda")
-        return lambda: K.conv1x1_wgrad(x, dy, out=out)
+        return lambda: K.conv1x1_wgrad(x, dy, out=out, split=split)
 
 
     def f16_case(Cin, Cout, H, W, mask=False):
@@ -151,6 +152,12 @@ def _run(iters, verbose):
         ("split 720->256 80x112 masked (cls_pred data gradient)", split_case(720, 256, [(80, 112)], mask=True, relu=False, bias=False)),
         ("split gemm 1024->256 40x56 + shortcut", gsplit_case(1024, 256, 40, 56)),
         ("split gemm 2048->512 20x28", gsplit_case(2048, 512, 20, 28, res=False)),
+        ("split gemm 256->1024 40x56 + shortcut (4 channel blocks per pixel tile)", gsplit_case(256, 1024, 40, 56)),
+        ("split filter gradient 256x256 five levels", wgrad_case(256, 256, [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)], split=True)),
+        ("split filter gradient 256x720 five levels (cls_pred)", wgrad_case(256, 720, [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)], split=True)),
+        ("split filter gradient 512x512 20x28", wgrad_case(512, 512, [(20, 28)], split=True)),
+        ("split pointwise filter gradient 1024x256 40x56", pw_wgrad_case(1024, 256, 40, 56, split=True)),
+        ("split pointwise filter gradient 512x2048 20x28", pw_wgrad_case(512, 2048, 20, 28, split=True)),
         ("wino filter gradient 256x256 five levels", wgrad_case(256, 256, [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)])),
         ("wino filter gradient 128x128 80x112", wgrad_case(128, 128, [(80, 112)])),
         ("gemm nn 256->1024 40x56 + shortcut", pw_case(256, 1024, 40, 56)),
