@@ -11,10 +11,11 @@
 //
 // Layout of the work.  The reduction index of one MFMA is 16 consecutive pixels of a row (lanes 0-31 carry pixels 0-7,
 // lanes 32-63 pixels 8-15), so every image is cut into strips 16 pixels wide and a CHUNK is 4 rows of one strip.  A
-// workgroup (4 waves, one per SIMD) owns a 64 x 64 (output x input channel) block of dW for one share of the chunks; a
-// wave owns 32 x 32 of it = 9 accumulator blocks = 144 registers (a 64 x 32 wave block needs 288 accumulators against
-// 256 AGPRs, and hipcc then spills accumulator blocks inside the loop).  Chunk c + 2's dY (64 channels x 4 x 16) and
-// X (64 channels x 6 x 18) are fetched as fp32 into registers while chunk c multiplies, then split and written to the
+// workgroup (8 waves, two per SIMD: one wave's fetch, split and waits run under the other's MFMAs) owns a 128 x 64
+// (output x input channel) block of dW for one share of the chunks; a wave owns 32 x 32 of it = 9 accumulator blocks =
+// 144 registers (a 64 x 32 wave block needs 288 accumulators against 256 AGPRs, and hipcc then spills accumulator
+// blocks inside the loop).  Chunk c + 2's dY (128 channels x 4 x 16) and X (64 channels x 6 x 18) are fetched as fp32
+// into registers while chunk c multiplies, then split and written to the
 // other LDS stage while chunk c + 1 multiplies: no packed copy of the tensors exists in memory.  The X
 // operand of the taps kx = 0 and kx = 2 is the kx = 1 operand shifted by one fp16: four v_alignbit_b32 on the
 // aligned 16-byte LDS read plus one neighbouring word, instead of a misaligned read or shifted copies.

@@ -220,6 +220,43 @@ class DistillHeads(object):
                 k += 1
         return arr
 
+    # -- |max| words of the split-operand engines (as backbone_pipeline._measure / _produces) ------------------------
+    # One table per pipeline, zeroed by one fill at the start of the forward segment.  A launch's words are one
+    # contiguous block in its problem order; the level list of every problem is registered too, so that a filter
+    # gradient (one tower's five levels) finds the words of the launch that produced or first read its tensors.
+    # Every activation / gradient buffer of the subnets is written by exactly one launch per step.
+    AMAX_WORDS = 2048
+
+    def _amax_block(self, lists):
+        n = sum(len(l) for l in lists)
+        base = self._amax_next
+        self._amax_next += n
+        if self._amax_next > self.AMAX_WORDS:
+            raise K.KernelError("|max| table full")
+        self._amax_groups[tuple(t.data_ptr() for l in lists for t in l)] = base
+        k = base
+        for l in lists:
+            self._amax_groups[tuple(t.data_ptr() for t in l)] = k
+            k += len(l)
+        return base
+
+    def _amax_addr(self, base):
+        return self.amax.data_ptr() + 4 * base
+
+    def _amax_known(self, lists):
+        return self._amax_groups.get(tuple(t.data_ptr() for l in lists for t in l))
+
+    def _amax_measure(self, P, arr, lists, channels, field=0):
+        """Words of the tensors a launch reads (its level table's field 0 = x, 1 = aux): found, or measured here on
+        the main stream into a fresh block."""
+        base = self._amax_known(lists)
+        if base is None:
+            base = self._amax_block(lists)
+            n = sum(len(l) for l in lists)
+            P.add(PR.SPLIT_ABSMAX_LEVELS, 73, i=(n, channels, field), p=(arr, self._amax_addr(base)),
+                  work=4.0 * sum(t.numel() for l in lists for t in l), keep=[t for l in lists for t in l], stream=0)
+        return base
+
     def _emit_conv(self, P, problems, Cout, Cin, flags, klass, f24=False, split=False):
         """One launch of independent convolutions of equal (Cout, Cin); f24: on the F(2x4, 3x3) engine; split: on the
         split-operand engine (its workspace is bound by _finish_workspaces)."""
@@ -231,7 +268,11 @@ class DistillHeads(object):
         if split:
             nb = K.lib().ssad_conv3x3_split_workspace_bytes(arr, len(arr), Cin)
             self._split_ws_need = max(self._split_ws_need, nb)
-            idx = P.add(PR.CONV3X3, klass, i=(len(arr), Cout, Cin, flags, 3), l=(nb,), p=(arr, None, None, None, None, None),
+            xa = ya = None
+            if self._amax_on:
+                xa = self._amax_addr(self._amax_measure(P, arr, [list(p[0]) for p in problems], Cin))
+                ya = self._amax_addr(self._amax_block([list(p[1]) for p in problems]))     # folded in by the epilogue
+            idx = P.add(PR.CONV3X3, klass, i=(len(arr), Cout, Cin, flags, 3), l=(nb,), p=(arr, None, None, None, xa, ya),
                         work=2.0 * 9 * Cout * Cin * px,
                         keep=[t for p in problems for t in (list(p[0]) + list(p[1] or []) + list(p[2] or []))
                               ] + [t for p in problems for t in p[3:] if t is not None])
@@ -251,13 +292,17 @@ class DistillHeads(object):
         nb = size_fn(arr, len(arr), Cout, self.D)
         self._wgrad_ws_need = max(getattr(self, "_wgrad_ws_need", 0), nb)
         px = sum(x.shape[0] * x.shape[2] * x.shape[3] for x in xs)
+        xa = da = None
+        if split and self._amax_on:     # (on the main stream, before the fork)
+            xa = self._amax_addr(self._amax_measure(P, arr, [list(xs)], self.D, 0))
+            da = self._amax_addr(self._amax_measure(P, arr, [list(dys)], Cout, 1))
         if self._wstream:
             P.fork(self._wstream)       # behind everything enqueued so far (the producer of dys)
         if split:
             klass = {5: 68, 6: 69}.get(klass, klass)
         idx = P.add(PR.CONV3X3_WGRAD, klass if self._use_wino(Cout) else 19,
                     i=(len(arr), Cout, self.D, 0, 1 if split else 0), l=(nb,),
-                    p=(arr, self.grads[name + "_w"], self.grads[name + "_b"], None),
+                    p=(arr, self.grads[name + "_w"], self.grads[name + "_b"], None, xa, da),
                     work=2.0 * 9 * Cout * self.D * px, keep=list(xs) + list(dys), stream=self._wstream)
         self._wgrad_ops.append(idx)
         return idx, arr
@@ -370,6 +415,10 @@ class DistillHeads(object):
         ov = self._overlap_wgrad
         self._wstream = 1 if (os.environ.get("SSAD_OVERLAP_WGRAD", "1") == "1" if ov is None else ov) else 0
         self._wgrad_ops, self._wgrad_ws_need = [], 0
+        # the table of |max| words serves the fp32 split engines (not the fp16-storage subclass)
+        self._amax_on = bool(self.split_conv) and not self.F16
+        self.amax = torch.zeros(self.AMAX_WORDS, dtype=torch.int32, device=self.device)
+        self._amax_groups, self._amax_next = {}, 0
         self._in_slots = []          # (table, index, which): entries that read the bound inputs
         self._entries_split = {}
         # filters (the teacher's are frozen: packed by a program of their own, run when they change)
@@ -394,6 +443,8 @@ class DistillHeads(object):
         P.mark("pack")
         self._emit_pack(P, s_entries, s_direct, *s_extra)
         P.mark("forward")
+        if self._amax_on:
+            P.add(PR.FILL, 11, p=(self.amax,), f=(0.0,), l=(self.AMAX_WORDS,), work=4.0 * self.AMAX_WORDS)
         self._emit_forward(P)
         P.mark("losses")
         self._emit_losses(P)

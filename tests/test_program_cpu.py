@@ -21,6 +21,13 @@ def _codes(h, lo, hi):
     return [o.code for o in h.prog.ops[h.prog.marks[lo]:h.prog.marks[hi]]]
 
 
+def _fwd_convs(h):
+    """the convolution launches of the forward segment (which also holds the fill of the |max| table and the |max|
+    pass over the bound inputs)"""
+    m = h.prog.marks
+    return [o for o in h.prog.ops[m["forward"]:m["losses"]] if o.code == PR.CONV3X3]
+
+
 def test_program_header_symbols_are_exported():
     text = open(os.path.join(ROOT, "include", "ssad_program.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -45,10 +52,14 @@ def test_distillation_step_program_structure():
     assert [(o.i[0], o.i[1]) for o in h.prog.ops[m["pack"]:m["forward"]]] == [(9, 3), (1, 2), (1, 0)]
     # 4 tower depths (teacher+student x cls+bbox in one launch each), teacher cls_pred (sigmoid),
     # student cls_pred, bbox_pred (student + teacher)
-    assert _codes(h, "forward", "losses") == [PR.CONV3X3] * 7
-    assert [o.i[0] for o in h.prog.ops[m["forward"]:m["losses"]]] == [8, 8, 8, 8, 2, 2, 4]
+    # (in front: one fill of the |max| table, one |max| pass over the 8 bound inputs of the first depth; every later
+    # launch is handed the words its producer's epilogue folded in)
+    assert _codes(h, "forward", "losses") == [PR.FILL, PR.SPLIT_ABSMAX_LEVELS] + [PR.CONV3X3] * 7
+    sp_f = [o for o in _fwd_convs(h) if o.i[4] == 3]
+    assert all(o.p[4] and o.p[5] for o in sp_f) and sp_f[1].p[4] == sp_f[0].p[5]       # depth 1 reads depth 0's words
+    assert [o.i[0] for o in _fwd_convs(h)] == [8, 8, 8, 8, 2, 2, 4]
     # engine (i[4]: 1 = F(2x2), 2 = F(2x4), 3 = split-operand) and timing class per launch
-    assert [(o.i[4], o.klass) for o in h.prog.ops[m["forward"]:m["losses"]]] == \
+    assert [(o.i[4], o.klass) for o in _fwd_convs(h)] == \
         [(3, 28)] * 4 + [(3, 25), (3, 26), (1, 4)]
     assert {(o.i[4], o.klass) for o in h.prog.ops[m["backward"]:m["sgd"]] if o.code == PR.CONV3X3} == \
         {(2, 24), (3, 27), (3, 29)}
@@ -58,13 +69,18 @@ def test_distillation_step_program_structure():
     assert _codes(h, "losses", "backward") == [PR.POW_SUM, PR.CLS_LOSSES_FUSED, PR.SMOOTH_L1]
     bw = _codes(h, "backward", "sgd")
     assert bw.count(PR.CONV3X3_WGRAD) == 10 and bw.count(PR.CONV3X3) == 6
+    # |max| passes of the backward segment: the loss gradient of the logits, bbox_pred's data gradient (its engine
+    # does not fold), and the first tower data-gradient launch re-measuring its two inputs as one block
+    assert bw.count(PR.SPLIT_ABSMAX_LEVELS) == 3
+    wg = [o for o in h.prog.ops if o.code == PR.CONV3X3_WGRAD and o.i[4] == 1]
+    assert len(wg) == 9 and all(o.p[4] and o.p[5] for o in wg)
     assert _codes(h, "sgd", "end") == [PR.SGD_FLAT]
     # the "late" bucket (predictions + upper tower half) is complete at the cut
     late = [o for o in h.prog.ops[m["backward"]:m["backward_late_done"]] if o.code == PR.CONV3X3_WGRAD]
     assert len(late) == 6
     # direct-form flops of SURVEY 8d: 2*9*Cout*Cin per output pixel
     px = sum(hh * ww for hh, ww in SHAPES)
-    first = h.prog.ops[m["forward"]]
+    first = _fwd_convs(h)[0]
     assert first.work == 2.0 * 9 * 256 * 256 * px * 4 and first.klass == 28
     # every wgrad shares the one workspace, sized for the largest
     ws = {o.p[3] for o in h.prog.ops if o.code == PR.CONV3X3_WGRAD}
@@ -80,7 +96,7 @@ def test_f24_switches_select_the_engine_per_launch(monkeypatch):
         monkeypatch.setenv("SSAD_TEACHER_F24", str(teacher))
         h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu")
         m = h.prog.marks
-        fwd = [(o.i[4], o.klass) for o in h.prog.ops[m["forward"]:m["losses"]]]
+        fwd = [(o.i[4], o.klass) for o in _fwd_convs(h)]
         bwd = {(o.i[4], o.klass) for o in h.prog.ops[m["backward"]:m["sgd"]] if o.code == PR.CONV3X3}
         packs = [(o.i[0], o.i[1]) for o in h.prog.ops[m["pack"]:m["forward"]]]
         return fwd, bwd, packs
@@ -104,7 +120,7 @@ def test_f24_switches_select_the_engine_per_launch(monkeypatch):
         monkeypatch.setenv("SSAD_TEACHER_F24", "0")
         h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu")
         m = h.prog.marks
-        fwd = [(o.i[4], o.klass) for o in h.prog.ops[m["forward"]:m["losses"]]]
+        fwd = [(o.i[4], o.klass) for o in _fwd_convs(h)]
         assert fwd == [(1, 2)] * 4 + [(1, 3), (2, 22), (1, 4)]
         for t in ("cls", "bbox"):
             for name in h._layers(t)[:-1]:
@@ -119,13 +135,13 @@ def test_f24_switches_select_the_engine_per_launch(monkeypatch):
         monkeypatch.setenv("SSAD_SPLIT_CONV", str(bits))
         h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu")
         m = h.prog.marks
-        assert [(o.i[4], o.klass) for o in h.prog.ops[m["forward"]:m["losses"]]][4:6] == want_f
+        assert [(o.i[4], o.klass) for o in _fwd_convs(h)][4:6] == want_f
         assert {(o.i[4], o.klass) for o in h.prog.ops[m["backward"]:m["sgd"]] if o.code == PR.CONV3X3} == want_b
         cp = h._layers("cls")[-1]
         assert h.packed[cp][0].numel() == (L.ssad_conv_split_filter_floats if bits & 1 else L.ssad_conv_wino24_filter_floats)(720, 256)
         assert h.packed[cp][1].numel() == (L.ssad_conv_split_filter_floats if bits & 2 else L.ssad_conv_wino24_filter_floats)(256, 720)
         tw = h._layers("cls")[0]
-        assert [(o.i[4], o.klass) for o in h.prog.ops[m["forward"]:m["losses"]]][:4] == [(3, 28) if bits & 4 else (2, 23)] * 4
+        assert [(o.i[4], o.klass) for o in _fwd_convs(h)][:4] == [(3, 28) if bits & 4 else (2, 23)] * 4
         assert h.packed[tw][0].numel() == (L.ssad_conv_split_filter_floats if bits & 4 else L.ssad_conv_wino24_filter_floats)(256, 256)
         assert h.packed[tw][1].numel() == (L.ssad_conv_split_filter_floats if bits & 8 else L.ssad_conv_wino24_filter_floats)(256, 256)
         assert h.t_packed[tw].numel() == h.packed[tw][0].numel()          # the teacher's towers share the launch
@@ -145,14 +161,14 @@ def test_f24_switches_select_the_engine_per_launch(monkeypatch):
     monkeypatch.setenv("SSAD_STUDENT_F24", "7")
     h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu", distill=False)
     m = h.prog.marks
-    assert [(o.i[4], o.klass) for o in h.prog.ops[m["forward"]:m["losses"]]][:4] == [(2, 23)] * 4
+    assert [(o.i[4], o.klass) for o in _fwd_convs(h)][:4] == [(2, 23)] * 4
     assert h.packed[h._layers("cls")[0]][0].numel() == L.ssad_conv_wino24_filter_floats(256, 256)
 
 
 def test_student_only_program_has_no_teacher_and_no_distillation():
     h = DistillHeads(HeadConfig(num_gpus=1), N=1, shapes=SHAPES, device="cpu", distill=False)
     assert h.teacher is None and not hasattr(h, "t_prob")
-    assert [o.i[0] for o in h.prog.ops[h.prog.marks["forward"]:h.prog.marks["losses"]]] == [4, 4, 4, 4, 2, 2]
+    assert [o.i[0] for o in _fwd_convs(h)] == [4, 4, 4, 4, 2, 2]
     assert _codes(h, "losses", "backward") == [PR.FOCAL_FWD, PR.FOCAL_BWD, PR.SMOOTH_L1]
     with pytest.raises(K.KernelError):
         h.step([torch.zeros(1, 256, a, b) for a, b in SHAPES], None, h.labels)   # no supervised inputs
@@ -175,7 +191,10 @@ def test_inputs_are_rebound_not_copied():
     s = [torch.zeros(1, 256, a, b) for a, b in SHAPES]
     t = [torch.zeros(1, 256, a, b) for a, b in SHAPES]
     h._bind(student_fpn=s, teacher_fpn=t)
-    first = ctypes.cast(h.prog.ops[h.prog.marks["forward"]].p[0], ctypes.POINTER(K.ConvLevel))
+    first = ctypes.cast(_fwd_convs(h)[0].p[0], ctypes.POINTER(K.ConvLevel))
+    # (the |max| pass over the bound inputs reads the same table, so it follows the rebinding)
+    am = [o for o in h.prog.ops[h.prog.marks["forward"]:h.prog.marks["losses"]] if o.code == PR.SPLIT_ABSMAX_LEVELS]
+    assert len(am) == 1 and am[0].p[0] == _fwd_convs(h)[0].p[0]
     # launch order of the first depth: teacher cls, student cls, teacher bbox, student bbox
     assert [first[k].x for k in range(8)] == [t[0].data_ptr(), t[1].data_ptr(), s[0].data_ptr(), s[1].data_ptr()] * 2
     with pytest.raises(K.KernelError):

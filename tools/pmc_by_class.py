@@ -46,6 +46,9 @@ def class_sequences(f16=False):
     from ssad_amd import kernels as K
     seq = {}
     for op in h.prog.ops:
+        if op.code == PR.SPLIT_ABSMAX_LEVELS:      # the |max| passes of the pipeline's table: a class of their own
+            seq.setdefault("ssad_split::split_absmax_kernel", []).append((op.klass, True))
+            continue
         n = names.get(op.code)
         if n is None or (op.code == PR.CONV3X3 and not op.i[4]):
             continue
@@ -62,8 +65,9 @@ def class_sequences(f16=False):
                 lv16[q] = src[q]
                 lv16[q].N = 16
             launches = K.lib().ssad_conv3x3_forward_wino_launches_for(lv16, op.i[0], op.i[1], op.i[2], op.i[3])
-            if op.i[4] == 3:      # the split-operand engine: a call = |max| pass + split pass + convolution, all its class
-                seq.setdefault("ssad_split::split_absmax_kernel", []).append((op.klass, False))
+            if op.i[4] == 3:      # the split-operand engine: a call = (|max| pass +) split pass + convolution, all its class
+                if not op.p[4]:   # (handed the words of the pipeline's |max| table: no pass of its own)
+                    seq.setdefault("ssad_split::split_absmax_kernel", []).append((op.klass, False))
                 seq.setdefault("ssad_split::split_pack_act_kernel", []).append((op.klass, False))
                 seq.setdefault("conv3x3_split_kernel", []).append((op.klass, True))
                 continue
@@ -75,7 +79,8 @@ def class_sequences(f16=False):
         if op.code == PR.CONV3X3_WGRAD and op.i[4] == 1:
             # the split-operand filter gradient: |max| pass + main kernel + slab reduction, all its class (the bias
             # gradient's two launches follow every filter gradient and stay out of the counters, as before)
-            seq.setdefault("wsplit_absmax_kernel", []).append((op.klass, False))
+            if not op.p[4]:
+                seq.setdefault("wsplit_absmax_kernel", []).append((op.klass, False))
             seq.setdefault("wsplit_kernel", []).append((op.klass, True))
             seq.setdefault("wsplit_reduce_kernel", []).append((op.klass, False))
             continue
