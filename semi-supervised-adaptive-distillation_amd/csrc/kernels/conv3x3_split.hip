@@ -614,7 +614,13 @@ int ssad_conv3x3_forward_split(const ssad_conv_level* lv, int n_levels, const fl
     pt.N[nl] = lv[l].N;
     pt.plane[nl] = (long long)lv[l].H * lv[l].W;
     pt.block_start[nl] = pblocks;
-    pblocks += (int)((p.slots[l] + kThreads - 1) / kThreads);
+    // a tensor read by several problems of the launch (the cls and bbox towers' first layer share the FPN levels) is
+    // split once: the later problems read the first one's planes (an entry without blocks is skipped by the pass)
+    int same = -1;
+    for (int j = 0; j < nl && same < 0; ++j)
+      if (at.x[j] == lv[l].x && q.N[j] == lv[l].N && q.H[j] == lv[l].H && q.W[j] == lv[l].W) same = j;
+    if (same >= 0) pt.planes[nl] = (uint4*)q.x[same];
+    else pblocks += (int)((p.slots[l] + kThreads - 1) / kThreads);
     q.x[nl] = (const uint4*)pt.planes[nl];
     q.y[nl] = lv[l].y;
     q.aux[nl] = lv[l].aux;
