@@ -689,8 +689,9 @@ def main():
                              exec_div=dom.get("exec_div"),
                              achieved_note=("executed MFMA FLOP/s: algorithmic direct-form flops (2*9*Cout*Cin "
                                             "per output pixel, SURVEY 8d) / exec_div -- 1/3 for the split-operand "
-                                            "engine (three fp16 MFMA products per direct-form product, the launch "
-                                            "includes its |max| and split passes), 3 for Winograd F(2x4,3x3) (24 "
+                                            "engine (three fp16 MFMA products per direct-form product, the call "
+                                            "includes its split pass; the |max| words come from the pipeline's table, "
+                                            "timing class 73), 3 for Winograd F(2x4,3x3) (24 "
                                             "products per 8 outputs), 2.25 for F(2x2,3x3); direct_equiv_tflops is "
                                             "the direct-form rate" if not f16
                                             else "algorithmic direct-form FLOP/s; the kernel executes exactly these"),

@@ -61,16 +61,16 @@ KLASS = {
     22: dict(name="cls_pred conv3x3 fwd, 720-wide, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma", wino=True, exec_div=3.0),
     23: dict(name="subnet tower conv3x3 forward, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma", wino=True, exec_div=3.0),
     # split-operand engine (conv3x3_split.hip): executes 3 x the direct-form flops, on the fp16 pipes (exec_div = 1/3:
-    # executed = direct-form x 3); the launch includes its |max| and split passes
-    25: dict(name="teacher cls_pred conv3x3 fwd + sigmoid, split-operand engine (conv3x3_split_kernel + |max| + split passes)",
+    # executed = direct-form x 3); the call includes its split pass; the |max| words come from the pipeline's table (class 73)
+    25: dict(name="teacher cls_pred conv3x3 fwd + sigmoid, split-operand engine (conv3x3_split_kernel + its split pass; |max| words from the table, class 73)",
              bound="mfma16", wino=True, exec_div=1.0 / 3.0),
-    26: dict(name="cls_pred conv3x3 fwd, split-operand engine (conv3x3_split_kernel + |max| + split passes)", bound="mfma16",
+    26: dict(name="cls_pred conv3x3 fwd, split-operand engine (conv3x3_split_kernel + its split pass; |max| words from the table, class 73)", bound="mfma16",
              wino=True, exec_div=1.0 / 3.0),
-    27: dict(name="cls_pred data gradient, split-operand engine (conv3x3_split_kernel + |max| + split passes)", bound="mfma16",
+    27: dict(name="cls_pred data gradient, split-operand engine (conv3x3_split_kernel + its split pass; |max| words from the table, class 73)", bound="mfma16",
              wino=True, exec_div=1.0 / 3.0),
-    28: dict(name="subnet tower conv3x3 forward, split-operand engine (conv3x3_split_kernel + |max| + split passes)",
+    28: dict(name="subnet tower conv3x3 forward, split-operand engine (conv3x3_split_kernel + its split pass; |max| words from the table, class 73)",
              bound="mfma16", wino=True, exec_div=1.0 / 3.0),
-    29: dict(name="subnet tower data gradient, split-operand engine (conv3x3_split_kernel + |max| + split passes)",
+    29: dict(name="subnet tower data gradient, split-operand engine (conv3x3_split_kernel + its split pass; |max| words from the table, class 73)",
              bound="mfma16", wino=True, exec_div=1.0 / 3.0),
     24: dict(name="subnet conv3x3 data gradient, F(2x4,3x3) (wino24_conv_kernel)", bound="mfma", wino=True, exec_div=3.0),
     # direct (non-Winograd) engine
@@ -105,16 +105,16 @@ KLASS = {
              bound="mfma16", wino=True, exec_div=1.0 / 3.0),
     67: dict(name="teacher backbone conv3x3 fwd, >= 256 wide, split-operand engine (conv3x3_split_kernel + passes)",
              bound="mfma16", wino=True, exec_div=1.0 / 3.0),
-    68: dict(name="subnet conv3x3 filter gradient, tower layers, split-operand engine (wsplit_kernel + |max| + reduce + bias "
+    68: dict(name="subnet conv3x3 filter gradient, tower layers, split-operand engine (wsplit_kernel + reduce + bias "
                   "grad; SSAD_SPLIT_CONV & 32)", bound="mfma16", wino=True, exec_div=1.0 / 3.0),
-    69: dict(name="cls_pred filter gradient, split-operand engine (wsplit_kernel + |max| + reduce + bias grad)",
+    69: dict(name="cls_pred filter gradient, split-operand engine (wsplit_kernel + reduce + bias grad)",
              bound="mfma16", wino=True, exec_div=1.0 / 3.0),
-    70: dict(name="backbone conv3x3 filter gradient, >= 128 wide, split-operand engine (wsplit_kernel + passes; "
+    70: dict(name="backbone conv3x3 filter gradient, >= 256 wide, split-operand engine (wsplit_kernel + reduce + bias grad; "
                   "SSAD_SPLIT_CONV & 64)", bound="mfma16", wino=True, exec_div=1.0 / 3.0),
-    71: dict(name="backbone pointwise conv fwd / data gradient, K and M >= 256, split-operand GEMM (gemm_fly_kernel + |max| "
-                  "+ filter split; SSAD_SPLIT_CONV & 128)", bound="mfma16", wino=True, exec_div=1.0 / 3.0),
+    71: dict(name="backbone pointwise conv fwd / data gradient, K and M >= 256, split-operand GEMM (gemm_fly_kernel; "
+                  "SSAD_SPLIT_CONV & 128)", bound="mfma16", wino=True, exec_div=1.0 / 3.0),
     72: dict(name="backbone pointwise conv filter gradient, C and M >= 256, split-operand engine (wpoint_split_kernel + "
-                  "|max| + reduce; SSAD_SPLIT_CONV & 256)", bound="mfma16", wino=True, exec_div=1.0 / 3.0),
+                  "reduce; SSAD_SPLIT_CONV & 256)", bound="mfma16", wino=True, exec_div=1.0 / 3.0),
     73: dict(name="|max| passes of the split-operand engines (split_absmax_kernel: one per tensor and step, shared by the "
                   "forward, data-gradient and filter-gradient calls that read it)", bound="hbm"),
     74: dict(name="pointwise filter split for the split-operand GEMM (gsplit_*_kernel, all filters in 3 launches)",

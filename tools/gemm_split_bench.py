@@ -1,5 +1,5 @@
 """Isolated timing of the pointwise engines on the backbones' bottleneck shapes (bs 16, 640 x 896): the split-operand
-GEMM (gemm_split.hip: |max| + split passes inside the timed region) against the exact-fp32 MFMA GEMM."""
+GEMM (gemm_split.hip: |max| pass + filter split inside the timed region) against the exact-fp32 MFMA GEMM."""
 import os
 import sys
 
