@@ -372,6 +372,49 @@ def test_kernel_entry_points_refuse_bad_arguments_without_a_device(lib):
     assert raw.ssad_momentum_sgd_flat(p, p, p, p, 0.9, 1e-4, seg, 1, None, None) == -1      # row_scale without row_len
 
 
+def test_split_engine_entry_points_refuse_bad_arguments_without_a_device(lib):
+    """Round 6: the split-operand engines validate before they launch -- the two |max| words of a filter gradient go
+    together, workspaces are checked against the size queries, tensors of 2 GiB and more are sent back to the exact
+    engines, the filter table refuses an entry whose leading dimension is too small."""
+    from ssad_amd import kernels as K
+    raw = ctypes.CDLL(_capi.LIB_PATH)
+    vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    one = ctypes.create_string_buffer(4096)
+    p = ctypes.cast(one, vp)
+    lv = (K.ConvLevel * 1)(K.ConvLevel(p.value, 0, p.value, 2, 10, 14, 0, 0))
+    raw.ssad_conv3x3_wgrad_split_workspace_bytes.restype = sz
+    raw.ssad_conv3x3_wgrad_split_workspace_bytes.argtypes = [ctypes.POINTER(K.ConvLevel), i32, i32, i32]
+    need = raw.ssad_conv3x3_wgrad_split_workspace_bytes(lv, 1, 256, 256)
+    assert need >= 9 * 256 * 256 * 4
+    raw.ssad_conv3x3_wgrad_split_amax.argtypes = [ctypes.POINTER(K.ConvLevel), i32, vp, vp, i32, i32, i32, vp, sz, vp, vp, vp]
+    assert raw.ssad_conv3x3_wgrad_split_amax(lv, 1, p, None, 256, 256, 0, p, need, p, None, None) == -1    # one word only
+    assert raw.ssad_conv3x3_wgrad_split_amax(lv, 1, p, None, 256, 256, 0, p, need - 1, p, p, None) == -2
+    assert raw.ssad_conv3x3_wgrad_split_amax(lv, 0, p, None, 256, 256, 0, p, need, p, p, None) == -1
+    raw.ssad_conv1x1_wgrad_split_workspace_bytes.restype = sz
+    raw.ssad_conv1x1_wgrad_split_workspace_bytes.argtypes = [i32] * 4
+    raw.ssad_conv1x1_wgrad_split_amax.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp, vp, vp]
+    need = raw.ssad_conv1x1_wgrad_split_workspace_bytes(2, 256, 160, 512)
+    assert need >= 256 * 512 * 4
+    assert raw.ssad_conv1x1_wgrad_split_workspace_bytes(2, 256, 12, 512) == 0                    # pixels % 8
+    assert raw.ssad_conv1x1_wgrad_split_workspace_bytes(16, 1024, 160 * 224, 256) == 0           # 2.3 GB: exact engine
+    assert raw.ssad_conv1x1_wgrad_split_amax(p, p, 2, 256, 160, 512, p, 0, p, need, None, p, None) == -1
+    assert raw.ssad_conv1x1_wgrad_split_amax(p, p, 2, 256, 160, 512, p, 0, p, need - 1, p, p, None) == -2
+    raw.ssad_gemm_split_filter_floats.restype = sz
+    raw.ssad_gemm_split_filter_floats.argtypes = [i32, i32]
+    assert raw.ssad_gemm_split_filter_floats(1024, 256) == 16 + 128 * 256 * 8
+    assert raw.ssad_gemm_split_filter_floats(0, 256) == 0
+    raw.ssad_gemm_split_pack_filters.argtypes = [ctypes.POINTER(K.GemmPackEntry), i32, vp]
+    bad = (K.GemmPackEntry * 1)(K.GemmPackEntry(p.value, p.value, 100, 64, 128))               # lda < M
+    assert raw.ssad_gemm_split_pack_filters(bad, 1, None) == -1
+    raw.ssad_split_absmax.argtypes = [vp, ctypes.c_longlong, vp, vp]
+    assert raw.ssad_split_absmax(p, 0, p, None) == -1 and raw.ssad_split_absmax(None, 16, p, None) == -1
+    raw.ssad_split_absmax_levels.argtypes = [ctypes.POINTER(K.ConvLevel), i32, i32, i32, vp, vp]
+    assert raw.ssad_split_absmax_levels(lv, 0, 256, 0, p, None) == -1
+    assert raw.ssad_split_absmax_levels(lv, 1, 256, 0, None, None) == -1
+    nox = (K.ConvLevel * 1)(K.ConvLevel(0, 0, p.value, 2, 10, 14, 0, 0))
+    assert raw.ssad_split_absmax_levels(nox, 1, 256, 0, p, None) == -1                           # field 0 = x: missing
+
+
 def test_winograd_launch_count_query_follows_the_level_shapes():
     """ssad_conv3x3_forward_wino_launches (host-side, no device work): one launch per staging geometry present.
     8 x 16 patches tile 80 x 112 exactly; 8 x 8 sub-patches save 12.5 % of the pixels on 40 x 56."""
