@@ -39,3 +39,5 @@ if os.environ.get("SPLIT_ALL", "1") == "1":
     case("tower data gradient (2 x 5, mask)", 2, 256, 256, lv, masked=True)
     case("cls_pred 256->720 (5 levels)", 1, 256, 720, lv)
     case("res4 256->256 @40x56", 1, 256, 256, [(40, 56)])
+    case("cls_pred data gradient 720->256 (5 levels, mask)", 1, 720, 256, lv, masked=True)
+    case("512->256 (5 levels)", 1, 512, 256, lv)
