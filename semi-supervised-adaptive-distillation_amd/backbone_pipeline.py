@@ -335,8 +335,9 @@ class NativeResNetFPN(object):
 
     def _produces(self, *tensors):
         """Slots for tensors whose PRODUCER (a split-engine kernel's epilogue) folds their |max| in: nobody has to
-        measure them.  Forward pass only: every activation is written exactly once there; in the backward pass gradient
-        buffers are also summed in place by element-wise kernels, which would leave a folded word stale."""
+        measure them.  The forward pass (every activation is written exactly once there) and, in the backward pass, the
+        three gradients inside a bottleneck block (fold=True at their call sites); the other gradient buffers are also
+        summed in place by element-wise kernels, which would leave a folded word stale."""
         base = self._amax_next
         self._amax_next += len(tensors)
         if self._amax_next > self.AMAX_WORDS:
@@ -358,8 +359,11 @@ class NativeResNetFPN(object):
             w.view(torch.float32)[: w.numel() // 4].fill_(value)
         self._packed_frozen = False
 
-    def _gemm(self, P, a, lda, x, y, Kc, M, bias=None, res=None, mask=None, relu=False, acc=False, klass=50, final=True):
-        """final=False: y is modified in place afterwards (the top-down sum of the FPN): its |max| is not folded in."""
+    def _gemm(self, P, a, lda, x, y, Kc, M, bias=None, res=None, mask=None, relu=False, acc=False, klass=50, final=True,
+              fold=False):
+        """final=False: y is modified in place afterwards (the top-down sum of the FPN): its |max| is not folded in.
+        fold=True: a backward-pass output that is written once and read only by split-engine calls (the gradients inside
+        a bottleneck block): folded like a forward activation."""
         d = K.gemm_conv_desc(a, lda, x, y, Kc, M, bias, res, mask, relu, acc)
         px = x.numel() // Kc
         # SSAD_SPLIT_CONV bit 128: the compute-bound pointwise layers (K, M >= 256: res4, res5, the laterals) on the
@@ -373,7 +377,7 @@ class NativeResNetFPN(object):
             if nb:
                 self._split_need = max(self._split_need, nb)
                 xa = self._amax_addr(self._measure(P, [x], Kc))
-                ya = self._amax_addr(self._produces(y)) if self._fwd and final and not acc else None
+                ya = self._amax_addr(self._produces(y)) if (self._fwd or fold) and final and not acc else None
                 idx = P.add(PR.GEMM_CONV_SPLIT, 71, p=(d, None, self._packed_a(a, lda, Kc, M), xa, ya), l=(nb,),
                             work=2.0 * px * Kc * M, keep=[t for t in (a, x, y, bias, res, mask) if t is not None])
                 self._gemm_split_ops.append(idx)
@@ -392,7 +396,7 @@ class NativeResNetFPN(object):
             (self._gpack_train if train else self._gpack_frozen).append((a, lda, Kc, M, dst))
         return self._gemm_packs[key]
 
-    def _conv3(self, P, probs, Cout, Cin, flags, klass=48, f24=False):
+    def _conv3(self, P, probs, Cout, Cin, flags, klass=48, f24=False, fold=False):
         """probs: [(x, y, mask or None, packed, bias or None)]: independent 3x3 convolutions of one
         (Cout, Cin) in one launch; f24: truthy = on the F(2x4, 3x3) engine (packs from ssad_conv_wino24_pack_filters),
         3 = on the split-operand engine (conv3x3_split.hip; its workspace is bound when the program is finished)."""
@@ -406,7 +410,7 @@ class NativeResNetFPN(object):
             self._split_need = max(getattr(self, "_split_need", 0), nb)
             px = sum(p[0].shape[0] * p[0].shape[2] * p[0].shape[3] for p in probs)
             xa = self._amax_addr(self._measure(P, [p[0] for p in probs], Cin))
-            ya = self._amax_addr(self._produces(*[p[1] for p in probs])) if self._fwd else None
+            ya = self._amax_addr(self._produces(*[p[1] for p in probs])) if (self._fwd or fold) else None
             idx = P.add(PR.CONV3X3, 66 if self.train else 67, i=(len(probs), Cout, Cin, flags, 3), l=(nb,),
                         p=(arr, None, None, None, xa, ya), work=2.0 * 9 * Cout * Cin * px,
                         keep=[t for p in probs for t in p if t is not None])
@@ -873,10 +877,10 @@ class NativeResNetFPN(object):
                 self._ew(P, PR.RELU_GRAD, p=(y, dy, dz), l=(y.numel(),), nbytes=12.0 * y.numel())
             self._wgrad1(P, y2, dz, l3)
             dz2 = self._like(y2)
-            self._gemm(P, l3.w.view(cout, cmid), cmid, dz, dz2, cout, cmid, mask=y2)
+            self._gemm(P, l3.w.view(cout, cmid), cmid, dz, dz2, cout, cmid, mask=y2, fold=True)
             self._wgrad3(P, y1, dz2, l2)                                   # + bias gradient of c2
             dz1 = self._like(y1)
-            self._conv3(P, [(dz2, dz1, y1, l2.pd, None)], cmid, cmid, K.CONV_MASK_AUX, f24=l2.f24)
+            self._conv3(P, [(dz2, dz1, y1, l2.pd, None)], cmid, cmid, K.CONV_MASK_AUX, f24=l2.f24, fold=True)
             self._wgrad1(P, xs, dz1, l1)
             first_trainable = (stage == 3 and j == 0)
             if proj:
@@ -897,7 +901,7 @@ class NativeResNetFPN(object):
                 # buffer: the auxiliary stream may still be reading dz)
                 # x is the previous block's output y: its ReluGradient mask goes into this epilogue
                 dx = self._like(dz)
-                self._gemm(P, l1.w.view(cmid, cin), cin, dz1, dx, cmid, cin, res=dz, mask=x)
+                self._gemm(P, l1.w.view(cmid, cin), cin, dz1, dx, cmid, cin, res=dz, mask=x, fold=True)
                 dy = dx
                 dy_is_dz = True
             if j == 0:
