@@ -433,6 +433,8 @@ class NativeResNetFPN(object):
         # SSAD_SPLIT_CONV bit 64 (default): the >= 256-wide 3x3 filter gradients on the split-operand engine (the
         # 128-wide res3 layers are level with the F(3x3, 2x2) engine there: 2 blocks of dW, 128 slabs to reduce)
         split = (int(os.environ.get("SSAD_SPLIT_CONV", "511")) & 64) != 0 and layer.cout >= 256 and layer.cin >= 256
+        if split and not K.lib().ssad_conv3x3_wgrad_split_workspace_bytes(arr, 1, layer.cout, layer.cin):
+            split = False           # (a tensor of 2 GiB or more: the exact engine)
         size_fn = K.lib().ssad_conv3x3_wgrad_split_workspace_bytes if split else K.lib().ssad_conv3x3_wgrad_workspace_bytes
         nb = size_fn(arr, 1, layer.cout, layer.cin)
         self._ws_need = max(self._ws_need, nb)
@@ -454,6 +456,8 @@ class NativeResNetFPN(object):
         # the forward GEMM) on the split-operand engine (gemm_split.hip, wpoint_split_kernel)
         split = ((int(os.environ.get("SSAD_SPLIT_CONV", "511")) & 256) != 0 and Cc >= 256 and layer.cout >= 256
                  and N * pix >= GEMM_SPLIT_MIN_PIXELS and pix % 8 == 0)
+        if split and not K.lib().ssad_conv1x1_wgrad_split_workspace_bytes(N, Cc, pix, layer.cout):
+            split = False           # (a tensor of 2 GiB or more: the exact engine)
         size_fn = K.lib().ssad_conv1x1_wgrad_split_workspace_bytes if split else K.lib().ssad_conv1x1_wgrad_workspace_bytes
         nb = size_fn(N, Cc, pix, layer.cout)
         self._ws_need = max(self._ws_need, nb)

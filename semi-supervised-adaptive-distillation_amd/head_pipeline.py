@@ -288,6 +288,8 @@ class DistillHeads(object):
         arr = self._conv_table([(xs, None, dys, None, None)])
         # SSAD_SPLIT_CONV bit 32 (default): the >= 128-wide filter gradients on the split-operand engine
         split = bool(self.split_conv & 32) and Cout >= 128 and self.D >= 64
+        if split and not K.lib().ssad_conv3x3_wgrad_split_workspace_bytes(arr, len(arr), Cout, self.D):
+            split = False           # (a level of 2 GiB or more: the exact engine)
         size_fn = K.lib().ssad_conv3x3_wgrad_split_workspace_bytes if split else K.lib().ssad_conv3x3_wgrad_workspace_bytes
         nb = size_fn(arr, len(arr), Cout, self.D)
         self._wgrad_ws_need = max(getattr(self, "_wgrad_ws_need", 0), nb)
